@@ -1,0 +1,393 @@
+"""ORACLE — test infrastructure only.  CPU (PyTorch fp32 / numpy / pure Python) restatement of the
+reference's Mr. BLIP train-step hot path, written from the reference's *behaviour*; every function cites
+the reference file:line (relative to /root/reference) it follows.
+
+Who may import this: ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg —
+as the CHECKER, never as the thing measured or shipped.  The product (``mr-blip_amd/``) never imports it.
+
+Pinning: ``tests/test_oracle_golden.py`` checks this file against golden vectors captured by importing the
+reference itself in the build container (``tests/golden/make_golden.py``): ViT, ln_vision+Q-Former, T5
+(loss / logits / encoder output / input grads), the full ``forward_mr`` (interleaved encoder input, mask,
+loss, grads of t5_proj and ln_vision), relative-position buckets, timestamp integers, ``post_process``,
+``moment_str_to_list`` and the LR schedule.
+Parity UNPINNED (third-party code absent from the reference tree): peft==0.13.0 LoRA
+(restated here from its published algorithm: y = W x + (alpha/r) * B A dropout(x); A kaiming-uniform,
+B zeros), the real flan-t5 SentencePiece vocabulary, and HF ``generate`` beam search.
+
+``emu_bf16=True`` rounds every matmul operand (and the attention probabilities) to bfloat16 at the same
+points where the HIP path stores/feeds bf16, keeping fp32 accumulation — this separates logic errors from
+rounding when the HIP path is compared with this oracle.
+"""
+from __future__ import annotations
+
+import ast
+import math
+import re
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+
+
+# ====================================================================================== integer / string logic
+def relative_position_bucket(rel: np.ndarray, bidirectional: bool, num_buckets: int = 32, max_distance: int = 128):
+    """modeling_t5.py:392-445.  rel = memory_position - query_position (int array).  Integer-exact restatement
+    of the float-log formula (float32 log, truncation toward zero)."""
+    rel = np.asarray(rel, dtype=np.int64)
+    ret = np.zeros_like(rel)
+    nb = num_buckets
+    if bidirectional:
+        nb //= 2
+        ret = ret + (rel > 0).astype(np.int64) * nb
+        n = np.abs(rel)
+    else:
+        n = -np.minimum(rel, 0)
+    max_exact = nb // 2
+    is_small = n < max_exact
+    with np.errstate(divide="ignore"):
+        big = max_exact + (
+            np.log(n.astype(np.float32) / np.float32(max_exact)) / np.float32(math.log(max_distance / max_exact))
+            * np.float32(nb - max_exact)
+        ).astype(np.float32)
+    big = np.where(is_small, 0, big).astype(np.int64)
+    big = np.minimum(big, nb - 1)
+    return ret + np.where(is_small, n, big)
+
+
+def shift_right(labels: Tensor, decoder_start_token_id: int = 0, pad_token_id: int = 0) -> Tensor:
+    """modeling_t5.py:919-948."""
+    out = torch.zeros_like(labels)
+    out[..., 1:] = labels[..., :-1]
+    out[..., 0] = decoder_start_token_id
+    return out.masked_fill(out == -100, pad_token_id)
+
+
+def find_annoying_numbers(tokenizer, range_end: int = 200) -> Tuple[List[int], List[int]]:
+    """blip2_mr.py:1497-1535."""
+    annoying, annoying_space = [], []
+    for i in range(range_end):
+        ids = tokenizer(str(i), padding="longest", add_special_tokens=False, truncation=True, max_length=300,
+                        return_tensors="pt")["input_ids"].tolist()[0]
+        if len(ids) > 1:
+            (annoying_space if ids[0] == 3 else annoying).append(i)
+    return annoying, annoying_space
+
+
+def annoying_replacement_dict(annoying: Sequence[int]) -> Dict[int, int]:
+    """blip2_mr.py:1537-1559: nearest non-annoying integer, i+j tried before i-j."""
+    out = {}
+    for i in annoying:
+        for j in range(100):
+            if (i + j) not in annoying:
+                new = i + j
+                break
+            if (i - j) not in annoying:
+                new = i - j
+                break
+        out[i] = new
+    return out
+
+
+def timestamps_as_seconds_integers(timestamps: Tensor, durations: Tensor, repl: Dict[int, int]):
+    """utils.py:388-434.  Python round() = round-half-even on the float64 value of the fp32 timestamp."""
+    new_ts, new_d, prompts = [], [], []
+    for t, d in zip(timestamps, durations):
+        ints = []
+        for x in t:
+            r = round(x.item())
+            ints.append(int(repl.get(r, r)))
+        dr = round(d.item())
+        dr = repl.get(dr, dr)
+        prompts.append(">" + ">".join(str(i) for i in ints) + ">" + str(dr))
+        new_ts.append(torch.tensor(ints))
+        new_d.append(dr)
+    return new_ts, new_d, prompts
+
+
+def clean_timestamp_tokens(tokenizer, values) -> List[List[int]]:
+    """blip2_mr.py:1576-1581: tokenise str(v) without specials, strip a leading id 3."""
+    toks = tokenizer([str(v.item() if torch.is_tensor(v) else v) for v in values], add_special_tokens=False)["input_ids"]
+    return [t[1:] if t[0] == 3 else t for t in toks]
+
+
+def post_process(pred: str) -> str:
+    """utils.py:18-83."""
+    pred = pred.split("</s>")[0]
+    if not re.match(r"\[\[.*\]\]", pred):
+        return "[[-1, -1]]"
+    pred = pred[1:-1]
+    out = []
+    for w in re.split(r"\s+(?=\[)", pred):
+        w = re.sub(r",+$", "", w)
+        w = re.sub(r"(\d) (\d)", r"\1, \2", w)
+        w = re.sub(r",+", ",", w)
+        nums = re.findall(r"\d+", w)
+        if len(nums) == 2 and int(nums[0]) > int(nums[1]):
+            w = "[" + nums[1] + ", " + nums[0] + "]"
+        out.append(w)
+    return "[" + ", ".join(out) + "]"
+
+
+def moment_str_to_list(m: str):
+    """utils.py:300-341."""
+    if m == "[[-1, -1]]" or not re.match(r"\[\[.*\]\]", m):
+        return [[-1, -1]]
+    try:
+        v = ast.literal_eval(m)
+    except Exception:
+        return [[-1, -1]]
+    if not isinstance(v, list):
+        return [[-1, -1]]
+    for i in range(len(v)):
+        if len(v[i]) != 2:
+            v[i] = [-1, -1]
+    return v
+
+
+def lr_at(cur_epoch: int, cur_step: int, state: dict, *, max_epoch, min_lr, init_lr, warmup_steps, warmup_start_lr):
+    """optims.py:79-119 (LinearWarmupCosineLRScheduler.step); ``state`` carries max_iters_per_epoch."""
+    if cur_step > state.get("max_iters_per_epoch", 0):
+        state["max_iters_per_epoch"] = cur_step
+    g = cur_epoch * state.get("max_iters_per_epoch", 0) + cur_step
+    if g < warmup_steps:
+        return min(init_lr, warmup_start_lr + (init_lr - warmup_start_lr) * g / max(warmup_steps, 1))
+    return (init_lr - min_lr) * 0.5 * (1.0 + math.cos(math.pi * cur_epoch / max_epoch)) + min_lr
+
+
+# ====================================================================================== floating-point path
+class Oracle:
+    """Functional forward over a flat state dict with the reference's parameter names."""
+
+    def __init__(self, sd: Dict[str, Tensor], cfg: dict, emu_bf16: bool = False, lora: Optional[dict] = None):
+        self.sd = sd
+        self.cfg = cfg
+        self.emu = emu_bf16
+        self.lora = lora  # dict(r=8, alpha=8) or None
+
+    # ---- helpers
+    def rb(self, x: Tensor) -> Tensor:
+        return x.bfloat16().float() if self.emu else x
+
+    def lin(self, x: Tensor, w: Tensor, b: Optional[Tensor] = None) -> Tensor:
+        y = self.rb(x) @ self.rb(w).t()
+        return y if b is None else y + b
+
+    def P(self, key: str) -> Tensor:
+        return self.sd[key]
+
+    # ---- ViT  (eva_vit.py:118-148, 173-180, 198-204, 324-340)
+    def vit(self, image: Tensor, n_blocks: Optional[int] = None) -> Tensor:
+        c = self.cfg["vit"]
+        D, H = c["embed_dim"], c["num_heads"]
+        hd = D // H
+        p = "visual_encoder."
+        w = self.P(p + "patch_embed.proj.weight")
+        B = image.shape[0]
+        # Conv2d k=s=14 == patchify + GEMM (eva_vit.py:196-203)
+        ps = w.shape[-1]
+        g = image.shape[-1] // ps
+        patches = image.reshape(B, 3, g, ps, g, ps).permute(0, 2, 4, 1, 3, 5).reshape(B, g * g, 3 * ps * ps)
+        x = self.lin(patches, w.reshape(D, -1), self.P(p + "patch_embed.proj.bias"))
+        x = torch.cat([self.P(p + "cls_token").expand(B, -1, -1), x], 1) + self.P(p + "pos_embed")
+        scale = hd ** -0.5
+        depth = c["depth"] if n_blocks is None else n_blocks
+        for i in range(depth):
+            q = p + f"blocks.{i}."
+            h = F.layer_norm(x, (D,), self.P(q + "norm1.weight"), self.P(q + "norm1.bias"), 1e-6)
+            bias = torch.cat([self.P(q + "attn.q_bias"), torch.zeros(D), self.P(q + "attn.v_bias")])
+            qkv = self.lin(h, self.P(q + "attn.qkv.weight"), bias)
+            N = x.shape[1]
+            qkv = qkv.reshape(B, N, 3, H, hd).permute(2, 0, 3, 1, 4)
+            o = self.attention(qkv[0], qkv[1], qkv[2], scale=scale)
+            o = o.transpose(1, 2).reshape(B, N, D)
+            x = x + self.lin(o, self.P(q + "attn.proj.weight"), self.P(q + "attn.proj.bias"))
+            h = F.layer_norm(x, (D,), self.P(q + "norm2.weight"), self.P(q + "norm2.bias"), 1e-6)
+            h = F.gelu(self.lin(h, self.P(q + "mlp.fc1.weight"), self.P(q + "mlp.fc1.bias")))
+            x = x + self.lin(h, self.P(q + "mlp.fc2.weight"), self.P(q + "mlp.fc2.bias"))
+        return x
+
+    def attention(self, q, k, v, scale=1.0, bias=None, p_drop_mask=None):
+        """softmax(q k^T * scale + bias) v with fp32 softmax (eva_vit.py:128-145, Qformer.py:195-262,
+        modeling_t5.py:561-599).  emu: q, k, v and the probabilities are bf16-rounded."""
+        s = (self.rb(q) @ self.rb(k).transpose(-1, -2)) * scale
+        if bias is not None:
+            s = s + bias
+        pr = torch.softmax(s.float(), -1)
+        if p_drop_mask is not None:
+            pr = pr * p_drop_mask
+        return self.rb(pr) @ self.rb(v)
+
+    def ln_vision(self, x: Tensor) -> Tensor:
+        """blip2.py:113-119 (fp32 LayerNorm, eps 1e-5)."""
+        return F.layer_norm(x.float(), (x.shape[-1],), self.P("ln_vision.weight"), self.P("ln_vision.bias"), 1e-5)
+
+    # ---- Q-Former, query branch only (Qformer.py:51-108, 111-289, 378-484, 487-589)
+    def qformer(self, image_embeds: Tensor) -> Tensor:
+        c = self.cfg["qf"]
+        D, H = c["hidden_size"], c["num_attention_heads"]
+        hd = D // H
+        eps = 1e-12
+        p = "Qformer.bert."
+        Bq = image_embeds.shape[0]
+        x = self.P("query_tokens").expand(Bq, -1, -1)
+        x = F.layer_norm(x, (D,), self.P(p + "embeddings.LayerNorm.weight"), self.P(p + "embeddings.LayerNorm.bias"), eps)
+
+        def heads(t):
+            return t.reshape(t.shape[0], t.shape[1], H, hd).transpose(1, 2)
+
+        def attn_block(pref, x, kv_src):
+            q = heads(self.lin(x, self.P(pref + "self.query.weight"), self.P(pref + "self.query.bias")))
+            k = heads(self.lin(kv_src, self.P(pref + "self.key.weight"), self.P(pref + "self.key.bias")))
+            v = heads(self.lin(kv_src, self.P(pref + "self.value.weight"), self.P(pref + "self.value.bias")))
+            o = self.attention(q, k, v, scale=1.0 / math.sqrt(hd))
+            o = o.transpose(1, 2).reshape(x.shape[0], x.shape[1], D)
+            o = self.lin(o, self.P(pref + "output.dense.weight"), self.P(pref + "output.dense.bias"))
+            return F.layer_norm(o + x, (D,), self.P(pref + "output.LayerNorm.weight"), self.P(pref + "output.LayerNorm.bias"), eps)
+
+        for i in range(c["num_hidden_layers"]):
+            l = p + f"encoder.layer.{i}."
+            x = attn_block(l + "attention.", x, x)
+            if i % c.get("cross_attention_freq", 2) == 0:
+                x = attn_block(l + "crossattention.", x, image_embeds)
+            h = F.gelu(self.lin(x, self.P(l + "intermediate_query.dense.weight"), self.P(l + "intermediate_query.dense.bias")))
+            h = self.lin(h, self.P(l + "output_query.dense.weight"), self.P(l + "output_query.dense.bias"))
+            x = F.layer_norm(h + x, (D,), self.P(l + "output_query.LayerNorm.weight"), self.P(l + "output_query.LayerNorm.bias"), eps)
+        return x
+
+    # ---- T5 with optional LoRA (modeling_t5.py:254-277, 314-329, 350-620, 697-826, 1021-1282, 1734-1893)
+    def _t5w(self, name: str) -> Tuple[Tensor, Optional[Tensor], Optional[Tensor]]:
+        """weights of T5 Linear `name` (e.g. 'encoder.block.0.layer.0.SelfAttention.q'): plain or peft naming."""
+        k = "t5_model." + name + ".weight"
+        if k in self.sd:
+            return self.sd[k], None, None
+        b = "t5_model.base_model.model." + name
+        return self.sd[b + ".base_layer.weight"], self.sd.get(b + ".lora_A.default.weight"), self.sd.get(b + ".lora_B.default.weight")
+
+    def _t5p(self, name: str) -> Tensor:
+        k = "t5_model." + name
+        return self.sd[k] if k in self.sd else self.sd["t5_model.base_model.model." + name]
+
+    def t5lin(self, x: Tensor, name: str) -> Tensor:
+        w, a, b = self._t5w(name)
+        y = self.lin(x, w)
+        if a is not None:
+            scale = self.lora["alpha"] / self.lora["r"] if self.lora else 1.0
+            y = y + self.lin(self.lin(x, a), b) * scale  # peft 0.13.0 Linear.forward (eval: dropout = identity)
+        return y
+
+    def rmsnorm(self, x: Tensor, w: Tensor, eps: float) -> Tensor:
+        var = x.float().pow(2).mean(-1, keepdim=True)
+        return w * (x * torch.rsqrt(var + eps))
+
+    def t5_bias(self, table: Tensor, qlen: int, klen: int, bidirectional: bool) -> Tensor:
+        c = self.cfg["t5"]
+        rel = np.arange(klen)[None, :] - np.arange(qlen)[:, None]
+        b = relative_position_bucket(rel, bidirectional, c.get("num_buckets", 32), c.get("max_distance", 128))
+        return table[torch.from_numpy(b)].permute(2, 0, 1).unsqueeze(0)  # [1,H,q,k]
+
+    def _t5_attn(self, pref: str, xq: Tensor, xkv: Tensor, bias: Tensor) -> Tensor:
+        c = self.cfg["t5"]
+        H, dk = c["num_heads"], c["d_kv"]
+
+        def heads(t):
+            return t.reshape(t.shape[0], t.shape[1], H, dk).transpose(1, 2)
+
+        q, k, v = heads(self.t5lin(xq, pref + ".q")), heads(self.t5lin(xkv, pref + ".k")), heads(self.t5lin(xkv, pref + ".v"))
+        o = self.attention(q, k, v, scale=1.0, bias=bias)  # no 1/sqrt(d) (modeling_t5.py:561-563)
+        o = o.transpose(1, 2).reshape(xq.shape[0], xq.shape[1], H * dk)
+        return self.t5lin(o, pref + ".o")
+
+    def _t5_ff(self, pref: str, x: Tensor) -> Tensor:
+        h = F.gelu(self.t5lin(x, pref + ".wi_0")) * self.t5lin(x, pref + ".wi_1")
+        return self.t5lin(h, pref + ".wo")
+
+    def t5_encoder(self, inputs_embeds: Tensor, attention_mask: Tensor) -> Tensor:
+        c = self.cfg["t5"]
+        eps = c.get("eps", 1e-6)
+        x = inputs_embeds
+        S = x.shape[1]
+        neg = torch.finfo(torch.float32).min
+        mask = (1.0 - attention_mask[:, None, None, :].float()) * neg
+        bias = self.t5_bias(self._t5p("encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight"), S, S, True) + mask
+        for i in range(c["num_layers"]):
+            b = f"encoder.block.{i}."
+            x = x + self._t5_attn(b + "layer.0.SelfAttention", *(2 * [self.rmsnorm(x, self._t5p(b + "layer.0.layer_norm.weight"), eps)]), bias)
+            x = x + self._t5_ff(b + "layer.1.DenseReluDense", self.rmsnorm(x, self._t5p(b + "layer.1.layer_norm.weight"), eps))
+        return self.rmsnorm(x, self._t5p("encoder.final_layer_norm.weight"), eps)
+
+    def t5_decoder(self, dec_ids: Tensor, dec_mask: Tensor, enc: Tensor, enc_mask: Tensor) -> Tensor:
+        c = self.cfg["t5"]
+        eps = c.get("eps", 1e-6)
+        x = self._t5p("shared.weight")[dec_ids]
+        L = x.shape[1]
+        neg = torch.finfo(torch.float32).min
+        causal = torch.tril(torch.ones(L, L))[None, None]
+        ext = causal * dec_mask[:, None, None, :].float()
+        self_bias = self.t5_bias(self._t5p("decoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight"), L, L, False) + (1.0 - ext) * neg
+        cross_bias = (1.0 - enc_mask[:, None, None, :].float()) * neg
+        for i in range(c["num_decoder_layers"]):
+            b = f"decoder.block.{i}."
+            h = self.rmsnorm(x, self._t5p(b + "layer.0.layer_norm.weight"), eps)
+            x = x + self._t5_attn(b + "layer.0.SelfAttention", h, h, self_bias)
+            h = self.rmsnorm(x, self._t5p(b + "layer.1.layer_norm.weight"), eps)
+            x = x + self._t5_attn(b + "layer.1.EncDecAttention", h, enc, cross_bias)
+            x = x + self._t5_ff(b + "layer.2.DenseReluDense", self.rmsnorm(x, self._t5p(b + "layer.2.layer_norm.weight"), eps))
+        return self.rmsnorm(x, self._t5p("decoder.final_layer_norm.weight"), eps)
+
+    def t5_loss(self, inputs_embeds: Tensor, attention_mask: Tensor, labels: Tensor, dec_mask: Tensor):
+        """T5ForConditionalGeneration.forward (modeling_t5.py:1796-1877): untied lm_head, CE ignore_index=-100 mean."""
+        enc = self.t5_encoder(inputs_embeds, attention_mask)
+        dec = self.t5_decoder(shift_right(labels), dec_mask, enc, attention_mask)
+        logits = self.t5lin(dec, "lm_head")
+        loss = F.cross_entropy(logits.reshape(-1, logits.shape[-1]).float(), labels.reshape(-1), ignore_index=-100)
+        return loss, logits, enc
+
+    # ---- prompt construction (blip2_mr.py:572-783, interleave branch) -----------------------------------
+    def prompt_concatenation(self, tok, timestamps, durations, frames_for_t5, video_prompt_end, query_prompt,
+                             task_prompt, repl: Dict[int, int], n_per_frame: int):
+        emb = self._t5p("shared.weight")
+        ts_int, dur_int, _ = timestamps_as_seconds_integers(timestamps, durations, repl)
+        end_tok = tok(video_prompt_end, padding="longest", add_special_tokens=False, truncation=True, max_length=200, return_tensors="pt")
+        text_tok = tok([q + t for q, t in zip(query_prompt, task_prompt)], padding="longest", truncation=True, max_length=200, return_tensors="pt")
+        dur_tokens = clean_timestamp_tokens(tok, dur_int)
+        sep = tok.convert_tokens_to_ids(">")
+        rows = []
+        for j in range(frames_for_t5.shape[0]):
+            tt = clean_timestamp_tokens(tok, ts_int[j])
+            parts = []
+            for i, tks in enumerate(tt):
+                parts.append(frames_for_t5[j, i * n_per_frame:(i + 1) * n_per_frame])
+                parts.append(emb[torch.tensor(tks)])
+            parts.append(emb[torch.tensor([sep])])
+            parts.append(emb[torch.tensor(dur_tokens[j])])
+            rows.append(torch.cat(parts))
+        mx = max(r.shape[0] for r in rows)
+        rows = [torch.cat([torch.zeros(mx - r.shape[0], r.shape[1]), r]) for r in rows]  # left zero-pad, mask stays 1
+        video = torch.stack(rows)
+        embs = torch.cat([video, emb[end_tok.input_ids], emb[text_tok.input_ids]], 1)
+        atts = torch.cat([torch.ones(video.shape[:2], dtype=torch.long), end_tok.attention_mask, text_tok.attention_mask], 1)
+        return embs, atts
+
+    # ---- whole train-step forward (blip2_mr.py:433-570) -------------------------------------------------
+    def forward_mr(self, tok, samples: dict, repl: Dict[int, int], mean_pool: bool = False):
+        video = samples["video"]
+        b, t = video.shape[:2]
+        with torch.no_grad():
+            vit_out = self.vit(video.reshape(b * t, *video.shape[2:]))
+        img = self.ln_vision(vit_out)
+        q = self.qformer(img)
+        f = self.lin(q, self.P("t5_proj.weight"), self.P("t5_proj.bias"))
+        if mean_pool:
+            f = f.mean(dim=1, keepdim=True)
+        n = f.shape[1]
+        f = f.reshape(b, t * n, -1)
+        embs, atts = self.prompt_concatenation(tok, samples["timestamps"], samples["duration"], f,
+                                               samples["video_prompt_end"], samples["query_prompt"],
+                                               samples["task_prompt"], repl, n)
+        ans = tok(samples["relevant_windows"], padding="longest", truncation=True, max_length=200, return_tensors="pt")
+        labels = ans.input_ids.masked_fill(ans.input_ids == tok.pad_token_id, -100)
+        loss, logits, enc = self.t5_loss(embs, atts, labels, ans.attention_mask)
+        return dict(loss=loss, logits=logits, inputs_embs=embs, inputs_atts=atts, labels=labels, enc=enc, frames=f)

@@ -42,9 +42,10 @@ def manifest_of(module):
     return out
 
 
-def load_seeded(module):
-    man = manifest_of(module)
-    sd = seeded_state_dict(man)
+def load_seeded(module, prefix=""):
+    """weights are keyed by the FULL reference parameter name (prefix + local name)."""
+    man = [(prefix + k, s) for k, s in manifest_of(module)]
+    sd = {k[len(prefix):]: v for k, v in seeded_state_dict(man).items()}
     missing = module.load_state_dict(sd, strict=False)
     assert not missing.unexpected_keys
     return man
@@ -70,7 +71,7 @@ def main():
 
     # ---------------------------------------------------------------- ViT (eva_vit.py:324-340)
     vit = blip2.create_eva_vit_g(img_size=IMG, drop_path_rate=0.0, precision="fp32").eval()
-    man = load_seeded(vit)
+    man = load_seeded(vit, "visual_encoder.")
     img = torch.randn(3, 3, IMG, IMG, generator=g)
     with torch.no_grad():
         y = vit(img)
@@ -79,7 +80,7 @@ def main():
 
     # ---------------------------------------------------------------- ln_vision + Q-Former (Qformer.py:804-965)
     ln = blip2.LayerNorm(TINY["vit"]["embed_dim"])
-    man_ln = load_seeded(ln)
+    man_ln = load_seeded(ln, "ln_vision.")
     Q, qt = blip2.Blip2Base.init_Qformer(NQ, TINY["vit"]["embed_dim"])
     Q.cls = None
     Q.bert.embeddings.word_embeddings = None
@@ -88,21 +89,20 @@ def main():
         layer.output = None
         layer.intermediate = None
     Q.eval()
-    man_q = load_seeded(Q)
+    man_q = load_seeded(Q, "Qformer.")
     qt_val = seeded_state_dict([("query_tokens", list(qt.shape))])["query_tokens"]
     with torch.no_grad():
         emb = ln(y)
         atts = torch.ones(emb.shape[:-1], dtype=torch.long)
         o = Q.bert(query_embeds=qt_val.expand(3, -1, -1), encoder_hidden_states=emb,
                    encoder_attention_mask=atts, return_dict=True).last_hidden_state
-    save("qformer_tiny", [("ln_vision." + k, s) for k, s in man_ln] + [("Qformer." + k, s) for k, s in man_q]
-         + [("query_tokens", list(qt.shape))], vit_out=y, ln_out=emb, out=o)
+    save("qformer_tiny", man_ln + man_q + [("query_tokens", list(qt.shape))], vit_out=y, ln_out=emb, out=o)
 
     # ---------------------------------------------------------------- T5 (modeling_t5.py:1734-1893)
     cfg = R["t5_config"]()
     cfg.dense_act_fn = "gelu"
     t5 = t5m.T5ForConditionalGeneration(cfg).eval()
-    man_t5 = load_seeded(t5)
+    man_t5 = load_seeded(t5, "t5_model.")
     B, S, Ld = 2, 150, 7
     x = torch.randn(B, S, cfg.d_model, generator=g) * 0.5
     am = torch.ones(B, S, dtype=torch.long)

@@ -157,6 +157,7 @@ def install(tokenizer_factory, tiny):
         c = t5m.T5Config(**tiny["t5"])
         c.decoder_start_token_id = 0
         c.pad_token_id = 0
+        c.tie_word_embeddings = False  # flan-t5 (transformers 5 ignores the constructor kwarg)
         return c
 
     t5m.T5Config.from_pretrained = classmethod(lambda cls, *a, **k: t5_config())

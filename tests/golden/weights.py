@@ -1,5 +1,6 @@
 """Deterministic, name-keyed synthetic weights shared by the golden generator and the tests, so the
 fixtures only have to carry inputs/outputs and the (key, shape) manifest — not the weights."""
+import re
 import zlib
 
 import numpy as np
@@ -7,6 +8,8 @@ import torch
 
 
 def seeded_array(key: str, shape, std=None) -> np.ndarray:
+    # T5 ties encoder/decoder embed_tokens to `shared` (one Parameter, three state-dict names)
+    key = re.sub(r"(encoder|decoder)\.embed_tokens\.weight$", "shared.weight", key)
     rs = np.random.RandomState(zlib.crc32(key.encode()) & 0x7FFFFFFF)
     x = rs.standard_normal(tuple(shape)).astype(np.float32)
     leaf = key.rsplit(".", 1)[-1]

@@ -1,0 +1,38 @@
+import json
+import os
+
+import numpy as np
+import torch
+
+from weights import seeded_state_dict
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+TINY_CFG = dict(
+    vit=dict(embed_dim=96, depth=2, num_heads=4, img=56, patch=14),
+    qf=dict(hidden_size=64, num_attention_heads=4, intermediate_size=128, num_hidden_layers=4, cross_attention_freq=2,
+            num_query_token=8),
+    t5=dict(d_model=64, d_kv=16, d_ff=128, num_layers=2, num_decoder_layers=2, num_heads=4, vocab_size=32128,
+            num_buckets=32, max_distance=128, eps=1e-6),
+)
+
+
+def load_golden(name):
+    d = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+    out = {}
+    for k, v in d.items():
+        if k.endswith("_json"):
+            out[k[:-5]] = json.loads(bytes(v).decode())
+        else:
+            out[k] = v
+    return out
+
+
+def golden_state_dict(g, prefix=""):
+    return {prefix + k: v for k, v in seeded_state_dict(g["manifest"]).items()}
+
+
+def relerr(a, b):
+    a = torch.as_tensor(a, dtype=torch.float64)
+    b = torch.as_tensor(b, dtype=torch.float64)
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
