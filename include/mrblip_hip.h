@@ -1,0 +1,103 @@
+/* libmrblip_hip.so — C ABI of the MI355X-native (gfx950) Mr. BLIP / Chrono train-step kernels.
+ *
+ * The reference (sudo-Boris/mr-Blip) is pure Python/PyTorch and has no FFI of its own; each entry point below
+ * replaces the torch call sites cited next to it (file:line relative to the reference tree) and is what a
+ * ctypes / pybind stub on the reference side would bind.
+ *
+ * Conventions: every function returns 0 on success or a negative code (message: mrblip_last_error(), thread
+ * local).  All buffers are device memory owned by the caller; the library never allocates, never synchronises,
+ * never changes the current device, and launches only on `stream`.  bf16 tensors are raw uint16 bits.
+ * Leading dimensions / strides are in ELEMENTS.  Dropout: mask = f(index, *seed_ptr, site) with a counter hash
+ * (csrc/common.h mrb_hash), p == 0 disables it; *seed_ptr is read on the device so captured hipGraphs replay
+ * with fresh masks after mrblip_seed_bump.
+ */
+#ifndef MRBLIP_HIP_H
+#define MRBLIP_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* mrblip_stream_t; /* hipStream_t */
+
+const char* mrblip_last_error(void);
+int mrblip_abi_version(void);
+
+/* C[M,N] = A[M,K] W[N,K]^T (+ Aext[M,64] Wext[N,64]^T : LoRA K-extension) with fused epilogue
+ *   v = acc + bias;  out2 = bf16(v) (optional pre-activation);  v = gelu_erf(v) if act==1;  v = dropout(v);
+ *   out = residual + v   (fp32 or bf16 out).
+ * gated != 0: W = [wi_0; wi_1] stacked ([N = 2*Nh, K]); out[M,Nh] = dropout(gelu(h0) * h1), out2 = [h0 | h1].
+ * tile_cfg: 0 auto, 1 = 256x256x64 / 8 waves, 2 = 128x128x64 / 4 waves, 3 = skinny-M weight-streaming kernel.
+ * Replaces F.linear / nn.Linear / Conv2d(k=s=14): eva_vit.py:120-126,146,54-61,196-203; Qformer.py:141-147,
+ * 285-289,349-375; modeling_t5.py:323-329,536-560,1870; blip2_mr.py:491 (t5_proj); peft LoRA Linear. */
+int mrblip_gemm_bf16(const void* A, long long lda, const void* W, long long ldw, const void* Aext, long long ldaext,
+                     const void* Wext, long long ldwext, int M, int N, int K, void* out, long long ldo, int out_f32,
+                     void* out2, long long ldo2, const float* bias, const float* residual, long long ldr, int act, int gated,
+                     const uint32_t* seed_ptr, uint32_t site, float p_drop, int tile_cfg, mrblip_stream_t stream);
+
+/* LayerNorm / T5 RMSNorm over rows of fp32 x[M,D] (D <= 2048, D % 4 == 0); fp32 statistics.
+ * eva_vit.py:157,163; blip2.py:113-119 (ln_vision); Qformer.py:104-107,285-289,372-375; modeling_t5.py:254-277. */
+int mrblip_layernorm_fwd(const float* x, long long ldx, const float* gamma, const float* beta, int M, int D, float eps,
+                         void* out_bf16, long long ldob, float* out_f32, long long ldof, mrblip_stream_t stream);
+int mrblip_rmsnorm_fwd(const float* x, long long ldx, const float* weight, int M, int D, float eps, void* out_bf16,
+                       long long ldob, float* out_f32, long long ldof, mrblip_stream_t stream);
+/* dx = dx_add + dLN(dy); optional dgamma/dbeta += (fp32 atomics) */
+int mrblip_layernorm_bwd(const float* dy, long long lddy, const float* x, long long ldx, const float* gamma, int M, int D,
+                         float eps, const float* dx_add, long long ldadd, float* dx, long long lddx, float* dgamma,
+                         float* dbeta, mrblip_stream_t stream);
+int mrblip_rmsnorm_bwd(const float* dy, long long lddy, const float* x, long long ldx, const float* weight, int M, int D,
+                       float eps, const float* dx_add, long long ldadd, float* dx, long long lddx, mrblip_stream_t stream);
+
+/* Fused softmax(Q K^T * scale + bias_lut[h][clamp(k-q,-128,128)+128] + masks) V, fp32 online softmax, bf16 I/O.
+ * strides = {batch, head, row} in elements (rows are contiguous in head_dim).  Vt/Kt/Qt/dOt are
+ * [B,H,roundup32(D),roundup32(S)] transposed zero-padded copies from mrblip_head_transpose.  LSE/Delta are
+ * [B,H,roundup32(Sq)] fp32.  eva_vit.py:128-145; Qformer.py:195-262; modeling_t5.py:392-472,536-603. */
+int mrblip_attention_fwd(const void* Q, const long long* q_strides, const void* K, const long long* k_strides, const void* Vt,
+                         void* O, const long long* o_strides, float* LSE, int B, int H, int Sq, int Sk, int D, float scale,
+                         const float* bias_lut, const int* kmask, int causal, const uint32_t* seed_ptr, uint32_t site,
+                         float p_drop, mrblip_stream_t stream);
+int mrblip_attention_bwd(const void* Q, const long long* q_strides, const void* K, const long long* k_strides, const void* V,
+                         const long long* v_strides, const void* O, const long long* o_strides, const void* dO,
+                         const long long* do_strides, const void* Kt, const void* Qt, const void* dOt, const float* LSE,
+                         float* Delta, void* dQ, const long long* dq_strides, void* dK, const long long* dk_strides, void* dV,
+                         const long long* dv_strides, int B, int H, int Sq, int Sk, int D, float scale, const float* bias_lut,
+                         const int* kmask, int causal, const uint32_t* seed_ptr, uint32_t site, float p_drop,
+                         mrblip_stream_t stream);
+int mrblip_head_transpose(const void* src, const long long* strides, void* dst, int B, int H, int S, int D, mrblip_stream_t stream);
+
+/* frames fp32 [F,3,IMG,IMG] -> bf16 patch rows [F*(IMG/P)^2, Kpad] in Conv2d weight order (eva_vit.py:196-203) */
+int mrblip_patchify(const float* video, void* out_bf16, int F, int IMG, int P, int Kpad, mrblip_stream_t stream);
+/* x = [cls ; patches] + pos  (eva_vit.py:328-331) */
+int mrblip_vit_assemble(const float* patch, const float* cls, const float* pos, float* x, int F, int NP, int D, mrblip_stream_t stream);
+/* dst[dst_idx[i],:] (=|+=) src[src_idx[i],:]; src_idx<0 -> zeros.  Embedding gathers and the frame/timestamp
+ * interleave of prompt_concatenation (blip2_mr.py:641-665, 691-757) and their backward. */
+int mrblip_row_copy(const float* src, long long lds, const int* src_idx, float* dst, long long ldd, const int* dst_idx, int n_rows,
+                    int D, int accumulate, mrblip_stream_t stream);
+/* 32 -> 1 frame-token mean (blip2_mr.py:493-498) and its backward */
+int mrblip_mean_pool(const float* x, float* out, int F, int n, int D, mrblip_stream_t stream);
+int mrblip_mean_pool_bwd(const float* dout, float* dx, int F, int n, int D, mrblip_stream_t stream);
+int mrblip_cast_dropout(const float* x, long long ldx, void* out_bf16, long long ldob, float* out_f32, long long ldof, int M, int N,
+                        const uint32_t* seed_ptr, uint32_t site, float p, mrblip_stream_t stream);
+int mrblip_gelu_bwd(const void* dy, const void* h, void* dh, long long n, mrblip_stream_t stream);
+int mrblip_gated_gelu_bwd(const void* dy, long long lddy, const void* h, long long ldh, void* dh, long long lddh, int M, int Nh,
+                          const uint32_t* seed_ptr, uint32_t site, float p, mrblip_stream_t stream);
+/* CrossEntropyLoss(ignore_index=-100, mean) + dlogits (modeling_t5.py:1873-1877) */
+int mrblip_cross_entropy(const float* logits, long long ldl, const int* labels, int R, int V, float inv_count, float* loss,
+                         void* dlogits_bf16, long long ldd, mrblip_stream_t stream);
+/* torch.optim.AdamW step on a flat segment; hyper = {lr, 1/bias_corr1, 1/sqrt(bias_corr2), grad_scale} on device
+ * (runner_base.py:102-132, moment_retrieval.py:221-233) */
+int mrblip_adamw(float* p, const float* g, float* m, float* v, long long n, const float* hyper, float beta1, float beta2, float eps,
+                 float weight_decay, mrblip_stream_t stream);
+int mrblip_seed_bump(uint32_t* seed, mrblip_stream_t stream);
+/* LoRA r=8 pieces (peft 0.13.0 Linear; blip2_mr.py:182-200,236): u = drop(x) A^T ; dW += drop(Y)^T U ; dx += mask*(G A) */
+int mrblip_lora_down(const void* x, long long ldx, const float* A, int M, int K, void* u, long long ldu, float scale,
+                     const uint32_t* seed_ptr, uint32_t site, float p, mrblip_stream_t stream);
+int mrblip_lora_dw(const void* Y, long long ldy, const void* U, long long ldu, int M, int C, float* dW, long long sc, long long sr,
+                   float scale, const uint32_t* seed_ptr, uint32_t site, float p, mrblip_stream_t stream);
+int mrblip_lora_dx_add(void* dx, long long lddx, int dx_f32, const void* G, long long ldg, const float* A, int M, int K, float scale,
+                       const uint32_t* seed_ptr, uint32_t site, float p, mrblip_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,487 @@
+// Flash-style fused attention for gfx950 (forward, dQ backward, dK/dV backward) on 32x32x16 bf16 MFMA.
+//
+// Replaces: eva_vit.py:128-145 (ViT, head_dim 88, scale 88^-0.5, no mask), Qformer.py:195-262 (self 32x32 and
+// cross 32x257, scale 1/8, dropout on probabilities), modeling_t5.py:536-603 (T5: NO 1/sqrt(d) scaling, shared
+// relative-position bias computed on the fly from a 257-entry per-head LUT instead of the reference's dense
+// [1,H,S,S] tensor, key-padding / causal masks, fp32 softmax, dropout on probabilities).
+//
+// Design: one wave owns 32 query rows (dKV kernel: 32 key rows) and never touches LDS for operands: the
+// "swapped" product S^T = K Q^T makes every lane own ONE query column, so the softmax reductions are in-lane
+// plus one lane^32 exchange, and the fp32 score registers, after bf16 packing, ARE the B operand of the second
+// product O^T = V^T P^T — provided the 32 keys of a tile are fed to the first MFMA in the row order pi(i)
+// (bits 2 and 3 of the row index swapped), which is a free address permutation.  V^T (and K^T, Q^T, dO^T for
+// the backward) are [B,H,DP,Spad] transposed copies produced by mrblip_head_transpose, zero padded so padded
+// keys/dims contribute exact zeros.  K/V tiles are re-read by every wave from L2 (per-head K+V are L2-resident).
+#include "common.h"
+
+struct T4 {  // element (b,h,s,d) at ptr + b*bs + h*hs + s*rs + d   (row-major in d)
+  const bf16_t* ptr;
+  long long bs, hs, rs;
+};
+struct T4T {  // element (b,h,d,s) at ptr + b*bs + h*hs + d*ds + s   (transposed copy)
+  const bf16_t* ptr;
+  long long bs, hs, ds;
+};
+
+struct AttnArgs {
+  T4 Q, K, V, O, dO, dQ, dK, dV;
+  T4T Vt, Kt, Qt, dOt;
+  float* LSE;          // [B,H,Sqpad]
+  float* Delta;        // [B,H,Sqpad]
+  const float* lut;    // [H,257] relative-position bias by clamp(key - q, -128, 128) + 128, or nullptr
+  const int* kmask;    // [B,Sk] 1 = attend, or nullptr
+  int B, H, Sq, Sk, D, Sqpad;
+  int causal;
+  float scale;
+  DropoutArg drop;
+};
+
+#define NEG_BIG (-1.0e30f)
+
+__device__ __forceinline__ int perm23(int i) { return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1); }
+__device__ __forceinline__ bf16x8 ld8(const bf16_t* p) { return *reinterpret_cast<const bf16x8*>(p); }
+__device__ __forceinline__ bf16x8 pack8(const float* v) {
+  union { bf16x8 v8; uint32_t u[4]; } r;
+  r.u[0] = pack2bf(v[0], v[1]); r.u[1] = pack2bf(v[2], v[3]); r.u[2] = pack2bf(v[4], v[5]); r.u[3] = pack2bf(v[6], v[7]);
+  return r.v8;
+}
+__device__ __forceinline__ void zero16(f32x16& a) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) a[r] = 0.f;
+}
+
+template <int DP>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
+  constexpr int KS = DP / 16, MT = DP / 32;
+  __shared__ float lut[257];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, hi = lane >> 5, l31 = lane & 31;
+  const int b = blockIdx.z, h = blockIdx.y;
+  if (p.lut) {
+    for (int i = threadIdx.x; i < 257; i += 256) lut[i] = p.lut[h * 257 + i];
+  }
+  __syncthreads();
+  const int q0 = (blockIdx.x * 4 + w) * 32;
+  if (q0 >= p.Sq) return;
+  const int q = q0 + l31;
+  const bool q_ok = q < p.Sq;
+  const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+  bf16x8 qf[KS];
+  {
+    const bf16_t* qp = p.Q.ptr + b * p.Q.bs + h * p.Q.hs + (long long)q * p.Q.rs;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int d0 = 16 * s + 8 * hi;
+      qf[s] = (q_ok && d0 < p.D) ? ld8(qp + d0) : zero;
+    }
+  }
+  float m_run = NEG_BIG, l_run = 0.f;
+  f32x16 o[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) zero16(o[mt]);
+  const int kend = p.causal ? min(p.Sk, q0 + 32) : p.Sk;
+  const bf16_t* kbase = p.K.ptr + b * p.K.bs + h * p.K.hs;
+  const bf16_t* vtbase = p.Vt.ptr + b * p.Vt.bs + h * p.Vt.hs;
+  const int* km = p.kmask ? p.kmask + (long long)b * p.Sk : nullptr;
+  const uint32_t drop_seed = p.drop.seed_ptr ? *p.drop.seed_ptr : 0u;
+  const uint32_t row_idx = ((uint32_t)(b * p.H + h) * (uint32_t)p.Sq + (uint32_t)q) * (uint32_t)p.Sk;
+
+  for (int k0 = 0; k0 < kend; k0 += 32) {
+    f32x16 sacc;
+    zero16(sacc);
+    {
+      const int krow = k0 + perm23(l31);
+      const bool k_ok = krow < p.Sk;
+      const bf16_t* kp = kbase + (long long)krow * p.K.rs;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const int d0 = 16 * s + 8 * hi;
+        const bf16x8 kf = (k_ok && d0 < p.D) ? ld8(kp + d0) : zero;
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc, 0, 0, 0);
+      }
+    }
+    float sv[16];
+    uint32_t vmask = 0;
+    float mx = NEG_BIG;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = k0 + 16 * (r >> 3) + 8 * hi + (r & 7);
+      float val = sacc[r] * p.scale;
+      if (p.lut) {
+        int rel = key - q;
+        rel = max(-128, min(128, rel));
+        val += lut[rel + 128];
+      }
+      bool ok = key < p.Sk;
+      if (p.causal) ok = ok && (key <= q);
+      if (km) ok = ok && (km[min(key, p.Sk - 1)] != 0);
+      sv[r] = val;
+      if (ok) { vmask |= 1u << r; mx = fmaxf(mx, val); }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __expf(m_run - m_new);
+    float psum = 0.f;
+    float pv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float e = (vmask >> r) & 1u ? __expf(sv[r] - m_new) : 0.f;
+      psum += e;
+      if (p.drop.seed_ptr) {
+        const int key = k0 + 16 * (r >> 3) + 8 * hi + (r & 7);
+        e = mrb_keep(row_idx + (uint32_t)key, drop_seed, p.drop.site, p.drop.thresh24) ? e * p.drop.inv_keep : 0.f;
+      }
+      pv[r] = e;
+    }
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[mt][r] *= alpha;
+    const bf16x8 pf0 = pack8(pv), pf1 = pack8(pv + 8);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const bf16_t* vp = vtbase + (long long)(mt * 32 + l31) * p.Vt.ds + k0 + 8 * hi;
+      o[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld8(vp), pf0, o[mt], 0, 0, 0);
+      o[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld8(vp + 16), pf1, o[mt], 0, 0, 0);
+    }
+  }
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+  if (q_ok) {
+    bf16_t* op = const_cast<bf16_t*>(p.O.ptr) + b * p.O.bs + h * p.O.hs + (long long)q * p.O.rs;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d0 = mt * 32 + 8 * g + 4 * hi;
+        if (d0 < p.D)
+          *reinterpret_cast<uint2*>(op + d0) = make_uint2(pack2bf(o[mt][4 * g] * inv, o[mt][4 * g + 1] * inv),
+                                                          pack2bf(o[mt][4 * g + 2] * inv, o[mt][4 * g + 3] * inv));
+      }
+    if (p.LSE && hi == 0) p.LSE[((long long)(b * p.H + h)) * p.Sqpad + q] = m_run + __logf(fmaxf(l_tot, 1e-37f));
+  }
+}
+
+// ---- backward, part 1: dQ (and Delta = rowsum(dO * O), needed by part 2).  Same ownership as the forward.
+template <int DP>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
+  constexpr int KS = DP / 16, MT = DP / 32;
+  __shared__ float lut[257];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, hi = lane >> 5, l31 = lane & 31;
+  const int b = blockIdx.z, h = blockIdx.y;
+  if (p.lut) {
+    for (int i = threadIdx.x; i < 257; i += 256) lut[i] = p.lut[h * 257 + i];
+  }
+  __syncthreads();
+  const int q0 = (blockIdx.x * 4 + w) * 32;
+  if (q0 >= p.Sq) return;
+  const int q = q0 + l31;
+  const bool q_ok = q < p.Sq;
+  const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+  bf16x8 qf[KS], dof[KS];
+  float delta = 0.f;
+  {
+    const bf16_t* qp = p.Q.ptr + b * p.Q.bs + h * p.Q.hs + (long long)q * p.Q.rs;
+    const bf16_t* dp = p.dO.ptr + b * p.dO.bs + h * p.dO.hs + (long long)q * p.dO.rs;
+    const bf16_t* op = p.O.ptr + b * p.O.bs + h * p.O.hs + (long long)q * p.O.rs;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int d0 = 16 * s + 8 * hi;
+      const bool ok = q_ok && d0 < p.D;
+      qf[s] = ok ? ld8(qp + d0) : zero;
+      dof[s] = ok ? ld8(dp + d0) : zero;
+      const bf16x8 of = ok ? ld8(op + d0) : zero;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) delta += bf2f((bf16_t)dof[s][j]) * bf2f((bf16_t)of[j]);
+    }
+  }
+  delta += __shfl_xor(delta, 32, 64);
+  const long long stat_off = ((long long)(b * p.H + h)) * p.Sqpad + q;
+  const float lse = q_ok ? p.LSE[stat_off] : 0.f;
+  if (q_ok && hi == 0) p.Delta[stat_off] = delta;
+
+  f32x16 dq[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) zero16(dq[mt]);
+  const int kend = p.causal ? min(p.Sk, q0 + 32) : p.Sk;
+  const bf16_t* kbase = p.K.ptr + b * p.K.bs + h * p.K.hs;
+  const bf16_t* vbase = p.V.ptr + b * p.V.bs + h * p.V.hs;
+  const bf16_t* ktbase = p.Kt.ptr + b * p.Kt.bs + h * p.Kt.hs;
+  const int* km = p.kmask ? p.kmask + (long long)b * p.Sk : nullptr;
+  const uint32_t drop_seed = p.drop.seed_ptr ? *p.drop.seed_ptr : 0u;
+  const uint32_t row_idx = ((uint32_t)(b * p.H + h) * (uint32_t)p.Sq + (uint32_t)q) * (uint32_t)p.Sk;
+
+  for (int k0 = 0; k0 < kend; k0 += 32) {
+    f32x16 sacc, dpacc;
+    zero16(sacc);
+    zero16(dpacc);
+    {
+      const int krow = k0 + perm23(l31);
+      const bool k_ok = krow < p.Sk;
+      const bf16_t* kp = kbase + (long long)krow * p.K.rs;
+      const bf16_t* vp = vbase + (long long)krow * p.V.rs;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const int d0 = 16 * s + 8 * hi;
+        const bool ok = k_ok && d0 < p.D;
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ok ? ld8(kp + d0) : zero, qf[s], sacc, 0, 0, 0);
+        dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ok ? ld8(vp + d0) : zero, dof[s], dpacc, 0, 0, 0);
+      }
+    }
+    float ds[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = k0 + 16 * (r >> 3) + 8 * hi + (r & 7);
+      float val = sacc[r] * p.scale;
+      if (p.lut) {
+        int rel = key - q;
+        rel = max(-128, min(128, rel));
+        val += lut[rel + 128];
+      }
+      bool ok = q_ok && key < p.Sk;
+      if (p.causal) ok = ok && (key <= q);
+      if (km) ok = ok && (km[min(key, p.Sk - 1)] != 0);
+      const float pr = ok ? __expf(val - lse) : 0.f;
+      float dpv = dpacc[r];
+      if (p.drop.seed_ptr) dpv = mrb_keep(row_idx + (uint32_t)key, drop_seed, p.drop.site, p.drop.thresh24) ? dpv * p.drop.inv_keep : 0.f;
+      ds[r] = ok ? pr * (dpv - delta) * p.scale : 0.f;
+    }
+    const bf16x8 f0 = pack8(ds), f1 = pack8(ds + 8);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const bf16_t* kt = ktbase + (long long)(mt * 32 + l31) * p.Kt.ds + k0 + 8 * hi;
+      dq[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld8(kt), f0, dq[mt], 0, 0, 0);
+      dq[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld8(kt + 16), f1, dq[mt], 0, 0, 0);
+    }
+  }
+  if (q_ok) {
+    bf16_t* op = const_cast<bf16_t*>(p.dQ.ptr) + b * p.dQ.bs + h * p.dQ.hs + (long long)q * p.dQ.rs;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d0 = mt * 32 + 8 * g + 4 * hi;
+        if (d0 < p.D)
+          *reinterpret_cast<uint2*>(op + d0) = make_uint2(pack2bf(dq[mt][4 * g], dq[mt][4 * g + 1]), pack2bf(dq[mt][4 * g + 2], dq[mt][4 * g + 3]));
+      }
+  }
+}
+
+// ---- backward, part 2: dK, dV.  One wave owns 32 keys and walks the query tiles.
+template <int DP>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
+  constexpr int KS = DP / 16, MT = DP / 32;
+  __shared__ float lut[257];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, hi = lane >> 5, l31 = lane & 31;
+  const int b = blockIdx.z, h = blockIdx.y;
+  if (p.lut) {
+    for (int i = threadIdx.x; i < 257; i += 256) lut[i] = p.lut[h * 257 + i];
+  }
+  __syncthreads();
+  const int kb0 = (blockIdx.x * 4 + w) * 32;
+  if (kb0 >= p.Sk) return;
+  const int key = kb0 + l31;
+  bool key_ok = key < p.Sk;
+  const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+  bf16x8 kf[KS], vf[KS];
+  {
+    const bf16_t* kp = p.K.ptr + b * p.K.bs + h * p.K.hs + (long long)key * p.K.rs;
+    const bf16_t* vp = p.V.ptr + b * p.V.bs + h * p.V.hs + (long long)key * p.V.rs;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int d0 = 16 * s + 8 * hi;
+      const bool ok = key_ok && d0 < p.D;
+      kf[s] = ok ? ld8(kp + d0) : zero;
+      vf[s] = ok ? ld8(vp + d0) : zero;
+    }
+  }
+  if (p.kmask && key_ok) key_ok = p.kmask[(long long)b * p.Sk + key] != 0;
+  f32x16 dk[MT], dv[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) { zero16(dk[mt]); zero16(dv[mt]); }
+  const bf16_t* qbase = p.Q.ptr + b * p.Q.bs + h * p.Q.hs;
+  const bf16_t* dobase = p.dO.ptr + b * p.dO.bs + h * p.dO.hs;
+  const bf16_t* qtbase = p.Qt.ptr + b * p.Qt.bs + h * p.Qt.hs;
+  const bf16_t* dotbase = p.dOt.ptr + b * p.dOt.bs + h * p.dOt.hs;
+  const float* lsebase = p.LSE + ((long long)(b * p.H + h)) * p.Sqpad;
+  const float* delbase = p.Delta + ((long long)(b * p.H + h)) * p.Sqpad;
+  const uint32_t drop_seed = p.drop.seed_ptr ? *p.drop.seed_ptr : 0u;
+  const uint32_t bh_idx = (uint32_t)(b * p.H + h) * (uint32_t)p.Sq;
+  const int qstart = p.causal ? (kb0 & ~31) : 0;
+
+  for (int q0 = qstart; q0 < p.Sq; q0 += 32) {
+    f32x16 sacc, dpacc;
+    zero16(sacc);
+    zero16(dpacc);
+    {
+      const int qrow = q0 + perm23(l31);
+      const bool r_ok = qrow < p.Sq;
+      const bf16_t* qp = qbase + (long long)qrow * p.Q.rs;
+      const bf16_t* dp = dobase + (long long)qrow * p.dO.rs;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const int d0 = 16 * s + 8 * hi;
+        const bool ok = r_ok && d0 < p.D;
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ok ? ld8(qp + d0) : zero, kf[s], sacc, 0, 0, 0);
+        dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ok ? ld8(dp + d0) : zero, vf[s], dpacc, 0, 0, 0);
+      }
+    }
+    float lse[16], del[16];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int qq = q0 + 16 * c + 8 * hi;  // Sqpad is a multiple of 32 -> in-bounds
+      const float4 a0 = *reinterpret_cast<const float4*>(lsebase + qq), a1 = *reinterpret_cast<const float4*>(lsebase + qq + 4);
+      const float4 b0 = *reinterpret_cast<const float4*>(delbase + qq), b1 = *reinterpret_cast<const float4*>(delbase + qq + 4);
+      lse[8 * c + 0] = a0.x; lse[8 * c + 1] = a0.y; lse[8 * c + 2] = a0.z; lse[8 * c + 3] = a0.w;
+      lse[8 * c + 4] = a1.x; lse[8 * c + 5] = a1.y; lse[8 * c + 6] = a1.z; lse[8 * c + 7] = a1.w;
+      del[8 * c + 0] = b0.x; del[8 * c + 1] = b0.y; del[8 * c + 2] = b0.z; del[8 * c + 3] = b0.w;
+      del[8 * c + 4] = b1.x; del[8 * c + 5] = b1.y; del[8 * c + 6] = b1.z; del[8 * c + 7] = b1.w;
+    }
+    float pd[16], ds[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int qq = q0 + 16 * (r >> 3) + 8 * hi + (r & 7);
+      float val = sacc[r] * p.scale;
+      if (p.lut) {
+        int rel = key - qq;
+        rel = max(-128, min(128, rel));
+        val += lut[rel + 128];
+      }
+      bool ok = key_ok && qq < p.Sq;
+      if (p.causal) ok = ok && (key <= qq);
+      const float pr = ok ? __expf(val - lse[r]) : 0.f;
+      float dpv = dpacc[r], prd = pr;
+      if (p.drop.seed_ptr) {
+        const bool keep = mrb_keep((bh_idx + (uint32_t)qq) * (uint32_t)p.Sk + (uint32_t)key, drop_seed, p.drop.site, p.drop.thresh24);
+        dpv = keep ? dpv * p.drop.inv_keep : 0.f;
+        prd = keep ? pr * p.drop.inv_keep : 0.f;
+      }
+      pd[r] = prd;
+      ds[r] = ok ? pr * (dpv - del[r]) * p.scale : 0.f;
+    }
+    const bf16x8 p0 = pack8(pd), p1 = pack8(pd + 8), s0 = pack8(ds), s1 = pack8(ds + 8);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const bf16_t* dot = dotbase + (long long)(mt * 32 + l31) * p.dOt.ds + q0 + 8 * hi;
+      const bf16_t* qt = qtbase + (long long)(mt * 32 + l31) * p.Qt.ds + q0 + 8 * hi;
+      dv[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld8(dot), p0, dv[mt], 0, 0, 0);
+      dv[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld8(dot + 16), p1, dv[mt], 0, 0, 0);
+      dk[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld8(qt), s0, dk[mt], 0, 0, 0);
+      dk[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld8(qt + 16), s1, dk[mt], 0, 0, 0);
+    }
+  }
+  if (key < p.Sk) {
+    bf16_t* kp = const_cast<bf16_t*>(p.dK.ptr) + b * p.dK.bs + h * p.dK.hs + (long long)key * p.dK.rs;
+    bf16_t* vp = const_cast<bf16_t*>(p.dV.ptr) + b * p.dV.bs + h * p.dV.hs + (long long)key * p.dV.rs;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d0 = mt * 32 + 8 * g + 4 * hi;
+        if (d0 < p.D) {
+          *reinterpret_cast<uint2*>(kp + d0) = make_uint2(pack2bf(dk[mt][4 * g], dk[mt][4 * g + 1]), pack2bf(dk[mt][4 * g + 2], dk[mt][4 * g + 3]));
+          *reinterpret_cast<uint2*>(vp + d0) = make_uint2(pack2bf(dv[mt][4 * g], dv[mt][4 * g + 1]), pack2bf(dv[mt][4 * g + 2], dv[mt][4 * g + 3]));
+        }
+      }
+  }
+}
+
+// ---- [B,S,H,D]-strided rows -> [B,H,DP,Spad] transposed, zero padded (Spad multiple of 32, DP multiple of 32)
+__global__ __launch_bounds__(256) void head_transpose_kernel(T4 src, bf16_t* dst, int S, int D, int DP, int Spad) {
+  __shared__ bf16_t tile[32][96 + 2];
+  const int b = blockIdx.z, h = blockIdx.y, s0 = blockIdx.x * 32;
+  const bf16_t* sp = src.ptr + b * src.bs + h * src.hs;
+  for (int i = threadIdx.x; i < 32 * DP; i += 256) {
+    const int r = i / DP, d = i % DP;
+    const int s = s0 + r;
+    tile[r][d] = (s < S && d < D) ? sp[(long long)s * src.rs + d] : (bf16_t)0;
+  }
+  __syncthreads();
+  bf16_t* dp = dst + ((long long)(b * gridDim.y + h) * DP) * Spad + s0;
+  for (int i = threadIdx.x; i < 32 * DP; i += 256) {
+    const int d = i / 32, r = i % 32;
+    dp[(long long)d * Spad + r] = tile[r][d];
+  }
+}
+
+static int attn_fill(AttnArgs& a, const void* Q, const long long* qs, const void* K, const long long* ks, const void* V,
+                     const long long* vs, int B, int H, int Sq, int Sk, int D) {
+  MRB_REQUIRE(B > 0 && H > 0 && Sq > 0 && Sk > 0, "attention: empty problem");
+  MRB_REQUIRE(D > 0 && D <= 96 && (D % 8) == 0, "attention: head_dim must be a multiple of 8 and <= 96 (got %d)", D);
+  a.Q = T4{(const bf16_t*)Q, qs[0], qs[1], qs[2]};
+  a.K = T4{(const bf16_t*)K, ks[0], ks[1], ks[2]};
+  a.V = T4{(const bf16_t*)V, vs[0], vs[1], vs[2]};
+  a.B = B; a.H = H; a.Sq = Sq; a.Sk = Sk; a.D = D; a.Sqpad = (Sq + 31) / 32 * 32;
+  return MRBLIP_OK;
+}
+
+static void attn_drop(AttnArgs& a, const uint32_t* seed_ptr, uint32_t site, float p_drop) {
+  a.drop.seed_ptr = (p_drop > 0.f) ? seed_ptr : nullptr;
+  a.drop.site = site;
+  a.drop.thresh24 = (uint32_t)(p_drop * 16777216.0f + 0.5f);
+  a.drop.inv_keep = 1.0f / (1.0f - p_drop);
+}
+
+// strides arrays: {batch, head, row} in elements.  Vt: [B,H,DP,Skpad] with DP = roundup32(D), Skpad = roundup32(Sk).
+extern "C" int mrblip_attention_fwd(const void* Q, const long long* q_strides, const void* K, const long long* k_strides,
+                                    const void* Vt, void* O, const long long* o_strides, float* LSE, int B, int H, int Sq, int Sk,
+                                    int D, float scale, const float* bias_lut, const int* kmask, int causal,
+                                    const uint32_t* seed_ptr, uint32_t site, float p_drop, hipStream_t stream) {
+  AttnArgs a = {};
+  long long dummy[3] = {0, 0, 0};
+  if (int e = attn_fill(a, Q, q_strides, K, k_strides, nullptr, dummy, B, H, Sq, Sk, D)) return e;
+  const int DP = (D + 31) / 32 * 32, Skpad = (Sk + 31) / 32 * 32;
+  a.Vt = T4T{(const bf16_t*)Vt, (long long)H * DP * Skpad, (long long)DP * Skpad, Skpad};
+  a.O = T4{(const bf16_t*)O, o_strides[0], o_strides[1], o_strides[2]};
+  a.LSE = LSE; a.lut = bias_lut; a.kmask = kmask; a.causal = causal; a.scale = scale;
+  attn_drop(a, seed_ptr, site, p_drop);
+  dim3 grid((Sq + 127) / 128, H, B);
+  if (DP == 32) hipLaunchKernelGGL(attn_fwd_kernel<32>, grid, dim3(256), 0, stream, a);
+  else if (DP == 64) hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL(attn_fwd_kernel<96>, grid, dim3(256), 0, stream, a);
+  return mrblip_check_launch("attention_fwd");
+}
+
+// Backward.  Needs the forward's O and LSE, the transposed copies Kt [B,H,DP,Skpad], Qt / dOt [B,H,DP,Sqpad];
+// writes Delta [B,H,Sqpad] (scratch), dQ, dK, dV (bf16, strided like their forward tensors).
+extern "C" int mrblip_attention_bwd(const void* Q, const long long* q_strides, const void* K, const long long* k_strides,
+                                    const void* V, const long long* v_strides, const void* O, const long long* o_strides,
+                                    const void* dO, const long long* do_strides, const void* Kt, const void* Qt, const void* dOt,
+                                    const float* LSE, float* Delta, void* dQ, const long long* dq_strides, void* dK,
+                                    const long long* dk_strides, void* dV, const long long* dv_strides, int B, int H, int Sq, int Sk,
+                                    int D, float scale, const float* bias_lut, const int* kmask, int causal,
+                                    const uint32_t* seed_ptr, uint32_t site, float p_drop, hipStream_t stream) {
+  AttnArgs a = {};
+  if (int e = attn_fill(a, Q, q_strides, K, k_strides, V, v_strides, B, H, Sq, Sk, D)) return e;
+  MRB_REQUIRE(D <= 64, "attention_bwd: head_dim <= 64 only (the ViT is frozen, its attention needs no backward)");
+  const int DP = (D + 31) / 32 * 32, Skpad = (Sk + 31) / 32 * 32, Sqpad = a.Sqpad;
+  a.O = T4{(const bf16_t*)O, o_strides[0], o_strides[1], o_strides[2]};
+  a.dO = T4{(const bf16_t*)dO, do_strides[0], do_strides[1], do_strides[2]};
+  a.dQ = T4{(const bf16_t*)dQ, dq_strides[0], dq_strides[1], dq_strides[2]};
+  a.dK = T4{(const bf16_t*)dK, dk_strides[0], dk_strides[1], dk_strides[2]};
+  a.dV = T4{(const bf16_t*)dV, dv_strides[0], dv_strides[1], dv_strides[2]};
+  a.Kt = T4T{(const bf16_t*)Kt, (long long)H * DP * Skpad, (long long)DP * Skpad, Skpad};
+  a.Qt = T4T{(const bf16_t*)Qt, (long long)H * DP * Sqpad, (long long)DP * Sqpad, Sqpad};
+  a.dOt = T4T{(const bf16_t*)dOt, (long long)H * DP * Sqpad, (long long)DP * Sqpad, Sqpad};
+  a.LSE = const_cast<float*>(LSE); a.Delta = Delta; a.lut = bias_lut; a.kmask = kmask; a.causal = causal; a.scale = scale;
+  attn_drop(a, seed_ptr, site, p_drop);
+  dim3 gq((Sq + 127) / 128, H, B), gk((Sk + 127) / 128, H, B);
+  if (DP == 32) {
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<32>, gq, dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<32>, gk, dim3(256), 0, stream, a);
+  } else {
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, gq, dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, gk, dim3(256), 0, stream, a);
+  }
+  return mrblip_check_launch("attention_bwd");
+}
+
+extern "C" int mrblip_head_transpose(const void* src, const long long* strides, void* dst, int B, int H, int S, int D,
+                                     hipStream_t stream) {
+  MRB_REQUIRE(B > 0 && H > 0 && S > 0 && D > 0 && D <= 96, "head_transpose: bad shape");
+  const int DP = (D + 31) / 32 * 32, Spad = (S + 31) / 32 * 32;
+  T4 s{(const bf16_t*)src, strides[0], strides[1], strides[2]};
+  hipLaunchKernelGGL(head_transpose_kernel, dim3(Spad / 32, H, B), dim3(256), 0, stream, s, (bf16_t*)dst, S, D, DP, Spad);
+  return mrblip_check_launch("head_transpose");
+}

@@ -1,0 +1,46 @@
+"""Builds libmrblip_hip.so (gfx950 only) in-tree:  python mr-blip_amd/csrc/build.py [--force]"""
+import concurrent.futures as cf
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRCS = ["errors.hip", "gemm.hip", "norm.hip", "attention.hip", "elementwise.hip"]
+LIB = os.path.join(HERE, "libmrblip_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast"]
+
+
+def _stale(out, deps):
+    if not os.path.exists(out):
+        return True
+    t = os.path.getmtime(out)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    objs, jobs = [], []
+    hdr = os.path.join(HERE, "common.h")
+    for s in SRCS:
+        src = os.path.join(HERE, s)
+        obj = os.path.join(HERE, s.replace(".hip", ".o"))
+        objs.append(obj)
+        if force or _stale(obj, [src, hdr]):
+            jobs.append([HIPCC, *FLAGS, "-c", src, "-o", obj])
+    def run(cmd):
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed: %s\n%s" % (" ".join(cmd), r.stderr))
+        return r.stderr
+    if jobs:
+        with cf.ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
+            for err in ex.map(run, jobs):
+                if verbose and err.strip():
+                    print(err, file=sys.stderr)
+    if jobs or force or _stale(LIB, objs):
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB])
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

@@ -1,0 +1,78 @@
+// Shared device/host helpers for libmrblip_hip.so (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;  // raw bfloat16 bits
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define MRBLIP_OK 0
+#define MRBLIP_EINVAL (-1)
+#define MRBLIP_ELAUNCH (-2)
+
+void mrblip_set_error(const char* fmt, ...);
+int mrblip_check_launch(const char* what);
+
+#define MRB_REQUIRE(cond, ...)            \
+  do {                                    \
+    if (!(cond)) {                        \
+      mrblip_set_error(__VA_ARGS__);      \
+      return MRBLIP_EINVAL;               \
+    }                                     \
+  } while (0)
+
+// ---- bf16 <-> f32 (round-to-nearest-even, like torch .bfloat16())
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+
+// ---- counter-based dropout RNG.  One 32-bit hash per element; the oracle restates it in numpy
+// (oracle/mrblip_oracle.py: dropout_keep) so training-mode parity can be checked with p > 0.
+// seed = *seed_ptr (device memory, bumped once per step so hipGraph replays draw fresh masks), site = call-site id.
+__device__ __forceinline__ uint32_t mrb_hash(uint32_t idx, uint32_t seed, uint32_t site) {
+  uint32_t h = idx ^ (seed * 0x9E3779B1u);
+  h *= 0x85EBCA77u;
+  h ^= h >> 15;
+  h += site * 0xC2B2AE3Du + 0x27D4EB2Fu;
+  h *= 0x9E3779B1u;
+  h ^= h >> 13;
+  h *= 0xC2B2AE3Du;
+  h ^= h >> 16;
+  return h;
+}
+// keep iff top 24 bits >= thresh24, thresh24 = round(p * 2^24)
+__device__ __forceinline__ bool mrb_keep(uint32_t idx, uint32_t seed, uint32_t site, uint32_t thresh24) {
+  return (mrb_hash(idx, seed, site) >> 8) >= thresh24;
+}
+
+struct DropoutArg {
+  const uint32_t* seed_ptr;  // nullptr or p == 0 -> disabled
+  uint32_t site;
+  uint32_t thresh24;
+  float inv_keep;  // 1 / (1 - p)
+};
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+  const float kInvSqrt2Pi = 0.39894228040143267794f;
+  return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * kInvSqrt2Pi * __expf(-0.5f * x * x);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}

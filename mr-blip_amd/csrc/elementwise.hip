@@ -1,0 +1,394 @@
+// HBM-bound side kernels of the Mr. BLIP hot path: frame patchify (coalesced reads of the [BT,3,H,W] frame
+// tensor), cls/pos assembly, indexed row copy (embedding gather + frame/timestamp interleave scatter and its
+// transpose for the backward), 32->1 frame-token mean pool, activation backward, casts/dropout, cross entropy,
+// AdamW.  All vectorised (8-16 B/lane) where the layout allows.
+#include "common.h"
+#define NEG_INF_F (-3.0e38f)
+
+// ---------------------------------------------------------------------------------------------------------
+// patchify: video fp32 [F,3,IMG,IMG] -> bf16 [F*G*G, Kpad], row = (f, gy, gx), col = c*P*P + py*P + px (the
+// Conv2d(k=s=P) weight order, eva_vit.py:196-203), cols >= 3*P*P zero.  One block per (f, gy): every image row
+// segment is read once, fully coalesced.
+__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ img, bf16_t* __restrict__ out, int IMG, int P, int G, int Kpad) {
+  const int f = blockIdx.y, gy = blockIdx.x;
+  const int K = 3 * P * P;
+  bf16_t* orow = out + ((long long)(f * G + gy) * G) * Kpad;
+  for (int c = 0; c < 3; ++c)
+    for (int py = 0; py < P; ++py) {
+      const float* src = img + (((long long)f * 3 + c) * IMG + gy * P + py) * IMG;
+      for (int x = threadIdx.x; x < G * P; x += 256) {
+        const int gx = x / P, px = x % P;
+        orow[(long long)gx * Kpad + c * P * P + py * P + px] = f2bf(src[x]);
+      }
+    }
+  for (int i = threadIdx.x; i < G * (Kpad - K); i += 256) {
+    const int gx = i / (Kpad - K), k = K + i % (Kpad - K);
+    orow[(long long)gx * Kpad + k] = 0;
+  }
+}
+
+// x[f,0,:] = cls + pos[0]; x[f,1+p,:] = patch[f*NP+p,:] + pos[1+p]   (eva_vit.py:328-331), fp32 residual stream
+__global__ __launch_bounds__(256) void vit_assemble_kernel(const float* __restrict__ patch, const float* __restrict__ cls,
+                                                           const float* __restrict__ pos, float* __restrict__ x, int NP, int D) {
+  const int f = blockIdx.y, t = blockIdx.x;  // t in [0, NP]
+  const float4* src = (t == 0) ? reinterpret_cast<const float4*>(cls) : reinterpret_cast<const float4*>(patch + ((long long)f * NP + t - 1) * D);
+  const float4* ps = reinterpret_cast<const float4*>(pos + (long long)t * D);
+  float4* dst = reinterpret_cast<float4*>(x + ((long long)f * (NP + 1) + t) * D);
+  for (int i = threadIdx.x; i < D / 4; i += 256) {
+    const float4 a = src[i], b = ps[i];
+    dst[i] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+  }
+}
+
+// dst[dst_idx[i], :] (=|+=) src[src_idx[i], :]; src_idx < 0 writes zeros (left zero-padding, blip2_mr.py:744-753)
+template <bool ACCUM>
+__global__ __launch_bounds__(256) void row_copy_kernel(const float* __restrict__ src, long long lds_, const int* __restrict__ src_idx,
+                                                       float* __restrict__ dst, long long ldd, const int* __restrict__ dst_idx, int D) {
+  const int i = blockIdx.x;
+  const int si = src_idx[i], di = dst_idx[i];
+  if (di < 0) return;
+  float4* d = reinterpret_cast<float4*>(dst + (long long)di * ldd);
+  const float4* s = reinterpret_cast<const float4*>(src + (long long)(si < 0 ? 0 : si) * lds_);
+  for (int j = threadIdx.x; j < D / 4; j += 256) {
+    float4 v = (si < 0) ? make_float4(0.f, 0.f, 0.f, 0.f) : s[j];
+    if (ACCUM) { const float4 o = d[j]; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+    d[j] = v;
+  }
+}
+
+// mean over the n tokens of a frame (blip2_mr.py:493-498).  One wave per (frame, 128-column slab): lane = (token half,
+// float4 column); 16 in-register adds per half, then ONE wavefront shuffle (lane ^ 32) combines the halves.
+__global__ __launch_bounds__(64) void mean_pool_kernel(const float* __restrict__ x, float* __restrict__ out, int n, int D) {
+  const int f = blockIdx.y, lane = threadIdx.x, th = lane >> 5, c4 = blockIdx.x * 32 + (lane & 31);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c4 * 4 < D) {
+    for (int t = th; t < n; t += 2) {
+      const float4 v = reinterpret_cast<const float4*>(x + ((long long)f * n + t) * D)[c4];
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+  }
+  acc.x += __shfl_xor(acc.x, 32, 64); acc.y += __shfl_xor(acc.y, 32, 64);
+  acc.z += __shfl_xor(acc.z, 32, 64); acc.w += __shfl_xor(acc.w, 32, 64);
+  if (th == 0 && c4 * 4 < D) {
+    const float inv = 1.0f / (float)n;
+    reinterpret_cast<float4*>(out + (long long)f * D)[c4] = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+  }
+}
+__global__ __launch_bounds__(256) void mean_pool_bwd_kernel(const float* __restrict__ dout, float* __restrict__ dx, int n, int D) {
+  const int f = blockIdx.y, t = blockIdx.x;
+  const float inv = 1.0f / (float)n;
+  for (int i = threadIdx.x; i < D / 4; i += 256) {
+    const float4 v = reinterpret_cast<const float4*>(dout + (long long)f * D)[i];
+    reinterpret_cast<float4*>(dx + ((long long)f * n + t) * D)[i] = make_float4(v.x * inv, v.y * inv, v.z * inv, v.w * inv);
+  }
+}
+
+// fp32 -> (dropout) -> bf16 and/or fp32.   idx = row * ncols + col (same convention as the GEMM epilogue)
+__global__ __launch_bounds__(256) void cast_drop_kernel(const float* __restrict__ x, long long ldx, bf16_t* out_b, long long ldob,
+                                                        float* out_f, long long ldof, int M, int N, DropoutArg drop) {
+  const long long total4 = (long long)M * (N / 4);
+  const uint32_t seed = drop.seed_ptr ? *drop.seed_ptr : 0u;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
+    const int m = (int)(i / (N / 4)), c = (int)(i % (N / 4)) * 4;
+    float4 v = *reinterpret_cast<const float4*>(x + (long long)m * ldx + c);
+    if (drop.seed_ptr) {
+      const uint32_t base = (uint32_t)m * (uint32_t)N + (uint32_t)c;
+      v.x = mrb_keep(base, seed, drop.site, drop.thresh24) ? v.x * drop.inv_keep : 0.f;
+      v.y = mrb_keep(base + 1, seed, drop.site, drop.thresh24) ? v.y * drop.inv_keep : 0.f;
+      v.z = mrb_keep(base + 2, seed, drop.site, drop.thresh24) ? v.z * drop.inv_keep : 0.f;
+      v.w = mrb_keep(base + 3, seed, drop.site, drop.thresh24) ? v.w * drop.inv_keep : 0.f;
+    }
+    if (out_f) *reinterpret_cast<float4*>(out_f + (long long)m * ldof + c) = v;
+    if (out_b) *reinterpret_cast<uint2*>(out_b + (long long)m * ldob + c) = make_uint2(pack2bf(v.x, v.y), pack2bf(v.z, v.w));
+  }
+}
+
+// dh = dy * gelu'(h)   (Qformer.py:349-360 backward), bf16 in/out, 8 elements per thread
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ h, bf16_t* __restrict__ dh, long long n8) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+    const bf16x8 a = reinterpret_cast<const bf16x8*>(dy)[i], b = reinterpret_cast<const bf16x8*>(h)[i];
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = bf2f((bf16_t)a[j]) * gelu_erf_grad(bf2f((bf16_t)b[j]));
+    uint4 r = make_uint4(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7]));
+    reinterpret_cast<uint4*>(dh)[i] = r;
+  }
+}
+
+// gated-GELU backward (modeling_t5.py:323-329): y = drop(gelu(h0) * h1);  h = [h0 | h1] ([M, 2*Nh]), dh same layout
+__global__ __launch_bounds__(256) void gated_bwd_kernel(const bf16_t* __restrict__ dy, long long lddy, const bf16_t* __restrict__ h, long long ldh,
+                                                        bf16_t* __restrict__ dh, long long lddh, int M, int Nh, DropoutArg drop) {
+  const long long total8 = (long long)M * (Nh / 8);
+  const uint32_t seed = drop.seed_ptr ? *drop.seed_ptr : 0u;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total8; i += (long long)gridDim.x * 256) {
+    const int m = (int)(i / (Nh / 8)), c = (int)(i % (Nh / 8)) * 8;
+    const bf16x8 g = *reinterpret_cast<const bf16x8*>(dy + (long long)m * lddy + c);
+    const bf16x8 a = *reinterpret_cast<const bf16x8*>(h + (long long)m * ldh + c);
+    const bf16x8 b = *reinterpret_cast<const bf16x8*>(h + (long long)m * ldh + Nh + c);
+    float d0[8], d1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float gy = bf2f((bf16_t)g[j]);
+      if (drop.seed_ptr) gy = mrb_keep((uint32_t)m * (uint32_t)Nh + (uint32_t)(c + j), seed, drop.site, drop.thresh24) ? gy * drop.inv_keep : 0.f;
+      const float h0 = bf2f((bf16_t)a[j]), h1 = bf2f((bf16_t)b[j]);
+      d0[j] = gy * h1 * gelu_erf_grad(h0);
+      d1[j] = gy * gelu_erf(h0);
+    }
+    *reinterpret_cast<uint4*>(dh + (long long)m * lddh + c) = make_uint4(pack2bf(d0[0], d0[1]), pack2bf(d0[2], d0[3]), pack2bf(d0[4], d0[5]), pack2bf(d0[6], d0[7]));
+    *reinterpret_cast<uint4*>(dh + (long long)m * lddh + Nh + c) = make_uint4(pack2bf(d1[0], d1[1]), pack2bf(d1[2], d1[3]), pack2bf(d1[4], d1[5]), pack2bf(d1[6], d1[7]));
+  }
+}
+
+// cross entropy over fp32 logits [R,V], ignore_index = -100, mean over valid rows (modeling_t5.py:1873-1877).
+// loss += -(log softmax)[label] * inv_count ; dlogits (bf16) = (softmax - onehot) * inv_count * loss_scale.
+__global__ __launch_bounds__(1024) void ce_kernel(const float* __restrict__ logits, long long ldl, const int* __restrict__ labels, int V,
+                                                  float inv_count, float* loss, bf16_t* dlogits, long long ldd) {
+  __shared__ float red[16];
+  const int r = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const float* lr = logits + (long long)r * ldl;
+  const int label = labels[r];
+  float mx = NEG_INF_F;
+  for (int i = threadIdx.x; i < V; i += 1024) mx = fmaxf(mx, lr[i]);
+  mx = wave_max(mx);
+  if (lane == 0) red[wv] = mx;
+  __syncthreads();
+  mx = red[0];
+#pragma unroll
+  for (int i = 1; i < 16; ++i) mx = fmaxf(mx, red[i]);
+  __syncthreads();
+  float s = 0.f;
+  for (int i = threadIdx.x; i < V; i += 1024) s += __expf(lr[i] - mx);
+  s = wave_sum(s);
+  if (lane == 0) red[wv] = s;
+  __syncthreads();
+  s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) s += red[i];
+  const float lse = mx + __logf(s);
+  const bool valid = label >= 0;
+  if (threadIdx.x == 0 && valid) atomicAdd(loss, (lse - lr[label]) * inv_count);
+  if (dlogits) {
+    bf16_t* dr = dlogits + (long long)r * ldd;
+    for (int i = threadIdx.x; i < V; i += 1024) {
+      float g = 0.f;
+      if (valid) g = (__expf(lr[i] - lse) - (i == label ? 1.f : 0.f)) * inv_count;
+      dr[i] = f2bf(g);
+    }
+  }
+}
+
+// AdamW on a flat fp32 segment (torch.optim.AdamW semantics; runner_base.py:102-132).  hyper = {lr, 1/bc1, 1/sqrt(bc2), grad_scale}
+// lives in device memory so a captured graph replays with fresh values.
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                    long long n, const float* __restrict__ hyper, float beta1, float beta2, float eps, float wd) {
+  const float lr = hyper[0], ibc1 = hyper[1], isbc2 = hyper[2], gs = hyper[3];
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const float gi = g[i] * gs;
+    float pi = p[i] * (1.0f - lr * wd);
+    const float mi = beta1 * m[i] + (1.0f - beta1) * gi;
+    const float vi = beta2 * v[i] + (1.0f - beta2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) * isbc2 + eps;
+    pi -= lr * ibc1 * (mi / denom);
+    p[i] = pi;
+  }
+}
+
+__global__ void seed_bump_kernel(uint32_t* seed) { if (threadIdx.x == 0) *seed = *seed * 1664525u + 1013904223u; }
+
+// ---------------------------------------------------------------------------------------------------------
+// LoRA (peft 0.13.0 Linear, r = 8):  y = W x + scale * B (A dropout(x)).   blip2_mr.py:182-200, 236.
+// lora_down: u[m, c0..c0+7] = sum_k drop(x)[m,k] * bf16(A[r,k])      (x bf16 [M,K], A fp32 [8,K]); 4 rows per wave.
+__global__ __launch_bounds__(256) void lora_down_kernel(const bf16_t* __restrict__ x, long long ldx, const float* __restrict__ A, int M, int K,
+                                                        bf16_t* __restrict__ u, long long ldu, float scale, DropoutArg drop) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int m0 = (blockIdx.x * 4 + wv) * 4;
+  if (m0 >= M) return;
+  const uint32_t seed = drop.seed_ptr ? *drop.seed_ptr : 0u;
+  float acc[4][8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 8; ++r) acc[i][r] = 0.f;
+  for (int k = lane * 8; k < K; k += 512) {
+    float a[8][8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const float4 a0 = *reinterpret_cast<const float4*>(A + (long long)r * K + k), a1 = *reinterpret_cast<const float4*>(A + (long long)r * K + k + 4);
+      a[r][0] = bf2f(f2bf(a0.x)); a[r][1] = bf2f(f2bf(a0.y)); a[r][2] = bf2f(f2bf(a0.z)); a[r][3] = bf2f(f2bf(a0.w));
+      a[r][4] = bf2f(f2bf(a1.x)); a[r][5] = bf2f(f2bf(a1.y)); a[r][6] = bf2f(f2bf(a1.z)); a[r][7] = bf2f(f2bf(a1.w));
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + i;
+      if (m < M) {
+        const bf16x8 xv = *reinterpret_cast<const bf16x8*>(x + (long long)m * ldx + k);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float xf = bf2f((bf16_t)xv[j]);
+          if (drop.seed_ptr) xf = mrb_keep((uint32_t)m * (uint32_t)K + (uint32_t)(k + j), seed, drop.site, drop.thresh24) ? bf2f(f2bf(xf * drop.inv_keep)) : 0.f;
+#pragma unroll
+          for (int r = 0; r < 8; ++r) acc[i][r] += xf * a[r][j];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float o[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) o[r] = wave_sum(acc[i][r]) * scale;
+    if (lane == 0 && m0 + i < M)
+      *reinterpret_cast<uint4*>(u + (long long)(m0 + i) * ldu) = make_uint4(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7]));
+  }
+}
+
+// lora_dw: dW[c*sc + r*sr] += sum_m drop(Y)[m,c] * U[m,r]    (Y bf16 [M,C], U bf16 [M,8] at ldu, dW fp32)
+__global__ __launch_bounds__(256) void lora_dw_kernel(const bf16_t* __restrict__ Y, long long ldy, const bf16_t* __restrict__ U, long long ldu, int M,
+                                                      int C, int rows_per_block, float* __restrict__ dW, long long sc, long long sr, float scale, DropoutArg drop) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int mbeg = blockIdx.y * rows_per_block, mend = min(M, mbeg + rows_per_block);
+  const uint32_t seed = drop.seed_ptr ? *drop.seed_ptr : 0u;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (c < C) {
+    for (int m = mbeg; m < mend; ++m) {
+      float y = bf2f(Y[(long long)m * ldy + c]);
+      if (drop.seed_ptr) y = mrb_keep((uint32_t)m * (uint32_t)C + (uint32_t)c, seed, drop.site, drop.thresh24) ? bf2f(f2bf(y * drop.inv_keep)) : 0.f;
+      const bf16x8 uv = *reinterpret_cast<const bf16x8*>(U + (long long)m * ldu);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) acc[r] += y * bf2f((bf16_t)uv[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) atomicAdd(dW + (long long)c * sc + (long long)r * sr, acc[r] * scale);
+  }
+}
+
+// lora_dx_add: dx[m,k] += drop_mask(m,k) * sum_r G[m,r] * bf16(A[r,k])     (dx fp32 or bf16; G bf16 [M,8]; A fp32 [8,K])
+template <bool DX_F32>
+__global__ __launch_bounds__(256) void lora_dx_add_kernel(void* __restrict__ dx_, long long lddx, const bf16_t* __restrict__ G, long long ldg,
+                                                          const float* __restrict__ A, int M, int K, float scale, DropoutArg drop) {
+  const long long total4 = (long long)M * (K / 4);
+  const uint32_t seed = drop.seed_ptr ? *drop.seed_ptr : 0u;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
+    const int m = (int)(i / (K / 4)), k = (int)(i % (K / 4)) * 4;
+    const bf16x8 gv = *reinterpret_cast<const bf16x8*>(G + (long long)m * ldg);
+    float add[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const float gr = bf2f((bf16_t)gv[r]);
+      const float4 a = *reinterpret_cast<const float4*>(A + (long long)r * K + k);
+      add[0] += gr * bf2f(f2bf(a.x)); add[1] += gr * bf2f(f2bf(a.y)); add[2] += gr * bf2f(f2bf(a.z)); add[3] += gr * bf2f(f2bf(a.w));
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      add[j] *= scale;
+      if (drop.seed_ptr) add[j] = mrb_keep((uint32_t)m * (uint32_t)K + (uint32_t)(k + j), seed, drop.site, drop.thresh24) ? add[j] * drop.inv_keep : 0.f;
+    }
+    if (DX_F32) {
+      float4* p = reinterpret_cast<float4*>(reinterpret_cast<float*>(dx_) + (long long)m * lddx + k);
+      float4 v = *p;
+      v.x += add[0]; v.y += add[1]; v.z += add[2]; v.w += add[3];
+      *p = v;
+    } else {
+      uint2* p = reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(dx_) + (long long)m * lddx + k);
+      const uint2 v = *p;
+      const float x0 = bf2f((bf16_t)(v.x & 0xffff)) + add[0], x1 = bf2f((bf16_t)(v.x >> 16)) + add[1];
+      const float x2 = bf2f((bf16_t)(v.y & 0xffff)) + add[2], x3 = bf2f((bf16_t)(v.y >> 16)) + add[3];
+      *p = make_uint2(pack2bf(x0, x1), pack2bf(x2, x3));
+    }
+  }
+}
+
+// ========================================================================================================= C ABI
+static DropoutArg mk_drop(const uint32_t* seed_ptr, uint32_t site, float p) {
+  DropoutArg d;
+  d.seed_ptr = (p > 0.f) ? seed_ptr : nullptr;
+  d.site = site;
+  d.thresh24 = (uint32_t)(p * 16777216.0f + 0.5f);
+  d.inv_keep = 1.0f / (1.0f - p);
+  return d;
+}
+static int grid_for(long long work_items) { return (int)((work_items + 255) / 256 > 4096 ? 4096 : (work_items + 255) / 256 < 1 ? 1 : (work_items + 255) / 256); }
+
+extern "C" int mrblip_patchify(const float* video, void* out_bf16, int F, int IMG, int P, int Kpad, hipStream_t stream) {
+  MRB_REQUIRE(F > 0 && P > 0 && IMG % P == 0 && Kpad >= 3 * P * P && Kpad % 64 == 0, "patchify: bad shape");
+  const int G = IMG / P;
+  hipLaunchKernelGGL(patchify_kernel, dim3(G, F), dim3(256), 0, stream, video, (bf16_t*)out_bf16, IMG, P, G, Kpad);
+  return mrblip_check_launch("patchify");
+}
+extern "C" int mrblip_vit_assemble(const float* patch, const float* cls, const float* pos, float* x, int F, int NP, int D, hipStream_t stream) {
+  MRB_REQUIRE(F > 0 && NP > 0 && D % 4 == 0, "vit_assemble: bad shape");
+  hipLaunchKernelGGL(vit_assemble_kernel, dim3(NP + 1, F), dim3(256), 0, stream, patch, cls, pos, x, NP, D);
+  return mrblip_check_launch("vit_assemble");
+}
+extern "C" int mrblip_row_copy(const float* src, long long lds_, const int* src_idx, float* dst, long long ldd, const int* dst_idx, int n_rows,
+                               int D, int accumulate, hipStream_t stream) {
+  MRB_REQUIRE(n_rows >= 0 && D % 4 == 0, "row_copy: bad shape");
+  if (n_rows == 0) return MRBLIP_OK;
+  if (accumulate) hipLaunchKernelGGL(row_copy_kernel<true>, dim3(n_rows), dim3(256), 0, stream, src, lds_, src_idx, dst, ldd, dst_idx, D);
+  else hipLaunchKernelGGL(row_copy_kernel<false>, dim3(n_rows), dim3(256), 0, stream, src, lds_, src_idx, dst, ldd, dst_idx, D);
+  return mrblip_check_launch("row_copy");
+}
+extern "C" int mrblip_mean_pool(const float* x, float* out, int F, int n, int D, hipStream_t stream) {
+  MRB_REQUIRE(F > 0 && n > 0 && D % 4 == 0, "mean_pool: bad shape");
+  hipLaunchKernelGGL(mean_pool_kernel, dim3((D / 4 + 31) / 32, F), dim3(64), 0, stream, x, out, n, D);
+  return mrblip_check_launch("mean_pool");
+}
+extern "C" int mrblip_mean_pool_bwd(const float* dout, float* dx, int F, int n, int D, hipStream_t stream) {
+  MRB_REQUIRE(F > 0 && n > 0 && D % 4 == 0, "mean_pool_bwd: bad shape");
+  hipLaunchKernelGGL(mean_pool_bwd_kernel, dim3(n, F), dim3(256), 0, stream, dout, dx, n, D);
+  return mrblip_check_launch("mean_pool_bwd");
+}
+extern "C" int mrblip_cast_dropout(const float* x, long long ldx, void* out_bf16, long long ldob, float* out_f32, long long ldof, int M, int N,
+                                   const uint32_t* seed_ptr, uint32_t site, float p, hipStream_t stream) {
+  MRB_REQUIRE(M > 0 && N > 0 && N % 4 == 0, "cast_dropout: bad shape");
+  hipLaunchKernelGGL(cast_drop_kernel, dim3(grid_for((long long)M * N / 4)), dim3(256), 0, stream, x, ldx, (bf16_t*)out_bf16, ldob, out_f32, ldof, M, N, mk_drop(seed_ptr, site, p));
+  return mrblip_check_launch("cast_dropout");
+}
+extern "C" int mrblip_gelu_bwd(const void* dy, const void* h, void* dh, long long n, hipStream_t stream) {
+  MRB_REQUIRE(n > 0 && n % 8 == 0, "gelu_bwd: n %% 8 != 0");
+  hipLaunchKernelGGL(gelu_bwd_kernel, dim3(grid_for(n / 8)), dim3(256), 0, stream, (const bf16_t*)dy, (const bf16_t*)h, (bf16_t*)dh, n / 8);
+  return mrblip_check_launch("gelu_bwd");
+}
+extern "C" int mrblip_gated_gelu_bwd(const void* dy, long long lddy, const void* h, long long ldh, void* dh, long long lddh, int M, int Nh,
+                                     const uint32_t* seed_ptr, uint32_t site, float p, hipStream_t stream) {
+  MRB_REQUIRE(M > 0 && Nh > 0 && Nh % 8 == 0, "gated_gelu_bwd: bad shape");
+  hipLaunchKernelGGL(gated_bwd_kernel, dim3(grid_for((long long)M * Nh / 8)), dim3(256), 0, stream, (const bf16_t*)dy, lddy, (const bf16_t*)h, ldh, (bf16_t*)dh, lddh, M, Nh, mk_drop(seed_ptr, site, p));
+  return mrblip_check_launch("gated_gelu_bwd");
+}
+extern "C" int mrblip_cross_entropy(const float* logits, long long ldl, const int* labels, int R, int V, float inv_count, float* loss,
+                                    void* dlogits_bf16, long long ldd, hipStream_t stream) {
+  MRB_REQUIRE(R > 0 && V > 0, "cross_entropy: bad shape");
+  hipLaunchKernelGGL(ce_kernel, dim3(R), dim3(1024), 0, stream, logits, ldl, labels, V, inv_count, loss, (bf16_t*)dlogits_bf16, ldd);
+  return mrblip_check_launch("cross_entropy");
+}
+extern "C" int mrblip_adamw(float* p, const float* g, float* m, float* v, long long n, const float* hyper, float beta1, float beta2, float eps,
+                            float weight_decay, hipStream_t stream) {
+  if (n <= 0) return MRBLIP_OK;
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n)), dim3(256), 0, stream, p, g, m, v, n, hyper, beta1, beta2, eps, weight_decay);
+  return mrblip_check_launch("adamw");
+}
+extern "C" int mrblip_seed_bump(uint32_t* seed, hipStream_t stream) {
+  hipLaunchKernelGGL(seed_bump_kernel, dim3(1), dim3(64), 0, stream, seed);
+  return mrblip_check_launch("seed_bump");
+}
+extern "C" int mrblip_lora_down(const void* x, long long ldx, const float* A, int M, int K, void* u, long long ldu, float scale,
+                                const uint32_t* seed_ptr, uint32_t site, float p, hipStream_t stream) {
+  MRB_REQUIRE(M > 0 && K > 0 && K % 8 == 0 && ldx % 8 == 0 && ldu % 8 == 0, "lora_down: bad shape");
+  hipLaunchKernelGGL(lora_down_kernel, dim3((M + 15) / 16), dim3(256), 0, stream, (const bf16_t*)x, ldx, A, M, K, (bf16_t*)u, ldu, scale, mk_drop(seed_ptr, site, p));
+  return mrblip_check_launch("lora_down");
+}
+extern "C" int mrblip_lora_dw(const void* Y, long long ldy, const void* U, long long ldu, int M, int C, float* dW, long long sc, long long sr,
+                              float scale, const uint32_t* seed_ptr, uint32_t site, float p, hipStream_t stream) {
+  MRB_REQUIRE(M > 0 && C > 0 && ldu % 8 == 0, "lora_dw: bad shape");
+  const int rpb = 128;
+  hipLaunchKernelGGL(lora_dw_kernel, dim3((C + 255) / 256, (M + rpb - 1) / rpb), dim3(256), 0, stream, (const bf16_t*)Y, ldy, (const bf16_t*)U, ldu, M, C, rpb, dW, sc, sr, scale, mk_drop(seed_ptr, site, p));
+  return mrblip_check_launch("lora_dw");
+}
+extern "C" int mrblip_lora_dx_add(void* dx, long long lddx, int dx_f32, const void* G, long long ldg, const float* A, int M, int K, float scale,
+                                  const uint32_t* seed_ptr, uint32_t site, float p, hipStream_t stream) {
+  MRB_REQUIRE(M > 0 && K > 0 && K % 4 == 0 && ldg % 8 == 0, "lora_dx_add: bad shape");
+  if (dx_f32) hipLaunchKernelGGL(lora_dx_add_kernel<true>, dim3(grid_for((long long)M * K / 4)), dim3(256), 0, stream, dx, lddx, (const bf16_t*)G, ldg, A, M, K, scale, mk_drop(seed_ptr, site, p));
+  else hipLaunchKernelGGL(lora_dx_add_kernel<false>, dim3(grid_for((long long)M * K / 4)), dim3(256), 0, stream, dx, lddx, (const bf16_t*)G, ldg, A, M, K, scale, mk_drop(seed_ptr, site, p));
+  return mrblip_check_launch("lora_dx_add");
+}

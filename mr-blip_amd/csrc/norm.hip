@@ -1,0 +1,197 @@
+// Fused LayerNorm / T5 RMSNorm, forward and backward, fp32 statistics (HBM-bound row kernels).
+// One wave owns one row (D <= 2048, D % 4 == 0), the row lives in registers between the passes, so every
+// row is read once and written once.
+//
+// Reference call sites: eva_vit.py:157,163 (norm1/norm2, eps 1e-6), blip2.py:113-119 (ln_vision, fp32),
+// Qformer.py:104-107, 285-289, 372-375 (post-LN, eps 1e-12), modeling_t5.py:254-277 (T5LayerNorm = RMS).
+#include "common.h"
+
+#define NORM_MAXV 8  // float4 per lane -> D <= 64*4*8 = 2048
+
+template <bool RMS>
+__global__ __launch_bounds__(256) void norm_fwd_kernel(const float* __restrict__ x, long long ldx, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, int M, int D, float eps, bf16_t* out_b,
+                                                       long long ldob, float* out_f, long long ldof) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int nv = D >> 2;
+  for (int row = blockIdx.x * 4 + wv; row < M; row += gridDim.x * 4) {
+    const float4* xr = reinterpret_cast<const float4*>(x + (long long)row * ldx);
+    float4 v[NORM_MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NORM_MAXV; ++j) {
+      const int i = lane + 64 * j;
+      v[j] = (i < nv) ? xr[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (!RMS) s += v[j].x + v[j].y + v[j].z + v[j].w;
+    }
+    float mean = 0.f;
+    if (!RMS) mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NORM_MAXV; ++j) {
+      const int i = lane + 64 * j;
+      if (i < nv) {
+        const float a = v[j].x - mean, b = v[j].y - mean, c = v[j].z - mean, d = v[j].w - mean;
+        q += a * a + b * b + c * c + d * d;
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+#pragma unroll
+    for (int j = 0; j < NORM_MAXV; ++j) {
+      const int i = lane + 64 * j;
+      if (i < nv) {
+        const float4 g = reinterpret_cast<const float4*>(gamma)[i];
+        float4 o;
+        o.x = (v[j].x - mean) * rstd * g.x; o.y = (v[j].y - mean) * rstd * g.y;
+        o.z = (v[j].z - mean) * rstd * g.z; o.w = (v[j].w - mean) * rstd * g.w;
+        if (!RMS && beta) {
+          const float4 b = reinterpret_cast<const float4*>(beta)[i];
+          o.x += b.x; o.y += b.y; o.z += b.z; o.w += b.w;
+        }
+        if (out_f) reinterpret_cast<float4*>(out_f + (long long)row * ldof)[i] = o;
+        if (out_b) reinterpret_cast<uint2*>(out_b + (long long)row * ldob)[i] = make_uint2(pack2bf(o.x, o.y), pack2bf(o.z, o.w));
+      }
+    }
+  }
+}
+
+// dx = dx_add + rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma   (RMS: no mean(g) term, xhat = x*rstd)
+// dgamma += sum_rows dy * xhat, dbeta += sum_rows dy  (optional, fp32 atomics, one per column per block)
+template <bool RMS>
+__global__ __launch_bounds__(256) void norm_bwd_kernel(const float* __restrict__ dy, long long lddy, const float* __restrict__ x,
+                                                       long long ldx, const float* __restrict__ gamma, int M, int D, float eps,
+                                                       const float* dx_add, long long ldadd, float* dx, long long lddx,
+                                                       float* dgamma, float* dbeta) {
+  __shared__ float red[2][4][64 * 4];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int nv = D >> 2;
+  float4 ag[NORM_MAXV], ab[NORM_MAXV];
+  const bool want_dw = dgamma != nullptr;
+  if (want_dw) {
+#pragma unroll
+    for (int j = 0; j < NORM_MAXV; ++j) ag[j] = ab[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  for (int row = blockIdx.x * 4 + wv; row < M; row += gridDim.x * 4) {
+    const float4* xr = reinterpret_cast<const float4*>(x + (long long)row * ldx);
+    const float4* dr = reinterpret_cast<const float4*>(dy + (long long)row * lddy);
+    float4 v[NORM_MAXV], g[NORM_MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NORM_MAXV; ++j) {
+      const int i = lane + 64 * j;
+      v[j] = (i < nv) ? xr[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      g[j] = (i < nv) ? dr[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (!RMS) s += v[j].x + v[j].y + v[j].z + v[j].w;
+    }
+    float mean = 0.f;
+    if (!RMS) mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NORM_MAXV; ++j) {
+      const int i = lane + 64 * j;
+      if (i < nv) {
+        v[j].x -= mean; v[j].y -= mean; v[j].z -= mean; v[j].w -= mean;
+        q += v[j].x * v[j].x + v[j].y * v[j].y + v[j].z * v[j].z + v[j].w * v[j].w;
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+    float sg = 0.f, sgx = 0.f;
+#pragma unroll
+    for (int j = 0; j < NORM_MAXV; ++j) {
+      const int i = lane + 64 * j;
+      if (i < nv) {
+        v[j].x *= rstd; v[j].y *= rstd; v[j].z *= rstd; v[j].w *= rstd;  // xhat
+        if (want_dw) {
+          ag[j].x += g[j].x * v[j].x; ag[j].y += g[j].y * v[j].y; ag[j].z += g[j].z * v[j].z; ag[j].w += g[j].w * v[j].w;
+          ab[j].x += g[j].x; ab[j].y += g[j].y; ab[j].z += g[j].z; ab[j].w += g[j].w;
+        }
+        const float4 w = reinterpret_cast<const float4*>(gamma)[i];
+        g[j].x *= w.x; g[j].y *= w.y; g[j].z *= w.z; g[j].w *= w.w;
+        sg += g[j].x + g[j].y + g[j].z + g[j].w;
+        sgx += g[j].x * v[j].x + g[j].y * v[j].y + g[j].z * v[j].z + g[j].w * v[j].w;
+      }
+    }
+    const float mg = RMS ? 0.f : wave_sum(sg) / (float)D;
+    const float mgx = wave_sum(sgx) / (float)D;
+#pragma unroll
+    for (int j = 0; j < NORM_MAXV; ++j) {
+      const int i = lane + 64 * j;
+      if (i < nv) {
+        float4 o;
+        o.x = rstd * (g[j].x - mg - v[j].x * mgx); o.y = rstd * (g[j].y - mg - v[j].y * mgx);
+        o.z = rstd * (g[j].z - mg - v[j].z * mgx); o.w = rstd * (g[j].w - mg - v[j].w * mgx);
+        if (dx_add) {
+          const float4 a = reinterpret_cast<const float4*>(dx_add + (long long)row * ldadd)[i];
+          o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+        }
+        reinterpret_cast<float4*>(dx + (long long)row * lddx)[i] = o;
+      }
+    }
+  }
+  if (want_dw) {
+    // reduce the 4 waves of the block through LDS, then one atomic per column
+#pragma unroll
+    for (int j = 0; j < NORM_MAXV; ++j) {
+      if (64 * j >= nv) break;  // uniform
+      float* r0 = &red[0][wv][lane * 4];
+      float* r1 = &red[1][wv][lane * 4];
+      r0[0] = ag[j].x; r0[1] = ag[j].y; r0[2] = ag[j].z; r0[3] = ag[j].w;
+      r1[0] = ab[j].x; r1[1] = ab[j].y; r1[2] = ab[j].z; r1[3] = ab[j].w;
+      __syncthreads();
+      if (wv == 0) {
+        const int i = lane + 64 * j;
+        if (i < nv) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const float sgm = red[0][0][lane * 4 + c] + red[0][1][lane * 4 + c] + red[0][2][lane * 4 + c] + red[0][3][lane * 4 + c];
+            const float sbt = red[1][0][lane * 4 + c] + red[1][1][lane * 4 + c] + red[1][2][lane * 4 + c] + red[1][3][lane * 4 + c];
+            atomicAdd(dgamma + i * 4 + c, sgm);
+            if (dbeta) atomicAdd(dbeta + i * 4 + c, sbt);
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+static int norm_check(int M, int D, const void* x, long long ldx) {
+  MRB_REQUIRE(M > 0 && D > 0 && D <= 2048 && (D % 4) == 0, "norm: need 0 < D <= 2048, D %% 4 == 0 (M=%d D=%d)", M, D);
+  MRB_REQUIRE(((uintptr_t)x % 16) == 0 && (ldx % 4) == 0, "norm: input must be 16-B aligned");
+  return MRBLIP_OK;
+}
+
+extern "C" int mrblip_layernorm_fwd(const float* x, long long ldx, const float* gamma, const float* beta, int M, int D, float eps,
+                                    void* out_bf16, long long ldob, float* out_f32, long long ldof, hipStream_t stream) {
+  if (int e = norm_check(M, D, x, ldx)) return e;
+  MRB_REQUIRE(out_bf16 || out_f32, "layernorm_fwd: no output");
+  const int grid = min((M + 3) / 4, 2048);
+  hipLaunchKernelGGL(norm_fwd_kernel<false>, dim3(grid), dim3(256), 0, stream, x, ldx, gamma, beta, M, D, eps, (bf16_t*)out_bf16, ldob, out_f32, ldof);
+  return mrblip_check_launch("layernorm_fwd");
+}
+
+extern "C" int mrblip_rmsnorm_fwd(const float* x, long long ldx, const float* weight, int M, int D, float eps, void* out_bf16,
+                                  long long ldob, float* out_f32, long long ldof, hipStream_t stream) {
+  if (int e = norm_check(M, D, x, ldx)) return e;
+  MRB_REQUIRE(out_bf16 || out_f32, "rmsnorm_fwd: no output");
+  const int grid = min((M + 3) / 4, 2048);
+  hipLaunchKernelGGL(norm_fwd_kernel<true>, dim3(grid), dim3(256), 0, stream, x, ldx, weight, (const float*)nullptr, M, D, eps, (bf16_t*)out_bf16, ldob, out_f32, ldof);
+  return mrblip_check_launch("rmsnorm_fwd");
+}
+
+extern "C" int mrblip_layernorm_bwd(const float* dy, long long lddy, const float* x, long long ldx, const float* gamma, int M, int D,
+                                    float eps, const float* dx_add, long long ldadd, float* dx, long long lddx, float* dgamma,
+                                    float* dbeta, hipStream_t stream) {
+  if (int e = norm_check(M, D, x, ldx)) return e;
+  const int grid = min((M + 3) / 4, dgamma ? 512 : 2048);
+  hipLaunchKernelGGL(norm_bwd_kernel<false>, dim3(grid), dim3(256), 0, stream, dy, lddy, x, ldx, gamma, M, D, eps, dx_add, ldadd, dx, lddx, dgamma, dbeta);
+  return mrblip_check_launch("layernorm_bwd");
+}
+
+extern "C" int mrblip_rmsnorm_bwd(const float* dy, long long lddy, const float* x, long long ldx, const float* weight, int M, int D,
+                                  float eps, const float* dx_add, long long ldadd, float* dx, long long lddx, hipStream_t stream) {
+  if (int e = norm_check(M, D, x, ldx)) return e;
+  const int grid = min((M + 3) / 4, 2048);
+  hipLaunchKernelGGL(norm_bwd_kernel<true>, dim3(grid), dim3(256), 0, stream, dy, lddy, x, ldx, weight, M, D, eps, dx_add, ldadd, dx, lddx, (float*)nullptr, (float*)nullptr);
+  return mrblip_check_launch("rmsnorm_bwd");
+}

@@ -1,0 +1,265 @@
+"""ctypes bindings of ``libmrblip_hip.so`` (include/mrblip_hip.h) over torch device tensors.
+
+PyTorch is plumbing here (device memory, streams); every op below launches a hand-written gfx950 kernel on the
+current torch stream.  There is NO fallback: if the library is missing the import fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libmrblip_hip.so")
+
+
+class MrblipError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise MrblipError(
+            f"{LIB_PATH} not found: build it with `python mr-blip_amd/csrc/build.py` (hipcc --offload-arch=gfx950). "
+            "The HIP extension is the product; there is no CPU/PyTorch fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    lib.mrblip_last_error.restype = C.c_char_p
+    return lib
+
+
+_lib = _load()
+
+vp, ll, i32, u32, f32 = C.c_void_p, C.c_longlong, C.c_int, C.c_uint32, C.c_float
+
+
+def _sig(name, *argtypes):
+    fn = getattr(_lib, name)
+    fn.argtypes = list(argtypes)
+    fn.restype = i32
+    return fn
+
+
+_gemm = _sig("mrblip_gemm_bf16", vp, ll, vp, ll, vp, ll, vp, ll, i32, i32, i32, vp, ll, i32, vp, ll, vp, vp, ll, i32, i32, vp, u32, f32, i32, vp)
+_ln_fwd = _sig("mrblip_layernorm_fwd", vp, ll, vp, vp, i32, i32, f32, vp, ll, vp, ll, vp)
+_rms_fwd = _sig("mrblip_rmsnorm_fwd", vp, ll, vp, i32, i32, f32, vp, ll, vp, ll, vp)
+_ln_bwd = _sig("mrblip_layernorm_bwd", vp, ll, vp, ll, vp, i32, i32, f32, vp, ll, vp, ll, vp, vp, vp)
+_rms_bwd = _sig("mrblip_rmsnorm_bwd", vp, ll, vp, ll, vp, i32, i32, f32, vp, ll, vp, ll, vp)
+_attn_fwd = _sig("mrblip_attention_fwd", vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp, vp, i32, vp, u32, f32, vp)
+_attn_bwd = _sig("mrblip_attention_bwd", vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
+                 i32, i32, i32, i32, i32, f32, vp, vp, i32, vp, u32, f32, vp)
+_head_t = _sig("mrblip_head_transpose", vp, vp, vp, i32, i32, i32, i32, vp)
+_patchify = _sig("mrblip_patchify", vp, vp, i32, i32, i32, i32, vp)
+_vit_asm = _sig("mrblip_vit_assemble", vp, vp, vp, vp, i32, i32, i32, vp)
+_row_copy = _sig("mrblip_row_copy", vp, ll, vp, vp, ll, vp, i32, i32, i32, vp)
+_mean_pool = _sig("mrblip_mean_pool", vp, vp, i32, i32, i32, vp)
+_mean_pool_bwd = _sig("mrblip_mean_pool_bwd", vp, vp, i32, i32, i32, vp)
+_cast_drop = _sig("mrblip_cast_dropout", vp, ll, vp, ll, vp, ll, i32, i32, vp, u32, f32, vp)
+_gelu_bwd = _sig("mrblip_gelu_bwd", vp, vp, vp, ll, vp)
+_gated_bwd = _sig("mrblip_gated_gelu_bwd", vp, ll, vp, ll, vp, ll, i32, i32, vp, u32, f32, vp)
+_ce = _sig("mrblip_cross_entropy", vp, ll, vp, i32, i32, f32, vp, vp, ll, vp)
+_adamw = _sig("mrblip_adamw", vp, vp, vp, vp, ll, vp, f32, f32, f32, f32, vp)
+_seed_bump = _sig("mrblip_seed_bump", vp, vp)
+_lora_down = _sig("mrblip_lora_down", vp, ll, vp, i32, i32, vp, ll, f32, vp, u32, f32, vp)
+_lora_dw = _sig("mrblip_lora_dw", vp, ll, vp, ll, i32, i32, vp, ll, ll, f32, vp, u32, f32, vp)
+_lora_dx = _sig("mrblip_lora_dx_add", vp, ll, i32, vp, ll, vp, i32, i32, f32, vp, u32, f32, vp)
+
+EXPORTS = [
+    "mrblip_last_error", "mrblip_abi_version", "mrblip_gemm_bf16", "mrblip_layernorm_fwd", "mrblip_rmsnorm_fwd",
+    "mrblip_layernorm_bwd", "mrblip_rmsnorm_bwd", "mrblip_attention_fwd", "mrblip_attention_bwd", "mrblip_head_transpose",
+    "mrblip_patchify", "mrblip_vit_assemble", "mrblip_row_copy", "mrblip_mean_pool", "mrblip_mean_pool_bwd",
+    "mrblip_cast_dropout", "mrblip_gelu_bwd", "mrblip_gated_gelu_bwd", "mrblip_cross_entropy", "mrblip_adamw",
+    "mrblip_seed_bump", "mrblip_lora_down", "mrblip_lora_dw", "mrblip_lora_dx_add",
+]
+
+
+def _chk(rc: int):
+    if rc != 0:
+        raise MrblipError(_lib.mrblip_last_error().decode())
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _ld(t: Optional[torch.Tensor]) -> int:
+    return 0 if t is None else t.stride(0)
+
+
+def _req(t, dtype, name):
+    if t.dtype != dtype or not t.is_cuda or t.stride(-1) != 1:
+        raise MrblipError(f"{name}: expected a cuda {dtype} tensor contiguous in its last dim, got {t.dtype} {tuple(t.shape)} {t.stride()}")
+
+
+class Dropout:
+    """(seed tensor on device, call-site id, p).  ``None`` disables dropout."""
+
+    __slots__ = ("seed", "site", "p")
+
+    def __init__(self, seed: torch.Tensor, site: int, p: float):
+        self.seed, self.site, self.p = seed, site & 0xFFFFFFFF, float(p)
+
+
+def _d(d: Optional[Dropout]):
+    if d is None or d.p <= 0.0:
+        return None, 0, 0.0
+    return d.seed.data_ptr(), d.site, d.p
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, aext=None, wext=None, out2=None, bias=None, residual=None,
+         act: int = 0, gated: bool = False, drop: Optional[Dropout] = None, tile_cfg: int = 0, K: Optional[int] = None):
+    """out[M,N] = a[M,K] @ w[N,K]^T (+ aext @ wext^T) with the fused epilogue of mrblip_gemm_bf16."""
+    _req(a, torch.bfloat16, "gemm.a"); _req(w, torch.bfloat16, "gemm.w")
+    M = a.shape[0]
+    N = w.shape[0]
+    K = a.shape[1] if K is None else K
+    sp, site, p = _d(drop)
+    _chk(_gemm(_p(a), _ld(a), _p(w), _ld(w), _p(aext), _ld(aext), _p(wext), _ld(wext), M, N, K, _p(out), _ld(out),
+               1 if out.dtype == torch.float32 else 0, _p(out2), _ld(out2), _p(bias), _p(residual), _ld(residual), act,
+               1 if gated else 0, sp, site, p, tile_cfg, _stream()))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ norms
+def layernorm_fwd(x, gamma, beta, eps, out_bf16=None, out_f32=None):
+    _req(x, torch.float32, "layernorm.x")
+    M, D = x.shape
+    _chk(_ln_fwd(_p(x), _ld(x), _p(gamma), _p(beta), M, D, eps, _p(out_bf16), _ld(out_bf16), _p(out_f32), _ld(out_f32), _stream()))
+
+
+def rmsnorm_fwd(x, weight, eps, out_bf16=None, out_f32=None):
+    _req(x, torch.float32, "rmsnorm.x")
+    M, D = x.shape
+    _chk(_rms_fwd(_p(x), _ld(x), _p(weight), M, D, eps, _p(out_bf16), _ld(out_bf16), _p(out_f32), _ld(out_f32), _stream()))
+
+
+def layernorm_bwd(dy, x, gamma, eps, dx, dx_add=None, dgamma=None, dbeta=None):
+    M, D = x.shape
+    _chk(_ln_bwd(_p(dy), _ld(dy), _p(x), _ld(x), _p(gamma), M, D, eps, _p(dx_add), _ld(dx_add), _p(dx), _ld(dx), _p(dgamma), _p(dbeta), _stream()))
+
+
+def rmsnorm_bwd(dy, x, weight, eps, dx, dx_add=None):
+    M, D = x.shape
+    _chk(_rms_bwd(_p(dy), _ld(dy), _p(x), _ld(x), _p(weight), M, D, eps, _p(dx_add), _ld(dx_add), _p(dx), _ld(dx), _stream()))
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def _strides3(t: torch.Tensor):
+    """t viewed as [B, S, H, D] (any strides, D contiguous) -> ctypes {batch, head, row} strides."""
+    assert t.dim() == 4 and t.stride(3) == 1
+    return (ll * 3)(t.stride(0), t.stride(2), t.stride(1))
+
+
+def rup32(n: int) -> int:
+    return (n + 31) // 32 * 32
+
+
+def head_transpose(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x: [B,S,H,D] view (bf16) -> [B,H,rup32(D),rup32(S)] zero-padded transposed copy."""
+    _req(x, torch.bfloat16, "head_transpose.x")
+    B, S, H, D = x.shape
+    if out is None:
+        out = torch.empty(B, H, rup32(D), rup32(S), dtype=torch.bfloat16, device=x.device)
+    _chk(_head_t(_p(x), _strides3(x), _p(out), B, H, S, D, _stream()))
+    return out
+
+
+def attention_fwd(q, k, vt, o, lse=None, *, scale=1.0, bias_lut=None, kmask=None, causal=False, drop: Optional[Dropout] = None):
+    """q,o: [B,Sq,H,D] views; k: [B,Sk,H,D] view; vt: head_transpose(v); lse: [B,H,rup32(Sq)] fp32."""
+    B, Sq, H, D = q.shape
+    Sk = k.shape[1]
+    sp, site, p = _d(drop)
+    _chk(_attn_fwd(_p(q), _strides3(q), _p(k), _strides3(k), _p(vt), _p(o), _strides3(o), _p(lse), B, H, Sq, Sk, D, scale,
+                   _p(bias_lut), _p(kmask), 1 if causal else 0, sp, site, p, _stream()))
+
+
+def attention_bwd(q, k, v, o, do, kt, qt, dot, lse, delta, dq, dk, dv, *, scale=1.0, bias_lut=None, kmask=None, causal=False,
+                  drop: Optional[Dropout] = None):
+    B, Sq, H, D = q.shape
+    Sk = k.shape[1]
+    sp, site, p = _d(drop)
+    _chk(_attn_bwd(_p(q), _strides3(q), _p(k), _strides3(k), _p(v), _strides3(v), _p(o), _strides3(o), _p(do), _strides3(do),
+                   _p(kt), _p(qt), _p(dot), _p(lse), _p(delta), _p(dq), _strides3(dq), _p(dk), _strides3(dk), _p(dv), _strides3(dv),
+                   B, H, Sq, Sk, D, scale, _p(bias_lut), _p(kmask), 1 if causal else 0, sp, site, p, _stream()))
+
+
+# ------------------------------------------------------------------------------------------------ side kernels
+def patchify(video: torch.Tensor, out: torch.Tensor, patch: int):
+    F_, _, IMG, _ = video.shape
+    _chk(_patchify(_p(video), _p(out), F_, IMG, patch, out.shape[1], _stream()))
+
+
+def vit_assemble(patch, cls, pos, x):
+    F_, T, D = x.shape
+    _chk(_vit_asm(_p(patch), _p(cls), _p(pos), _p(x), F_, T - 1, D, _stream()))
+
+
+def row_copy(src, src_idx, dst, dst_idx, accumulate=False):
+    n = src_idx.numel()
+    _chk(_row_copy(_p(src), _ld(src), _p(src_idx), _p(dst), _ld(dst), _p(dst_idx), n, src.shape[1], 1 if accumulate else 0, _stream()))
+
+
+def mean_pool(x, out):
+    F_, n, D = x.shape
+    _chk(_mean_pool(_p(x), _p(out), F_, n, D, _stream()))
+
+
+def mean_pool_bwd(dout, dx):
+    F_, n, D = dx.shape
+    _chk(_mean_pool_bwd(_p(dout), _p(dx), F_, n, D, _stream()))
+
+
+def cast_dropout(x, out_bf16=None, out_f32=None, drop: Optional[Dropout] = None):
+    M, N = x.shape
+    sp, site, p = _d(drop)
+    _chk(_cast_drop(_p(x), _ld(x), _p(out_bf16), _ld(out_bf16), _p(out_f32), _ld(out_f32), M, N, sp, site, p, _stream()))
+
+
+def gelu_bwd(dy, h, dh):
+    _chk(_gelu_bwd(_p(dy), _p(h), _p(dh), dy.numel(), _stream()))
+
+
+def gated_gelu_bwd(dy, h, dh, drop: Optional[Dropout] = None):
+    M, Nh = dy.shape
+    sp, site, p = _d(drop)
+    _chk(_gated_bwd(_p(dy), _ld(dy), _p(h), _ld(h), _p(dh), _ld(dh), M, Nh, sp, site, p, _stream()))
+
+
+def cross_entropy(logits, labels_i32, inv_count, loss, dlogits=None):
+    R, V = logits.shape
+    _chk(_ce(_p(logits), _ld(logits), _p(labels_i32), R, V, inv_count, _p(loss), _p(dlogits), _ld(dlogits), _stream()))
+
+
+def adamw(p, g, m, v, hyper, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0):
+    _chk(_adamw(_p(p), _p(g), _p(m), _p(v), p.numel(), _p(hyper), beta1, beta2, eps, weight_decay, _stream()))
+
+
+def seed_bump(seed):
+    _chk(_seed_bump(_p(seed), _stream()))
+
+
+def lora_down(x, A, u, scale=1.0, drop: Optional[Dropout] = None):
+    """u[:, :8] = drop(x) @ bf16(A)^T * scale;  x bf16 [M,K], A fp32 [8,K], u: bf16 view whose first 8 columns are written."""
+    M, K = x.shape
+    sp, site, p = _d(drop)
+    _chk(_lora_down(_p(x), _ld(x), _p(A), M, K, _p(u), _ld(u), scale, sp, site, p, _stream()))
+
+
+def lora_dw(Y, U, dW, sc, sr, scale=1.0, drop: Optional[Dropout] = None):
+    """dW[c*sc + r*sr] += sum_m drop(Y)[m,c] * U[m,r]"""
+    M, Cc = Y.shape
+    sp, site, p = _d(drop)
+    _chk(_lora_dw(_p(Y), _ld(Y), _p(U), _ld(U), M, Cc, _p(dW), sc, sr, scale, sp, site, p, _stream()))
+
+
+def lora_dx_add(dx, G, A, scale=1.0, drop: Optional[Dropout] = None):
+    M, K = dx.shape
+    sp, site, p = _d(drop)
+    _chk(_lora_dx(_p(dx), _ld(dx), 1 if dx.dtype == torch.float32 else 0, _p(G), _ld(G), _p(A), M, K, scale, sp, site, p, _stream()))

@@ -391,3 +391,32 @@ class Oracle:
         labels = ans.input_ids.masked_fill(ans.input_ids == tok.pad_token_id, -100)
         loss, logits, enc = self.t5_loss(embs, atts, labels, ans.attention_mask)
         return dict(loss=loss, logits=logits, inputs_embs=embs, inputs_atts=atts, labels=labels, enc=enc, frames=f)
+
+
+# ====================================================================================== dropout mask restatement
+def _u32(x):
+    return x & 0xFFFFFFFF
+
+
+def dropout_hash(idx: Tensor, seed: int, site: int) -> Tensor:
+    """Restates csrc/common.h mrb_hash (uint32 arithmetic emulated in int64).  idx: int64 tensor of element indices."""
+    idx = idx.to(torch.int64)
+    h = _u32(idx ^ _u32(torch.tensor(seed, dtype=torch.int64) * 0x9E3779B1))
+    h = _u32(h * 0x85EBCA77)
+    h = h ^ (h >> 15)
+    h = _u32(h + _u32(site * 0xC2B2AE3D + 0x27D4EB2F))
+    h = _u32(h * 0x9E3779B1)
+    h = h ^ (h >> 13)
+    h = _u32(h * 0xC2B2AE3D)
+    h = h ^ (h >> 16)
+    return h
+
+
+def dropout_keep(shape, seed: int, site: int, p: float) -> Tensor:
+    """keep mask (float 0/1) of an element-indexed dropout site: idx = flat row-major index mod 2^32."""
+    n = 1
+    for s in shape:
+        n *= s
+    idx = torch.arange(n, dtype=torch.int64) & 0xFFFFFFFF
+    thresh = int(p * 16777216.0 + 0.5)
+    return ((dropout_hash(idx, seed, site) >> 8) >= thresh).reshape(shape).float()

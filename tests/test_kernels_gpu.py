@@ -1,0 +1,331 @@
+"""Per-kernel parity tests of libmrblip_hip.so, called through the C ABI (ctypes, mrblip.ops) on a real MI355X,
+against plain PyTorch fp32 references of the same op evaluated on the same bf16-rounded operands, plus the
+oracle's restatement of the dropout hash.  Tolerances are stated per test.
+"""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from mrblip import ops as _ops
+
+    return _ops
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rel(a, b):
+    a, b = a.double(), b.double()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def bf(x):
+    return x.bfloat16()
+
+
+def keep_mask(shape, seed, site, p):
+    from oracle.mrblip_oracle import dropout_keep
+
+    return dropout_keep(shape, seed, site, p).to(dev())
+
+
+@pytest.mark.parametrize("cfg", [1, 2, 3])
+@pytest.mark.parametrize("M,N,K", [(300, 264, 128), (64, 520, 192), (513, 1408, 576)])
+def test_gemm_plain(ops, cfg, M, N, K):
+    torch.manual_seed(0)
+    a = bf(torch.randn(M, K, device=dev()))
+    w = bf(torch.randn(N, K, device=dev()) * 0.1)
+    ref = a.float() @ w.float().t()
+    for dt in (torch.float32, torch.bfloat16):
+        out = torch.full((M, N), float("nan"), dtype=dt, device=dev())
+        ops.gemm(a, w, out, tile_cfg=cfg)
+        tol = 2e-6 if dt == torch.float32 else 3e-3  # fp32 accumulate; bf16 output rounding
+        assert rel(out.float(), ref) < tol, (cfg, dt)
+
+
+@pytest.mark.parametrize("cfg", [1, 2, 3])
+def test_gemm_epilogues(ops, cfg):
+    torch.manual_seed(1)
+    M, N, K = 200, 328, 256
+    a = bf(torch.randn(M, K, device=dev()))
+    w = bf(torch.randn(N, K, device=dev()) * 0.1)
+    ae = bf(torch.randn(M, 64, device=dev()))
+    we = bf(torch.randn(N, 64, device=dev()) * 0.1)
+    bias = torch.randn(N, device=dev())
+    res = torch.randn(M, N, device=dev())
+    base = a.float() @ w.float().t() + ae.float() @ we.float().t() + bias
+    # bias + K-extension + gelu + pre-activation copy
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=dev())
+    pre = torch.empty(M, N, dtype=torch.bfloat16, device=dev())
+    ops.gemm(a, w, out, aext=ae, wext=we, bias=bias, act=1, out2=pre, tile_cfg=cfg)
+    assert rel(pre.float(), base) < 3e-3
+    assert rel(out.float(), torch.nn.functional.gelu(base)) < 3e-3
+    # residual + dropout, fp32 out (in place on the residual stream)
+    seed = torch.tensor([1234567], dtype=torch.int32, device=dev())
+    x = res.clone()
+    ops.gemm(a, w, x, aext=ae, wext=we, bias=bias, residual=x, drop=ops.Dropout(seed, 17, 0.1), tile_cfg=cfg)
+    mask = keep_mask((M, N), 1234567, 17, 0.1)
+    assert 0.85 < mask.mean().item() < 0.95
+    assert rel(x, res + base * mask / 0.9) < 2e-6
+
+
+@pytest.mark.parametrize("cfg", [1, 2])
+def test_gemm_gated(ops, cfg):
+    torch.manual_seed(2)
+    M, Nh, K = 300, 200, 128
+    a = bf(torch.randn(M, K, device=dev()))
+    w = bf(torch.randn(2 * Nh, K, device=dev()) * 0.1)
+    y = torch.empty(M, Nh, dtype=torch.bfloat16, device=dev())
+    h = torch.empty(M, 2 * Nh, dtype=torch.bfloat16, device=dev())
+    seed = torch.tensor([99], dtype=torch.int32, device=dev())
+    ops.gemm(a, w, y, out2=h, gated=True, drop=ops.Dropout(seed, 3, 0.1), tile_cfg=cfg)
+    hr = a.float() @ w.float().t()
+    assert rel(h.float(), hr) < 3e-3
+    mask = keep_mask((M, Nh), 99, 3, 0.1)
+    ref = torch.nn.functional.gelu(hr[:, :Nh]) * hr[:, Nh:] * mask / 0.9
+    assert rel(y.float(), ref) < 4e-3
+    # backward kernel against autograd on the saved bf16 pre-activations
+    dy = bf(torch.randn(M, Nh, device=dev()))
+    dh = torch.empty(M, 2 * Nh, dtype=torch.bfloat16, device=dev())
+    ops.gated_gelu_bwd(dy, h, dh, drop=ops.Dropout(seed, 3, 0.1))
+    hh = h.float().requires_grad_(True)
+    (torch.nn.functional.gelu(hh[:, :Nh]) * hh[:, Nh:] * mask / 0.9 * dy.float()).sum().backward()
+    assert rel(dh.float(), hh.grad) < 4e-3
+
+
+@pytest.mark.parametrize("D", [1408, 768, 2048, 96])
+def test_norms(ops, D):
+    torch.manual_seed(3)
+    M = 77
+    x = torch.randn(M, D, device=dev()) * 2 + 0.5
+    g = torch.randn(D, device=dev()) * 0.1 + 1
+    b = torch.randn(D, device=dev()) * 0.1
+    dy = torch.randn(M, D, device=dev())
+    add = torch.randn(M, D, device=dev())
+    # LayerNorm
+    xr, gr, br = x.clone().requires_grad_(True), g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xr, (D,), gr, br, 1e-6)
+    ref.backward(dy)
+    of = torch.empty_like(x)
+    ob = torch.empty(M, D, dtype=torch.bfloat16, device=dev())
+    ops.layernorm_fwd(x, g, b, 1e-6, out_bf16=ob, out_f32=of)
+    assert rel(of, ref) < 2e-6 and rel(ob.float(), ref) < 3e-3
+    dx = torch.empty_like(x)
+    dg, db = torch.zeros(D, device=dev()), torch.zeros(D, device=dev())
+    ops.layernorm_bwd(dy, x, g, 1e-6, dx, dx_add=add, dgamma=dg, dbeta=db)
+    assert rel(dx, xr.grad + add) < 1e-5
+    assert rel(dg, gr.grad) < 1e-5 and rel(db, br.grad) < 1e-5
+    # T5 RMSNorm
+    xr = x.clone().requires_grad_(True)
+    ref = g * (xr * torch.rsqrt(xr.pow(2).mean(-1, keepdim=True) + 1e-6))
+    ref.backward(dy)
+    ops.rmsnorm_fwd(x, g, 1e-6, out_bf16=ob, out_f32=of)
+    assert rel(of, ref) < 2e-6 and rel(ob.float(), ref) < 3e-3
+    ops.rmsnorm_bwd(dy, x, g, 1e-6, dx, dx_add=add)
+    assert rel(dx, xr.grad + add) < 1e-5
+
+
+def _attn_ref(q, k, v, scale, bias=None, mask=None, drop_mask=None, p=0.0):
+    """q,k,v: [B,H,S,D] fp32 (already bf16-rounded values).  fp32 softmax, probabilities bf16-rounded before PV."""
+    s = q @ k.transpose(-1, -2) * scale
+    if bias is not None:
+        s = s + bias
+    if mask is not None:
+        s = s.masked_fill(~mask, -1e30)
+    pr = torch.softmax(s, -1)
+    if drop_mask is not None:
+        pr = pr * drop_mask / (1 - p)
+    return pr @ v, pr
+
+
+def _lut_bias(lut, Sq, Sk):
+    rel_ = (torch.arange(Sk, device=dev())[None, :] - torch.arange(Sq, device=dev())[:, None]).clamp(-128, 128) + 128
+    return lut[:, rel_]  # [H,Sq,Sk]
+
+
+@pytest.mark.parametrize("B,H,Sq,Sk,D", [(2, 3, 257, 257, 88), (1, 2, 32, 257, 64), (2, 4, 300, 300, 64), (1, 2, 12, 333, 16), (2, 2, 17, 17, 24)])
+def test_attention_fwd(ops, B, H, Sq, Sk, D):
+    torch.manual_seed(4)
+    scale = D ** -0.5
+    q = bf(torch.randn(B, Sq, H, D, device=dev()))
+    k = bf(torch.randn(B, Sk, H, D, device=dev()))
+    v = bf(torch.randn(B, Sk, H, D, device=dev()))
+    vt = ops.head_transpose(v)
+    assert torch.equal(vt[:, :, :D, :Sk], v.permute(0, 2, 3, 1)) and vt[:, :, D:].abs().max() == 0 and vt[..., Sk:].abs().max() == 0
+    o = torch.empty(B, Sq, H, D, dtype=torch.bfloat16, device=dev())
+    lse = torch.zeros(B, H, ops.rup32(Sq), device=dev())
+    ops.attention_fwd(q, k, vt, o, lse, scale=scale)
+    ref, pr = _attn_ref(q.float().permute(0, 2, 1, 3), k.float().permute(0, 2, 1, 3), v.float().permute(0, 2, 1, 3), scale)
+    assert rel(o.float().permute(0, 2, 1, 3), ref) < 6e-3  # P and O are bf16-rounded
+    s = q.float().permute(0, 2, 1, 3) @ k.float().permute(0, 2, 1, 3).transpose(-1, -2) * scale
+    assert (lse[..., :Sq] - torch.logsumexp(s, -1)).abs().max() < 1e-3
+
+
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("B,H,Sq,Sk,D", [(2, 4, 150, 150, 64), (1, 2, 40, 40, 16), (2, 3, 12, 200, 64), (3, 2, 32, 257, 64)])
+def test_attention_bias_mask_dropout_fwd_bwd(ops, causal, B, H, Sq, Sk, D):
+    if causal and Sq != Sk:
+        pytest.skip("causal only for self-attention")
+    torch.manual_seed(5)
+    scale = 1.0 if D == 64 else 0.25
+    p = 0.1
+    q = bf(torch.randn(B, Sq, H, D, device=dev()) * 0.5)
+    k = bf(torch.randn(B, Sk, H, D, device=dev()) * 0.5)
+    v = bf(torch.randn(B, Sk, H, D, device=dev()))
+    do = bf(torch.randn(B, Sq, H, D, device=dev()))
+    lut = torch.randn(H, 257, device=dev())
+    kmask = torch.ones(B, Sk, dtype=torch.int32, device=dev())
+    kmask[0, Sk - 7:] = 0
+    seed = torch.tensor([4242], dtype=torch.int32, device=dev())
+    drop = ops.Dropout(seed, 11, p)
+    vt = ops.head_transpose(v)
+    o = torch.empty_like(q)
+    lse = torch.zeros(B, H, ops.rup32(Sq), device=dev())
+    ops.attention_fwd(q, k, vt, o, lse, scale=scale, bias_lut=lut, kmask=kmask, causal=causal, drop=drop)
+    # reference with autograd
+    qr, kr, vr = (t.float().permute(0, 2, 1, 3).clone().requires_grad_(True) for t in (q, k, v))
+    bias = _lut_bias(lut, Sq, Sk)[None]
+    mask = kmask.bool()[:, None, None, :].expand(B, H, Sq, Sk)
+    if causal:
+        mask = mask & torch.tril(torch.ones(Sq, Sk, dtype=torch.bool, device=dev()))[None, None]
+    dmask = keep_mask((B, H, Sq, Sk), 4242, 11, p)
+    ref, _ = _attn_ref(qr, kr, vr, scale, bias, mask, dmask, p)
+    assert rel(o.float().permute(0, 2, 1, 3), ref) < 6e-3
+    ref.backward(do.float().permute(0, 2, 1, 3))
+    kt, qt, dot = ops.head_transpose(k), ops.head_transpose(q), ops.head_transpose(do)
+    delta = torch.zeros_like(lse)
+    dq, dk, dv = torch.zeros_like(q), torch.zeros_like(k), torch.zeros_like(v)
+    ops.attention_bwd(q, k, v, o, do, kt, qt, dot, lse, delta, dq, dk, dv, scale=scale, bias_lut=lut, kmask=kmask, causal=causal, drop=drop)
+    assert rel(dq.float().permute(0, 2, 1, 3), qr.grad) < 1.5e-2
+    assert rel(dk.float().permute(0, 2, 1, 3), kr.grad) < 1.5e-2
+    assert rel(dv.float().permute(0, 2, 1, 3), vr.grad) < 1.5e-2
+
+
+def test_attention_strided_qkv_buffer(ops):
+    """ViT/T5 layout: q, k, v are column slices of one [B*S, 3*H*D] GEMM output."""
+    torch.manual_seed(6)
+    B, S, H, D = 2, 70, 4, 64
+    qkv = bf(torch.randn(B, S, 3, H, D, device=dev()))
+    q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+    o = torch.empty(B, S, H, D, dtype=torch.bfloat16, device=dev())
+    ops.attention_fwd(q, k, ops.head_transpose(v), o, None, scale=0.125)
+    ref, _ = _attn_ref(q.float().permute(0, 2, 1, 3), k.float().permute(0, 2, 1, 3), v.float().permute(0, 2, 1, 3), 0.125)
+    assert rel(o.float().permute(0, 2, 1, 3), ref) < 6e-3
+
+
+def test_patchify_assemble_rowcopy_meanpool(ops):
+    torch.manual_seed(7)
+    F_, IMG, P, D = 3, 56, 14, 96
+    G = IMG // P
+    video = torch.randn(F_, 3, IMG, IMG, device=dev())
+    out = torch.full((F_ * G * G, 640), 7.0, dtype=torch.bfloat16, device=dev())
+    ops.patchify(video, out, P)
+    ref = video.reshape(F_, 3, G, P, G, P).permute(0, 2, 4, 1, 3, 5).reshape(F_ * G * G, 3 * P * P)
+    assert torch.equal(out[:, :588], ref.bfloat16()) and out[:, 588:].abs().max() == 0
+    patch = torch.randn(F_ * G * G, D, device=dev())
+    cls, pos = torch.randn(D, device=dev()), torch.randn(G * G + 1, D, device=dev())
+    x = torch.empty(F_, G * G + 1, D, device=dev())
+    ops.vit_assemble(patch, cls, pos, x)
+    assert torch.equal(x, torch.cat([cls.expand(F_, 1, D), patch.reshape(F_, G * G, D)], 1) + pos)
+    # indexed row copy: bit exact, zero rows, accumulate
+    src = torch.randn(10, D, device=dev())
+    dst = torch.full((6, D), 3.0, device=dev())
+    si = torch.tensor([4, -1, 9, 0], dtype=torch.int32, device=dev())
+    di = torch.tensor([0, 2, 5, 3], dtype=torch.int32, device=dev())
+    ops.row_copy(src, si, dst, di)
+    assert torch.equal(dst[0], src[4]) and dst[2].abs().max() == 0 and torch.equal(dst[5], src[9]) and torch.equal(dst[3], src[0]) and (dst[1] == 3).all()
+    ops.row_copy(src, si, dst, di, accumulate=True)
+    assert torch.equal(dst[0], src[4] * 2)
+    # mean pool 32 -> 1
+    t = torch.randn(5, 32, 2048, device=dev())
+    m = torch.empty(5, 2048, device=dev())
+    ops.mean_pool(t, m)
+    assert rel(m, t.mean(1)) < 1e-6
+    dx = torch.empty_like(t)
+    ops.mean_pool_bwd(m, dx)
+    assert torch.allclose(dx, (m / 32)[:, None].expand_as(t))
+
+
+def test_cast_gelu_ce_adamw(ops):
+    torch.manual_seed(8)
+    M, N = 33, 256
+    x = torch.randn(M, N, device=dev())
+    seed = torch.tensor([5], dtype=torch.int32, device=dev())
+    ob = torch.empty(M, N, dtype=torch.bfloat16, device=dev())
+    ops.cast_dropout(x, out_bf16=ob, drop=ops.Dropout(seed, 2, 0.1))
+    assert torch.equal(ob, (x * keep_mask((M, N), 5, 2, 0.1) / 0.9).bfloat16())
+    ops.seed_bump(seed)
+    assert seed.item() == (5 * 1664525 + 1013904223) % 2 ** 32 - (2 ** 32 if (5 * 1664525 + 1013904223) % 2 ** 32 >= 2 ** 31 else 0)
+    h = bf(torch.randn(M, N, device=dev()))
+    dy = bf(torch.randn(M, N, device=dev()))
+    dh = torch.empty_like(h)
+    ops.gelu_bwd(dy, h, dh)
+    hh = h.float().requires_grad_(True)
+    torch.nn.functional.gelu(hh).backward(dy.float())
+    assert rel(dh.float(), hh.grad) < 4e-3
+    # cross entropy with ignore_index
+    R, V = 9, 32128
+    logits = torch.randn(R, V, device=dev()) * 2
+    labels = torch.randint(0, V, (R,), device=dev())
+    labels[3] = -100
+    lg = logits.clone().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(lg, labels, ignore_index=-100)
+    ref.backward()
+    loss = torch.zeros(1, device=dev())
+    dl = torch.empty(R, V, dtype=torch.bfloat16, device=dev())
+    ops.cross_entropy(logits, labels.int(), 1.0 / 8, loss, dl)
+    assert abs(loss.item() - ref.item()) < 1e-4 * abs(ref.item())
+    assert rel(dl.float(), lg.grad) < 4e-3
+    # AdamW vs torch.optim.AdamW, 3 steps
+    n = 1000
+    p0 = torch.randn(n, device=dev())
+    pt = p0.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([pt], lr=3e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.05)
+    p, m, v = p0.clone(), torch.zeros(n, device=dev()), torch.zeros(n, device=dev())
+    for step in range(1, 4):
+        g = torch.randn(n, device=dev())
+        pt.grad = g.clone()
+        opt.step()
+        hyper = torch.tensor([3e-4, 1 / (1 - 0.9 ** step), 1 / math.sqrt(1 - 0.999 ** step), 1.0], device=dev())
+        ops.adamw(p, g, m, v, hyper, weight_decay=0.05)
+    assert rel(p, pt.detach()) < 1e-6
+
+
+def test_lora_pieces(ops):
+    torch.manual_seed(9)
+    M, K, Cc = 101, 256, 200
+    x = bf(torch.randn(M, K, device=dev()))
+    A = torch.randn(8, K, device=dev()) * 0.1
+    seed = torch.tensor([77], dtype=torch.int32, device=dev())
+    drop = ops.Dropout(seed, 21, 0.05)
+    u = torch.zeros(M, 64, dtype=torch.bfloat16, device=dev())
+    ops.lora_down(x, A, u[:, 8:], drop=drop)
+    mask = keep_mask((M, K), 77, 21, 0.05)
+    xd = (x.float() * mask / 0.95).bfloat16().float()
+    ref = xd @ A.bfloat16().float().t()
+    assert rel(u[:, 8:16].float(), ref) < 3e-3 and u[:, :8].abs().max() == 0 and u[:, 16:].abs().max() == 0
+    # dW[c, r] += sum_m drop(Y)[m,c] U[m,r]   (both output orientations)
+    U = bf(torch.randn(M, 8, device=dev()))
+    Upad = torch.zeros(M, 64, dtype=torch.bfloat16, device=dev())
+    Upad[:, :8] = U
+    dB = torch.zeros(K, 8, device=dev())
+    ops.lora_dw(x, Upad, dB, 8, 1, drop=drop)
+    assert rel(dB, xd.t() @ U.float()) < 1e-5
+    dAt = torch.zeros(8, K, device=dev())
+    ops.lora_dw(x, Upad, dAt, 1, K, drop=drop)
+    assert rel(dAt, (xd.t() @ U.float()).t()) < 1e-5
+    # dx += mask * (G A)
+    for dt in (torch.float32, torch.bfloat16):
+        dx0 = torch.randn(M, K, device=dev()).to(dt)
+        dx = dx0.clone()
+        ops.lora_dx_add(dx, Upad, A, drop=drop)
+        ref = dx0.float() + (U.float() @ A.bfloat16().float()) * mask / 0.95
+        assert rel(dx.float(), ref) < (1e-6 if dt == torch.float32 else 4e-3)
