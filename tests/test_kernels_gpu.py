@@ -159,7 +159,7 @@ def test_attention_fwd(ops, B, H, Sq, Sk, D):
     k = bf(torch.randn(B, Sk, H, D, device=dev()))
     v = bf(torch.randn(B, Sk, H, D, device=dev()))
     vt = ops.head_transpose(v)
-    assert torch.equal(vt[:, :, :D, :Sk], v.permute(0, 2, 3, 1)) and vt[:, :, D:].abs().max() == 0 and vt[..., Sk:].abs().max() == 0
+    assert torch.equal(vt[:, :, :D, :Sk], v.permute(0, 2, 3, 1)) and vt[:, :, D:].abs().sum() == 0 and vt[..., Sk:].abs().sum() == 0
     o = torch.empty(B, Sq, H, D, dtype=torch.bfloat16, device=dev())
     lse = torch.zeros(B, H, ops.rup32(Sq), device=dev())
     ops.attention_fwd(q, k, vt, o, lse, scale=scale)
