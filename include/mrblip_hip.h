@@ -63,7 +63,8 @@ int mrblip_attention_bwd(const void* Q, const long long* q_strides, const void* 
                          const long long* dv_strides, int B, int H, int Sq, int Sk, int D, float scale, const float* bias_lut,
                          const int* kmask, int causal, const uint32_t* seed_ptr, uint32_t site, float p_drop,
                          mrblip_stream_t stream);
-int mrblip_head_transpose(const void* src, const long long* strides, void* dst, int B, int H, int S, int D, mrblip_stream_t stream);
+/* Spad: padded row length of the transposed copy (multiple of 32), 0 = roundup32(S) */
+int mrblip_head_transpose(const void* src, const long long* strides, void* dst, int B, int H, int S, int D, int Spad, mrblip_stream_t stream);
 
 /* frames fp32 [F,3,IMG,IMG] -> bf16 patch rows [F*(IMG/P)^2, Kpad] in Conv2d weight order (eva_vit.py:196-203) */
 int mrblip_patchify(const float* video, void* out_bf16, int F, int IMG, int P, int Kpad, mrblip_stream_t stream);
@@ -96,6 +97,12 @@ int mrblip_lora_dw(const void* Y, long long ldy, const void* U, long long ldu, i
                    float scale, const uint32_t* seed_ptr, uint32_t site, float p, mrblip_stream_t stream);
 int mrblip_lora_dx_add(void* dx, long long lddx, int dx_f32, const void* G, long long ldg, const float* A, int M, int K, float scale,
                        const uint32_t* seed_ptr, uint32_t site, float p, mrblip_stream_t stream);
+
+/* out[c] += sum_m x[m,c] (bias gradient of t5_proj, blip2_mr.py:270-272) */
+int mrblip_colsum(const float* x, long long ldx, int M, int N, float* out, mrblip_stream_t stream);
+/* Wext[row, col..col+7] = bf16(scale * Bt[:, n]) for a device table of {bt_off, n_out, wext_off} triples */
+int mrblip_lora_pack_wext(const float* flat, void* wext_bf16, const long long* desc, int n_adapters, int max_out, float scale,
+                          mrblip_stream_t stream);
 
 #ifdef __cplusplus
 }

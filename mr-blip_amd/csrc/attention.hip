@@ -477,10 +477,12 @@ extern "C" int mrblip_attention_bwd(const void* Q, const long long* q_strides, c
   return mrblip_check_launch("attention_bwd");
 }
 
-extern "C" int mrblip_head_transpose(const void* src, const long long* strides, void* dst, int B, int H, int S, int D,
+extern "C" int mrblip_head_transpose(const void* src, const long long* strides, void* dst, int B, int H, int S, int D, int Spad,
                                      hipStream_t stream) {
   MRB_REQUIRE(B > 0 && H > 0 && S > 0 && D > 0 && D <= 96, "head_transpose: bad shape");
-  const int DP = (D + 31) / 32 * 32, Spad = (S + 31) / 32 * 32;
+  const int DP = (D + 31) / 32 * 32;
+  if (Spad <= 0) Spad = (S + 31) / 32 * 32;
+  MRB_REQUIRE(Spad >= S && (Spad % 32) == 0, "head_transpose: Spad must be a multiple of 32 and >= S");
   T4 s{(const bf16_t*)src, strides[0], strides[1], strides[2]};
   hipLaunchKernelGGL(head_transpose_kernel, dim3(Spad / 32, H, B), dim3(256), 0, stream, s, (bf16_t*)dst, S, D, DP, Spad);
   return mrblip_check_launch("head_transpose");

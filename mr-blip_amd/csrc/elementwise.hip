@@ -299,6 +299,28 @@ __global__ __launch_bounds__(256) void lora_dx_add_kernel(void* __restrict__ dx_
   }
 }
 
+// out[c] += sum_m x[m,c]  (bias gradients)
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, long long ldx, int M, int N, int rows_per_block, float* __restrict__ out) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= N) return;
+  const int mbeg = blockIdx.y * rows_per_block, mend = min(M, mbeg + rows_per_block);
+  float acc = 0.f;
+  for (int m = mbeg; m < mend; ++m) acc += x[(long long)m * ldx + c];
+  atomicAdd(out + c, acc);
+}
+
+// LoRA B -> K-extension operand of the GEMM: Wext[row0 + n, col0 + r] = bf16(scale * Bt[r, n]) for every adapter of a
+// descriptor table {bt_off, n_out, wext_off (elements, already including row0*64 + col0)} in device memory.
+__global__ __launch_bounds__(256) void lora_pack_wext_kernel(const float* __restrict__ flat, bf16_t* __restrict__ wext, const long long* __restrict__ desc, float scale) {
+  const long long bt_off = desc[blockIdx.y * 3 + 0], n_out = desc[blockIdx.y * 3 + 1], w_off = desc[blockIdx.y * 3 + 2];
+  for (long long n = (long long)blockIdx.x * 256 + threadIdx.x; n < n_out; n += (long long)gridDim.x * 256) {
+    float v[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] = flat[bt_off + r * n_out + n] * scale;
+    *reinterpret_cast<uint4*>(wext + w_off + n * 64) = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+  }
+}
+
 // ========================================================================================================= C ABI
 static DropoutArg mk_drop(const uint32_t* seed_ptr, uint32_t site, float p) {
   DropoutArg d;
@@ -391,4 +413,17 @@ extern "C" int mrblip_lora_dx_add(void* dx, long long lddx, int dx_f32, const vo
   if (dx_f32) hipLaunchKernelGGL(lora_dx_add_kernel<true>, dim3(grid_for((long long)M * K / 4)), dim3(256), 0, stream, dx, lddx, (const bf16_t*)G, ldg, A, M, K, scale, mk_drop(seed_ptr, site, p));
   else hipLaunchKernelGGL(lora_dx_add_kernel<false>, dim3(grid_for((long long)M * K / 4)), dim3(256), 0, stream, dx, lddx, (const bf16_t*)G, ldg, A, M, K, scale, mk_drop(seed_ptr, site, p));
   return mrblip_check_launch("lora_dx_add");
+}
+
+extern "C" int mrblip_colsum(const float* x, long long ldx, int M, int N, float* out, hipStream_t stream) {
+  MRB_REQUIRE(M > 0 && N > 0, "colsum: bad shape");
+  const int rpb = 64;
+  hipLaunchKernelGGL(colsum_kernel, dim3((N + 255) / 256, (M + rpb - 1) / rpb), dim3(256), 0, stream, x, ldx, M, N, rpb, out);
+  return mrblip_check_launch("colsum");
+}
+extern "C" int mrblip_lora_pack_wext(const float* flat, void* wext_bf16, const long long* desc, int n_adapters, int max_out, float scale,
+                                     hipStream_t stream) {
+  MRB_REQUIRE(n_adapters > 0 && max_out > 0, "lora_pack_wext: bad shape");
+  hipLaunchKernelGGL(lora_pack_wext_kernel, dim3((max_out + 255) / 256 > 8 ? 8 : (max_out + 255) / 256, n_adapters), dim3(256), 0, stream, flat, (bf16_t*)wext_bf16, desc, scale);
+  return mrblip_check_launch("lora_pack_wext");
 }

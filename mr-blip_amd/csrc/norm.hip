@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const float* __restrict__
           const float4 a = reinterpret_cast<const float4*>(dx_add + (long long)row * ldadd)[i];
           o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
         }
-        reinterpret_cast<float4*>(dx + (long long)row * lddx)[i] = o;
+        if (dx) reinterpret_cast<float4*>(dx + (long long)row * lddx)[i] = o;
       }
     }
   }

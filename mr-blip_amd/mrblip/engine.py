@@ -1,0 +1,928 @@
+"""MrBlipEngine — the MI355X-native train step of Mr. BLIP / Chrono: ViT-g frame encoding -> ln_vision -> Q-Former ->
+t5_proj (-> 32->1 mean pool) -> frame/timestamp interleave -> Flan-T5 encoder/decoder with LoRA -> CE loss, and the
+hand-written backward (dX through T5, t5_proj, Q-Former; dW for LoRA A/B, t5_proj, ln_vision), all as launches of
+the gfx950 kernels in libmrblip_hip.so on ONE stream with static workspaces (hipGraph-capturable).
+
+Follows the behaviour of ``BLIP2_MR.forward_mr`` (blip2_mr.py:433-570) and the modules it calls (eva_vit.py:324-340,
+Qformer.py:804-965, modeling_t5.py:1734-1893, peft LoRA r=8).  Residual streams are fp32, GEMM/attention operands bf16,
+accumulation fp32 (the reference's GPU path is fp16/bf16 autocast with fp32 residuals).
+Frozen: ViT, Q-Former, query_tokens, T5 base weights.  Trainable: LoRA A/B, t5_proj.{weight,bias}, ln_vision.{weight,bias}
+(SURVEY.md §3.1).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Callable, Dict, List, Optional
+
+import torch
+
+from . import ops
+from .prompt import EncoderLayout, bias_lut
+
+bf16, f32 = torch.bfloat16, torch.float32
+
+
+def pad64(n: int) -> int:
+    return (n + 63) // 64 * 64
+
+
+@dataclass
+class EngineConfig:
+    # ViT (eva_vit.py:415-428)
+    img: int = 224
+    patch: int = 14
+    vit_dim: int = 1408
+    vit_depth: int = 39
+    vit_heads: int = 16
+    vit_mlp: int = 6144
+    # Q-Former (bert-base-uncased + blip2.py:46-61)
+    qf_dim: int = 768
+    qf_heads: int = 12
+    qf_inter: int = 3072
+    qf_layers: int = 12
+    qf_cross_freq: int = 2
+    num_query: int = 32
+    qf_dropout: float = 0.1
+    # T5 (google/flan-t5-xl)
+    d_model: int = 2048
+    d_kv: int = 64
+    t5_heads: int = 32
+    d_ff: int = 5120
+    t5_layers: int = 24
+    t5_dec_layers: int = 24
+    vocab: int = 32128
+    t5_eps: float = 1e-6
+    t5_dropout: float = 0.1
+    # LoRA (blip2_mr.py:193-200)
+    lora_r: int = 8
+    lora_alpha: float = 8.0
+    lora_dropout: float = 0.05
+    mean_pool: bool = False
+
+    @staticmethod
+    def flan_t5_xl_qvh(**kw):
+        return EngineConfig(**kw)
+
+    @staticmethod
+    def tiny(**kw):
+        base = dict(img=56, vit_dim=96, vit_depth=2, vit_heads=4, vit_mlp=418, qf_dim=64, qf_heads=4, qf_inter=128, qf_layers=4,
+                    num_query=8, d_model=64, d_kv=16, t5_heads=4, d_ff=128, t5_layers=2, t5_dec_layers=2)
+        base.update(kw)
+        return EngineConfig(**base)
+
+
+class StateDictSource:
+    """Weights by reference state-dict key (plain HF names or peft names for T5)."""
+
+    def __init__(self, sd: Dict[str, torch.Tensor]):
+        self.sd = sd
+
+    def get(self, key: str, shape=None) -> torch.Tensor:
+        if key in self.sd:
+            return self.sd[key]
+        if key.startswith("t5_model."):
+            k2 = "t5_model.base_model.model." + key[len("t5_model."):]
+            if k2 in self.sd:
+                return self.sd[k2]
+            k3 = k2.replace(".weight", ".base_layer.weight")
+            if k3 in self.sd:
+                return self.sd[k3]
+        raise KeyError(key)
+
+    def has(self, key: str) -> bool:
+        try:
+            self.get(key)
+            return True
+        except KeyError:
+            return False
+
+
+class RandomSource:
+    """Seeded N(0, std) weights generated directly on the device (benchmark: no checkpoints in the container)."""
+
+    def __init__(self, device, seed: int = 1234, std: float = 0.02):
+        self.g = torch.Generator(device=device).manual_seed(seed)
+        self.device, self.std = device, std
+
+    def get(self, key: str, shape) -> torch.Tensor:
+        leaf = key.rsplit(".", 1)[-1]
+        lower = key.lower()
+        if leaf == "weight" and ("norm" in lower or "ln_" in lower) and len(shape) == 1:
+            return torch.ones(shape, device=self.device)
+        if leaf in ("bias", "q_bias", "v_bias"):
+            return torch.zeros(shape, device=self.device)
+        return torch.randn(shape, device=self.device, generator=self.g) * self.std
+
+    def has(self, key: str) -> bool:
+        return True
+
+
+@dataclass
+class Adapter:
+    name: str          # e.g. encoder.block.0.layer.0.SelfAttention.q
+    in_dim: int
+    out: int
+    row0: int
+    col0: int
+    site: int
+    A: torch.Tensor = None     # fp32 [8, in] view into the flat trainable buffer
+    Bt: torch.Tensor = None    # fp32 [8, out]  (B transposed)
+    dA: torch.Tensor = None
+    dBt: torch.Tensor = None
+    a_off: int = 0
+    bt_off: int = 0
+
+
+@dataclass
+class LoraGroup:
+    W: torch.Tensor            # bf16 [N, Kp]
+    Wt: torch.Tensor           # bf16 [K, Np]  (for dX)
+    N: int
+    K: int
+    adapters: List[Adapter] = field(default_factory=list)
+    wext: torch.Tensor = None  # bf16 [N, 64] view
+
+
+class MrBlipEngine:
+    @torch.no_grad()
+    def __init__(self, cfg: EngineConfig, src, device, lora_init: Optional[Callable] = None, seed: int = 42):
+        self.cfg, self.dev = cfg, device
+        self.ws: Dict[str, torch.Tensor] = {}
+        self.training = True
+        self.seed = torch.tensor([seed & 0x7FFFFFFF], dtype=torch.int32, device=device)
+        self.hyper = torch.tensor([0.0, 1.0, 1.0, 1.0], dtype=f32, device=device)
+        self.opt_step = 0
+        self._site = 100
+        inner = cfg.t5_heads * cfg.d_kv
+        for nm, v in (("d_model", cfg.d_model), ("t5 inner", inner), ("d_ff", cfg.d_ff), ("qf_dim", cfg.qf_dim), ("qf_inter", cfg.qf_inter)):
+            assert v % 64 == 0, f"{nm} must be a multiple of 64 (got {v})"
+        assert cfg.vit_dim % 8 == 0 and (cfg.vit_dim // cfg.vit_heads) % 8 == 0 and cfg.vit_dim // cfg.vit_heads <= 96
+        self._build_vit(src)
+        self._build_qformer(src)
+        self._build_t5(src, lora_init)
+
+    # ------------------------------------------------------------------------------------------ utilities
+    def buf(self, name: str, shape, dtype, zero: bool = True) -> torch.Tensor:
+        t = self.ws.get(name)
+        shape = tuple(int(s) for s in shape)
+        if t is None or tuple(t.shape) != shape or t.dtype != dtype:
+            t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.dev)
+            self.ws[name] = t
+        return t
+
+    def new_site(self) -> int:
+        self._site += 1
+        return self._site
+
+    def drop(self, site: int, p: float):
+        return ops.Dropout(self.seed, site, p) if (self.training and p > 0) else None
+
+    def _w(self, w: torch.Tensor, n_pad: Optional[int] = None) -> torch.Tensor:
+        """fp32 [N,K] -> bf16 [Np, pad64(K)] zero padded"""
+        N, K = w.shape
+        Np = n_pad or N
+        out = torch.zeros(Np, pad64(K), dtype=bf16, device=self.dev)
+        out[:N, :K] = w.to(self.dev)
+        return out
+
+    def _v(self, v: torch.Tensor, n_pad: Optional[int] = None) -> torch.Tensor:
+        out = torch.zeros(n_pad or v.numel(), dtype=f32, device=self.dev)
+        out[: v.numel()] = v.to(self.dev).float().reshape(-1)
+        return out
+
+    @staticmethod
+    def v4(t2d: torch.Tensor, B: int, S: int, H: int, D: int, col0: int = 0) -> torch.Tensor:
+        """[B*S, ld] buffer -> strided [B,S,H,D] view of columns col0 .. col0+H*D"""
+        ld = t2d.stride(0)
+        return torch.as_strided(t2d, (B, S, H, D), (S * ld, ld, D, 1), t2d.storage_offset() + col0)
+
+    # ------------------------------------------------------------------------------------------ ViT (frozen)
+    def _build_vit(self, src):
+        c = self.cfg
+        D, P = c.vit_dim, c.patch
+        p = "visual_encoder."
+        self.vit_kpad = pad64(3 * P * P)
+        self.vit_fp = pad64(c.vit_mlp)
+        self.vit = dict(
+            pe_w=self._w(src.get(p + "patch_embed.proj.weight", (D, 3, P, P)).reshape(D, -1)),
+            pe_b=self._v(src.get(p + "patch_embed.proj.bias", (D,))),
+            cls=self._v(src.get(p + "cls_token", (1, 1, D))),
+            pos=src.get(p + "pos_embed", (1, (c.img // P) ** 2 + 1, D)).to(self.dev).float().reshape(-1, D).contiguous(),
+            blocks=[],
+        )
+        for i in range(c.vit_depth):
+            q = p + f"blocks.{i}."
+            qb, vb = src.get(q + "attn.q_bias", (D,)), src.get(q + "attn.v_bias", (D,))
+            self.vit["blocks"].append(dict(
+                n1w=self._v(src.get(q + "norm1.weight", (D,))), n1b=self._v(src.get(q + "norm1.bias", (D,))),
+                qkv_w=self._w(src.get(q + "attn.qkv.weight", (3 * D, D))),
+                qkv_b=self._v(torch.cat([qb.float().cpu(), torch.zeros(D), vb.float().cpu()])),
+                proj_w=self._w(src.get(q + "attn.proj.weight", (D, D))), proj_b=self._v(src.get(q + "attn.proj.bias", (D,))),
+                n2w=self._v(src.get(q + "norm2.weight", (D,))), n2b=self._v(src.get(q + "norm2.bias", (D,))),
+                fc1_w=self._w(src.get(q + "mlp.fc1.weight", (c.vit_mlp, D)), self.vit_fp), fc1_b=self._v(src.get(q + "mlp.fc1.bias", (c.vit_mlp,)), self.vit_fp),
+                fc2_w=self._w(src.get(q + "mlp.fc2.weight", (D, c.vit_mlp))), fc2_b=self._v(src.get(q + "mlp.fc2.bias", (D,))),
+            ))
+
+    @torch.no_grad()
+    def vit_forward(self, video: torch.Tensor, n_blocks: Optional[int] = None) -> torch.Tensor:
+        """video fp32 [F,3,IMG,IMG] -> fp32 [F*(NP+1), D] (no final norm, eva_vit.py:324-340).  No activations are kept:
+        the ViT is frozen and its output needs no gradient."""
+        c, v = self.cfg, self.vit
+        F_ = video.shape[0]
+        G = c.img // c.patch
+        NP, D, H = G * G, c.vit_dim, c.vit_heads
+        hd = D // H
+        T = NP + 1
+        M = F_ * T
+        patches = self.buf("vit_patches", (F_ * NP, self.vit_kpad), bf16, zero=False)
+        ops.patchify(video, patches, c.patch)
+        pe = self.buf("vit_pe", (F_ * NP, D), f32, zero=False)
+        ops.gemm(patches, v["pe_w"], pe, bias=v["pe_b"])
+        x = self.buf("vit_x", (M, D), f32, zero=False)
+        ops.vit_assemble(pe, v["cls"], v["pos"], x.view(F_, T, D))
+        h = self.buf("vit_h", (M, pad64(D)), bf16)
+        qkv = self.buf("vit_qkv", (M, 3 * D), bf16, zero=False)
+        o = self.buf("vit_o", (M, pad64(D)), bf16)
+        f = self.buf("vit_f", (M, self.vit_fp), bf16, zero=False)
+        vt = self.buf("vit_vt", (F_, H, ops.rup32(hd), ops.rup32(T)), bf16)
+        q4, k4, v4 = self.v4(qkv, F_, T, H, hd, 0), self.v4(qkv, F_, T, H, hd, D), self.v4(qkv, F_, T, H, hd, 2 * D)
+        o4 = self.v4(o, F_, T, H, hd)
+        scale = hd ** -0.5
+        for blk in v["blocks"][: (c.vit_depth if n_blocks is None else n_blocks)]:
+            ops.layernorm_fwd(x, blk["n1w"], blk["n1b"], 1e-6, out_bf16=h)
+            ops.gemm(h, blk["qkv_w"], qkv, bias=blk["qkv_b"])
+            ops.head_transpose(v4, out=vt)
+            ops.attention_fwd(q4, k4, vt, o4, None, scale=scale)
+            ops.gemm(o, blk["proj_w"], x, bias=blk["proj_b"], residual=x)
+            ops.layernorm_fwd(x, blk["n2w"], blk["n2b"], 1e-6, out_bf16=h)
+            ops.gemm(h, blk["fc1_w"], f, bias=blk["fc1_b"], act=1)
+            ops.gemm(f, blk["fc2_w"], x, bias=blk["fc2_b"], residual=x)
+        return x
+
+    # ------------------------------------------------------------------------------------------ Q-Former (frozen weights, dX needed)
+    def _build_qformer(self, src):
+        c = self.cfg
+        D, Dv, I = c.qf_dim, c.vit_dim, c.qf_inter
+        p = "Qformer.bert."
+        g = lambda k, s: src.get(p + k, s)  # noqa: E731
+        self.qf = dict(
+            query=src.get("query_tokens", (1, c.num_query, D)).to(self.dev).float().reshape(c.num_query, D).contiguous(),
+            emb_w=self._v(g("embeddings.LayerNorm.weight", (D,))), emb_b=self._v(g("embeddings.LayerNorm.bias", (D,))),
+            layers=[],
+        )
+
+        def att(pref, kv_dim):
+            qw, kw, vw = g(pref + "self.query.weight", (D, D)), g(pref + "self.key.weight", (D, kv_dim)), g(pref + "self.value.weight", (D, kv_dim))
+            qb, kb, vb = g(pref + "self.query.bias", (D,)), g(pref + "self.key.bias", (D,)), g(pref + "self.value.bias", (D,))
+            ow = g(pref + "output.dense.weight", (D, D))
+            d = dict(ob=self._v(g(pref + "output.dense.bias", (D,))), ow=self._w(ow), owt=self._w(ow.t()),
+                     lnw=self._v(g(pref + "output.LayerNorm.weight", (D,))), lnb=self._v(g(pref + "output.LayerNorm.bias", (D,))),
+                     sites=(self.new_site(), self.new_site()))
+            if kv_dim == D:  # self-attention: fused q,k,v
+                w = torch.cat([qw, kw, vw]).float()
+                d.update(qkv_w=self._w(w), qkv_wt=self._w(w.t()), qkv_b=self._v(torch.cat([qb, kb, vb])))
+            else:
+                w = torch.cat([kw, vw]).float()
+                d.update(q_w=self._w(qw), q_wt=self._w(qw.t()), q_b=self._v(qb), kv_w=self._w(w), kv_wt=self._w(w.t()), kv_b=self._v(torch.cat([kb, vb])))
+            return d
+
+        self.ln_vision_eps = 1e-5
+        for i in range(c.qf_layers):
+            l = f"encoder.layer.{i}."
+            iw, ow = g(l + "intermediate_query.dense.weight", (I, D)), g(l + "output_query.dense.weight", (D, I))
+            self.qf["layers"].append(dict(
+                self=att(l + "attention.", D),
+                cross=att(l + "crossattention.", Dv) if i % c.qf_cross_freq == 0 else None,
+                iw=self._w(iw), iwt=self._w(iw.t()), ib=self._v(g(l + "intermediate_query.dense.bias", (I,))),
+                ow=self._w(ow), owt=self._w(ow.t()), ob=self._v(g(l + "output_query.dense.bias", (D,))),
+                lnw=self._v(g(l + "output_query.LayerNorm.weight", (D,))), lnb=self._v(g(l + "output_query.LayerNorm.bias", (D,))),
+                site=self.new_site(),
+            ))
+        self.qf_emb_site = self.new_site()
+
+    @torch.no_grad()
+    def qformer_forward(self, img: torch.Tensor, F_: int) -> torch.Tensor:
+        """img: bf16 [F*Tv, pad64(Dv)] (ln_vision output).  Returns the bf16 [F*nq, pad64(D)] last hidden state; keeps what
+        the backward needs in the workspace."""
+        c = self.cfg
+        D, H, nq, I = c.qf_dim, c.qf_heads, c.num_query, c.qf_inter
+        hd = D // H
+        Mq = F_ * nq
+        Tv = img.shape[0] // F_
+        eps, pdrop = 1e-12, c.qf_dropout
+        scale = 1.0 / math.sqrt(hd)
+        q_exp = self.buf("qf_qexp", (Mq, D), f32, zero=False)
+        q_exp.view(F_, nq, D).copy_(self.qf["query"])
+        x = self.buf("qf_x0", (Mq, D), f32, zero=False)
+        ops.layernorm_fwd(q_exp, self.qf["emb_w"], self.qf["emb_b"], eps, out_f32=x)
+        xb = self.buf("qf_xb0", (Mq, pad64(D)), bf16)
+        ops.cast_dropout(x, out_bf16=xb, out_f32=x, drop=self.drop(self.qf_emb_site, pdrop))
+        vt_s = self.buf("qf_vt_s", (F_, H, ops.rup32(hd), ops.rup32(nq)), bf16)
+        vt_c = self.buf("qf_vt_c", (F_, H, ops.rup32(hd), ops.rup32(Tv)), bf16)
+        for i, L in enumerate(self.qf["layers"]):
+            S_ = L["self"]
+            qkv = self.buf(f"qf{i}_qkv", (Mq, 3 * D), bf16, zero=False)
+            ops.gemm(xb, S_["qkv_w"], qkv, bias=S_["qkv_b"])
+            q4, k4, v4 = self.v4(qkv, F_, nq, H, hd, 0), self.v4(qkv, F_, nq, H, hd, D), self.v4(qkv, F_, nq, H, hd, 2 * D)
+            ops.head_transpose(v4, out=vt_s)
+            o = self.buf(f"qf{i}_o", (Mq, pad64(D)), bf16)
+            lse = self.buf(f"qf{i}_lse", (F_, H, ops.rup32(nq)), f32)
+            ops.attention_fwd(q4, k4, vt_s, self.v4(o, F_, nq, H, hd), lse, scale=scale, drop=self.drop(S_["sites"][0], pdrop))
+            y = self.buf(f"qf{i}_y", (Mq, D), f32, zero=False)
+            ops.gemm(o, S_["ow"], y, bias=S_["ob"], residual=x, drop=self.drop(S_["sites"][1], pdrop))
+            x = self.buf(f"qf{i}_x1", (Mq, D), f32, zero=False)
+            xb = self.buf(f"qf{i}_x1b", (Mq, pad64(D)), bf16)
+            ops.layernorm_fwd(y, S_["lnw"], S_["lnb"], eps, out_bf16=xb, out_f32=x)
+            if L["cross"] is not None:
+                C_ = L["cross"]
+                qc = self.buf(f"qf{i}_qc", (Mq, D), bf16, zero=False)
+                ops.gemm(xb, C_["q_w"], qc, bias=C_["q_b"])
+                kv = self.buf(f"qf{i}_kvc", (F_ * Tv, 2 * D), bf16, zero=False)
+                ops.gemm(img, C_["kv_w"], kv, bias=C_["kv_b"])
+                k4, v4 = self.v4(kv, F_, Tv, H, hd, 0), self.v4(kv, F_, Tv, H, hd, D)
+                ops.head_transpose(v4, out=vt_c)
+                oc = self.buf(f"qf{i}_oc", (Mq, pad64(D)), bf16)
+                lsec = self.buf(f"qf{i}_lsec", (F_, H, ops.rup32(nq)), f32)
+                ops.attention_fwd(self.v4(qc, F_, nq, H, hd), k4, vt_c, self.v4(oc, F_, nq, H, hd), lsec, scale=scale, drop=self.drop(C_["sites"][0], pdrop))
+                y2 = self.buf(f"qf{i}_y2", (Mq, D), f32, zero=False)
+                ops.gemm(oc, C_["ow"], y2, bias=C_["ob"], residual=x, drop=self.drop(C_["sites"][1], pdrop))
+                x = self.buf(f"qf{i}_x2", (Mq, D), f32, zero=False)
+                xb = self.buf(f"qf{i}_x2b", (Mq, pad64(D)), bf16)
+                ops.layernorm_fwd(y2, C_["lnw"], C_["lnb"], eps, out_bf16=xb, out_f32=x)
+            hact = self.buf(f"qf{i}_hact", (Mq, pad64(I)), bf16, zero=False)
+            hpre = self.buf(f"qf{i}_hpre", (Mq, pad64(I)), bf16, zero=False)
+            ops.gemm(xb, L["iw"], hact, bias=L["ib"], act=1, out2=hpre)
+            y3 = self.buf(f"qf{i}_y3", (Mq, D), f32, zero=False)
+            ops.gemm(hact, L["ow"], y3, bias=L["ob"], residual=x, drop=self.drop(L["site"], pdrop))
+            x = self.buf(f"qf{i}_x3", (Mq, D), f32, zero=False)
+            xb = self.buf(f"qf{i}_x3b", (Mq, pad64(D)), bf16)
+            ops.layernorm_fwd(y3, L["lnw"], L["lnb"], eps, out_bf16=xb, out_f32=x)
+        self._qf_last_f32 = x
+        return xb
+
+    @torch.no_grad()
+    def qformer_backward(self, dx: torch.Tensor, img: torch.Tensor, F_: int) -> torch.Tensor:
+        """dx: fp32 [F*nq, D] grad of the last hidden state.  Returns fp32 d(img) [F*Tv, Dv] (grad of ln_vision's output)."""
+        c = self.cfg
+        D, H, nq, I, Dv = c.qf_dim, c.qf_heads, c.num_query, c.qf_inter, c.vit_dim
+        hd = D // H
+        Mq = F_ * nq
+        Tv = img.shape[0] // F_
+        eps, pdrop = 1e-12, c.qf_dropout
+        scale = 1.0 / math.sqrt(hd)
+        dimg = self.buf("qf_dimg", (F_ * Tv, Dv), f32)
+        dimg.zero_()
+        dy = self.buf("qf_dy", (Mq, D), f32, zero=False)
+        dyb = self.buf("qf_dyb", (Mq, pad64(D)), bf16)
+        dh = self.buf("qf_dh", (Mq, pad64(I)), bf16, zero=False)
+        dhp = self.buf("qf_dhp", (Mq, pad64(I)), bf16, zero=False)
+        do = self.buf("qf_do", (Mq, D), bf16, zero=False)
+        dqkv = self.buf("qf_dqkv", (Mq, 3 * D), bf16, zero=False)
+        dqc = self.buf("qf_dqc", (Mq, D), bf16, zero=False)
+        dkv = self.buf("qf_dkvc", (F_ * Tv, 2 * D), bf16, zero=False)
+        delta = self.buf("qf_delta", (F_, H, ops.rup32(nq)), f32)
+        rq, rt = ops.rup32(nq), ops.rup32(Tv)
+        kt_s, qt_s, dot_s = (self.buf(n, (F_, H, ops.rup32(hd), rq), bf16) for n in ("qf_kt_s", "qf_qt_s", "qf_dot_s"))
+        kt_c = self.buf("qf_kt_c", (F_, H, ops.rup32(hd), rt), bf16)
+        cur = dx
+        for i in reversed(range(len(self.qf["layers"]))):
+            L = self.qf["layers"][i]
+            nxt = self.buf(f"qf_dx_{i % 2}", (Mq, D), f32, zero=False)
+            # FFN: x3 = LN(y3), y3 = x2 + drop(dense(gelu(dense_i(x2b))))
+            ops.layernorm_bwd(cur, self.ws[f"qf{i}_y3"], L["lnw"], eps, dy)
+            ops.cast_dropout(dy, out_bf16=dyb, drop=self.drop(L["site"], pdrop))
+            ops.gemm(dyb, L["owt"], dh)
+            ops.gelu_bwd(dh, self.ws[f"qf{i}_hpre"], dhp)
+            ops.gemm(dhp, L["iwt"], nxt, residual=dy)
+            cur = nxt
+            if L["cross"] is not None:
+                C_ = L["cross"]
+                nxt = self.buf(f"qf_dxc_{i % 2}", (Mq, D), f32, zero=False)
+                ops.layernorm_bwd(cur, self.ws[f"qf{i}_y2"], C_["lnw"], eps, dy)
+                ops.cast_dropout(dy, out_bf16=dyb, drop=self.drop(C_["sites"][1], pdrop))
+                ops.gemm(dyb, C_["owt"], do)
+                qc, kv, oc = self.ws[f"qf{i}_qc"], self.ws[f"qf{i}_kvc"], self.ws[f"qf{i}_oc"]
+                q4, k4, v4 = self.v4(qc, F_, nq, H, hd), self.v4(kv, F_, Tv, H, hd, 0), self.v4(kv, F_, Tv, H, hd, D)
+                do4 = self.v4(do, F_, nq, H, hd)
+                ops.head_transpose(k4, out=kt_c)
+                ops.head_transpose(q4, out=qt_s)
+                ops.head_transpose(do4, out=dot_s)
+                ops.attention_bwd(q4, k4, v4, self.v4(oc, F_, nq, H, hd), do4, kt_c, qt_s, dot_s, self.ws[f"qf{i}_lsec"], delta,
+                                  self.v4(dqc, F_, nq, H, hd), self.v4(dkv, F_, Tv, H, hd, 0), self.v4(dkv, F_, Tv, H, hd, D),
+                                  scale=scale, drop=self.drop(C_["sites"][0], pdrop))
+                ops.gemm(dkv, C_["kv_wt"], dimg, residual=dimg)
+                if i > 0:
+                    ops.gemm(dqc, C_["q_wt"], nxt, residual=dy)
+                    cur = nxt
+            if i == 0:
+                break  # layer 0's self-attention only feeds the frozen query tokens
+            S_ = L["self"]
+            nxt = self.buf(f"qf_dxs_{i % 2}", (Mq, D), f32, zero=False)
+            ops.layernorm_bwd(cur, self.ws[f"qf{i}_y"], S_["lnw"], eps, dy)
+            ops.cast_dropout(dy, out_bf16=dyb, drop=self.drop(S_["sites"][1], pdrop))
+            ops.gemm(dyb, S_["owt"], do)
+            qkv, o = self.ws[f"qf{i}_qkv"], self.ws[f"qf{i}_o"]
+            q4, k4, v4 = self.v4(qkv, F_, nq, H, hd, 0), self.v4(qkv, F_, nq, H, hd, D), self.v4(qkv, F_, nq, H, hd, 2 * D)
+            do4 = self.v4(do, F_, nq, H, hd)
+            ops.head_transpose(k4, out=kt_s)
+            ops.head_transpose(q4, out=qt_s)
+            ops.head_transpose(do4, out=dot_s)
+            ops.attention_bwd(q4, k4, v4, self.v4(o, F_, nq, H, hd), do4, kt_s, qt_s, dot_s, self.ws[f"qf{i}_lse"], delta,
+                              self.v4(dqkv, F_, nq, H, hd, 0), self.v4(dqkv, F_, nq, H, hd, D), self.v4(dqkv, F_, nq, H, hd, 2 * D),
+                              scale=scale, drop=self.drop(S_["sites"][0], pdrop))
+            ops.gemm(dqkv, S_["qkv_wt"], nxt, residual=dy)
+            cur = nxt
+        return dimg
+
+    # ------------------------------------------------------------------------------------------ T5 + LoRA, t5_proj, ln_vision
+    def _build_t5(self, src, lora_init):
+        c = self.cfg
+        d, inner, ff, V = c.d_model, c.t5_heads * c.d_kv, c.d_ff, c.vocab
+        r = c.lora_r
+        self.lora_scale = c.lora_alpha / c.lora_r
+        t = "t5_model."
+        groups: List[LoraGroup] = []
+        adapters: List[Adapter] = []
+
+        def W(name, shape):
+            return src.get(t + name + ".weight", shape).float()
+
+        def group(names, in_dim, outs):
+            w = torch.cat([W(n, (o, in_dim)) for n, o in zip(names, outs)])
+            N = w.shape[0]
+            g = LoraGroup(W=self._w(w), Wt=self._w(w.t()), N=N, K=in_dim)
+            row = 0
+            for j, (n, o) in enumerate(zip(names, outs)):
+                a = Adapter(name=n, in_dim=in_dim, out=o, row0=row, col0=8 * j, site=self.new_site())
+                g.adapters.append(a)
+                adapters.append(a)
+                row += o
+            groups.append(g)
+            return g
+
+        self.t5 = dict(enc=[], dec=[])
+        self.emb = src.get(t + "shared.weight", (V, d)).to(self.dev).float().contiguous()
+        for i in range(c.t5_layers):
+            b = f"encoder.block.{i}."
+            self.t5["enc"].append(dict(
+                ln0=self._v(src.get(t + b + "layer.0.layer_norm.weight", (d,))),
+                qkv=group([b + "layer.0.SelfAttention." + x for x in "qkv"], d, [inner] * 3),
+                o=group([b + "layer.0.SelfAttention.o"], inner, [d]),
+                ln1=self._v(src.get(t + b + "layer.1.layer_norm.weight", (d,))),
+                wi=group([b + "layer.1.DenseReluDense.wi_0", b + "layer.1.DenseReluDense.wi_1"], d, [ff, ff]),
+                wo=group([b + "layer.1.DenseReluDense.wo"], ff, [d]),
+                sites=[self.new_site() for _ in range(4)],
+            ))
+        for i in range(c.t5_dec_layers):
+            b = f"decoder.block.{i}."
+            self.t5["dec"].append(dict(
+                ln0=self._v(src.get(t + b + "layer.0.layer_norm.weight", (d,))),
+                qkv=group([b + "layer.0.SelfAttention." + x for x in "qkv"], d, [inner] * 3),
+                o=group([b + "layer.0.SelfAttention.o"], inner, [d]),
+                ln1=self._v(src.get(t + b + "layer.1.layer_norm.weight", (d,))),
+                cq=group([b + "layer.1.EncDecAttention.q"], d, [inner]),
+                ckv=group([b + "layer.1.EncDecAttention.k", b + "layer.1.EncDecAttention.v"], d, [inner] * 2),
+                co=group([b + "layer.1.EncDecAttention.o"], inner, [d]),
+                ln2=self._v(src.get(t + b + "layer.2.layer_norm.weight", (d,))),
+                wi=group([b + "layer.2.DenseReluDense.wi_0", b + "layer.2.DenseReluDense.wi_1"], d, [ff, ff]),
+                wo=group([b + "layer.2.DenseReluDense.wo"], ff, [d]),
+                sites=[self.new_site() for _ in range(6)],
+            ))
+        self.t5["enc_final"] = self._v(src.get(t + "encoder.final_layer_norm.weight", (d,)))
+        self.t5["dec_final"] = self._v(src.get(t + "decoder.final_layer_norm.weight", (d,)))
+        self.t5["lm"] = group(["lm_head"], d, [V])
+        self.t5["sites"] = [self.new_site() for _ in range(4)]
+        nb = 32
+        self.lut_enc = bias_lut(src.get(t + "encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight", (nb, c.t5_heads)).cpu(), True).to(self.dev)
+        self.lut_dec = bias_lut(src.get(t + "decoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight", (nb, c.t5_heads)).cpu(), False).to(self.dev)
+
+        # ---- flat trainable buffer: [LoRA A, Bt ...] [t5_proj.weight] | [t5_proj.bias, ln_vision.weight, ln_vision.bias]
+        Dq, Dv = c.qf_dim, c.vit_dim
+        n_lora = sum(r * (a.in_dim + a.out) for a in adapters)
+        n_decay = n_lora + d * Dq
+        n_total = n_decay + d + 2 * Dv
+        self.flat = torch.zeros(n_total, dtype=f32, device=self.dev)
+        self.grad = torch.zeros_like(self.flat)
+        self.adam_m = torch.zeros_like(self.flat)
+        self.adam_v = torch.zeros_like(self.flat)
+        self.n_decay = n_decay
+        off = 0
+        desc = []
+        n_wext_rows = sum(g.N for g in groups)
+        self.wext_all = torch.zeros(n_wext_rows, 64, dtype=bf16, device=self.dev)
+        wrow = 0
+        gen = torch.Generator(device="cpu").manual_seed(4321)
+        for g in groups:
+            g.wext = self.wext_all[wrow: wrow + g.N]
+            for a in g.adapters:
+                a.a_off, a.bt_off = off, off + r * a.in_dim
+                a.A = self.flat[a.a_off: a.a_off + r * a.in_dim].view(r, a.in_dim)
+                a.Bt = self.flat[a.bt_off: a.bt_off + r * a.out].view(r, a.out)
+                a.dA = self.grad[a.a_off: a.a_off + r * a.in_dim].view(r, a.in_dim)
+                a.dBt = self.grad[a.bt_off: a.bt_off + r * a.out].view(r, a.out)
+                off += r * (a.in_dim + a.out)
+                desc.append([a.bt_off, a.out, (wrow + a.row0) * 64 + a.col0])
+                ka, kb = t + "base_model.model." + a.name + ".lora_A.default.weight", t + "base_model.model." + a.name + ".lora_B.default.weight"
+                if isinstance(src, StateDictSource) and ka in src.sd:
+                    a.A.copy_(src.sd[ka])
+                    a.Bt.copy_(src.sd[kb].t())
+                elif lora_init is not None:
+                    lora_init(a, gen)
+                else:  # peft default: A kaiming-uniform(a=sqrt(5)), B zeros
+                    bound = 1.0 / math.sqrt(a.in_dim)
+                    a.A.copy_((torch.rand(r, a.in_dim, generator=gen) * 2 - 1) * bound)
+            wrow += g.N
+        self.adapters, self.groups = adapters, groups
+        self.lora_desc = torch.tensor(desc, dtype=torch.int64, device=self.dev)
+        self.max_out = max(a.out for a in adapters)
+        # t5_proj / ln_vision (trainable)
+        self.proj_w = self.flat[off: off + d * Dq].view(d, Dq)
+        self.dproj_w = self.grad[off: off + d * Dq].view(d, Dq)
+        off += d * Dq
+        assert off == n_decay
+        self.proj_b, self.dproj_b = self.flat[off: off + d], self.grad[off: off + d]
+        off += d
+        self.lnv_w, self.dlnv_w = self.flat[off: off + Dv], self.grad[off: off + Dv]
+        off += Dv
+        self.lnv_b, self.dlnv_b = self.flat[off: off + Dv], self.grad[off: off + Dv]
+        self.proj_w.copy_(src.get("t5_proj.weight", (d, Dq)))
+        self.proj_b.copy_(src.get("t5_proj.bias", (d,)))
+        self.lnv_w.copy_(src.get("ln_vision.weight", (Dv,)))
+        self.lnv_b.copy_(src.get("ln_vision.bias", (Dv,)))
+        self.proj_wb = torch.zeros(d, pad64(Dq), dtype=bf16, device=self.dev)      # bf16 operand copies, refreshed per step
+        self.proj_wtb = torch.zeros(Dq, pad64(d), dtype=bf16, device=self.dev)
+        self.refresh_trainable()
+
+    def transpose2d(self, src: torch.Tensor, C: int, dst: torch.Tensor):
+        """bf16 src[R, :C] (row stride src.stride(0)) -> dst[C, Rp] = src^T, zero padded to dst.shape[1] (multiple of 32)."""
+        R = src.shape[0]
+        hd = 64 if C % 64 == 0 else 32
+        assert C % hd == 0 and dst.shape[0] == C and dst.shape[1] % 32 == 0 and dst.shape[1] >= R
+        v = torch.as_strided(src, (1, R, C // hd, hd), (0, src.stride(0), hd, 1), src.storage_offset())
+        ops.head_transpose(v, out=dst.view(1, C // hd, hd, dst.shape[1]), spad=dst.shape[1])
+
+    @torch.no_grad()
+    def refresh_trainable(self):
+        """Re-derive the bf16 operand copies of the trainable tensors (after init / optimizer step / checkpoint load)."""
+        c = self.cfg
+        ops.lora_pack_wext(self.flat, self.wext_all, self.lora_desc, len(self.adapters), self.max_out, self.lora_scale)
+        ops.cast_dropout(self.proj_w, out_bf16=self.proj_wb)
+        self.transpose2d(self.proj_wb, c.qf_dim, self.proj_wtb)
+
+    # ---- LoRA-group forward / backward -------------------------------------------------------------------------
+    def lg_fwd(self, g: LoraGroup, x: torch.Tensor, u: torch.Tensor, out: torch.Tensor, **kw):
+        p = self.cfg.lora_dropout
+        xv = x[:, : g.K]
+        for a in g.adapters:
+            ops.lora_down(xv, a.A, u[:, a.col0:], drop=self.drop(a.site, p))
+        ops.gemm(x, g.W, out, aext=u, wext=g.wext, **kw)
+
+    def lg_bwd(self, g: LoraGroup, dy: torch.Tensor, x: torch.Tensor, u: torch.Tensor, gbuf: torch.Tensor, dx: Optional[torch.Tensor],
+               residual: Optional[torch.Tensor] = None):
+        """dy bf16 [M,N]; x the saved bf16 input; u the saved [M,64] LoRA activations; dx = dy @ W (+ residual) + LoRA path."""
+        p, s = self.cfg.lora_dropout, self.lora_scale
+        xv = x[:, : g.K]
+        for a in g.adapters:
+            dya = dy[:, a.row0: a.row0 + a.out]
+            ops.lora_down(dya, a.Bt, gbuf[:, a.col0:], scale=s)
+            ops.lora_dw(dya, u[:, a.col0:], a.dBt, 1, a.out, scale=s)
+            ops.lora_dw(xv, gbuf[:, a.col0:], a.dA, 1, a.in_dim, drop=self.drop(a.site, p))
+        if dx is not None:
+            ops.gemm(dy, g.Wt, dx, residual=residual, K=pad64(g.N))
+            for a in g.adapters:
+                ops.lora_dx_add(dx[:, : g.K], gbuf[:, a.col0:], a.A, drop=self.drop(a.site, p))
+
+    # ---- encoder ---------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def t5_encoder_forward(self, x0: torch.Tensor, B: int, S: int, kmask: torch.Tensor) -> torch.Tensor:
+        """x0 fp32 [B*S, d] (inputs_embeds).  Returns bf16 encoder output [B*S, d]."""
+        c = self.cfg
+        d, H, dk, ff, p = c.d_model, c.t5_heads, c.d_kv, c.d_ff, c.t5_dropout
+        inner = H * dk
+        M = B * S
+        x = self.buf("e_x0", (M, d), f32, zero=False)
+        ops.cast_dropout(x0, out_f32=x, drop=self.drop(self.t5["sites"][0], p))
+        vt = self.buf("e_vt", (B, H, ops.rup32(dk), ops.rup32(S)), bf16)
+        for i, L in enumerate(self.t5["enc"]):
+            xn = self.buf(f"e{i}_xn", (M, pad64(d)), bf16)
+            ops.rmsnorm_fwd(x, L["ln0"], c.t5_eps, out_bf16=xn)
+            u = self.buf(f"e{i}_u_qkv", (M, 64), bf16)
+            qkv = self.buf(f"e{i}_qkv", (M, 3 * inner), bf16, zero=False)
+            self.lg_fwd(L["qkv"], xn, u, qkv)
+            q4, k4, v4 = self.v4(qkv, B, S, H, dk, 0), self.v4(qkv, B, S, H, dk, inner), self.v4(qkv, B, S, H, dk, 2 * inner)
+            ops.head_transpose(v4, out=vt)
+            o = self.buf(f"e{i}_o", (M, pad64(inner)), bf16)
+            lse = self.buf(f"e{i}_lse", (B, H, ops.rup32(S)), f32)
+            ops.attention_fwd(q4, k4, vt, self.v4(o, B, S, H, dk), lse, scale=1.0, bias_lut=self.lut_enc, kmask=kmask, drop=self.drop(L["sites"][0], p))
+            uo = self.buf(f"e{i}_u_o", (M, 64), bf16)
+            xm = self.buf(f"e{i}_xm", (M, d), f32, zero=False)
+            self.lg_fwd(L["o"], o, uo, xm, residual=x, drop=self.drop(L["sites"][1], p))
+            xn2 = self.buf(f"e{i}_xn2", (M, pad64(d)), bf16)
+            ops.rmsnorm_fwd(xm, L["ln1"], c.t5_eps, out_bf16=xn2)
+            uw = self.buf(f"e{i}_u_wi", (M, 64), bf16)
+            y = self.buf(f"e{i}_y", (M, pad64(ff)), bf16)
+            h = self.buf(f"e{i}_h", (M, 2 * ff), bf16, zero=False)
+            self.lg_fwd(L["wi"], xn2, uw, y, out2=h, gated=True, drop=self.drop(L["sites"][2], p))
+            uwo = self.buf(f"e{i}_u_wo", (M, 64), bf16)
+            xo = self.buf(f"e{i + 1}_x" if i + 1 < len(self.t5["enc"]) else "e_xlast", (M, d), f32, zero=False)
+            self.lg_fwd(L["wo"], y, uwo, xo, residual=xm, drop=self.drop(L["sites"][3], p))
+            self.ws[f"e{i}_xin"] = x
+            x = xo
+        nf = self.buf("e_nf", (M, d), f32, zero=False)
+        ops.rmsnorm_fwd(x, self.t5["enc_final"], c.t5_eps, out_f32=nf)
+        enc = self.buf("e_out", (M, pad64(d)), bf16)
+        ops.cast_dropout(nf, out_bf16=enc, drop=self.drop(self.t5["sites"][1], p))
+        self.ws["e_xfinal_in"] = x
+        return enc
+
+    @torch.no_grad()
+    def t5_encoder_backward(self, denc: torch.Tensor, B: int, S: int, kmask: torch.Tensor) -> torch.Tensor:
+        """denc fp32 [B*S, d]: grad of the encoder output.  Returns fp32 grad of inputs_embeds."""
+        c = self.cfg
+        d, H, dk, ff, p = c.d_model, c.t5_heads, c.d_kv, c.d_ff, c.t5_dropout
+        inner = H * dk
+        M = B * S
+        t = self.buf("eb_t", (M, d), f32, zero=False)
+        ops.cast_dropout(denc, out_f32=t, drop=self.drop(self.t5["sites"][1], p))
+        dx = self.buf("eb_dx_a", (M, d), f32, zero=False)
+        ops.rmsnorm_bwd(t, self.ws["e_xfinal_in"], self.t5["enc_final"], c.t5_eps, dx)
+        dyb = self.buf("eb_dyb", (M, pad64(d)), bf16)
+        gb = self.buf("eb_g", (M, 64), bf16)
+        dyact = self.buf("eb_dyact", (M, ff), bf16, zero=False)
+        dh = self.buf("eb_dh", (M, 2 * ff), bf16, zero=False)
+        dxn = self.buf("eb_dxn", (M, d), f32, zero=False)
+        do = self.buf("eb_do", (M, inner), bf16, zero=False)
+        dqkv = self.buf("eb_dqkv", (M, 3 * inner), bf16, zero=False)
+        rs = ops.rup32(S)
+        kt, qt, dot = (self.buf(n, (B, H, ops.rup32(dk), rs), bf16) for n in ("eb_kt", "eb_qt", "eb_dot"))
+        delta = self.buf("eb_delta", (B, H, rs), f32)
+        other = self.buf("eb_dx_b", (M, d), f32, zero=False)
+        for i in reversed(range(len(self.t5["enc"]))):
+            L = self.t5["enc"][i]
+            # x_out = xm + drop(wo(y));  y = drop(gelu(wi_0 xn2) * wi_1 xn2)
+            ops.cast_dropout(dx, out_bf16=dyb, drop=self.drop(L["sites"][3], p))
+            self.lg_bwd(L["wo"], dyb, self.ws[f"e{i}_y"], self.ws[f"e{i}_u_wo"], gb, dyact)
+            ops.gated_gelu_bwd(dyact, self.ws[f"e{i}_h"], dh, drop=self.drop(L["sites"][2], p))
+            self.lg_bwd(L["wi"], dh, self.ws[f"e{i}_xn2"], self.ws[f"e{i}_u_wi"], gb, dxn)
+            ops.rmsnorm_bwd(dxn, self.ws[f"e{i}_xm"], L["ln1"], c.t5_eps, other, dx_add=dx)
+            dx, other = other, dx
+            # xm = x_in + drop(o(attn(qkv(xn))))
+            ops.cast_dropout(dx, out_bf16=dyb, drop=self.drop(L["sites"][1], p))
+            self.lg_bwd(L["o"], dyb, self.ws[f"e{i}_o"], self.ws[f"e{i}_u_o"], gb, do)
+            qkv, o = self.ws[f"e{i}_qkv"], self.ws[f"e{i}_o"]
+            q4, k4, v4 = self.v4(qkv, B, S, H, dk, 0), self.v4(qkv, B, S, H, dk, inner), self.v4(qkv, B, S, H, dk, 2 * inner)
+            do4 = self.v4(do, B, S, H, dk)
+            ops.head_transpose(k4, out=kt)
+            ops.head_transpose(q4, out=qt)
+            ops.head_transpose(do4, out=dot)
+            ops.attention_bwd(q4, k4, v4, self.v4(o, B, S, H, dk), do4, kt, qt, dot, self.ws[f"e{i}_lse"], delta,
+                              self.v4(dqkv, B, S, H, dk, 0), self.v4(dqkv, B, S, H, dk, inner), self.v4(dqkv, B, S, H, dk, 2 * inner),
+                              scale=1.0, bias_lut=self.lut_enc, kmask=kmask, drop=self.drop(L["sites"][0], p))
+            self.lg_bwd(L["qkv"], dqkv, self.ws[f"e{i}_xn"], self.ws[f"e{i}_u_qkv"], gb, dxn)
+            ops.rmsnorm_bwd(dxn, self.ws[f"e{i}_xin"], L["ln0"], c.t5_eps, other, dx_add=dx)
+            dx, other = other, dx
+        dinp = self.buf("eb_dinp", (M, d), f32, zero=False)
+        ops.cast_dropout(dx, out_f32=dinp, drop=self.drop(self.t5["sites"][0], p))
+        return dinp
+
+    # ---- decoder + LM head + loss (forward and backward) ---------------------------------------------------------
+    @torch.no_grad()
+    def t5_decoder_forward(self, dec_ids: torch.Tensor, dec_mask: torch.Tensor, enc: torch.Tensor, B: int, S: int, kmask: torch.Tensor,
+                           labels: torch.Tensor, want_grad: bool = True):
+        c = self.cfg
+        d, H, dk, ff, p, V = c.d_model, c.t5_heads, c.d_kv, c.d_ff, c.t5_dropout, c.vocab
+        inner = H * dk
+        Ld = dec_ids.shape[1]
+        R, Me = B * Ld, B * S
+        ids32 = dec_ids.reshape(-1).to(self.dev, torch.int32)
+        rows = torch.arange(R, dtype=torch.int32, device=self.dev)
+        x0 = self.buf("d_emb", (R, d), f32, zero=False)
+        ops.row_copy(self.emb, ids32, x0, rows)
+        x = self.buf("d_x0", (R, d), f32, zero=False)
+        ops.cast_dropout(x0, out_f32=x, drop=self.drop(self.t5["sites"][2], p))
+        vt_s = self.buf("d_vt_s", (B, H, ops.rup32(dk), ops.rup32(Ld)), bf16)
+        vt_c = self.buf("d_vt_c", (B, H, ops.rup32(dk), ops.rup32(S)), bf16)
+        dmask = dec_mask.to(self.dev, torch.int32).contiguous()
+        for i, L in enumerate(self.t5["dec"]):
+            xn = self.buf(f"d{i}_xn", (R, pad64(d)), bf16)
+            ops.rmsnorm_fwd(x, L["ln0"], c.t5_eps, out_bf16=xn)
+            u = self.buf(f"d{i}_u_qkv", (R, 64), bf16)
+            qkv = self.buf(f"d{i}_qkv", (R, 3 * inner), bf16, zero=False)
+            self.lg_fwd(L["qkv"], xn, u, qkv)
+            q4, k4, v4 = self.v4(qkv, B, Ld, H, dk, 0), self.v4(qkv, B, Ld, H, dk, inner), self.v4(qkv, B, Ld, H, dk, 2 * inner)
+            ops.head_transpose(v4, out=vt_s)
+            o = self.buf(f"d{i}_o", (R, pad64(inner)), bf16)
+            lse = self.buf(f"d{i}_lse", (B, H, ops.rup32(Ld)), f32)
+            ops.attention_fwd(q4, k4, vt_s, self.v4(o, B, Ld, H, dk), lse, scale=1.0, bias_lut=self.lut_dec, kmask=dmask, causal=True, drop=self.drop(L["sites"][0], p))
+            uo = self.buf(f"d{i}_u_o", (R, 64), bf16)
+            x1 = self.buf(f"d{i}_x1", (R, d), f32, zero=False)
+            self.lg_fwd(L["o"], o, uo, x1, residual=x, drop=self.drop(L["sites"][1], p))
+            # cross attention
+            xn1 = self.buf(f"d{i}_xn1", (R, pad64(d)), bf16)
+            ops.rmsnorm_fwd(x1, L["ln1"], c.t5_eps, out_bf16=xn1)
+            ucq = self.buf(f"d{i}_u_cq", (R, 64), bf16)
+            cq = self.buf(f"d{i}_cq", (R, inner), bf16, zero=False)
+            self.lg_fwd(L["cq"], xn1, ucq, cq)
+            ukv = self.buf(f"d{i}_u_ckv", (Me, 64), bf16)
+            ckv = self.buf(f"d{i}_ckv", (Me, 2 * inner), bf16, zero=False)
+            self.lg_fwd(L["ckv"], enc, ukv, ckv)
+            ck4, cv4 = self.v4(ckv, B, S, H, dk, 0), self.v4(ckv, B, S, H, dk, inner)
+            ops.head_transpose(cv4, out=vt_c)
+            co = self.buf(f"d{i}_co", (R, pad64(inner)), bf16)
+            lsec = self.buf(f"d{i}_lsec", (B, H, ops.rup32(Ld)), f32)
+            ops.attention_fwd(self.v4(cq, B, Ld, H, dk), ck4, vt_c, self.v4(co, B, Ld, H, dk), lsec, scale=1.0, kmask=kmask, drop=self.drop(L["sites"][2], p))
+            uco = self.buf(f"d{i}_u_co", (R, 64), bf16)
+            x2 = self.buf(f"d{i}_x2", (R, d), f32, zero=False)
+            self.lg_fwd(L["co"], co, uco, x2, residual=x1, drop=self.drop(L["sites"][3], p))
+            # FFN
+            xn2 = self.buf(f"d{i}_xn2", (R, pad64(d)), bf16)
+            ops.rmsnorm_fwd(x2, L["ln2"], c.t5_eps, out_bf16=xn2)
+            uw = self.buf(f"d{i}_u_wi", (R, 64), bf16)
+            y = self.buf(f"d{i}_y", (R, pad64(ff)), bf16)
+            h = self.buf(f"d{i}_h", (R, 2 * ff), bf16, zero=False)
+            self.lg_fwd(L["wi"], xn2, uw, y, out2=h, gated=True, drop=self.drop(L["sites"][4], p), tile_cfg=2)
+            uwo = self.buf(f"d{i}_u_wo", (R, 64), bf16)
+            x3 = self.buf(f"d{i}_x3", (R, d), f32, zero=False)
+            self.lg_fwd(L["wo"], y, uwo, x3, residual=x2, drop=self.drop(L["sites"][5], p))
+            self.ws[f"d{i}_xin"] = x
+            x = x3
+        self.ws["d_xfinal_in"] = x
+        nf = self.buf("d_nf", (R, d), f32, zero=False)
+        ops.rmsnorm_fwd(x, self.t5["dec_final"], c.t5_eps, out_f32=nf)
+        seq = self.buf("d_seq", (R, pad64(d)), bf16)
+        ops.cast_dropout(nf, out_bf16=seq, drop=self.drop(self.t5["sites"][3], p))
+        ulm = self.buf("d_u_lm", (R, 64), bf16)
+        logits = self.buf("d_logits", (R, V), f32, zero=False)
+        self.lg_fwd(self.t5["lm"], seq, ulm, logits)
+        lab = labels.reshape(-1).to(self.dev, torch.int32)
+        n_valid = int((labels != -100).sum())
+        loss = self.buf("loss", (1,), f32)
+        loss.zero_()
+        dlog = self.buf("d_dlogits", (R, V), bf16, zero=False) if want_grad else None
+        ops.cross_entropy(logits, lab, 1.0 / max(n_valid, 1), loss, dlog)
+        return loss, logits
+
+    @torch.no_grad()
+    def t5_decoder_backward(self, enc: torch.Tensor, B: int, S: int, Ld: int, kmask: torch.Tensor, dec_mask: torch.Tensor) -> torch.Tensor:
+        """Backward from d_dlogits.  Returns fp32 grad of the encoder output [B*S, d]."""
+        c = self.cfg
+        d, H, dk, ff, p, V = c.d_model, c.t5_heads, c.d_kv, c.d_ff, c.t5_dropout, c.vocab
+        inner = H * dk
+        R, Me = B * Ld, B * S
+        dmask = dec_mask.to(self.dev, torch.int32).contiguous()
+        gb = self.buf("db_g", (R, 64), bf16)
+        gbe = self.buf("db_ge", (Me, 64), bf16)
+        dseq = self.buf("db_dseq", (R, d), f32, zero=False)
+        self.lg_bwd(self.t5["lm"], self.ws["d_dlogits"], self.ws["d_seq"], self.ws["d_u_lm"], gb, dseq)
+        t = self.buf("db_t", (R, d), f32, zero=False)
+        ops.cast_dropout(dseq, out_f32=t, drop=self.drop(self.t5["sites"][3], p))
+        dx = self.buf("db_dx_a", (R, d), f32, zero=False)
+        other = self.buf("db_dx_b", (R, d), f32, zero=False)
+        ops.rmsnorm_bwd(t, self.ws["d_xfinal_in"], self.t5["dec_final"], c.t5_eps, dx)
+        denc = self.buf("db_denc", (Me, d), f32)
+        denc.zero_()
+        dyb = self.buf("db_dyb", (R, pad64(d)), bf16)
+        dyact = self.buf("db_dyact", (R, ff), bf16, zero=False)
+        dh = self.buf("db_dh", (R, 2 * ff), bf16, zero=False)
+        dxn = self.buf("db_dxn", (R, d), f32, zero=False)
+        do = self.buf("db_do", (R, inner), bf16, zero=False)
+        dqkv = self.buf("db_dqkv", (R, 3 * inner), bf16, zero=False)
+        dcq = self.buf("db_dcq", (R, inner), bf16, zero=False)
+        dckv = self.buf("db_dckv", (Me, 2 * inner), bf16, zero=False)
+        rl, rs = ops.rup32(Ld), ops.rup32(S)
+        kt_s, qt_s, dot_s = (self.buf(n, (B, H, ops.rup32(dk), rl), bf16) for n in ("db_kt_s", "db_qt_s", "db_dot_s"))
+        kt_c = self.buf("db_kt_c", (B, H, ops.rup32(dk), rs), bf16)
+        delta = self.buf("db_delta", (B, H, rl), f32)
+        for i in reversed(range(len(self.t5["dec"]))):
+            L = self.t5["dec"][i]
+            ops.cast_dropout(dx, out_bf16=dyb, drop=self.drop(L["sites"][5], p))
+            self.lg_bwd(L["wo"], dyb, self.ws[f"d{i}_y"], self.ws[f"d{i}_u_wo"], gb, dyact)
+            ops.gated_gelu_bwd(dyact, self.ws[f"d{i}_h"], dh, drop=self.drop(L["sites"][4], p))
+            self.lg_bwd(L["wi"], dh, self.ws[f"d{i}_xn2"], self.ws[f"d{i}_u_wi"], gb, dxn)
+            ops.rmsnorm_bwd(dxn, self.ws[f"d{i}_x2"], L["ln2"], c.t5_eps, other, dx_add=dx)
+            dx, other = other, dx
+            # cross attention
+            ops.cast_dropout(dx, out_bf16=dyb, drop=self.drop(L["sites"][3], p))
+            self.lg_bwd(L["co"], dyb, self.ws[f"d{i}_co"], self.ws[f"d{i}_u_co"], gb, do)
+            cq, ckv, co = self.ws[f"d{i}_cq"], self.ws[f"d{i}_ckv"], self.ws[f"d{i}_co"]
+            q4, k4, v4 = self.v4(cq, B, Ld, H, dk), self.v4(ckv, B, S, H, dk, 0), self.v4(ckv, B, S, H, dk, inner)
+            do4 = self.v4(do, B, Ld, H, dk)
+            ops.head_transpose(k4, out=kt_c)
+            ops.head_transpose(q4, out=qt_s)
+            ops.head_transpose(do4, out=dot_s)
+            ops.attention_bwd(q4, k4, v4, self.v4(co, B, Ld, H, dk), do4, kt_c, qt_s, dot_s, self.ws[f"d{i}_lsec"], delta,
+                              self.v4(dcq, B, Ld, H, dk), self.v4(dckv, B, S, H, dk, 0), self.v4(dckv, B, S, H, dk, inner),
+                              scale=1.0, kmask=kmask, drop=self.drop(L["sites"][2], p))
+            self.lg_bwd(L["ckv"], dckv, enc, self.ws[f"d{i}_u_ckv"], gbe, denc, residual=denc)
+            self.lg_bwd(L["cq"], dcq, self.ws[f"d{i}_xn1"], self.ws[f"d{i}_u_cq"], gb, dxn)
+            ops.rmsnorm_bwd(dxn, self.ws[f"d{i}_x1"], L["ln1"], c.t5_eps, other, dx_add=dx)
+            dx, other = other, dx
+            # self attention
+            ops.cast_dropout(dx, out_bf16=dyb, drop=self.drop(L["sites"][1], p))
+            self.lg_bwd(L["o"], dyb, self.ws[f"d{i}_o"], self.ws[f"d{i}_u_o"], gb, do)
+            qkv, o = self.ws[f"d{i}_qkv"], self.ws[f"d{i}_o"]
+            q4, k4, v4 = self.v4(qkv, B, Ld, H, dk, 0), self.v4(qkv, B, Ld, H, dk, inner), self.v4(qkv, B, Ld, H, dk, 2 * inner)
+            do4 = self.v4(do, B, Ld, H, dk)
+            ops.head_transpose(k4, out=kt_s)
+            ops.head_transpose(q4, out=qt_s)
+            ops.head_transpose(do4, out=dot_s)
+            ops.attention_bwd(q4, k4, v4, self.v4(o, B, Ld, H, dk), do4, kt_s, qt_s, dot_s, self.ws[f"d{i}_lse"], delta,
+                              self.v4(dqkv, B, Ld, H, dk, 0), self.v4(dqkv, B, Ld, H, dk, inner), self.v4(dqkv, B, Ld, H, dk, 2 * inner),
+                              scale=1.0, bias_lut=self.lut_dec, kmask=dmask, causal=True, drop=self.drop(L["sites"][0], p))
+            self.lg_bwd(L["qkv"], dqkv, self.ws[f"d{i}_xn"], self.ws[f"d{i}_u_qkv"], gb, dxn)
+            ops.rmsnorm_bwd(dxn, self.ws[f"d{i}_xin"], L["ln0"], c.t5_eps, other, dx_add=dx)
+            dx, other = other, dx
+        # the decoder embeddings are frozen: nothing flows below dx
+        return denc
+
+    # ------------------------------------------------------------------------------------------ whole step
+    @torch.no_grad()
+    def frames_forward(self, video: torch.Tensor):
+        """video fp32 [B,T,3,IMG,IMG] -> frames_for_t5 fp32 [B*T*n, d]   (blip2_mr.py:444-510)"""
+        c = self.cfg
+        Bv, T = video.shape[:2]
+        F_ = Bv * T
+        Tv = (c.img // c.patch) ** 2 + 1
+        xv = self.vit_forward(video.reshape(F_, 3, c.img, c.img))
+        img = self.buf("img", (F_ * Tv, pad64(c.vit_dim)), bf16)
+        ops.layernorm_fwd(xv, self.lnv_w, self.lnv_b, self.ln_vision_eps, out_bf16=img)
+        qb = self.qformer_forward(img, F_)
+        fr = self.buf("frames", (F_ * c.num_query, c.d_model), f32, zero=False)
+        ops.gemm(qb, self.proj_wb, fr, bias=self.proj_b)
+        if c.mean_pool:
+            pooled = self.buf("frames_pooled", (F_, c.d_model), f32, zero=False)
+            ops.mean_pool(fr.view(F_, c.num_query, c.d_model), pooled)
+            return pooled, img, xv, qb
+        return fr, img, xv, qb
+
+    @torch.no_grad()
+    def forward_backward(self, video: torch.Tensor, layout: EncoderLayout, backward: bool = True):
+        """One micro-step: loss (device scalar) and, if ``backward``, gradients accumulated into self.grad."""
+        c = self.cfg
+        Bv, T = video.shape[:2]
+        F_ = Bv * T
+        S, d = layout.S, c.d_model
+        n = 1 if c.mean_pool else c.num_query
+        if self.training:
+            ops.seed_bump(self.seed)
+        fr, img, xv, qb = self.frames_forward(video)
+        dev = self.dev
+        L = self._layout_dev(layout)
+        inp = self.buf("inputs_embeds", (Bv * S, d), f32, zero=False)
+        ops.row_copy(fr, L["frame_src"], inp, L["frame_dst"])
+        ops.row_copy(self.emb, L["emb_src"], inp, L["emb_dst"])
+        kmask = L["mask"]
+        enc = self.t5_encoder_forward(inp, Bv, S, kmask)
+        loss, logits = self.t5_decoder_forward(layout.decoder_input_ids, layout.decoder_mask, enc, Bv, S, kmask, layout.labels, want_grad=backward)
+        if not backward:
+            return loss
+        Ld = layout.labels.shape[1]
+        denc = self.t5_decoder_backward(enc, Bv, S, Ld, kmask, layout.decoder_mask)
+        dinp = self.t5_encoder_backward(denc, Bv, S, kmask)
+        # interleave backward: only frame-token rows carry gradient (embeddings are frozen)
+        dfr = self.buf("dframes", (F_ * n, d), f32)
+        ops.row_copy(dinp, L["frame_dst"], dfr, L["frame_src"])
+        if c.mean_pool:
+            dfull = self.buf("dframes_full", (F_, c.num_query, d), f32, zero=False)
+            ops.mean_pool_bwd(dfr, dfull)
+            dfr = dfull.view(F_ * c.num_query, d)
+        # t5_proj backward: dW = dfr^T x, db = colsum(dfr), dx = dfr W
+        Mq = F_ * c.num_query
+        dfb = self.buf("dframes_b", (Mq, pad64(d)), bf16)
+        ops.cast_dropout(dfr, out_bf16=dfb)
+        ops.colsum(dfr, self.dproj_b)
+        mp = pad64(Mq)
+        dft = self.buf("dframes_t", (d, mp), bf16)
+        self.transpose2d(dfb, d, dft)
+        Dq = c.qf_dim
+        qbt = self.buf("qb_t", (Dq, mp), bf16)
+        self.transpose2d(qb, Dq, qbt)
+        ops.gemm(dft, qbt, self.dproj_w, residual=self.dproj_w, K=mp)
+        dq_last = self.buf("dq_last", (Mq, Dq), f32, zero=False)
+        ops.gemm(dfb, self.proj_wtb, dq_last, K=pad64(d))
+        dimg = self.qformer_backward(dq_last, img, F_)
+        ops.layernorm_bwd(dimg, xv, self.lnv_w, self.ln_vision_eps, None, dgamma=self.dlnv_w, dbeta=self.dlnv_b)
+        return loss
+
+    def _layout_dev(self, layout: EncoderLayout):
+        dev = self.dev
+        return dict(frame_src=layout.frame_src.to(dev), frame_dst=layout.frame_dst.to(dev), emb_src=layout.emb_src.to(dev),
+                    emb_dst=layout.emb_dst.to(dev), mask=layout.attention_mask.to(dev).contiguous())
+
+    # ------------------------------------------------------------------------------------------ optimizer
+    @torch.no_grad()
+    def zero_grad(self):
+        self.grad.zero_()
+
+    @torch.no_grad()
+    def optimizer_step(self, lr: float, weight_decay: float = 0.05, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8,
+                       grad_scale: float = 1.0):
+        """AdamW(beta=(0.9,0.999), wd on >=2-D non-bias/ln params) as in runner_base.py:102-132."""
+        self.opt_step += 1
+        t = self.opt_step
+        self.hyper.copy_(torch.tensor([lr, 1.0 / (1 - beta1 ** t), 1.0 / math.sqrt(1 - beta2 ** t), grad_scale], dtype=f32))
+        nd = self.n_decay
+        ops.adamw(self.flat[:nd], self.grad[:nd], self.adam_m[:nd], self.adam_v[:nd], self.hyper, beta1, beta2, eps, weight_decay)
+        ops.adamw(self.flat[nd:], self.grad[nd:], self.adam_m[nd:], self.adam_v[nd:], self.hyper, beta1, beta2, eps, 0.0)
+        self.refresh_trainable()

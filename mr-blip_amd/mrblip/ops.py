@@ -50,7 +50,9 @@ _rms_bwd = _sig("mrblip_rmsnorm_bwd", vp, ll, vp, ll, vp, i32, i32, f32, vp, ll,
 _attn_fwd = _sig("mrblip_attention_fwd", vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp, vp, i32, vp, u32, f32, vp)
 _attn_bwd = _sig("mrblip_attention_bwd", vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
                  i32, i32, i32, i32, i32, f32, vp, vp, i32, vp, u32, f32, vp)
-_head_t = _sig("mrblip_head_transpose", vp, vp, vp, i32, i32, i32, i32, vp)
+_head_t = _sig("mrblip_head_transpose", vp, vp, vp, i32, i32, i32, i32, i32, vp)
+_colsum = _sig("mrblip_colsum", vp, ll, i32, i32, vp, vp)
+_pack_wext = _sig("mrblip_lora_pack_wext", vp, vp, vp, i32, i32, f32, vp)
 _patchify = _sig("mrblip_patchify", vp, vp, i32, i32, i32, i32, vp)
 _vit_asm = _sig("mrblip_vit_assemble", vp, vp, vp, vp, i32, i32, i32, vp)
 _row_copy = _sig("mrblip_row_copy", vp, ll, vp, vp, ll, vp, i32, i32, i32, vp)
@@ -71,7 +73,7 @@ EXPORTS = [
     "mrblip_layernorm_bwd", "mrblip_rmsnorm_bwd", "mrblip_attention_fwd", "mrblip_attention_bwd", "mrblip_head_transpose",
     "mrblip_patchify", "mrblip_vit_assemble", "mrblip_row_copy", "mrblip_mean_pool", "mrblip_mean_pool_bwd",
     "mrblip_cast_dropout", "mrblip_gelu_bwd", "mrblip_gated_gelu_bwd", "mrblip_cross_entropy", "mrblip_adamw",
-    "mrblip_seed_bump", "mrblip_lora_down", "mrblip_lora_dw", "mrblip_lora_dx_add",
+    "mrblip_seed_bump", "mrblip_lora_down", "mrblip_lora_dw", "mrblip_lora_dx_add", "mrblip_colsum", "mrblip_lora_pack_wext",
 ]
 
 
@@ -161,14 +163,23 @@ def rup32(n: int) -> int:
     return (n + 31) // 32 * 32
 
 
-def head_transpose(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """x: [B,S,H,D] view (bf16) -> [B,H,rup32(D),rup32(S)] zero-padded transposed copy."""
+def head_transpose(x: torch.Tensor, out: Optional[torch.Tensor] = None, spad: int = 0) -> torch.Tensor:
+    """x: [B,S,H,D] view (bf16) -> [B,H,rup32(D),spad or rup32(S)] zero-padded transposed copy."""
     _req(x, torch.bfloat16, "head_transpose.x")
     B, S, H, D = x.shape
     if out is None:
-        out = torch.empty(B, H, rup32(D), rup32(S), dtype=torch.bfloat16, device=x.device)
-    _chk(_head_t(_p(x), _strides3(x), _p(out), B, H, S, D, _stream()))
+        out = torch.empty(B, H, rup32(D), spad or rup32(S), dtype=torch.bfloat16, device=x.device)
+    _chk(_head_t(_p(x), _strides3(x), _p(out), B, H, S, D, spad, _stream()))
     return out
+
+
+def colsum(x, out):
+    M, N = x.shape
+    _chk(_colsum(_p(x), _ld(x), M, N, _p(out), _stream()))
+
+
+def lora_pack_wext(flat, wext, desc, n_adapters, max_out, scale=1.0):
+    _chk(_pack_wext(_p(flat), _p(wext), _p(desc), n_adapters, max_out, scale, _stream()))
 
 
 def attention_fwd(q, k, vt, o, lse=None, *, scale=1.0, bias_lut=None, kmask=None, causal=False, drop: Optional[Dropout] = None):

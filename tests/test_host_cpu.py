@@ -1,0 +1,75 @@
+"""Host-side integer logic of the product (mrblip.prompt) against the golden vectors and the pinned oracle: bit-exact
+timestamp-token indexing, interleave index map, masks, labels, relative-position LUT.  CPU only."""
+import numpy as np
+import torch
+
+from oracle import mrblip_oracle as O
+from mrblip import prompt as P
+from mrblip.tokenizer import FixtureTokenizer
+from util import TINY_CFG, load_golden, golden_state_dict
+
+
+def test_annoying_numbers_and_timestamps_match_golden():
+    tok = FixtureTokenizer()
+    g = load_golden("mr_tiny")
+    multi, _ = P.find_annoying_numbers(tok, 200)
+    assert multi == g["annoying"].tolist()
+    repl = P.annoying_replacement_dict(multi)
+    assert sorted(repl.items()) == [tuple(r) for r in g["annoying_map"].tolist()]
+    t = load_golden("timestamps")
+    ts, d = P.seconds_integers(torch.from_numpy(t["ts"]), torch.from_numpy(t["dur"]), repl)
+    assert ts[0] == t["out"].tolist() and d == t["out_dur"].tolist()
+
+
+def _layout_case(tag, mean):
+    g = load_golden(tag)
+    tok = FixtureTokenizer()
+    sd = golden_state_dict(g)
+    orc = O.Oracle(sd, TINY_CFG)
+    repl = P.annoying_replacement_dict(P.find_annoying_numbers(tok, 200)[0])
+    s = g["strings"]
+    samples = dict(video=torch.from_numpy(g["video"]), timestamps=torch.from_numpy(g["timestamps"]), duration=torch.from_numpy(g["duration"]),
+                   query_prompt=s["query_prompt"], task_prompt=s["task_prompt"], video_prompt_end=s["video_prompt_end"],
+                   relevant_windows=s["relevant_windows"])
+    with torch.no_grad():
+        out = orc.forward_mr(tok, samples, repl, mean_pool=mean)
+    n = 1 if mean else 8
+    lay = P.build_layout(tok, samples, repl, n, T=3)
+    B = 2
+    assert lay.S == g["inputs_embs"].shape[1]
+    assert torch.equal(lay.attention_mask.long(), torch.from_numpy(g["inputs_atts"]))          # bit-exact mask
+    assert torch.equal(lay.labels, torch.from_numpy(g["labels"]))                               # bit-exact labels
+    assert torch.equal(lay.decoder_input_ids, O.shift_right(torch.from_numpy(g["labels"])))
+    emb = sd["t5_model.shared.weight"]
+    frames = out["frames"].reshape(-1, emb.shape[1])
+    inp = torch.full((B * lay.S, emb.shape[1]), float("nan"))
+    inp[lay.frame_dst.long()] = frames[lay.frame_src.long()]
+    src = lay.emb_src.long()
+    rows = torch.where((src >= 0)[:, None], emb[src.clamp_min(0)], torch.zeros(1, emb.shape[1]))
+    inp[lay.emb_dst.long()] = rows
+    assert not torch.isnan(inp).any()                                                             # every row is covered exactly
+    assert len(set(lay.frame_dst.tolist()) | set(lay.emb_dst.tolist())) == B * lay.S
+    assert torch.equal(inp.reshape(B, lay.S, -1), out["inputs_embs"])                           # bit-exact interleave
+    assert np.allclose(inp.reshape(B, lay.S, -1).numpy(), g["inputs_embs"], rtol=0, atol=2e-5)
+
+
+def test_interleave_layout_bit_exact():
+    _layout_case("mr_tiny", False)
+
+
+def test_interleave_layout_meanpool_bit_exact():
+    _layout_case("mr_tiny_mean", True)
+
+
+def test_bias_lut_matches_bucket_golden():
+    g = load_golden("t5_buckets")
+    for bidir, key in ((True, "bidir"), (False, "unidir")):
+        got = [P.relative_position_bucket(int(r), bidir) for r in g["rel"]]
+        assert got == g[key].tolist()
+    table = torch.randn(32, 4)
+    orc = O.Oracle({}, TINY_CFG)
+    for bidir in (True, False):
+        lut = P.bias_lut(table, bidir)
+        ref = orc.t5_bias(table, 300, 300, bidir)[0]                       # [H, q, k]
+        rel = (torch.arange(300)[None, :] - torch.arange(300)[:, None]).clamp(-128, 128) + 128
+        assert torch.equal(lut[:, rel], ref)
