@@ -64,7 +64,8 @@ int mrblip_attention_bwd(const void* Q, const long long* q_strides, const void* 
                          const int* kmask, int causal, const uint32_t* seed_ptr, uint32_t site, float p_drop,
                          mrblip_stream_t stream);
 /* Spad: padded row length of the transposed copy (multiple of 32), 0 = roundup32(S) */
-int mrblip_head_transpose(const void* src, const long long* strides, void* dst, int B, int H, int S, int D, int Spad, mrblip_stream_t stream);
+int mrblip_head_transpose(const void* src, const long long* strides, void* dst, int B, int H, int S, int D, int Spad,
+                          const uint32_t* seed_ptr, uint32_t site, float p_drop, mrblip_stream_t stream);
 
 /* frames fp32 [F,3,IMG,IMG] -> bf16 patch rows [F*(IMG/P)^2, Kpad] in Conv2d weight order (eva_vit.py:196-203) */
 int mrblip_patchify(const float* video, void* out_bf16, int F, int IMG, int P, int Kpad, mrblip_stream_t stream);
@@ -90,19 +91,19 @@ int mrblip_cross_entropy(const float* logits, long long ldl, const int* labels, 
 int mrblip_adamw(float* p, const float* g, float* m, float* v, long long n, const float* hyper, float beta1, float beta2, float eps,
                  float weight_decay, mrblip_stream_t stream);
 int mrblip_seed_bump(uint32_t* seed, mrblip_stream_t stream);
-/* LoRA r=8 pieces (peft 0.13.0 Linear; blip2_mr.py:182-200,236): u = drop(x) A^T ; dW += drop(Y)^T U ; dx += mask*(G A) */
-int mrblip_lora_down(const void* x, long long ldx, const float* A, int M, int K, void* u, long long ldu, float scale,
-                     const uint32_t* seed_ptr, uint32_t site, float p, mrblip_stream_t stream);
-int mrblip_lora_dw(const void* Y, long long ldy, const void* U, long long ldu, int M, int C, float* dW, long long sc, long long sr,
-                   float scale, const uint32_t* seed_ptr, uint32_t site, float p, mrblip_stream_t stream);
-int mrblip_lora_dx_add(void* dx, long long lddx, int dx_f32, const void* G, long long ldg, const float* A, int M, int K, float scale,
+/* LoRA r=8 (peft 0.13.0 Linear; blip2_mr.py:182-200,236).  The rank-8 products themselves run on mrblip_gemm_bf16
+ * (u = drop(x) Acat^T, g = dy Bblk^T, dBt += u^T dy, dA += g^T drop(x) on transposed copies); these are the side pieces:
+ *   dx[m,k] += drop_mask(m,k) * sum_{r<R} G[m,r] Acat[r,k]   ;   out = dropout(x) bf16 -> bf16 (lora_dropout) */
+int mrblip_lora_dx_add(void* dx, long long lddx, int dx_f32, const void* G, long long ldg, const void* Acat_bf16, int R, int M, int K,
                        const uint32_t* seed_ptr, uint32_t site, float p, mrblip_stream_t stream);
-
+int mrblip_dropout_bf16(const void* x, long long ldx, void* out, long long ldo, int M, int N, const uint32_t* seed_ptr, uint32_t site,
+                        float p, mrblip_stream_t stream);
 /* out[c] += sum_m x[m,c] (bias gradient of t5_proj, blip2_mr.py:270-272) */
 int mrblip_colsum(const float* x, long long ldx, int M, int N, float* out, mrblip_stream_t stream);
-/* Wext[row, col..col+7] = bf16(scale * Bt[:, n]) for a device table of {bt_off, n_out, wext_off} triples */
-int mrblip_lora_pack_wext(const float* flat, void* wext_bf16, const long long* desc, int n_adapters, int max_out, float scale,
-                          mrblip_stream_t stream);
+/* fp32 LoRA master weights -> bf16 GEMM operands for every adapter of a device descriptor table (8 int64 per adapter:
+ * a_off, bt_off, K, out, acat_off, wext_off, bblk_off, Ntot) */
+int mrblip_lora_pack(const float* flat, void* acat_bf16, void* wext_bf16, void* bblk_bf16, const long long* desc, int n_adapters,
+                     float scale, mrblip_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -387,21 +387,39 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
   }
 }
 
-// ---- [B,S,H,D]-strided rows -> [B,H,DP,Spad] transposed, zero padded (Spad multiple of 32, DP multiple of 32)
-__global__ __launch_bounds__(256) void head_transpose_kernel(T4 src, bf16_t* dst, int S, int D, int DP, int Spad) {
-  __shared__ bf16_t tile[32][96 + 2];
+// ---- [B,S,H,D]-strided rows -> [B,H,DP,Spad] transposed, zero padded (Spad multiple of 32, DP multiple of 32).
+// 16-B loads along d, LDS tile, 16-B stores along s.  Optional dropout on the SOURCE elements (index = row * ncols + col of
+// the [B*S, H*D] matrix) so that drop(x)^T for the LoRA dA GEMM never has to be materialised un-transposed.
+__global__ __launch_bounds__(256) void head_transpose_kernel(T4 src, bf16_t* dst, int S, int D, int DP, int Spad, DropoutArg drop) {
+  __shared__ __attribute__((aligned(16))) bf16_t tile[32][96 + 8];
   const int b = blockIdx.z, h = blockIdx.y, s0 = blockIdx.x * 32;
   const bf16_t* sp = src.ptr + b * src.bs + h * src.hs;
-  for (int i = threadIdx.x; i < 32 * DP; i += 256) {
-    const int r = i / DP, d = i % DP;
-    const int s = s0 + r;
-    tile[r][d] = (s < S && d < D) ? sp[(long long)s * src.rs + d] : (bf16_t)0;
+  const int cpr = DP / 8;  // 16-B chunks per row
+  const uint32_t seed = drop.seed_ptr ? *drop.seed_ptr : 0u;
+  const int ncols = gridDim.y * D;
+  for (int i = threadIdx.x; i < 32 * cpr; i += 256) {
+    const int r = i / cpr, c8 = (i % cpr) * 8;
+    const int sidx = s0 + r;
+    bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (sidx < S && c8 < D) {
+      v = *reinterpret_cast<const bf16x8*>(sp + (long long)sidx * src.rs + c8);
+      if (drop.seed_ptr) {
+        const uint32_t base = (uint32_t)(b * S + sidx) * (uint32_t)ncols + (uint32_t)(h * D + c8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          v[j] = mrb_keep(base + j, seed, drop.site, drop.thresh24) ? (short)f2bf(bf2f((bf16_t)v[j]) * drop.inv_keep) : (short)0;
+      }
+    }
+    *reinterpret_cast<bf16x8*>(&tile[r][c8]) = v;
   }
   __syncthreads();
   bf16_t* dp = dst + ((long long)(b * gridDim.y + h) * DP) * Spad + s0;
-  for (int i = threadIdx.x; i < 32 * DP; i += 256) {
-    const int d = i / 32, r = i % 32;
-    dp[(long long)d * Spad + r] = tile[r][d];
+  for (int i = threadIdx.x; i < DP * 4; i += 256) {
+    const int d = i >> 2, q = (i & 3) * 8;
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (short)tile[q + j][d];
+    *reinterpret_cast<bf16x8*>(dp + (long long)d * Spad + q) = o;
   }
 }
 
@@ -478,12 +496,15 @@ extern "C" int mrblip_attention_bwd(const void* Q, const long long* q_strides, c
 }
 
 extern "C" int mrblip_head_transpose(const void* src, const long long* strides, void* dst, int B, int H, int S, int D, int Spad,
-                                     hipStream_t stream) {
+                                     const uint32_t* seed_ptr, uint32_t site, float p_drop, hipStream_t stream) {
   MRB_REQUIRE(B > 0 && H > 0 && S > 0 && D > 0 && D <= 96, "head_transpose: bad shape");
   const int DP = (D + 31) / 32 * 32;
   if (Spad <= 0) Spad = (S + 31) / 32 * 32;
   MRB_REQUIRE(Spad >= S && (Spad % 32) == 0, "head_transpose: Spad must be a multiple of 32 and >= S");
   T4 s{(const bf16_t*)src, strides[0], strides[1], strides[2]};
-  hipLaunchKernelGGL(head_transpose_kernel, dim3(Spad / 32, H, B), dim3(256), 0, stream, s, (bf16_t*)dst, S, D, DP, Spad);
+  MRB_REQUIRE((D % 8) == 0 && (strides[2] % 8) == 0 && ((uintptr_t)src % 16) == 0, "head_transpose: rows must be 16-B aligned, D %% 8 == 0");
+  AttnArgs tmp = {};
+  attn_drop(tmp, seed_ptr, site, p_drop);
+  hipLaunchKernelGGL(head_transpose_kernel, dim3(Spad / 32, H, B), dim3(256), 0, stream, s, (bf16_t*)dst, S, D, DP, Spad, tmp.drop);
   return mrblip_check_launch("head_transpose");
 }

@@ -198,91 +198,29 @@ __global__ void seed_bump_kernel(uint32_t* seed) { if (threadIdx.x == 0) *seed =
 
 // ---------------------------------------------------------------------------------------------------------
 // LoRA (peft 0.13.0 Linear, r = 8):  y = W x + scale * B (A dropout(x)).   blip2_mr.py:182-200, 236.
-// lora_down: u[m, c0..c0+7] = sum_k drop(x)[m,k] * bf16(A[r,k])      (x bf16 [M,K], A fp32 [8,K]); 4 rows per wave.
-__global__ __launch_bounds__(256) void lora_down_kernel(const bf16_t* __restrict__ x, long long ldx, const float* __restrict__ A, int M, int K,
-                                                        bf16_t* __restrict__ u, long long ldu, float scale, DropoutArg drop) {
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int m0 = (blockIdx.x * 4 + wv) * 4;
-  if (m0 >= M) return;
-  const uint32_t seed = drop.seed_ptr ? *drop.seed_ptr : 0u;
-  float acc[4][8];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int r = 0; r < 8; ++r) acc[i][r] = 0.f;
-  for (int k = lane * 8; k < K; k += 512) {
-    float a[8][8];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      const float4 a0 = *reinterpret_cast<const float4*>(A + (long long)r * K + k), a1 = *reinterpret_cast<const float4*>(A + (long long)r * K + k + 4);
-      a[r][0] = bf2f(f2bf(a0.x)); a[r][1] = bf2f(f2bf(a0.y)); a[r][2] = bf2f(f2bf(a0.z)); a[r][3] = bf2f(f2bf(a0.w));
-      a[r][4] = bf2f(f2bf(a1.x)); a[r][5] = bf2f(f2bf(a1.y)); a[r][6] = bf2f(f2bf(a1.z)); a[r][7] = bf2f(f2bf(a1.w));
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int m = m0 + i;
-      if (m < M) {
-        const bf16x8 xv = *reinterpret_cast<const bf16x8*>(x + (long long)m * ldx + k);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          float xf = bf2f((bf16_t)xv[j]);
-          if (drop.seed_ptr) xf = mrb_keep((uint32_t)m * (uint32_t)K + (uint32_t)(k + j), seed, drop.site, drop.thresh24) ? bf2f(f2bf(xf * drop.inv_keep)) : 0.f;
-#pragma unroll
-          for (int r = 0; r < 8; ++r) acc[i][r] += xf * a[r][j];
-        }
-      }
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    float o[8];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) o[r] = wave_sum(acc[i][r]) * scale;
-    if (lane == 0 && m0 + i < M)
-      *reinterpret_cast<uint4*>(u + (long long)(m0 + i) * ldu) = make_uint4(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7]));
-  }
-}
-
-// lora_dw: dW[c*sc + r*sr] += sum_m drop(Y)[m,c] * U[m,r]    (Y bf16 [M,C], U bf16 [M,8] at ldu, dW fp32)
-__global__ __launch_bounds__(256) void lora_dw_kernel(const bf16_t* __restrict__ Y, long long ldy, const bf16_t* __restrict__ U, long long ldu, int M,
-                                                      int C, int rows_per_block, float* __restrict__ dW, long long sc, long long sr, float scale, DropoutArg drop) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  const int mbeg = blockIdx.y * rows_per_block, mend = min(M, mbeg + rows_per_block);
-  const uint32_t seed = drop.seed_ptr ? *drop.seed_ptr : 0u;
-  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  if (c < C) {
-    for (int m = mbeg; m < mend; ++m) {
-      float y = bf2f(Y[(long long)m * ldy + c]);
-      if (drop.seed_ptr) y = mrb_keep((uint32_t)m * (uint32_t)C + (uint32_t)c, seed, drop.site, drop.thresh24) ? bf2f(f2bf(y * drop.inv_keep)) : 0.f;
-      const bf16x8 uv = *reinterpret_cast<const bf16x8*>(U + (long long)m * ldu);
-#pragma unroll
-      for (int r = 0; r < 8; ++r) acc[r] += y * bf2f((bf16_t)uv[r]);
-    }
-#pragma unroll
-    for (int r = 0; r < 8; ++r) atomicAdd(dW + (long long)c * sc + (long long)r * sr, acc[r] * scale);
-  }
-}
-
-// lora_dx_add: dx[m,k] += drop_mask(m,k) * sum_r G[m,r] * bf16(A[r,k])     (dx fp32 or bf16; G bf16 [M,8]; A fp32 [8,K])
+// lora_dx_add: dx[m,k] += drop_mask(m,k) * sum_{r<R} G[m,r] * Acat[r,k]     (dx fp32 or bf16; G bf16 [M,ldg]; Acat bf16 [R,K], R <= 32)
 template <bool DX_F32>
 __global__ __launch_bounds__(256) void lora_dx_add_kernel(void* __restrict__ dx_, long long lddx, const bf16_t* __restrict__ G, long long ldg,
-                                                          const float* __restrict__ A, int M, int K, float scale, DropoutArg drop) {
+                                                          const bf16_t* __restrict__ A, int R, int M, int K, DropoutArg drop) {
   const long long total4 = (long long)M * (K / 4);
   const uint32_t seed = drop.seed_ptr ? *drop.seed_ptr : 0u;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
     const int m = (int)(i / (K / 4)), k = (int)(i % (K / 4)) * 4;
-    const bf16x8 gv = *reinterpret_cast<const bf16x8*>(G + (long long)m * ldg);
     float add[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int r0 = 0; r0 < R; r0 += 8) {
+      const bf16x8 gv = *reinterpret_cast<const bf16x8*>(G + (long long)m * ldg + r0);
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      const float gr = bf2f((bf16_t)gv[r]);
-      const float4 a = *reinterpret_cast<const float4*>(A + (long long)r * K + k);
-      add[0] += gr * bf2f(f2bf(a.x)); add[1] += gr * bf2f(f2bf(a.y)); add[2] += gr * bf2f(f2bf(a.z)); add[3] += gr * bf2f(f2bf(a.w));
+      for (int r = 0; r < 8; ++r) {
+        const float gr = bf2f((bf16_t)gv[r]);
+        const uint2 a = *reinterpret_cast<const uint2*>(A + (long long)(r0 + r) * K + k);
+        add[0] += gr * bf2f((bf16_t)(a.x & 0xffff)); add[1] += gr * bf2f((bf16_t)(a.x >> 16));
+        add[2] += gr * bf2f((bf16_t)(a.y & 0xffff)); add[3] += gr * bf2f((bf16_t)(a.y >> 16));
+      }
     }
+    if (drop.seed_ptr) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      add[j] *= scale;
-      if (drop.seed_ptr) add[j] = mrb_keep((uint32_t)m * (uint32_t)K + (uint32_t)(k + j), seed, drop.site, drop.thresh24) ? add[j] * drop.inv_keep : 0.f;
+      for (int j = 0; j < 4; ++j)
+        add[j] = mrb_keep((uint32_t)m * (uint32_t)K + (uint32_t)(k + j), seed, drop.site, drop.thresh24) ? add[j] * drop.inv_keep : 0.f;
     }
     if (DX_F32) {
       float4* p = reinterpret_cast<float4*>(reinterpret_cast<float*>(dx_) + (long long)m * lddx + k);
@@ -299,6 +237,23 @@ __global__ __launch_bounds__(256) void lora_dx_add_kernel(void* __restrict__ dx_
   }
 }
 
+// bf16 -> dropout -> bf16 (LoRA input dropout, peft lora_dropout): idx = row * N + col
+__global__ __launch_bounds__(256) void dropout_bf16_kernel(const bf16_t* __restrict__ x, long long ldx, bf16_t* __restrict__ out, long long ldo, int M, int N, DropoutArg drop) {
+  const long long total8 = (long long)M * (N / 8);
+  const uint32_t seed = drop.seed_ptr ? *drop.seed_ptr : 0u;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total8; i += (long long)gridDim.x * 256) {
+    const int m = (int)(i / (N / 8)), c = (int)(i % (N / 8)) * 8;
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + (long long)m * ldx + c);
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      o[j] = bf2f((bf16_t)v[j]);
+      if (drop.seed_ptr) o[j] = mrb_keep((uint32_t)m * (uint32_t)N + (uint32_t)(c + j), seed, drop.site, drop.thresh24) ? o[j] * drop.inv_keep : 0.f;
+    }
+    *reinterpret_cast<uint4*>(out + (long long)m * ldo + c) = make_uint4(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7]));
+  }
+}
+
 // out[c] += sum_m x[m,c]  (bias gradients)
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, long long ldx, int M, int N, int rows_per_block, float* __restrict__ out) {
   const int c = blockIdx.x * 256 + threadIdx.x;
@@ -309,15 +264,24 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
   atomicAdd(out + c, acc);
 }
 
-// LoRA B -> K-extension operand of the GEMM: Wext[row0 + n, col0 + r] = bf16(scale * Bt[r, n]) for every adapter of a
-// descriptor table {bt_off, n_out, wext_off (elements, already including row0*64 + col0)} in device memory.
-__global__ __launch_bounds__(256) void lora_pack_wext_kernel(const float* __restrict__ flat, bf16_t* __restrict__ wext, const long long* __restrict__ desc, float scale) {
-  const long long bt_off = desc[blockIdx.y * 3 + 0], n_out = desc[blockIdx.y * 3 + 1], w_off = desc[blockIdx.y * 3 + 2];
-  for (long long n = (long long)blockIdx.x * 256 + threadIdx.x; n < n_out; n += (long long)gridDim.x * 256) {
+// LoRA master weights (fp32 flat buffer: A [8,K], Bt [8,out] per adapter) -> bf16 GEMM operands, one launch for all
+// adapters via a device descriptor table of 8 int64 per adapter {a_off, bt_off, K, out, acat_off, wext_off, bblk_off, Ntot}:
+//   acat[acat_off + r*K + k]      = bf16(scale * A[r,k])        (stacked [8*nad, K] "down" operand of a group)
+//   wext[wext_off + n*64 + r]     = bf16(Bt[r,n])               (K-extension operand of the forward GEMM)
+//   bblk[bblk_off + r*Ntot + n]   = bf16(scale * Bt[r,n])       (block-diagonal [8*nad, Ntot] operand of g = dy @ B)
+__global__ __launch_bounds__(256) void lora_pack_kernel(const float* __restrict__ flat, bf16_t* __restrict__ acat, bf16_t* __restrict__ wext,
+                                                        bf16_t* __restrict__ bblk, const long long* __restrict__ desc, float scale) {
+  const long long* d = desc + (long long)blockIdx.y * 8;
+  const long long a_off = d[0], bt_off = d[1], K = d[2], out = d[3], acat_off = d[4], wext_off = d[5], bblk_off = d[6], ntot = d[7];
+  const long long stride = (long long)gridDim.x * 256, t0 = (long long)blockIdx.x * 256 + threadIdx.x;
+  for (long long i = t0; i < 8 * K; i += stride) acat[acat_off + i] = f2bf(flat[a_off + i] * scale);
+  for (long long n = t0; n < out; n += stride) {
     float v[8];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) v[r] = flat[bt_off + r * n_out + n] * scale;
-    *reinterpret_cast<uint4*>(wext + w_off + n * 64) = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+    for (int r = 0; r < 8; ++r) v[r] = flat[bt_off + r * out + n];
+    *reinterpret_cast<uint4*>(wext + wext_off + n * 64) = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+#pragma unroll
+    for (int r = 0; r < 8; ++r) bblk[bblk_off + r * ntot + n] = f2bf(v[r] * scale);
   }
 }
 
@@ -394,36 +358,28 @@ extern "C" int mrblip_seed_bump(uint32_t* seed, hipStream_t stream) {
   hipLaunchKernelGGL(seed_bump_kernel, dim3(1), dim3(64), 0, stream, seed);
   return mrblip_check_launch("seed_bump");
 }
-extern "C" int mrblip_lora_down(const void* x, long long ldx, const float* A, int M, int K, void* u, long long ldu, float scale,
-                                const uint32_t* seed_ptr, uint32_t site, float p, hipStream_t stream) {
-  MRB_REQUIRE(M > 0 && K > 0 && K % 8 == 0 && ldx % 8 == 0 && ldu % 8 == 0, "lora_down: bad shape");
-  hipLaunchKernelGGL(lora_down_kernel, dim3((M + 15) / 16), dim3(256), 0, stream, (const bf16_t*)x, ldx, A, M, K, (bf16_t*)u, ldu, scale, mk_drop(seed_ptr, site, p));
-  return mrblip_check_launch("lora_down");
-}
-extern "C" int mrblip_lora_dw(const void* Y, long long ldy, const void* U, long long ldu, int M, int C, float* dW, long long sc, long long sr,
-                              float scale, const uint32_t* seed_ptr, uint32_t site, float p, hipStream_t stream) {
-  MRB_REQUIRE(M > 0 && C > 0 && ldu % 8 == 0, "lora_dw: bad shape");
-  const int rpb = 128;
-  hipLaunchKernelGGL(lora_dw_kernel, dim3((C + 255) / 256, (M + rpb - 1) / rpb), dim3(256), 0, stream, (const bf16_t*)Y, ldy, (const bf16_t*)U, ldu, M, C, rpb, dW, sc, sr, scale, mk_drop(seed_ptr, site, p));
-  return mrblip_check_launch("lora_dw");
-}
-extern "C" int mrblip_lora_dx_add(void* dx, long long lddx, int dx_f32, const void* G, long long ldg, const float* A, int M, int K, float scale,
+extern "C" int mrblip_lora_dx_add(void* dx, long long lddx, int dx_f32, const void* G, long long ldg, const void* Acat_bf16, int R, int M, int K,
                                   const uint32_t* seed_ptr, uint32_t site, float p, hipStream_t stream) {
-  MRB_REQUIRE(M > 0 && K > 0 && K % 4 == 0 && ldg % 8 == 0, "lora_dx_add: bad shape");
-  if (dx_f32) hipLaunchKernelGGL(lora_dx_add_kernel<true>, dim3(grid_for((long long)M * K / 4)), dim3(256), 0, stream, dx, lddx, (const bf16_t*)G, ldg, A, M, K, scale, mk_drop(seed_ptr, site, p));
-  else hipLaunchKernelGGL(lora_dx_add_kernel<false>, dim3(grid_for((long long)M * K / 4)), dim3(256), 0, stream, dx, lddx, (const bf16_t*)G, ldg, A, M, K, scale, mk_drop(seed_ptr, site, p));
+  MRB_REQUIRE(M > 0 && K > 0 && K % 4 == 0 && ldg % 8 == 0 && R > 0 && R <= 32 && R % 8 == 0, "lora_dx_add: bad shape");
+  if (dx_f32) hipLaunchKernelGGL(lora_dx_add_kernel<true>, dim3(grid_for((long long)M * K / 4)), dim3(256), 0, stream, dx, lddx, (const bf16_t*)G, ldg, (const bf16_t*)Acat_bf16, R, M, K, mk_drop(seed_ptr, site, p));
+  else hipLaunchKernelGGL(lora_dx_add_kernel<false>, dim3(grid_for((long long)M * K / 4)), dim3(256), 0, stream, dx, lddx, (const bf16_t*)G, ldg, (const bf16_t*)Acat_bf16, R, M, K, mk_drop(seed_ptr, site, p));
   return mrblip_check_launch("lora_dx_add");
 }
-
+extern "C" int mrblip_dropout_bf16(const void* x, long long ldx, void* out, long long ldo, int M, int N, const uint32_t* seed_ptr, uint32_t site,
+                                   float p, hipStream_t stream) {
+  MRB_REQUIRE(M > 0 && N > 0 && N % 8 == 0 && ldx % 8 == 0 && ldo % 8 == 0, "dropout_bf16: bad shape");
+  hipLaunchKernelGGL(dropout_bf16_kernel, dim3(grid_for((long long)M * N / 8)), dim3(256), 0, stream, (const bf16_t*)x, ldx, (bf16_t*)out, ldo, M, N, mk_drop(seed_ptr, site, p));
+  return mrblip_check_launch("dropout_bf16");
+}
 extern "C" int mrblip_colsum(const float* x, long long ldx, int M, int N, float* out, hipStream_t stream) {
   MRB_REQUIRE(M > 0 && N > 0, "colsum: bad shape");
   const int rpb = 64;
   hipLaunchKernelGGL(colsum_kernel, dim3((N + 255) / 256, (M + rpb - 1) / rpb), dim3(256), 0, stream, x, ldx, M, N, rpb, out);
   return mrblip_check_launch("colsum");
 }
-extern "C" int mrblip_lora_pack_wext(const float* flat, void* wext_bf16, const long long* desc, int n_adapters, int max_out, float scale,
-                                     hipStream_t stream) {
-  MRB_REQUIRE(n_adapters > 0 && max_out > 0, "lora_pack_wext: bad shape");
-  hipLaunchKernelGGL(lora_pack_wext_kernel, dim3((max_out + 255) / 256 > 8 ? 8 : (max_out + 255) / 256, n_adapters), dim3(256), 0, stream, flat, (bf16_t*)wext_bf16, desc, scale);
-  return mrblip_check_launch("lora_pack_wext");
+extern "C" int mrblip_lora_pack(const float* flat, void* acat_bf16, void* wext_bf16, void* bblk_bf16, const long long* desc, int n_adapters,
+                                float scale, hipStream_t stream) {
+  MRB_REQUIRE(n_adapters > 0, "lora_pack: bad shape");
+  hipLaunchKernelGGL(lora_pack_kernel, dim3(16, n_adapters), dim3(256), 0, stream, flat, (bf16_t*)acat_bf16, (bf16_t*)wext_bf16, (bf16_t*)bblk_bf16, desc, scale);
+  return mrblip_check_launch("lora_pack");
 }

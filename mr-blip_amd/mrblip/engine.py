@@ -141,7 +141,10 @@ class LoraGroup:
     N: int
     K: int
     adapters: List[Adapter] = field(default_factory=list)
-    wext: torch.Tensor = None  # bf16 [N, 64] view
+    wext: torch.Tensor = None  # bf16 [N, 64] view: B (K-extension operand of the forward GEMM)
+    acat: torch.Tensor = None  # bf16 [8*nad, K]: scale * A stacked ("down" operand)
+    bblk: torch.Tensor = None  # bf16 [8*nad, N]: scale * B^T block-diagonal (operand of g = dy @ B)
+    site: int = 0              # lora_dropout site (one mask per group input)
 
 
 class MrBlipEngine:
@@ -459,7 +462,7 @@ class MrBlipEngine:
         def group(names, in_dim, outs):
             w = torch.cat([W(n, (o, in_dim)) for n, o in zip(names, outs)])
             N = w.shape[0]
-            g = LoraGroup(W=self._w(w), Wt=self._w(w.t()), N=N, K=in_dim)
+            g = LoraGroup(W=self._w(w), Wt=self._w(w.t()), N=N, K=in_dim, site=self.new_site())
             row = 0
             for j, (n, o) in enumerate(zip(names, outs)):
                 a = Adapter(name=n, in_dim=in_dim, out=o, row0=row, col0=8 * j, site=self.new_site())
@@ -519,18 +522,26 @@ class MrBlipEngine:
         desc = []
         n_wext_rows = sum(g.N for g in groups)
         self.wext_all = torch.zeros(n_wext_rows, 64, dtype=bf16, device=self.dev)
-        wrow = 0
+        n_acat = sum(8 * len(g.adapters) * g.K for g in groups)
+        n_bblk = sum(8 * len(g.adapters) * g.N for g in groups)
+        self.acat_all = torch.zeros(n_acat, dtype=bf16, device=self.dev)
+        self.bblk_all = torch.zeros(n_bblk, dtype=bf16, device=self.dev)
+        wrow = aoff = boff = 0
         gen = torch.Generator(device="cpu").manual_seed(4321)
         for g in groups:
+            nad = len(g.adapters)
             g.wext = self.wext_all[wrow: wrow + g.N]
-            for a in g.adapters:
+            g.acat = self.acat_all[aoff: aoff + 8 * nad * g.K].view(8 * nad, g.K)
+            g.bblk = self.bblk_all[boff: boff + 8 * nad * g.N].view(8 * nad, g.N)
+            for j, a in enumerate(g.adapters):
                 a.a_off, a.bt_off = off, off + r * a.in_dim
                 a.A = self.flat[a.a_off: a.a_off + r * a.in_dim].view(r, a.in_dim)
                 a.Bt = self.flat[a.bt_off: a.bt_off + r * a.out].view(r, a.out)
                 a.dA = self.grad[a.a_off: a.a_off + r * a.in_dim].view(r, a.in_dim)
                 a.dBt = self.grad[a.bt_off: a.bt_off + r * a.out].view(r, a.out)
                 off += r * (a.in_dim + a.out)
-                desc.append([a.bt_off, a.out, (wrow + a.row0) * 64 + a.col0])
+                desc.append([a.a_off, a.bt_off, a.in_dim, a.out, aoff + 8 * j * g.K, (wrow + a.row0) * 64 + a.col0,
+                             boff + 8 * j * g.N + a.row0, g.N])
                 ka, kb = t + "base_model.model." + a.name + ".lora_A.default.weight", t + "base_model.model." + a.name + ".lora_B.default.weight"
                 if isinstance(src, StateDictSource) and ka in src.sd:
                     a.A.copy_(src.sd[ka])
@@ -541,9 +552,10 @@ class MrBlipEngine:
                     bound = 1.0 / math.sqrt(a.in_dim)
                     a.A.copy_((torch.rand(r, a.in_dim, generator=gen) * 2 - 1) * bound)
             wrow += g.N
+            aoff += 8 * nad * g.K
+            boff += 8 * nad * g.N
         self.adapters, self.groups = adapters, groups
         self.lora_desc = torch.tensor(desc, dtype=torch.int64, device=self.dev)
-        self.max_out = max(a.out for a in adapters)
         # t5_proj / ln_vision (trainable)
         self.proj_w = self.flat[off: off + d * Dq].view(d, Dq)
         self.dproj_w = self.grad[off: off + d * Dq].view(d, Dq)
@@ -562,44 +574,56 @@ class MrBlipEngine:
         self.proj_wtb = torch.zeros(Dq, pad64(d), dtype=bf16, device=self.dev)
         self.refresh_trainable()
 
-    def transpose2d(self, src: torch.Tensor, C: int, dst: torch.Tensor):
+    def transpose2d(self, src: torch.Tensor, C: int, dst: torch.Tensor, drop=None):
         """bf16 src[R, :C] (row stride src.stride(0)) -> dst[C, Rp] = src^T, zero padded to dst.shape[1] (multiple of 32)."""
         R = src.shape[0]
         hd = 64 if C % 64 == 0 else 32
         assert C % hd == 0 and dst.shape[0] == C and dst.shape[1] % 32 == 0 and dst.shape[1] >= R
         v = torch.as_strided(src, (1, R, C // hd, hd), (0, src.stride(0), hd, 1), src.storage_offset())
-        ops.head_transpose(v, out=dst.view(1, C // hd, hd, dst.shape[1]), spad=dst.shape[1])
+        ops.head_transpose(v, out=dst.view(1, C // hd, hd, dst.shape[1]), spad=dst.shape[1], drop=drop)
 
     @torch.no_grad()
     def refresh_trainable(self):
         """Re-derive the bf16 operand copies of the trainable tensors (after init / optimizer step / checkpoint load)."""
         c = self.cfg
-        ops.lora_pack_wext(self.flat, self.wext_all, self.lora_desc, len(self.adapters), self.max_out, self.lora_scale)
+        ops.lora_pack(self.flat, self.acat_all, self.wext_all, self.bblk_all, self.lora_desc, len(self.adapters), self.lora_scale)
         ops.cast_dropout(self.proj_w, out_bf16=self.proj_wb)
         self.transpose2d(self.proj_wb, c.qf_dim, self.proj_wtb)
 
     # ---- LoRA-group forward / backward -------------------------------------------------------------------------
     def lg_fwd(self, g: LoraGroup, x: torch.Tensor, u: torch.Tensor, out: torch.Tensor, **kw):
-        p = self.cfg.lora_dropout
-        xv = x[:, : g.K]
-        for a in g.adapters:
-            ops.lora_down(xv, a.A, u[:, a.col0:], drop=self.drop(a.site, p))
+        """out = x W^T + u B^T with u = dropout(x) (scale*A)^T:  the rank-8 "down" product is a thin GEMM on the MFMA kernel,
+        the "up" product rides in the main GEMM as a 64-wide K extension."""
+        drop = self.drop(g.site, self.cfg.lora_dropout)
+        src = x
+        if drop is not None:
+            src = self.buf(f"lg_xd_{x.shape[0]}_{x.shape[1]}", x.shape, bf16)
+            ops.dropout_bf16(x[:, : g.K], src, drop)
+        ops.gemm(src, g.acat, u, tile_cfg=3, K=g.K)
         ops.gemm(x, g.W, out, aext=u, wext=g.wext, **kw)
 
     def lg_bwd(self, g: LoraGroup, dy: torch.Tensor, x: torch.Tensor, u: torch.Tensor, gbuf: torch.Tensor, dx: Optional[torch.Tensor],
                residual: Optional[torch.Tensor] = None):
-        """dy bf16 [M,N]; x the saved bf16 input; u the saved [M,64] LoRA activations; dx = dy @ W (+ residual) + LoRA path."""
-        p, s = self.cfg.lora_dropout, self.lora_scale
-        xv = x[:, : g.K]
-        for a in g.adapters:
-            dya = dy[:, a.row0: a.row0 + a.out]
-            ops.lora_down(dya, a.Bt, gbuf[:, a.col0:], scale=s)
-            ops.lora_dw(dya, u[:, a.col0:], a.dBt, 1, a.out, scale=s)
-            ops.lora_dw(xv, gbuf[:, a.col0:], a.dA, 1, a.in_dim, drop=self.drop(a.site, p))
+        """dy bf16 [M,N]; x the saved bf16 input; u the saved [M,64] LoRA activations.  Accumulates dA, dB of every adapter of the
+        group and (optionally) dx = dy W (+ residual) + mask * (g A)."""
+        drop = self.drop(g.site, self.cfg.lora_dropout)
+        M = dy.shape[0]
+        Mp = pad64(M)
+        ops.gemm(dy, g.bblk, gbuf, tile_cfg=3, K=g.N)                      # g' = scale * dy @ B      [M, 8*nad]
+        dyT = self.buf(f"lg_dyT_{g.N}_{Mp}", (g.N, Mp), bf16)
+        self.transpose2d(dy, g.N, dyT)
+        xdT = self.buf(f"lg_xdT_{g.K}_{Mp}", (g.K, Mp), bf16)
+        self.transpose2d(x, g.K, xdT, drop=drop)                           # dropout(x)^T, same mask as the forward
+        uT = self.buf(f"lg_uT_{Mp}", (64, Mp), bf16)
+        gT = self.buf(f"lg_gT_{Mp}", (64, Mp), bf16)
+        self.transpose2d(u, 64, uT)
+        self.transpose2d(gbuf, 64, gT)
+        for j, a in enumerate(g.adapters):
+            ops.gemm(uT[8 * j: 8 * j + 8], dyT[a.row0: a.row0 + a.out], a.dBt, residual=a.dBt, tile_cfg=3, K=Mp)   # dB^T += u^T dy
+            ops.gemm(gT[8 * j: 8 * j + 8], xdT, a.dA, residual=a.dA, tile_cfg=3, K=Mp)                              # dA  += g^T drop(x)
         if dx is not None:
             ops.gemm(dy, g.Wt, dx, residual=residual, K=pad64(g.N))
-            for a in g.adapters:
-                ops.lora_dx_add(dx[:, : g.K], gbuf[:, a.col0:], a.A, drop=self.drop(a.site, p))
+            ops.lora_dx_add(dx[:, : g.K], gbuf, g.acat, drop=drop)
 
     # ---- encoder ---------------------------------------------------------------------------------------------
     @torch.no_grad()

@@ -50,9 +50,10 @@ _rms_bwd = _sig("mrblip_rmsnorm_bwd", vp, ll, vp, ll, vp, i32, i32, f32, vp, ll,
 _attn_fwd = _sig("mrblip_attention_fwd", vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp, vp, i32, vp, u32, f32, vp)
 _attn_bwd = _sig("mrblip_attention_bwd", vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
                  i32, i32, i32, i32, i32, f32, vp, vp, i32, vp, u32, f32, vp)
-_head_t = _sig("mrblip_head_transpose", vp, vp, vp, i32, i32, i32, i32, i32, vp)
+_head_t = _sig("mrblip_head_transpose", vp, vp, vp, i32, i32, i32, i32, i32, vp, u32, f32, vp)
 _colsum = _sig("mrblip_colsum", vp, ll, i32, i32, vp, vp)
-_pack_wext = _sig("mrblip_lora_pack_wext", vp, vp, vp, i32, i32, f32, vp)
+_lora_pack = _sig("mrblip_lora_pack", vp, vp, vp, vp, vp, i32, f32, vp)
+_drop_b16 = _sig("mrblip_dropout_bf16", vp, ll, vp, ll, i32, i32, vp, u32, f32, vp)
 _patchify = _sig("mrblip_patchify", vp, vp, i32, i32, i32, i32, vp)
 _vit_asm = _sig("mrblip_vit_assemble", vp, vp, vp, vp, i32, i32, i32, vp)
 _row_copy = _sig("mrblip_row_copy", vp, ll, vp, vp, ll, vp, i32, i32, i32, vp)
@@ -64,16 +65,14 @@ _gated_bwd = _sig("mrblip_gated_gelu_bwd", vp, ll, vp, ll, vp, ll, i32, i32, vp,
 _ce = _sig("mrblip_cross_entropy", vp, ll, vp, i32, i32, f32, vp, vp, ll, vp)
 _adamw = _sig("mrblip_adamw", vp, vp, vp, vp, ll, vp, f32, f32, f32, f32, vp)
 _seed_bump = _sig("mrblip_seed_bump", vp, vp)
-_lora_down = _sig("mrblip_lora_down", vp, ll, vp, i32, i32, vp, ll, f32, vp, u32, f32, vp)
-_lora_dw = _sig("mrblip_lora_dw", vp, ll, vp, ll, i32, i32, vp, ll, ll, f32, vp, u32, f32, vp)
-_lora_dx = _sig("mrblip_lora_dx_add", vp, ll, i32, vp, ll, vp, i32, i32, f32, vp, u32, f32, vp)
+_lora_dx = _sig("mrblip_lora_dx_add", vp, ll, i32, vp, ll, vp, i32, i32, i32, vp, u32, f32, vp)
 
 EXPORTS = [
     "mrblip_last_error", "mrblip_abi_version", "mrblip_gemm_bf16", "mrblip_layernorm_fwd", "mrblip_rmsnorm_fwd",
     "mrblip_layernorm_bwd", "mrblip_rmsnorm_bwd", "mrblip_attention_fwd", "mrblip_attention_bwd", "mrblip_head_transpose",
     "mrblip_patchify", "mrblip_vit_assemble", "mrblip_row_copy", "mrblip_mean_pool", "mrblip_mean_pool_bwd",
     "mrblip_cast_dropout", "mrblip_gelu_bwd", "mrblip_gated_gelu_bwd", "mrblip_cross_entropy", "mrblip_adamw",
-    "mrblip_seed_bump", "mrblip_lora_down", "mrblip_lora_dw", "mrblip_lora_dx_add", "mrblip_colsum", "mrblip_lora_pack_wext",
+    "mrblip_seed_bump", "mrblip_lora_dx_add", "mrblip_dropout_bf16", "mrblip_colsum", "mrblip_lora_pack",
 ]
 
 
@@ -163,13 +162,14 @@ def rup32(n: int) -> int:
     return (n + 31) // 32 * 32
 
 
-def head_transpose(x: torch.Tensor, out: Optional[torch.Tensor] = None, spad: int = 0) -> torch.Tensor:
+def head_transpose(x: torch.Tensor, out: Optional[torch.Tensor] = None, spad: int = 0, drop: Optional[Dropout] = None) -> torch.Tensor:
     """x: [B,S,H,D] view (bf16) -> [B,H,rup32(D),spad or rup32(S)] zero-padded transposed copy."""
     _req(x, torch.bfloat16, "head_transpose.x")
     B, S, H, D = x.shape
     if out is None:
         out = torch.empty(B, H, rup32(D), spad or rup32(S), dtype=torch.bfloat16, device=x.device)
-    _chk(_head_t(_p(x), _strides3(x), _p(out), B, H, S, D, spad, _stream()))
+    sp, site, p = _d(drop)
+    _chk(_head_t(_p(x), _strides3(x), _p(out), B, H, S, D, spad, sp, site, p, _stream()))
     return out
 
 
@@ -178,8 +178,14 @@ def colsum(x, out):
     _chk(_colsum(_p(x), _ld(x), M, N, _p(out), _stream()))
 
 
-def lora_pack_wext(flat, wext, desc, n_adapters, max_out, scale=1.0):
-    _chk(_pack_wext(_p(flat), _p(wext), _p(desc), n_adapters, max_out, scale, _stream()))
+def lora_pack(flat, acat, wext, bblk, desc, n_adapters, scale=1.0):
+    _chk(_lora_pack(_p(flat), _p(acat), _p(wext), _p(bblk), _p(desc), n_adapters, scale, _stream()))
+
+
+def dropout_bf16(x, out, drop: Optional[Dropout] = None):
+    M, N = x.shape
+    sp, site, p = _d(drop)
+    _chk(_drop_b16(_p(x), _ld(x), _p(out), _ld(out), M, N, sp, site, p, _stream()))
 
 
 def attention_fwd(q, k, vt, o, lse=None, *, scale=1.0, bias_lut=None, kmask=None, causal=False, drop: Optional[Dropout] = None):
@@ -256,21 +262,8 @@ def seed_bump(seed):
     _chk(_seed_bump(_p(seed), _stream()))
 
 
-def lora_down(x, A, u, scale=1.0, drop: Optional[Dropout] = None):
-    """u[:, :8] = drop(x) @ bf16(A)^T * scale;  x bf16 [M,K], A fp32 [8,K], u: bf16 view whose first 8 columns are written."""
-    M, K = x.shape
-    sp, site, p = _d(drop)
-    _chk(_lora_down(_p(x), _ld(x), _p(A), M, K, _p(u), _ld(u), scale, sp, site, p, _stream()))
-
-
-def lora_dw(Y, U, dW, sc, sr, scale=1.0, drop: Optional[Dropout] = None):
-    """dW[c*sc + r*sr] += sum_m drop(Y)[m,c] * U[m,r]"""
-    M, Cc = Y.shape
-    sp, site, p = _d(drop)
-    _chk(_lora_dw(_p(Y), _ld(Y), _p(U), _ld(U), M, Cc, _p(dW), sc, sr, scale, sp, site, p, _stream()))
-
-
-def lora_dx_add(dx, G, A, scale=1.0, drop: Optional[Dropout] = None):
+def lora_dx_add(dx, G, acat, drop: Optional[Dropout] = None):
+    """dx[m,k] += mask(m,k) * sum_r G[m,r] * acat[r,k];  acat bf16 [R,K]"""
     M, K = dx.shape
     sp, site, p = _d(drop)
-    _chk(_lora_dx(_p(dx), _ld(dx), 1 if dx.dtype == torch.float32 else 0, _p(G), _ld(G), _p(A), M, K, scale, sp, site, p, _stream()))
+    _chk(_lora_dx(_p(dx), _ld(dx), 1 if dx.dtype == torch.float32 else 0, _p(G), _ld(G), _p(acat), acat.shape[0], M, K, sp, site, p, _stream()))

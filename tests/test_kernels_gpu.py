@@ -300,32 +300,53 @@ def test_cast_gelu_ce_adamw(ops):
 
 
 def test_lora_pieces(ops):
+    """LoRA side kernels: lora_dropout (bf16->bf16), the transposing copy with the same mask, dx += mask*(G A), operand packing."""
     torch.manual_seed(9)
-    M, K, Cc = 101, 256, 200
+    M, K = 101, 256
     x = bf(torch.randn(M, K, device=dev()))
-    A = torch.randn(8, K, device=dev()) * 0.1
     seed = torch.tensor([77], dtype=torch.int32, device=dev())
     drop = ops.Dropout(seed, 21, 0.05)
-    u = torch.zeros(M, 64, dtype=torch.bfloat16, device=dev())
-    ops.lora_down(x, A, u[:, 8:], drop=drop)
     mask = keep_mask((M, K), 77, 21, 0.05)
-    xd = (x.float() * mask / 0.95).bfloat16().float()
-    ref = xd @ A.bfloat16().float().t()
-    assert rel(u[:, 8:16].float(), ref) < 3e-3 and u[:, :8].abs().max() == 0 and u[:, 16:].abs().max() == 0
-    # dW[c, r] += sum_m drop(Y)[m,c] U[m,r]   (both output orientations)
-    U = bf(torch.randn(M, 8, device=dev()))
-    Upad = torch.zeros(M, 64, dtype=torch.bfloat16, device=dev())
-    Upad[:, :8] = U
-    dB = torch.zeros(K, 8, device=dev())
-    ops.lora_dw(x, Upad, dB, 8, 1, drop=drop)
-    assert rel(dB, xd.t() @ U.float()) < 1e-5
-    dAt = torch.zeros(8, K, device=dev())
-    ops.lora_dw(x, Upad, dAt, 1, K, drop=drop)
-    assert rel(dAt, (xd.t() @ U.float()).t()) < 1e-5
-    # dx += mask * (G A)
+    xd = torch.zeros_like(x)
+    ops.dropout_bf16(x, xd, drop)
+    ref = (x.float() * mask / 0.95).bfloat16()
+    assert torch.equal(xd, ref)
+    # transposed copy of dropout(x): [K, Mpad] through the head-transpose kernel with the same mask
+    Mp = 128
+    xt = torch.full((K, Mp), 9.0, dtype=torch.bfloat16, device=dev())
+    v = torch.as_strided(x, (1, M, K // 64, 64), (0, x.stride(0), 64, 1))
+    ops.head_transpose(v, out=xt.view(1, K // 64, 64, Mp), spad=Mp, drop=drop)
+    assert torch.equal(xt[:, :M], ref.t()) and xt[:, M:].abs().sum() == 0
+    # dx += mask * (G Acat)
+    R = 16
+    G = torch.zeros(M, 64, dtype=torch.bfloat16, device=dev())
+    G[:, :R] = bf(torch.randn(M, R, device=dev()))
+    A = bf(torch.randn(R, K, device=dev()) * 0.1)
     for dt in (torch.float32, torch.bfloat16):
         dx0 = torch.randn(M, K, device=dev()).to(dt)
         dx = dx0.clone()
-        ops.lora_dx_add(dx, Upad, A, drop=drop)
-        ref = dx0.float() + (U.float() @ A.bfloat16().float()) * mask / 0.95
-        assert rel(dx.float(), ref) < (1e-6 if dt == torch.float32 else 4e-3)
+        ops.lora_dx_add(dx, G, A, drop=drop)
+        want = dx0.float() + (G[:, :R].float() @ A.float()) * mask / 0.95
+        assert rel(dx.float(), want) < (1e-6 if dt == torch.float32 else 4e-3)
+    # packing: A [8,K], Bt [8,out] fp32 -> acat (scaled), wext, bblk (block-diagonal, scaled)
+    out_, Ntot, row0, col0 = 72, 200, 64, 8
+    flat = torch.randn(8 * K + 8 * out_, device=dev())
+    acat = torch.zeros(16 * K, dtype=torch.bfloat16, device=dev())
+    wext = torch.zeros(Ntot * 64, dtype=torch.bfloat16, device=dev())
+    bblk = torch.zeros(16 * Ntot, dtype=torch.bfloat16, device=dev())
+    desc = torch.tensor([[0, 8 * K, K, out_, 8 * K, row0 * 64 + col0, 8 * Ntot + row0, Ntot]], dtype=torch.int64, device=dev())
+    ops.lora_pack(flat, acat, wext, bblk, desc, 1, scale=2.0)
+    Af, Bt = flat[: 8 * K].view(8, K), flat[8 * K:].view(8, out_)
+    assert torch.equal(acat.view(16, K)[8:], (Af * 2).bfloat16()) and acat.view(16, K)[:8].abs().sum() == 0
+    assert torch.equal(wext.view(Ntot, 64)[row0: row0 + out_, col0: col0 + 8], Bt.t().bfloat16())
+    assert torch.equal(bblk.view(16, Ntot)[8:, row0: row0 + out_], (Bt * 2).bfloat16())
+    assert wext.float().abs().sum() == Bt.t().bfloat16().float().abs().sum()
+    # the thin rank-8 products run on the GEMM kernel: u = x A^T (N=8), dB^T += u^T dy via transposed operands (M'=8 rows)
+    u = torch.zeros(M, 64, dtype=torch.bfloat16, device=dev())
+    ops.gemm(x, acat.view(16, K), u, tile_cfg=3)
+    assert rel(u[:, :16].float(), x.float() @ acat.view(16, K).float().t()) < 3e-3 and u[:, 16:].abs().sum() == 0
+    uT = torch.zeros(64, Mp, dtype=torch.bfloat16, device=dev())
+    ops.head_transpose(torch.as_strided(u, (1, M, 1, 64), (0, 64, 64, 1)), out=uT.view(1, 1, 64, Mp), spad=Mp)
+    dW = torch.ones(8, K, device=dev())
+    ops.gemm(uT[8:16], xt, dW, residual=dW, tile_cfg=3, K=Mp)
+    assert rel(dW, 1 + u[:, 8:16].float().t() @ ref.float()) < 1e-5
