@@ -12,6 +12,10 @@
 // (bits 2 and 3 of the row index swapped), which is a free address permutation.  V^T (and K^T, Q^T, dO^T for
 // the backward) are [B,H,DP,Spad] transposed copies produced by mrblip_head_transpose, zero padded so padded
 // keys/dims contribute exact zeros.  K/V tiles are re-read by every wave from L2 (per-head K+V are L2-resident).
+// The per-element work is specialised at compile time (FLAGS: LUT bias / key mask / causal / dropout / key-split)
+// and is branch-free: loads use clamped addresses + selects, the 16 LUT reads of a tile are issued together, the
+// key mask arrives as four 16-B loads per tile.  With few queries (decoder cross-attention, Sq <= 32) the four
+// waves of a block split the key range and merge their partial (m, l, O) / dQ through LDS.
 #include "common.h"
 
 struct T4 {  // element (b,h,s,d) at ptr + b*bs + h*hs + s*rs + d   (row-major in d)
@@ -29,17 +33,21 @@ struct AttnArgs {
   float* LSE;          // [B,H,Sqpad]
   float* Delta;        // [B,H,Sqpad]
   const float* lut;    // [H,257] relative-position bias by clamp(key - q, -128, 128) + 128, or nullptr
-  const int* kmask;    // [B,Sk] 1 = attend, or nullptr
-  int B, H, Sq, Sk, D, Sqpad;
-  int causal;
+  const int* kmask;    // [B,Skpad] 1 = attend (padded to a multiple of 32 ints per row), or nullptr
+  int B, H, Sq, Sk, D, Sqpad, Skpad;
   float scale;
   DropoutArg drop;
 };
 
+enum { F_LUT = 1, F_MASK = 2, F_CAUSAL = 4, F_DROP = 8, F_SPLIT = 16 };
 #define NEG_BIG (-1.0e30f)
 
 __device__ __forceinline__ int perm23(int i) { return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1); }
 __device__ __forceinline__ bf16x8 ld8(const bf16_t* p) { return *reinterpret_cast<const bf16x8*>(p); }
+__device__ __forceinline__ bf16x8 sel8(bool ok, bf16x8 v) {
+  const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+  return ok ? v : z;
+}
 __device__ __forceinline__ bf16x8 pack8(const float* v) {
   union { bf16x8 v8; uint32_t u[4]; } r;
   r.u[0] = pack2bf(v[0], v[1]); r.u[1] = pack2bf(v[2], v[3]); r.u[2] = pack2bf(v[4], v[5]); r.u[3] = pack2bf(v[6], v[7]);
@@ -50,72 +58,105 @@ __device__ __forceinline__ void zero16(f32x16& a) {
   for (int r = 0; r < 16; ++r) a[r] = 0.f;
 }
 
-template <int DP>
+// rows of a row-major [S, D] head slice as MFMA fragments: lane (row, hi) gets d = 16 s + 8 hi .. +7, zero outside.
+// Branch-free: the address is clamped into the tensor and the value selected afterwards.
+template <int KS>
+__device__ __forceinline__ void load_rows(bf16x8 (&f)[KS], const bf16_t* base, long long rs, int row, int nrows, int D, int hi) {
+  const bool r_ok = row < nrows;
+  const bf16_t* rp = base + (long long)min(row, nrows - 1) * rs;
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    const int d0 = 16 * s + 8 * hi;
+    f[s] = sel8(r_ok && d0 < D, ld8(rp + min(d0, D - 8)));
+  }
+}
+
+// valid-key bits of one 32-key tile for this lane's 16 keys (k0 + 16c + 8hi + j), from four 16-B loads
+__device__ __forceinline__ uint32_t mask_bits(const int* km, int k0, int hi) {
+  uint32_t bits = 0;
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const int4 a = *reinterpret_cast<const int4*>(km + k0 + 16 * c + 8 * hi), b = *reinterpret_cast<const int4*>(km + k0 + 16 * c + 8 * hi + 4);
+    bits |= (uint32_t)(a.x != 0) << (8 * c + 0); bits |= (uint32_t)(a.y != 0) << (8 * c + 1);
+    bits |= (uint32_t)(a.z != 0) << (8 * c + 2); bits |= (uint32_t)(a.w != 0) << (8 * c + 3);
+    bits |= (uint32_t)(b.x != 0) << (8 * c + 4); bits |= (uint32_t)(b.y != 0) << (8 * c + 5);
+    bits |= (uint32_t)(b.z != 0) << (8 * c + 6); bits |= (uint32_t)(b.w != 0) << (8 * c + 7);
+  }
+  return bits;
+}
+
+template <int DP, int FLAGS>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
   constexpr int KS = DP / 16, MT = DP / 32;
-  __shared__ float lut[257];
+  constexpr bool LUT = FLAGS & F_LUT, MASK = FLAGS & F_MASK, CAUSAL = FLAGS & F_CAUSAL, DROP = FLAGS & F_DROP, SPLIT = FLAGS & F_SPLIT;
+  __shared__ float lut[LUT ? 257 : 1];
+  __shared__ float red[SPLIT ? 3 * (MT * 16 + 2) * 64 : 1];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, hi = lane >> 5, l31 = lane & 31;
   const int b = blockIdx.z, h = blockIdx.y;
-  if (p.lut) {
+  if (LUT) {
     for (int i = threadIdx.x; i < 257; i += 256) lut[i] = p.lut[h * 257 + i];
+    __syncthreads();
   }
-  __syncthreads();
-  const int q0 = (blockIdx.x * 4 + w) * 32;
-  if (q0 >= p.Sq) return;
+  const int q0 = SPLIT ? blockIdx.x * 32 : (blockIdx.x * 4 + w) * 32;
+  if (!SPLIT && q0 >= p.Sq) return;
   const int q = q0 + l31;
   const bool q_ok = q < p.Sq;
-  const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
   bf16x8 qf[KS];
-  {
-    const bf16_t* qp = p.Q.ptr + b * p.Q.bs + h * p.Q.hs + (long long)q * p.Q.rs;
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      const int d0 = 16 * s + 8 * hi;
-      qf[s] = (q_ok && d0 < p.D) ? ld8(qp + d0) : zero;
-    }
-  }
+  load_rows<KS>(qf, p.Q.ptr + b * p.Q.bs + h * p.Q.hs, p.Q.rs, q, p.Sq, p.D, hi);
   float m_run = NEG_BIG, l_run = 0.f;
   f32x16 o[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) zero16(o[mt]);
-  const int kend = p.causal ? min(p.Sk, q0 + 32) : p.Sk;
+  const int kend = CAUSAL ? min(p.Sk, q0 + 32) : p.Sk;
   const bf16_t* kbase = p.K.ptr + b * p.K.bs + h * p.K.hs;
   const bf16_t* vtbase = p.Vt.ptr + b * p.Vt.bs + h * p.Vt.hs;
-  const int* km = p.kmask ? p.kmask + (long long)b * p.Sk : nullptr;
-  const uint32_t drop_seed = p.drop.seed_ptr ? *p.drop.seed_ptr : 0u;
+  const int* km = MASK ? p.kmask + (long long)b * p.Skpad : nullptr;
+  const uint32_t drop_seed = DROP ? *p.drop.seed_ptr : 0u;
   const uint32_t row_idx = ((uint32_t)(b * p.H + h) * (uint32_t)p.Sq + (uint32_t)q) * (uint32_t)p.Sk;
+  const int kstart = SPLIT ? w * 32 : 0, kstep = SPLIT ? 128 : 32;
 
-  for (int k0 = 0; k0 < kend; k0 += 32) {
+  // software pipeline: K fragments of the next tile and V^T fragments of this tile are in flight during the score math
+  bf16x8 kcur[KS];
+  load_rows<KS>(kcur, kbase, p.K.rs, kstart + perm23(l31), p.Sk, p.D, hi);
+  for (int k0 = kstart; k0 < kend; k0 += kstep) {
+    bf16x8 vf[MT][2];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const bf16_t* vp = vtbase + (long long)(mt * 32 + l31) * p.Vt.ds + k0 + 8 * hi;
+      vf[mt][0] = ld8(vp);
+      vf[mt][1] = ld8(vp + 16);
+    }
+    uint32_t vmask = 0xffffu;
+    if (MASK) vmask = mask_bits(km, k0, hi);
+    bf16x8 knext[KS];
+    load_rows<KS>(knext, kbase, p.K.rs, k0 + kstep + perm23(l31), p.Sk, p.D, hi);
     f32x16 sacc;
     zero16(sacc);
-    {
-      const int krow = k0 + perm23(l31);
-      const bool k_ok = krow < p.Sk;
-      const bf16_t* kp = kbase + (long long)krow * p.K.rs;
 #pragma unroll
-      for (int s = 0; s < KS; ++s) {
-        const int d0 = 16 * s + 8 * hi;
-        const bf16x8 kf = (k_ok && d0 < p.D) ? ld8(kp + d0) : zero;
-        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc, 0, 0, 0);
-      }
-    }
+    for (int s = 0; s < KS; ++s) sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kcur[s], qf[s], sacc, 0, 0, 0);
+    // lane (q, hi), register r  <->  key k0 + 16*(r>>3) + 8*hi + (r&7)
     float sv[16];
-    uint32_t vmask = 0;
+    if (LUT) {
+      float bias[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rel = (k0 + 16 * (r >> 3) + 8 * hi + (r & 7)) - q;
+        bias[r] = lut[max(-128, min(128, rel)) + 128];
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sv[r] = sacc[r] * p.scale + bias[r];
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sv[r] = sacc[r] * p.scale;
+    }
     float mx = NEG_BIG;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int key = k0 + 16 * (r >> 3) + 8 * hi + (r & 7);
-      float val = sacc[r] * p.scale;
-      if (p.lut) {
-        int rel = key - q;
-        rel = max(-128, min(128, rel));
-        val += lut[rel + 128];
-      }
       bool ok = key < p.Sk;
-      if (p.causal) ok = ok && (key <= q);
-      if (km) ok = ok && (km[min(key, p.Sk - 1)] != 0);
-      sv[r] = val;
-      if (ok) { vmask |= 1u << r; mx = fmaxf(mx, val); }
+      if (CAUSAL) ok = ok && (key <= q);
+      if (!ok) vmask &= ~(1u << r);
+      mx = fmaxf(mx, ((vmask >> r) & 1u) ? sv[r] : NEG_BIG);
     }
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_new = fmaxf(m_run, mx);
@@ -124,9 +165,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
     float pv[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      float e = (vmask >> r) & 1u ? __expf(sv[r] - m_new) : 0.f;
+      float e = ((vmask >> r) & 1u) ? __expf(sv[r] - m_new) : 0.f;
       psum += e;
-      if (p.drop.seed_ptr) {
+      if (DROP) {
         const int key = k0 + 16 * (r >> 3) + 8 * hi + (r & 7);
         e = mrb_keep(row_idx + (uint32_t)key, drop_seed, p.drop.site, p.drop.thresh24) ? e * p.drop.inv_keep : 0.f;
       }
@@ -141,12 +182,47 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
     const bf16x8 pf0 = pack8(pv), pf1 = pack8(pv + 8);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-      const bf16_t* vp = vtbase + (long long)(mt * 32 + l31) * p.Vt.ds + k0 + 8 * hi;
-      o[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld8(vp), pf0, o[mt], 0, 0, 0);
-      o[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld8(vp + 16), pf1, o[mt], 0, 0, 0);
+      o[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[mt][0], pf0, o[mt], 0, 0, 0);
+      o[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[mt][1], pf1, o[mt], 0, 0, 0);
     }
+#pragma unroll
+    for (int s = 0; s < KS; ++s) kcur[s] = knext[s];
   }
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  if (SPLIT) {  // merge the four key-range partials: wave 0 collects (m, l, O) of waves 1..3
+    constexpr int STR = (MT * 16 + 2) * 64;
+    if (w > 0) {
+      float* r = red + (w - 1) * STR;
+      r[lane] = m_run;
+      r[64 + lane] = l_tot;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) r[(2 + mt * 16 + i) * 64 + lane] = o[mt][i];
+    }
+    __syncthreads();
+    if (w > 0) return;
+    float m_all = m_run;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) m_all = fmaxf(m_all, red[j * STR + lane]);
+    const float f0 = __expf(m_run - m_all);
+    l_tot *= f0;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) o[mt][i] *= f0;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const float* r = red + j * STR;
+      const float fj = __expf(r[lane] - m_all);
+      l_tot += r[64 + lane] * fj;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[mt][i] += r[(2 + mt * 16 + i) * 64 + lane] * fj;
+    }
+    m_run = m_all;
+  }
   const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
   if (q_ok) {
     bf16_t* op = const_cast<bf16_t*>(p.O.ptr) + b * p.O.bs + h * p.O.hs + (long long)q * p.O.rs;
@@ -164,96 +240,125 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
 }
 
 // ---- backward, part 1: dQ (and Delta = rowsum(dO * O), needed by part 2).  Same ownership as the forward.
-template <int DP>
+template <int DP, int FLAGS>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
   constexpr int KS = DP / 16, MT = DP / 32;
-  __shared__ float lut[257];
+  constexpr bool LUT = FLAGS & F_LUT, MASK = FLAGS & F_MASK, CAUSAL = FLAGS & F_CAUSAL, DROP = FLAGS & F_DROP, SPLIT = FLAGS & F_SPLIT;
+  __shared__ float lut[LUT ? 257 : 1];
+  __shared__ float red[SPLIT ? 3 * MT * 16 * 64 : 1];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, hi = lane >> 5, l31 = lane & 31;
   const int b = blockIdx.z, h = blockIdx.y;
-  if (p.lut) {
+  if (LUT) {
     for (int i = threadIdx.x; i < 257; i += 256) lut[i] = p.lut[h * 257 + i];
+    __syncthreads();
   }
-  __syncthreads();
-  const int q0 = (blockIdx.x * 4 + w) * 32;
-  if (q0 >= p.Sq) return;
+  const int q0 = SPLIT ? blockIdx.x * 32 : (blockIdx.x * 4 + w) * 32;
+  if (!SPLIT && q0 >= p.Sq) return;
   const int q = q0 + l31;
   const bool q_ok = q < p.Sq;
-  const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
   bf16x8 qf[KS], dof[KS];
   float delta = 0.f;
   {
-    const bf16_t* qp = p.Q.ptr + b * p.Q.bs + h * p.Q.hs + (long long)q * p.Q.rs;
-    const bf16_t* dp = p.dO.ptr + b * p.dO.bs + h * p.dO.hs + (long long)q * p.dO.rs;
-    const bf16_t* op = p.O.ptr + b * p.O.bs + h * p.O.hs + (long long)q * p.O.rs;
+    load_rows<KS>(qf, p.Q.ptr + b * p.Q.bs + h * p.Q.hs, p.Q.rs, q, p.Sq, p.D, hi);
+    load_rows<KS>(dof, p.dO.ptr + b * p.dO.bs + h * p.dO.hs, p.dO.rs, q, p.Sq, p.D, hi);
+    bf16x8 of[KS];
+    load_rows<KS>(of, p.O.ptr + b * p.O.bs + h * p.O.hs, p.O.rs, q, p.Sq, p.D, hi);
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      const int d0 = 16 * s + 8 * hi;
-      const bool ok = q_ok && d0 < p.D;
-      qf[s] = ok ? ld8(qp + d0) : zero;
-      dof[s] = ok ? ld8(dp + d0) : zero;
-      const bf16x8 of = ok ? ld8(op + d0) : zero;
+    for (int s = 0; s < KS; ++s)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) delta += bf2f((bf16_t)dof[s][j]) * bf2f((bf16_t)of[j]);
-    }
+      for (int j = 0; j < 8; ++j) delta += bf2f((bf16_t)dof[s][j]) * bf2f((bf16_t)of[s][j]);
   }
   delta += __shfl_xor(delta, 32, 64);
-  const long long stat_off = ((long long)(b * p.H + h)) * p.Sqpad + q;
+  const long long stat_off = ((long long)(b * p.H + h)) * p.Sqpad + min(q, p.Sqpad - 1);
   const float lse = q_ok ? p.LSE[stat_off] : 0.f;
-  if (q_ok && hi == 0) p.Delta[stat_off] = delta;
+  if (q_ok && hi == 0 && (!SPLIT || w == 0)) p.Delta[stat_off] = delta;
 
   f32x16 dq[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) zero16(dq[mt]);
-  const int kend = p.causal ? min(p.Sk, q0 + 32) : p.Sk;
+  const int kend = CAUSAL ? min(p.Sk, q0 + 32) : p.Sk;
   const bf16_t* kbase = p.K.ptr + b * p.K.bs + h * p.K.hs;
   const bf16_t* vbase = p.V.ptr + b * p.V.bs + h * p.V.hs;
   const bf16_t* ktbase = p.Kt.ptr + b * p.Kt.bs + h * p.Kt.hs;
-  const int* km = p.kmask ? p.kmask + (long long)b * p.Sk : nullptr;
-  const uint32_t drop_seed = p.drop.seed_ptr ? *p.drop.seed_ptr : 0u;
+  const int* km = MASK ? p.kmask + (long long)b * p.Skpad : nullptr;
+  const uint32_t drop_seed = DROP ? *p.drop.seed_ptr : 0u;
   const uint32_t row_idx = ((uint32_t)(b * p.H + h) * (uint32_t)p.Sq + (uint32_t)q) * (uint32_t)p.Sk;
+  const int kstart = SPLIT ? w * 32 : 0, kstep = SPLIT ? 128 : 32;
 
-  for (int k0 = 0; k0 < kend; k0 += 32) {
+  bf16x8 kcur[KS], vcur[KS];
+  load_rows<KS>(kcur, kbase, p.K.rs, kstart + perm23(l31), p.Sk, p.D, hi);
+  load_rows<KS>(vcur, vbase, p.V.rs, kstart + perm23(l31), p.Sk, p.D, hi);
+  for (int k0 = kstart; k0 < kend; k0 += kstep) {
+    bf16x8 ktf[MT][2];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const bf16_t* kt = ktbase + (long long)(mt * 32 + l31) * p.Kt.ds + k0 + 8 * hi;
+      ktf[mt][0] = ld8(kt);
+      ktf[mt][1] = ld8(kt + 16);
+    }
+    uint32_t vmask = 0xffffu;
+    if (MASK) vmask = mask_bits(km, k0, hi);
+    bf16x8 knext[KS], vnext[KS];
+    load_rows<KS>(knext, kbase, p.K.rs, k0 + kstep + perm23(l31), p.Sk, p.D, hi);
+    load_rows<KS>(vnext, vbase, p.V.rs, k0 + kstep + perm23(l31), p.Sk, p.D, hi);
     f32x16 sacc, dpacc;
     zero16(sacc);
     zero16(dpacc);
-    {
-      const int krow = k0 + perm23(l31);
-      const bool k_ok = krow < p.Sk;
-      const bf16_t* kp = kbase + (long long)krow * p.K.rs;
-      const bf16_t* vp = vbase + (long long)krow * p.V.rs;
 #pragma unroll
-      for (int s = 0; s < KS; ++s) {
-        const int d0 = 16 * s + 8 * hi;
-        const bool ok = k_ok && d0 < p.D;
-        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ok ? ld8(kp + d0) : zero, qf[s], sacc, 0, 0, 0);
-        dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ok ? ld8(vp + d0) : zero, dof[s], dpacc, 0, 0, 0);
+    for (int s = 0; s < KS; ++s) {
+      sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kcur[s], qf[s], sacc, 0, 0, 0);
+      dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vcur[s], dof[s], dpacc, 0, 0, 0);
+    }
+    float sv[16];
+    if (LUT) {
+      float bias[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rel = (k0 + 16 * (r >> 3) + 8 * hi + (r & 7)) - q;
+        bias[r] = lut[max(-128, min(128, rel)) + 128];
       }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sv[r] = sacc[r] * p.scale + bias[r];
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sv[r] = sacc[r] * p.scale;
     }
     float ds[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int key = k0 + 16 * (r >> 3) + 8 * hi + (r & 7);
-      float val = sacc[r] * p.scale;
-      if (p.lut) {
-        int rel = key - q;
-        rel = max(-128, min(128, rel));
-        val += lut[rel + 128];
-      }
-      bool ok = q_ok && key < p.Sk;
-      if (p.causal) ok = ok && (key <= q);
-      if (km) ok = ok && (km[min(key, p.Sk - 1)] != 0);
-      const float pr = ok ? __expf(val - lse) : 0.f;
+      bool ok = q_ok && key < p.Sk && ((vmask >> r) & 1u);
+      if (CAUSAL) ok = ok && (key <= q);
+      const float pr = ok ? __expf(sv[r] - lse) : 0.f;
       float dpv = dpacc[r];
-      if (p.drop.seed_ptr) dpv = mrb_keep(row_idx + (uint32_t)key, drop_seed, p.drop.site, p.drop.thresh24) ? dpv * p.drop.inv_keep : 0.f;
+      if (DROP) dpv = mrb_keep(row_idx + (uint32_t)key, drop_seed, p.drop.site, p.drop.thresh24) ? dpv * p.drop.inv_keep : 0.f;
       ds[r] = ok ? pr * (dpv - delta) * p.scale : 0.f;
     }
     const bf16x8 f0 = pack8(ds), f1 = pack8(ds + 8);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-      const bf16_t* kt = ktbase + (long long)(mt * 32 + l31) * p.Kt.ds + k0 + 8 * hi;
-      dq[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld8(kt), f0, dq[mt], 0, 0, 0);
-      dq[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld8(kt + 16), f1, dq[mt], 0, 0, 0);
+      dq[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf[mt][0], f0, dq[mt], 0, 0, 0);
+      dq[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf[mt][1], f1, dq[mt], 0, 0, 0);
     }
+#pragma unroll
+    for (int s = 0; s < KS; ++s) { kcur[s] = knext[s]; vcur[s] = vnext[s]; }
+  }
+  if (SPLIT) {
+    if (w > 0) {
+      float* r = red + (w - 1) * MT * 16 * 64;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) r[(mt * 16 + i) * 64 + lane] = dq[mt][i];
+    }
+    __syncthreads();
+    if (w > 0) return;
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dq[mt][i] += red[(j * MT * 16 + mt * 16 + i) * 64 + lane];
   }
   if (q_ok) {
     bf16_t* op = const_cast<bf16_t*>(p.dQ.ptr) + b * p.dQ.bs + h * p.dQ.hs + (long long)q * p.dQ.rs;
@@ -269,34 +374,25 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
 }
 
 // ---- backward, part 2: dK, dV.  One wave owns 32 keys and walks the query tiles.
-template <int DP>
+template <int DP, int FLAGS>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
   constexpr int KS = DP / 16, MT = DP / 32;
-  __shared__ float lut[257];
+  constexpr bool LUT = FLAGS & F_LUT, MASK = FLAGS & F_MASK, CAUSAL = FLAGS & F_CAUSAL, DROP = FLAGS & F_DROP;
+  __shared__ float lut[LUT ? 257 : 1];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, hi = lane >> 5, l31 = lane & 31;
   const int b = blockIdx.z, h = blockIdx.y;
-  if (p.lut) {
+  if (LUT) {
     for (int i = threadIdx.x; i < 257; i += 256) lut[i] = p.lut[h * 257 + i];
+    __syncthreads();
   }
-  __syncthreads();
   const int kb0 = (blockIdx.x * 4 + w) * 32;
   if (kb0 >= p.Sk) return;
   const int key = kb0 + l31;
   bool key_ok = key < p.Sk;
-  const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
   bf16x8 kf[KS], vf[KS];
-  {
-    const bf16_t* kp = p.K.ptr + b * p.K.bs + h * p.K.hs + (long long)key * p.K.rs;
-    const bf16_t* vp = p.V.ptr + b * p.V.bs + h * p.V.hs + (long long)key * p.V.rs;
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      const int d0 = 16 * s + 8 * hi;
-      const bool ok = key_ok && d0 < p.D;
-      kf[s] = ok ? ld8(kp + d0) : zero;
-      vf[s] = ok ? ld8(vp + d0) : zero;
-    }
-  }
-  if (p.kmask && key_ok) key_ok = p.kmask[(long long)b * p.Sk + key] != 0;
+  load_rows<KS>(kf, p.K.ptr + b * p.K.bs + h * p.K.hs, p.K.rs, key, p.Sk, p.D, hi);
+  load_rows<KS>(vf, p.V.ptr + b * p.V.bs + h * p.V.hs, p.V.rs, key, p.Sk, p.D, hi);
+  if (MASK) key_ok = key_ok && (p.kmask[(long long)b * p.Skpad + key] != 0);
   f32x16 dk[MT], dv[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) { zero16(dk[mt]); zero16(dv[mt]); }
@@ -306,26 +402,21 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
   const bf16_t* dotbase = p.dOt.ptr + b * p.dOt.bs + h * p.dOt.hs;
   const float* lsebase = p.LSE + ((long long)(b * p.H + h)) * p.Sqpad;
   const float* delbase = p.Delta + ((long long)(b * p.H + h)) * p.Sqpad;
-  const uint32_t drop_seed = p.drop.seed_ptr ? *p.drop.seed_ptr : 0u;
+  const uint32_t drop_seed = DROP ? *p.drop.seed_ptr : 0u;
   const uint32_t bh_idx = (uint32_t)(b * p.H + h) * (uint32_t)p.Sq;
-  const int qstart = p.causal ? (kb0 & ~31) : 0;
+  const int qstart = CAUSAL ? kb0 : 0;
 
+  bf16x8 qcur[KS], docur[KS];
+  load_rows<KS>(qcur, qbase, p.Q.rs, qstart + perm23(l31), p.Sq, p.D, hi);
+  load_rows<KS>(docur, dobase, p.dO.rs, qstart + perm23(l31), p.Sq, p.D, hi);
   for (int q0 = qstart; q0 < p.Sq; q0 += 32) {
-    f32x16 sacc, dpacc;
-    zero16(sacc);
-    zero16(dpacc);
-    {
-      const int qrow = q0 + perm23(l31);
-      const bool r_ok = qrow < p.Sq;
-      const bf16_t* qp = qbase + (long long)qrow * p.Q.rs;
-      const bf16_t* dp = dobase + (long long)qrow * p.dO.rs;
+    bf16x8 dotf[MT][2], qtf[MT][2];
 #pragma unroll
-      for (int s = 0; s < KS; ++s) {
-        const int d0 = 16 * s + 8 * hi;
-        const bool ok = r_ok && d0 < p.D;
-        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ok ? ld8(qp + d0) : zero, kf[s], sacc, 0, 0, 0);
-        dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ok ? ld8(dp + d0) : zero, vf[s], dpacc, 0, 0, 0);
-      }
+    for (int mt = 0; mt < MT; ++mt) {
+      const bf16_t* dot = dotbase + (long long)(mt * 32 + l31) * p.dOt.ds + q0 + 8 * hi;
+      const bf16_t* qt = qtbase + (long long)(mt * 32 + l31) * p.Qt.ds + q0 + 8 * hi;
+      dotf[mt][0] = ld8(dot); dotf[mt][1] = ld8(dot + 16);
+      qtf[mt][0] = ld8(qt); qtf[mt][1] = ld8(qt + 16);
     }
     float lse[16], del[16];
 #pragma unroll
@@ -338,21 +429,41 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
       del[8 * c + 0] = b0.x; del[8 * c + 1] = b0.y; del[8 * c + 2] = b0.z; del[8 * c + 3] = b0.w;
       del[8 * c + 4] = b1.x; del[8 * c + 5] = b1.y; del[8 * c + 6] = b1.z; del[8 * c + 7] = b1.w;
     }
+    bf16x8 qnext[KS], donext[KS];
+    load_rows<KS>(qnext, qbase, p.Q.rs, q0 + 32 + perm23(l31), p.Sq, p.D, hi);
+    load_rows<KS>(donext, dobase, p.dO.rs, q0 + 32 + perm23(l31), p.Sq, p.D, hi);
+    f32x16 sacc, dpacc;
+    zero16(sacc);
+    zero16(dpacc);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qcur[s], kf[s], sacc, 0, 0, 0);
+      dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(docur[s], vf[s], dpacc, 0, 0, 0);
+    }
+    // lane (key, hi), register r  <->  query q0 + 16*(r>>3) + 8*hi + (r&7)
+    float sv[16];
+    if (LUT) {
+      float bias[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rel = key - (q0 + 16 * (r >> 3) + 8 * hi + (r & 7));
+        bias[r] = lut[max(-128, min(128, rel)) + 128];
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sv[r] = sacc[r] * p.scale + bias[r];
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sv[r] = sacc[r] * p.scale;
+    }
     float pd[16], ds[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int qq = q0 + 16 * (r >> 3) + 8 * hi + (r & 7);
-      float val = sacc[r] * p.scale;
-      if (p.lut) {
-        int rel = key - qq;
-        rel = max(-128, min(128, rel));
-        val += lut[rel + 128];
-      }
       bool ok = key_ok && qq < p.Sq;
-      if (p.causal) ok = ok && (key <= qq);
-      const float pr = ok ? __expf(val - lse[r]) : 0.f;
+      if (CAUSAL) ok = ok && (key <= qq);
+      const float pr = ok ? __expf(sv[r] - lse[r]) : 0.f;
       float dpv = dpacc[r], prd = pr;
-      if (p.drop.seed_ptr) {
+      if (DROP) {
         const bool keep = mrb_keep((bh_idx + (uint32_t)qq) * (uint32_t)p.Sk + (uint32_t)key, drop_seed, p.drop.site, p.drop.thresh24);
         dpv = keep ? dpv * p.drop.inv_keep : 0.f;
         prd = keep ? pr * p.drop.inv_keep : 0.f;
@@ -363,13 +474,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
     const bf16x8 p0 = pack8(pd), p1 = pack8(pd + 8), s0 = pack8(ds), s1 = pack8(ds + 8);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-      const bf16_t* dot = dotbase + (long long)(mt * 32 + l31) * p.dOt.ds + q0 + 8 * hi;
-      const bf16_t* qt = qtbase + (long long)(mt * 32 + l31) * p.Qt.ds + q0 + 8 * hi;
-      dv[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld8(dot), p0, dv[mt], 0, 0, 0);
-      dv[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld8(dot + 16), p1, dv[mt], 0, 0, 0);
-      dk[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld8(qt), s0, dk[mt], 0, 0, 0);
-      dk[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld8(qt + 16), s1, dk[mt], 0, 0, 0);
+      dv[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dotf[mt][0], p0, dv[mt], 0, 0, 0);
+      dv[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dotf[mt][1], p1, dv[mt], 0, 0, 0);
+      dk[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf[mt][0], s0, dk[mt], 0, 0, 0);
+      dk[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf[mt][1], s1, dk[mt], 0, 0, 0);
     }
+#pragma unroll
+    for (int s = 0; s < KS; ++s) { qcur[s] = qnext[s]; docur[s] = donext[s]; }
   }
   if (key < p.Sk) {
     bf16_t* kp = const_cast<bf16_t*>(p.dK.ptr) + b * p.dK.bs + h * p.dK.hs + (long long)key * p.dK.rs;
@@ -430,7 +541,7 @@ static int attn_fill(AttnArgs& a, const void* Q, const long long* qs, const void
   a.Q = T4{(const bf16_t*)Q, qs[0], qs[1], qs[2]};
   a.K = T4{(const bf16_t*)K, ks[0], ks[1], ks[2]};
   a.V = T4{(const bf16_t*)V, vs[0], vs[1], vs[2]};
-  a.B = B; a.H = H; a.Sq = Sq; a.Sk = Sk; a.D = D; a.Sqpad = (Sq + 31) / 32 * 32;
+  a.B = B; a.H = H; a.Sq = Sq; a.Sk = Sk; a.D = D; a.Sqpad = (Sq + 31) / 32 * 32; a.Skpad = (Sk + 31) / 32 * 32;
   return MRBLIP_OK;
 }
 
@@ -441,7 +552,51 @@ static void attn_drop(AttnArgs& a, const uint32_t* seed_ptr, uint32_t site, floa
   a.drop.inv_keep = 1.0f / (1.0f - p_drop);
 }
 
+static int attn_flags(const AttnArgs& a, int causal) {
+  return (a.lut ? F_LUT : 0) | (a.kmask ? F_MASK : 0) | (causal ? F_CAUSAL : 0) | (a.drop.seed_ptr ? F_DROP : 0);
+}
+
+// The flag combinations the hot path uses (anything else is rejected loudly): 0 plain (ViT, eval Q-Former), DROP (Q-Former),
+// LUT|MASK[|DROP] (T5 encoder), LUT|MASK|CAUSAL[|DROP] (decoder self), MASK[|DROP] (decoder cross).
+#define ATTN_FLAG_CASES(X, DPV)                                                                                          \
+  X(DPV, 0) X(DPV, F_DROP) X(DPV, F_LUT | F_MASK) X(DPV, F_LUT | F_MASK | F_DROP) X(DPV, F_LUT | F_MASK | F_CAUSAL)       \
+  X(DPV, F_LUT | F_MASK | F_CAUSAL | F_DROP) X(DPV, F_MASK) X(DPV, F_MASK | F_DROP)
+
+template <int DP>
+static int launch_fwd(const AttnArgs& a, int flags, hipStream_t stream) {
+  const bool split = a.Sq <= 32 && a.Sk >= 256 && !(flags & F_CAUSAL);
+  dim3 grid(split ? 1 : (a.Sq + 127) / 128, a.H, a.B);
+#define X(DPV, FL)                                                                                             \
+  if (flags == (FL)) {                                                                                         \
+    if (split && !((FL) & F_CAUSAL)) hipLaunchKernelGGL((attn_fwd_kernel<DPV, ((FL) & ~F_CAUSAL) | F_SPLIT>), grid, dim3(256), 0, stream, a); \
+    else hipLaunchKernelGGL((attn_fwd_kernel<DPV, (FL)>), grid, dim3(256), 0, stream, a);                       \
+    return mrblip_check_launch("attention_fwd");                                                               \
+  }
+  ATTN_FLAG_CASES(X, DP)
+#undef X
+  mrblip_set_error("attention_fwd: unsupported feature combination (flags=%d)", flags);
+  return MRBLIP_EINVAL;
+}
+
+template <int DP>
+static int launch_bwd(const AttnArgs& a, int flags, hipStream_t stream) {
+  const bool split = a.Sq <= 32 && a.Sk >= 256 && !(flags & F_CAUSAL);
+  dim3 gq(split ? 1 : (a.Sq + 127) / 128, a.H, a.B), gk((a.Sk + 127) / 128, a.H, a.B);
+#define X(DPV, FL)                                                                                             \
+  if (flags == (FL)) {                                                                                         \
+    if (split && !((FL) & F_CAUSAL)) hipLaunchKernelGGL((attn_bwd_dq_kernel<DPV, ((FL) & ~F_CAUSAL) | F_SPLIT>), gq, dim3(256), 0, stream, a); \
+    else hipLaunchKernelGGL((attn_bwd_dq_kernel<DPV, (FL)>), gq, dim3(256), 0, stream, a);                      \
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<DPV, (FL)>), gk, dim3(256), 0, stream, a);                          \
+    return mrblip_check_launch("attention_bwd");                                                               \
+  }
+  ATTN_FLAG_CASES(X, DP)
+#undef X
+  mrblip_set_error("attention_bwd: unsupported feature combination (flags=%d)", flags);
+  return MRBLIP_EINVAL;
+}
+
 // strides arrays: {batch, head, row} in elements.  Vt: [B,H,DP,Skpad] with DP = roundup32(D), Skpad = roundup32(Sk).
+// kmask (optional): int32 [B, Skpad] (rows padded to a multiple of 32 entries).
 extern "C" int mrblip_attention_fwd(const void* Q, const long long* q_strides, const void* K, const long long* k_strides,
                                     const void* Vt, void* O, const long long* o_strides, float* LSE, int B, int H, int Sq, int Sk,
                                     int D, float scale, const float* bias_lut, const int* kmask, int causal,
@@ -449,15 +604,16 @@ extern "C" int mrblip_attention_fwd(const void* Q, const long long* q_strides, c
   AttnArgs a = {};
   long long dummy[3] = {0, 0, 0};
   if (int e = attn_fill(a, Q, q_strides, K, k_strides, nullptr, dummy, B, H, Sq, Sk, D)) return e;
-  const int DP = (D + 31) / 32 * 32, Skpad = (Sk + 31) / 32 * 32;
+  const int DP = (D + 31) / 32 * 32, Skpad = a.Skpad;
   a.Vt = T4T{(const bf16_t*)Vt, (long long)H * DP * Skpad, (long long)DP * Skpad, Skpad};
   a.O = T4{(const bf16_t*)O, o_strides[0], o_strides[1], o_strides[2]};
-  a.LSE = LSE; a.lut = bias_lut; a.kmask = kmask; a.causal = causal; a.scale = scale;
+  a.LSE = LSE; a.lut = bias_lut; a.kmask = kmask; a.scale = scale;
   attn_drop(a, seed_ptr, site, p_drop);
-  dim3 grid((Sq + 127) / 128, H, B);
-  if (DP == 32) hipLaunchKernelGGL(attn_fwd_kernel<32>, grid, dim3(256), 0, stream, a);
-  else if (DP == 64) hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, dim3(256), 0, stream, a);
-  else hipLaunchKernelGGL(attn_fwd_kernel<96>, grid, dim3(256), 0, stream, a);
+  const int flags = attn_flags(a, causal);
+  if (DP == 32) return launch_fwd<32>(a, flags, stream);
+  if (DP == 64) return launch_fwd<64>(a, flags, stream);
+  MRB_REQUIRE(flags == 0, "attention_fwd: head_dim > 64 supports the plain (ViT) form only");
+  hipLaunchKernelGGL((attn_fwd_kernel<96, 0>), dim3((Sq + 127) / 128, H, B), dim3(256), 0, stream, a);
   return mrblip_check_launch("attention_fwd");
 }
 
@@ -473,7 +629,7 @@ extern "C" int mrblip_attention_bwd(const void* Q, const long long* q_strides, c
   AttnArgs a = {};
   if (int e = attn_fill(a, Q, q_strides, K, k_strides, V, v_strides, B, H, Sq, Sk, D)) return e;
   MRB_REQUIRE(D <= 64, "attention_bwd: head_dim <= 64 only (the ViT is frozen, its attention needs no backward)");
-  const int DP = (D + 31) / 32 * 32, Skpad = (Sk + 31) / 32 * 32, Sqpad = a.Sqpad;
+  const int DP = (D + 31) / 32 * 32, Skpad = a.Skpad, Sqpad = a.Sqpad;
   a.O = T4{(const bf16_t*)O, o_strides[0], o_strides[1], o_strides[2]};
   a.dO = T4{(const bf16_t*)dO, do_strides[0], do_strides[1], do_strides[2]};
   a.dQ = T4{(const bf16_t*)dQ, dq_strides[0], dq_strides[1], dq_strides[2]};
@@ -482,17 +638,11 @@ extern "C" int mrblip_attention_bwd(const void* Q, const long long* q_strides, c
   a.Kt = T4T{(const bf16_t*)Kt, (long long)H * DP * Skpad, (long long)DP * Skpad, Skpad};
   a.Qt = T4T{(const bf16_t*)Qt, (long long)H * DP * Sqpad, (long long)DP * Sqpad, Sqpad};
   a.dOt = T4T{(const bf16_t*)dOt, (long long)H * DP * Sqpad, (long long)DP * Sqpad, Sqpad};
-  a.LSE = const_cast<float*>(LSE); a.Delta = Delta; a.lut = bias_lut; a.kmask = kmask; a.causal = causal; a.scale = scale;
+  a.LSE = const_cast<float*>(LSE); a.Delta = Delta; a.lut = bias_lut; a.kmask = kmask; a.scale = scale;
   attn_drop(a, seed_ptr, site, p_drop);
-  dim3 gq((Sq + 127) / 128, H, B), gk((Sk + 127) / 128, H, B);
-  if (DP == 32) {
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<32>, gq, dim3(256), 0, stream, a);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<32>, gk, dim3(256), 0, stream, a);
-  } else {
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, gq, dim3(256), 0, stream, a);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, gk, dim3(256), 0, stream, a);
-  }
-  return mrblip_check_launch("attention_bwd");
+  const int flags = attn_flags(a, causal);
+  if (DP == 32) return launch_bwd<32>(a, flags, stream);
+  return launch_bwd<64>(a, flags, stream);
 }
 
 extern "C" int mrblip_head_transpose(const void* src, const long long* strides, void* dst, int B, int H, int S, int D, int Spad,

@@ -355,8 +355,10 @@ extern "C" int mrblip_gemm_bf16(const void* A, long long lda, const void* W, lon
   if (cfg == 0) {
     if (M <= 64 && !gated) cfg = 3;
     else {
+      // measured on MI355X (tools/gemm_bench.py): the 256x256 one-barrier-per-K-tile kernel (1 block/CU) only wins for long-K,
+      // many-tile problems; the 128x128 variant (2 blocks/CU hide each other's staging latency) wins at the hot-path shapes.
       const long long t256 = (long long)((M + 255) / 256) * (((gated ? N / 2 : N) + (gated ? 127 : 255)) / (gated ? 128 : 256));
-      cfg = (t256 >= 200) ? 1 : 2;
+      cfg = (t256 >= 512 && K >= 4096) ? 1 : 2;
     }
   }
   if (cfg == 3) {

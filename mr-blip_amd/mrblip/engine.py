@@ -735,7 +735,7 @@ class MrBlipEngine:
         ops.cast_dropout(x0, out_f32=x, drop=self.drop(self.t5["sites"][2], p))
         vt_s = self.buf("d_vt_s", (B, H, ops.rup32(dk), ops.rup32(Ld)), bf16)
         vt_c = self.buf("d_vt_c", (B, H, ops.rup32(dk), ops.rup32(S)), bf16)
-        dmask = dec_mask.to(self.dev, torch.int32).contiguous()
+        dmask = self.pad_mask(dec_mask)
         for i, L in enumerate(self.t5["dec"]):
             xn = self.buf(f"d{i}_xn", (R, pad64(d)), bf16)
             ops.rmsnorm_fwd(x, L["ln0"], c.t5_eps, out_bf16=xn)
@@ -802,7 +802,7 @@ class MrBlipEngine:
         d, H, dk, ff, p, V = c.d_model, c.t5_heads, c.d_kv, c.d_ff, c.t5_dropout, c.vocab
         inner = H * dk
         R, Me = B * Ld, B * S
-        dmask = dec_mask.to(self.dev, torch.int32).contiguous()
+        dmask = self.pad_mask(dec_mask)
         gb = self.buf("db_g", (R, 64), bf16)
         gbe = self.buf("db_ge", (Me, 64), bf16)
         dseq = self.buf("db_dseq", (R, d), f32, zero=False)
@@ -940,7 +940,14 @@ class MrBlipEngine:
     def _layout_dev(self, layout: EncoderLayout):
         dev = self.dev
         return dict(frame_src=layout.frame_src.to(dev), frame_dst=layout.frame_dst.to(dev), emb_src=layout.emb_src.to(dev),
-                    emb_dst=layout.emb_dst.to(dev), mask=layout.attention_mask.to(dev).contiguous())
+                    emb_dst=layout.emb_dst.to(dev), mask=self.pad_mask(layout.attention_mask))
+
+    def pad_mask(self, m: torch.Tensor) -> torch.Tensor:
+        """[B,S] 0/1 mask -> int32 [B, rup32(S)] on the device (the attention kernels read the key mask 16 B at a time)."""
+        B, S = m.shape
+        out = torch.zeros(B, ops.rup32(S), dtype=torch.int32, device=self.dev)
+        out[:, :S] = m.to(self.dev, torch.int32)
+        return out
 
     # ------------------------------------------------------------------------------------------ optimizer
     @torch.no_grad()

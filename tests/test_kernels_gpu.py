@@ -170,7 +170,7 @@ def test_attention_fwd(ops, B, H, Sq, Sk, D):
 
 
 @pytest.mark.parametrize("causal", [False, True])
-@pytest.mark.parametrize("B,H,Sq,Sk,D", [(2, 4, 150, 150, 64), (1, 2, 40, 40, 16), (2, 3, 12, 200, 64), (3, 2, 32, 257, 64)])
+@pytest.mark.parametrize("B,H,Sq,Sk,D", [(2, 4, 150, 150, 64), (1, 2, 40, 40, 16), (2, 3, 12, 200, 64), (3, 2, 32, 257, 64), (2, 4, 8, 700, 64)])
 def test_attention_bias_mask_dropout_fwd_bwd(ops, causal, B, H, Sq, Sk, D):
     if causal and Sq != Sk:
         pytest.skip("causal only for self-attention")
@@ -182,7 +182,8 @@ def test_attention_bias_mask_dropout_fwd_bwd(ops, causal, B, H, Sq, Sk, D):
     v = bf(torch.randn(B, Sk, H, D, device=dev()))
     do = bf(torch.randn(B, Sq, H, D, device=dev()))
     lut = torch.randn(H, 257, device=dev())
-    kmask = torch.ones(B, Sk, dtype=torch.int32, device=dev())
+    kmask = torch.zeros(B, ops.rup32(Sk), dtype=torch.int32, device=dev())  # rows padded to a multiple of 32 entries
+    kmask[:, :Sk] = 1
     kmask[0, Sk - 7:] = 0
     seed = torch.tensor([4242], dtype=torch.int32, device=dev())
     drop = ops.Dropout(seed, 11, p)
@@ -193,7 +194,7 @@ def test_attention_bias_mask_dropout_fwd_bwd(ops, causal, B, H, Sq, Sk, D):
     # reference with autograd
     qr, kr, vr = (t.float().permute(0, 2, 1, 3).clone().requires_grad_(True) for t in (q, k, v))
     bias = _lut_bias(lut, Sq, Sk)[None]
-    mask = kmask.bool()[:, None, None, :].expand(B, H, Sq, Sk)
+    mask = kmask[:, :Sk].bool()[:, None, None, :].expand(B, H, Sq, Sk)
     if causal:
         mask = mask & torch.tril(torch.ones(Sq, Sk, dtype=torch.bool, device=dev()))[None, None]
     dmask = keep_mask((B, H, Sq, Sk), 4242, 11, p)
