@@ -60,10 +60,19 @@ struct DropoutArg {
   float inv_keep;  // 1 / (1 - p)
 };
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// erf by Abramowitz-Stegun 7.1.26 (max abs error 1.5e-7): ~12 instructions instead of libm's ~40; the result feeds
+// bf16 (8-bit mantissa) activations or fp32 values whose error budget is the bf16 GEMM operands.
+__device__ __forceinline__ float fast_erf(float x) {
+  const float ax = fabsf(x);
+  const float t = __frcp_rn(1.0f + 0.3275911f * ax);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float r = 1.0f - poly * __expf(-ax * ax);
+  return copysignf(r, x);
+}
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float gelu_erf_grad(float x) {
   const float kInvSqrt2Pi = 0.39894228040143267794f;
-  return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * kInvSqrt2Pi * __expf(-0.5f * x * x);
+  return 0.5f * (1.0f + fast_erf(x * 0.70710678118654752440f)) + x * kInvSqrt2Pi * __expf(-0.5f * x * x);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

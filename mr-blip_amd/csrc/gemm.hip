@@ -263,15 +263,26 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const GemmArgs p) {
   const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
   const bf16_t* wp = p.W + (long long)n_row * p.ldw + hi * 32;
   const bf16_t* xp = p.A + (long long)m_row * p.lda + hi * 32;
-  for (int kb = w; kb < nkb; kb += 4) {
-    bf16x8 wf[4], xf[4];
+  // each wave owns a contiguous quarter of the k blocks; 4 blocks (32 independent 16-B loads per lane) are in flight at a time
+  const int per = (nkb + 3) >> 2;
+  const int kb_beg = w * per, kb_end = min(nkb, kb_beg + per);
+#pragma unroll 1
+  for (int kb0 = kb_beg; kb0 < kb_end; kb0 += 4) {
+    bf16x8 wf[4][4], xf[4][4];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      wf[s] = n_ok ? *reinterpret_cast<const bf16x8*>(wp + kb * 64 + s * 8) : zero;
-      xf[s] = m_ok ? *reinterpret_cast<const bf16x8*>(xp + kb * 64 + s * 8) : zero;
+    for (int u = 0; u < 4; ++u) {
+      const int kb = min(kb0 + u, kb_end - 1);
+      const bool live = kb0 + u < kb_end;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        wf[u][s] = (n_ok && live) ? *reinterpret_cast<const bf16x8*>(wp + kb * 64 + s * 8) : zero;
+        xf[u][s] = (m_ok && live) ? *reinterpret_cast<const bf16x8*>(xp + kb * 64 + s * 8) : zero;
+      }
     }
 #pragma unroll
-    for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s], xf[s], acc, 0, 0, 0);
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[u][s], xf[u][s], acc, 0, 0, 0);
   }
   if (p.Aext && w == 3) {  // K-extension segment (one 64-wide block), taken by the last wave
     const bf16_t* wpe = p.Wext + (long long)n_row * p.ldwext + hi * 32;
