@@ -1,0 +1,107 @@
+"""Dataset builders of the Mr. BLIP path: the annotation-JSON moment-retrieval dataset (qvh / charades_sta / anet) and a synthetic
+one with the same sample dict for runs without the video corpora."""
+import json
+import os
+
+import torch
+from torch.utils.data import Dataset
+
+from lavis.common.registry import registry
+
+CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
+CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+TASK_PROMPT = "Given the video and the query, find the relevant windows.\nRelevant windows: "
+
+
+def collate(batch):
+    out = {}
+    for k in batch[0]:
+        v = [b[k] for b in batch]
+        out[k] = torch.stack(v) if torch.is_tensor(v[0]) else (torch.tensor(v) if isinstance(v[0], float) else v)
+    return out
+
+
+class _MRBase(Dataset):
+    collater = staticmethod(collate)
+
+    def _sample(self, video, timestamps, duration, query, windows, qid):
+        """the ``samples`` contract of lavis/datasets/datasets/moment_retrieval_dataset.py:17-60"""
+        return {"video": video, "timestamps": timestamps, "duration": float(duration), "query_id": qid,
+                "query_prompt": "Query: " + query + "\n", "task_prompt": TASK_PROMPT, "video_prompt_end": "<extra_id_0>",
+                "relevant_windows": str(windows)}
+
+
+class SyntheticMomentRetrievalDataset(_MRBase):
+    def __init__(self, n_items=16, n_frms=60, image_size=224, duration=150.0, seed=0):
+        self.n, self.T, self.img, self.dur, self.seed = n_items, n_frms, image_size, duration, seed
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        g = torch.Generator().manual_seed(self.seed * 100003 + i)
+        u8 = torch.randint(0, 256, (self.T, 3, self.img, self.img), generator=g, dtype=torch.uint8)
+        mean, std = torch.tensor(CLIP_MEAN).view(1, 3, 1, 1), torch.tensor(CLIP_STD).view(1, 3, 1, 1)
+        video = (u8.float() / 255.0 - mean) / std
+        ts = torch.tensor([round((k + 0.5) * self.dur / self.T, 2) for k in range(self.T)], dtype=torch.float32)
+        s = int(torch.randint(0, int(self.dur) - 10, (1,), generator=g))
+        return self._sample(video, ts, self.dur, "a person opens the red door and walks into the kitchen", [[s, s + 8]], f"syn{i}")
+
+
+class MomentRetrievalDataset(_MRBase):
+    """annotation JSON of {video, qid, query, duration, relevant_windows}; frames decoded by a pluggable ``frame_loader``
+    (decord/av are not in this image: a clear error is raised unless a loader is supplied)."""
+
+    def __init__(self, ann_path, vis_root, n_frms=60, image_size=224, frame_loader=None):
+        self.ann = json.load(open(ann_path))
+        self.vis_root, self.T, self.img, self.frame_loader = vis_root, n_frms, image_size, frame_loader
+
+    def __len__(self):
+        return len(self.ann)
+
+    def __getitem__(self, i):
+        a = self.ann[i]
+        if self.frame_loader is None:
+            raise RuntimeError("no video decoder available (decord/av not installed): pass frame_loader=callable(path, n_frms, size) -> (uint8 [T,3,H,W], fps indices)")
+        u8, idx, fps = self.frame_loader(os.path.join(self.vis_root, a["video"]), self.T, self.img)
+        mean, std = torch.tensor(CLIP_MEAN).view(1, 3, 1, 1), torch.tensor(CLIP_STD).view(1, 3, 1, 1)
+        video = (u8.float() / 255.0 - mean) / std
+        ts = torch.tensor([round(k / fps, 2) for k in idx], dtype=torch.float32)
+        return self._sample(video, ts, a["duration"], a["query"], a["relevant_windows"], a["qid"])
+
+
+class _Builder:
+    DATASET_CONFIG_DICT = {}
+
+    def __init__(self, cfg):
+        self.config = cfg
+
+    @classmethod
+    def default_config_path(cls, type="default"):
+        return os.path.join(registry.get_path("library_root"), cls.DATASET_CONFIG_DICT[type])
+
+
+@registry.register_builder("synthetic_mr")
+class SyntheticBuilder(_Builder):
+    DATASET_CONFIG_DICT = {"default": "configs/datasets/qvh/synthetic.yaml"}
+
+    def build_datasets(self):
+        c = self.config
+        vp = c.get("vis_processor", {}).get("train", {})
+        kw = dict(n_frms=vp.get("n_frms", 60), image_size=vp.get("image_size", 224), duration=c.get("duration", 150.0))
+        return {"train": SyntheticMomentRetrievalDataset(n_items=c.get("n_train", 16), seed=1, **kw),
+                "val": SyntheticMomentRetrievalDataset(n_items=c.get("n_val", 4), seed=2, **kw)}
+
+
+@registry.register_builder("qvh")
+class QVHBuilder(_Builder):
+    DATASET_CONFIG_DICT = {"default": "configs/datasets/qvh/defaults.yaml"}
+
+    def build_datasets(self):
+        info = self.config.build_info
+        vp = self.config.get("vis_processor", {}).get("train", {})
+        out = {}
+        for split, ann in info.annotations.items():
+            if os.path.isfile(str(ann.storage)):
+                out[split] = MomentRetrievalDataset(ann.storage, info.videos.storage, n_frms=vp.get("n_frms", 60), image_size=vp.get("image_size", 224))
+        return out

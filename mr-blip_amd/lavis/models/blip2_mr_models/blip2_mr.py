@@ -1,0 +1,225 @@
+"""``blip2_mr`` — the reference's registry entry (blip2_mr.py:49-50) backed by the MI355X-native engine.
+
+Same surface as the reference class: ``PRETRAINED_MODEL_CONFIG_DICT``, ``from_config(cfg)`` (reads the keys of
+blip2_mr.py:1422-1441), ``forward(samples) -> {"loss"}``, ``generate(samples, ...) -> {"duration","prediction",
+"raw_prediction","answer","qid"}``, ``load_checkpoint``, ``state_dict`` with the reference's parameter names for the
+trainable tensors (LoRA in peft naming, t5_proj, ln_vision).  The frozen backbones live inside ``mrblip.engine`` as
+packed bf16 operands; ``loss.backward()`` hands autograd the gradient the HIP backward already produced.
+"""
+import logging
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from lavis.common.registry import registry
+from lavis.models.base_model import BaseModel
+from lavis.models.blip2_mr_models.utils import post_process
+from mrblip import prompt as P
+from mrblip.engine import EngineConfig, MrBlipEngine, RandomSource, StateDictSource
+from mrblip.tokenizer import load_tokenizer
+
+
+class _TrainStep(torch.autograd.Function):
+    """forward = whole HIP train step (loss AND gradients); backward = hand the flat gradients to autograd."""
+
+    @staticmethod
+    def forward(ctx, decay, no_decay, model, video, layout, need_grad):
+        eng = model.engine  # (grad mode is always off inside Function.forward, hence the explicit flag)
+        eng.zero_grad()
+        loss = eng.forward_backward(video, layout, backward=need_grad)
+        ctx.eng = eng
+        return loss.clone().reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        eng = ctx.eng
+        nd = eng.n_decay
+        return eng.grad[:nd] * g, eng.grad[nd:] * g, None, None, None, None
+
+
+@registry.register_model("blip2_mr")
+class BLIP2_MR(BaseModel):
+    PRETRAINED_MODEL_CONFIG_DICT = {
+        "pretrain_flant5xl": "configs/models/blip2/blip2_pretrain_flant5xl.yaml",
+        "tiny_synthetic": "configs/models/blip2/blip2_tiny_synthetic.yaml",
+    }
+
+    def __init__(self, img_size=224, drop_path_rate=0, use_grad_checkpoint=False, vit_precision="fp16", freeze_vit=True,
+                 num_query_token=32, t5_model="google/flan-t5-xl", num_beams=5, prompt="", max_txt_len=200, apply_lemmatizer=False,
+                 input_time_format="seconds_integers", interleave_data=False, frame_token_aggregation=None, task="lora",
+                 num_frames_for_answer=4, resample_frames=False, engine_config: Optional[EngineConfig] = None, weights=None,
+                 tokenizer=None, device=None, seed=42):
+        super().__init__()
+        if not freeze_vit:
+            raise NotImplementedError("the MI355X engine keeps the ViT frozen (every Mr. BLIP config sets freeze_vit: True)")
+        if "QA" in task:
+            raise NotImplementedError("video-QA variants (forward_QA) are outside the moment-retrieval hot path")
+        if input_time_format != "seconds_integers":
+            raise NotImplementedError(f"input_time_format={input_time_format!r}: only 'seconds_integers' (every shipped config) is implemented; "
+                                      "the reference's relative_*/framenumbers formats are broken upstream (SURVEY.md §8c)")
+        if not interleave_data:
+            raise NotImplementedError("interleave_data: False (non-interleaved prompt) is not on the benchmarked path")
+        if "lora" not in task or "qformer_freeze" not in task:
+            raise NotImplementedError("task must contain 'lora' and 'qformer_freeze' (the shipped Mr. BLIP fine-tuning recipe)")
+        assert frame_token_aggregation in (None, False, "mean"), "Invalid aggregation method, please choose from ['mean']"
+        self.task, self.num_beams, self.max_txt_len = task, num_beams, max_txt_len
+        self.input_time_format, self.interleave_data = input_time_format, interleave_data
+        self.frame_token_aggregation = frame_token_aggregation
+        self._device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        cfg = engine_config or EngineConfig(img=img_size, num_query=num_query_token)
+        cfg.mean_pool = frame_token_aggregation == "mean"
+        self.t5_tokenizer = tokenizer or load_tokenizer(t5_model)
+        self.annoying_numbers, _ = P.find_annoying_numbers(self.t5_tokenizer, 200)
+        self.annoying_numbers_replacement_dict = P.annoying_replacement_dict(self.annoying_numbers)
+        src = weights if weights is not None else RandomSource(self._device, seed=1234)
+        if isinstance(src, dict):
+            src = StateDictSource(src)
+        self.engine = MrBlipEngine(cfg, src, self._device, seed=seed)
+        nd = self.engine.n_decay
+        # the trainable tensors as two flat Parameters that ALIAS the engine's buffer (AdamW decay / no-decay groups)
+        self.trainable_decay = nn.Parameter(self.engine.flat[:nd])
+        self.trainable_no_decay = nn.Parameter(self.engine.flat[nd:])
+        self.post_process = post_process
+
+    # ------------------------------------------------------------------ reference surface
+    @classmethod
+    def from_config(cls, cfg):
+        ecfg = None
+        if cfg.get("engine"):
+            ecfg = EngineConfig(**dict(cfg.engine))
+        model = cls(
+            img_size=cfg.get("image_size", 224), num_query_token=cfg.get("num_query_token", 32), t5_model=cfg.get("t5_model", "google/flan-t5-xl"),
+            num_beams=cfg.get("num_beams", 5), drop_path_rate=cfg.get("drop_path_rate", 0), use_grad_checkpoint=cfg.get("use_grad_checkpoint", False),
+            vit_precision=cfg.get("vit_precision", "fp16"), freeze_vit=cfg.get("freeze_vit", True), prompt=cfg.get("prompt", ""),
+            max_txt_len=cfg.get("max_txt_len", 200), apply_lemmatizer=cfg.get("apply_lemmatizer", False),
+            input_time_format=cfg.get("input_time_format", "seconds_integers"), interleave_data=cfg.get("interleave_data", False),
+            frame_token_aggregation=cfg.get("frame_token_aggregation", None), task=cfg.get("task", "lora"),
+            num_frames_for_answer=cfg.get("num_frames_for_answer", 4), resample_frames=cfg.get("resample_frames", False), engine_config=ecfg,
+        )
+        model.load_checkpoint_from_config(cfg)
+        return model
+
+    def train(self, mode=True):
+        super().train(mode)
+        self.engine.training = mode
+        return self
+
+    def _layout(self, samples):
+        T = samples["video"].shape[1]
+        n = 1 if self.engine.cfg.mean_pool else self.engine.cfg.num_query
+        return P.build_layout(self.t5_tokenizer, samples, self.annoying_numbers_replacement_dict, n, T, self.max_txt_len,
+                              no_task_prompt="no_task_prompt" in self.task)
+
+    def forward(self, samples):
+        video = samples["video"].to(self._device, torch.float32)
+        layout = self._layout(samples)
+        need_grad = torch.is_grad_enabled() and (self.trainable_decay.requires_grad or self.trainable_no_decay.requires_grad)
+        loss = _TrainStep.apply(self.trainable_decay, self.trainable_no_decay, self, video, layout, need_grad)
+        return {"loss": loss}
+
+    @torch.no_grad()
+    def generate(self, samples, use_nucleus_sampling=False, num_beams=5, max_length=50, min_length=1, top_p=0.9, repetition_penalty=1.0,
+                 length_penalty=1.0, num_captions=1, temperature=1, output_attentions=False):
+        """Beam search over the HIP decoder (blip2_mr.py:826-946).  The decoder is re-run on the growing prefix each step
+        (no KV cache yet — SURVEY.md §8f row 1)."""
+        eng = self.engine
+        was_training = eng.training
+        eng.training = False
+        try:
+            video = samples["video"].to(self._device, torch.float32)
+            s2 = dict(samples)
+            s2.setdefault("relevant_windows", ["[[0, 0]]"] * video.shape[0])
+            s2["relevant_windows"] = [str(w) for w in s2["relevant_windows"]]
+            layout = self._layout(s2)
+            B, S, d = video.shape[0], layout.S, eng.cfg.d_model
+            fr, img, xv, qb = eng.frames_forward(video)
+            L = eng._layout_dev(layout)
+            inp = eng.buf("inputs_embeds", (B * S, d), torch.float32, zero=False)
+            from mrblip import ops
+            ops.row_copy(fr, L["frame_src"], inp, L["frame_dst"])
+            ops.row_copy(eng.emb, L["emb_src"], inp, L["emb_dst"])
+            enc = eng.t5_encoder_forward(inp, B, S, L["mask"])
+            K = max(1, int(num_beams))
+            # replicate encoder rows per beam: [B*K sequences]
+            enc_k = enc.view(B, S, -1).repeat_interleave(K, 0).reshape(B * K * S, -1).contiguous()
+            mask_k = L["mask"].repeat_interleave(K, 0).contiguous()
+            seqs = torch.zeros(B * K, 1, dtype=torch.long)
+            scores = torch.zeros(B, K)
+            scores[:, 1:] = -1e9
+            finished = [[] for _ in range(B)]
+            for step in range(max_length):
+                Ld = seqs.shape[1]
+                _, logits = eng.t5_decoder_forward(seqs, torch.ones(B * K, Ld, dtype=torch.int32), enc_k, B * K, S, mask_k, labels=None)
+                lp = torch.log_softmax(logits.view(B * K, Ld, -1)[:, -1].float().cpu() / float(temperature), -1)
+                if step + 1 < min_length:
+                    lp[:, 1] = -1e9
+                V = lp.shape[-1]
+                cand = (scores.view(B * K, 1) + lp).view(B, K * V)
+                top, idx = cand.topk(2 * K, -1)
+                new_seqs, new_scores = [], torch.full((B, K), -1e9)
+                for b in range(B):
+                    kept = 0
+                    for sc, ix in zip(top[b].tolist(), idx[b].tolist()):
+                        beam, tok = ix // V, ix % V
+                        seq = torch.cat([seqs[b * K + beam], torch.tensor([tok])])
+                        if tok == 1:  # </s>
+                            finished[b].append((sc / (len(seq) - 1) ** length_penalty, seq))
+                            continue
+                        new_seqs.append(seq)
+                        new_scores[b, kept] = sc
+                        kept += 1
+                        if kept == K:
+                            break
+                    while kept < K:
+                        new_seqs.append(torch.cat([seqs[b * K], torch.tensor([0])]))
+                        kept += 1
+                seqs, scores = torch.stack(new_seqs), new_scores
+                if all(len(f) >= K and max(x[0] for x in f) >= scores[b].max().item() / (seqs.shape[1]) ** length_penalty for b, f in enumerate(finished)):
+                    break
+            out_text = []
+            for b in range(B):
+                cands = finished[b] or [(scores[b, 0].item() / seqs.shape[1] ** length_penalty, seqs[b * K])]
+                best = max(cands, key=lambda x: x[0])[1]
+                out_text.append(self.t5_tokenizer.decode(best[1:], skip_special_tokens=True))
+            raw = list(out_text)
+            pred = [self.post_process(t) for t in out_text]
+            return {"duration": [float(x) for x in samples["duration"]], "prediction": pred, "raw_prediction": raw,
+                    "answer": samples.get("relevant_windows", [""] * B), "qid": samples.get("query_id", [str(i) for i in range(B)])}
+        finally:
+            eng.training = was_training
+
+    # ------------------------------------------------------------------ checkpoints: trainable tensors only, reference key names
+    def state_dict(self, *args, **kwargs):
+        eng = self.engine
+        sd = {"t5_proj.weight": eng.proj_w.detach().clone(), "t5_proj.bias": eng.proj_b.detach().clone(),
+              "ln_vision.weight": eng.lnv_w.detach().clone(), "ln_vision.bias": eng.lnv_b.detach().clone()}
+        for a in eng.adapters:
+            base = "t5_model.base_model.model." + a.name
+            sd[base + ".lora_A.default.weight"] = a.A.detach().clone()
+            sd[base + ".lora_B.default.weight"] = a.Bt.detach().t().contiguous()
+        return sd
+
+    def load_state_dict(self, state_dict, strict=False):
+        eng = self.engine
+        own = self.state_dict()
+        missing = [k for k in own if k not in state_dict]
+        unexpected = [k for k in state_dict if k not in own]
+        with torch.no_grad():
+            for k, dst in (("t5_proj.weight", eng.proj_w), ("t5_proj.bias", eng.proj_b), ("ln_vision.weight", eng.lnv_w), ("ln_vision.bias", eng.lnv_b)):
+                if k in state_dict:
+                    dst.copy_(state_dict[k])
+            for a in eng.adapters:
+                base = "t5_model.base_model.model." + a.name
+                if base + ".lora_A.default.weight" in state_dict:
+                    a.A.copy_(state_dict[base + ".lora_A.default.weight"])
+                if base + ".lora_B.default.weight" in state_dict:
+                    a.Bt.copy_(state_dict[base + ".lora_B.default.weight"].t())
+        eng.refresh_trainable()
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"missing {missing[:5]} unexpected {unexpected[:5]}")
+        return torch.nn.modules.module._IncompatibleKeys(missing, unexpected)
+
+    def load_from_pretrained(self, url_or_filename):
+        logging.info("frozen backbone weights are packed at construction (weights=...); loading trainable tensors from %s", url_or_filename)
+        return self.load_checkpoint(url_or_filename)

@@ -1,0 +1,159 @@
+"""``runner_base``: epochs, fused AdamW on the flat trainable buffer, cosine+warmup LR, one RCCL all-reduce of the flat gradient per
+optimizer step, checkpoints holding only the trainable tensors (behaviour of lavis/runners/runner_base.py:47-658)."""
+import json
+import logging
+import math
+import os
+import time
+
+import torch
+import torch.distributed as dist
+from torch.utils.data import DataLoader, DistributedSampler
+
+from lavis.common.dist_utils import get_rank, get_world_size, is_dist_avail_and_initialized, is_main_process, main_process
+from lavis.common.registry import registry
+from mrblip import ops
+
+
+class FlatAdamW:
+    """torch.optim.AdamW semantics (betas (0.9, 0.999), weight decay on the decay group only; runner_base.py:102-132) executed by
+    the fused HIP kernel over the model's two flat parameters."""
+
+    def __init__(self, model, lr, weight_decay, betas=(0.9, 0.999), eps=1e-8):
+        self.model, self.lr, self.wd, self.betas, self.eps = model, lr, weight_decay, betas, eps
+        self.params = [(model.trainable_decay, weight_decay), (model.trainable_no_decay, 0.0)]
+        self.m = [torch.zeros_like(p.data) for p, _ in self.params]
+        self.v = [torch.zeros_like(p.data) for p, _ in self.params]
+        self.t = 0
+        self.hyper = torch.zeros(4, device=model.trainable_decay.device)
+
+    def set_lr(self, lr):
+        self.lr = lr
+
+    def zero_grad(self):
+        for p, _ in self.params:
+            p.grad = None
+
+    @torch.no_grad()
+    def step(self):
+        self.t += 1
+        b1, b2 = self.betas
+        self.hyper.copy_(torch.tensor([self.lr, 1.0 / (1 - b1 ** self.t), 1.0 / math.sqrt(1 - b2 ** self.t), 1.0]))
+        for (p, wd), m, v in zip(self.params, self.m, self.v):
+            if p.grad is not None:
+                ops.adamw(p.data, p.grad.contiguous(), m, v, self.hyper, b1, b2, self.eps, wd)
+        self.model.engine.refresh_trainable()
+
+    def state_dict(self):
+        return {"t": self.t, "m": self.m, "v": self.v, "lr": self.lr}
+
+    def load_state_dict(self, sd):
+        self.t, self.lr = sd["t"], sd["lr"]
+        for dst, src in zip(self.m + self.v, sd["m"] + sd["v"]):
+            dst.copy_(src)
+
+
+@registry.register_runner("runner_base")
+class RunnerBase:
+    def __init__(self, cfg, task, model, datasets, job_id):
+        self.config, self.task, self.model, self.datasets, self.job_id = cfg, task, model, datasets, job_id
+        self.start_epoch = 0
+        run = cfg.run_cfg
+        self.output_dir = os.path.join(registry.get_path("repo_root") or ".", run.get("output_dir", "output"), str(job_id))
+        os.makedirs(self.output_dir, exist_ok=True)
+        if registry.get_path("result_dir") is None:
+            registry.register_path("result_dir", os.path.join(self.output_dir, "result"))
+            registry.register_path("output_dir", self.output_dir)
+        self.optimizer = FlatAdamW(model, lr=float(run.init_lr), weight_decay=float(run.get("weight_decay", 0.05)))
+        sched_cls = registry.get_lr_scheduler_class(run.lr_sched)
+        self.lr_scheduler = sched_cls(optimizer=self.optimizer, max_epoch=run.max_epoch, min_lr=float(run.min_lr), init_lr=float(run.init_lr),
+                                      decay_rate=run.get("lr_decay_rate", None), warmup_start_lr=float(run.get("warmup_lr", -1)),
+                                      warmup_steps=run.get("warmup_steps", 0))
+        if run.get("resume_ckpt_path"):
+            self._load_checkpoint(run.resume_ckpt_path)
+
+    # ---- data
+    def _loader(self, split, is_train):
+        run = self.config.run_cfg
+        ds = None
+        for name, splits in self.datasets.items():
+            if split in splits:
+                ds = splits[split]
+        if ds is None:
+            return None
+        sampler = DistributedSampler(ds, shuffle=is_train, num_replicas=get_world_size(), rank=get_rank()) if is_dist_avail_and_initialized() else None
+        bs = run.batch_size_train if is_train else run.batch_size_eval
+        return DataLoader(ds, batch_size=bs, num_workers=run.get("num_workers", 0), shuffle=(sampler is None and is_train), sampler=sampler,
+                          collate_fn=getattr(ds, "collater", None), drop_last=is_train)
+
+    def _reduce_grads(self):
+        """ONE all-reduce(SUM)/world of the flat gradients per optimizer step (the reference's DDP does it per micro-step)."""
+        if not is_dist_avail_and_initialized():
+            return
+        w = get_world_size()
+        for p in (self.model.trainable_decay, self.model.trainable_no_decay):
+            if p.grad is not None:
+                dist.all_reduce(p.grad, op=dist.ReduceOp.SUM)
+                p.grad.div_(w)
+
+    # ---- loops
+    def train(self):
+        run = self.config.run_cfg
+        best, best_epoch = -1.0, 0
+        t0 = time.time()
+        train_splits = run.get("train_splits", ["train"])
+        for epoch in range(self.start_epoch, run.max_epoch):
+            if not run.get("evaluate", False):
+                loader = self._loader(train_splits[0], True)
+                if hasattr(loader.sampler, "set_epoch"):
+                    loader.sampler.set_epoch(epoch)
+                stats = self.task.train_epoch(epoch=epoch, model=self.model, data_loader=loader, optimizer=self.optimizer,
+                                              lr_scheduler=self.lr_scheduler, log_freq=run.get("log_freq", 50),
+                                              accum_grad_iters=run.get("accum_grad_iters", 1), reduce_grads=self._reduce_grads)
+                self.log_stats(stats, "train")
+            for split in run.get("valid_splits", []):
+                m = self.eval_epoch(split, epoch)
+                if m is not None and is_main_process() and split == "val":
+                    if m["agg_metrics"] > best:
+                        best, best_epoch = m["agg_metrics"], epoch
+                        self._save_checkpoint(epoch, is_best=True)
+                    self.log_stats({**m, "best_epoch": best_epoch}, split)
+            if not run.get("valid_splits"):
+                self._save_checkpoint(epoch, is_best=False)
+            if run.get("evaluate", False):
+                break
+            if is_dist_avail_and_initialized():
+                dist.barrier()
+        logging.info("Training time {:.0f}s".format(time.time() - t0))
+
+    def evaluate(self, cur_epoch="best", skip_reload=False):
+        return {s: self.eval_epoch(s, cur_epoch) for s in self.config.run_cfg.get("test_splits", [])}
+
+    @torch.no_grad()
+    def eval_epoch(self, split_name, cur_epoch):
+        loader = self._loader(split_name, False)
+        if loader is None:
+            return None
+        self.model.eval()
+        results = self.task.evaluation(self.model, loader)
+        return self.task.after_evaluation(val_result=results, split_name=split_name, epoch=cur_epoch)
+
+    # ---- checkpoints: trainable tensors only (runner_base.py:572-600)
+    @main_process
+    def _save_checkpoint(self, cur_epoch, is_best=False):
+        obj = {"model": self.model.state_dict(), "optimizer": self.optimizer.state_dict(), "config": self.config.to_dict(), "epoch": cur_epoch}
+        path = os.path.join(self.output_dir, "checkpoint_{}.pth".format("best" if is_best else cur_epoch))
+        logging.info("Saving checkpoint at epoch {} to {}.".format(cur_epoch, path))
+        torch.save(obj, path)
+
+    def _load_checkpoint(self, path):
+        ck = torch.load(path, map_location="cpu")
+        self.model.load_state_dict(ck["model"], strict=True)
+        self.optimizer.load_state_dict(ck["optimizer"])
+        self.start_epoch = ck["epoch"] + 1
+        logging.info("Resume checkpoint from {}".format(path))
+
+    @main_process
+    def log_stats(self, stats, split_name):
+        with open(os.path.join(self.output_dir, "log.txt"), "a") as f:
+            f.write(json.dumps({f"{split_name}_{k}": v for k, v in stats.items()}, default=str) + "\n")

@@ -721,7 +721,7 @@ class MrBlipEngine:
     # ---- decoder + LM head + loss (forward and backward) ---------------------------------------------------------
     @torch.no_grad()
     def t5_decoder_forward(self, dec_ids: torch.Tensor, dec_mask: torch.Tensor, enc: torch.Tensor, B: int, S: int, kmask: torch.Tensor,
-                           labels: torch.Tensor, want_grad: bool = True):
+                           labels: Optional[torch.Tensor] = None, want_grad: bool = True):
         c = self.cfg
         d, H, dk, ff, p, V = c.d_model, c.t5_heads, c.d_kv, c.d_ff, c.t5_dropout, c.vocab
         inner = H * dk
@@ -787,6 +787,8 @@ class MrBlipEngine:
         ulm = self.buf("d_u_lm", (R, 64), bf16)
         logits = self.buf("d_logits", (R, V), f32, zero=False)
         self.lg_fwd(self.t5["lm"], seq, ulm, logits)
+        if labels is None:  # generation: logits only
+            return None, logits
         lab = labels.reshape(-1).to(self.dev, torch.int32)
         n_valid = int((labels != -100).sum())
         loss = self.buf("loss", (1,), f32)

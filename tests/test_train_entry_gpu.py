@@ -1,0 +1,65 @@
+"""End-to-end through the reference's entry points on a GPU: train.py --cfg-path ... (Config -> task -> blip2_mr -> runner_base),
+generate-based validation, trainable-only checkpoints, and loss.backward() through the autograd bridge."""
+import glob
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_train_py_synthetic_tiny(tmp_path):
+    import train
+    from lavis.common.registry import registry
+
+    cfg = os.path.join(ROOT, "mr-blip_amd/lavis/projects/mr_BLIP/train/synthetic_tiny.yaml")
+    train.main(["--cfg-path", cfg, "--options", f"run.output_dir={tmp_path}/out", "run.max_epoch=2"])
+    out = registry.get_path("output_dir")
+    log = open(os.path.join(out, "log.txt")).read().strip().splitlines()
+    assert any("train_loss" in l for l in log) and any("val_agg_metrics" in l for l in log)
+    import json
+    losses = [float(json.loads(l)["train_loss"]) for l in log if "train_loss" in l]
+    assert len(losses) == 2 and losses[1] < losses[0], losses          # the optimizer really moves the trainable tensors
+    ck = glob.glob(os.path.join(out, "checkpoint_*.pth"))
+    assert ck
+    sd = torch.load(ck[0], map_location="cpu")["model"]
+    # trainable tensors only, reference key names (peft naming for LoRA)
+    assert "t5_proj.weight" in sd and "ln_vision.bias" in sd
+    assert "t5_model.base_model.model.encoder.block.0.layer.0.SelfAttention.q.lora_A.default.weight" in sd
+    assert sd["t5_model.base_model.model.lm_head.lora_B.default.weight"].shape == (32128, 8)
+    assert not any(k.startswith("visual_encoder") or k.startswith("Qformer") for k in sd)
+
+
+def test_forward_backward_bridge_and_generate():
+    import lavis  # noqa: F401
+    from lavis.common.config import load_yaml
+    from lavis.common.registry import registry
+    from lavis.datasets import SyntheticMomentRetrievalDataset, collate
+
+    cls = registry.get_model_class("blip2_mr")
+    mcfg = load_yaml(cls.default_config_path("tiny_synthetic")).model
+    mcfg.update(dict(task="qformer_freeze_lora", input_time_format="seconds_integers", interleave_data=True))
+    model = cls.from_config(mcfg)
+    ds = SyntheticMomentRetrievalDataset(n_items=2, n_frms=4, image_size=56, duration=60.0)
+    samples = collate([ds[0], ds[1]])
+    model.train()
+    out = model(samples)
+    assert out["loss"].dim() == 0 and out["loss"].requires_grad
+    out["loss"].backward()
+    g = model.trainable_decay.grad
+    assert g is not None and torch.isfinite(g).all() and g.abs().sum() > 0
+    assert model.trainable_no_decay.grad.abs().sum() > 0
+    # checkpoint round trip keeps the loss
+    model.eval()
+    with torch.no_grad():
+        l0 = model(samples)["loss"].item()
+    sd = model.state_dict()
+    m2 = cls.from_config(mcfg)
+    m2.load_state_dict(sd, strict=True)
+    m2.eval()
+    with torch.no_grad():
+        assert abs(m2(samples)["loss"].item() - l0) < 1e-4
+    res = model.generate(samples, num_beams=2, max_length=6)
+    assert set(res) == {"duration", "prediction", "raw_prediction", "answer", "qid"} and len(res["prediction"]) == 2
