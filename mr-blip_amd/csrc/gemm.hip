@@ -30,16 +30,13 @@ struct GemmArgs {
   DropoutArg drop;
 };
 
-__device__ __forceinline__ void epilogue_store4(const GemmArgs& p, bool out_f32, int m, int n0, float v[4], int ncols) {
-  // v: 4 consecutive columns n0..n0+3 of row m (accumulator + nothing else yet)
+// v: 4 consecutive columns n0..n0+3 of row m (raw accumulator). Applies bias -> (pre-activation copy) -> GELU -> dropout -> residual.
+__device__ __forceinline__ void epilogue_apply4(const GemmArgs& p, int m, int n0, float v[4], int ncols, uint2* pre_out) {
   if (p.bias) {
     const float4 b = *reinterpret_cast<const float4*>(p.bias + n0);
     v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
   }
-  if (p.out2) {
-    uint2 pk = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
-    *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out2) + (long long)m * p.ldo2 + n0) = pk;
-  }
+  if (pre_out) *pre_out = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
   if (p.act == 1) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] = gelu_erf(v[i]);
@@ -54,31 +51,53 @@ __device__ __forceinline__ void epilogue_store4(const GemmArgs& p, bool out_f32,
     const float4 r = *reinterpret_cast<const float4*>(p.residual + (long long)m * p.ldr + n0);
     v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
   }
+}
+
+__device__ __forceinline__ void epilogue_store4(const GemmArgs& p, bool out_f32, int m, int n0, float v[4], int ncols) {
+  uint2 pre;
+  epilogue_apply4(p, m, n0, v, ncols, p.out2 ? &pre : nullptr);
+  if (p.out2) *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out2) + (long long)m * p.ldo2 + n0) = pre;
   if (out_f32) {
     *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + (long long)m * p.ldo + n0) = make_float4(v[0], v[1], v[2], v[3]);
   } else {
-    uint2 pk = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
-    *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + (long long)m * p.ldo + n0) = pk;
+    *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + (long long)m * p.ldo + n0) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
   }
 }
 
-__device__ __forceinline__ void epilogue_gated4(const GemmArgs& p, int m, int n0, const float h0[4], const float h1[4], int nh) {
-  // y = dropout(gelu(h0) * h1) -> bf16 out[m, n0..]; optional out2 = [h0 | h1] stacked ([M, 2*nh])
+// 8 consecutive columns of one row: 16-B bf16 stores (half the store instructions of the 4-wide form), 2 x 16 B for fp32
+__device__ __forceinline__ void epilogue_store8(const GemmArgs& p, bool out_f32, int m, int n0, float v[8], int ncols) {
+  uint2 pre0, pre1;
+  epilogue_apply4(p, m, n0, v, ncols, p.out2 ? &pre0 : nullptr);
+  epilogue_apply4(p, m, n0 + 4, v + 4, ncols, p.out2 ? &pre1 : nullptr);
+  if (p.out2) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.out2) + (long long)m * p.ldo2 + n0) = make_uint4(pre0.x, pre0.y, pre1.x, pre1.y);
+  if (out_f32) {
+    float4* o = reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + (long long)m * p.ldo + n0);
+    o[0] = make_float4(v[0], v[1], v[2], v[3]);
+    o[1] = make_float4(v[4], v[5], v[6], v[7]);
+  } else {
+    *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.out) + (long long)m * p.ldo + n0) =
+        make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+  }
+}
+
+// gated: y = dropout(gelu(h0) * h1) for 8 consecutive columns; optional out2 = [h0 | h1] stacked ([M, 2*nh])
+__device__ __forceinline__ void epilogue_gated8(const GemmArgs& p, int m, int n0, const float h0[8], const float h1[8], int nh) {
   if (p.out2) {
     bf16_t* o2 = reinterpret_cast<bf16_t*>(p.out2) + (long long)m * p.ldo2;
-    *reinterpret_cast<uint2*>(o2 + n0) = make_uint2(pack2bf(h0[0], h0[1]), pack2bf(h0[2], h0[3]));
-    *reinterpret_cast<uint2*>(o2 + nh + n0) = make_uint2(pack2bf(h1[0], h1[1]), pack2bf(h1[2], h1[3]));
+    *reinterpret_cast<uint4*>(o2 + n0) = make_uint4(pack2bf(h0[0], h0[1]), pack2bf(h0[2], h0[3]), pack2bf(h0[4], h0[5]), pack2bf(h0[6], h0[7]));
+    *reinterpret_cast<uint4*>(o2 + nh + n0) = make_uint4(pack2bf(h1[0], h1[1]), pack2bf(h1[2], h1[3]), pack2bf(h1[4], h1[5]), pack2bf(h1[6], h1[7]));
   }
-  float v[4];
+  float v[8];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) v[i] = gelu_erf(h0[i]) * h1[i];
+  for (int i = 0; i < 8; ++i) v[i] = gelu_erf(h0[i]) * h1[i];
   if (p.drop.seed_ptr) {
     const uint32_t seed = *p.drop.seed_ptr;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 8; ++i)
       v[i] = mrb_keep((uint32_t)m * (uint32_t)nh + (uint32_t)(n0 + i), seed, p.drop.site, p.drop.thresh24) ? v[i] * p.drop.inv_keep : 0.f;
   }
-  *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + (long long)m * p.ldo + n0) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+  *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.out) + (long long)m * p.ldo + n0) =
+      make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
 }
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -98,20 +117,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_tile_kernel(const GemmArgs
   const int wm = w / WGN, wn = w % WGN;
   const int hi = lane >> 5, l31 = lane & 31;
 
-  // ---- block -> tile: XCD-contiguous remap (bijective), then grouped ordering for L2 reuse of the W panel
-  const int nwg = gridDim.x;
-  int bid = blockIdx.x;
-  {
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  constexpr int GROUP_M = 8;
-  const int per_group = GROUP_M * p.tiles_n;
-  const int gid = bid / per_group;
-  const int first_m = gid * GROUP_M;
-  const int gsize = min(p.tiles_m - first_m, GROUP_M);
-  const int bm = first_m + (bid % per_group) % gsize;
-  const int bn = (bid % per_group) / gsize;
+  int bm = 0, bn = 0;  // current tile (persistent loop below)
 
   const int Nh = p.N >> 1;                    // GATED only
   constexpr int BNO = GATED ? BN / 2 : BN;  // output columns per block
@@ -173,12 +179,6 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_tile_kernel(const GemmArgs
   };
 
   f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   // fragment read offsets (bytes) inside a stage
   const int swz = (lane >> 1) & 7;
@@ -187,6 +187,28 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_tile_kernel(const GemmArgs
 #pragma unroll
   for (int nt = 0; nt < TN; ++nt)
     w_row_off[nt] = A_BYTES + (GATED ? (nt * (BN / 2) + wn * 32 + l31) : (wn * (BN / WGN) + nt * 32 + l31)) * 128;
+
+  // ---- persistent tile loop: grid = resident blocks; a block's epilogue stores drain while it already stages the next tile
+  const int ntiles = p.tiles_m * p.tiles_n;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  {  // tile id -> (bm, bn): XCD-contiguous remap (bijective), then grouped ordering for L2 reuse of the W panel
+    int bid = tile;
+    const int q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    constexpr int GROUP_M = 8;
+    const int per_group = GROUP_M * p.tiles_n;
+    const int gid = bid / per_group;
+    const int first_m = gid * GROUP_M;
+    const int gsize = min(p.tiles_m - first_m, GROUP_M);
+    bm = first_m + (bid % per_group) % gsize;
+    bn = (bid % per_group) / gsize;
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   stage(0, 0);
   for (int kt = 0; kt < nk; ++kt) {
@@ -210,37 +232,57 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_tile_kernel(const GemmArgs
     }
   }
 
-  // ---- epilogue: lane owns output row m = ... + l31; per accumulator group g: 4 consecutive columns
+  // ---- epilogue, staged through LDS so that global stores are full contiguous row segments (a lane holds 4 consecutive columns
+  // of ONE row per accumulator group: stored directly, every store instruction would touch 32 different 128-B lines).
+  // Each wave transposes 32 x (TN*32) fp32 slabs through its private LDS region (row stride padded by 16 B: conflict-free
+  // ds_write_b128 / ds_read_b128), then 16 lanes cover one row: 256-B (fp32) / 128-B (bf16) contiguous stores.
+  constexpr int SLAB_COLS = TN * 32;
+  constexpr int RS = SLAB_COLS * 4 + 16;          // bytes per slab row
+  constexpr int CPR = SLAB_COLS / 4;               // 16-B chunks per row
+  static_assert(32 * RS * NW <= 2 * STAGE, "epilogue slabs must fit in the staging buffers");
+  __syncthreads();                                 // every wave is done reading the staging buffers
+  char* slab = smem + w * (32 * RS);
   const int ncols = GATED ? Nh : p.N;
 #pragma unroll
   for (int mt = 0; mt < TM; ++mt) {
-    const int m = bm * BM + wm * (BM / WGM) + mt * 32 + l31;
-    if (m >= p.M) continue;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int nloc = 8 * g + 4 * hi;
-      if (GATED) {
-        const int n0 = bn * BNO + wn * 32 + nloc;
-        if (n0 < Nh) {
-          float h0[4], h1[4];
+    for (int nt = 0; nt < TN; ++nt)
 #pragma unroll
-          for (int i = 0; i < 4; ++i) { h0[i] = acc[mt][0][4 * g + i]; h1[i] = acc[mt][TN - 1][4 * g + i]; }
-          epilogue_gated4(p, m, n0, h0, h1, Nh);
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<float4*>(slab + l31 * RS + (nt * 32 + 8 * g + 4 * hi) * 4) =
+            make_float4(acc[mt][nt][4 * g], acc[mt][nt][4 * g + 1], acc[mt][nt][4 * g + 2], acc[mt][nt][4 * g + 3]);
+    const int m_base = bm * BM + wm * (BM / WGM) + mt * 32;
+    if (GATED) {
+      constexpr int ITEMS = 32 * 4;                // (row, 8-column group) items of the 32 x 32 gated output slab
+#pragma unroll
+      for (int i = 0; i < ITEMS / 64; ++i) {
+        const int idx = i * 64 + lane, r = idx >> 2, c = (idx & 3) * 2;
+        const float4 a0 = *reinterpret_cast<const float4*>(slab + r * RS + c * 16), a1 = *reinterpret_cast<const float4*>(slab + r * RS + (c + 1) * 16);
+        const float4 b0 = *reinterpret_cast<const float4*>(slab + r * RS + (c + 8) * 16), b1 = *reinterpret_cast<const float4*>(slab + r * RS + (c + 9) * 16);
+        const int m = m_base + r, n0 = bn * BNO + wn * 32 + c * 4;
+        if (m < p.M && n0 < Nh) {
+          const float h0[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w}, h1[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+          epilogue_gated8(p, m, n0, h0, h1, Nh);
         }
-      } else {
+      }
+    } else {
+      constexpr int GPR = CPR / 2;                 // 8-column groups per slab row
 #pragma unroll
-        for (int nt = 0; nt < TN; ++nt) {
-          const int n0 = bn * BN + wn * (BN / WGN) + nt * 32 + nloc;
-          if (n0 < p.N) {
-            float v[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = acc[mt][nt][4 * g + i];
-            epilogue_store4(p, OUT_F32, m, n0, v, ncols);
-          }
+      for (int i = 0; i < 32 * GPR / 64; ++i) {
+        const int idx = i * 64 + lane, r = idx / GPR, c = (idx % GPR) * 2;
+        const float4 a0 = *reinterpret_cast<const float4*>(slab + r * RS + c * 16), a1 = *reinterpret_cast<const float4*>(slab + r * RS + (c + 1) * 16);
+        const int m = m_base + r, n0 = bn * BN + wn * (BN / WGN) + c * 4;
+        if (m < p.M && n0 < p.N) {
+          float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+          epilogue_store8(p, OUT_F32, m, n0, v, ncols);
         }
       }
     }
   }
+  // the next tile's LDS-DMA overwrites the slabs: wait for this wave's LDS reads only (NOT for the global stores) and meet
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  }  // persistent tile loop
 }
 
 // ---- skinny-M kernel (decoder rows, M <= a few 32-row tiles): weight-streaming bound.  One block = 32 output
@@ -333,7 +375,18 @@ static int launch_tile(GemmArgs& a, hipStream_t st) {
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(WGM * WGN * 64), LDS, st, a);
+  static int num_cu = 0;
+  if (num_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { mrblip_set_error("gemm: cannot query device"); return MRBLIP_ELAUNCH; }
+    num_cu = prop.multiProcessorCount;
+  }
+  // 256x256 (one block per CU): persistent, one block per CU walks the tiles.  128x128: one block per tile (the hardware's dynamic
+  // dispatch of 2 blocks/CU measured slightly faster than a static persistent walk).
+  const int ntiles = a.tiles_m * a.tiles_n;
+  const int grid = (LDS > 80 * 1024 && ntiles > num_cu) ? num_cu : ntiles;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(WGM * WGN * 64), LDS, st, a);
   return mrblip_check_launch("gemm_tile");
 }
 
@@ -345,7 +398,7 @@ extern "C" int mrblip_gemm_bf16(const void* A, long long lda, const void* W, lon
   MRB_REQUIRE(M > 0 && N > 0 && K >= 0 && (K % 64) == 0, "gemm: need M,N>0 and K%%64==0 (M=%d N=%d K=%d)", M, N, K);
   MRB_REQUIRE(K > 0 || Aext, "gemm: empty contraction");
   MRB_REQUIRE((N % 8) == 0, "gemm: N %% 8 != 0 (N=%d)", N);
-  MRB_REQUIRE((lda % 8) == 0 && (ldw % 8) == 0 && (ldo % 4) == 0, "gemm: leading dims must keep 16-B alignment");
+  MRB_REQUIRE((lda % 8) == 0 && (ldw % 8) == 0 && (ldo % (out_f32 ? 4 : 8)) == 0 && (!out2 || (ldo2 % 8) == 0), "gemm: leading dims must keep 16-B alignment");
   MRB_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0 && ((uintptr_t)out % 16) == 0, "gemm: pointers must be 16-B aligned");
   MRB_REQUIRE((Aext == nullptr) == (Wext == nullptr), "gemm: Aext/Wext must come together");
   MRB_REQUIRE(((long long)(M + 256) * lda * 2 + 256) < (1ll << 32) && ((long long)(N + 256) * ldw * 2 + 256) < (1ll << 32),
