@@ -40,6 +40,12 @@ struct AttnArgs {
 };
 
 enum { F_LUT = 1, F_MASK = 2, F_CAUSAL = 4, F_DROP = 8, F_SPLIT = 16 };
+
+// attention-probability dropout draws: one 32-bit hash per (row, key pair): index = row * ceil(Sk/2) + key/2, the low 16 bits
+// serve the even key and the high 16 bits the odd key -> 8 hashes per 16 scores where a lane owns consecutive keys.
+__device__ __forceinline__ uint32_t attn_drop_hash(uint32_t row, int key, int skh, uint32_t seed, uint32_t site) {
+  return mrb_hash(row * (uint32_t)skh + (uint32_t)(key >> 1), seed, site);
+}
 #define NEG_BIG (-1.0e30f)
 
 __device__ __forceinline__ int perm23(int i) { return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1); }
@@ -112,7 +118,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
   const bf16_t* vtbase = p.Vt.ptr + b * p.Vt.bs + h * p.Vt.hs;
   const int* km = MASK ? p.kmask + (long long)b * p.Skpad : nullptr;
   const uint32_t drop_seed = DROP ? *p.drop.seed_ptr : 0u;
-  const uint32_t row_idx = ((uint32_t)(b * p.H + h) * (uint32_t)p.Sq + (uint32_t)q) * (uint32_t)p.Sk;
+  const uint32_t row_id = (uint32_t)(b * p.H + h) * (uint32_t)p.Sq + (uint32_t)q;
+  const int skh = (p.Sk + 1) >> 1;
   const int kstart = SPLIT ? w * 32 : 0, kstep = SPLIT ? 128 : 32;
 
   // software pipeline: K fragments of the next tile and V^T fragments of this tile are in flight during the score math
@@ -137,14 +144,21 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
     // lane (q, hi), register r  <->  key k0 + 16*(r>>3) + 8*hi + (r&7)
     float sv[16];
     if (LUT) {
-      float bias[16];
+      // every |key - q| >= 128 shares one bucket: tiles entirely beyond that distance need one LUT value, not sixteen reads
+      if (k0 - (q0 + 31) >= 128 || (q0 - (k0 + 31)) >= 128) {
+        const float bconst = lut[k0 > q0 ? 256 : 0];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int rel = (k0 + 16 * (r >> 3) + 8 * hi + (r & 7)) - q;
-        bias[r] = lut[max(-128, min(128, rel)) + 128];
+        for (int r = 0; r < 16; ++r) sv[r] = sacc[r] * p.scale + bconst;
+      } else {
+        float bias[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int rel = (k0 + 16 * (r >> 3) + 8 * hi + (r & 7)) - q;
+          bias[r] = lut[max(-128, min(128, rel)) + 128];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sv[r] = sacc[r] * p.scale + bias[r];
       }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sv[r] = sacc[r] * p.scale + bias[r];
     } else {
 #pragma unroll
       for (int r = 0; r < 16; ++r) sv[r] = sacc[r] * p.scale;
@@ -165,13 +179,17 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
     float pv[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      float e = ((vmask >> r) & 1u) ? __expf(sv[r] - m_new) : 0.f;
+      const float e = ((vmask >> r) & 1u) ? __expf(sv[r] - m_new) : 0.f;
       psum += e;
-      if (DROP) {
-        const int key = k0 + 16 * (r >> 3) + 8 * hi + (r & 7);
-        e = mrb_keep(row_idx + (uint32_t)key, drop_seed, p.drop.site, p.drop.thresh24) ? e * p.drop.inv_keep : 0.f;
-      }
       pv[r] = e;
+    }
+    if (DROP) {
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const uint32_t hsh = attn_drop_hash(row_id, k0 + 16 * (r >> 3) + 8 * hi + (r & 7), skh, drop_seed, p.drop.site);
+        pv[r] = (hsh & 0xffffu) >= p.drop.thresh24 ? pv[r] * p.drop.inv_keep : 0.f;
+        pv[r + 1] = (hsh >> 16) >= p.drop.thresh24 ? pv[r + 1] * p.drop.inv_keep : 0.f;
+      }
     }
     l_run = l_run * alpha + psum;
     m_run = m_new;
@@ -282,7 +300,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
   const bf16_t* ktbase = p.Kt.ptr + b * p.Kt.bs + h * p.Kt.hs;
   const int* km = MASK ? p.kmask + (long long)b * p.Skpad : nullptr;
   const uint32_t drop_seed = DROP ? *p.drop.seed_ptr : 0u;
-  const uint32_t row_idx = ((uint32_t)(b * p.H + h) * (uint32_t)p.Sq + (uint32_t)q) * (uint32_t)p.Sk;
+  const uint32_t row_id = (uint32_t)(b * p.H + h) * (uint32_t)p.Sq + (uint32_t)q;
+  const int skh = (p.Sk + 1) >> 1;
   const int kstart = SPLIT ? w * 32 : 0, kstep = SPLIT ? 128 : 32;
 
   bf16x8 kcur[KS], vcur[KS];
@@ -311,28 +330,43 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
     }
     float sv[16];
     if (LUT) {
-      float bias[16];
+      // every |key - q| >= 128 shares one bucket: tiles entirely beyond that distance need one LUT value, not sixteen reads
+      if (k0 - (q0 + 31) >= 128 || (q0 - (k0 + 31)) >= 128) {
+        const float bconst = lut[k0 > q0 ? 256 : 0];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int rel = (k0 + 16 * (r >> 3) + 8 * hi + (r & 7)) - q;
-        bias[r] = lut[max(-128, min(128, rel)) + 128];
+        for (int r = 0; r < 16; ++r) sv[r] = sacc[r] * p.scale + bconst;
+      } else {
+        float bias[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int rel = (k0 + 16 * (r >> 3) + 8 * hi + (r & 7)) - q;
+          bias[r] = lut[max(-128, min(128, rel)) + 128];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sv[r] = sacc[r] * p.scale + bias[r];
       }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sv[r] = sacc[r] * p.scale + bias[r];
     } else {
 #pragma unroll
       for (int r = 0; r < 16; ++r) sv[r] = sacc[r] * p.scale;
     }
-    float ds[16];
+    float ds[16], dpv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dpv[r] = dpacc[r];
+    if (DROP) {
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const uint32_t hsh = attn_drop_hash(row_id, k0 + 16 * (r >> 3) + 8 * hi + (r & 7), skh, drop_seed, p.drop.site);
+        dpv[r] = (hsh & 0xffffu) >= p.drop.thresh24 ? dpv[r] * p.drop.inv_keep : 0.f;
+        dpv[r + 1] = (hsh >> 16) >= p.drop.thresh24 ? dpv[r + 1] * p.drop.inv_keep : 0.f;
+      }
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int key = k0 + 16 * (r >> 3) + 8 * hi + (r & 7);
       bool ok = q_ok && key < p.Sk && ((vmask >> r) & 1u);
       if (CAUSAL) ok = ok && (key <= q);
       const float pr = ok ? __expf(sv[r] - lse) : 0.f;
-      float dpv = dpacc[r];
-      if (DROP) dpv = mrb_keep(row_idx + (uint32_t)key, drop_seed, p.drop.site, p.drop.thresh24) ? dpv * p.drop.inv_keep : 0.f;
-      ds[r] = ok ? pr * (dpv - delta) * p.scale : 0.f;
+      ds[r] = ok ? pr * (dpv[r] - delta) * p.scale : 0.f;
     }
     const bf16x8 f0 = pack8(ds), f1 = pack8(ds + 8);
 #pragma unroll
@@ -443,14 +477,20 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
     // lane (key, hi), register r  <->  query q0 + 16*(r>>3) + 8*hi + (r&7)
     float sv[16];
     if (LUT) {
-      float bias[16];
+      if (kb0 - (q0 + 31) >= 128 || (q0 - (kb0 + 31)) >= 128) {
+        const float bconst = lut[kb0 > q0 ? 256 : 0];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int rel = key - (q0 + 16 * (r >> 3) + 8 * hi + (r & 7));
-        bias[r] = lut[max(-128, min(128, rel)) + 128];
+        for (int r = 0; r < 16; ++r) sv[r] = sacc[r] * p.scale + bconst;
+      } else {
+        float bias[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int rel = key - (q0 + 16 * (r >> 3) + 8 * hi + (r & 7));
+          bias[r] = lut[max(-128, min(128, rel)) + 128];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sv[r] = sacc[r] * p.scale + bias[r];
       }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sv[r] = sacc[r] * p.scale + bias[r];
     } else {
 #pragma unroll
       for (int r = 0; r < 16; ++r) sv[r] = sacc[r] * p.scale;
@@ -464,7 +504,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
       const float pr = ok ? __expf(sv[r] - lse[r]) : 0.f;
       float dpv = dpacc[r], prd = pr;
       if (DROP) {
-        const bool keep = mrb_keep((bh_idx + (uint32_t)qq) * (uint32_t)p.Sk + (uint32_t)key, drop_seed, p.drop.site, p.drop.thresh24);
+        const uint32_t hsh = attn_drop_hash(bh_idx + (uint32_t)qq, key, (p.Sk + 1) >> 1, drop_seed, p.drop.site);
+        const bool keep = ((key & 1) ? (hsh >> 16) : (hsh & 0xffffu)) >= p.drop.thresh24;
         dpv = keep ? dpv * p.drop.inv_keep : 0.f;
         prd = keep ? pr * p.drop.inv_keep : 0.f;
       }
@@ -481,6 +522,177 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
     }
 #pragma unroll
     for (int s = 0; s < KS; ++s) { qcur[s] = qnext[s]; docur[s] = donext[s]; }
+  }
+  if (key < p.Sk) {
+    bf16_t* kp = const_cast<bf16_t*>(p.dK.ptr) + b * p.dK.bs + h * p.dK.hs + (long long)key * p.dK.rs;
+    bf16_t* vp = const_cast<bf16_t*>(p.dV.ptr) + b * p.dV.bs + h * p.dV.hs + (long long)key * p.dV.rs;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d0 = mt * 32 + 8 * g + 4 * hi;
+        if (d0 < p.D) {
+          *reinterpret_cast<uint2*>(kp + d0) = make_uint2(pack2bf(dk[mt][4 * g], dk[mt][4 * g + 1]), pack2bf(dk[mt][4 * g + 2], dk[mt][4 * g + 3]));
+          *reinterpret_cast<uint2*>(vp + d0) = make_uint2(pack2bf(dv[mt][4 * g], dv[mt][4 * g + 1]), pack2bf(dv[mt][4 * g + 2], dv[mt][4 * g + 3]));
+        }
+      }
+  }
+}
+
+// ---- dK/dV with the query-side tiles shared through LDS (head_dim 64).  The four key-waves of a block consume the SAME Q, dO,
+// Q^T, dO^T, LSE, Delta tile per step, so the block loads each tile once (16-B coalesced global loads -> registers -> LDS,
+// issued one step ahead: the loads of tile t+1 fly while tile t is computed) instead of four times from L2; fragments are read
+// with ds_read_b128 from XOR-swizzled rows (128-B rows: chunk ^= (row>>1)&7; 64-B rows: chunk ^= (row>>2)&3), conflict-free.
+template <int FLAGS>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_lds_kernel(const AttnArgs p) {
+  constexpr int KS = 4, MT = 2;
+  constexpr bool LUT = FLAGS & F_LUT, MASK = FLAGS & F_MASK, CAUSAL = FLAGS & F_CAUSAL, DROP = FLAGS & F_DROP;
+  constexpr int TILE = 4 * 4096 + 256;  // Q rows | dO rows | Q^T | dO^T | lse[32] delta[32]
+  __shared__ float lut[LUT ? 257 : 1];
+  __shared__ __attribute__((aligned(16))) char sm[2 * TILE];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, hi = lane >> 5, l31 = lane & 31;
+  const int b = blockIdx.z, h = blockIdx.y;
+  if (LUT) {
+    for (int i = tid; i < 257; i += 256) lut[i] = p.lut[h * 257 + i];
+  }
+  const int kb0 = (blockIdx.x * 4 + w) * 32;
+  const int key = kb0 + l31;
+  bool key_ok = key < p.Sk;
+  bf16x8 kf[KS], vf[KS];
+  load_rows<KS>(kf, p.K.ptr + b * p.K.bs + h * p.K.hs, p.K.rs, key, p.Sk, p.D, hi);
+  load_rows<KS>(vf, p.V.ptr + b * p.V.bs + h * p.V.hs, p.V.rs, key, p.Sk, p.D, hi);
+  if (MASK) key_ok = key_ok && (p.kmask[(long long)b * p.Skpad + min(key, p.Skpad - 1)] != 0);
+  f32x16 dk[MT], dv[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) { zero16(dk[mt]); zero16(dv[mt]); }
+  const bf16_t* qbase = p.Q.ptr + b * p.Q.bs + h * p.Q.hs;
+  const bf16_t* dobase = p.dO.ptr + b * p.dO.bs + h * p.dO.hs;
+  const bf16_t* qtbase = p.Qt.ptr + b * p.Qt.bs + h * p.Qt.hs;
+  const bf16_t* dotbase = p.dOt.ptr + b * p.dOt.bs + h * p.dOt.hs;
+  const float* lsebase = p.LSE + ((long long)(b * p.H + h)) * p.Sqpad;
+  const float* delbase = p.Delta + ((long long)(b * p.H + h)) * p.Sqpad;
+  const uint32_t drop_seed = DROP ? *p.drop.seed_ptr : 0u;
+  const uint32_t bh_idx = (uint32_t)(b * p.H + h) * (uint32_t)p.Sq;
+  const int qstart = CAUSAL ? blockIdx.x * 128 : 0;  // block-uniform (the per-wave causal limit is applied by the mask)
+
+  // staging roles of this thread: row tile (32 rows x 8 chunks) and transposed tile (64 rows x 4 chunks)
+  const int r_row = tid >> 3, r_chunk = tid & 7, t_row = tid >> 2, t_chunk = tid & 3;
+  const int r_off = r_row * 128 + ((r_chunk ^ ((r_row >> 1) & 7)) << 4);
+  const int t_off = t_row * 64 + ((t_chunk ^ ((t_row >> 2) & 3)) << 4);
+  const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+  bf16x8 g_q, g_do, g_qt, g_dot;
+  float4 g_st;
+  auto gload = [&](int q0) {
+    const int qr = q0 + r_row;
+    const bool ok = qr < p.Sq && r_chunk * 8 < p.D;
+    const long long ro = (long long)min(qr, p.Sq - 1) * p.Q.rs + min(r_chunk * 8, p.D - 8);
+    const long long rdo = (long long)min(qr, p.Sq - 1) * p.dO.rs + min(r_chunk * 8, p.D - 8);
+    g_q = sel8(ok, ld8(qbase + ro));
+    g_do = sel8(ok, ld8(dobase + rdo));
+    g_qt = ld8(qtbase + (long long)t_row * p.Qt.ds + q0 + t_chunk * 8);      // padded copies: always in bounds, zeros outside
+    g_dot = ld8(dotbase + (long long)t_row * p.dOt.ds + q0 + t_chunk * 8);
+    if (tid < 16) g_st = *reinterpret_cast<const float4*>((tid < 8 ? lsebase : delbase) + q0 + (tid & 7) * 4);
+  };
+  auto lstore = [&](int buf) {
+    char* base = sm + buf * TILE;
+    *reinterpret_cast<bf16x8*>(base + r_off) = g_q;
+    *reinterpret_cast<bf16x8*>(base + 4096 + r_off) = g_do;
+    *reinterpret_cast<bf16x8*>(base + 8192 + t_off) = g_qt;
+    *reinterpret_cast<bf16x8*>(base + 12288 + t_off) = g_dot;
+    if (tid < 16) *reinterpret_cast<float4*>(base + 16384 + tid * 16) = g_st;
+  };
+  gload(qstart);
+  lstore(0);
+  __syncthreads();
+
+  const int frow = perm23(l31);                    // fragment row of the row tiles (the MFMA row permutation)
+  const int f_sw = (frow >> 1) & 7, t_sw = (l31 >> 2) & 3;
+  int it = 0;
+  for (int q0 = qstart; q0 < p.Sq; q0 += 32, ++it) {
+    const char* base = sm + (it & 1) * TILE;
+    const bool more = q0 + 32 < p.Sq;
+    if (more) gload(q0 + 32);
+    bf16x8 qcur[KS], docur[KS], dotf[MT][2], qtf[MT][2];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int off = frow * 128 + (((2 * s + hi) ^ f_sw) << 4);
+      qcur[s] = *reinterpret_cast<const bf16x8*>(base + off);
+      docur[s] = *reinterpret_cast<const bf16x8*>(base + 4096 + off);
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const int off = (mt * 32 + l31) * 64 + (((2 * s2 + hi) ^ t_sw) << 4);
+        qtf[mt][s2] = *reinterpret_cast<const bf16x8*>(base + 8192 + off);
+        dotf[mt][s2] = *reinterpret_cast<const bf16x8*>(base + 12288 + off);
+      }
+    float lse[16], del[16];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const float* sp = reinterpret_cast<const float*>(base + 16384) + 16 * c + 8 * hi;
+      const float4 a0 = *reinterpret_cast<const float4*>(sp), a1 = *reinterpret_cast<const float4*>(sp + 4);
+      const float4 b0 = *reinterpret_cast<const float4*>(sp + 32), b1 = *reinterpret_cast<const float4*>(sp + 36);
+      lse[8 * c + 0] = a0.x; lse[8 * c + 1] = a0.y; lse[8 * c + 2] = a0.z; lse[8 * c + 3] = a0.w;
+      lse[8 * c + 4] = a1.x; lse[8 * c + 5] = a1.y; lse[8 * c + 6] = a1.z; lse[8 * c + 7] = a1.w;
+      del[8 * c + 0] = b0.x; del[8 * c + 1] = b0.y; del[8 * c + 2] = b0.z; del[8 * c + 3] = b0.w;
+      del[8 * c + 4] = b1.x; del[8 * c + 5] = b1.y; del[8 * c + 6] = b1.z; del[8 * c + 7] = b1.w;
+    }
+    f32x16 sacc, dpacc;
+    zero16(sacc);
+    zero16(dpacc);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qcur[s], kf[s], sacc, 0, 0, 0);
+      dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(docur[s], vf[s], dpacc, 0, 0, 0);
+    }
+    float sv[16];
+    if (LUT) {
+      if (kb0 - (q0 + 31) >= 128 || (q0 - (kb0 + 31)) >= 128) {
+        const float bconst = lut[kb0 > q0 ? 256 : 0];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sv[r] = sacc[r] * p.scale + bconst;
+      } else {
+        float bias[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int rel = key - (q0 + 16 * (r >> 3) + 8 * hi + (r & 7));
+          bias[r] = lut[max(-128, min(128, rel)) + 128];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sv[r] = sacc[r] * p.scale + bias[r];
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sv[r] = sacc[r] * p.scale;
+    }
+    float pd[16], ds[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int qq = q0 + 16 * (r >> 3) + 8 * hi + (r & 7);
+      bool ok = key_ok && qq < p.Sq;
+      if (CAUSAL) ok = ok && (key <= qq);
+      const float pr = ok ? __expf(sv[r] - lse[r]) : 0.f;
+      float dpv = dpacc[r], prd = pr;
+      if (DROP) {
+        const uint32_t hsh = attn_drop_hash(bh_idx + (uint32_t)qq, key, (p.Sk + 1) >> 1, drop_seed, p.drop.site);
+        const bool keep = ((key & 1) ? (hsh >> 16) : (hsh & 0xffffu)) >= p.drop.thresh24;
+        dpv = keep ? dpv * p.drop.inv_keep : 0.f;
+        prd = keep ? pr * p.drop.inv_keep : 0.f;
+      }
+      pd[r] = prd;
+      ds[r] = ok ? pr * (dpv - del[r]) * p.scale : 0.f;
+    }
+    const bf16x8 p0 = pack8(pd), p1 = pack8(pd + 8), s0 = pack8(ds), s1 = pack8(ds + 8);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      dv[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dotf[mt][0], p0, dv[mt], 0, 0, 0);
+      dv[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dotf[mt][1], p1, dv[mt], 0, 0, 0);
+      dk[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf[mt][0], s0, dk[mt], 0, 0, 0);
+      dk[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf[mt][1], s1, dk[mt], 0, 0, 0);
+    }
+    if (more) lstore((it & 1) ^ 1);
+    __syncthreads();
   }
   if (key < p.Sk) {
     bf16_t* kp = const_cast<bf16_t*>(p.dK.ptr) + b * p.dK.bs + h * p.dK.hs + (long long)key * p.dK.rs;
@@ -548,7 +760,7 @@ static int attn_fill(AttnArgs& a, const void* Q, const long long* qs, const void
 static void attn_drop(AttnArgs& a, const uint32_t* seed_ptr, uint32_t site, float p_drop) {
   a.drop.seed_ptr = (p_drop > 0.f) ? seed_ptr : nullptr;
   a.drop.site = site;
-  a.drop.thresh24 = (uint32_t)(p_drop * 16777216.0f + 0.5f);
+  a.drop.thresh24 = (uint32_t)(p_drop * 65536.0f + 0.5f);
   a.drop.inv_keep = 1.0f / (1.0f - p_drop);
 }
 
@@ -560,7 +772,8 @@ static int attn_flags(const AttnArgs& a, int causal) {
 // LUT|MASK[|DROP] (T5 encoder), LUT|MASK|CAUSAL[|DROP] (decoder self), MASK[|DROP] (decoder cross).
 #define ATTN_FLAG_CASES(X, DPV)                                                                                          \
   X(DPV, 0) X(DPV, F_DROP) X(DPV, F_LUT | F_MASK) X(DPV, F_LUT | F_MASK | F_DROP) X(DPV, F_LUT | F_MASK | F_CAUSAL)       \
-  X(DPV, F_LUT | F_MASK | F_CAUSAL | F_DROP) X(DPV, F_MASK) X(DPV, F_MASK | F_DROP)
+  X(DPV, F_LUT | F_MASK | F_CAUSAL | F_DROP) X(DPV, F_MASK) X(DPV, F_MASK | F_DROP)                                    \
+  X(DPV, F_LUT) X(DPV, F_LUT | F_DROP) X(DPV, F_LUT | F_CAUSAL) X(DPV, F_LUT | F_CAUSAL | F_DROP)
 
 template <int DP>
 static int launch_fwd(const AttnArgs& a, int flags, hipStream_t stream) {
@@ -586,7 +799,8 @@ static int launch_bwd(const AttnArgs& a, int flags, hipStream_t stream) {
   if (flags == (FL)) {                                                                                         \
     if (split && !((FL) & F_CAUSAL)) hipLaunchKernelGGL((attn_bwd_dq_kernel<DPV, ((FL) & ~F_CAUSAL) | F_SPLIT>), gq, dim3(256), 0, stream, a); \
     else hipLaunchKernelGGL((attn_bwd_dq_kernel<DPV, (FL)>), gq, dim3(256), 0, stream, a);                      \
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<DPV, (FL)>), gk, dim3(256), 0, stream, a);                          \
+    if (DPV == 64 && a.D == 64 && a.Sq > 32) hipLaunchKernelGGL((attn_bwd_dkv_lds_kernel<(FL)>), gk, dim3(256), 0, stream, a); \
+    else hipLaunchKernelGGL((attn_bwd_dkv_kernel<DPV, (FL)>), gk, dim3(256), 0, stream, a);                     \
     return mrblip_check_launch("attention_bwd");                                                               \
   }
   ATTN_FLAG_CASES(X, DP)

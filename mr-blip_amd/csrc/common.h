@@ -38,25 +38,30 @@ __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) { return (uint32
 // (oracle/mrblip_oracle.py: dropout_keep) so training-mode parity can be checked with p > 0.
 // seed = *seed_ptr (device memory, bumped once per step so hipGraph replays draw fresh masks), site = call-site id.
 __device__ __forceinline__ uint32_t mrb_hash(uint32_t idx, uint32_t seed, uint32_t site) {
-  uint32_t h = idx ^ (seed * 0x9E3779B1u);
-  h *= 0x85EBCA77u;
+  // two multiply-xorshift rounds (integer multiplies are quarter rate on CDNA: keep them to two)
+  uint32_t h = (idx ^ seed) * 0x9E3779B1u + site * 0x85EBCA77u;
   h ^= h >> 15;
-  h += site * 0xC2B2AE3Du + 0x27D4EB2Fu;
-  h *= 0x9E3779B1u;
-  h ^= h >> 13;
   h *= 0xC2B2AE3Du;
-  h ^= h >> 16;
+  h ^= h >> 13;
   return h;
 }
-// keep iff top 24 bits >= thresh24, thresh24 = round(p * 2^24)
-__device__ __forceinline__ bool mrb_keep(uint32_t idx, uint32_t seed, uint32_t site, uint32_t thresh24) {
-  return (mrb_hash(idx, seed, site) >> 8) >= thresh24;
+// One 32-bit hash serves the element PAIR (idx & ~1, idx | 1): even index -> low 16 bits, odd index -> high 16 bits.
+// keep iff the 16-bit draw >= thresh16 = round(p * 65536)   (p = 0.1 -> 6554/65536 = 0.10001)
+__device__ __forceinline__ bool mrb_keep(uint32_t idx, uint32_t seed, uint32_t site, uint32_t thresh16) {
+  const uint32_t h = mrb_hash(idx >> 1, seed, site);
+  return ((idx & 1u) ? (h >> 16) : (h & 0xffffu)) >= thresh16;
+}
+// both draws of the pair starting at the EVEN index idx
+__device__ __forceinline__ void mrb_keep2(uint32_t idx_even, uint32_t seed, uint32_t site, uint32_t thresh16, bool& k0, bool& k1) {
+  const uint32_t h = mrb_hash(idx_even >> 1, seed, site);
+  k0 = (h & 0xffffu) >= thresh16;
+  k1 = (h >> 16) >= thresh16;
 }
 
 struct DropoutArg {
   const uint32_t* seed_ptr;  // nullptr or p == 0 -> disabled
   uint32_t site;
-  uint32_t thresh24;
+  uint32_t thresh24;  // 16-bit threshold round(p * 65536) (historic field name)
   float inv_keep;  // 1 / (1 - p)
 };
 

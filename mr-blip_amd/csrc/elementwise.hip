@@ -290,7 +290,7 @@ static DropoutArg mk_drop(const uint32_t* seed_ptr, uint32_t site, float p) {
   DropoutArg d;
   d.seed_ptr = (p > 0.f) ? seed_ptr : nullptr;
   d.site = site;
-  d.thresh24 = (uint32_t)(p * 16777216.0f + 0.5f);
+  d.thresh24 = (uint32_t)(p * 65536.0f + 0.5f);
   d.inv_keep = 1.0f / (1.0f - p);
   return d;
 }

@@ -411,7 +411,7 @@ extern "C" int mrblip_gemm_bf16(const void* A, long long lda, const void* W, lon
   a.M = M; a.N = N; a.K = K; a.act = act; a.tiles_m = a.tiles_n = 0;
   a.drop.seed_ptr = (p_drop > 0.f) ? seed_ptr : nullptr;
   a.drop.site = site;
-  a.drop.thresh24 = (uint32_t)(p_drop * 16777216.0f + 0.5f);
+  a.drop.thresh24 = (uint32_t)(p_drop * 65536.0f + 0.5f);
   a.drop.inv_keep = 1.0f / (1.0f - p_drop);
   MRB_REQUIRE(!(p_drop > 0.f) || seed_ptr, "gemm: dropout needs a device seed pointer");
   // tile_cfg: 0 auto, 1 = 256x256, 2 = 128x128, 3 = skinny

@@ -143,7 +143,7 @@ class BLIP2_MR(BaseModel):
             K = max(1, int(num_beams))
             # replicate encoder rows per beam: [B*K sequences]
             enc_k = enc.view(B, S, -1).repeat_interleave(K, 0).reshape(B * K * S, -1).contiguous()
-            mask_k = L["mask"].repeat_interleave(K, 0).contiguous()
+            mask_k = None if L["mask"] is None else L["mask"].repeat_interleave(K, 0).contiguous()
             seqs = torch.zeros(B * K, 1, dtype=torch.long)
             scores = torch.zeros(B, K)
             scores[:, 1:] = -1e9

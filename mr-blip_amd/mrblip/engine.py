@@ -944,8 +944,10 @@ class MrBlipEngine:
         return dict(frame_src=layout.frame_src.to(dev), frame_dst=layout.frame_dst.to(dev), emb_src=layout.emb_src.to(dev),
                     emb_dst=layout.emb_dst.to(dev), mask=self.pad_mask(layout.attention_mask))
 
-    def pad_mask(self, m: torch.Tensor) -> torch.Tensor:
+    def pad_mask(self, m: torch.Tensor) -> Optional[torch.Tensor]:
         """[B,S] 0/1 mask -> int32 [B, rup32(S)] on the device (the attention kernels read the key mask 16 B at a time)."""
+        if bool((m != 0).all()):
+            return None  # nothing is masked: the attention kernels run their mask-free specialisation
         B, S = m.shape
         out = torch.zeros(B, ops.rup32(S), dtype=torch.int32, device=self.dev)
         out[:, :S] = m.to(self.dev, torch.int32)

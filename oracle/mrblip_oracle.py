@@ -399,24 +399,34 @@ def _u32(x):
 
 
 def dropout_hash(idx: Tensor, seed: int, site: int) -> Tensor:
-    """Restates csrc/common.h mrb_hash (uint32 arithmetic emulated in int64).  idx: int64 tensor of element indices."""
+    """Restates csrc/common.h mrb_hash (uint32 arithmetic emulated in int64).  idx: int64 tensor of PAIR indices."""
     idx = idx.to(torch.int64)
-    h = _u32(idx ^ _u32(torch.tensor(seed, dtype=torch.int64) * 0x9E3779B1))
-    h = _u32(h * 0x85EBCA77)
+    h = _u32(_u32((idx ^ (seed & 0xFFFFFFFF)) * 0x9E3779B1) + _u32(site * 0x85EBCA77))
     h = h ^ (h >> 15)
-    h = _u32(h + _u32(site * 0xC2B2AE3D + 0x27D4EB2F))
-    h = _u32(h * 0x9E3779B1)
-    h = h ^ (h >> 13)
     h = _u32(h * 0xC2B2AE3D)
-    h = h ^ (h >> 16)
+    h = h ^ (h >> 13)
     return h
 
 
 def dropout_keep(shape, seed: int, site: int, p: float) -> Tensor:
-    """keep mask (float 0/1) of an element-indexed dropout site: idx = flat row-major index mod 2^32."""
+    """keep mask (float 0/1) of an element-indexed dropout site: element idx = flat row-major index mod 2^32; one 32-bit hash
+    per index pair, low half -> even index, high half -> odd index, keep iff the 16-bit draw >= round(p * 65536)."""
     n = 1
     for s in shape:
         n *= s
     idx = torch.arange(n, dtype=torch.int64) & 0xFFFFFFFF
-    thresh = int(p * 16777216.0 + 0.5)
-    return ((dropout_hash(idx, seed, site) >> 8) >= thresh).reshape(shape).float()
+    h = dropout_hash(idx >> 1, seed, site)
+    draw = torch.where((idx & 1) == 1, h >> 16, h & 0xFFFF)
+    thresh = int(p * 65536.0 + 0.5)
+    return (draw >= thresh).reshape(shape).float()
+
+
+def dropout_keep_attn(B: int, H: int, Sq: int, Sk: int, seed: int, site: int, p: float) -> Tensor:
+    """keep mask [B,H,Sq,Sk] of the attention-probability dropout (csrc/attention.hip attn_drop_hash): one hash per
+    (row = (b*H+h)*Sq+q, key pair), low 16 bits -> even key, high 16 bits -> odd key."""
+    skh = (Sk + 1) // 2
+    row = torch.arange(B * H * Sq, dtype=torch.int64)[:, None]
+    key = torch.arange(Sk, dtype=torch.int64)[None, :]
+    h = dropout_hash((row * skh + (key >> 1)) & 0xFFFFFFFF, seed, site)
+    draw = torch.where((key & 1) == 1, h >> 16, h & 0xFFFF)
+    return (draw >= int(p * 65536.0 + 0.5)).reshape(B, H, Sq, Sk).float()

@@ -197,7 +197,8 @@ def test_attention_bias_mask_dropout_fwd_bwd(ops, causal, B, H, Sq, Sk, D):
     mask = kmask[:, :Sk].bool()[:, None, None, :].expand(B, H, Sq, Sk)
     if causal:
         mask = mask & torch.tril(torch.ones(Sq, Sk, dtype=torch.bool, device=dev()))[None, None]
-    dmask = keep_mask((B, H, Sq, Sk), 4242, 11, p)
+    from oracle.mrblip_oracle import dropout_keep_attn
+    dmask = dropout_keep_attn(B, H, Sq, Sk, 4242, 11, p).to(dev())
     ref, _ = _attn_ref(qr, kr, vr, scale, bias, mask, dmask, p)
     assert rel(o.float().permute(0, 2, 1, 3), ref) < 6e-3
     ref.backward(do.float().permute(0, 2, 1, 3))
