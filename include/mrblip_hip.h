@@ -100,6 +100,10 @@ int mrblip_dropout_bf16(const void* x, long long ldx, void* out, long long ldo, 
                         float p, mrblip_stream_t stream);
 /* out[c] += sum_m x[m,c] (bias gradient of t5_proj, blip2_mr.py:270-272) */
 int mrblip_colsum(const float* x, long long ldx, int M, int N, float* out, mrblip_stream_t stream);
+/* LoRA weight gradients without transposed copies: for j < R/8: outs[j][(r%8)*lds[j] + c - col0[j]] += sum_m U[m, 8j + r%8] * drop(Y)[m, c]
+ * for the columns col0[j] <= c < col0[j] + ncols[j]  (dB^T = u^T dy is block-diagonal over the adapters of a fused group, dA = g^T dropout(x)) */
+int mrblip_lora_tn(const void* Y, long long ldy, const void* U, long long ldu, int M, int C, int R, float* const* outs, const int* col0,
+                   const int* ncols, const long long* lds, const uint32_t* seed_ptr, uint32_t site, float p_drop, mrblip_stream_t stream);
 /* fp32 LoRA master weights -> bf16 GEMM operands for every adapter of a device descriptor table (8 int64 per adapter:
  * a_off, bt_off, K, out, acat_off, wext_off, bblk_off, Ntot) */
 int mrblip_lora_pack(const float* flat, void* acat_bf16, void* wext_bf16, void* bblk_bf16, const long long* desc, int n_adapters,

@@ -439,3 +439,93 @@ extern "C" int mrblip_gemm_bf16(const void* A, long long lda, const void* W, lon
   if (gated) return launch_tile<128, 128, 2, 2, false, true>(a, stream);
   return out_f32 ? launch_tile<128, 128, 2, 2, true, false>(a, stream) : launch_tile<128, 128, 2, 2, false, false>(a, stream);
 }
+
+// ---- thin "TN" product for the LoRA weight gradients:  D[r, c] += sum_m U[m, r] * drop(Y)[m, c],  r < 32, contraction over the
+// ROWS of two row-major matrices (dB^T = u^T dy, dA = g^T dropout(x)).  No transposed copies: the MFMA fragments are gathered with
+// 2-byte loads that are 64-B coalesced across lanes (lane = column), which is cheap for this memory-light product (Y is read once).
+// One block = 32 columns of Y, its 8 waves split M and reduce through LDS; every (r, c) has one owner block, so the += needs no
+// atomics.  Up to 4 adapters share one launch: rows [8j, 8j+8) go to seg[j] for the columns seg[j] owns (block-diagonal for dB^T).
+struct TnSeg { float* out; int col0, ncols; long long ld; };
+struct TnArgs {
+  const bf16_t* Y; const bf16_t* U;
+  long long ldy, ldu;
+  int M, C, R;
+  TnSeg seg[4];
+  DropoutArg drop;
+};
+
+__global__ __launch_bounds__(512) void lora_tn_kernel(const TnArgs p) {
+  __shared__ float red[7][16][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, hi = lane >> 5, l31 = lane & 31;
+  const int c = blockIdx.x * 32 + l31;
+  const bool c_ok = c < p.C, r_ok = l31 < p.R;
+  const uint32_t seed = p.drop.seed_ptr ? *p.drop.seed_ptr : 0u;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int steps = (p.M + 15) / 16;                 // 16 rows of M per MFMA
+  const int per = (steps + 7) / 8;
+  const int s_beg = w * per, s_end = min(steps, s_beg + per);
+  const bf16_t* yp = p.Y + (c_ok ? c : 0);
+  const bf16_t* up = p.U + (r_ok ? l31 : 0);
+#pragma unroll 1
+  for (int s0 = s_beg; s0 < s_end; s0 += 4) {
+    bf16x8 uf[4], yf[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int m0 = (s0 + u) * 16 + 8 * hi;
+      const bool live = s0 + u < s_end;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int m = m0 + j;
+        const bool ok = live && m < p.M;
+        const long long mm = ok ? m : 0;
+        bf16_t yv = yp[mm * p.ldy], uv = up[mm * p.ldu];
+        if (p.drop.seed_ptr) {
+          const bool keep = mrb_keep((uint32_t)m * (uint32_t)p.C + (uint32_t)c, seed, p.drop.site, p.drop.thresh24);
+          yv = keep ? f2bf(bf2f(yv) * p.drop.inv_keep) : (bf16_t)0;
+        }
+        yf[u][j] = (ok && c_ok) ? (short)yv : (short)0;
+        uf[u][j] = (ok && r_ok) ? (short)uv : (short)0;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uf[u], yf[u], acc, 0, 0, 0);
+  }
+  if (w > 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[w - 1][r][lane] = acc[r];
+  }
+  __syncthreads();
+  if (w == 0 && c_ok) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float v = acc[r];
+#pragma unroll
+      for (int j = 0; j < 7; ++j) v += red[j][r][lane];
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;   // D row (= LoRA rank index over the stacked adapters), column c = lane
+      if (row < p.R) {
+        const TnSeg sg = p.seg[row >> 3];
+        if (sg.out && c >= sg.col0 && c < sg.col0 + sg.ncols) sg.out[(long long)(row & 7) * sg.ld + (c - sg.col0)] += v;
+      }
+    }
+  }
+}
+
+extern "C" int mrblip_lora_tn(const void* Y, long long ldy, const void* U, long long ldu, int M, int C, int R, float* const* outs,
+                              const int* col0, const int* ncols, const long long* lds, const uint32_t* seed_ptr, uint32_t site, float p_drop,
+                              hipStream_t stream) {
+  MRB_REQUIRE(M > 0 && C > 0 && R > 0 && R <= 32 && (R % 8) == 0, "lora_tn: bad shape (M=%d C=%d R=%d)", M, C, R);
+  TnArgs a;
+  a.Y = (const bf16_t*)Y; a.U = (const bf16_t*)U; a.ldy = ldy; a.ldu = ldu; a.M = M; a.C = C; a.R = R;
+  for (int j = 0; j < 4; ++j) {
+    if (j < R / 8) a.seg[j] = TnSeg{outs[j], col0[j], ncols[j], lds[j]};
+    else a.seg[j] = TnSeg{nullptr, 0, 0, 0};
+  }
+  a.drop.seed_ptr = (p_drop > 0.f) ? seed_ptr : nullptr;
+  a.drop.site = site;
+  a.drop.thresh24 = (uint32_t)(p_drop * 65536.0f + 0.5f);
+  a.drop.inv_keep = 1.0f / (1.0f - p_drop);
+  hipLaunchKernelGGL(lora_tn_kernel, dim3((C + 31) / 32), dim3(512), 0, stream, a);
+  return mrblip_check_launch("lora_tn");
+}

@@ -607,20 +607,10 @@ class MrBlipEngine:
         """dy bf16 [M,N]; x the saved bf16 input; u the saved [M,64] LoRA activations.  Accumulates dA, dB of every adapter of the
         group and (optionally) dx = dy W (+ residual) + mask * (g A)."""
         drop = self.drop(g.site, self.cfg.lora_dropout)
-        M = dy.shape[0]
-        Mp = pad64(M)
         ops.gemm(dy, g.bblk, gbuf, tile_cfg=3, K=g.N)                      # g' = scale * dy @ B      [M, 8*nad]
-        dyT = self.buf(f"lg_dyT_{g.N}_{Mp}", (g.N, Mp), bf16)
-        self.transpose2d(dy, g.N, dyT)
-        xdT = self.buf(f"lg_xdT_{g.K}_{Mp}", (g.K, Mp), bf16)
-        self.transpose2d(x, g.K, xdT, drop=drop)                           # dropout(x)^T, same mask as the forward
-        uT = self.buf(f"lg_uT_{Mp}", (64, Mp), bf16)
-        gT = self.buf(f"lg_gT_{Mp}", (64, Mp), bf16)
-        self.transpose2d(u, 64, uT)
-        self.transpose2d(gbuf, 64, gT)
-        for j, a in enumerate(g.adapters):
-            ops.gemm(uT[8 * j: 8 * j + 8], dyT[a.row0: a.row0 + a.out], a.dBt, residual=a.dBt, tile_cfg=3, K=Mp)   # dB^T += u^T dy
-            ops.gemm(gT[8 * j: 8 * j + 8], xdT, a.dA, residual=a.dA, tile_cfg=3, K=Mp)                              # dA  += g^T drop(x)
+        ads = g.adapters
+        ops.lora_tn(dy, u, [a.dBt for a in ads], [a.row0 for a in ads], [a.out for a in ads], [a.out for a in ads])       # dB^T += u^T dy
+        ops.lora_tn(x[:, : g.K], gbuf, [a.dA for a in ads], [0] * len(ads), [g.K] * len(ads), [g.K] * len(ads), drop=drop)  # dA += g^T drop(x)
         if dx is not None:
             ops.gemm(dy, g.Wt, dx, residual=residual, K=pad64(g.N))
             ops.lora_dx_add(dx[:, : g.K], gbuf, g.acat, drop=drop)

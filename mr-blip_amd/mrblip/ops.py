@@ -52,6 +52,7 @@ _attn_bwd = _sig("mrblip_attention_bwd", vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
                  i32, i32, i32, i32, i32, f32, vp, vp, i32, vp, u32, f32, vp)
 _head_t = _sig("mrblip_head_transpose", vp, vp, vp, i32, i32, i32, i32, i32, vp, u32, f32, vp)
 _colsum = _sig("mrblip_colsum", vp, ll, i32, i32, vp, vp)
+_lora_tn = _sig("mrblip_lora_tn", vp, ll, vp, ll, i32, i32, i32, vp, vp, vp, vp, vp, u32, f32, vp)
 _lora_pack = _sig("mrblip_lora_pack", vp, vp, vp, vp, vp, i32, f32, vp)
 _drop_b16 = _sig("mrblip_dropout_bf16", vp, ll, vp, ll, i32, i32, vp, u32, f32, vp)
 _patchify = _sig("mrblip_patchify", vp, vp, i32, i32, i32, i32, vp)
@@ -72,7 +73,7 @@ EXPORTS = [
     "mrblip_layernorm_bwd", "mrblip_rmsnorm_bwd", "mrblip_attention_fwd", "mrblip_attention_bwd", "mrblip_head_transpose",
     "mrblip_patchify", "mrblip_vit_assemble", "mrblip_row_copy", "mrblip_mean_pool", "mrblip_mean_pool_bwd",
     "mrblip_cast_dropout", "mrblip_gelu_bwd", "mrblip_gated_gelu_bwd", "mrblip_cross_entropy", "mrblip_adamw",
-    "mrblip_seed_bump", "mrblip_lora_dx_add", "mrblip_dropout_bf16", "mrblip_colsum", "mrblip_lora_pack",
+    "mrblip_seed_bump", "mrblip_lora_dx_add", "mrblip_dropout_bf16", "mrblip_colsum", "mrblip_lora_pack", "mrblip_lora_tn",
 ]
 
 
@@ -176,6 +177,15 @@ def head_transpose(x: torch.Tensor, out: Optional[torch.Tensor] = None, spad: in
 def colsum(x, out):
     M, N = x.shape
     _chk(_colsum(_p(x), _ld(x), M, N, _p(out), _stream()))
+
+
+def lora_tn(Y, U, outs, col0, ncols, lds, drop: Optional[Dropout] = None):
+    """outs[j][r, c - col0[j]] += sum_m U[m, 8j + r] * drop(Y)[m, c] for col0[j] <= c < col0[j] + ncols[j]; outs: fp32 [8, *] views."""
+    M, Cc = Y.shape
+    n = len(outs)
+    sp, site, p = _d(drop)
+    _chk(_lora_tn(_p(Y), _ld(Y), _p(U), _ld(U), M, Cc, 8 * n, (vp * n)(*[o.data_ptr() for o in outs]), (i32 * n)(*col0), (i32 * n)(*ncols),
+                  (ll * n)(*lds), sp, site, p, _stream()))
 
 
 def lora_pack(flat, acat, wext, bblk, desc, n_adapters, scale=1.0):

@@ -352,3 +352,26 @@ def test_lora_pieces(ops):
     dW = torch.ones(8, K, device=dev())
     ops.gemm(uT[8:16], xt, dW, residual=dW, tile_cfg=3, K=Mp)
     assert rel(dW, 1 + u[:, 8:16].float().t() @ ref.float()) < 1e-5
+
+
+def test_lora_tn_weight_gradients(ops):
+    """dB^T = u^T dy (block-diagonal over the adapters of a fused group) and dA = g^T dropout(x), contraction over rows, no transposes."""
+    torch.manual_seed(10)
+    M, K, outs_ = 333, 192, [64, 64, 72]
+    Ntot = sum(outs_)
+    dy = bf(torch.randn(M, Ntot, device=dev()))
+    u = torch.zeros(M, 64, dtype=torch.bfloat16, device=dev())
+    u[:, :24] = bf(torch.randn(M, 24, device=dev()))
+    dB = [torch.ones(8, o, device=dev()) for o in outs_]
+    col0 = [0, 64, 128]
+    ops.lora_tn(dy, u, dB, col0, outs_, outs_)
+    for j, o in enumerate(outs_):
+        ref = 1 + u[:, 8 * j: 8 * j + 8].float().t() @ dy[:, col0[j]: col0[j] + o].float()
+        assert rel(dB[j], ref) < 1e-5, j
+    x = bf(torch.randn(M, K, device=dev()))
+    seed = torch.tensor([31], dtype=torch.int32, device=dev())
+    dA = [torch.zeros(8, K, device=dev()) for _ in range(3)]
+    ops.lora_tn(x, u, dA, [0] * 3, [K] * 3, [K] * 3, drop=ops.Dropout(seed, 5, 0.05))
+    xd = (x.float() * keep_mask((M, K), 31, 5, 0.05) / 0.95).bfloat16().float()
+    for j in range(3):
+        assert rel(dA[j], u[:, 8 * j: 8 * j + 8].float().t() @ xd) < 1e-5, j
