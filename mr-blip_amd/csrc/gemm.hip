@@ -455,10 +455,15 @@ struct TnArgs {
 };
 
 __global__ __launch_bounds__(512) void lora_tn_kernel(const TnArgs p) {
+  // Each wave stages its own 16-row slices of Y (16 x 32 columns) and U (16 x 32) with ONE 16-B global load per lane each,
+  // parks them in a wave-private LDS slot and gathers the k-major MFMA fragments from there with 2-byte LDS reads.
+  constexpr int UNROLL = 2;
   __shared__ float red[7][16][64];
+  __shared__ __attribute__((aligned(16))) bf16_t slot[8][UNROLL][2][16 * 32];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, hi = lane >> 5, l31 = lane & 31;
-  const int c = blockIdx.x * 32 + l31;
-  const bool c_ok = c < p.C, r_ok = l31 < p.R;
+  const int c0 = blockIdx.x * 32;
+  const int c = c0 + l31;
+  const bool c_ok = c < p.C;
   const uint32_t seed = p.drop.seed_ptr ? *p.drop.seed_ptr : 0u;
   f32x16 acc;
 #pragma unroll
@@ -466,31 +471,41 @@ __global__ __launch_bounds__(512) void lora_tn_kernel(const TnArgs p) {
   const int steps = (p.M + 15) / 16;                 // 16 rows of M per MFMA
   const int per = (steps + 7) / 8;
   const int s_beg = w * per, s_end = min(steps, s_beg + per);
-  const bf16_t* yp = p.Y + (c_ok ? c : 0);
-  const bf16_t* up = p.U + (r_ok ? l31 : 0);
+  const int srow = lane >> 2, schunk = lane & 3;     // staging role: row of the 16-row slice, 8-column chunk
+  const bool ychunk_ok = c0 + 8 * schunk < p.C, uchunk_ok = 8 * schunk < p.R;
+  const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll 1
-  for (int s0 = s_beg; s0 < s_end; s0 += 4) {
-    bf16x8 uf[4], yf[4];
+  for (int s0 = s_beg; s0 < s_end; s0 += UNROLL) {
+    bf16x8 gy[UNROLL], gu[UNROLL];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int m0 = (s0 + u) * 16 + 8 * hi;
-      const bool live = s0 + u < s_end;
+    for (int u = 0; u < UNROLL; ++u) {
+      const int m = (s0 + u) * 16 + srow;
+      const bool ok = (s0 + u < s_end) && m < p.M;
+      const long long mm = ok ? m : 0;
+      gy[u] = (ok && ychunk_ok) ? *reinterpret_cast<const bf16x8*>(p.Y + mm * p.ldy + c0 + 8 * schunk) : zero;
+      gu[u] = (ok && uchunk_ok) ? *reinterpret_cast<const bf16x8*>(p.U + mm * p.ldu + 8 * schunk) : zero;
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      *reinterpret_cast<bf16x8*>(&slot[w][u][0][srow * 32 + schunk * 8]) = gy[u];
+      *reinterpret_cast<bf16x8*>(&slot[w][u][1][srow * 32 + schunk * 8]) = gu[u];
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      bf16x8 yf, uf;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const int m = m0 + j;
-        const bool ok = live && m < p.M;
-        const long long mm = ok ? m : 0;
-        bf16_t yv = yp[mm * p.ldy], uv = up[mm * p.ldu];
+        bf16_t yv = slot[w][u][0][(8 * hi + j) * 32 + l31];
         if (p.drop.seed_ptr) {
+          const int m = (s0 + u) * 16 + 8 * hi + j;
           const bool keep = mrb_keep((uint32_t)m * (uint32_t)p.C + (uint32_t)c, seed, p.drop.site, p.drop.thresh24);
           yv = keep ? f2bf(bf2f(yv) * p.drop.inv_keep) : (bf16_t)0;
         }
-        yf[u][j] = (ok && c_ok) ? (short)yv : (short)0;
-        uf[u][j] = (ok && r_ok) ? (short)uv : (short)0;
+        yf[j] = (short)yv;
+        uf[j] = (short)slot[w][u][1][(8 * hi + j) * 32 + l31];
       }
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uf, yf, acc, 0, 0, 0);
     }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uf[u], yf[u], acc, 0, 0, 0);
   }
   if (w > 0) {
 #pragma unroll
@@ -516,6 +531,7 @@ extern "C" int mrblip_lora_tn(const void* Y, long long ldy, const void* U, long 
                               const int* col0, const int* ncols, const long long* lds, const uint32_t* seed_ptr, uint32_t site, float p_drop,
                               hipStream_t stream) {
   MRB_REQUIRE(M > 0 && C > 0 && R > 0 && R <= 32 && (R % 8) == 0, "lora_tn: bad shape (M=%d C=%d R=%d)", M, C, R);
+  MRB_REQUIRE((C % 8) == 0 && (ldy % 8) == 0 && (ldu % 8) == 0 && ((uintptr_t)Y % 16) == 0 && ((uintptr_t)U % 16) == 0, "lora_tn: 16-B alignment");
   TnArgs a;
   a.Y = (const bf16_t*)Y; a.U = (const bf16_t*)U; a.ldy = ldy; a.ldu = ldu; a.M = M; a.C = C; a.R = R;
   for (int j = 0; j < 4; ++j) {
