@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--workload", default="qvh", choices=list(WORKLOADS))
     ap.add_argument("--batch-per-gpu", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--vit-chunk", type=int, default=0, help="frames per ViT pass (0 = engine default)")
     ap.add_argument("--no-dropout", action="store_true", help="debug only: the headline number keeps the reference's dropouts on")
     args = ap.parse_args()
 
@@ -115,6 +116,8 @@ def main():
     cfg = EngineConfig.flan_t5_xl_qvh(mean_pool=wl["mean_pool"])
     eng = MrBlipEngine(cfg, RandomSource(dev, seed=1234), dev, lora_init=lora_init_nonzero, seed=42 + rank)
     eng.training = not args.no_dropout
+    if args.vit_chunk > 0:
+        eng.vit_chunk = args.vit_chunk
     tok = FixtureTokenizer()
     repl = P.annoying_replacement_dict(P.find_annoying_numbers(tok, 200)[0])
     B = args.batch_per_gpu
@@ -158,7 +161,7 @@ def main():
         global_batch = B * world
         clips_s = global_batch * args.steps / elapsed
         durs = [s.elapsed_time(e) * 1e-3 for s, e in probe_events]
-        F_ = B * wl["T"]
+        F_ = min(B * wl["T"], eng.vit_chunk)
         m, n, k = F_ * 257, cfg.vit_mlp, cfg.vit_dim
         if durs:
             avg = sum(durs) / len(durs)

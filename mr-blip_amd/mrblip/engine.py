@@ -157,6 +157,7 @@ class MrBlipEngine:
         self.hyper = torch.tensor([0.0, 1.0, 1.0, 1.0], dtype=f32, device=device)
         self.opt_step = 0
         self.probe = None
+        self.vit_chunk = 1 << 20  # frames per ViT pass (chunking measured slower on MI355X: fewer tiles per launch; kept as a knob)
         self._site = 100
         inner = cfg.t5_heads * cfg.d_kv
         for nm, v in (("d_model", cfg.d_model), ("t5 inner", inner), ("d_ff", cfg.d_ff), ("qf_dim", cfg.qf_dim), ("qf_inter", cfg.qf_inter)):
@@ -230,8 +231,20 @@ class MrBlipEngine:
 
     @torch.no_grad()
     def vit_forward(self, video: torch.Tensor, n_blocks: Optional[int] = None) -> torch.Tensor:
-        """video fp32 [F,3,IMG,IMG] -> fp32 [F*(NP+1), D] (no final norm, eva_vit.py:324-340).  No activations are kept:
-        the ViT is frozen and its output needs no gradient."""
+        """video fp32 [F,3,IMG,IMG] -> fp32 [F*(NP+1), D] (no final norm, eva_vit.py:324-340).  No activations are kept (the ViT is
+        frozen and its output needs no gradient).  Frames are independent through the ViT; ``vit_chunk`` optionally processes them in
+        groups (measured on MI355X: one pass over all frames is fastest — larger GEMMs beat Infinity-Cache residency)."""
+        c = self.cfg
+        F_ = video.shape[0]
+        T = (c.img // c.patch) ** 2 + 1
+        x_all = self.buf("vit_x", (F_ * T, c.vit_dim), f32, zero=False)
+        chunk = max(1, min(F_, self.vit_chunk))
+        for f0 in range(0, F_, chunk):
+            f1 = min(F_, f0 + chunk)
+            self._vit_chunk(video[f0:f1], x_all[f0 * T: f1 * T], n_blocks)
+        return x_all
+
+    def _vit_chunk(self, video: torch.Tensor, x: torch.Tensor, n_blocks: Optional[int]):
         c, v = self.cfg, self.vit
         F_ = video.shape[0]
         G = c.img // c.patch
@@ -239,17 +252,17 @@ class MrBlipEngine:
         hd = D // H
         T = NP + 1
         M = F_ * T
-        patches = self.buf("vit_patches", (F_ * NP, self.vit_kpad), bf16, zero=False)
+        tag = f"_{F_}"
+        patches = self.buf("vit_patches" + tag, (F_ * NP, self.vit_kpad), bf16, zero=False)
         ops.patchify(video, patches, c.patch)
-        pe = self.buf("vit_pe", (F_ * NP, D), f32, zero=False)
+        pe = self.buf("vit_pe" + tag, (F_ * NP, D), f32, zero=False)
         ops.gemm(patches, v["pe_w"], pe, bias=v["pe_b"])
-        x = self.buf("vit_x", (M, D), f32, zero=False)
         ops.vit_assemble(pe, v["cls"], v["pos"], x.view(F_, T, D))
-        h = self.buf("vit_h", (M, pad64(D)), bf16)
-        qkv = self.buf("vit_qkv", (M, 3 * D), bf16, zero=False)
-        o = self.buf("vit_o", (M, pad64(D)), bf16)
-        f = self.buf("vit_f", (M, self.vit_fp), bf16, zero=False)
-        vt = self.buf("vit_vt", (F_, H, ops.rup32(hd), ops.rup32(T)), bf16)
+        h = self.buf("vit_h" + tag, (M, pad64(D)), bf16)
+        qkv = self.buf("vit_qkv" + tag, (M, 3 * D), bf16, zero=False)
+        o = self.buf("vit_o" + tag, (M, pad64(D)), bf16)
+        f = self.buf("vit_f" + tag, (M, self.vit_fp), bf16, zero=False)
+        vt = self.buf("vit_vt" + tag, (F_, H, ops.rup32(hd), ops.rup32(T)), bf16)
         q4, k4, v4 = self.v4(qkv, F_, T, H, hd, 0), self.v4(qkv, F_, T, H, hd, D), self.v4(qkv, F_, T, H, hd, 2 * D)
         o4 = self.v4(o, F_, T, H, hd)
         scale = hd ** -0.5
@@ -269,7 +282,6 @@ class MrBlipEngine:
                 ev[1].record()
                 probe.append(ev)
             ops.gemm(f, blk["fc2_w"], x, bias=blk["fc2_b"], residual=x)
-        return x
 
     # ------------------------------------------------------------------------------------------ Q-Former (frozen weights, dX needed)
     def _build_qformer(self, src):
