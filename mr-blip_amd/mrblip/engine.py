@@ -955,6 +955,33 @@ class MrBlipEngine:
         out[:, :S] = m.to(self.dev, torch.int32)
         return out
 
+    def dropout_site_map(self) -> Dict[str, tuple]:
+        """logical dropout site (named after the reference's nn.Dropout modules) -> (call-site id, p, kind); used by the parity
+        tests to rebuild the exact masks of a training step on the CPU oracle."""
+        c = self.cfg
+        m = {"qf.emb": (self.qf_emb_site, c.qf_dropout, "2d")}
+        for i, L in enumerate(self.qf["layers"]):
+            m[f"qf.{i}.self.attn"] = (L["self"]["sites"][0], c.qf_dropout, "attn")
+            m[f"qf.{i}.self.out"] = (L["self"]["sites"][1], c.qf_dropout, "2d")
+            if L["cross"] is not None:
+                m[f"qf.{i}.cross.attn"] = (L["cross"]["sites"][0], c.qf_dropout, "attn")
+                m[f"qf.{i}.cross.out"] = (L["cross"]["sites"][1], c.qf_dropout, "2d")
+            m[f"qf.{i}.ffn.out"] = (L["site"], c.qf_dropout, "2d")
+        p = c.t5_dropout
+        for k, j in (("t5.enc.emb", 0), ("t5.enc.final", 1), ("t5.dec.emb", 2), ("t5.dec.final", 3)):
+            m[k] = (self.t5["sites"][j], p, "2d")
+        for i, L in enumerate(self.t5["enc"]):
+            for j, (k, kind) in enumerate(((".attn", "attn"), (".attn_out", "2d"), (".ffn_inner", "2d"), (".ffn_out", "2d"))):
+                m[f"t5.enc.{i}{k}"] = (L["sites"][j], p, kind)
+        for i, L in enumerate(self.t5["dec"]):
+            for j, (k, kind) in enumerate(((".self.attn", "attn"), (".self_out", "2d"), (".cross.attn", "attn"), (".cross_out", "2d"),
+                                           (".ffn_inner", "2d"), (".ffn_out", "2d"))):
+                m[f"t5.dec.{i}{k}"] = (L["sites"][j], p, kind)
+        for g in self.groups:
+            for a in g.adapters:
+                m["lora:" + a.name] = (g.site, c.lora_dropout, "2d")
+        return m
+
     # ------------------------------------------------------------------------------------------ optimizer
     @torch.no_grad()
     def zero_grad(self):

@@ -161,11 +161,24 @@ def lr_at(cur_epoch: int, cur_step: int, state: dict, *, max_epoch, min_lr, init
 class Oracle:
     """Functional forward over a flat state dict with the reference's parameter names."""
 
-    def __init__(self, sd: Dict[str, Tensor], cfg: dict, emu_bf16: bool = False, lora: Optional[dict] = None):
+    def __init__(self, sd: Dict[str, Tensor], cfg: dict, emu_bf16: bool = False, lora: Optional[dict] = None, dropout=None):
         self.sd = sd
         self.cfg = cfg
         self.emu = emu_bf16
         self.lora = lora  # dict(r=8, alpha=8) or None
+        # training-mode parity: dropout(name, shape) -> multiplicative mask (keep / (1-p)) or None.  Site names follow the
+        # reference's nn.Dropout modules (T5: modeling_t5.py:329,599,694,824,1151,1279; Q-Former: Qformer.py:107,262,288,374;
+        # peft lora_dropout); the test maps them to the HIP engine's call-site ids and restates its counter hash.
+        self.dropout = dropout
+
+    def dm(self, x: Tensor, name: str) -> Tensor:
+        if self.dropout is None:
+            return x
+        m = self.dropout(name, tuple(x.shape))
+        return x if m is None else x * m
+
+    def am(self, name: str, shape):
+        return None if self.dropout is None else self.dropout(name, tuple(shape))
 
     # ---- helpers
     def rb(self, x: Tensor) -> Tensor:
@@ -217,7 +230,7 @@ class Oracle:
             s = s + bias
         pr = torch.softmax(s.float(), -1)
         if p_drop_mask is not None:
-            pr = pr * p_drop_mask
+            pr = pr * p_drop_mask  # keep / (1 - p)
         return self.rb(pr) @ self.rb(v)
 
     def ln_vision(self, x: Tensor) -> Tensor:
@@ -234,26 +247,29 @@ class Oracle:
         Bq = image_embeds.shape[0]
         x = self.P("query_tokens").expand(Bq, -1, -1)
         x = F.layer_norm(x, (D,), self.P(p + "embeddings.LayerNorm.weight"), self.P(p + "embeddings.LayerNorm.bias"), eps)
+        x = self.dm(x.reshape(-1, D), "qf.emb").reshape(x.shape)
 
         def heads(t):
             return t.reshape(t.shape[0], t.shape[1], H, hd).transpose(1, 2)
 
-        def attn_block(pref, x, kv_src):
+        def attn_block(pref, x, kv_src, tag):
             q = heads(self.lin(x, self.P(pref + "self.query.weight"), self.P(pref + "self.query.bias")))
             k = heads(self.lin(kv_src, self.P(pref + "self.key.weight"), self.P(pref + "self.key.bias")))
             v = heads(self.lin(kv_src, self.P(pref + "self.value.weight"), self.P(pref + "self.value.bias")))
-            o = self.attention(q, k, v, scale=1.0 / math.sqrt(hd))
+            o = self.attention(q, k, v, scale=1.0 / math.sqrt(hd), p_drop_mask=self.am(tag + ".attn", (q.shape[0], H, q.shape[2], k.shape[2])))
             o = o.transpose(1, 2).reshape(x.shape[0], x.shape[1], D)
             o = self.lin(o, self.P(pref + "output.dense.weight"), self.P(pref + "output.dense.bias"))
+            o = self.dm(o.reshape(-1, D), tag + ".out").reshape(o.shape)
             return F.layer_norm(o + x, (D,), self.P(pref + "output.LayerNorm.weight"), self.P(pref + "output.LayerNorm.bias"), eps)
 
         for i in range(c["num_hidden_layers"]):
             l = p + f"encoder.layer.{i}."
-            x = attn_block(l + "attention.", x, x)
+            x = attn_block(l + "attention.", x, x, f"qf.{i}.self")
             if i % c.get("cross_attention_freq", 2) == 0:
-                x = attn_block(l + "crossattention.", x, image_embeds)
+                x = attn_block(l + "crossattention.", x, image_embeds, f"qf.{i}.cross")
             h = F.gelu(self.lin(x, self.P(l + "intermediate_query.dense.weight"), self.P(l + "intermediate_query.dense.bias")))
             h = self.lin(h, self.P(l + "output_query.dense.weight"), self.P(l + "output_query.dense.bias"))
+            h = self.dm(h.reshape(-1, D), f"qf.{i}.ffn.out").reshape(h.shape)
             x = F.layer_norm(h + x, (D,), self.P(l + "output_query.LayerNorm.weight"), self.P(l + "output_query.LayerNorm.bias"), eps)
         return x
 
@@ -275,7 +291,8 @@ class Oracle:
         y = self.lin(x, w)
         if a is not None:
             scale = self.lora["alpha"] / self.lora["r"] if self.lora else 1.0
-            y = y + self.lin(self.lin(x, a), b) * scale  # peft 0.13.0 Linear.forward (eval: dropout = identity)
+            xd = self.dm(self.rb(x).reshape(-1, x.shape[-1]), "lora:" + name).reshape(x.shape)  # lora_dropout on the (bf16) input
+            y = y + self.lin(self.lin(xd, a), b) * scale  # peft 0.13.0 Linear.forward
         return y
 
     def rmsnorm(self, x: Tensor, w: Tensor, eps: float) -> Tensor:
@@ -288,7 +305,7 @@ class Oracle:
         b = relative_position_bucket(rel, bidirectional, c.get("num_buckets", 32), c.get("max_distance", 128))
         return table[torch.from_numpy(b)].permute(2, 0, 1).unsqueeze(0)  # [1,H,q,k]
 
-    def _t5_attn(self, pref: str, xq: Tensor, xkv: Tensor, bias: Tensor) -> Tensor:
+    def _t5_attn(self, pref: str, xq: Tensor, xkv: Tensor, bias: Tensor, tag: str = "") -> Tensor:
         c = self.cfg["t5"]
         H, dk = c["num_heads"], c["d_kv"]
 
@@ -296,32 +313,37 @@ class Oracle:
             return t.reshape(t.shape[0], t.shape[1], H, dk).transpose(1, 2)
 
         q, k, v = heads(self.t5lin(xq, pref + ".q")), heads(self.t5lin(xkv, pref + ".k")), heads(self.t5lin(xkv, pref + ".v"))
-        o = self.attention(q, k, v, scale=1.0, bias=bias)  # no 1/sqrt(d) (modeling_t5.py:561-563)
+        o = self.attention(q, k, v, scale=1.0, bias=bias, p_drop_mask=self.am(tag + ".attn", (q.shape[0], H, q.shape[2], k.shape[2])))  # no 1/sqrt(d)
         o = o.transpose(1, 2).reshape(xq.shape[0], xq.shape[1], H * dk)
         return self.t5lin(o, pref + ".o")
 
-    def _t5_ff(self, pref: str, x: Tensor) -> Tensor:
+    def _t5_ff(self, pref: str, x: Tensor, tag: str = "") -> Tensor:
         h = F.gelu(self.t5lin(x, pref + ".wi_0")) * self.t5lin(x, pref + ".wi_1")
+        h = self.dm(h.reshape(-1, h.shape[-1]), tag + ".ffn_inner").reshape(h.shape)
         return self.t5lin(h, pref + ".wo")
+
+    def _d2(self, x: Tensor, name: str) -> Tensor:
+        return self.dm(x.reshape(-1, x.shape[-1]), name).reshape(x.shape)
 
     def t5_encoder(self, inputs_embeds: Tensor, attention_mask: Tensor) -> Tensor:
         c = self.cfg["t5"]
         eps = c.get("eps", 1e-6)
-        x = inputs_embeds
+        x = self._d2(inputs_embeds, "t5.enc.emb")
         S = x.shape[1]
         neg = torch.finfo(torch.float32).min
         mask = (1.0 - attention_mask[:, None, None, :].float()) * neg
         bias = self.t5_bias(self._t5p("encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight"), S, S, True) + mask
         for i in range(c["num_layers"]):
             b = f"encoder.block.{i}."
-            x = x + self._t5_attn(b + "layer.0.SelfAttention", *(2 * [self.rmsnorm(x, self._t5p(b + "layer.0.layer_norm.weight"), eps)]), bias)
-            x = x + self._t5_ff(b + "layer.1.DenseReluDense", self.rmsnorm(x, self._t5p(b + "layer.1.layer_norm.weight"), eps))
-        return self.rmsnorm(x, self._t5p("encoder.final_layer_norm.weight"), eps)
+            t = f"t5.enc.{i}"
+            x = x + self._d2(self._t5_attn(b + "layer.0.SelfAttention", *(2 * [self.rmsnorm(x, self._t5p(b + "layer.0.layer_norm.weight"), eps)]), bias, t), t + ".attn_out")
+            x = x + self._d2(self._t5_ff(b + "layer.1.DenseReluDense", self.rmsnorm(x, self._t5p(b + "layer.1.layer_norm.weight"), eps), t), t + ".ffn_out")
+        return self._d2(self.rmsnorm(x, self._t5p("encoder.final_layer_norm.weight"), eps), "t5.enc.final")
 
     def t5_decoder(self, dec_ids: Tensor, dec_mask: Tensor, enc: Tensor, enc_mask: Tensor) -> Tensor:
         c = self.cfg["t5"]
         eps = c.get("eps", 1e-6)
-        x = self._t5p("shared.weight")[dec_ids]
+        x = self._d2(self._t5p("shared.weight")[dec_ids], "t5.dec.emb")
         L = x.shape[1]
         neg = torch.finfo(torch.float32).min
         causal = torch.tril(torch.ones(L, L))[None, None]
@@ -330,12 +352,13 @@ class Oracle:
         cross_bias = (1.0 - enc_mask[:, None, None, :].float()) * neg
         for i in range(c["num_decoder_layers"]):
             b = f"decoder.block.{i}."
+            t = f"t5.dec.{i}"
             h = self.rmsnorm(x, self._t5p(b + "layer.0.layer_norm.weight"), eps)
-            x = x + self._t5_attn(b + "layer.0.SelfAttention", h, h, self_bias)
+            x = x + self._d2(self._t5_attn(b + "layer.0.SelfAttention", h, h, self_bias, t + ".self"), t + ".self_out")
             h = self.rmsnorm(x, self._t5p(b + "layer.1.layer_norm.weight"), eps)
-            x = x + self._t5_attn(b + "layer.1.EncDecAttention", h, enc, cross_bias)
-            x = x + self._t5_ff(b + "layer.2.DenseReluDense", self.rmsnorm(x, self._t5p(b + "layer.2.layer_norm.weight"), eps))
-        return self.rmsnorm(x, self._t5p("decoder.final_layer_norm.weight"), eps)
+            x = x + self._d2(self._t5_attn(b + "layer.1.EncDecAttention", h, enc, cross_bias, t + ".cross"), t + ".cross_out")
+            x = x + self._d2(self._t5_ff(b + "layer.2.DenseReluDense", self.rmsnorm(x, self._t5p(b + "layer.2.layer_norm.weight"), eps), t), t + ".ffn_out")
+        return self._d2(self.rmsnorm(x, self._t5p("decoder.final_layer_norm.weight"), eps), "t5.dec.final")
 
     def t5_loss(self, inputs_embeds: Tensor, attention_mask: Tensor, labels: Tensor, dec_mask: Tensor):
         """T5ForConditionalGeneration.forward (modeling_t5.py:1796-1877): untied lm_head, CE ignore_index=-100 mean."""

@@ -128,3 +128,57 @@ def test_train_step_forward_backward(tag, mean):
     eng.optimizer_step(lr=1e-2, weight_decay=0.0)
     l2 = eng.forward_backward(samples["video"].cuda(), lay, backward=False).item()
     assert l2 < l1, (l1, l2)
+
+
+def test_training_mode_dropout_parity():
+    """Training mode (every dropout of the reference ON): the HIP step against the oracle fed with the SAME masks, rebuilt on the CPU
+    from the engine's call-site ids and the oracle's restatement of the counter hash.  Checks that every backward kernel regenerates
+    exactly the mask its forward used (a wrong site id would leave the loss right and the gradients wrong)."""
+    from oracle import mrblip_oracle as O
+    from mrblip import prompt as P
+    from mrblip.tokenizer import FixtureTokenizer
+
+    g = load_golden("mr_tiny")
+    tok = FixtureTokenizer()
+    repl = P.annoying_replacement_dict(P.find_annoying_numbers(tok, 200)[0])
+    samples = _samples(g)
+    sdl = _peft_sd(golden_state_dict(g))
+    for k, v in sdl.items():
+        v.requires_grad_(("lora_" in k) or k.startswith("t5_proj") or k.startswith("ln_vision"))
+    eng = _engine(sdl)
+    eng.training = True
+    lay = P.build_layout(tok, samples, repl, 8, T=3)
+    eng.zero_grad()
+    loss = eng.forward_backward(samples["video"].cuda(), lay, backward=True)
+    seed = int(eng.seed.item()) & 0xFFFFFFFF
+    sites = eng.dropout_site_map()
+    used = set()
+
+    def provider(name, shape):
+        site, p, kind = sites[name]
+        used.add(name)
+        if p <= 0:
+            return None
+        if kind == "attn":
+            return O.dropout_keep_attn(*shape, seed, site, p) / (1.0 - p)
+        return O.dropout_keep(shape, seed, site, p) / (1.0 - p)
+
+    orc = O.Oracle(sdl, TINY_CFG, emu_bf16=True, lora=dict(r=8, alpha=8), dropout=provider)
+    ref = orc.forward_mr(tok, samples, repl)
+    assert len(used) > 60 and any(k.startswith("lora:") for k in used) and "t5.dec.1.cross.attn" in used
+    assert abs(loss.item() - ref["loss"].item()) < 3e-3 * abs(ref["loss"].item()), (loss.item(), ref["loss"].item())
+    # dropout really happened (the eval-mode loss differs)
+    eng.training = False
+    l_eval = eng.forward_backward(samples["video"].cuda(), lay, backward=False).item()
+    assert abs(l_eval - ref["loss"].item()) > 1e-3
+    ref["loss"].backward()
+    assert relerr(eng.dproj_w.cpu(), sdl["t5_proj.weight"].grad) < 4e-2
+    assert relerr(eng.dlnv_w.cpu(), sdl["ln_vision.weight"].grad) < 4e-2
+    worst = 0.0
+    for a in eng.adapters:
+        base = "t5_model.base_model.model." + a.name
+        ea = relerr(a.dA.cpu(), sdl[base + ".lora_A.default.weight"].grad)
+        eb = relerr(a.dBt.cpu().t(), sdl[base + ".lora_B.default.weight"].grad)
+        worst = max(worst, ea, eb)
+        assert ea < 5e-2 and eb < 5e-2, (a.name, ea, eb)
+    print("training-mode worst LoRA grad rel err", worst)
