@@ -38,8 +38,8 @@ __device__ __forceinline__ void epilogue_apply4(const GemmArgs& p, int m, int n0
   }
   if (pre_out) *pre_out = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
   if (p.act == 1) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = gelu_erf(v[i]);
+    gelu_erf2(v[0], v[1]);
+    gelu_erf2(v[2], v[3]);
   }
   if (p.drop.seed_ptr) {
     const uint32_t seed = *p.drop.seed_ptr;
@@ -89,7 +89,12 @@ __device__ __forceinline__ void epilogue_gated8(const GemmArgs& p, int m, int n0
   }
   float v[8];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) v[i] = gelu_erf(h0[i]) * h1[i];
+  for (int i = 0; i < 8; i += 2) {
+    float g0 = h0[i], g1 = h0[i + 1];
+    gelu_erf2(g0, g1);
+    v[i] = g0 * h1[i];
+    v[i + 1] = g1 * h1[i + 1];
+  }
   if (p.drop.seed_ptr) {
     const uint32_t seed = *p.drop.seed_ptr;
 #pragma unroll
