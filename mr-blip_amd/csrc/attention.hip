@@ -48,6 +48,24 @@ __device__ __forceinline__ uint32_t attn_drop_hash(uint32_t row, int key, int sk
 }
 #define NEG_BIG (-1.0e30f)
 
+// dropout draws for the key-owner (dK/dV) kernels: lane owns one key, register j a query row.  The hash is shared by the key pair
+// (2i, 2i+1) = the lane pair (l, l^1), so each lane hashes 4 of the 8 rows and the pair swaps them through DPP (quad_perm 1,0,3,2).
+// draw[j] = 16-bit draw of (row rowbase + j, key), j < 8.
+__device__ __forceinline__ void drop_draws8_keyowner(uint32_t (&draw)[8], uint32_t rowbase, int key, int lane, int skh, uint32_t seed, uint32_t site) {
+  const bool odd = lane & 1;
+  const uint32_t sh = (key & 1) ? 16u : 0u;
+  uint32_t mine[4], other[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) mine[j] = attn_drop_hash(rowbase + (odd ? 4u : 0u) + (uint32_t)j, key, skh, seed, site);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) other[j] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine[j], 0xB1, 0xF, 0xF, true);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    draw[j] = ((odd ? other[j] : mine[j]) >> sh) & 0xffffu;
+    draw[4 + j] = ((odd ? mine[j] : other[j]) >> sh) & 0xffffu;
+  }
+}
+
 __device__ __forceinline__ int perm23(int i) { return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1); }
 __device__ __forceinline__ bf16x8 ld8(const bf16_t* p) { return *reinterpret_cast<const bf16x8*>(p); }
 __device__ __forceinline__ bf16x8 sel8(bool ok, bf16x8 v) {
@@ -59,6 +77,39 @@ __device__ __forceinline__ bf16x8 pack8(const float* v) {
   r.u[0] = pack2bf(v[0], v[1]); r.u[1] = pack2bf(v[2], v[3]); r.u[2] = pack2bf(v[4], v[5]); r.u[3] = pack2bf(v[6], v[7]);
   return r.v8;
 }
+// Scores live in the log2 domain: s2 = (q.k * scale + bias) * log2(e), so every softmax exponential is one v_exp_f32
+// (no multiply), and masked scores are -inf (exp2 -> exact 0 without a select; running maxima start at the finite NEG_BIG).
+#define MRB_LOG2E 1.4426950408889634f
+#define MRB_LN2 0.6931471805599453f
+#define NEG_INF (-__builtin_inff())
+__device__ __forceinline__ float ex2(float x) { return __builtin_amdgcn_exp2f(x); }
+template <bool V> struct BoolC { static constexpr bool value = V; };
+
+// sv[r] = sacc[r] * scale2 + lut[clamp(rel_r)] with rel_r = relbase + SGN * (16*(r>>3) + (r&7)); a tile whose every |rel| >= 128
+// shares one bucket (far_idx) -> one LUT read instead of sixteen.
+template <bool LUT, int SGN>
+__device__ __forceinline__ void tile_scores(float (&sv)[16], const f32x16& sacc, float scale2, const float* lut, bool far_tile, int far_idx, int relbase) {
+  if (LUT) {
+    if (far_tile) {
+      const float bconst = lut[far_idx];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sv[r] = sacc[r] * scale2 + bconst;
+    } else {
+      float bias[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rel = relbase + SGN * (16 * (r >> 3) + (r & 7));
+        bias[r] = lut[max(-128, min(128, rel)) + 128];
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sv[r] = sacc[r] * scale2 + bias[r];
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sv[r] = sacc[r] * scale2;
+  }
+}
+
 __device__ __forceinline__ void zero16(f32x16& a) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) a[r] = 0.f;
@@ -92,7 +143,7 @@ __device__ __forceinline__ uint32_t mask_bits(const int* km, int k0, int hi) {
 }
 
 template <int DP, int FLAGS>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs p) {
   constexpr int KS = DP / 16, MT = DP / 32;
   constexpr bool LUT = FLAGS & F_LUT, MASK = FLAGS & F_MASK, CAUSAL = FLAGS & F_CAUSAL, DROP = FLAGS & F_DROP, SPLIT = FLAGS & F_SPLIT;
   __shared__ float lut[LUT ? 257 : 1];
@@ -100,7 +151,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, hi = lane >> 5, l31 = lane & 31;
   const int b = blockIdx.z, h = blockIdx.y;
   if (LUT) {
-    for (int i = threadIdx.x; i < 257; i += 256) lut[i] = p.lut[h * 257 + i];
+    for (int i = threadIdx.x; i < 257; i += 256) lut[i] = p.lut[h * 257 + i] * MRB_LOG2E;
     __syncthreads();
   }
   const int q0 = SPLIT ? blockIdx.x * 32 : (blockIdx.x * 4 + w) * 32;
@@ -121,11 +172,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
   const uint32_t row_id = (uint32_t)(b * p.H + h) * (uint32_t)p.Sq + (uint32_t)q;
   const int skh = (p.Sk + 1) >> 1;
   const int kstart = SPLIT ? w * 32 : 0, kstep = SPLIT ? 128 : 32;
+  const float scale2 = p.scale * MRB_LOG2E;
 
   // software pipeline: K fragments of the next tile and V^T fragments of this tile are in flight during the score math
   bf16x8 kcur[KS];
   load_rows<KS>(kcur, kbase, p.K.rs, kstart + perm23(l31), p.Sk, p.D, hi);
-  for (int k0 = kstart; k0 < kend; k0 += kstep) {
+  // EDGE tiles (ragged key tail, causal diagonal, key mask) pay for per-element validity; interior tiles do not.
+  auto tile = [&](auto edge_c, int k0) {
+    constexpr bool EDGE = decltype(edge_c)::value;
     bf16x8 vf[MT][2];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -143,60 +197,46 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
     for (int s = 0; s < KS; ++s) sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kcur[s], qf[s], sacc, 0, 0, 0);
     // lane (q, hi), register r  <->  key k0 + 16*(r>>3) + 8*hi + (r&7)
     float sv[16];
-    if (LUT) {
-      // every |key - q| >= 128 shares one bucket: tiles entirely beyond that distance need one LUT value, not sixteen reads
-      if (k0 - (q0 + 31) >= 128 || (q0 - (k0 + 31)) >= 128) {
-        const float bconst = lut[k0 > q0 ? 256 : 0];
+    tile_scores<LUT, 1>(sv, sacc, scale2, lut, k0 - (q0 + 31) >= 128 || (q0 - (k0 + 31)) >= 128, k0 > q0 ? 256 : 0, k0 + 8 * hi - q);
+    if (EDGE) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sv[r] = sacc[r] * p.scale + bconst;
-      } else {
-        float bias[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int rel = (k0 + 16 * (r >> 3) + 8 * hi + (r & 7)) - q;
-          bias[r] = lut[max(-128, min(128, rel)) + 128];
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sv[r] = sacc[r] * p.scale + bias[r];
+      for (int r = 0; r < 16; ++r) {
+        const int key = k0 + 16 * (r >> 3) + 8 * hi + (r & 7);
+        bool ok = key < p.Sk && ((vmask >> r) & 1u);
+        if (CAUSAL) ok = ok && (key <= q);
+        sv[r] = ok ? sv[r] : NEG_INF;
       }
-    } else {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sv[r] = sacc[r] * p.scale;
     }
-    float mx = NEG_BIG;
+    float mx = fmaxf(sv[0], sv[1]);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int key = k0 + 16 * (r >> 3) + 8 * hi + (r & 7);
-      bool ok = key < p.Sk;
-      if (CAUSAL) ok = ok && (key <= q);
-      if (!ok) vmask &= ~(1u << r);
-      mx = fmaxf(mx, ((vmask >> r) & 1u) ? sv[r] : NEG_BIG);
-    }
+    for (int r = 2; r < 16; r += 2) mx = fmaxf(fmaxf(mx, sv[r]), sv[r + 1]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = __expf(m_run - m_new);
+    if (__builtin_amdgcn_ballot_w64(mx > m_run) != 0) {  // lazy rescale: once the running max has settled nothing is multiplied
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = ex2(m_run - m_new);
+      l_run *= alpha;
+      m_run = m_new;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[mt][r] *= alpha;
+    }
     float psum = 0.f;
     float pv[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float e = ((vmask >> r) & 1u) ? __expf(sv[r] - m_new) : 0.f;
-      psum += e;
-      pv[r] = e;
+      pv[r] = ex2(sv[r] - m_run);
+      psum += pv[r];
     }
-    if (DROP) {
+    if (DROP) {  // the 1/(1-p) factor is applied once to O at the end
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
         const uint32_t hsh = attn_drop_hash(row_id, k0 + 16 * (r >> 3) + 8 * hi + (r & 7), skh, drop_seed, p.drop.site);
-        pv[r] = (hsh & 0xffffu) >= p.drop.thresh24 ? pv[r] * p.drop.inv_keep : 0.f;
-        pv[r + 1] = (hsh >> 16) >= p.drop.thresh24 ? pv[r + 1] * p.drop.inv_keep : 0.f;
+        pv[r] = (hsh & 0xffffu) >= p.drop.thresh24 ? pv[r] : 0.f;
+        pv[r + 1] = (hsh >> 16) >= p.drop.thresh24 ? pv[r + 1] : 0.f;
       }
     }
-    l_run = l_run * alpha + psum;
-    m_run = m_new;
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[mt][r] *= alpha;
+    l_run += psum;
     const bf16x8 pf0 = pack8(pv), pf1 = pack8(pv + 8);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -205,6 +245,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
     }
 #pragma unroll
     for (int s = 0; s < KS; ++s) kcur[s] = knext[s];
+  };
+  for (int k0 = kstart; k0 < kend; k0 += kstep) {
+    const bool edge = MASK || k0 + 32 > p.Sk || (CAUSAL && k0 + 31 > q0);
+    if (edge) tile(BoolC<true>(), k0);
+    else tile(BoolC<false>(), k0);
   }
   float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   if (SPLIT) {  // merge the four key-range partials: wave 0 collects (m, l, O) of waves 1..3
@@ -223,7 +268,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
     float m_all = m_run;
 #pragma unroll
     for (int j = 0; j < 3; ++j) m_all = fmaxf(m_all, red[j * STR + lane]);
-    const float f0 = __expf(m_run - m_all);
+    const float f0 = ex2(m_run - m_all);
     l_tot *= f0;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -232,7 +277,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       const float* r = red + j * STR;
-      const float fj = __expf(r[lane] - m_all);
+      const float fj = ex2(r[lane] - m_all);
       l_tot += r[64 + lane] * fj;
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
@@ -241,7 +286,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
     }
     m_run = m_all;
   }
-  const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+  const float inv = l_tot > 0.f ? (DROP ? p.drop.inv_keep : 1.0f) / l_tot : 0.f;
   if (q_ok) {
     bf16_t* op = const_cast<bf16_t*>(p.O.ptr) + b * p.O.bs + h * p.O.hs + (long long)q * p.O.rs;
 #pragma unroll
@@ -253,13 +298,204 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
           *reinterpret_cast<uint2*>(op + d0) = make_uint2(pack2bf(o[mt][4 * g] * inv, o[mt][4 * g + 1] * inv),
                                                           pack2bf(o[mt][4 * g + 2] * inv, o[mt][4 * g + 3] * inv));
       }
-    if (p.LSE && hi == 0) p.LSE[((long long)(b * p.H + h)) * p.Sqpad + q] = m_run + __logf(fmaxf(l_tot, 1e-37f));
+    if (p.LSE && hi == 0) p.LSE[((long long)(b * p.H + h)) * p.Sqpad + q] = m_run * MRB_LN2 + __logf(fmaxf(l_tot, 1e-37f));
+  }
+}
+
+// ---- forward with the key-side tiles shared through LDS.  The four query-waves of a block consume the SAME K / V^T tiles, so the
+// block fetches each 64-key stage once with LDS-DMA (buffer_load ... lds, 16 B per lane, no VGPR round trip) instead of every wave
+// gathering 32-B row pieces from L1/L2 (the per-wave form is bound by the texture-address path, not by MFMA or VALU).  Two stages,
+// one barrier per stage: the DMA of stage t+1 flies while stage t is consumed.  LDS rows are XOR-swizzled at 16-B granularity through
+// the SOURCE address (the DMA destination is lane-linear), reads are conflict-free ds_read_b128.
+typedef __attribute__((address_space(3))) void* attn_lds_ptr_t;
+
+// one stage of LDS-DMA: CNT_A + CNT_B instructions per thread, destinations lane-linear (16 B per lane, 1 KB per wave and instruction)
+template <int CNT_A, int CNT_B>
+__device__ __forceinline__ void attn_stage_dma(char* dstA, char* dstB, const void* srcA, uint32_t bytesA, const void* srcB, uint32_t bytesB,
+                                               const uint32_t* vA, const uint32_t* vB, int w, uint32_t sA, uint32_t sB) {
+  // (the buffer resource type exists on the device side only: it cannot appear in a signature the host pass also parses)
+  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(srcA), 0, (int)bytesA, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(srcB), 0, (int)bytesB, 0x00020000);
+#pragma unroll
+  for (int j = 0; j < CNT_A; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (attn_lds_ptr_t)(dstA + (j * 256 + w * 64) * 16), 16, vA[j], sA, 0, 0);
+#pragma unroll
+  for (int j = 0; j < CNT_B; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (attn_lds_ptr_t)(dstB + (j * 256 + w * 64) * 16), 16, vB[j], sB, 0, 0);
+}
+
+template <int DP, int FLAGS>
+__global__ __launch_bounds__(256, 2) void attn_fwd_lds_kernel(const AttnArgs p) {
+  constexpr int KS = DP / 16, MT = DP / 32;
+  constexpr bool LUT = FLAGS & F_LUT, MASK = FLAGS & F_MASK, DROP = FLAGS & F_DROP;
+  constexpr int KROW = DP * 2, KCPR = DP / 8;                 // K row bytes, 16-B chunks per K row
+  constexpr int K_BYTES = 64 * KROW, V_BYTES = DP * 128, STAGE = K_BYTES + V_BYTES;
+  constexpr int NJK = 64 * KCPR / 256, NJV = DP * 8 / 256;    // DMA instructions per thread per stage
+  __shared__ float lut[LUT ? 257 : 1];
+  extern __shared__ __attribute__((aligned(16))) char sm[];  // 2 * STAGE bytes
+  const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.z, h = blockIdx.y;
+  if (LUT) {
+    for (int i = tid; i < 257; i += 256) lut[i] = p.lut[h * 257 + i] * MRB_LOG2E;
+  }
+  const int q0 = (blockIdx.x * 4 + w) * 32;
+  const bool active = q0 < p.Sq;  // wave-uniform; inactive waves still stage and hit the barriers
+  const int q = q0 + l31;
+  const bool q_ok = q < p.Sq;
+  bf16x8 qf[KS];
+  load_rows<KS>(qf, p.Q.ptr + b * p.Q.bs + h * p.Q.hs, p.Q.rs, q, p.Sq, p.D, hi);
+  float m_run = NEG_BIG, l_run = 0.f;
+  f32x16 o[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) zero16(o[mt]);
+  const int* km = MASK ? p.kmask + (long long)b * p.Skpad : nullptr;
+  const uint32_t drop_seed = DROP ? *p.drop.seed_ptr : 0u;
+  const uint32_t row_id = (uint32_t)(b * p.H + h) * (uint32_t)p.Sq + (uint32_t)q;
+  const int skh = (p.Sk + 1) >> 1;
+  const float scale2 = p.scale * MRB_LOG2E;
+
+  // ---- staging: buffer resources span from this head's first element to the end of the tensor (reads past the head's rows stay
+  // inside the tensor or return 0; whatever they return is finite and meets P == 0 / zero-padded Q)
+  const bf16_t* kbase = p.K.ptr + b * p.K.bs + h * p.K.hs;
+  const bf16_t* vtbase = p.Vt.ptr + b * p.Vt.bs + h * p.Vt.hs;
+  const long long k_rem = ((long long)(p.B - 1 - b) * p.K.bs + (long long)(p.H - 1 - h) * p.K.hs + (long long)(p.Sk - 1) * p.K.rs + p.D) * 2;
+  const long long v_rem = ((long long)(p.B - 1 - b) * p.Vt.bs + (long long)(p.H - h) * p.Vt.hs) * 2;
+  const uint32_t k_bytes = (uint32_t)(k_rem > 0xffffffffLL ? 0xffffffffLL : k_rem), v_bytes = (uint32_t)(v_rem > 0xffffffffLL ? 0xffffffffLL : v_rem);
+  auto ksw = [](int row) { return DP == 64 ? ((row >> 1) & 7) : ((row >> 2) & 3); };
+  uint32_t vK[NJK], vV[NJV];
+#pragma unroll
+  for (int j = 0; j < NJK; ++j) {
+    const int g = j * 256 + tid, row = g / KCPR, c = g % KCPR;
+    vK[j] = (uint32_t)((long long)row * p.K.rs * 2) + (uint32_t)((c ^ ksw(row)) * 16);
+  }
+#pragma unroll
+  for (int j = 0; j < NJV; ++j) {
+    const int g = j * 256 + tid, d = g >> 3, c = g & 7;
+    vV[j] = (uint32_t)((long long)d * p.Vt.ds * 2) + (uint32_t)((c ^ ((d >> 1) & 7)) * 16);
+  }
+  auto stage = [&](int st, int buf) {
+    attn_stage_dma<NJK, NJV>(sm + buf * STAGE, sm + buf * STAGE + K_BYTES, kbase, k_bytes, vtbase, v_bytes, vK, vV, w, (uint32_t)((long long)st * 64 * p.K.rs * 2),
+                             (uint32_t)(st * 128));
+  };
+
+  // fragment addresses inside a stage (bytes)
+  const int krow = perm23(l31);
+  int k_off[2][KS], v_off[MT][2][2];
+#pragma unroll
+  for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int row = 32 * sub + krow;
+      k_off[sub][s] = row * KROW + (((2 * s + hi) ^ ksw(row)) << 4);
+    }
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const int d = mt * 32 + l31;
+        v_off[mt][sub][hf] = K_BYTES + d * 128 + (((4 * sub + 2 * hf + hi) ^ ((d >> 1) & 7)) << 4);
+      }
+
+  auto tile = [&](auto edge_c, int k0, const char* base, int sub, uint32_t vmask) {
+    constexpr bool EDGE = decltype(edge_c)::value;
+    f32x16 sacc;
+    zero16(sacc);
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+      sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(base + k_off[sub][s]), qf[s], sacc, 0, 0, 0);
+    // lane (q, hi), register r  <->  key k0 + 16*(r>>3) + 8*hi + (r&7)
+    float sv[16];
+    tile_scores<LUT, 1>(sv, sacc, scale2, lut, k0 - (q0 + 31) >= 128 || (q0 - (k0 + 31)) >= 128, k0 > q0 ? 256 : 0, k0 + 8 * hi - q);
+    if (EDGE) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = k0 + 16 * (r >> 3) + 8 * hi + (r & 7);
+        const bool ok = key < p.Sk && ((vmask >> r) & 1u);
+        sv[r] = ok ? sv[r] : NEG_INF;
+      }
+    }
+    float mx = fmaxf(sv[0], sv[1]);
+#pragma unroll
+    for (int r = 2; r < 16; r += 2) mx = fmaxf(fmaxf(mx, sv[r]), sv[r + 1]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    if (__builtin_amdgcn_ballot_w64(mx > m_run) != 0) {  // lazy rescale
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = ex2(m_run - m_new);
+      l_run *= alpha;
+      m_run = m_new;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[mt][r] *= alpha;
+    }
+    float psum = 0.f;
+    float pv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      pv[r] = ex2(sv[r] - m_run);
+      psum += pv[r];
+    }
+    if (DROP) {
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const uint32_t hsh = attn_drop_hash(row_id, k0 + 16 * (r >> 3) + 8 * hi + (r & 7), skh, drop_seed, p.drop.site);
+        pv[r] = (hsh & 0xffffu) >= p.drop.thresh24 ? pv[r] : 0.f;
+        pv[r + 1] = (hsh >> 16) >= p.drop.thresh24 ? pv[r + 1] : 0.f;
+      }
+    }
+    l_run += psum;
+    const bf16x8 pf0 = pack8(pv), pf1 = pack8(pv + 8);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      o[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(base + v_off[mt][sub][0]), pf0, o[mt], 0, 0, 0);
+      o[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(base + v_off[mt][sub][1]), pf1, o[mt], 0, 0, 0);
+    }
+  };
+
+  const int nst = (p.Sk + 63) >> 6;
+  stage(0, 0);
+  for (int st = 0; st < nst; ++st) {
+    uint32_t vm0 = 0xffffu, vm1 = 0xffffu;
+    if (MASK) {  // Skpad is a multiple of 32: the second half of the last stage may lie past the row
+      vm0 = mask_bits(km, st * 64, hi);
+      vm1 = st * 64 + 32 < p.Skpad ? mask_bits(km, st * 64 + 32, hi) : 0u;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // stage st has landed for every wave; every wave is done reading the other buffer
+    if (st + 1 < nst) stage(st + 1, (st + 1) & 1);
+    const char* base = sm + (st & 1) * STAGE;
+    if (active) {
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub) {
+        const int k0 = st * 64 + 32 * sub;
+        if (k0 < p.Sk) {
+          if (MASK || k0 + 32 > p.Sk) tile(BoolC<true>(), k0, base, sub, sub ? vm1 : vm0);
+          else tile(BoolC<false>(), k0, base, sub, 0xffffu);
+        }
+      }
+    }
+  }
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = l_tot > 0.f ? (DROP ? p.drop.inv_keep : 1.0f) / l_tot : 0.f;
+  if (q_ok) {
+    bf16_t* op = const_cast<bf16_t*>(p.O.ptr) + b * p.O.bs + h * p.O.hs + (long long)q * p.O.rs;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d0 = mt * 32 + 8 * g + 4 * hi;
+        if (d0 < p.D)
+          *reinterpret_cast<uint2*>(op + d0) = make_uint2(pack2bf(o[mt][4 * g] * inv, o[mt][4 * g + 1] * inv),
+                                                          pack2bf(o[mt][4 * g + 2] * inv, o[mt][4 * g + 3] * inv));
+      }
+    if (p.LSE && hi == 0) p.LSE[((long long)(b * p.H + h)) * p.Sqpad + q] = m_run * MRB_LN2 + __logf(fmaxf(l_tot, 1e-37f));
   }
 }
 
 // ---- backward, part 1: dQ (and Delta = rowsum(dO * O), needed by part 2).  Same ownership as the forward.
 template <int DP, int FLAGS>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
   constexpr int KS = DP / 16, MT = DP / 32;
   constexpr bool LUT = FLAGS & F_LUT, MASK = FLAGS & F_MASK, CAUSAL = FLAGS & F_CAUSAL, DROP = FLAGS & F_DROP, SPLIT = FLAGS & F_SPLIT;
   __shared__ float lut[LUT ? 257 : 1];
@@ -267,7 +503,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, hi = lane >> 5, l31 = lane & 31;
   const int b = blockIdx.z, h = blockIdx.y;
   if (LUT) {
-    for (int i = threadIdx.x; i < 257; i += 256) lut[i] = p.lut[h * 257 + i];
+    for (int i = threadIdx.x; i < 257; i += 256) lut[i] = p.lut[h * 257 + i] * MRB_LOG2E;
     __syncthreads();
   }
   const int q0 = SPLIT ? blockIdx.x * 32 : (blockIdx.x * 4 + w) * 32;
@@ -288,8 +524,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
   }
   delta += __shfl_xor(delta, 32, 64);
   const long long stat_off = ((long long)(b * p.H + h)) * p.Sqpad + min(q, p.Sqpad - 1);
-  const float lse = q_ok ? p.LSE[stat_off] : 0.f;
+  const float lse2 = q_ok ? p.LSE[stat_off] * MRB_LOG2E : 0.f;
   if (q_ok && hi == 0 && (!SPLIT || w == 0)) p.Delta[stat_off] = delta;
+  const float scale2 = p.scale * MRB_LOG2E;
+  const float keep_scale = DROP ? p.drop.inv_keep : 1.0f;
 
   f32x16 dq[MT];
 #pragma unroll
@@ -307,7 +545,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
   bf16x8 kcur[KS], vcur[KS];
   load_rows<KS>(kcur, kbase, p.K.rs, kstart + perm23(l31), p.Sk, p.D, hi);
   load_rows<KS>(vcur, vbase, p.V.rs, kstart + perm23(l31), p.Sk, p.D, hi);
-  for (int k0 = kstart; k0 < kend; k0 += kstep) {
+  auto tile = [&](auto edge_c, int k0) {
+    constexpr bool EDGE = decltype(edge_c)::value;
     bf16x8 ktf[MT][2];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -329,44 +568,29 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
       dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vcur[s], dof[s], dpacc, 0, 0, 0);
     }
     float sv[16];
-    if (LUT) {
-      // every |key - q| >= 128 shares one bucket: tiles entirely beyond that distance need one LUT value, not sixteen reads
-      if (k0 - (q0 + 31) >= 128 || (q0 - (k0 + 31)) >= 128) {
-        const float bconst = lut[k0 > q0 ? 256 : 0];
+    tile_scores<LUT, 1>(sv, sacc, scale2, lut, k0 - (q0 + 31) >= 128 || (q0 - (k0 + 31)) >= 128, k0 > q0 ? 256 : 0, k0 + 8 * hi - q);
+    float kf[16];  // dropout factor of dP: keep ? 1/(1-p) : 0
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sv[r] = sacc[r] * p.scale + bconst;
-      } else {
-        float bias[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int rel = (k0 + 16 * (r >> 3) + 8 * hi + (r & 7)) - q;
-          bias[r] = lut[max(-128, min(128, rel)) + 128];
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sv[r] = sacc[r] * p.scale + bias[r];
-      }
-    } else {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sv[r] = sacc[r] * p.scale;
-    }
-    float ds[16], dpv[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) dpv[r] = dpacc[r];
+    for (int r = 0; r < 16; ++r) kf[r] = keep_scale;
     if (DROP) {
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
         const uint32_t hsh = attn_drop_hash(row_id, k0 + 16 * (r >> 3) + 8 * hi + (r & 7), skh, drop_seed, p.drop.site);
-        dpv[r] = (hsh & 0xffffu) >= p.drop.thresh24 ? dpv[r] * p.drop.inv_keep : 0.f;
-        dpv[r + 1] = (hsh >> 16) >= p.drop.thresh24 ? dpv[r + 1] * p.drop.inv_keep : 0.f;
+        kf[r] = (hsh & 0xffffu) >= p.drop.thresh24 ? keep_scale : 0.f;
+        kf[r + 1] = (hsh >> 16) >= p.drop.thresh24 ? keep_scale : 0.f;
       }
     }
+    float ds[16];  // dS / scale (the scale is applied once to dQ at the end)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int key = k0 + 16 * (r >> 3) + 8 * hi + (r & 7);
-      bool ok = q_ok && key < p.Sk && ((vmask >> r) & 1u);
-      if (CAUSAL) ok = ok && (key <= q);
-      const float pr = ok ? __expf(sv[r] - lse) : 0.f;
-      ds[r] = ok ? pr * (dpv[r] - delta) * p.scale : 0.f;
+      float pr = ex2(sv[r] - lse2);
+      if (EDGE) {
+        const int key = k0 + 16 * (r >> 3) + 8 * hi + (r & 7);
+        bool ok = key < p.Sk && ((vmask >> r) & 1u);
+        if (CAUSAL) ok = ok && (key <= q);
+        pr = ok ? pr : 0.f;
+      }
+      ds[r] = pr * (kf[r] * dpacc[r] - delta);
     }
     const bf16x8 f0 = pack8(ds), f1 = pack8(ds + 8);
 #pragma unroll
@@ -376,6 +600,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
     }
 #pragma unroll
     for (int s = 0; s < KS; ++s) { kcur[s] = knext[s]; vcur[s] = vnext[s]; }
+  };
+  for (int k0 = kstart; k0 < kend; k0 += kstep) {
+    const bool edge = MASK || k0 + 32 > p.Sk || (CAUSAL && k0 + 31 > q0);
+    if (edge) tile(BoolC<true>(), k0);
+    else tile(BoolC<false>(), k0);
   }
   if (SPLIT) {
     if (w > 0) {
@@ -402,7 +631,173 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
       for (int g = 0; g < 4; ++g) {
         const int d0 = mt * 32 + 8 * g + 4 * hi;
         if (d0 < p.D)
-          *reinterpret_cast<uint2*>(op + d0) = make_uint2(pack2bf(dq[mt][4 * g], dq[mt][4 * g + 1]), pack2bf(dq[mt][4 * g + 2], dq[mt][4 * g + 3]));
+          *reinterpret_cast<uint2*>(op + d0) = make_uint2(pack2bf(dq[mt][4 * g] * p.scale, dq[mt][4 * g + 1] * p.scale),
+                                                          pack2bf(dq[mt][4 * g + 2] * p.scale, dq[mt][4 * g + 3] * p.scale));
+      }
+  }
+}
+
+// ---- dQ with the key-side tiles (K rows, V rows, K^T) shared through LDS: same staging scheme as attn_fwd_lds_kernel (head_dim 64).
+template <int FLAGS>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_lds_kernel(const AttnArgs p) {
+  constexpr int KS = 4, MT = 2;
+  constexpr bool LUT = FLAGS & F_LUT, MASK = FLAGS & F_MASK, DROP = FLAGS & F_DROP;
+  constexpr int T_BYTES = 64 * 128, STAGE = 3 * T_BYTES;  // K rows | V rows | K^T, 64 keys each
+  __shared__ float lut[LUT ? 257 : 1];
+  extern __shared__ __attribute__((aligned(16))) char sm[];  // 2 * STAGE bytes
+  const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.z, h = blockIdx.y;
+  if (LUT) {
+    for (int i = tid; i < 257; i += 256) lut[i] = p.lut[h * 257 + i] * MRB_LOG2E;
+  }
+  const int q0 = (blockIdx.x * 4 + w) * 32;
+  const bool active = q0 < p.Sq;
+  const int q = q0 + l31;
+  const bool q_ok = q < p.Sq;
+  bf16x8 qf[KS], dof[KS];
+  float delta = 0.f;
+  {
+    load_rows<KS>(qf, p.Q.ptr + b * p.Q.bs + h * p.Q.hs, p.Q.rs, q, p.Sq, p.D, hi);
+    load_rows<KS>(dof, p.dO.ptr + b * p.dO.bs + h * p.dO.hs, p.dO.rs, q, p.Sq, p.D, hi);
+    bf16x8 of[KS];
+    load_rows<KS>(of, p.O.ptr + b * p.O.bs + h * p.O.hs, p.O.rs, q, p.Sq, p.D, hi);
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) delta += bf2f((bf16_t)dof[s][j]) * bf2f((bf16_t)of[s][j]);
+  }
+  delta += __shfl_xor(delta, 32, 64);
+  const long long stat_off = ((long long)(b * p.H + h)) * p.Sqpad + min(q, p.Sqpad - 1);
+  const float lse2 = q_ok ? p.LSE[stat_off] * MRB_LOG2E : 0.f;
+  if (q_ok && hi == 0) p.Delta[stat_off] = delta;
+  const float scale2 = p.scale * MRB_LOG2E;
+  const float keep_scale = DROP ? p.drop.inv_keep : 1.0f;
+
+  f32x16 dq[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) zero16(dq[mt]);
+  const int* km = MASK ? p.kmask + (long long)b * p.Skpad : nullptr;
+  const uint32_t drop_seed = DROP ? *p.drop.seed_ptr : 0u;
+  const uint32_t row_id = (uint32_t)(b * p.H + h) * (uint32_t)p.Sq + (uint32_t)q;
+  const int skh = (p.Sk + 1) >> 1;
+
+  const bf16_t* kbase = p.K.ptr + b * p.K.bs + h * p.K.hs;
+  const bf16_t* vbase = p.V.ptr + b * p.V.bs + h * p.V.hs;
+  const bf16_t* ktbase = p.Kt.ptr + b * p.Kt.bs + h * p.Kt.hs;
+  auto clamp32 = [](long long v) { return (uint32_t)(v > 0xffffffffLL ? 0xffffffffLL : v); };
+  const uint32_t k_bytes = clamp32(((long long)(p.B - 1 - b) * p.K.bs + (long long)(p.H - 1 - h) * p.K.hs + (long long)(p.Sk - 1) * p.K.rs + p.D) * 2);
+  const uint32_t v_bytes = clamp32(((long long)(p.B - 1 - b) * p.V.bs + (long long)(p.H - 1 - h) * p.V.hs + (long long)(p.Sk - 1) * p.V.rs + p.D) * 2);
+  const uint32_t kt_bytes = clamp32(((long long)(p.B - 1 - b) * p.Kt.bs + (long long)(p.H - h) * p.Kt.hs) * 2);
+  uint32_t vK[2], vV[2], vT[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int g = j * 256 + tid, row = g >> 3, c = g & 7, sw = (c ^ ((row >> 1) & 7)) * 16;
+    vK[j] = (uint32_t)((long long)row * p.K.rs * 2) + (uint32_t)sw;
+    vV[j] = (uint32_t)((long long)row * p.V.rs * 2) + (uint32_t)sw;
+    vT[j] = (uint32_t)((long long)row * p.Kt.ds * 2) + (uint32_t)sw;
+  }
+  auto stage = [&](int st, int buf) {
+    char* base = sm + buf * STAGE;
+    attn_stage_dma<2, 2>(base, base + T_BYTES, kbase, k_bytes, vbase, v_bytes, vK, vV, w, (uint32_t)((long long)st * 64 * p.K.rs * 2),
+                         (uint32_t)((long long)st * 64 * p.V.rs * 2));
+    attn_stage_dma<2, 0>(base + 2 * T_BYTES, base, ktbase, kt_bytes, ktbase, kt_bytes, vT, vT, w, (uint32_t)(st * 128), 0u);
+  };
+
+  const int krow = perm23(l31);
+  int k_off[2][KS], t_off[MT][2][2];
+#pragma unroll
+  for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int row = 32 * sub + krow;
+      k_off[sub][s] = row * 128 + (((2 * s + hi) ^ ((row >> 1) & 7)) << 4);
+    }
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const int d = mt * 32 + l31;
+        t_off[mt][sub][hf] = 2 * T_BYTES + d * 128 + (((4 * sub + 2 * hf + hi) ^ ((d >> 1) & 7)) << 4);
+      }
+
+  auto tile = [&](auto edge_c, int k0, const char* base, int sub, uint32_t vmask) {
+    constexpr bool EDGE = decltype(edge_c)::value;
+    f32x16 sacc, dpacc;
+    zero16(sacc);
+    zero16(dpacc);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(base + k_off[sub][s]), qf[s], sacc, 0, 0, 0);
+      dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(base + T_BYTES + k_off[sub][s]), dof[s], dpacc, 0, 0, 0);
+    }
+    float sv[16];
+    tile_scores<LUT, 1>(sv, sacc, scale2, lut, k0 - (q0 + 31) >= 128 || (q0 - (k0 + 31)) >= 128, k0 > q0 ? 256 : 0, k0 + 8 * hi - q);
+    float kf[16];  // dropout factor of dP: keep ? 1/(1-p) : 0
+#pragma unroll
+    for (int r = 0; r < 16; ++r) kf[r] = keep_scale;
+    if (DROP) {
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const uint32_t hsh = attn_drop_hash(row_id, k0 + 16 * (r >> 3) + 8 * hi + (r & 7), skh, drop_seed, p.drop.site);
+        kf[r] = (hsh & 0xffffu) >= p.drop.thresh24 ? keep_scale : 0.f;
+        kf[r + 1] = (hsh >> 16) >= p.drop.thresh24 ? keep_scale : 0.f;
+      }
+    }
+    float ds[16];  // dS / scale (the scale is applied once to dQ at the end)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float pr = ex2(sv[r] - lse2);
+      if (EDGE) {
+        const int key = k0 + 16 * (r >> 3) + 8 * hi + (r & 7);
+        const bool ok = key < p.Sk && ((vmask >> r) & 1u);
+        pr = ok ? pr : 0.f;
+      }
+      ds[r] = pr * (kf[r] * dpacc[r] - delta);
+    }
+    const bf16x8 f0 = pack8(ds), f1 = pack8(ds + 8);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      dq[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(base + t_off[mt][sub][0]), f0, dq[mt], 0, 0, 0);
+      dq[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(base + t_off[mt][sub][1]), f1, dq[mt], 0, 0, 0);
+    }
+  };
+
+  const int nst = (p.Sk + 63) >> 6;
+  stage(0, 0);
+  for (int st = 0; st < nst; ++st) {
+    uint32_t vm0 = 0xffffu, vm1 = 0xffffu;
+    if (MASK) {
+      vm0 = mask_bits(km, st * 64, hi);
+      vm1 = st * 64 + 32 < p.Skpad ? mask_bits(km, st * 64 + 32, hi) : 0u;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (st + 1 < nst) stage(st + 1, (st + 1) & 1);
+    const char* base = sm + (st & 1) * STAGE;
+    if (active) {
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub) {
+        const int k0 = st * 64 + 32 * sub;
+        if (k0 < p.Sk) {
+          if (MASK || k0 + 32 > p.Sk) tile(BoolC<true>(), k0, base, sub, sub ? vm1 : vm0);
+          else tile(BoolC<false>(), k0, base, sub, 0xffffu);
+        }
+      }
+    }
+  }
+  if (q_ok) {
+    bf16_t* op = const_cast<bf16_t*>(p.dQ.ptr) + b * p.dQ.bs + h * p.dQ.hs + (long long)q * p.dQ.rs;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d0 = mt * 32 + 8 * g + 4 * hi;
+        if (d0 < p.D)
+          *reinterpret_cast<uint2*>(op + d0) = make_uint2(pack2bf(dq[mt][4 * g] * p.scale, dq[mt][4 * g + 1] * p.scale),
+                                                          pack2bf(dq[mt][4 * g + 2] * p.scale, dq[mt][4 * g + 3] * p.scale));
       }
   }
 }
@@ -416,7 +811,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, hi = lane >> 5, l31 = lane & 31;
   const int b = blockIdx.z, h = blockIdx.y;
   if (LUT) {
-    for (int i = threadIdx.x; i < 257; i += 256) lut[i] = p.lut[h * 257 + i];
+    for (int i = threadIdx.x; i < 257; i += 256) lut[i] = p.lut[h * 257 + i] * MRB_LOG2E;
     __syncthreads();
   }
   const int kb0 = (blockIdx.x * 4 + w) * 32;
@@ -439,11 +834,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
   const uint32_t drop_seed = DROP ? *p.drop.seed_ptr : 0u;
   const uint32_t bh_idx = (uint32_t)(b * p.H + h) * (uint32_t)p.Sq;
   const int qstart = CAUSAL ? kb0 : 0;
+  const float scale2 = p.scale * MRB_LOG2E;
+  const float keep_scale = DROP ? p.drop.inv_keep : 1.0f;
 
   bf16x8 qcur[KS], docur[KS];
   load_rows<KS>(qcur, qbase, p.Q.rs, qstart + perm23(l31), p.Sq, p.D, hi);
   load_rows<KS>(docur, dobase, p.dO.rs, qstart + perm23(l31), p.Sq, p.D, hi);
-  for (int q0 = qstart; q0 < p.Sq; q0 += 32) {
+  auto tile = [&](auto edge_c, int q0) {
+    constexpr bool EDGE = decltype(edge_c)::value;
     bf16x8 dotf[MT][2], qtf[MT][2];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -476,53 +874,48 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
     }
     // lane (key, hi), register r  <->  query q0 + 16*(r>>3) + 8*hi + (r&7)
     float sv[16];
-    if (LUT) {
-      if (kb0 - (q0 + 31) >= 128 || (q0 - (kb0 + 31)) >= 128) {
-        const float bconst = lut[kb0 > q0 ? 256 : 0];
+    tile_scores<LUT, -1>(sv, sacc, scale2, lut, kb0 - (q0 + 31) >= 128 || (q0 - (kb0 + 31)) >= 128, kb0 > q0 ? 256 : 0, key - q0 - 8 * hi);
+    // two independent halves (8 query rows each): short live ranges for the per-element temporaries
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sv[r] = sacc[r] * p.scale + bconst;
-      } else {
-        float bias[16];
+    for (int c = 0; c < 2; ++c) {
+      uint32_t draw[8];
+      if (DROP) drop_draws8_keyowner(draw, bh_idx + (uint32_t)(q0 + 16 * c + 8 * hi), key, lane, (p.Sk + 1) >> 1, drop_seed, p.drop.site);
+      float pd[8], ds[8];  // pd: dropped P (without 1/(1-p));  ds: dS / scale  — both factors are applied once at the end
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int rel = key - (q0 + 16 * (r >> 3) + 8 * hi + (r & 7));
-          bias[r] = lut[max(-128, min(128, rel)) + 128];
+      for (int j = 0; j < 8; ++j) {
+        const int r = 8 * c + j;
+        float pr = ex2(fmaf(lse[r], -MRB_LOG2E, sv[r]));
+        if (EDGE) {
+          const int qq = q0 + 16 * c + 8 * hi + j;
+          bool ok = qq < p.Sq;
+          if (CAUSAL) ok = ok && (key <= qq);
+          pr = ok ? pr : 0.f;
         }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sv[r] = sacc[r] * p.scale + bias[r];
+        float kfr = keep_scale, prd = pr;
+        if (DROP) {
+          const bool keep = draw[j] >= p.drop.thresh24;
+          kfr = keep ? keep_scale : 0.f;
+          prd = keep ? pr : 0.f;
+        }
+        pd[j] = prd;
+        ds[j] = pr * (kfr * dpacc[r] - del[r]);
       }
-    } else {
+      const bf16x8 pc = pack8(pd), sc = pack8(ds);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) sv[r] = sacc[r] * p.scale;
-    }
-    float pd[16], ds[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int qq = q0 + 16 * (r >> 3) + 8 * hi + (r & 7);
-      bool ok = key_ok && qq < p.Sq;
-      if (CAUSAL) ok = ok && (key <= qq);
-      const float pr = ok ? __expf(sv[r] - lse[r]) : 0.f;
-      float dpv = dpacc[r], prd = pr;
-      if (DROP) {
-        const uint32_t hsh = attn_drop_hash(bh_idx + (uint32_t)qq, key, (p.Sk + 1) >> 1, drop_seed, p.drop.site);
-        const bool keep = ((key & 1) ? (hsh >> 16) : (hsh & 0xffffu)) >= p.drop.thresh24;
-        dpv = keep ? dpv * p.drop.inv_keep : 0.f;
-        prd = keep ? pr * p.drop.inv_keep : 0.f;
+      for (int mt = 0; mt < MT; ++mt) {
+        dv[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dotf[mt][c], pc, dv[mt], 0, 0, 0);
+        dk[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf[mt][c], sc, dk[mt], 0, 0, 0);
       }
-      pd[r] = prd;
-      ds[r] = ok ? pr * (dpv - del[r]) * p.scale : 0.f;
-    }
-    const bf16x8 p0 = pack8(pd), p1 = pack8(pd + 8), s0 = pack8(ds), s1 = pack8(ds + 8);
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      dv[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dotf[mt][0], p0, dv[mt], 0, 0, 0);
-      dv[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dotf[mt][1], p1, dv[mt], 0, 0, 0);
-      dk[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf[mt][0], s0, dk[mt], 0, 0, 0);
-      dk[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf[mt][1], s1, dk[mt], 0, 0, 0);
     }
 #pragma unroll
     for (int s = 0; s < KS; ++s) { qcur[s] = qnext[s]; docur[s] = donext[s]; }
+  };
+  for (int q0 = qstart; q0 < p.Sq; q0 += 32) {
+    const bool edge = q0 + 32 > p.Sq || (CAUSAL && q0 < kb0 + 31);
+    if (edge) tile(BoolC<true>(), q0);
+    else tile(BoolC<false>(), q0);
   }
+  const float fk = key_ok ? p.scale : 0.f, fv = key_ok ? keep_scale : 0.f;  // masked keys: exact zeros
   if (key < p.Sk) {
     bf16_t* kp = const_cast<bf16_t*>(p.dK.ptr) + b * p.dK.bs + h * p.dK.hs + (long long)key * p.dK.rs;
     bf16_t* vp = const_cast<bf16_t*>(p.dV.ptr) + b * p.dV.bs + h * p.dV.hs + (long long)key * p.dV.rs;
@@ -532,30 +925,42 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
       for (int g = 0; g < 4; ++g) {
         const int d0 = mt * 32 + 8 * g + 4 * hi;
         if (d0 < p.D) {
-          *reinterpret_cast<uint2*>(kp + d0) = make_uint2(pack2bf(dk[mt][4 * g], dk[mt][4 * g + 1]), pack2bf(dk[mt][4 * g + 2], dk[mt][4 * g + 3]));
-          *reinterpret_cast<uint2*>(vp + d0) = make_uint2(pack2bf(dv[mt][4 * g], dv[mt][4 * g + 1]), pack2bf(dv[mt][4 * g + 2], dv[mt][4 * g + 3]));
+          *reinterpret_cast<uint2*>(kp + d0) = make_uint2(pack2bf(dk[mt][4 * g] * fk, dk[mt][4 * g + 1] * fk), pack2bf(dk[mt][4 * g + 2] * fk, dk[mt][4 * g + 3] * fk));
+          *reinterpret_cast<uint2*>(vp + d0) = make_uint2(pack2bf(dv[mt][4 * g] * fv, dv[mt][4 * g + 1] * fv), pack2bf(dv[mt][4 * g + 2] * fv, dv[mt][4 * g + 3] * fv));
         }
       }
   }
 }
 
 // ---- dK/dV with the query-side tiles shared through LDS (head_dim 64).  The four key-waves of a block consume the SAME Q, dO,
-// Q^T, dO^T, LSE, Delta tile per step, so the block loads each tile once (16-B coalesced global loads -> registers -> LDS,
-// issued one step ahead: the loads of tile t+1 fly while tile t is computed) instead of four times from L2; fragments are read
-// with ds_read_b128 from XOR-swizzled rows (128-B rows: chunk ^= (row>>1)&7; 64-B rows: chunk ^= (row>>2)&3), conflict-free.
+// Q^T, dO^T, LSE, Delta tiles, so the block fetches each 64-query stage once with LDS-DMA (two stages, one barrier per stage, the
+// DMA of stage t+1 flies while stage t is consumed) instead of four times from L2; MFMA operands are ds_read_b128 from rows that
+// are XOR-swizzled at 16-B granularity through the DMA source address.
+__device__ __forceinline__ void attn_stage_stats(char* dst, const float* lse, const float* del, uint32_t bytes, int lane, uint32_t soff) {
+  // 64 LSE + 64 Delta floats: lanes 0..15 of one wave, 16 B each
+  const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(lse), 0, (int)bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(del), 0, (int)bytes, 0x00020000);
+  if (lane < 16) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r0, (attn_lds_ptr_t)dst, 16, (uint32_t)lane * 16u, soff, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r1, (attn_lds_ptr_t)(dst + 256), 16, (uint32_t)lane * 16u, soff, 0, 0);
+  }
+}
+
 template <int FLAGS>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_lds_kernel(const AttnArgs p) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_lds_kernel(const AttnArgs p) {
   constexpr int KS = 4, MT = 2;
   constexpr bool LUT = FLAGS & F_LUT, MASK = FLAGS & F_MASK, CAUSAL = FLAGS & F_CAUSAL, DROP = FLAGS & F_DROP;
-  constexpr int TILE = 4 * 4096 + 256;  // Q rows | dO rows | Q^T | dO^T | lse[32] delta[32]
+  constexpr int T_BYTES = 64 * 128, STAGE = 4 * T_BYTES + 512;  // Q rows | dO rows | Q^T | dO^T | lse[64] delta[64]
   __shared__ float lut[LUT ? 257 : 1];
-  __shared__ __attribute__((aligned(16))) char sm[2 * TILE];
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, hi = lane >> 5, l31 = lane & 31;
+  extern __shared__ __attribute__((aligned(16))) char sm[];  // 2 * STAGE bytes
+  const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.z, h = blockIdx.y;
   if (LUT) {
-    for (int i = tid; i < 257; i += 256) lut[i] = p.lut[h * 257 + i];
+    for (int i = tid; i < 257; i += 256) lut[i] = p.lut[h * 257 + i] * MRB_LOG2E;
   }
   const int kb0 = (blockIdx.x * 4 + w) * 32;
+  const bool active = kb0 < p.Sk;
   const int key = kb0 + l31;
   bool key_ok = key < p.Sk;
   bf16x8 kf[KS], vf[KS];
@@ -565,135 +970,122 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_lds_kernel(const AttnArgs p)
   f32x16 dk[MT], dv[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) { zero16(dk[mt]); zero16(dv[mt]); }
+  const uint32_t drop_seed = DROP ? *p.drop.seed_ptr : 0u;
+  const uint32_t bh_idx = (uint32_t)(b * p.H + h) * (uint32_t)p.Sq;
+  const int st0 = CAUSAL ? blockIdx.x * 2 : 0;  // first 64-query stage (block-uniform); the per-wave causal limit is applied below
+  const float scale2 = p.scale * MRB_LOG2E;
+  const float keep_scale = DROP ? p.drop.inv_keep : 1.0f;
+
   const bf16_t* qbase = p.Q.ptr + b * p.Q.bs + h * p.Q.hs;
   const bf16_t* dobase = p.dO.ptr + b * p.dO.bs + h * p.dO.hs;
   const bf16_t* qtbase = p.Qt.ptr + b * p.Qt.bs + h * p.Qt.hs;
   const bf16_t* dotbase = p.dOt.ptr + b * p.dOt.bs + h * p.dOt.hs;
   const float* lsebase = p.LSE + ((long long)(b * p.H + h)) * p.Sqpad;
   const float* delbase = p.Delta + ((long long)(b * p.H + h)) * p.Sqpad;
-  const uint32_t drop_seed = DROP ? *p.drop.seed_ptr : 0u;
-  const uint32_t bh_idx = (uint32_t)(b * p.H + h) * (uint32_t)p.Sq;
-  const int qstart = CAUSAL ? blockIdx.x * 128 : 0;  // block-uniform (the per-wave causal limit is applied by the mask)
-
-  // staging roles of this thread: row tile (32 rows x 8 chunks) and transposed tile (64 rows x 4 chunks)
-  const int r_row = tid >> 3, r_chunk = tid & 7, t_row = tid >> 2, t_chunk = tid & 3;
-  const int r_off = r_row * 128 + ((r_chunk ^ ((r_row >> 1) & 7)) << 4);
-  const int t_off = t_row * 64 + ((t_chunk ^ ((t_row >> 2) & 3)) << 4);
-  const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
-  bf16x8 g_q, g_do, g_qt, g_dot;
-  float4 g_st;
-  auto gload = [&](int q0) {
-    const int qr = q0 + r_row;
-    const bool ok = qr < p.Sq && r_chunk * 8 < p.D;
-    const long long ro = (long long)min(qr, p.Sq - 1) * p.Q.rs + min(r_chunk * 8, p.D - 8);
-    const long long rdo = (long long)min(qr, p.Sq - 1) * p.dO.rs + min(r_chunk * 8, p.D - 8);
-    g_q = sel8(ok, ld8(qbase + ro));
-    g_do = sel8(ok, ld8(dobase + rdo));
-    g_qt = ld8(qtbase + (long long)t_row * p.Qt.ds + q0 + t_chunk * 8);      // padded copies: always in bounds, zeros outside
-    g_dot = ld8(dotbase + (long long)t_row * p.dOt.ds + q0 + t_chunk * 8);
-    if (tid < 16) g_st = *reinterpret_cast<const float4*>((tid < 8 ? lsebase : delbase) + q0 + (tid & 7) * 4);
+  auto clamp32 = [](long long v) { return (uint32_t)(v > 0xffffffffLL ? 0xffffffffLL : v); };
+  const uint32_t q_bytes = clamp32(((long long)(p.B - 1 - b) * p.Q.bs + (long long)(p.H - 1 - h) * p.Q.hs + (long long)(p.Sq - 1) * p.Q.rs + p.D) * 2);
+  const uint32_t do_bytes = clamp32(((long long)(p.B - 1 - b) * p.dO.bs + (long long)(p.H - 1 - h) * p.dO.hs + (long long)(p.Sq - 1) * p.dO.rs + p.D) * 2);
+  const uint32_t t_bytes = clamp32(((long long)(p.B - 1 - b) * p.Qt.bs + (long long)(p.H - h) * p.Qt.hs) * 2);
+  const uint32_t st_bytes = clamp32((long long)(p.B * p.H - (b * p.H + h)) * p.Sqpad * 4);
+  uint32_t vQ[2], vDO[2], vT[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int g = j * 256 + tid, row = g >> 3, c = g & 7, sw = (c ^ ((row >> 1) & 7)) * 16;
+    vQ[j] = (uint32_t)((long long)row * p.Q.rs * 2) + (uint32_t)sw;
+    vDO[j] = (uint32_t)((long long)row * p.dO.rs * 2) + (uint32_t)sw;
+    vT[j] = (uint32_t)((long long)row * p.Qt.ds * 2) + (uint32_t)sw;  // Qt and dOt share their geometry
+  }
+  auto stage = [&](int st, int buf) {
+    char* base = sm + buf * STAGE;
+    attn_stage_dma<2, 2>(base, base + T_BYTES, qbase, q_bytes, dobase, do_bytes, vQ, vDO, w, (uint32_t)((long long)st * 64 * p.Q.rs * 2),
+                         (uint32_t)((long long)st * 64 * p.dO.rs * 2));
+    attn_stage_dma<2, 2>(base + 2 * T_BYTES, base + 3 * T_BYTES, qtbase, t_bytes, dotbase, t_bytes, vT, vT, w, (uint32_t)(st * 128), (uint32_t)(st * 128));
+    if (w == 0) attn_stage_stats(base + 4 * T_BYTES, lsebase, delbase, st_bytes, lane, (uint32_t)(st * 256));
   };
-  auto lstore = [&](int buf) {
-    char* base = sm + buf * TILE;
-    *reinterpret_cast<bf16x8*>(base + r_off) = g_q;
-    *reinterpret_cast<bf16x8*>(base + 4096 + r_off) = g_do;
-    *reinterpret_cast<bf16x8*>(base + 8192 + t_off) = g_qt;
-    *reinterpret_cast<bf16x8*>(base + 12288 + t_off) = g_dot;
-    if (tid < 16) *reinterpret_cast<float4*>(base + 16384 + tid * 16) = g_st;
-  };
-  gload(qstart);
-  lstore(0);
-  __syncthreads();
 
-  const int frow = perm23(l31);                    // fragment row of the row tiles (the MFMA row permutation)
-  const int f_sw = (frow >> 1) & 7, t_sw = (l31 >> 2) & 3;
-  int it = 0;
-  for (int q0 = qstart; q0 < p.Sq; q0 += 32, ++it) {
-    const char* base = sm + (it & 1) * TILE;
-    const bool more = q0 + 32 < p.Sq;
-    if (more) gload(q0 + 32);
-    bf16x8 qcur[KS], docur[KS], dotf[MT][2], qtf[MT][2];
+  const int frow = perm23(l31);  // fragment row of the row tiles (the MFMA row permutation)
+  int r_off[KS], t_off[MT][2][2];  // rows of sub-tile 1 sit 32 * 128 B further: same swizzle ((row >> 1) & 7 ignores bit 5)
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      const int off = frow * 128 + (((2 * s + hi) ^ f_sw) << 4);
-      qcur[s] = *reinterpret_cast<const bf16x8*>(base + off);
-      docur[s] = *reinterpret_cast<const bf16x8*>(base + 4096 + off);
-    }
+  for (int s = 0; s < KS; ++s) r_off[s] = frow * 128 + (((2 * s + hi) ^ ((frow >> 1) & 7)) << 4);
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+  for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        const int off = (mt * 32 + l31) * 64 + (((2 * s2 + hi) ^ t_sw) << 4);
-        qtf[mt][s2] = *reinterpret_cast<const bf16x8*>(base + 8192 + off);
-        dotf[mt][s2] = *reinterpret_cast<const bf16x8*>(base + 12288 + off);
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const int d = mt * 32 + l31;
+        t_off[mt][sub][hf] = 2 * T_BYTES + d * 128 + (((4 * sub + 2 * hf + hi) ^ ((d >> 1) & 7)) << 4);
       }
-    float lse[16], del[16];
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      const float* sp = reinterpret_cast<const float*>(base + 16384) + 16 * c + 8 * hi;
-      const float4 a0 = *reinterpret_cast<const float4*>(sp), a1 = *reinterpret_cast<const float4*>(sp + 4);
-      const float4 b0 = *reinterpret_cast<const float4*>(sp + 32), b1 = *reinterpret_cast<const float4*>(sp + 36);
-      lse[8 * c + 0] = a0.x; lse[8 * c + 1] = a0.y; lse[8 * c + 2] = a0.z; lse[8 * c + 3] = a0.w;
-      lse[8 * c + 4] = a1.x; lse[8 * c + 5] = a1.y; lse[8 * c + 6] = a1.z; lse[8 * c + 7] = a1.w;
-      del[8 * c + 0] = b0.x; del[8 * c + 1] = b0.y; del[8 * c + 2] = b0.z; del[8 * c + 3] = b0.w;
-      del[8 * c + 4] = b1.x; del[8 * c + 5] = b1.y; del[8 * c + 6] = b1.z; del[8 * c + 7] = b1.w;
-    }
+
+  auto tile = [&](auto edge_c, int q0, const char* base, int sub) {
+    constexpr bool EDGE = decltype(edge_c)::value;
     f32x16 sacc, dpacc;
     zero16(sacc);
     zero16(dpacc);
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-      sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qcur[s], kf[s], sacc, 0, 0, 0);
-      dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(docur[s], vf[s], dpacc, 0, 0, 0);
+      sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(base + sub * 4096 + r_off[s]), kf[s], sacc, 0, 0, 0);
+      dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(base + T_BYTES + sub * 4096 + r_off[s]), vf[s], dpacc, 0, 0, 0);
     }
+    // lane (key, hi), register r  <->  query q0 + 16*(r>>3) + 8*hi + (r&7)
     float sv[16];
-    if (LUT) {
-      if (kb0 - (q0 + 31) >= 128 || (q0 - (kb0 + 31)) >= 128) {
-        const float bconst = lut[kb0 > q0 ? 256 : 0];
+    tile_scores<LUT, -1>(sv, sacc, scale2, lut, kb0 - (q0 + 31) >= 128 || (q0 - (kb0 + 31)) >= 128, kb0 > q0 ? 256 : 0, key - q0 - 8 * hi);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sv[r] = sacc[r] * p.scale + bconst;
-      } else {
-        float bias[16];
+    for (int c = 0; c < 2; ++c) {  // two independent halves (8 query rows each): short live ranges
+      const float* sp = reinterpret_cast<const float*>(base + 4 * T_BYTES) + 32 * sub + 16 * c + 8 * hi;
+      const float4 a0 = *reinterpret_cast<const float4*>(sp), a1 = *reinterpret_cast<const float4*>(sp + 4);
+      const float4 b0 = *reinterpret_cast<const float4*>(sp + 64), b1 = *reinterpret_cast<const float4*>(sp + 68);
+      const float lse[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w}, del[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+      uint32_t draw[8];
+      if (DROP) drop_draws8_keyowner(draw, bh_idx + (uint32_t)(q0 + 16 * c + 8 * hi), key, lane, (p.Sk + 1) >> 1, drop_seed, p.drop.site);
+      float pd[8], ds[8];  // pd: dropped P (without 1/(1-p));  ds: dS / scale  — both factors are applied once at the end
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int rel = key - (q0 + 16 * (r >> 3) + 8 * hi + (r & 7));
-          bias[r] = lut[max(-128, min(128, rel)) + 128];
+      for (int j = 0; j < 8; ++j) {
+        const int r = 8 * c + j;
+        float pr = ex2(fmaf(lse[j], -MRB_LOG2E, sv[r]));
+        if (EDGE) {
+          const int qq = q0 + 16 * c + 8 * hi + j;
+          bool ok = qq < p.Sq;
+          if (CAUSAL) ok = ok && (key <= qq);
+          pr = ok ? pr : 0.f;
         }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sv[r] = sacc[r] * p.scale + bias[r];
+        float kfr = keep_scale, prd = pr;
+        if (DROP) {
+          const bool keep = draw[j] >= p.drop.thresh24;
+          kfr = keep ? keep_scale : 0.f;
+          prd = keep ? pr : 0.f;
+        }
+        pd[j] = prd;
+        ds[j] = pr * (kfr * dpacc[r] - del[j]);
       }
-    } else {
+      const bf16x8 pc = pack8(pd), sc = pack8(ds);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) sv[r] = sacc[r] * p.scale;
-    }
-    float pd[16], ds[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int qq = q0 + 16 * (r >> 3) + 8 * hi + (r & 7);
-      bool ok = key_ok && qq < p.Sq;
-      if (CAUSAL) ok = ok && (key <= qq);
-      const float pr = ok ? __expf(sv[r] - lse[r]) : 0.f;
-      float dpv = dpacc[r], prd = pr;
-      if (DROP) {
-        const uint32_t hsh = attn_drop_hash(bh_idx + (uint32_t)qq, key, (p.Sk + 1) >> 1, drop_seed, p.drop.site);
-        const bool keep = ((key & 1) ? (hsh >> 16) : (hsh & 0xffffu)) >= p.drop.thresh24;
-        dpv = keep ? dpv * p.drop.inv_keep : 0.f;
-        prd = keep ? pr * p.drop.inv_keep : 0.f;
+      for (int mt = 0; mt < MT; ++mt) {
+        dv[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(base + T_BYTES + t_off[mt][sub][c]), pc, dv[mt], 0, 0, 0);
+        dk[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(base + t_off[mt][sub][c]), sc, dk[mt], 0, 0, 0);
       }
-      pd[r] = prd;
-      ds[r] = ok ? pr * (dpv - del[r]) * p.scale : 0.f;
     }
-    const bf16x8 p0 = pack8(pd), p1 = pack8(pd + 8), s0 = pack8(ds), s1 = pack8(ds + 8);
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      dv[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dotf[mt][0], p0, dv[mt], 0, 0, 0);
-      dv[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dotf[mt][1], p1, dv[mt], 0, 0, 0);
-      dk[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf[mt][0], s0, dk[mt], 0, 0, 0);
-      dk[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf[mt][1], s1, dk[mt], 0, 0, 0);
-    }
-    if (more) lstore((it & 1) ^ 1);
+  };
+
+  const int nst = (p.Sq + 63) >> 6;
+  if (st0 < nst) stage(st0, 0);
+  for (int st = st0, it = 0; st < nst; ++st, ++it) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if (st + 1 < nst) stage(st + 1, (it + 1) & 1);
+    const char* base = sm + (it & 1) * STAGE;
+    if (active) {
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub) {
+        const int q0 = st * 64 + 32 * sub;
+        if (q0 < p.Sq && !(CAUSAL && q0 + 31 < kb0)) {
+          if (q0 + 32 > p.Sq || (CAUSAL && q0 < kb0 + 31)) tile(BoolC<true>(), q0, base, sub);
+          else tile(BoolC<false>(), q0, base, sub);
+        }
+      }
+    }
   }
+  const float fk = key_ok ? p.scale : 0.f, fv = key_ok ? keep_scale : 0.f;  // masked keys: exact zeros
   if (key < p.Sk) {
     bf16_t* kp = const_cast<bf16_t*>(p.dK.ptr) + b * p.dK.bs + h * p.dK.hs + (long long)key * p.dK.rs;
     bf16_t* vp = const_cast<bf16_t*>(p.dV.ptr) + b * p.dV.bs + h * p.dV.hs + (long long)key * p.dV.rs;
@@ -703,8 +1095,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_lds_kernel(const AttnArgs p)
       for (int g = 0; g < 4; ++g) {
         const int d0 = mt * 32 + 8 * g + 4 * hi;
         if (d0 < p.D) {
-          *reinterpret_cast<uint2*>(kp + d0) = make_uint2(pack2bf(dk[mt][4 * g], dk[mt][4 * g + 1]), pack2bf(dk[mt][4 * g + 2], dk[mt][4 * g + 3]));
-          *reinterpret_cast<uint2*>(vp + d0) = make_uint2(pack2bf(dv[mt][4 * g], dv[mt][4 * g + 1]), pack2bf(dv[mt][4 * g + 2], dv[mt][4 * g + 3]));
+          *reinterpret_cast<uint2*>(kp + d0) = make_uint2(pack2bf(dk[mt][4 * g] * fk, dk[mt][4 * g + 1] * fk), pack2bf(dk[mt][4 * g + 2] * fk, dk[mt][4 * g + 3] * fk));
+          *reinterpret_cast<uint2*>(vp + d0) = make_uint2(pack2bf(dv[mt][4 * g] * fv, dv[mt][4 * g + 1] * fv), pack2bf(dv[mt][4 * g + 2] * fv, dv[mt][4 * g + 3] * fv));
         }
       }
   }
@@ -775,6 +1167,22 @@ static int attn_flags(const AttnArgs& a, int causal) {
   X(DPV, F_LUT | F_MASK | F_CAUSAL | F_DROP) X(DPV, F_MASK) X(DPV, F_MASK | F_DROP)                                    \
   X(DPV, F_LUT) X(DPV, F_LUT | F_DROP) X(DPV, F_LUT | F_CAUSAL) X(DPV, F_LUT | F_CAUSAL | F_DROP)
 
+template <int FL>
+static void fwd_lds64(const AttnArgs& a, dim3 grid, hipStream_t stream) {
+  hipLaunchKernelGGL((attn_fwd_lds_kernel<64, FL>), grid, dim3(256), 2 * (64 * 128 + 64 * 128), stream, a);
+}
+template <int FL>
+static void dq_lds64(const AttnArgs& a, dim3 grid, hipStream_t stream) {
+  hipLaunchKernelGGL((attn_bwd_dq_lds_kernel<FL>), grid, dim3(256), 2 * 3 * 64 * 128, stream, a);
+}
+template <int FL>
+static void dkv_lds64(const AttnArgs& a, dim3 grid, hipStream_t stream) {
+  hipLaunchKernelGGL((attn_bwd_dkv_lds_kernel<FL>), grid, dim3(256), 2 * (4 * 64 * 128 + 512), stream, a);
+}
+static void fwd_lds96(const AttnArgs& a, dim3 grid, hipStream_t stream) {
+  hipLaunchKernelGGL((attn_fwd_lds_kernel<96, 0>), grid, dim3(256), 2 * (64 * 192 + 96 * 128), stream, a);
+}
+
 template <int DP>
 static int launch_fwd(const AttnArgs& a, int flags, hipStream_t stream) {
   const bool split = a.Sq <= 32 && a.Sk >= 256 && !(flags & F_CAUSAL);
@@ -782,6 +1190,7 @@ static int launch_fwd(const AttnArgs& a, int flags, hipStream_t stream) {
 #define X(DPV, FL)                                                                                             \
   if (flags == (FL)) {                                                                                         \
     if (split && !((FL) & F_CAUSAL)) hipLaunchKernelGGL((attn_fwd_kernel<DPV, ((FL) & ~F_CAUSAL) | F_SPLIT>), grid, dim3(256), 0, stream, a); \
+    else if (DPV == 64 && !((FL) & F_CAUSAL) && a.Sq > 32) fwd_lds64<((FL) & ~F_CAUSAL)>(a, grid, stream);         \
     else hipLaunchKernelGGL((attn_fwd_kernel<DPV, (FL)>), grid, dim3(256), 0, stream, a);                       \
     return mrblip_check_launch("attention_fwd");                                                               \
   }
@@ -798,8 +1207,9 @@ static int launch_bwd(const AttnArgs& a, int flags, hipStream_t stream) {
 #define X(DPV, FL)                                                                                             \
   if (flags == (FL)) {                                                                                         \
     if (split && !((FL) & F_CAUSAL)) hipLaunchKernelGGL((attn_bwd_dq_kernel<DPV, ((FL) & ~F_CAUSAL) | F_SPLIT>), gq, dim3(256), 0, stream, a); \
+    else if (DPV == 64 && a.D == 64 && !((FL) & F_CAUSAL) && a.Sq > 32) dq_lds64<((FL) & ~F_CAUSAL)>(a, gq, stream);  \
     else hipLaunchKernelGGL((attn_bwd_dq_kernel<DPV, (FL)>), gq, dim3(256), 0, stream, a);                      \
-    if (DPV == 64 && a.D == 64 && a.Sq > 32) hipLaunchKernelGGL((attn_bwd_dkv_lds_kernel<(FL)>), gk, dim3(256), 0, stream, a); \
+    if (DPV == 64 && a.D == 64 && a.Sq > 32) dkv_lds64<(FL)>(a, gk, stream);                                     \
     else hipLaunchKernelGGL((attn_bwd_dkv_kernel<DPV, (FL)>), gk, dim3(256), 0, stream, a);                     \
     return mrblip_check_launch("attention_bwd");                                                               \
   }
@@ -827,7 +1237,8 @@ extern "C" int mrblip_attention_fwd(const void* Q, const long long* q_strides, c
   if (DP == 32) return launch_fwd<32>(a, flags, stream);
   if (DP == 64) return launch_fwd<64>(a, flags, stream);
   MRB_REQUIRE(flags == 0, "attention_fwd: head_dim > 64 supports the plain (ViT) form only");
-  hipLaunchKernelGGL((attn_fwd_kernel<96, 0>), dim3((Sq + 127) / 128, H, B), dim3(256), 0, stream, a);
+  if (Sq > 32) fwd_lds96(a, dim3((Sq + 127) / 128, H, B), stream);
+  else hipLaunchKernelGGL((attn_fwd_kernel<96, 0>), dim3((Sq + 127) / 128, H, B), dim3(256), 0, stream, a);
   return mrblip_check_launch("attention_fwd");
 }
 

@@ -419,15 +419,22 @@ extern "C" int mrblip_gemm_bf16(const void* A, long long lda, const void* W, lon
   a.drop.thresh24 = (uint32_t)(p_drop * 65536.0f + 0.5f);
   a.drop.inv_keep = 1.0f / (1.0f - p_drop);
   MRB_REQUIRE(!(p_drop > 0.f) || seed_ptr, "gemm: dropout needs a device seed pointer");
-  // tile_cfg: 0 auto, 1 = 256x256, 2 = 128x128, 3 = skinny
+  // tile_cfg: 0 auto, 1 = 256x256, 2 = 128x128, 3 = skinny, 4 = 64x128, 5 = 64x64
   int cfg = tile_cfg;
   if (cfg == 0) {
     if (M <= 64 && !gated) cfg = 3;
     else {
-      // measured on MI355X (tools/gemm_bench.py): the 256x256 one-barrier-per-K-tile kernel (1 block/CU) only wins for long-K,
-      // many-tile problems; the 128x128 variant (2 blocks/CU hide each other's staging latency) wins at the hot-path shapes.
-      const long long t256 = (long long)((M + 255) / 256) * (((gated ? N / 2 : N) + (gated ? 127 : 255)) / (gated ? 128 : 256));
-      cfg = (t256 >= 512 && K >= 4096) ? 1 : 2;
+      // measured on MI355X (tools/gemm_bench.py, tools/gemm_kfit.py): the 256x256 kernel (1 block/CU) only wins for long-K, many-tile
+      // problems; 128x128 (2 blocks/CU hide each other's staging latency and epilogue) wins at the ViT shapes; outputs with fewer
+      // 128x128 tiles than resident block slots (T5 [2012,2048], Q-Former [1920,768]) are tile-starved -> 64x128 / 64x64 tiles.
+      const int ncols = gated ? N / 2 : N;
+      const long long t256 = (long long)((M + 255) / 256) * ((ncols + (gated ? 127 : 255)) / (gated ? 128 : 256));
+      const long long t128 = (long long)((M + 127) / 128) * ((ncols + (gated ? 63 : 127)) / (gated ? 64 : 128));
+      const long long t64x128 = (long long)((M + 63) / 64) * ((ncols + (gated ? 63 : 127)) / (gated ? 64 : 128));
+      if (t256 >= 512 && K >= 4096) cfg = 1;
+      else if (t128 >= 400) cfg = 2;
+      else if (t64x128 >= 400 || gated) cfg = 4;
+      else cfg = 5;
     }
   }
   if (cfg == 3) {
@@ -440,6 +447,14 @@ extern "C" int mrblip_gemm_bf16(const void* A, long long lda, const void* W, lon
   if (cfg == 1) {
     if (gated) return launch_tile<256, 256, 2, 4, false, true>(a, stream);
     return out_f32 ? launch_tile<256, 256, 2, 4, true, false>(a, stream) : launch_tile<256, 256, 2, 4, false, false>(a, stream);
+  }
+  if (cfg == 4) {
+    if (gated) return launch_tile<64, 128, 2, 2, false, true>(a, stream);
+    return out_f32 ? launch_tile<64, 128, 2, 2, true, false>(a, stream) : launch_tile<64, 128, 2, 2, false, false>(a, stream);
+  }
+  if (cfg == 5) {
+    MRB_REQUIRE(!gated, "gemm: the 64x64 tile has no gated epilogue");
+    return out_f32 ? launch_tile<64, 64, 2, 2, true, false>(a, stream) : launch_tile<64, 64, 2, 2, false, false>(a, stream);
   }
   if (gated) return launch_tile<128, 128, 2, 2, false, true>(a, stream);
   return out_f32 ? launch_tile<128, 128, 2, 2, true, false>(a, stream) : launch_tile<128, 128, 2, 2, false, false>(a, stream);

@@ -16,11 +16,12 @@ def timeit(fn, iters=10, warm=2):
 dev = torch.device("cuda:0")
 seed = torch.tensor([1], dtype=torch.int32, device=dev)
 for name, B, H, Sq, Sk, D, lut_on, drop_on, causal in [
-    ("t5enc", 1, 32, 2012, 2012, 64, True, True, False), ("t5enc_nodrop", 1, 32, 2012, 2012, 64, True, False, False),
+    ("t5enc", 1, 32, 2012, 2012, 64, True, True, False), ("t5enc_masked", 1, 32, 2012, 2012, 64, True, True, False),
+    ("t5enc_nodrop", 1, 32, 2012, 2012, 64, True, False, False),
     ("t5enc_plain", 1, 32, 2012, 2012, 64, False, False, False), ("vit", 60, 16, 257, 257, 88, False, False, False),
     ("qf_cross", 60, 12, 32, 257, 64, False, True, False), ("dec_cross", 1, 32, 8, 2012, 64, False, True, False)]:
     kmask = None
-    if lut_on or name == "dec_cross":
+    if name in ("t5enc_masked", "dec_cross"):
         kmask = torch.zeros(B, ops.rup32(Sk), dtype=torch.int32, device=dev); kmask[:, :Sk] = 1
     q = torch.randn(B, Sq, H, D, device=dev).bfloat16(); k = torch.randn(B, Sk, H, D, device=dev).bfloat16(); v = torch.randn(B, Sk, H, D, device=dev).bfloat16()
     do = torch.randn(B, Sq, H, D, device=dev).bfloat16()

@@ -13,7 +13,8 @@ from mrblip import ops  # noqa: E402
 SHAPES = [  # (name, M, N, K)
     ("vit_qkv", 15420, 4224, 1408), ("vit_proj", 15420, 1408, 1408), ("vit_fc1", 15420, 6144, 1408), ("vit_fc2", 15420, 1408, 6144),
     ("t5_qkv", 2023, 6144, 2048), ("t5_o", 2023, 2048, 2048), ("t5_wi", 2023, 10240, 2048), ("t5_wo", 2023, 2048, 5120),
-    ("qf_kv", 15420, 1536, 1408), ("qf_q", 1920, 768, 768), ("sq4096", 4096, 4096, 4096), ("sq8192", 8192, 8192, 8192),
+    ("t5_dx_wi", 2023, 2048, 10240), ("t5_dx_qkv", 2023, 2048, 6144),
+    ("qf_kv", 15420, 1536, 1408), ("qf_q", 1920, 768, 768), ("qf_qkv", 1920, 2304, 768), ("qf_fc1", 1920, 3072, 768), ("qf_fc2", 1920, 768, 3072), ("sq4096", 4096, 4096, 4096), ("sq8192", 8192, 8192, 8192),
     ("dec_q", 12, 2048, 2048), ("dec_wi", 12, 10240, 2048), ("lm_head", 12, 32128, 2048),
 ]
 
@@ -40,7 +41,7 @@ def main():
         out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
         row = dict(name=name, M=M, N=N, K=K)
         fl = 2.0 * M * N * K
-        cfgs = [3] if M <= 64 else [1, 2]
+        cfgs = [3] if M <= 64 else [1, 2, 4, 5]
         for cfg in cfgs:
             t = timeit(lambda: ops.gemm(a, w, out, tile_cfg=cfg))
             row[f"cfg{cfg}_us"] = round(t * 1e6, 1)

@@ -10,18 +10,25 @@ def short(name):
     return name[:110]
 
 
-def main(db, out=None, skip_first_frac=0.0):
+def main(db, out=None, skip_first_frac=0.0, by_grid=False):
     con = sqlite3.connect(db)
     cur = con.cursor()
     cols = [r[1] for r in cur.execute("pragma table_info(kernels)").fetchall()]
-    rows = cur.execute("select name, start, end from kernels order by start").fetchall()
+    gcol = next((c for c in ("grid_x", "grid_size_x", "grid_size") if c in cols), None)
+    if by_grid and gcol:  # one row per (kernel, grid): separates the GEMM shapes
+        rows = cur.execute(f"select name, {gcol}, start, end from kernels order by start").fetchall()
+        rows = [(f"{short(n)[:90]} grid={g}", s, e) for n, g, s, e in rows]
+    else:
+        if by_grid:
+            print("# no grid column among", cols)
+        rows = cur.execute("select name, start, end from kernels order by start").fetchall()
     t0, t1 = rows[0][1], rows[-1][2]
     cut = t0 + (t1 - t0) * skip_first_frac
     agg = {}
     for name, s, e in rows:
         if s < cut:
             continue
-        a = agg.setdefault(short(name), [0, 0, 1 << 62, 0])
+        a = agg.setdefault(name if (by_grid and gcol) else short(name), [0, 0, 1 << 62, 0])
         d = e - s
         a[0] += 1; a[1] += d; a[2] = min(a[2], d); a[3] = max(a[3], d)
     tot = sum(a[1] for a in agg.values())
@@ -36,4 +43,5 @@ def main(db, out=None, skip_first_frac=0.0):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else None, float(sys.argv[3]) if len(sys.argv) > 3 else 0.0)
+    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else None, float(sys.argv[3]) if len(sys.argv) > 3 else 0.0,
+         by_grid=len(sys.argv) > 4 and sys.argv[4] == "grid")
