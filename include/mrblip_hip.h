@@ -51,18 +51,21 @@ int mrblip_rmsnorm_bwd(const float* dy, long long lddy, const float* x, long lon
 /* Fused softmax(Q K^T * scale + bias_lut[h][clamp(k-q,-128,128)+128] + masks) V, fp32 online softmax, bf16 I/O.
  * strides = {batch, head, row} in elements (rows are contiguous in head_dim).  Vt/Kt/Qt/dOt are
  * [B,H,roundup32(D),roundup32(S)] transposed zero-padded copies from mrblip_head_transpose.  LSE/Delta are
- * [B,H,roundup32(Sq)] fp32.  eva_vit.py:128-145; Qformer.py:195-262; modeling_t5.py:392-472,536-603. */
+ * [B,H,roundup32(Sq)] fp32.  eva_vit.py:128-145; Qformer.py:195-262; modeling_t5.py:392-472,536-603.
+ * drop_bits (optional, with dropout): uint32 [B*H, roundup32(Sk)/32, roundup32(Sq)] scratch that carries the keep mask of the
+ * probability dropout from the forward to the backward (head_dim 64, non-causal, Sq > 32 shapes; ignored elsewhere) so the
+ * backward does not recompute the counter hash; pass the SAME buffer (or NULL to both) to fwd and bwd of one attention. */
 int mrblip_attention_fwd(const void* Q, const long long* q_strides, const void* K, const long long* k_strides, const void* Vt,
                          void* O, const long long* o_strides, float* LSE, int B, int H, int Sq, int Sk, int D, float scale,
                          const float* bias_lut, const int* kmask, int causal, const uint32_t* seed_ptr, uint32_t site,
-                         float p_drop, mrblip_stream_t stream);
+                         float p_drop, uint32_t* drop_bits, mrblip_stream_t stream);
 int mrblip_attention_bwd(const void* Q, const long long* q_strides, const void* K, const long long* k_strides, const void* V,
                          const long long* v_strides, const void* O, const long long* o_strides, const void* dO,
                          const long long* do_strides, const void* Kt, const void* Qt, const void* dOt, const float* LSE,
                          float* Delta, void* dQ, const long long* dq_strides, void* dK, const long long* dk_strides, void* dV,
                          const long long* dv_strides, int B, int H, int Sq, int Sk, int D, float scale, const float* bias_lut,
                          const int* kmask, int causal, const uint32_t* seed_ptr, uint32_t site, float p_drop,
-                         mrblip_stream_t stream);
+                         const uint32_t* drop_bits, mrblip_stream_t stream);
 /* Spad: padded row length of the transposed copy (multiple of 32), 0 = roundup32(S) */
 int mrblip_head_transpose(const void* src, const long long* strides, void* dst, int B, int H, int S, int D, int Spad,
                           const uint32_t* seed_ptr, uint32_t site, float p_drop, mrblip_stream_t stream);
@@ -104,10 +107,23 @@ int mrblip_colsum(const float* x, long long ldx, int M, int N, float* out, mrbli
  * for the columns col0[j] <= c < col0[j] + ncols[j]  (dB^T = u^T dy is block-diagonal over the adapters of a fused group, dA = g^T dropout(x)) */
 int mrblip_lora_tn(const void* Y, long long ldy, const void* U, long long ldu, int M, int C, int R, float* const* outs, const int* col0,
                    const int* ncols, const long long* lds, const uint32_t* seed_ptr, uint32_t site, float p_drop, mrblip_stream_t stream);
-/* fp32 LoRA master weights -> bf16 GEMM operands for every adapter of a device descriptor table (8 int64 per adapter:
- * a_off, bt_off, K, out, acat_off, wext_off, bblk_off, Ntot) */
-int mrblip_lora_pack(const float* flat, void* acat_bf16, void* wext_bf16, void* bblk_bf16, const long long* desc, int n_adapters,
-                     float scale, mrblip_stream_t stream);
+/* both weight gradients of a fused LoRA group in one launch: dBt_j += U_j^T dY (adapter j's output columns), dA_j += G_j^T dropout(X) */
+int mrblip_lora_grads(const void* dY, long long lddy, const void* U, long long ldu, const void* X, long long ldx, const void* G,
+                      long long ldg, int M, int N, int K, int R, float* const* dBt, const int* b_col0, const int* b_ncols,
+                      const long long* b_lds, float* const* dA, const long long* a_lds, const uint32_t* seed_ptr, uint32_t site,
+                      float p_drop, mrblip_stream_t stream);
+/* LoRA "down" product with the lora_dropout fused into the operand load: U[M,N] = dropout(X)[M,K] Acat[N,K]^T (bf16; peft lora_A(lora_dropout(x))) */
+int mrblip_gemm_lora_down(const void* X, long long ldx, const void* Acat, long long lda, int M, int N, int K, void* U, long long ldu,
+                          const uint32_t* seed_ptr, uint32_t site, float p_drop, mrblip_stream_t stream);
+/* LoRA backward input gradient in one launch: dX[M,N] = dY[M,K] Wt[N,K]^T (+ residual) + mask(site,p) * (G[M,64] AcatT[N,64]^T);
+ * N = in_features, K = out_features padded to 64, mask = the forward's lora_dropout keep mask scaled by 1/(1-p) */
+int mrblip_gemm_lora_dx(const void* dY, long long lddy, const void* Wt, long long ldwt, const void* G, long long ldg, const void* AcatT,
+                        long long ldat, int M, int N, int K, void* dX, long long lddx, int out_f32, const float* residual, long long ldr,
+                        const uint32_t* seed_ptr, uint32_t site, float p_drop, int tile_cfg, mrblip_stream_t stream);
+/* fp32 LoRA master weights -> bf16 GEMM operands for every adapter of a device descriptor table (10 int64 per adapter:
+ * a_off, bt_off, K, out, acat_off, wext_off, bblk_off, Ntot, acatt_off, 0); acatt = [K,64] transposed copy of scale*A */
+int mrblip_lora_pack(const float* flat, void* acat_bf16, void* wext_bf16, void* bblk_bf16, void* acatt_bf16, const long long* desc,
+                     int n_adapters, float scale, mrblip_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -37,9 +37,11 @@ struct AttnArgs {
   int B, H, Sq, Sk, D, Sqpad, Skpad;
   float scale;
   DropoutArg drop;
+  uint32_t* dbits;     // optional [B*H, Skpad/32, Sqpad]: keep bits of the probability dropout (bit i of word (kt, q) <-> key 32 kt + i),
+                       // written by the LDS forward kernel and read back by the LDS backward kernels instead of re-hashing
 };
 
-enum { F_LUT = 1, F_MASK = 2, F_CAUSAL = 4, F_DROP = 8, F_SPLIT = 16 };
+enum { F_LUT = 1, F_MASK = 2, F_CAUSAL = 4, F_DROP = 8, F_SPLIT = 16, F_DBITS = 32 };
 
 // attention-probability dropout draws: one 32-bit hash per (row, key pair): index = row * ceil(Sk/2) + key/2, the low 16 bits
 // serve the even key and the high 16 bits the odd key -> 8 hashes per 16 scores where a lane owns consecutive keys.
@@ -325,12 +327,13 @@ __device__ __forceinline__ void attn_stage_dma(char* dstA, char* dstB, const voi
 template <int DP, int FLAGS>
 __global__ __launch_bounds__(256, 2) void attn_fwd_lds_kernel(const AttnArgs p) {
   constexpr int KS = DP / 16, MT = DP / 32;
-  constexpr bool LUT = FLAGS & F_LUT, MASK = FLAGS & F_MASK, DROP = FLAGS & F_DROP;
+  constexpr bool LUT = FLAGS & F_LUT, MASK = FLAGS & F_MASK, DROP = FLAGS & F_DROP, DBITS = FLAGS & F_DBITS;
   constexpr int KROW = DP * 2, KCPR = DP / 8;                 // K row bytes, 16-B chunks per K row
   constexpr int K_BYTES = 64 * KROW, V_BYTES = DP * 128, STAGE = K_BYTES + V_BYTES;
   constexpr int NJK = 64 * KCPR / 256, NJV = DP * 8 / 256;    // DMA instructions per thread per stage
-  __shared__ float lut[LUT ? 257 : 1];
-  extern __shared__ __attribute__((aligned(16))) char sm[];  // 2 * STAGE bytes
+  // everything lives in the dynamic region (a static array in front of it would shift its base off 16-B alignment)
+  extern __shared__ __attribute__((aligned(16))) char sm[];  // 2 * STAGE bytes + 257-float bias LUT
+  float* lut = reinterpret_cast<float*>(sm + 2 * STAGE);
   const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.z, h = blockIdx.y;
@@ -352,6 +355,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_lds_kernel(const AttnArgs p) 
   const uint32_t row_id = (uint32_t)(b * p.H + h) * (uint32_t)p.Sq + (uint32_t)q;
   const int skh = (p.Sk + 1) >> 1;
   const float scale2 = p.scale * MRB_LOG2E;
+  uint32_t* dbits_row = DBITS ? p.dbits + (long long)(b * p.H + h) * (p.Skpad >> 5) * p.Sqpad + q : nullptr;
 
   // ---- staging: buffer resources span from this head's first element to the end of the tensor (reads past the head's rows stay
   // inside the tensor or return 0; whatever they return is finite and meets P == 0 / zero-padded Q)
@@ -437,11 +441,19 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_lds_kernel(const AttnArgs p) 
       psum += pv[r];
     }
     if (DROP) {
+      uint32_t bits = 0;  // keep bit of register r at position 16*(r>>3) + (r&7); shifted by 8*hi it is the key's bit in the tile word
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
         const uint32_t hsh = attn_drop_hash(row_id, k0 + 16 * (r >> 3) + 8 * hi + (r & 7), skh, drop_seed, p.drop.site);
-        pv[r] = (hsh & 0xffffu) >= p.drop.thresh24 ? pv[r] : 0.f;
-        pv[r + 1] = (hsh >> 16) >= p.drop.thresh24 ? pv[r + 1] : 0.f;
+        const bool k0_ = (hsh & 0xffffu) >= p.drop.thresh24, k1_ = (hsh >> 16) >= p.drop.thresh24;
+        pv[r] = k0_ ? pv[r] : 0.f;
+        pv[r + 1] = k1_ ? pv[r + 1] : 0.f;
+        if (DBITS) bits |= (k0_ ? 1u << (16 * (r >> 3) + (r & 7)) : 0u) | (k1_ ? 2u << (16 * (r >> 3) + (r & 7)) : 0u);
+      }
+      if (DBITS) {
+        uint32_t wbits = bits << (8 * hi);
+        wbits |= (uint32_t)__shfl_xor((int)wbits, 32, 64);
+        if (hi == 0) dbits_row[(long long)(k0 >> 5) * p.Sqpad] = wbits;
       }
     }
     l_run += psum;
@@ -641,10 +653,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
 template <int FLAGS>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_lds_kernel(const AttnArgs p) {
   constexpr int KS = 4, MT = 2;
-  constexpr bool LUT = FLAGS & F_LUT, MASK = FLAGS & F_MASK, DROP = FLAGS & F_DROP;
+  constexpr bool LUT = FLAGS & F_LUT, MASK = FLAGS & F_MASK, DROP = FLAGS & F_DROP, DBITS = FLAGS & F_DBITS;
   constexpr int T_BYTES = 64 * 128, STAGE = 3 * T_BYTES;  // K rows | V rows | K^T, 64 keys each
-  __shared__ float lut[LUT ? 257 : 1];
-  extern __shared__ __attribute__((aligned(16))) char sm[];  // 2 * STAGE bytes
+  // everything lives in the dynamic region (a static array in front of it would shift its base off 16-B alignment)
+  extern __shared__ __attribute__((aligned(16))) char sm[];  // 2 * STAGE bytes + 257-float bias LUT
+  float* lut = reinterpret_cast<float*>(sm + 2 * STAGE);
   const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.z, h = blockIdx.y;
@@ -723,7 +736,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_lds_kernel(const AttnArgs 
         t_off[mt][sub][hf] = 2 * T_BYTES + d * 128 + (((4 * sub + 2 * hf + hi) ^ ((d >> 1) & 7)) << 4);
       }
 
-  auto tile = [&](auto edge_c, int k0, const char* base, int sub, uint32_t vmask) {
+  auto tile = [&](auto edge_c, int k0, const char* base, int sub, uint32_t vmask, uint32_t dword) {
     constexpr bool EDGE = decltype(edge_c)::value;
     f32x16 sacc, dpacc;
     zero16(sacc);
@@ -738,7 +751,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_lds_kernel(const AttnArgs 
     float kf[16];  // dropout factor of dP: keep ? 1/(1-p) : 0
 #pragma unroll
     for (int r = 0; r < 16; ++r) kf[r] = keep_scale;
-    if (DROP) {
+    if (DROP && DBITS) {  // keep bits stored by the forward
+      const uint32_t wsh = dword >> (8 * hi);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) kf[r] = (wsh & (1u << (16 * (r >> 3) + (r & 7)))) ? keep_scale : 0.f;
+    } else if (DROP) {
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
         const uint32_t hsh = attn_drop_hash(row_id, k0 + 16 * (r >> 3) + 8 * hi + (r & 7), skh, drop_seed, p.drop.site);
@@ -766,7 +783,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_lds_kernel(const AttnArgs 
   };
 
   const int nst = (p.Sk + 63) >> 6;
+  const uint32_t* dbits_row = DBITS ? p.dbits + (long long)(b * p.H + h) * (p.Skpad >> 5) * p.Sqpad + min(q, p.Sqpad - 1) : nullptr;
+  const int nkt = p.Skpad >> 5;
+  uint32_t dw0 = 0, dw1 = 0;  // keep-bit words of the NEXT stage's two sub-tiles (loaded one stage ahead)
   stage(0, 0);
+  if (DBITS) {
+    dw0 = dbits_row[0];
+    dw1 = 1 < nkt ? dbits_row[p.Sqpad] : 0u;
+  }
   for (int st = 0; st < nst; ++st) {
     uint32_t vm0 = 0xffffu, vm1 = 0xffffu;
     if (MASK) {
@@ -775,15 +799,22 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_lds_kernel(const AttnArgs 
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (st + 1 < nst) stage(st + 1, (st + 1) & 1);
+    const uint32_t cw0 = dw0, cw1 = dw1;
+    if (st + 1 < nst) {
+      stage(st + 1, (st + 1) & 1);
+      if (DBITS) {
+        dw0 = dbits_row[(long long)(2 * st + 2) * p.Sqpad];
+        dw1 = 2 * st + 3 < nkt ? dbits_row[(long long)(2 * st + 3) * p.Sqpad] : 0u;
+      }
+    }
     const char* base = sm + (st & 1) * STAGE;
     if (active) {
 #pragma unroll
       for (int sub = 0; sub < 2; ++sub) {
         const int k0 = st * 64 + 32 * sub;
         if (k0 < p.Sk) {
-          if (MASK || k0 + 32 > p.Sk) tile(BoolC<true>(), k0, base, sub, sub ? vm1 : vm0);
-          else tile(BoolC<false>(), k0, base, sub, 0xffffu);
+          if (MASK || k0 + 32 > p.Sk) tile(BoolC<true>(), k0, base, sub, sub ? vm1 : vm0, sub ? cw1 : cw0);
+          else tile(BoolC<false>(), k0, base, sub, 0xffffu, sub ? cw1 : cw0);
         }
       }
     }
@@ -946,13 +977,19 @@ __device__ __forceinline__ void attn_stage_stats(char* dst, const float* lse, co
   }
 }
 
+__device__ __forceinline__ void attn_stage_bits(char* dst, const uint32_t* src, uint32_t bytes, int lane, uint32_t soff) {
+  const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(src), 0, (int)bytes, 0x00020000);
+  if (lane < 16) __builtin_amdgcn_raw_ptr_buffer_load_lds(r0, (attn_lds_ptr_t)dst, 16, (uint32_t)lane * 16u, soff, 0, 0);
+}
+
 template <int FLAGS>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_lds_kernel(const AttnArgs p) {
   constexpr int KS = 4, MT = 2;
-  constexpr bool LUT = FLAGS & F_LUT, MASK = FLAGS & F_MASK, CAUSAL = FLAGS & F_CAUSAL, DROP = FLAGS & F_DROP;
-  constexpr int T_BYTES = 64 * 128, STAGE = 4 * T_BYTES + 512;  // Q rows | dO rows | Q^T | dO^T | lse[64] delta[64]
-  __shared__ float lut[LUT ? 257 : 1];
-  extern __shared__ __attribute__((aligned(16))) char sm[];  // 2 * STAGE bytes
+  constexpr bool LUT = FLAGS & F_LUT, MASK = FLAGS & F_MASK, CAUSAL = FLAGS & F_CAUSAL, DROP = FLAGS & F_DROP, DBITS = FLAGS & F_DBITS;
+  constexpr int T_BYTES = 64 * 128, STAGE = 4 * T_BYTES + 512 + 1024;  // Q rows | dO rows | Q^T | dO^T | lse[64] delta[64] | keep bits 4 x [64]
+  // everything lives in the dynamic region (a static array in front of it would shift its base off 16-B alignment)
+  extern __shared__ __attribute__((aligned(16))) char sm[];  // 2 * STAGE bytes + 257-float bias LUT
+  float* lut = reinterpret_cast<float*>(sm + 2 * STAGE);
   const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.z, h = blockIdx.y;
@@ -987,6 +1024,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_lds_kernel(const AttnArgs
   const uint32_t do_bytes = clamp32(((long long)(p.B - 1 - b) * p.dO.bs + (long long)(p.H - 1 - h) * p.dO.hs + (long long)(p.Sq - 1) * p.dO.rs + p.D) * 2);
   const uint32_t t_bytes = clamp32(((long long)(p.B - 1 - b) * p.Qt.bs + (long long)(p.H - h) * p.Qt.hs) * 2);
   const uint32_t st_bytes = clamp32((long long)(p.B * p.H - (b * p.H + h)) * p.Sqpad * 4);
+  // keep bits of this wave's key tile: row (bh, kt = kb0 / 32) of the [B*H, Skpad/32, Sqpad] word array
+  const long long bits_row_idx = (long long)(b * p.H + h) * (p.Skpad >> 5) + (kb0 >> 5);
+  const uint32_t* bits_row = DBITS ? p.dbits + bits_row_idx * p.Sqpad : nullptr;
+  const uint32_t bits_bytes = DBITS ? clamp32(((long long)p.B * p.H * (p.Skpad >> 5) - bits_row_idx) * p.Sqpad * 4) : 0u;
   uint32_t vQ[2], vDO[2], vT[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
@@ -1001,6 +1042,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_lds_kernel(const AttnArgs
                          (uint32_t)((long long)st * 64 * p.dO.rs * 2));
     attn_stage_dma<2, 2>(base + 2 * T_BYTES, base + 3 * T_BYTES, qtbase, t_bytes, dotbase, t_bytes, vT, vT, w, (uint32_t)(st * 128), (uint32_t)(st * 128));
     if (w == 0) attn_stage_stats(base + 4 * T_BYTES, lsebase, delbase, st_bytes, lane, (uint32_t)(st * 256));
+    if (DBITS && active) attn_stage_bits(base + 4 * T_BYTES + 512 + w * 256, bits_row, bits_bytes, lane, (uint32_t)(st * 256));
   };
 
   const int frow = perm23(l31);  // fragment row of the row tiles (the MFMA row permutation)
@@ -1037,7 +1079,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_lds_kernel(const AttnArgs
       const float4 b0 = *reinterpret_cast<const float4*>(sp + 64), b1 = *reinterpret_cast<const float4*>(sp + 68);
       const float lse[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w}, del[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
       uint32_t draw[8];
-      if (DROP) drop_draws8_keyowner(draw, bh_idx + (uint32_t)(q0 + 16 * c + 8 * hi), key, lane, (p.Sk + 1) >> 1, drop_seed, p.drop.site);
+      if (DROP && DBITS) {  // stored keep bits: word j = query row q0 + 16c + 8hi + j, bit l31 = this lane's key
+        const uint32_t* bp = reinterpret_cast<const uint32_t*>(base + 4 * T_BYTES + 512 + w * 256) + 32 * sub + 16 * c + 8 * hi;
+        const uint4 w0 = *reinterpret_cast<const uint4*>(bp), w1 = *reinterpret_cast<const uint4*>(bp + 4);
+        const uint32_t ws[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) draw[j] = ((ws[j] >> l31) & 1u) ? 0xffffu : 0u;  // >= thresh <=> keep
+      } else if (DROP) {
+        drop_draws8_keyowner(draw, bh_idx + (uint32_t)(q0 + 16 * c + 8 * hi), key, lane, (p.Sk + 1) >> 1, drop_seed, p.drop.site);
+      }
       float pd[8], ds[8];  // pd: dropped P (without 1/(1-p));  ds: dS / scale  — both factors are applied once at the end
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -1167,20 +1217,31 @@ static int attn_flags(const AttnArgs& a, int causal) {
   X(DPV, F_LUT | F_MASK | F_CAUSAL | F_DROP) X(DPV, F_MASK) X(DPV, F_MASK | F_DROP)                                    \
   X(DPV, F_LUT) X(DPV, F_LUT | F_DROP) X(DPV, F_LUT | F_CAUSAL) X(DPV, F_LUT | F_CAUSAL | F_DROP)
 
+// the LDS kernels of the head_dim-64, non-causal, Sq > 32 shapes (T5 encoder, Q-Former... ): all three passes take the same
+// decision, so the stored keep bits are either written and read or ignored by all of them
+static bool use_lds64(const AttnArgs& a, int flags) { return a.D == 64 && !(flags & F_CAUSAL) && a.Sq > 32; }
+
 template <int FL>
 static void fwd_lds64(const AttnArgs& a, dim3 grid, hipStream_t stream) {
-  hipLaunchKernelGGL((attn_fwd_lds_kernel<64, FL>), grid, dim3(256), 2 * (64 * 128 + 64 * 128), stream, a);
+  constexpr int LDS = 2 * (64 * 128 + 64 * 128) + 1040;
+  if ((FL & F_DROP) && a.dbits) hipLaunchKernelGGL((attn_fwd_lds_kernel<64, (FL & F_DROP) ? (FL | F_DBITS) : FL>), grid, dim3(256), LDS, stream, a);
+  else hipLaunchKernelGGL((attn_fwd_lds_kernel<64, FL>), grid, dim3(256), LDS, stream, a);
 }
 template <int FL>
 static void dq_lds64(const AttnArgs& a, dim3 grid, hipStream_t stream) {
-  hipLaunchKernelGGL((attn_bwd_dq_lds_kernel<FL>), grid, dim3(256), 2 * 3 * 64 * 128, stream, a);
+  constexpr int LDS = 2 * 3 * 64 * 128 + 1040;
+  if ((FL & F_DROP) && a.dbits) hipLaunchKernelGGL((attn_bwd_dq_lds_kernel<(FL & F_DROP) ? (FL | F_DBITS) : FL>), grid, dim3(256), LDS, stream, a);
+  else hipLaunchKernelGGL((attn_bwd_dq_lds_kernel<FL>), grid, dim3(256), LDS, stream, a);
 }
 template <int FL>
 static void dkv_lds64(const AttnArgs& a, dim3 grid, hipStream_t stream) {
-  hipLaunchKernelGGL((attn_bwd_dkv_lds_kernel<FL>), grid, dim3(256), 2 * (4 * 64 * 128 + 512), stream, a);
+  constexpr int LDS = 2 * (4 * 64 * 128 + 512 + 1024) + 1040;
+  if ((FL & F_DROP) && a.dbits && !(FL & F_CAUSAL))
+    hipLaunchKernelGGL((attn_bwd_dkv_lds_kernel<((FL & F_DROP) && !(FL & F_CAUSAL)) ? (FL | F_DBITS) : FL>), grid, dim3(256), LDS, stream, a);
+  else hipLaunchKernelGGL((attn_bwd_dkv_lds_kernel<FL>), grid, dim3(256), LDS, stream, a);
 }
 static void fwd_lds96(const AttnArgs& a, dim3 grid, hipStream_t stream) {
-  hipLaunchKernelGGL((attn_fwd_lds_kernel<96, 0>), grid, dim3(256), 2 * (64 * 192 + 96 * 128), stream, a);
+  hipLaunchKernelGGL((attn_fwd_lds_kernel<96, 0>), grid, dim3(256), 2 * (64 * 192 + 96 * 128) + 1040, stream, a);
 }
 
 template <int DP>
@@ -1190,7 +1251,7 @@ static int launch_fwd(const AttnArgs& a, int flags, hipStream_t stream) {
 #define X(DPV, FL)                                                                                             \
   if (flags == (FL)) {                                                                                         \
     if (split && !((FL) & F_CAUSAL)) hipLaunchKernelGGL((attn_fwd_kernel<DPV, ((FL) & ~F_CAUSAL) | F_SPLIT>), grid, dim3(256), 0, stream, a); \
-    else if (DPV == 64 && !((FL) & F_CAUSAL) && a.Sq > 32) fwd_lds64<((FL) & ~F_CAUSAL)>(a, grid, stream);         \
+    else if (DPV == 64 && use_lds64(a, (FL))) fwd_lds64<((FL) & ~F_CAUSAL)>(a, grid, stream);                       \
     else hipLaunchKernelGGL((attn_fwd_kernel<DPV, (FL)>), grid, dim3(256), 0, stream, a);                       \
     return mrblip_check_launch("attention_fwd");                                                               \
   }
@@ -1207,7 +1268,7 @@ static int launch_bwd(const AttnArgs& a, int flags, hipStream_t stream) {
 #define X(DPV, FL)                                                                                             \
   if (flags == (FL)) {                                                                                         \
     if (split && !((FL) & F_CAUSAL)) hipLaunchKernelGGL((attn_bwd_dq_kernel<DPV, ((FL) & ~F_CAUSAL) | F_SPLIT>), gq, dim3(256), 0, stream, a); \
-    else if (DPV == 64 && a.D == 64 && !((FL) & F_CAUSAL) && a.Sq > 32) dq_lds64<((FL) & ~F_CAUSAL)>(a, gq, stream);  \
+    else if (DPV == 64 && use_lds64(a, (FL))) dq_lds64<((FL) & ~F_CAUSAL)>(a, gq, stream);                          \
     else hipLaunchKernelGGL((attn_bwd_dq_kernel<DPV, (FL)>), gq, dim3(256), 0, stream, a);                      \
     if (DPV == 64 && a.D == 64 && a.Sq > 32) dkv_lds64<(FL)>(a, gk, stream);                                     \
     else hipLaunchKernelGGL((attn_bwd_dkv_kernel<DPV, (FL)>), gk, dim3(256), 0, stream, a);                     \
@@ -1224,8 +1285,9 @@ static int launch_bwd(const AttnArgs& a, int flags, hipStream_t stream) {
 extern "C" int mrblip_attention_fwd(const void* Q, const long long* q_strides, const void* K, const long long* k_strides,
                                     const void* Vt, void* O, const long long* o_strides, float* LSE, int B, int H, int Sq, int Sk,
                                     int D, float scale, const float* bias_lut, const int* kmask, int causal,
-                                    const uint32_t* seed_ptr, uint32_t site, float p_drop, hipStream_t stream) {
+                                    const uint32_t* seed_ptr, uint32_t site, float p_drop, uint32_t* drop_bits, hipStream_t stream) {
   AttnArgs a = {};
+  a.dbits = drop_bits;
   long long dummy[3] = {0, 0, 0};
   if (int e = attn_fill(a, Q, q_strides, K, k_strides, nullptr, dummy, B, H, Sq, Sk, D)) return e;
   const int DP = (D + 31) / 32 * 32, Skpad = a.Skpad;
@@ -1250,9 +1312,10 @@ extern "C" int mrblip_attention_bwd(const void* Q, const long long* q_strides, c
                                     const float* LSE, float* Delta, void* dQ, const long long* dq_strides, void* dK,
                                     const long long* dk_strides, void* dV, const long long* dv_strides, int B, int H, int Sq, int Sk,
                                     int D, float scale, const float* bias_lut, const int* kmask, int causal,
-                                    const uint32_t* seed_ptr, uint32_t site, float p_drop, hipStream_t stream) {
+                                    const uint32_t* seed_ptr, uint32_t site, float p_drop, const uint32_t* drop_bits, hipStream_t stream) {
   AttnArgs a = {};
   if (int e = attn_fill(a, Q, q_strides, K, k_strides, V, v_strides, B, H, Sq, Sk, D)) return e;
+  a.dbits = const_cast<uint32_t*>(drop_bits);
   MRB_REQUIRE(D <= 64, "attention_bwd: head_dim <= 64 only (the ViT is frozen, its attention needs no backward)");
   const int DP = (D + 31) / 32 * 32, Skpad = a.Skpad, Sqpad = a.Sqpad;
   a.O = T4{(const bf16_t*)O, o_strides[0], o_strides[1], o_strides[2]};

@@ -265,16 +265,23 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
 }
 
 // LoRA master weights (fp32 flat buffer: A [8,K], Bt [8,out] per adapter) -> bf16 GEMM operands, one launch for all
-// adapters via a device descriptor table of 8 int64 per adapter {a_off, bt_off, K, out, acat_off, wext_off, bblk_off, Ntot}:
+// adapters via a device descriptor table of 10 int64 per adapter {a_off, bt_off, K, out, acat_off, wext_off, bblk_off, Ntot, acatt_off, 0}:
 //   acat[acat_off + r*K + k]      = bf16(scale * A[r,k])        (stacked [8*nad, K] "down" operand of a group)
+//   acatt[acatt_off + k*64 + r]   = bf16(scale * A[r,k])        ([K, 64] transposed copy: K-extension operand of the dX GEMM)
 //   wext[wext_off + n*64 + r]     = bf16(Bt[r,n])               (K-extension operand of the forward GEMM)
 //   bblk[bblk_off + r*Ntot + n]   = bf16(scale * Bt[r,n])       (block-diagonal [8*nad, Ntot] operand of g = dy @ B)
 __global__ __launch_bounds__(256) void lora_pack_kernel(const float* __restrict__ flat, bf16_t* __restrict__ acat, bf16_t* __restrict__ wext,
-                                                        bf16_t* __restrict__ bblk, const long long* __restrict__ desc, float scale) {
-  const long long* d = desc + (long long)blockIdx.y * 8;
-  const long long a_off = d[0], bt_off = d[1], K = d[2], out = d[3], acat_off = d[4], wext_off = d[5], bblk_off = d[6], ntot = d[7];
+                                                        bf16_t* __restrict__ bblk, bf16_t* __restrict__ acatt, const long long* __restrict__ desc, float scale) {
+  const long long* d = desc + (long long)blockIdx.y * 10;
+  const long long a_off = d[0], bt_off = d[1], K = d[2], out = d[3], acat_off = d[4], wext_off = d[5], bblk_off = d[6], ntot = d[7], acatt_off = d[8];
   const long long stride = (long long)gridDim.x * 256, t0 = (long long)blockIdx.x * 256 + threadIdx.x;
   for (long long i = t0; i < 8 * K; i += stride) acat[acat_off + i] = f2bf(flat[a_off + i] * scale);
+  for (long long k = t0; k < K; k += stride) {
+    float v[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] = flat[a_off + r * K + k] * scale;
+    *reinterpret_cast<uint4*>(acatt + acatt_off + k * 64) = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+  }
   for (long long n = t0; n < out; n += stride) {
     float v[8];
 #pragma unroll
@@ -377,9 +384,10 @@ extern "C" int mrblip_colsum(const float* x, long long ldx, int M, int N, float*
   hipLaunchKernelGGL(colsum_kernel, dim3((N + 255) / 256, (M + rpb - 1) / rpb), dim3(256), 0, stream, x, ldx, M, N, rpb, out);
   return mrblip_check_launch("colsum");
 }
-extern "C" int mrblip_lora_pack(const float* flat, void* acat_bf16, void* wext_bf16, void* bblk_bf16, const long long* desc, int n_adapters,
-                                float scale, hipStream_t stream) {
+extern "C" int mrblip_lora_pack(const float* flat, void* acat_bf16, void* wext_bf16, void* bblk_bf16, void* acatt_bf16, const long long* desc,
+                                int n_adapters, float scale, hipStream_t stream) {
   MRB_REQUIRE(n_adapters > 0, "lora_pack: bad shape");
-  hipLaunchKernelGGL(lora_pack_kernel, dim3(16, n_adapters), dim3(256), 0, stream, flat, (bf16_t*)acat_bf16, (bf16_t*)wext_bf16, (bf16_t*)bblk_bf16, desc, scale);
+  hipLaunchKernelGGL(lora_pack_kernel, dim3(16, n_adapters), dim3(256), 0, stream, flat, (bf16_t*)acat_bf16, (bf16_t*)wext_bf16, (bf16_t*)bblk_bf16,
+                     (bf16_t*)acatt_bf16, desc, scale);
   return mrblip_check_launch("lora_pack");
 }

@@ -13,6 +13,7 @@
 // (A-operand = W tile, B-operand = X tile) so each lane owns one output row and 4 consecutive columns per
 // accumulator group -> 16-B (fp32) / 8-B (bf16) row-major stores.
 #include "common.h"
+#include <stdlib.h>
 
 struct GemmArgs {
   const bf16_t* A;
@@ -28,6 +29,11 @@ struct GemmArgs {
   int act;      // 0 none, 1 gelu(erf)
   int tiles_m, tiles_n;
   DropoutArg drop;
+  // LoRA backward form  out = A W^T + mask(ext_drop) * (Aext Wext^T):  the K-extension tile is taken FIRST and the accumulators
+  // (then holding only its product) are masked in registers before the main K loop adds to them
+  int ext_first;
+  DropoutArg ext_drop;
+  DropoutArg a_drop;  // skinny kernel only: dropout of the A operand as it is loaded (zeroing; the 1/(1-p) is applied to the result)
 };
 
 // v: 4 consecutive columns n0..n0+3 of row m (raw accumulator). Applies bias -> (pre-activation copy) -> GELU -> dropout -> residual.
@@ -215,11 +221,13 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_tile_kernel(const GemmArgs
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  stage(0, 0);
+  const bool ext_first = p.ext_first != 0;  // uniform
+  auto kmap = [&](int i) { return ext_first ? (i == 0 ? nk_main : i - 1) : i; };
+  stage(kmap(0), 0);
   for (int kt = 0; kt < nk; ++kt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
+    if (kt + 1 < nk) stage(kmap(kt + 1), (kt + 1) & 1);
     const char* base = smem + (kt & 1) * STAGE;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
@@ -234,6 +242,26 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_tile_kernel(const GemmArgs
 #pragma unroll
         for (int nt = 0; nt < TN; ++nt)
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nt], xf[mt], acc[mt][nt], 0, 0, 0);
+    }
+    if (!GATED && ext_first && kt == 0 && p.ext_drop.seed_ptr) {  // acc == Aext Wext^T: apply the LoRA input-dropout mask to it
+      const uint32_t seed = *p.ext_drop.seed_ptr;
+#pragma unroll
+      for (int mt = 0; mt < TM; ++mt) {
+        const uint32_t m = (uint32_t)(bm * BM + wm * (BM / WGM) + mt * 32 + l31);
+#pragma unroll
+        for (int nt = 0; nt < TN; ++nt)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const uint32_t n0 = (uint32_t)(bn * BN + wn * (BN / WGN) + nt * 32 + 8 * g + 4 * hi);
+#pragma unroll
+            for (int i = 0; i < 4; i += 2) {
+              bool k0, k1;
+              mrb_keep2(m * (uint32_t)p.N + n0 + i, seed, p.ext_drop.site, p.ext_drop.thresh24, k0, k1);
+              acc[mt][nt][4 * g + i] = k0 ? acc[mt][nt][4 * g + i] * p.ext_drop.inv_keep : 0.f;
+              acc[mt][nt][4 * g + i + 1] = k1 ? acc[mt][nt][4 * g + i + 1] * p.ext_drop.inv_keep : 0.f;
+            }
+          }
+      }
     }
   }
 
@@ -326,6 +354,25 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const GemmArgs p) {
         xf[u][s] = (m_ok && live) ? *reinterpret_cast<const bf16x8*>(xp + kb * 64 + s * 8) : zero;
       }
     }
+    if (p.a_drop.seed_ptr) {  // dropout(x) for the LoRA "down" product: element (m_row, k) of the [M, K] input, pair-hashed
+      const uint32_t seed = *p.a_drop.seed_ptr;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint32_t kbase = (uint32_t)m_row * (uint32_t)p.K + (uint32_t)(min(kb0 + u, kb_end - 1) * 64 + hi * 32);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          union { bf16x8 v; uint32_t d[4]; } f;
+          f.v = xf[u][s];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            bool k0, k1;
+            mrb_keep2(kbase + (uint32_t)(s * 8 + 2 * i), seed, p.a_drop.site, p.a_drop.thresh24, k0, k1);
+            f.d[i] = (k0 ? f.d[i] & 0xffffu : 0u) | (k1 ? f.d[i] & 0xffff0000u : 0u);
+          }
+          xf[u][s] = f.v;
+        }
+      }
+    }
 #pragma unroll
     for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -334,12 +381,31 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const GemmArgs p) {
   if (p.Aext && w == 3) {  // K-extension segment (one 64-wide block), taken by the last wave
     const bf16_t* wpe = p.Wext + (long long)n_row * p.ldwext + hi * 32;
     const bf16_t* xpe = p.Aext + (long long)m_row * p.ldaext + hi * 32;
+    f32x16 e;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) e[r] = 0.f;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const bf16x8 wf = n_ok ? *reinterpret_cast<const bf16x8*>(wpe + s * 8) : zero;
       const bf16x8 xf = m_ok ? *reinterpret_cast<const bf16x8*>(xpe + s * 8) : zero;
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, acc, 0, 0, 0);
+      e = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, e, 0, 0, 0);
     }
+    if (p.ext_first && p.ext_drop.seed_ptr) {  // LoRA backward form: mask the extension product (see GemmArgs)
+      const uint32_t seed = *p.ext_drop.seed_ptr;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const uint32_t n0 = (uint32_t)(blockIdx.x * 32 + 8 * g + 4 * hi);
+#pragma unroll
+        for (int i = 0; i < 4; i += 2) {
+          bool k0, k1;
+          mrb_keep2((uint32_t)m_row * (uint32_t)p.N + n0 + i, seed, p.ext_drop.site, p.ext_drop.thresh24, k0, k1);
+          e[4 * g + i] = k0 ? e[4 * g + i] * p.ext_drop.inv_keep : 0.f;
+          e[4 * g + i + 1] = k1 ? e[4 * g + i + 1] * p.ext_drop.inv_keep : 0.f;
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] += e[r];
   }
   if (w > 0) {
 #pragma unroll
@@ -349,6 +415,10 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const GemmArgs p) {
   if (w == 0) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] += red[0][r][lane] + red[1][r][lane] + red[2][r][lane];
+    if (p.a_drop.seed_ptr) {  // the kept inputs' 1/(1-p)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] *= p.a_drop.inv_keep;
+    }
     if (m_ok) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -395,11 +465,19 @@ static int launch_tile(GemmArgs& a, hipStream_t st) {
   return mrblip_check_launch("gemm_tile");
 }
 
-extern "C" int mrblip_gemm_bf16(const void* A, long long lda, const void* W, long long ldw, const void* Aext, long long ldaext,
-                                const void* Wext, long long ldwext, int M, int N, int K, void* out, long long ldo, int out_f32,
-                                void* out2, long long ldo2, const float* bias, const float* residual, long long ldr, int act,
-                                int gated, const uint32_t* seed_ptr, uint32_t site, float p_drop, int tile_cfg,
-                                hipStream_t stream) {
+static void mk_drop_arg(DropoutArg& d, const uint32_t* seed_ptr, uint32_t site, float p) {
+  d.seed_ptr = (p > 0.f) ? seed_ptr : nullptr;
+  d.site = site;
+  d.thresh24 = (uint32_t)(p * 65536.0f + 0.5f);
+  d.inv_keep = 1.0f / (1.0f - p);
+}
+
+// shared by the C entry points: validation, tile selection, launch.  ext_first / ext_* / a_* : see GemmArgs.
+static int gemm_dispatch(const void* A, long long lda, const void* W, long long ldw, const void* Aext, long long ldaext,
+                         const void* Wext, long long ldwext, int M, int N, int K, void* out, long long ldo, int out_f32,
+                         void* out2, long long ldo2, const float* bias, const float* residual, long long ldr, int act,
+                         int gated, const uint32_t* seed_ptr, uint32_t site, float p_drop, int tile_cfg, int ext_first,
+                         uint32_t ext_site, float ext_p, uint32_t a_site, float a_p, hipStream_t stream) {
   MRB_REQUIRE(M > 0 && N > 0 && K >= 0 && (K % 64) == 0, "gemm: need M,N>0 and K%%64==0 (M=%d N=%d K=%d)", M, N, K);
   MRB_REQUIRE(K > 0 || Aext, "gemm: empty contraction");
   MRB_REQUIRE((N % 8) == 0, "gemm: N %% 8 != 0 (N=%d)", N);
@@ -410,6 +488,11 @@ extern "C" int mrblip_gemm_bf16(const void* A, long long lda, const void* W, lon
               "gemm: operand exceeds the 4 GiB buffer-descriptor range");
   MRB_REQUIRE(!gated || (!out_f32 && !bias && !residual && act == 0 && (N % 16) == 0), "gemm: gated mode takes no bias/residual/act");
   GemmArgs a;
+  a.ext_first = ext_first;
+  mk_drop_arg(a.ext_drop, seed_ptr, ext_site, ext_p);
+  mk_drop_arg(a.a_drop, seed_ptr, a_site, a_p);
+  MRB_REQUIRE(!(ext_p > 0.f || a_p > 0.f) || seed_ptr, "gemm: dropout needs a device seed pointer");
+  MRB_REQUIRE(!ext_first || (Aext && !gated), "gemm: ext_first needs a K-extension and no gating");
   a.A = (const bf16_t*)A; a.W = (const bf16_t*)W; a.Aext = (const bf16_t*)Aext; a.Wext = (const bf16_t*)Wext;
   a.out = out; a.out2 = out2; a.bias = bias; a.residual = residual;
   a.lda = lda; a.ldw = ldw; a.ldaext = Aext ? ldaext : 0; a.ldwext = Wext ? ldwext : 0; a.ldo = ldo; a.ldo2 = ldo2; a.ldr = ldr;
@@ -448,6 +531,10 @@ extern "C" int mrblip_gemm_bf16(const void* A, long long lda, const void* W, lon
     if (gated) return launch_tile<256, 256, 2, 4, false, true>(a, stream);
     return out_f32 ? launch_tile<256, 256, 2, 4, true, false>(a, stream) : launch_tile<256, 256, 2, 4, false, false>(a, stream);
   }
+  if (cfg == 6) {
+    MRB_REQUIRE(!gated, "gemm: the 4-wave 256x256 tile has no gated epilogue");
+    return out_f32 ? launch_tile<256, 256, 2, 2, true, false>(a, stream) : launch_tile<256, 256, 2, 2, false, false>(a, stream);
+  }
   if (cfg == 4) {
     if (gated) return launch_tile<64, 128, 2, 2, false, true>(a, stream);
     return out_f32 ? launch_tile<64, 128, 2, 2, true, false>(a, stream) : launch_tile<64, 128, 2, 2, false, false>(a, stream);
@@ -458,6 +545,33 @@ extern "C" int mrblip_gemm_bf16(const void* A, long long lda, const void* W, lon
   }
   if (gated) return launch_tile<128, 128, 2, 2, false, true>(a, stream);
   return out_f32 ? launch_tile<128, 128, 2, 2, true, false>(a, stream) : launch_tile<128, 128, 2, 2, false, false>(a, stream);
+}
+
+extern "C" int mrblip_gemm_bf16(const void* A, long long lda, const void* W, long long ldw, const void* Aext, long long ldaext,
+                                const void* Wext, long long ldwext, int M, int N, int K, void* out, long long ldo, int out_f32,
+                                void* out2, long long ldo2, const float* bias, const float* residual, long long ldr, int act,
+                                int gated, const uint32_t* seed_ptr, uint32_t site, float p_drop, int tile_cfg,
+                                hipStream_t stream) {
+  return gemm_dispatch(A, lda, W, ldw, Aext, ldaext, Wext, ldwext, M, N, K, out, ldo, out_f32, out2, ldo2, bias, residual, ldr, act, gated,
+                       seed_ptr, site, p_drop, tile_cfg, 0, 0, 0.f, 0, 0.f, stream);
+}
+
+// LoRA "down" product with the input dropout fused into the operand load:  U[M, N] = dropout(X)[M, K] Acat[N, K]^T, bf16 out.
+// peft Linear.forward: lora_A(lora_dropout(x)).
+extern "C" int mrblip_gemm_lora_down(const void* X, long long ldx, const void* Acat, long long lda_, int M, int N, int K, void* U, long long ldu,
+                                     const uint32_t* seed_ptr, uint32_t site, float p_drop, hipStream_t stream) {
+  return gemm_dispatch(X, ldx, Acat, lda_, nullptr, 0, nullptr, 0, M, N, K, U, ldu, 0, nullptr, 0, nullptr, nullptr, 0, 0, 0, seed_ptr, 0, 0.f, 3,
+                       0, 0, 0.f, site, p_drop, stream);
+}
+
+// LoRA backward input gradient in one launch:  dX[M, N] = dY[M, K] Wt[N, K]^T (+ residual) + mask(site, p) * (G[M, 64] AcatT[N, 64]^T)
+// where mask is the lora_dropout keep mask of the forward input (scaled by 1/(1-p)), N = in_features, K = padded out_features.
+extern "C" int mrblip_gemm_lora_dx(const void* dY, long long lddy, const void* Wt, long long ldwt, const void* G, long long ldg,
+                                   const void* AcatT, long long ldat, int M, int N, int K, void* dX, long long lddx, int out_f32,
+                                   const float* residual, long long ldr, const uint32_t* seed_ptr, uint32_t site, float p_drop,
+                                   int tile_cfg, hipStream_t stream) {
+  return gemm_dispatch(dY, lddy, Wt, ldwt, G, ldg, AcatT, ldat, M, N, K, dX, lddx, out_f32, nullptr, 0, nullptr, residual, ldr, 0, 0, seed_ptr, 0,
+                       0.f, tile_cfg, 1, site, p_drop, 0, 0.f, stream);
 }
 
 // ---- thin "TN" product for the LoRA weight gradients:  D[r, c] += sum_m U[m, r] * drop(Y)[m, c],  r < 32, contraction over the
@@ -474,14 +588,19 @@ struct TnArgs {
   DropoutArg drop;
 };
 
-__global__ __launch_bounds__(512) void lora_tn_kernel(const TnArgs p) {
+struct TnArgs2 { TnArgs a, b; int blocks_a; };  // two independent problems in one launch (blocks [0, blocks_a) -> a, the rest -> b)
+
+__global__ __launch_bounds__(512) void lora_tn_kernel(const TnArgs2 q) {
+  const bool second = (int)blockIdx.x >= q.blocks_a;  // block-uniform
+  const TnArgs& p = second ? q.b : q.a;
+  const int bx = second ? blockIdx.x - q.blocks_a : blockIdx.x;
   // Each wave stages its own 16-row slices of Y (16 x 32 columns) and U (16 x 32) with ONE 16-B global load per lane each,
   // parks them in a wave-private LDS slot and gathers the k-major MFMA fragments from there with 2-byte LDS reads.
   constexpr int UNROLL = 2;
   __shared__ float red[7][16][64];
   __shared__ __attribute__((aligned(16))) bf16_t slot[8][UNROLL][2][16 * 32];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, hi = lane >> 5, l31 = lane & 31;
-  const int c0 = blockIdx.x * 32;
+  const int c0 = bx * 32;
   const int c = c0 + l31;
   const bool c_ok = c < p.C;
   const uint32_t seed = p.drop.seed_ptr ? *p.drop.seed_ptr : 0u;
@@ -547,21 +666,41 @@ __global__ __launch_bounds__(512) void lora_tn_kernel(const TnArgs p) {
   }
 }
 
+static int tn_fill(TnArgs& a, const void* Y, long long ldy, const void* U, long long ldu, int M, int C, int R, float* const* outs, const int* col0,
+                   const int* ncols, const long long* lds, const uint32_t* seed_ptr, uint32_t site, float p_drop) {
+  MRB_REQUIRE(M > 0 && C > 0 && R > 0 && R <= 32 && (R % 8) == 0, "lora_tn: bad shape (M=%d C=%d R=%d)", M, C, R);
+  MRB_REQUIRE((C % 8) == 0 && (ldy % 8) == 0 && (ldu % 8) == 0 && ((uintptr_t)Y % 16) == 0 && ((uintptr_t)U % 16) == 0, "lora_tn: 16-B alignment");
+  a.Y = (const bf16_t*)Y; a.U = (const bf16_t*)U; a.ldy = ldy; a.ldu = ldu; a.M = M; a.C = C; a.R = R;
+  for (int j = 0; j < 4; ++j) {
+    if (j < R / 8) a.seg[j] = TnSeg{outs[j], col0 ? col0[j] : 0, ncols ? ncols[j] : C, lds[j]};
+    else a.seg[j] = TnSeg{nullptr, 0, 0, 0};
+  }
+  mk_drop_arg(a.drop, seed_ptr, site, p_drop);
+  return MRBLIP_OK;
+}
+
 extern "C" int mrblip_lora_tn(const void* Y, long long ldy, const void* U, long long ldu, int M, int C, int R, float* const* outs,
                               const int* col0, const int* ncols, const long long* lds, const uint32_t* seed_ptr, uint32_t site, float p_drop,
                               hipStream_t stream) {
-  MRB_REQUIRE(M > 0 && C > 0 && R > 0 && R <= 32 && (R % 8) == 0, "lora_tn: bad shape (M=%d C=%d R=%d)", M, C, R);
-  MRB_REQUIRE((C % 8) == 0 && (ldy % 8) == 0 && (ldu % 8) == 0 && ((uintptr_t)Y % 16) == 0 && ((uintptr_t)U % 16) == 0, "lora_tn: 16-B alignment");
-  TnArgs a;
-  a.Y = (const bf16_t*)Y; a.U = (const bf16_t*)U; a.ldy = ldy; a.ldu = ldu; a.M = M; a.C = C; a.R = R;
-  for (int j = 0; j < 4; ++j) {
-    if (j < R / 8) a.seg[j] = TnSeg{outs[j], col0[j], ncols[j], lds[j]};
-    else a.seg[j] = TnSeg{nullptr, 0, 0, 0};
-  }
-  a.drop.seed_ptr = (p_drop > 0.f) ? seed_ptr : nullptr;
-  a.drop.site = site;
-  a.drop.thresh24 = (uint32_t)(p_drop * 65536.0f + 0.5f);
-  a.drop.inv_keep = 1.0f / (1.0f - p_drop);
-  hipLaunchKernelGGL(lora_tn_kernel, dim3((C + 31) / 32), dim3(512), 0, stream, a);
+  TnArgs2 q = {};
+  if (int e = tn_fill(q.a, Y, ldy, U, ldu, M, C, R, outs, col0, ncols, lds, seed_ptr, site, p_drop)) return e;
+  q.b = q.a;
+  q.blocks_a = (C + 31) / 32;
+  hipLaunchKernelGGL(lora_tn_kernel, dim3(q.blocks_a), dim3(512), 0, stream, q);
   return mrblip_check_launch("lora_tn");
+}
+
+// Both LoRA weight gradients of a fused group in ONE launch:
+//   dBt_j[r, c - col0_j] += sum_m U[m, 8j + r] dY[m, c]   (c in adapter j's output columns)      peft lora_B.weight.grad^T
+//   dA_j[r, k]           += sum_m G[m, 8j + r] dropout(X)[m, k]                                   peft lora_A.weight.grad
+extern "C" int mrblip_lora_grads(const void* dY, long long lddy, const void* U, long long ldu, const void* X, long long ldx, const void* G,
+                                 long long ldg, int M, int N, int K, int R, float* const* dBt, const int* b_col0, const int* b_ncols,
+                                 const long long* b_lds, float* const* dA, const long long* a_lds, const uint32_t* seed_ptr, uint32_t site,
+                                 float p_drop, hipStream_t stream) {
+  TnArgs2 q = {};
+  if (int e = tn_fill(q.a, dY, lddy, U, ldu, M, N, R, dBt, b_col0, b_ncols, b_lds, nullptr, 0, 0.f)) return e;
+  if (int e = tn_fill(q.b, X, ldx, G, ldg, M, K, R, dA, nullptr, nullptr, a_lds, seed_ptr, site, p_drop)) return e;
+  q.blocks_a = (N + 31) / 32;
+  hipLaunchKernelGGL(lora_tn_kernel, dim3(q.blocks_a + (K + 31) / 32), dim3(512), 0, stream, q);
+  return mrblip_check_launch("lora_grads");
 }

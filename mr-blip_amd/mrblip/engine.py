@@ -144,6 +144,7 @@ class LoraGroup:
     wext: torch.Tensor = None  # bf16 [N, 64] view: B (K-extension operand of the forward GEMM)
     acat: torch.Tensor = None  # bf16 [8*nad, K]: scale * A stacked ("down" operand)
     bblk: torch.Tensor = None  # bf16 [8*nad, N]: scale * B^T block-diagonal (operand of g = dy @ B)
+    acatt: torch.Tensor = None  # bf16 [K, 64]: (scale * A)^T, K-extension operand of the dX GEMM
     site: int = 0              # lora_dropout site (one mask per group input)
 
 
@@ -538,13 +539,15 @@ class MrBlipEngine:
         n_bblk = sum(8 * len(g.adapters) * g.N for g in groups)
         self.acat_all = torch.zeros(n_acat, dtype=bf16, device=self.dev)
         self.bblk_all = torch.zeros(n_bblk, dtype=bf16, device=self.dev)
-        wrow = aoff = boff = 0
+        self.acatt_all = torch.zeros(sum(g.K for g in groups), 64, dtype=bf16, device=self.dev)
+        wrow = aoff = boff = trow = 0
         gen = torch.Generator(device="cpu").manual_seed(4321)
         for g in groups:
             nad = len(g.adapters)
             g.wext = self.wext_all[wrow: wrow + g.N]
             g.acat = self.acat_all[aoff: aoff + 8 * nad * g.K].view(8 * nad, g.K)
             g.bblk = self.bblk_all[boff: boff + 8 * nad * g.N].view(8 * nad, g.N)
+            g.acatt = self.acatt_all[trow: trow + g.K]
             for j, a in enumerate(g.adapters):
                 a.a_off, a.bt_off = off, off + r * a.in_dim
                 a.A = self.flat[a.a_off: a.a_off + r * a.in_dim].view(r, a.in_dim)
@@ -553,7 +556,7 @@ class MrBlipEngine:
                 a.dBt = self.grad[a.bt_off: a.bt_off + r * a.out].view(r, a.out)
                 off += r * (a.in_dim + a.out)
                 desc.append([a.a_off, a.bt_off, a.in_dim, a.out, aoff + 8 * j * g.K, (wrow + a.row0) * 64 + a.col0,
-                             boff + 8 * j * g.N + a.row0, g.N])
+                             boff + 8 * j * g.N + a.row0, g.N, trow * 64 + 8 * j, 0])
                 ka, kb = t + "base_model.model." + a.name + ".lora_A.default.weight", t + "base_model.model." + a.name + ".lora_B.default.weight"
                 if isinstance(src, StateDictSource) and ka in src.sd:
                     a.A.copy_(src.sd[ka])
@@ -566,6 +569,7 @@ class MrBlipEngine:
             wrow += g.N
             aoff += 8 * nad * g.K
             boff += 8 * nad * g.N
+            trow += g.K
         self.adapters, self.groups = adapters, groups
         self.lora_desc = torch.tensor(desc, dtype=torch.int64, device=self.dev)
         # t5_proj / ln_vision (trainable)
@@ -598,7 +602,7 @@ class MrBlipEngine:
     def refresh_trainable(self):
         """Re-derive the bf16 operand copies of the trainable tensors (after init / optimizer step / checkpoint load)."""
         c = self.cfg
-        ops.lora_pack(self.flat, self.acat_all, self.wext_all, self.bblk_all, self.lora_desc, len(self.adapters), self.lora_scale)
+        ops.lora_pack(self.flat, self.acat_all, self.wext_all, self.bblk_all, self.acatt_all, self.lora_desc, len(self.adapters), self.lora_scale)
         ops.cast_dropout(self.proj_w, out_bf16=self.proj_wb)
         self.transpose2d(self.proj_wb, c.qf_dim, self.proj_wtb)
 
@@ -606,26 +610,19 @@ class MrBlipEngine:
     def lg_fwd(self, g: LoraGroup, x: torch.Tensor, u: torch.Tensor, out: torch.Tensor, **kw):
         """out = x W^T + u B^T with u = dropout(x) (scale*A)^T:  the rank-8 "down" product is a thin GEMM on the MFMA kernel,
         the "up" product rides in the main GEMM as a 64-wide K extension."""
-        drop = self.drop(g.site, self.cfg.lora_dropout)
-        src = x
-        if drop is not None:
-            src = self.buf(f"lg_xd_{x.shape[0]}_{x.shape[1]}", x.shape, bf16)
-            ops.dropout_bf16(x[:, : g.K], src, drop)
-        ops.gemm(src, g.acat, u, tile_cfg=3, K=g.K)
+        ops.lora_down(x, g.acat, u, g.K, drop=self.drop(g.site, self.cfg.lora_dropout))
         ops.gemm(x, g.W, out, aext=u, wext=g.wext, **kw)
 
     def lg_bwd(self, g: LoraGroup, dy: torch.Tensor, x: torch.Tensor, u: torch.Tensor, gbuf: torch.Tensor, dx: Optional[torch.Tensor],
                residual: Optional[torch.Tensor] = None):
         """dy bf16 [M,N]; x the saved bf16 input; u the saved [M,64] LoRA activations.  Accumulates dA, dB of every adapter of the
-        group and (optionally) dx = dy W (+ residual) + mask * (g A)."""
+        group (one launch) and (optionally) dx = dy W (+ residual) + mask * (g A) (one GEMM: the rank-8 term is its K-extension)."""
         drop = self.drop(g.site, self.cfg.lora_dropout)
         ops.gemm(dy, g.bblk, gbuf, tile_cfg=3, K=g.N)                      # g' = scale * dy @ B      [M, 8*nad]
         ads = g.adapters
-        ops.lora_tn(dy, u, [a.dBt for a in ads], [a.row0 for a in ads], [a.out for a in ads], [a.out for a in ads])       # dB^T += u^T dy
-        ops.lora_tn(x[:, : g.K], gbuf, [a.dA for a in ads], [0] * len(ads), [g.K] * len(ads), [g.K] * len(ads), drop=drop)  # dA += g^T drop(x)
+        ops.lora_grads(dy, u, x, gbuf, [a.dBt for a in ads], [a.row0 for a in ads], [a.out for a in ads], [a.dA for a in ads], g.K, drop=drop)
         if dx is not None:
-            ops.gemm(dy, g.Wt, dx, residual=residual, K=pad64(g.N))
-            ops.lora_dx_add(dx[:, : g.K], gbuf, g.acat, drop=drop)
+            ops.lora_dx(dy, g.Wt, gbuf, g.acatt, dx, pad64(g.N), residual=residual, drop=drop)
 
     # ---- encoder ---------------------------------------------------------------------------------------------
     @torch.no_grad()
@@ -648,7 +645,9 @@ class MrBlipEngine:
             ops.head_transpose(v4, out=vt)
             o = self.buf(f"e{i}_o", (M, pad64(inner)), bf16)
             lse = self.buf(f"e{i}_lse", (B, H, ops.rup32(S)), f32)
-            ops.attention_fwd(q4, k4, vt, self.v4(o, B, S, H, dk), lse, scale=1.0, bias_lut=self.lut_enc, kmask=kmask, drop=self.drop(L["sites"][0], p))
+            adrop = self.drop(L["sites"][0], p)
+            dbits = self.buf(f"e{i}_dbits", ops.drop_bits_shape(B, H, S, S), torch.int32, zero=False) if adrop is not None else None
+            ops.attention_fwd(q4, k4, vt, self.v4(o, B, S, H, dk), lse, scale=1.0, bias_lut=self.lut_enc, kmask=kmask, drop=adrop, drop_bits=dbits)
             uo = self.buf(f"e{i}_u_o", (M, 64), bf16)
             xm = self.buf(f"e{i}_xm", (M, d), f32, zero=False)
             self.lg_fwd(L["o"], o, uo, xm, residual=x, drop=self.drop(L["sites"][1], p))
@@ -712,7 +711,8 @@ class MrBlipEngine:
             ops.head_transpose(do4, out=dot)
             ops.attention_bwd(q4, k4, v4, self.v4(o, B, S, H, dk), do4, kt, qt, dot, self.ws[f"e{i}_lse"], delta,
                               self.v4(dqkv, B, S, H, dk, 0), self.v4(dqkv, B, S, H, dk, inner), self.v4(dqkv, B, S, H, dk, 2 * inner),
-                              scale=1.0, bias_lut=self.lut_enc, kmask=kmask, drop=self.drop(L["sites"][0], p))
+                              scale=1.0, bias_lut=self.lut_enc, kmask=kmask, drop=self.drop(L["sites"][0], p),
+                              drop_bits=self.ws.get(f"e{i}_dbits") if self.drop(L["sites"][0], p) is not None else None)
             self.lg_bwd(L["qkv"], dqkv, self.ws[f"e{i}_xn"], self.ws[f"e{i}_u_qkv"], gb, dxn)
             ops.rmsnorm_bwd(dxn, self.ws[f"e{i}_xin"], L["ln0"], c.t5_eps, other, dx_add=dx)
             dx, other = other, dx
@@ -902,7 +902,9 @@ class MrBlipEngine:
         n = 1 if c.mean_pool else c.num_query
         if self.training:
             ops.seed_bump(self.seed)
+        self._mark("start")
         fr, img, xv, qb = self.frames_forward(video)
+        self._mark("frames_forward (ViT + ln_vision + Q-Former + t5_proj)")
         dev = self.dev
         L = self._layout_dev(layout)
         inp = self.buf("inputs_embeds", (Bv * S, d), f32, zero=False)
@@ -910,12 +912,16 @@ class MrBlipEngine:
         ops.row_copy(self.emb, L["emb_src"], inp, L["emb_dst"])
         kmask = L["mask"]
         enc = self.t5_encoder_forward(inp, Bv, S, kmask)
+        self._mark("t5_encoder_forward")
         loss, logits = self.t5_decoder_forward(layout.decoder_input_ids, layout.decoder_mask, enc, Bv, S, kmask, layout.labels, want_grad=backward)
+        self._mark("t5_decoder_forward + loss")
         if not backward:
             return loss
         Ld = layout.labels.shape[1]
         denc = self.t5_decoder_backward(enc, Bv, S, Ld, kmask, layout.decoder_mask)
+        self._mark("t5_decoder_backward")
         dinp = self.t5_encoder_backward(denc, Bv, S, kmask)
+        self._mark("t5_encoder_backward")
         # interleave backward: only frame-token rows carry gradient (embeddings are frozen)
         dfr = self.buf("dframes", (F_ * n, d), f32)
         ops.row_copy(dinp, L["frame_dst"], dfr, L["frame_src"])
@@ -939,7 +945,16 @@ class MrBlipEngine:
         ops.gemm(dfb, self.proj_wtb, dq_last, K=pad64(d))
         dimg = self.qformer_backward(dq_last, img, F_)
         ops.layernorm_bwd(dimg, xv, self.lnv_w, self.ln_vision_eps, None, dgamma=self.dlnv_w, dbeta=self.dlnv_b)
+        self._mark("t5_proj + Q-Former backward")
         return loss
+
+    def _mark(self, name: str):
+        """phase boundary for tools/phase_times.py (self.phase_events = [] enables it; None = off)"""
+        ev = getattr(self, "phase_events", None)
+        if ev is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            ev.append((name, e))
 
     def _layout_dev(self, layout: EncoderLayout):
         dev = self.dev

@@ -47,13 +47,16 @@ _ln_fwd = _sig("mrblip_layernorm_fwd", vp, ll, vp, vp, i32, i32, f32, vp, ll, vp
 _rms_fwd = _sig("mrblip_rmsnorm_fwd", vp, ll, vp, i32, i32, f32, vp, ll, vp, ll, vp)
 _ln_bwd = _sig("mrblip_layernorm_bwd", vp, ll, vp, ll, vp, i32, i32, f32, vp, ll, vp, ll, vp, vp, vp)
 _rms_bwd = _sig("mrblip_rmsnorm_bwd", vp, ll, vp, ll, vp, i32, i32, f32, vp, ll, vp, ll, vp)
-_attn_fwd = _sig("mrblip_attention_fwd", vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp, vp, i32, vp, u32, f32, vp)
+_attn_fwd = _sig("mrblip_attention_fwd", vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp, vp, i32, vp, u32, f32, vp, vp)
 _attn_bwd = _sig("mrblip_attention_bwd", vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
-                 i32, i32, i32, i32, i32, f32, vp, vp, i32, vp, u32, f32, vp)
+                 i32, i32, i32, i32, i32, f32, vp, vp, i32, vp, u32, f32, vp, vp)
 _head_t = _sig("mrblip_head_transpose", vp, vp, vp, i32, i32, i32, i32, i32, vp, u32, f32, vp)
 _colsum = _sig("mrblip_colsum", vp, ll, i32, i32, vp, vp)
 _lora_tn = _sig("mrblip_lora_tn", vp, ll, vp, ll, i32, i32, i32, vp, vp, vp, vp, vp, u32, f32, vp)
-_lora_pack = _sig("mrblip_lora_pack", vp, vp, vp, vp, vp, i32, f32, vp)
+_lora_pack = _sig("mrblip_lora_pack", vp, vp, vp, vp, vp, vp, i32, f32, vp)
+_lora_grads = _sig("mrblip_lora_grads", vp, ll, vp, ll, vp, ll, vp, ll, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, u32, f32, vp)
+_lora_down = _sig("mrblip_gemm_lora_down", vp, ll, vp, ll, i32, i32, i32, vp, ll, vp, u32, f32, vp)
+_gemm_lora_dx = _sig("mrblip_gemm_lora_dx", vp, ll, vp, ll, vp, ll, vp, ll, i32, i32, i32, vp, ll, i32, vp, ll, vp, u32, f32, i32, vp)
 _drop_b16 = _sig("mrblip_dropout_bf16", vp, ll, vp, ll, i32, i32, vp, u32, f32, vp)
 _patchify = _sig("mrblip_patchify", vp, vp, i32, i32, i32, i32, vp)
 _vit_asm = _sig("mrblip_vit_assemble", vp, vp, vp, vp, i32, i32, i32, vp)
@@ -74,6 +77,7 @@ EXPORTS = [
     "mrblip_patchify", "mrblip_vit_assemble", "mrblip_row_copy", "mrblip_mean_pool", "mrblip_mean_pool_bwd",
     "mrblip_cast_dropout", "mrblip_gelu_bwd", "mrblip_gated_gelu_bwd", "mrblip_cross_entropy", "mrblip_adamw",
     "mrblip_seed_bump", "mrblip_lora_dx_add", "mrblip_dropout_bf16", "mrblip_colsum", "mrblip_lora_pack", "mrblip_lora_tn",
+    "mrblip_lora_grads", "mrblip_gemm_lora_down", "mrblip_gemm_lora_dx",
 ]
 
 
@@ -188,8 +192,34 @@ def lora_tn(Y, U, outs, col0, ncols, lds, drop: Optional[Dropout] = None):
                   (ll * n)(*lds), sp, site, p, _stream()))
 
 
-def lora_pack(flat, acat, wext, bblk, desc, n_adapters, scale=1.0):
-    _chk(_lora_pack(_p(flat), _p(acat), _p(wext), _p(bblk), _p(desc), n_adapters, scale, _stream()))
+def lora_pack(flat, acat, wext, bblk, acatt, desc, n_adapters, scale=1.0):
+    _chk(_lora_pack(_p(flat), _p(acat), _p(wext), _p(bblk), _p(acatt), _p(desc), n_adapters, scale, _stream()))
+
+
+def lora_grads(dy, u, x, g, dBt, b_col0, b_ncols, dA, K, drop: Optional[Dropout] = None):
+    """both weight gradients of a fused LoRA group in one launch: dBt[j] += u_j^T dy[:, cols_j], dA[j] += g_j^T dropout(x[:, :K])"""
+    M, N = dy.shape
+    n = len(dBt)
+    sp, site, p = _d(drop)
+    _chk(_lora_grads(_p(dy), _ld(dy), _p(u), _ld(u), _p(x), _ld(x), _p(g), _ld(g), M, N, K, 8 * n,
+                     (vp * n)(*[o.data_ptr() for o in dBt]), (i32 * n)(*b_col0), (i32 * n)(*b_ncols), (ll * n)(*b_ncols),
+                     (vp * n)(*[o.data_ptr() for o in dA]), (ll * n)(*([K] * n)), sp, site, p, _stream()))
+
+
+def lora_down(x, acat, u, K, drop: Optional[Dropout] = None):
+    """u[:, :R] = dropout(x[:, :K]) @ acat^T  (acat: bf16 [R, K]); dropout fused into the operand load"""
+    M = x.shape[0]
+    sp, site, p = _d(drop)
+    _chk(_lora_down(_p(x), _ld(x), _p(acat), _ld(acat), M, acat.shape[0], K, _p(u), _ld(u), sp, site, p, _stream()))
+
+
+def lora_dx(dy, wt, g, acatt, dx, K, residual=None, drop: Optional[Dropout] = None, tile_cfg=0):
+    """dx = dy[:, :K] @ wt^T (+ residual) + mask(drop) * (g @ acatt^T);  wt: bf16 [N_in, >=K], acatt: bf16 [N_in, 64]"""
+    M = dy.shape[0]
+    N = wt.shape[0]
+    sp, site, p = _d(drop)
+    _chk(_gemm_lora_dx(_p(dy), _ld(dy), _p(wt), _ld(wt), _p(g), _ld(g), _p(acatt), _ld(acatt), M, N, K, _p(dx), _ld(dx),
+                  1 if dx.dtype == torch.float32 else 0, _p(residual), _ld(residual) if residual is not None else 0, sp, site, p, tile_cfg, _stream()))
 
 
 def dropout_bf16(x, out, drop: Optional[Dropout] = None):
@@ -198,23 +228,29 @@ def dropout_bf16(x, out, drop: Optional[Dropout] = None):
     _chk(_drop_b16(_p(x), _ld(x), _p(out), _ld(out), M, N, sp, site, p, _stream()))
 
 
-def attention_fwd(q, k, vt, o, lse=None, *, scale=1.0, bias_lut=None, kmask=None, causal=False, drop: Optional[Dropout] = None):
+def drop_bits_shape(B, H, Sq, Sk):
+    """shape of the uint32 (int32 tensor) scratch carrying the attention-dropout keep mask from forward to backward"""
+    return (B * H, rup32(Sk) // 32, rup32(Sq))
+
+
+def attention_fwd(q, k, vt, o, lse=None, *, scale=1.0, bias_lut=None, kmask=None, causal=False, drop: Optional[Dropout] = None,
+                  drop_bits=None):
     """q,o: [B,Sq,H,D] views; k: [B,Sk,H,D] view; vt: head_transpose(v); lse: [B,H,rup32(Sq)] fp32."""
     B, Sq, H, D = q.shape
     Sk = k.shape[1]
     sp, site, p = _d(drop)
     _chk(_attn_fwd(_p(q), _strides3(q), _p(k), _strides3(k), _p(vt), _p(o), _strides3(o), _p(lse), B, H, Sq, Sk, D, scale,
-                   _p(bias_lut), _p(kmask), 1 if causal else 0, sp, site, p, _stream()))
+                   _p(bias_lut), _p(kmask), 1 if causal else 0, sp, site, p, _p(drop_bits), _stream()))
 
 
 def attention_bwd(q, k, v, o, do, kt, qt, dot, lse, delta, dq, dk, dv, *, scale=1.0, bias_lut=None, kmask=None, causal=False,
-                  drop: Optional[Dropout] = None):
+                  drop: Optional[Dropout] = None, drop_bits=None):
     B, Sq, H, D = q.shape
     Sk = k.shape[1]
     sp, site, p = _d(drop)
     _chk(_attn_bwd(_p(q), _strides3(q), _p(k), _strides3(k), _p(v), _strides3(v), _p(o), _strides3(o), _p(do), _strides3(do),
                    _p(kt), _p(qt), _p(dot), _p(lse), _p(delta), _p(dq), _strides3(dq), _p(dk), _strides3(dk), _p(dv), _strides3(dv),
-                   B, H, Sq, Sk, D, scale, _p(bias_lut), _p(kmask), 1 if causal else 0, sp, site, p, _stream()))
+                   B, H, Sq, Sk, D, scale, _p(bias_lut), _p(kmask), 1 if causal else 0, sp, site, p, _p(drop_bits), _stream()))
 
 
 # ------------------------------------------------------------------------------------------------ side kernels

@@ -211,6 +211,46 @@ def test_attention_bias_mask_dropout_fwd_bwd(ops, causal, B, H, Sq, Sk, D):
     assert rel(dv.float().permute(0, 2, 1, 3), vr.grad) < 1.5e-2
 
 
+@pytest.mark.parametrize("use_bits", [False, True])
+@pytest.mark.parametrize("use_lut", [False, True])
+@pytest.mark.parametrize("B,H,Sq,Sk,D", [(1, 3, 300, 300, 64), (2, 2, 257, 190, 64), (1, 2, 70, 333, 64)])
+def test_attention_lds_path_dropout_bits(ops, use_bits, use_lut, B, H, Sq, Sk, D):
+    """T5-encoder form (no key mask -> interior tiles take the check-free path; several 64-key stages; ragged tails), with the
+    dropout keep mask either re-hashed in the backward or carried forward->backward in the drop_bits scratch."""
+    torch.manual_seed(7)
+    p = 0.1
+    q = bf(torch.randn(B, Sq, H, D, device=dev()) * 0.5)
+    k = bf(torch.randn(B, Sk, H, D, device=dev()) * 0.5)
+    v = bf(torch.randn(B, Sk, H, D, device=dev()))
+    do = bf(torch.randn(B, Sq, H, D, device=dev()))
+    lut = torch.randn(H, 257, device=dev()) if use_lut else None
+    seed = torch.tensor([977], dtype=torch.int32, device=dev())
+    drop = ops.Dropout(seed, 5, p)
+    bits = torch.full(ops.drop_bits_shape(B, H, Sq, Sk), 0x55555555, dtype=torch.int32, device=dev()) if use_bits else None
+    vt = ops.head_transpose(v)
+    o = torch.empty_like(q)
+    lse = torch.zeros(B, H, ops.rup32(Sq), device=dev())
+    ops.attention_fwd(q, k, vt, o, lse, scale=1.0, bias_lut=lut, drop=drop, drop_bits=bits)
+    qr, kr, vr = (t.float().permute(0, 2, 1, 3).clone().requires_grad_(True) for t in (q, k, v))
+    bias = _lut_bias(lut, Sq, Sk)[None] if use_lut else None
+    from oracle.mrblip_oracle import dropout_keep_attn
+    dmask = dropout_keep_attn(B, H, Sq, Sk, 977, 5, p).to(dev())
+    ref, _ = _attn_ref(qr, kr, vr, 1.0, bias, None, dmask, p)
+    assert rel(o.float().permute(0, 2, 1, 3), ref) < 6e-3
+    if use_bits:  # the stored words are exactly the oracle's keep mask
+        w = bits.view(B, H, ops.rup32(Sk) // 32, ops.rup32(Sq))
+        got = ((w[:, :, :, :Sq, None] >> torch.arange(32, device=dev())) & 1).permute(0, 1, 3, 2, 4).reshape(B, H, Sq, -1)[..., :Sk]
+        assert torch.equal(got.bool(), dmask.bool())
+    ref.backward(do.float().permute(0, 2, 1, 3))
+    kt, qt, dot = ops.head_transpose(k), ops.head_transpose(q), ops.head_transpose(do)
+    delta = torch.zeros_like(lse)
+    dq, dk, dv = torch.zeros_like(q), torch.zeros_like(k), torch.zeros_like(v)
+    ops.attention_bwd(q, k, v, o, do, kt, qt, dot, lse, delta, dq, dk, dv, scale=1.0, bias_lut=lut, drop=drop, drop_bits=bits)
+    assert rel(dq.float().permute(0, 2, 1, 3), qr.grad) < 1.5e-2
+    assert rel(dk.float().permute(0, 2, 1, 3), kr.grad) < 1.5e-2
+    assert rel(dv.float().permute(0, 2, 1, 3), vr.grad) < 1.5e-2
+
+
 def test_attention_strided_qkv_buffer(ops):
     """ViT/T5 layout: q, k, v are column slices of one [B*S, 3*H*D] GEMM output."""
     torch.manual_seed(6)
@@ -336,9 +376,11 @@ def test_lora_pieces(ops):
     acat = torch.zeros(16 * K, dtype=torch.bfloat16, device=dev())
     wext = torch.zeros(Ntot * 64, dtype=torch.bfloat16, device=dev())
     bblk = torch.zeros(16 * Ntot, dtype=torch.bfloat16, device=dev())
-    desc = torch.tensor([[0, 8 * K, K, out_, 8 * K, row0 * 64 + col0, 8 * Ntot + row0, Ntot]], dtype=torch.int64, device=dev())
-    ops.lora_pack(flat, acat, wext, bblk, desc, 1, scale=2.0)
+    acatt = torch.zeros(K, 64, dtype=torch.bfloat16, device=dev())
+    desc = torch.tensor([[0, 8 * K, K, out_, 8 * K, row0 * 64 + col0, 8 * Ntot + row0, Ntot, 8, 0]], dtype=torch.int64, device=dev())
+    ops.lora_pack(flat, acat, wext, bblk, acatt, desc, 1, scale=2.0)
     Af, Bt = flat[: 8 * K].view(8, K), flat[8 * K:].view(8, out_)
+    assert torch.equal(acatt[:, 8:16], (Af * 2).bfloat16().t()) and acatt[:, :8].abs().sum() == 0 and acatt[:, 16:].abs().sum() == 0
     assert torch.equal(acat.view(16, K)[8:], (Af * 2).bfloat16()) and acat.view(16, K)[:8].abs().sum() == 0
     assert torch.equal(wext.view(Ntot, 64)[row0: row0 + out_, col0: col0 + 8], Bt.t().bfloat16())
     assert torch.equal(bblk.view(16, Ntot)[8:, row0: row0 + out_], (Bt * 2).bfloat16())
@@ -352,6 +394,51 @@ def test_lora_pieces(ops):
     dW = torch.ones(8, K, device=dev())
     ops.gemm(uT[8:16], xt, dW, residual=dW, tile_cfg=3, K=Mp)
     assert rel(dW, 1 + u[:, 8:16].float().t() @ ref.float()) < 1e-5
+
+
+@pytest.mark.parametrize("M", [12, 333])
+def test_lora_fused_launches(ops, M):
+    """The one-launch forms of the LoRA side products against their definitions (same masks as the separate kernels):
+    u = dropout(x) Acat^T, dx = dy Wt^T + residual + mask * (g AcatT^T) on the tile and the skinny kernel, and both weight gradients."""
+    torch.manual_seed(12)
+    K, N, p = 256, 320, 0.05       # in_features, out_features
+    x = bf(torch.randn(M, K, device=dev()))
+    seed = torch.tensor([55], dtype=torch.int32, device=dev())
+    drop = ops.Dropout(seed, 9, p)
+    mask = keep_mask((M, K), 55, 9, p)
+    acat = bf(torch.randn(24, K, device=dev()) * 0.1)
+    # down
+    u = torch.zeros(M, 64, dtype=torch.bfloat16, device=dev())
+    ops.lora_down(x, acat, u, K, drop=drop)
+    want = (x.float() * mask) @ acat.float().t() / (1 - p)
+    assert rel(u[:, :24].float(), want) < 4e-3 and u[:, 24:].abs().sum() == 0
+    ops.lora_down(x, acat, u, K)
+    assert rel(u[:, :24].float(), x.float() @ acat.float().t()) < 4e-3
+    # dx
+    dy = bf(torch.randn(M, N, device=dev()))
+    wt = bf(torch.randn(K, N, device=dev()) * 0.1)             # [in, out]
+    g = torch.zeros(M, 64, dtype=torch.bfloat16, device=dev())
+    g[:, :24] = bf(torch.randn(M, 24, device=dev()))
+    acatt = torch.zeros(K, 64, dtype=torch.bfloat16, device=dev())
+    acatt[:, :24] = acat.t()
+    res = torch.randn(M, K, device=dev())
+    want = dy.float() @ wt.float().t() + res + (g[:, :24].float() @ acat.float()) * mask / (1 - p)
+    for cfg in ([3] if M <= 64 else [2, 4, 5, 1]):
+        dx = torch.full((M, K), float("nan"), device=dev())
+        ops.lora_dx(dy, wt, g, acatt, dx, N, residual=res, drop=drop, tile_cfg=cfg)
+        assert rel(dx, want) < 1e-5, cfg
+        dxb = torch.zeros(M, K, dtype=torch.bfloat16, device=dev())
+        ops.lora_dx(dy, wt, g, acatt, dxb, N, drop=None, tile_cfg=cfg)
+        assert rel(dxb.float(), dy.float() @ wt.float().t() + g[:, :24].float() @ acat.float()) < 4e-3, cfg
+    # both weight gradients, one launch
+    outs_, col0 = [128, 64, 128], [0, 128, 192]
+    dB = [torch.ones(8, o, device=dev()) for o in outs_]
+    dA = [torch.ones(8, K, device=dev()) for _ in range(3)]
+    ops.lora_grads(dy, u, x, g, dB, col0, outs_, dA, K, drop=drop)
+    xd = (x.float() * mask / (1 - p)).bfloat16().float()
+    for j, o in enumerate(outs_):
+        assert rel(dB[j], 1 + u[:, 8 * j: 8 * j + 8].float().t() @ dy[:, col0[j]: col0[j] + o].float()) < 1e-5, j
+        assert rel(dA[j], 1 + g[:, 8 * j: 8 * j + 8].float().t() @ xd) < 1e-5, j
 
 
 def test_lora_tn_weight_gradients(ops):

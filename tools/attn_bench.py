@@ -30,12 +30,13 @@ for name, B, H, Sq, Sk, D, lut_on, drop_on, causal in [
     drop = ops.Dropout(seed, 3, 0.1) if drop_on else None
     vt = ops.head_transpose(v)
     scale = 1.0 if D == 64 else D ** -0.5
-    t = timeit(lambda: ops.attention_fwd(q, k, vt, o, lse, scale=scale, bias_lut=lut, kmask=kmask, causal=causal, drop=drop))
+    dbits = torch.empty(ops.drop_bits_shape(B, H, Sq, Sk), dtype=torch.int32, device=dev) if (drop_on and os.environ.get("NO_DBITS") is None) else None
+    t = timeit(lambda: ops.attention_fwd(q, k, vt, o, lse, scale=scale, bias_lut=lut, kmask=kmask, causal=causal, drop=drop, drop_bits=dbits))
     fl = 4.0 * B * H * Sq * Sk * D
     row = dict(name=name, fwd_us=round(t * 1e6, 1), fwd_TF=round(fl / t / 1e12, 1))
     if D <= 64:
         kt, qt, dot = ops.head_transpose(k), ops.head_transpose(q), ops.head_transpose(do)
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
-        t = timeit(lambda: ops.attention_bwd(q, k, v, o, do, kt, qt, dot, lse, delta, dq, dk, dv, scale=scale, bias_lut=lut, kmask=kmask, causal=causal, drop=drop))
+        t = timeit(lambda: ops.attention_bwd(q, k, v, o, do, kt, qt, dot, lse, delta, dq, dk, dv, scale=scale, bias_lut=lut, kmask=kmask, causal=causal, drop=drop, drop_bits=dbits))
         row.update(bwd_us=round(t * 1e6, 1), bwd_TF=round(2.5 * fl / t / 1e12, 1))
     print(json.dumps(row), flush=True)

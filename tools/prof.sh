@@ -6,4 +6,5 @@ cd $GRAFT_REPO_ROOT
 DB=$(find gpurun_out/prof -name "*.db" | head -1)
 python tools/prof_summary.py $DB gpurun_out/prof_summary.txt 0.0 > /dev/null
 python tools/prof_summary.py $DB gpurun_out/prof_summary_grid.txt 0.0 grid > /dev/null
+python tools/prof_gaps.py $DB 0.5 > gpurun_out/prof_gaps.txt
 rm -rf gpurun_out/prof
