@@ -113,13 +113,19 @@ __device__ __forceinline__ void epilogue_gated8(const GemmArgs& p, int m, int n0
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-template <int BM, int BN, int WGM, int WGN, bool OUT_F32, bool GATED>
-__global__ __launch_bounds__(WGM* WGN * 64) void gemm_tile_kernel(const GemmArgs p) {
+// BK = k extent of one LDS stage (64: 128-B rows, 8 chunks; 32: 64-B rows, 4 chunks), NS = stages in the ring (2, or 3 for the
+// non-persistent BK = 32 form: prefetch distance two K-tiles with a counted vmcnt wait — the main loop holds only LDS-DMA loads,
+// which retire in order).
+template <int BM, int BN, int WGM, int WGN, bool OUT_F32, bool GATED, int BK = 64, int NS = 2>
+__global__ __launch_bounds__(WGM* WGN * 64, (NS * (BM + BN) * BK * 2 <= 80 * 1024 && WGM * WGN <= 4) ? 2 : 1) void gemm_tile_kernel(const GemmArgs p) {
   constexpr int NW = WGM * WGN;
   constexpr int TM = BM / WGM / 32;  // 32x32 tiles per wave along M
   constexpr int TN = BN / WGN / 32;
-  constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, STAGE = A_BYTES + W_BYTES;
-  constexpr int JA = BM / 8 / NW, JW = BN / 8 / NW;  // LDS-DMA instructions per wave per operand tile
+  constexpr int RB = BK * 2, CPR = BK / 8, RPI = 64 / CPR;  // LDS row bytes, 16-B chunks per row, rows per LDS-DMA instruction
+  constexpr int KK = BK / 16, NEXT = 64 / BK;                // MFMA k-steps per stage, stages of the 64-wide K extension
+  constexpr int A_BYTES = BM * RB, W_BYTES = BN * RB, STAGE = A_BYTES + W_BYTES;
+  constexpr int JA = BM / RPI / NW, JW = BN / RPI / NW;  // LDS-DMA instructions per wave per operand tile
+  static_assert(BK == 64 || BK == 32, "BK");
   static_assert(!GATED || TN == 2, "gated epilogue pairs the wave's two n-tiles");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -133,71 +139,60 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_tile_kernel(const GemmArgs
   const int Nh = p.N >> 1;                    // GATED only
   constexpr int BNO = GATED ? BN / 2 : BN;  // output columns per block
 
-  // ---- buffer resources (bounds-checked: rows >= M / >= N read as zero, never fault)
-  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)(uint32_t)((long long)p.M * p.lda * 2), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, (int)(uint32_t)((long long)p.N * p.ldw * 2), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rAe = __builtin_amdgcn_make_buffer_rsrc((void*)p.Aext, 0, (int)(uint32_t)((long long)p.M * p.ldaext * 2), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rWe = __builtin_amdgcn_make_buffer_rsrc((void*)p.Wext, 0, (int)(uint32_t)((long long)p.N * p.ldwext * 2), 0x00020000);
+  // ---- operands are read through bounds-checked buffer resources (built in stage()): rows >= M / >= N read as zero, never fault
 
-  // per-lane source offset inside one 8-row LDS-DMA piece: row (lane>>3), swizzled 16-B chunk
-  const int prow = lane >> 3;
-  const int chunk = (lane & 7) ^ ((w * 4 + (lane >> 4)) & 7);  // == (lane&7) ^ ((tile_row>>1)&7)
+  // per-lane source offset inside one LDS-DMA piece (RPI rows): row lane / CPR, swizzled 16-B chunk
+  //   BK = 64: chunk ^= (tile_row >> 1) & 7  == (w*4 + (lane>>4)) & 7        BK = 32: chunk ^= (tile_row >> 2) & 3 == (lane >> 4) & 3
+  const int prow = lane / CPR;
+  const int chunk = BK == 64 ? ((lane & 7) ^ ((w * 4 + (lane >> 4)) & 7)) : ((lane & 3) ^ ((lane >> 4) & 3));
   const uint32_t vA = (uint32_t)((long long)prow * p.lda * 2) + chunk * 16;
   const uint32_t vW = (uint32_t)((long long)prow * p.ldw * 2) + chunk * 16;
   const uint32_t vAe = (uint32_t)((long long)prow * p.ldaext * 2) + chunk * 16;
   const uint32_t vWe = (uint32_t)((long long)prow * p.ldwext * 2) + chunk * 16;
 
-  const int nk_main = p.K >> 6;
-  const int nk = nk_main + (p.Aext ? 1 : 0);
+  const int nk_main = p.K / BK;
+  const int nk = nk_main + (p.Aext ? NEXT : 0);
 
-  auto w_row_base = [&](int j) -> int {  // global W row of tile row (j*NW + w)*8
-    const int tr = (j * NW + w) * 8;
+  auto w_row_base = [&](int j) __attribute__((always_inline)) -> int {  // global W row of tile row (j*NW + w)*RPI
+    const int tr = (j * NW + w) * RPI;
     if (GATED) return (tr < BN / 2) ? bn * BNO + tr : Nh + bn * BNO + (tr - BN / 2);
     return bn * BN + tr;
   };
 
-  auto stage = [&](int kt, int buf) {
+  auto stage = [&](int kt, int buf) __attribute__((always_inline)) {
     char* base = smem + buf * STAGE;
+    // main segment or K extension: everything that differs is selected as a plain scalar / vector VALUE (uniform condition) and the
+    // buffer resources are rebuilt from the selected base pointers — selecting between the resource objects themselves would force
+    // them (and the offsets) through scratch memory, and a scratch reload between two LDS-DMA loads serialises them on vmcnt.
     const bool ext = kt >= nk_main;
-    if (!ext) {
-      const uint32_t koff = (uint32_t)kt * 128u;
+    const long long ld_a = ext ? p.ldaext : p.lda, ld_w = ext ? p.ldwext : p.ldw;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(ext ? p.Aext : p.A), 0, (int)(uint32_t)((long long)p.M * ld_a * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)(ext ? p.Wext : p.W), 0, (int)(uint32_t)((long long)p.N * ld_w * 2), 0x00020000);
+    const uint32_t va = ext ? vAe : vA, vw = ext ? vWe : vW;
+    const uint32_t koff = (uint32_t)(ext ? kt - nk_main : kt) * (uint32_t)RB;
 #pragma unroll
-      for (int j = 0; j < JA; ++j) {
-        const int tr = (j * NW + w) * 8;
-        const uint32_t so = (uint32_t)((long long)(bm * BM + tr) * p.lda * 2) + koff;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr_t)(base + tr * 128), 16, vA, so, 0, 0);
-      }
+    for (int j = 0; j < JA; ++j) {
+      const int tr = (j * NW + w) * RPI;
+      const uint32_t so = (uint32_t)((long long)(bm * BM + tr) * ld_a * 2) + koff;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr_t)(base + tr * RB), 16, va, so, 0, 0);
+    }
 #pragma unroll
-      for (int j = 0; j < JW; ++j) {
-        const int tr = (j * NW + w) * 8;
-        const uint32_t so = (uint32_t)((long long)w_row_base(j) * p.ldw * 2) + koff;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lds_ptr_t)(base + A_BYTES + tr * 128), 16, vW, so, 0, 0);
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < JA; ++j) {
-        const int tr = (j * NW + w) * 8;
-        const uint32_t so = (uint32_t)((long long)(bm * BM + tr) * p.ldaext * 2);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rAe, (lds_ptr_t)(base + tr * 128), 16, vAe, so, 0, 0);
-      }
-#pragma unroll
-      for (int j = 0; j < JW; ++j) {
-        const int tr = (j * NW + w) * 8;
-        const uint32_t so = (uint32_t)((long long)w_row_base(j) * p.ldwext * 2);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rWe, (lds_ptr_t)(base + A_BYTES + tr * 128), 16, vWe, so, 0, 0);
-      }
+    for (int j = 0; j < JW; ++j) {
+      const int tr = (j * NW + w) * RPI;
+      const uint32_t so = (uint32_t)((long long)w_row_base(j) * ld_w * 2) + koff;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(base + A_BYTES + tr * RB), 16, vw, so, 0, 0);
     }
   };
 
   f32x16 acc[TM][TN];
 
   // fragment read offsets (bytes) inside a stage
-  const int swz = (lane >> 1) & 7;
-  const int a_row_off = (wm * (BM / WGM) + l31) * 128;
+  const int swz = BK == 64 ? ((lane >> 1) & 7) : ((lane >> 2) & 3);
+  const int a_row_off = (wm * (BM / WGM) + l31) * RB;
   int w_row_off[TN];
 #pragma unroll
   for (int nt = 0; nt < TN; ++nt)
-    w_row_off[nt] = A_BYTES + (GATED ? (nt * (BN / 2) + wn * 32 + l31) : (wn * (BN / WGN) + nt * 32 + l31)) * 128;
+    w_row_off[nt] = A_BYTES + (GATED ? (nt * (BN / 2) + wn * 32 + l31) : (wn * (BN / WGN) + nt * 32 + l31)) * RB;
 
   // ---- persistent tile loop: grid = resident blocks; a block's epilogue stores drain while it already stages the next tile
   const int ntiles = p.tiles_m * p.tiles_n;
@@ -222,19 +217,22 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_tile_kernel(const GemmArgs
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const bool ext_first = p.ext_first != 0;  // uniform
-  auto kmap = [&](int i) { return ext_first ? (i == 0 ? nk_main : i - 1) : i; };
+  auto kmap = [&](int i) __attribute__((always_inline)) { return ext_first ? (i < NEXT ? nk_main + i : i - NEXT) : i; };
   stage(kmap(0), 0);
+  if (NS == 3 && 1 < nk) stage(kmap(1), 1);
   for (int kt = 0; kt < nk; ++kt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // stage kt must have landed; with a 3-deep ring the newest stage (issued one iteration ago) may still be in flight
+    if (NS == 3 && kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(JA + JW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (kt + 1 < nk) stage(kmap(kt + 1), (kt + 1) & 1);
-    const char* base = smem + (kt & 1) * STAGE;
+    if (kt + NS - 1 < nk) stage(kmap(kt + NS - 1), (kt + NS - 1) % NS);
+    const char* base = smem + (kt % NS) * STAGE;
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
+    for (int kk = 0; kk < KK; ++kk) {
       const int coff = (((kk * 2 + hi) ^ swz) << 4);
       bf16x8 xf[TM], wf[TN];
 #pragma unroll
-      for (int mt = 0; mt < TM; ++mt) xf[mt] = *reinterpret_cast<const bf16x8*>(base + a_row_off + mt * 32 * 128 + coff);
+      for (int mt = 0; mt < TM; ++mt) xf[mt] = *reinterpret_cast<const bf16x8*>(base + a_row_off + mt * 32 * RB + coff);
 #pragma unroll
       for (int nt = 0; nt < TN; ++nt) wf[nt] = *reinterpret_cast<const bf16x8*>(base + w_row_off[nt] + coff);
 #pragma unroll
@@ -243,7 +241,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_tile_kernel(const GemmArgs
         for (int nt = 0; nt < TN; ++nt)
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nt], xf[mt], acc[mt][nt], 0, 0, 0);
     }
-    if (!GATED && ext_first && kt == 0 && p.ext_drop.seed_ptr) {  // acc == Aext Wext^T: apply the LoRA input-dropout mask to it
+    if (!GATED && ext_first && kt == NEXT - 1 && p.ext_drop.seed_ptr) {  // acc == Aext Wext^T: apply the LoRA input-dropout mask to it
       const uint32_t seed = *p.ext_drop.seed_ptr;
 #pragma unroll
       for (int mt = 0; mt < TM; ++mt) {
@@ -272,7 +270,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_tile_kernel(const GemmArgs
   constexpr int SLAB_COLS = TN * 32;
   constexpr int RS = SLAB_COLS * 4 + 16;          // bytes per slab row
   constexpr int CPR = SLAB_COLS / 4;               // 16-B chunks per row
-  static_assert(32 * RS * NW <= 2 * STAGE, "epilogue slabs must fit in the staging buffers");
+  static_assert(32 * RS * NW <= NS * STAGE, "epilogue slabs must fit in the staging buffers");
   __syncthreads();                                 // every wave is done reading the staging buffers
   char* slab = smem + w * (32 * RS);
   const int ncols = GATED ? Nh : p.N;
@@ -322,9 +320,9 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_tile_kernel(const GemmArgs
 // columns x 32 rows; its 4 waves split K, each lane streams 64 contiguous bytes of one W row per 64-wide k block
 // (the contraction order inside a k block is permuted identically for W and X so both load 16-B vectors from full
 // 128-B lines), partial sums are reduced through LDS.
-template <bool OUT_F32>
-__global__ __launch_bounds__(256) void gemm_skinny_kernel(const GemmArgs p) {
-  __shared__ float red[3][16][64];
+template <bool OUT_F32, int NW>
+__global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const GemmArgs p) {
+  __shared__ float red[NW - 1][16][64];
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int hi = lane >> 5, l31 = lane & 31;
@@ -338,8 +336,8 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const GemmArgs p) {
   const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
   const bf16_t* wp = p.W + (long long)n_row * p.ldw + hi * 32;
   const bf16_t* xp = p.A + (long long)m_row * p.lda + hi * 32;
-  // each wave owns a contiguous quarter of the k blocks; 4 blocks (32 independent 16-B loads per lane) are in flight at a time
-  const int per = (nkb + 3) >> 2;
+  // each of the NW waves owns a contiguous share of the k blocks; 4 blocks (32 independent 16-B loads per lane) are in flight at a time
+  const int per = (nkb + NW - 1) / NW;
   const int kb_beg = w * per, kb_end = min(nkb, kb_beg + per);
 #pragma unroll 1
   for (int kb0 = kb_beg; kb0 < kb_end; kb0 += 4) {
@@ -378,7 +376,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const GemmArgs p) {
 #pragma unroll
       for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[u][s], xf[u][s], acc, 0, 0, 0);
   }
-  if (p.Aext && w == 3) {  // K-extension segment (one 64-wide block), taken by the last wave
+  if (p.Aext && w == NW - 1) {  // K-extension segment (one 64-wide block), taken by the last wave
     const bf16_t* wpe = p.Wext + (long long)n_row * p.ldwext + hi * 32;
     const bf16_t* xpe = p.Aext + (long long)m_row * p.ldaext + hi * 32;
     f32x16 e;
@@ -414,7 +412,10 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const GemmArgs p) {
   __syncthreads();
   if (w == 0) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] += red[0][r][lane] + red[1][r][lane] + red[2][r][lane];
+    for (int r = 0; r < 16; ++r) {
+#pragma unroll
+      for (int j = 0; j < NW - 1; ++j) acc[r] += red[j][r][lane];
+    }
     if (p.a_drop.seed_ptr) {  // the kept inputs' 1/(1-p)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] *= p.a_drop.inv_keep;
@@ -434,14 +435,14 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const GemmArgs p) {
   }
 }
 
-template <int BM, int BN, int WGM, int WGN, bool OUT_F32, bool GATED>
+template <int BM, int BN, int WGM, int WGN, bool OUT_F32, bool GATED, int BK = 64, int NS = 2>
 static int launch_tile(GemmArgs& a, hipStream_t st) {
   constexpr int BNO = GATED ? BN / 2 : BN;
   const int ncols = GATED ? a.N / 2 : a.N;
   a.tiles_m = (a.M + BM - 1) / BM;
   a.tiles_n = (ncols + BNO - 1) / BNO;
-  constexpr int LDS = 2 * (BM + BN) * 128;
-  auto kern = gemm_tile_kernel<BM, BN, WGM, WGN, OUT_F32, GATED>;
+  constexpr int LDS = NS * (BM + BN) * BK * 2;
+  auto kern = gemm_tile_kernel<BM, BN, WGM, WGN, OUT_F32, GATED, BK, NS>;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
@@ -460,7 +461,7 @@ static int launch_tile(GemmArgs& a, hipStream_t st) {
   // 256x256 (one block per CU): persistent, one block per CU walks the tiles.  128x128: one block per tile (the hardware's dynamic
   // dispatch of 2 blocks/CU measured slightly faster than a static persistent walk).
   const int ntiles = a.tiles_m * a.tiles_n;
-  const int grid = (LDS > 80 * 1024 && ntiles > num_cu) ? num_cu : ntiles;
+  const int grid = (NS == 2 && LDS > 80 * 1024 && ntiles > num_cu) ? num_cu : ntiles;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(WGM * WGN * 64), LDS, st, a);
   return mrblip_check_launch("gemm_tile");
 }
@@ -523,8 +524,10 @@ static int gemm_dispatch(const void* A, long long lda, const void* W, long long 
   if (cfg == 3) {
     MRB_REQUIRE(!gated, "gemm: skinny kernel has no gated epilogue");
     dim3 grid((N + 31) / 32, (M + 31) / 32);
-    if (out_f32) hipLaunchKernelGGL(gemm_skinny_kernel<true>, grid, dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL(gemm_skinny_kernel<false>, grid, dim3(256), 0, stream, a);
+    // (a 16-wave K-split was measured 2x SLOWER at every decoder shape: these launches are bound by their fixed cost, not by one
+    // wave's load chain)
+    if (out_f32) hipLaunchKernelGGL((gemm_skinny_kernel<true, 4>), grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((gemm_skinny_kernel<false, 4>), grid, dim3(256), 0, stream, a);
     return mrblip_check_launch("gemm_skinny");
   }
   if (cfg == 1) {
@@ -534,6 +537,10 @@ static int gemm_dispatch(const void* A, long long lda, const void* W, long long 
   if (cfg == 6) {
     MRB_REQUIRE(!gated, "gemm: the 4-wave 256x256 tile has no gated epilogue");
     return out_f32 ? launch_tile<256, 256, 2, 2, true, false>(a, stream) : launch_tile<256, 256, 2, 2, false, false>(a, stream);
+  }
+  if (cfg == 7) {  // 256x128 tile, 4 waves of 128x64, BK = 32, 3-stage ring (72 KB): two blocks per CU at 0.75 KB of LDS reads per MFMA
+    if (gated) return launch_tile<256, 128, 2, 2, false, true, 32, 3>(a, stream);
+    return out_f32 ? launch_tile<256, 128, 2, 2, true, false, 32, 3>(a, stream) : launch_tile<256, 128, 2, 2, false, false, 32, 3>(a, stream);
   }
   if (cfg == 4) {
     if (gated) return launch_tile<64, 128, 2, 2, false, true>(a, stream);
