@@ -323,6 +323,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, (NS * (BM + BN) * BK * 2 <= 80 * 102
 template <bool OUT_F32, int NW>
 __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const GemmArgs p) {
   __shared__ float red[NW - 1][16][64];
+  constexpr int UNR = NW > 4 ? 2 : 4;  // k blocks in flight per wave (16 waves x 64 lanes leave 128 VGPRs per lane)
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int hi = lane >> 5, l31 = lane & 31;
@@ -336,14 +337,14 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const GemmArgs p) 
   const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
   const bf16_t* wp = p.W + (long long)n_row * p.ldw + hi * 32;
   const bf16_t* xp = p.A + (long long)m_row * p.lda + hi * 32;
-  // each of the NW waves owns a contiguous share of the k blocks; 4 blocks (32 independent 16-B loads per lane) are in flight at a time
+  // each of the NW waves owns a contiguous share of the k blocks; UNR blocks (8 independent 16-B loads per lane each) are in flight
   const int per = (nkb + NW - 1) / NW;
   const int kb_beg = w * per, kb_end = min(nkb, kb_beg + per);
 #pragma unroll 1
-  for (int kb0 = kb_beg; kb0 < kb_end; kb0 += 4) {
-    bf16x8 wf[4][4], xf[4][4];
+  for (int kb0 = kb_beg; kb0 < kb_end; kb0 += UNR) {
+    bf16x8 wf[UNR][4], xf[UNR][4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < UNR; ++u) {
       const int kb = min(kb0 + u, kb_end - 1);
       const bool live = kb0 + u < kb_end;
 #pragma unroll
@@ -355,7 +356,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const GemmArgs p) 
     if (p.a_drop.seed_ptr) {  // dropout(x) for the LoRA "down" product: element (m_row, k) of the [M, K] input, pair-hashed
       const uint32_t seed = *p.a_drop.seed_ptr;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < UNR; ++u) {
         const uint32_t kbase = (uint32_t)m_row * (uint32_t)p.K + (uint32_t)(min(kb0 + u, kb_end - 1) * 64 + hi * 32);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -372,7 +373,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const GemmArgs p) 
       }
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < UNR; ++u)
 #pragma unroll
       for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[u][s], xf[u][s], acc, 0, 0, 0);
   }
@@ -515,7 +516,9 @@ static int gemm_dispatch(const void* A, long long lda, const void* W, long long 
       const long long t256 = (long long)((M + 255) / 256) * ((ncols + (gated ? 127 : 255)) / (gated ? 128 : 256));
       const long long t128 = (long long)((M + 127) / 128) * ((ncols + (gated ? 63 : 127)) / (gated ? 64 : 128));
       const long long t64x128 = (long long)((M + 63) / 64) * ((ncols + (gated ? 63 : 127)) / (gated ? 64 : 128));
-      if (t256 >= 512 && K >= 4096) cfg = 1;
+      static int c1_t = -1, c1_k = -1;
+      if (c1_t < 0) { const char* e = getenv("MRB_CFG1_T256"); c1_t = e ? atoi(e) : 512; const char* f = getenv("MRB_CFG1_K"); c1_k = f ? atoi(f) : 4096; }
+      if (t256 >= c1_t && K >= c1_k) cfg = 1;
       else if (t128 >= 400) cfg = 2;
       else if (t64x128 >= 400 || gated) cfg = 4;
       else cfg = 5;
@@ -524,8 +527,8 @@ static int gemm_dispatch(const void* A, long long lda, const void* W, long long 
   if (cfg == 3) {
     MRB_REQUIRE(!gated, "gemm: skinny kernel has no gated epilogue");
     dim3 grid((N + 31) / 32, (M + 31) / 32);
-    // (a 16-wave K-split was measured 2x SLOWER at every decoder shape: these launches are bound by their fixed cost, not by one
-    // wave's load chain)
+    // (a 16-wave K-split changes nothing here: with one lane per operand row these launches are bound by the number of row-gather
+    // load instructions one CU's address unit can retire, not by a wave's sequential load rounds)
     if (out_f32) hipLaunchKernelGGL((gemm_skinny_kernel<true, 4>), grid, dim3(256), 0, stream, a);
     else hipLaunchKernelGGL((gemm_skinny_kernel<false, 4>), grid, dim3(256), 0, stream, a);
     return mrblip_check_launch("gemm_skinny");
