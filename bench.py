@@ -163,11 +163,15 @@ def main():
         durs = [s.elapsed_time(e) * 1e-3 for s, e in probe_events]
         F_ = min(B * wl["T"], eng.vit_chunk)
         m, n, k = F_ * 257, cfg.vit_mlp, cfg.vit_dim
+        traffic = None  # HBM-side bytes per launch of the same kernel from the committed PMC pass (tools/pmc_fc1.sh), QVH B=1 shape only
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_fc1.json")
+        if os.path.exists(pmc) and args.workload == "qvh" and B == 1 and F_ == 60:
+            traffic = json.load(open(pmc)).get("traffic_bytes_per_launch")
         if durs:
             avg = sum(durs) / len(durs)
             ach = 2.0 * m * n * k / avg / 1e12
             roof = dict(bound="mfma", achieved=round(ach, 1), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_BF16_TFLOPS, 4),
-                        traffic=None, kernel="gemm_tile_kernel (ViT fc1 %dx%dx%d)" % (m, n, k), launches=len(durs), avg_us=round(avg * 1e6, 1))
+                        traffic=traffic, kernel="gemm_tile_kernel (ViT fc1 %dx%dx%d)" % (m, n, k), launches=len(durs), avg_us=round(avg * 1e6, 1))
         else:
             roof = None
         out = {

@@ -117,7 +117,11 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 // non-persistent BK = 32 form: prefetch distance two K-tiles with a counted vmcnt wait — the main loop holds only LDS-DMA loads,
 // which retire in order).
 template <int BM, int BN, int WGM, int WGN, bool OUT_F32, bool GATED, int BK = 64, int NS = 2>
-__global__ __launch_bounds__(WGM* WGN * 64, (NS * (BM + BN) * BK * 2 <= 80 * 1024 && WGM * WGN <= 4) ? 2 : 1) void gemm_tile_kernel(const GemmArgs p) {
+__global__ __launch_bounds__(WGM* WGN * 64, (WGM * WGN > 4)                              ? 1
+                                             : (NS * (BM + BN) * BK * 2 <= 40 * 1024) ? 4
+                                             : (NS * (BM + BN) * BK * 2 <= 53 * 1024) ? 3
+                                             : (NS * (BM + BN) * BK * 2 <= 80 * 1024) ? 2
+                                                                                      : 1) void gemm_tile_kernel(const GemmArgs p) {
   constexpr int NW = WGM * WGN;
   constexpr int TM = BM / WGM / 32;  // 32x32 tiles per wave along M
   constexpr int TN = BN / WGN / 32;
@@ -270,7 +274,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, (NS * (BM + BN) * BK * 2 <= 80 * 102
   constexpr int SLAB_COLS = TN * 32;
   constexpr int RS = SLAB_COLS * 4 + 16;          // bytes per slab row
   constexpr int CPR = SLAB_COLS / 4;               // 16-B chunks per row
-  static_assert(32 * RS * NW <= NS * STAGE, "epilogue slabs must fit in the staging buffers");
+  // (the launcher allocates max(NS * STAGE, 32 * RS * NW) bytes of dynamic LDS)
   __syncthreads();                                 // every wave is done reading the staging buffers
   char* slab = smem + w * (32 * RS);
   const int ncols = GATED ? Nh : p.N;
@@ -442,7 +446,8 @@ static int launch_tile(GemmArgs& a, hipStream_t st) {
   const int ncols = GATED ? a.N / 2 : a.N;
   a.tiles_m = (a.M + BM - 1) / BM;
   a.tiles_n = (ncols + BNO - 1) / BNO;
-  constexpr int LDS = NS * (BM + BN) * BK * 2;
+  constexpr int TN_ = BN / WGN / 32, SLAB = 32 * (TN_ * 32 * 4 + 16) * WGM * WGN;   // epilogue staging (see the kernel)
+  constexpr int LDS = NS * (BM + BN) * BK * 2 > SLAB ? NS * (BM + BN) * BK * 2 : SLAB;
   auto kern = gemm_tile_kernel<BM, BN, WGM, WGN, OUT_F32, GATED, BK, NS>;
   static bool attr_set = false;
   if (!attr_set) {
@@ -504,7 +509,9 @@ static int gemm_dispatch(const void* A, long long lda, const void* W, long long 
   a.drop.thresh24 = (uint32_t)(p_drop * 65536.0f + 0.5f);
   a.drop.inv_keep = 1.0f / (1.0f - p_drop);
   MRB_REQUIRE(!(p_drop > 0.f) || seed_ptr, "gemm: dropout needs a device seed pointer");
-  // tile_cfg: 0 auto, 1 = 256x256, 2 = 128x128, 3 = skinny, 4 = 64x128, 5 = 64x64
+  // tile_cfg: 0 auto, 1 = 256x256 (8 waves, persistent), 2 = 128x128, 3 = skinny, 4 = 64x128, 5 = 64x64; measured and not auto-selected:
+  // 6 = 256x256 with 4 waves of 128x128 (1 wave/SIMD: 0.7x), 7 = 256x128 BK=32 3-stage (= 128x128), [128x128 BK=32 at 3-4 blocks/CU: 0.8x,
+  // 256x128 / 128x256 BK=64 with one 4-wave block per CU: 0.6x]
   int cfg = tile_cfg;
   if (cfg == 0) {
     if (M <= 64 && !gated) cfg = 3;
