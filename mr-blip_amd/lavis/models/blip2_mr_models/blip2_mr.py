@@ -24,10 +24,10 @@ class _TrainStep(torch.autograd.Function):
     """forward = whole HIP train step (loss AND gradients); backward = hand the flat gradients to autograd."""
 
     @staticmethod
-    def forward(ctx, decay, no_decay, model, video, layout, need_grad):
+    def forward(ctx, decay, no_decay, model, video, layout, need_grad, next_video=None):
         eng = model.engine  # (grad mode is always off inside Function.forward, hence the explicit flag)
         eng.zero_grad()
-        loss = eng.forward_backward(video, layout, backward=need_grad)
+        loss = eng.forward_backward(video, layout, backward=need_grad, next_video=next_video)
         ctx.eng = eng
         return loss.clone().reshape(())
 
@@ -35,7 +35,7 @@ class _TrainStep(torch.autograd.Function):
     def backward(ctx, g):
         eng = ctx.eng
         nd = eng.n_decay
-        return eng.grad[:nd] * g, eng.grad[nd:] * g, None, None, None, None
+        return eng.grad[:nd] * g, eng.grad[nd:] * g, None, None, None, None, None
 
 
 @registry.register_model("blip2_mr")
@@ -111,11 +111,25 @@ class BLIP2_MR(BaseModel):
         return P.build_layout(self.t5_tokenizer, samples, self.annoying_numbers_replacement_dict, n, T, self.max_txt_len,
                               no_task_prompt="no_task_prompt" in self.task)
 
+    _staged_next = None  # (host tensor of the next batch's frames, its device copy): see forward()
+
     def forward(self, samples):
-        video = samples["video"].to(self._device, torch.float32)
+        """samples: the reference's dict (blip2_mr.py:433-445).  Optional extra key ``next_video``: the NEXT batch's frames (the train
+        loop's one-batch look-ahead, tasks/moment_retrieval.py); its frozen-ViT forward is overlapped with this step's T5 decoder."""
+        src = samples["video"]
+        if self._staged_next is not None and self._staged_next[0] is src:
+            video = self._staged_next[1]  # the device copy whose ViT features were prefetched during the previous step
+        else:
+            video = src.to(self._device, torch.float32)
+        self._staged_next = None
         layout = self._layout(samples)
         need_grad = torch.is_grad_enabled() and (self.trainable_decay.requires_grad or self.trainable_no_decay.requires_grad)
-        loss = _TrainStep.apply(self.trainable_decay, self.trainable_no_decay, self, video, layout, need_grad)
+        nxt = samples.get("next_video") if need_grad else None
+        nxt_dev = None
+        if nxt is not None:
+            nxt_dev = nxt.to(self._device, torch.float32)
+            self._staged_next = (nxt, nxt_dev)
+        loss = _TrainStep.apply(self.trainable_decay, self.trainable_no_decay, self, video, layout, need_grad, nxt_dev)
         return {"loss": loss}
 
     @torch.no_grad()

@@ -20,6 +20,19 @@ def temporal_iou(a, b):
     return inter / union if union > 0 else 0.0
 
 
+def _with_next(it):
+    """(item, next item or None) pairs of an iterable"""
+    it = iter(it)
+    try:
+        cur = next(it)
+    except StopIteration:
+        return
+    for nxt in it:
+        yield cur, nxt
+        cur = nxt
+    yield cur, None
+
+
 @registry.register_task("moment_retrieval")
 class MomentRetrievalTask(BaseTask):
     def valid_step(self, model, samples):
@@ -61,8 +74,10 @@ class MomentRetrievalTask(BaseTask):
         iters_per_epoch = len(data_loader)
         model.train()
         optimizer.zero_grad()
-        for i, samples in enumerate(metric_logger.log_every(data_loader, log_freq, f"Train: data epoch: [{epoch}]")):
+        for i, (samples, nxt) in enumerate(_with_next(metric_logger.log_every(data_loader, log_freq, f"Train: data epoch: [{epoch}]"))):
             samples.update({"epoch": epoch, "num_iters_per_epoch": iters_per_epoch, "iters": i})
+            if nxt is not None:  # one-batch look-ahead: the model overlaps the next clip's frozen-ViT forward with this step's decoder
+                samples["next_video"] = nxt["video"]
             lr_scheduler.step(cur_epoch=epoch, cur_step=i)
             loss = self.train_step(model=model, samples=samples)
             (loss / accum_grad_iters).backward()

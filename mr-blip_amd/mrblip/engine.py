@@ -231,21 +231,23 @@ class MrBlipEngine:
             ))
 
     @torch.no_grad()
-    def vit_forward(self, video: torch.Tensor, n_blocks: Optional[int] = None) -> torch.Tensor:
+    def vit_forward(self, video: torch.Tensor, n_blocks: Optional[int] = None, slot: int = 0, blocks: Optional[tuple] = None) -> torch.Tensor:
         """video fp32 [F,3,IMG,IMG] -> fp32 [F*(NP+1), D] (no final norm, eva_vit.py:324-340).  No activations are kept (the ViT is
         frozen and its output needs no gradient).  Frames are independent through the ViT; ``vit_chunk`` optionally processes them in
         groups (measured on MI355X: one pass over all frames is fastest — larger GEMMs beat Infinity-Cache residency)."""
         c = self.cfg
         F_ = video.shape[0]
         T = (c.img // c.patch) ** 2 + 1
-        x_all = self.buf("vit_x", (F_ * T, c.vit_dim), f32, zero=False)
+        x_all = self.buf("vit_x" if slot == 0 else f"vit_x{slot}", (F_ * T, c.vit_dim), f32, zero=False)
         chunk = max(1, min(F_, self.vit_chunk))
         for f0 in range(0, F_, chunk):
             f1 = min(F_, f0 + chunk)
-            self._vit_chunk(video[f0:f1], x_all[f0 * T: f1 * T], n_blocks)
+            self._vit_chunk(video[f0:f1], x_all[f0 * T: f1 * T], n_blocks, blocks)
         return x_all
 
-    def _vit_chunk(self, video: torch.Tensor, x: torch.Tensor, n_blocks: Optional[int]):
+    def _vit_chunk(self, video: torch.Tensor, x: torch.Tensor, n_blocks: Optional[int], blocks: Optional[tuple] = None):
+        """blocks = (b0, b1): run only transformer blocks b0..b1-1 on the residual stream already in ``x`` (b0 > 0 skips the patch
+        embedding) — the look-ahead runs a prefix of the ViT beside the decoder and the next step finishes it."""
         c, v = self.cfg, self.vit
         F_ = video.shape[0]
         G = c.img // c.patch
@@ -254,11 +256,13 @@ class MrBlipEngine:
         T = NP + 1
         M = F_ * T
         tag = f"_{F_}"
-        patches = self.buf("vit_patches" + tag, (F_ * NP, self.vit_kpad), bf16, zero=False)
-        ops.patchify(video, patches, c.patch)
-        pe = self.buf("vit_pe" + tag, (F_ * NP, D), f32, zero=False)
-        ops.gemm(patches, v["pe_w"], pe, bias=v["pe_b"])
-        ops.vit_assemble(pe, v["cls"], v["pos"], x.view(F_, T, D))
+        b0, b1 = blocks if blocks is not None else (0, c.vit_depth if n_blocks is None else n_blocks)
+        if b0 == 0:
+            patches = self.buf("vit_patches" + tag, (F_ * NP, self.vit_kpad), bf16, zero=False)
+            ops.patchify(video, patches, c.patch)
+            pe = self.buf("vit_pe" + tag, (F_ * NP, D), f32, zero=False)
+            ops.gemm(patches, v["pe_w"], pe, bias=v["pe_b"])
+            ops.vit_assemble(pe, v["cls"], v["pos"], x.view(F_, T, D))
         h = self.buf("vit_h" + tag, (M, pad64(D)), bf16)
         qkv = self.buf("vit_qkv" + tag, (M, 3 * D), bf16, zero=False)
         o = self.buf("vit_o" + tag, (M, pad64(D)), bf16)
@@ -268,7 +272,7 @@ class MrBlipEngine:
         o4 = self.v4(o, F_, T, H, hd)
         scale = hd ** -0.5
         probe = getattr(self, "probe", None)
-        for blk in v["blocks"][: (c.vit_depth if n_blocks is None else n_blocks)]:
+        for blk in v["blocks"][b0:b1]:
             ops.layernorm_fwd(x, blk["n1w"], blk["n1b"], 1e-6, out_bf16=h)
             ops.gemm(h, blk["qkv_w"], qkv, bias=blk["qkv_b"])
             ops.head_transpose(v4, out=vt)
@@ -880,7 +884,9 @@ class MrBlipEngine:
         Bv, T = video.shape[:2]
         F_ = Bv * T
         Tv = (c.img // c.patch) ** 2 + 1
-        xv = self.vit_forward(video.reshape(F_, 3, c.img, c.img))
+        xv = self._take_prefetched_vit(video)
+        if xv is None:
+            xv = self.vit_forward(video.reshape(F_, 3, c.img, c.img), slot=self._vit_slot)
         img = self.buf("img", (F_ * Tv, pad64(c.vit_dim)), bf16)
         ops.layernorm_fwd(xv, self.lnv_w, self.lnv_b, self.ln_vision_eps, out_bf16=img)
         qb = self.qformer_forward(img, F_)
@@ -892,9 +898,59 @@ class MrBlipEngine:
             return pooled, img, xv, qb
         return fr, img, xv, qb
 
+    # ---- frozen-ViT look-ahead.  The ViT is frozen (freeze_vit: True), so its forward of the NEXT clip depends on nothing this
+    # step computes.  It is enqueued on a second HIP stream once the T5 encoder forward has been issued and runs beside the T5
+    # decoder, whose ~1700 launches on 12 tokens leave most of the CUs idle.  Its output goes to the other of two buffers (the current
+    # one is still needed by this step's ln_vision backward); the next step picks it up after waiting on the completion event.
+    _vit_slot = 0
+    _vit_ready = None
+    _vit_stream = None
+    vit_lookahead_blocks = None  # how many ViT blocks the look-ahead runs beside the decoder (None = all); the rest run in the next step
+    vit_prefetch_hits = 0    # (class-wide tallies) steps that consumed a prefetched ViT output / prefetches issued but not matched
+    vit_prefetch_misses = 0
+
+    @staticmethod
+    def _video_key(video: torch.Tensor):
+        return (video.data_ptr(), tuple(video.shape), video._version)
+
     @torch.no_grad()
-    def forward_backward(self, video: torch.Tensor, layout: EncoderLayout, backward: bool = True):
-        """One micro-step: loss (device scalar) and, if ``backward``, gradients accumulated into self.grad."""
+    def prefetch_vit(self, next_video: torch.Tensor):
+        c = self.cfg
+        if self._vit_stream is None:
+            self._vit_stream = torch.cuda.Stream(device=self.dev)
+        start = torch.cuda.Event()
+        start.record()
+        slot = 1 - self._vit_slot
+        with torch.cuda.stream(self._vit_stream):
+            self._vit_stream.wait_event(start)
+            F_ = next_video.shape[0] * next_video.shape[1]
+            nb = c.vit_depth if self.vit_lookahead_blocks is None else max(1, min(c.vit_depth, int(self.vit_lookahead_blocks)))
+            xv = self.vit_forward(next_video.reshape(F_, 3, c.img, c.img), slot=slot, blocks=(0, nb))
+            done = torch.cuda.Event()
+            done.record()
+        self._vit_ready = (self._video_key(next_video), xv, done, slot, nb)
+
+    def _take_prefetched_vit(self, video: torch.Tensor):
+        r, self._vit_ready = self._vit_ready, None
+        if r is None:
+            return None
+        if r[0] != self._video_key(video):
+            MrBlipEngine.vit_prefetch_misses += 1
+            torch.cuda.current_stream().wait_event(r[2])  # the side stream still owns the ViT workspaces until then
+            return None
+        torch.cuda.current_stream().wait_event(r[2])
+        self._vit_slot = r[3]
+        MrBlipEngine.vit_prefetch_hits += 1
+        if r[4] < self.cfg.vit_depth:  # finish the remaining blocks here
+            c = self.cfg
+            F_ = video.shape[0] * video.shape[1]
+            self.vit_forward(video.reshape(F_, 3, c.img, c.img), slot=r[3], blocks=(r[4], c.vit_depth))
+        return r[1]
+
+    @torch.no_grad()
+    def forward_backward(self, video: torch.Tensor, layout: EncoderLayout, backward: bool = True, next_video: Optional[torch.Tensor] = None):
+        """One micro-step: loss (device scalar) and, if ``backward``, gradients accumulated into self.grad.  ``next_video`` (optional):
+        the next step's clip, whose frozen-ViT forward is overlapped with this step's decoder (see prefetch_vit)."""
         c = self.cfg
         Bv, T = video.shape[:2]
         F_ = Bv * T
@@ -913,6 +969,8 @@ class MrBlipEngine:
         kmask = L["mask"]
         enc = self.t5_encoder_forward(inp, Bv, S, kmask)
         self._mark("t5_encoder_forward")
+        if next_video is not None:
+            self.prefetch_vit(next_video)
         loss, logits = self.t5_decoder_forward(layout.decoder_input_ids, layout.decoder_mask, enc, Bv, S, kmask, layout.labels, want_grad=backward)
         self._mark("t5_decoder_forward + loss")
         if not backward:

@@ -182,3 +182,40 @@ def test_training_mode_dropout_parity():
         worst = max(worst, ea, eb)
         assert ea < 5e-2 and eb < 5e-2, (a.name, ea, eb)
     print("training-mode worst LoRA grad rel err", worst)
+
+
+@pytest.mark.gpu
+def test_vit_lookahead_is_transparent():
+    """The frozen-ViT look-ahead (next clip's ViT forward on a second stream beside this step's decoder) must not change anything:
+    three optimizer steps over two alternating clips, with and without look-ahead, give the same losses and the same parameters
+    (up to the fp32 atomics' summation order)."""
+    from mrblip import prompt as P
+    from mrblip.tokenizer import FixtureTokenizer
+
+    g = load_golden("mr_tiny")
+    tok = FixtureTokenizer()
+    repl = P.annoying_replacement_dict(P.find_annoying_numbers(tok, 200)[0])
+    samples = _samples(g)
+    lay = P.build_layout(tok, samples, repl, 8, T=3)
+    v0 = samples["video"].cuda()
+    v1 = (v0 * 0.5 + 0.25).contiguous()
+    clips = [v0, v1, v0, v1]
+
+    def run(lookahead):
+        eng = _engine(_peft_sd(golden_state_dict(g)))
+        eng.training = True
+        losses = []
+        for i in range(3):
+            eng.zero_grad()
+            loss = eng.forward_backward(clips[i], lay, backward=True, next_video=clips[i + 1] if lookahead else None)
+            losses.append(loss.item())
+            eng.optimizer_step(lr=1e-3, weight_decay=0.05)
+        torch.cuda.synchronize()
+        return losses, eng.flat.clone()
+
+    la, pa = run(False)
+    lb, pb = run(True)
+    assert la[0] != la[1]  # the clips really differ
+    for a, b in zip(la, lb):
+        assert abs(a - b) < 2e-4 * abs(a), (la, lb)
+    assert relerr(pb, pa) < 1e-4

@@ -13,6 +13,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_train_py_synthetic_tiny(tmp_path):
     import train
     from lavis.common.registry import registry
+    from mrblip.engine import MrBlipEngine
+    hits0, miss0 = MrBlipEngine.vit_prefetch_hits, MrBlipEngine.vit_prefetch_misses
 
     cfg = os.path.join(ROOT, "mr-blip_amd/lavis/projects/mr_BLIP/train/synthetic_tiny.yaml")
     train.main(["--cfg-path", cfg, "--options", f"run.output_dir={tmp_path}/out", "run.max_epoch=2"])
@@ -22,6 +24,9 @@ def test_train_py_synthetic_tiny(tmp_path):
     import json
     losses = [float(json.loads(l)["train_loss"]) for l in log if "train_loss" in l]
     assert len(losses) == 2 and losses[1] < losses[0], losses          # the optimizer really moves the trainable tensors
+    # the train loop's one-batch look-ahead reached the engine (next clip's frozen-ViT forward overlapped with the decoder)
+    from mrblip.engine import MrBlipEngine
+    assert MrBlipEngine.vit_prefetch_hits > hits0 and MrBlipEngine.vit_prefetch_misses == miss0
     ck = glob.glob(os.path.join(out, "checkpoint_*.pth"))
     assert ck
     sd = torch.load(ck[0], map_location="cpu")["model"]

@@ -9,6 +9,7 @@ from mrblip import prompt as P
 from mrblip.tokenizer import FixtureTokenizer
 
 dev = torch.device("cuda:0")
+LOOKAHEAD = "--lookahead" in sys.argv
 wl = bench.WORKLOADS["qvh"]
 cfg = EngineConfig.flan_t5_xl_qvh(mean_pool=False)
 eng = MrBlipEngine(cfg, RandomSource(dev, seed=1234), dev, lora_init=bench.lora_init_nonzero, seed=42)
@@ -20,7 +21,7 @@ layout = P.build_layout(tok, samples, repl, cfg.num_query, T=wl["T"])
 for it in range(5):
     eng.phase_events = [] if it >= 2 else None
     eng.zero_grad()
-    eng.forward_backward(samples["video"], layout, backward=True)
+    eng.forward_backward(samples["video"], layout, backward=True, next_video=samples["video"] if LOOKAHEAD else None)
     eng._mark("fwd/bwd done") if eng.phase_events is not None else None
     eng.optimizer_step(lr=3e-4, weight_decay=0.05)
     if eng.phase_events is not None:
