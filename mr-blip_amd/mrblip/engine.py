@@ -12,6 +12,7 @@ Frozen: ViT, Q-Former, query_tokens, T5 base weights.  Trainable: LoRA A/B, t5_p
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass, field
 from typing import Callable, Dict, List, Optional
 
@@ -618,15 +619,41 @@ class MrBlipEngine:
         ops.gemm(x, g.W, out, aext=u, wext=g.wext, **kw)
 
     def lg_bwd(self, g: LoraGroup, dy: torch.Tensor, x: torch.Tensor, u: torch.Tensor, gbuf: torch.Tensor, dx: Optional[torch.Tensor],
-               residual: Optional[torch.Tensor] = None):
+               residual: Optional[torch.Tensor] = None, side: bool = False):
         """dy bf16 [M,N]; x the saved bf16 input; u the saved [M,64] LoRA activations.  Accumulates dA, dB of every adapter of the
-        group (one launch) and (optionally) dx = dy W (+ residual) + mask * (g A) (one GEMM: the rank-8 term is its K-extension)."""
+        group (one launch) and (optionally) dx = dy W (+ residual) + mask * (g A) (one GEMM: the rank-8 term is its K-extension).
+        side=True: the weight-gradient launch goes to the gradient side stream and runs beside the dX GEMM (the caller guarantees
+        that dy / gbuf are not overwritten before its next side_join_layer())."""
         drop = self.drop(g.site, self.cfg.lora_dropout)
         ops.gemm(dy, g.bblk, gbuf, tile_cfg=3, K=g.N)                      # g' = scale * dy @ B      [M, 8*nad]
         ads = g.adapters
-        ops.lora_grads(dy, u, x, gbuf, [a.dBt for a in ads], [a.row0 for a in ads], [a.out for a in ads], [a.dA for a in ads], g.K, drop=drop)
+        if side and self.grad_side_stream_enabled:
+            st = self._grad_stream()
+            ev = torch.cuda.Event()
+            ev.record()
+            with torch.cuda.stream(st):
+                st.wait_event(ev)
+                ops.lora_grads(dy, u, x, gbuf, [a.dBt for a in ads], [a.row0 for a in ads], [a.out for a in ads], [a.dA for a in ads], g.K, drop=drop)
+        else:
+            ops.lora_grads(dy, u, x, gbuf, [a.dBt for a in ads], [a.row0 for a in ads], [a.out for a in ads], [a.dA for a in ads], g.K, drop=drop)
         if dx is not None:
             ops.lora_dx(dy, g.Wt, gbuf, g.acatt, dx, pad64(g.N), residual=residual, drop=drop)
+
+    grad_side_stream_enabled = os.environ.get("MRB_GRAD_SIDE", "1") == "1"
+    _gstream = None
+
+    def _grad_stream(self):
+        if self._gstream is None:
+            self._gstream = torch.cuda.Stream(device=self.dev)
+        return self._gstream
+
+    def side_join(self):
+        """the main stream waits for everything issued to the gradient side stream so far"""
+        if self._gstream is not None:
+            ev = torch.cuda.Event()
+            with torch.cuda.stream(self._gstream):
+                ev.record()
+            torch.cuda.current_stream().wait_event(ev)
 
     # ---- encoder ---------------------------------------------------------------------------------------------
     @torch.no_grad()
@@ -684,8 +711,8 @@ class MrBlipEngine:
         ops.cast_dropout(denc, out_f32=t, drop=self.drop(self.t5["sites"][1], p))
         dx = self.buf("eb_dx_a", (M, d), f32, zero=False)
         ops.rmsnorm_bwd(t, self.ws["e_xfinal_in"], self.t5["enc_final"], c.t5_eps, dx)
-        dyb = self.buf("eb_dyb", (M, pad64(d)), bf16)
-        gb = self.buf("eb_g", (M, 64), bf16)
+        dyb, dyb2 = self.buf("eb_dyb", (M, pad64(d)), bf16), self.buf("eb_dyb2", (M, pad64(d)), bf16)
+        gb, gb2, gb3, gb4 = (self.buf(n, (M, 64), bf16) for n in ("eb_g", "eb_g2", "eb_g3", "eb_g4"))
         dyact = self.buf("eb_dyact", (M, ff), bf16, zero=False)
         dh = self.buf("eb_dh", (M, 2 * ff), bf16, zero=False)
         dxn = self.buf("eb_dxn", (M, d), f32, zero=False)
@@ -697,29 +724,48 @@ class MrBlipEngine:
         other = self.buf("eb_dx_b", (M, d), f32, zero=False)
         for i in reversed(range(len(self.t5["enc"]))):
             L = self.t5["enc"][i]
+            # the LoRA weight-gradient launches of this layer run on the side stream beside the dX GEMMs; their inputs (dyb/dyb2/dh/
+            # dqkv and the four g buffers) are written once per layer, so one join per layer keeps every reader ahead of its next writer
+            self.side_join()
+            # K^T / Q^T of this layer depend only on saved forward activations: transposed on the side stream while the FFN backward runs
+            kq_ready = None
+            if self.grad_side_stream_enabled:
+                qkv_i = self.ws[f"e{i}_qkv"]
+                st, ev = self._grad_stream(), torch.cuda.Event()
+                ev.record()  # (the previous layer's attention backward, the last reader of kt / qt, is ahead of this point)
+                with torch.cuda.stream(st):
+                    st.wait_event(ev)
+                    ops.head_transpose(self.v4(qkv_i, B, S, H, dk, inner), out=kt)
+                    ops.head_transpose(self.v4(qkv_i, B, S, H, dk, 0), out=qt)
+                    kq_ready = torch.cuda.Event()
+                    kq_ready.record()
             # x_out = xm + drop(wo(y));  y = drop(gelu(wi_0 xn2) * wi_1 xn2)
             ops.cast_dropout(dx, out_bf16=dyb, drop=self.drop(L["sites"][3], p))
-            self.lg_bwd(L["wo"], dyb, self.ws[f"e{i}_y"], self.ws[f"e{i}_u_wo"], gb, dyact)
+            self.lg_bwd(L["wo"], dyb, self.ws[f"e{i}_y"], self.ws[f"e{i}_u_wo"], gb, dyact, side=True)
             ops.gated_gelu_bwd(dyact, self.ws[f"e{i}_h"], dh, drop=self.drop(L["sites"][2], p))
-            self.lg_bwd(L["wi"], dh, self.ws[f"e{i}_xn2"], self.ws[f"e{i}_u_wi"], gb, dxn)
+            self.lg_bwd(L["wi"], dh, self.ws[f"e{i}_xn2"], self.ws[f"e{i}_u_wi"], gb2, dxn, side=True)
             ops.rmsnorm_bwd(dxn, self.ws[f"e{i}_xm"], L["ln1"], c.t5_eps, other, dx_add=dx)
             dx, other = other, dx
             # xm = x_in + drop(o(attn(qkv(xn))))
-            ops.cast_dropout(dx, out_bf16=dyb, drop=self.drop(L["sites"][1], p))
-            self.lg_bwd(L["o"], dyb, self.ws[f"e{i}_o"], self.ws[f"e{i}_u_o"], gb, do)
+            ops.cast_dropout(dx, out_bf16=dyb2, drop=self.drop(L["sites"][1], p))
+            self.lg_bwd(L["o"], dyb2, self.ws[f"e{i}_o"], self.ws[f"e{i}_u_o"], gb3, do, side=True)
             qkv, o = self.ws[f"e{i}_qkv"], self.ws[f"e{i}_o"]
             q4, k4, v4 = self.v4(qkv, B, S, H, dk, 0), self.v4(qkv, B, S, H, dk, inner), self.v4(qkv, B, S, H, dk, 2 * inner)
             do4 = self.v4(do, B, S, H, dk)
-            ops.head_transpose(k4, out=kt)
-            ops.head_transpose(q4, out=qt)
             ops.head_transpose(do4, out=dot)
+            if kq_ready is not None:
+                torch.cuda.current_stream().wait_event(kq_ready)
+            else:
+                ops.head_transpose(k4, out=kt)
+                ops.head_transpose(q4, out=qt)
             ops.attention_bwd(q4, k4, v4, self.v4(o, B, S, H, dk), do4, kt, qt, dot, self.ws[f"e{i}_lse"], delta,
                               self.v4(dqkv, B, S, H, dk, 0), self.v4(dqkv, B, S, H, dk, inner), self.v4(dqkv, B, S, H, dk, 2 * inner),
                               scale=1.0, bias_lut=self.lut_enc, kmask=kmask, drop=self.drop(L["sites"][0], p),
                               drop_bits=self.ws.get(f"e{i}_dbits") if self.drop(L["sites"][0], p) is not None else None)
-            self.lg_bwd(L["qkv"], dqkv, self.ws[f"e{i}_xn"], self.ws[f"e{i}_u_qkv"], gb, dxn)
+            self.lg_bwd(L["qkv"], dqkv, self.ws[f"e{i}_xn"], self.ws[f"e{i}_u_qkv"], gb4, dxn, side=True)
             ops.rmsnorm_bwd(dxn, self.ws[f"e{i}_xin"], L["ln0"], c.t5_eps, other, dx_add=dx)
             dx, other = other, dx
+        self.side_join()
         dinp = self.buf("eb_dinp", (M, d), f32, zero=False)
         ops.cast_dropout(dx, out_f32=dinp, drop=self.drop(self.t5["sites"][0], p))
         return dinp
@@ -969,7 +1015,7 @@ class MrBlipEngine:
         kmask = L["mask"]
         enc = self.t5_encoder_forward(inp, Bv, S, kmask)
         self._mark("t5_encoder_forward")
-        if next_video is not None:
+        if next_video is not None:  # (starting it earlier, beside the encoder forward, measured the same)
             self.prefetch_vit(next_video)
         loss, logits = self.t5_decoder_forward(layout.decoder_input_ids, layout.decoder_mask, enc, Bv, S, kmask, layout.labels, want_grad=backward)
         self._mark("t5_decoder_forward + loss")
