@@ -113,15 +113,18 @@ __device__ __forceinline__ void epilogue_gated8(const GemmArgs& p, int m, int n0
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
+// blocks per CU the register allocation must allow: what the LDS footprint permits (160 KB per CU), at most 16 waves per CU
+constexpr int gemm_min_blocks(int lds_bytes, int nwaves) {
+  int b = lds_bytes <= 40 * 1024 ? 4 : lds_bytes <= 53 * 1024 ? 3 : lds_bytes <= 80 * 1024 ? 2 : 1;
+  while (b > 1 && b * nwaves > 16) --b;
+  return nwaves > 4 && lds_bytes > 80 * 1024 ? 1 : b;
+}
+
 // BK = k extent of one LDS stage (64: 128-B rows, 8 chunks; 32: 64-B rows, 4 chunks), NS = stages in the ring (2, or 3 for the
 // non-persistent BK = 32 form: prefetch distance two K-tiles with a counted vmcnt wait — the main loop holds only LDS-DMA loads,
 // which retire in order).
 template <int BM, int BN, int WGM, int WGN, bool OUT_F32, bool GATED, int BK = 64, int NS = 2>
-__global__ __launch_bounds__(WGM* WGN * 64, (WGM * WGN > 4)                              ? 1
-                                             : (NS * (BM + BN) * BK * 2 <= 40 * 1024) ? 4
-                                             : (NS * (BM + BN) * BK * 2 <= 53 * 1024) ? 3
-                                             : (NS * (BM + BN) * BK * 2 <= 80 * 1024) ? 2
-                                                                                      : 1) void gemm_tile_kernel(const GemmArgs p) {
+__global__ __launch_bounds__(WGM* WGN * 64, gemm_min_blocks(NS * (BM + BN) * BK * 2, WGM * WGN)) void gemm_tile_kernel(const GemmArgs p) {
   constexpr int NW = WGM * WGN;
   constexpr int TM = BM / WGM / 32;  // 32x32 tiles per wave along M
   constexpr int TN = BN / WGN / 32;
@@ -226,11 +229,32 @@ __global__ __launch_bounds__(WGM* WGN * 64, (WGM * WGN > 4)                     
   if (NS == 3 && 1 < nk) stage(kmap(1), 1);
   for (int kt = 0; kt < nk; ++kt) {
     // stage kt must have landed; with a 3-deep ring the newest stage (issued one iteration ago) may still be in flight
+#ifndef EXP_NOSYNC
     if (NS == 3 && kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(JA + JW) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+#endif
+#ifndef EXP_NODMA
     if (kt + NS - 1 < nk) stage(kmap(kt + NS - 1), (kt + NS - 1) % NS);
+#endif
     const char* base = smem + (kt % NS) * STAGE;
+#ifdef EXP_NOLDS
+    {  // EXPERIMENT (wrong results): fragments read once per K-tile
+      const int coff = (((0 * 2 + hi) ^ swz) << 4);
+      bf16x8 xf[TM], wf[TN];
+#pragma unroll
+      for (int mt = 0; mt < TM; ++mt) xf[mt] = *reinterpret_cast<const bf16x8*>(base + a_row_off + mt * 32 * RB + coff);
+#pragma unroll
+      for (int nt = 0; nt < TN; ++nt) wf[nt] = *reinterpret_cast<const bf16x8*>(base + w_row_off[nt] + coff);
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+        for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < TN; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nt], xf[mt], acc[mt][nt], 0, 0, 0);
+    }
+#else
 #pragma unroll
     for (int kk = 0; kk < KK; ++kk) {
       const int coff = (((kk * 2 + hi) ^ swz) << 4);
@@ -245,6 +269,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, (WGM * WGN > 4)                     
         for (int nt = 0; nt < TN; ++nt)
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nt], xf[mt], acc[mt][nt], 0, 0, 0);
     }
+#endif
     if (!GATED && ext_first && kt == NEXT - 1 && p.ext_drop.seed_ptr) {  // acc == Aext Wext^T: apply the LoRA input-dropout mask to it
       const uint32_t seed = *p.ext_drop.seed_ptr;
 #pragma unroll
@@ -523,9 +548,20 @@ static int gemm_dispatch(const void* A, long long lda, const void* W, long long 
       const long long t256 = (long long)((M + 255) / 256) * ((ncols + (gated ? 127 : 255)) / (gated ? 128 : 256));
       const long long t128 = (long long)((M + 127) / 128) * ((ncols + (gated ? 63 : 127)) / (gated ? 64 : 128));
       const long long t64x128 = (long long)((M + 63) / 64) * ((ncols + (gated ? 63 : 127)) / (gated ? 64 : 128));
-      static int c1_t = -1, c1_k = -1;
-      if (c1_t < 0) { const char* e = getenv("MRB_CFG1_T256"); c1_t = e ? atoi(e) : 512; const char* f = getenv("MRB_CFG1_K"); c1_k = f ? atoi(f) : 4096; }
-      if (t256 >= c1_t && K >= c1_k) cfg = 1;
+      // 256x256 with 16 waves of 64x64 (4 waves per SIMD hide each other's LDS-DMA issue; half the L2->LDS bytes per flop of 128x128)
+      // is the fastest main loop, but it runs one block per CU: it pays only when its rounds are full (ViT fc1: 1464 tiles = 5.7
+      // rounds of 256 CUs) or when one partial round covers most CUs (T5 qkv: 192 tiles)
+      static int ncu = 0;
+      if (ncu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+      }
+      const long long rounds = (t256 + ncu - 1) / ncu;
+      const double eff256 = (double)t256 / (double)(rounds * ncu);
+      static int no8 = -1;
+      if (no8 < 0) no8 = getenv("MRB_NO_CFG8") ? 1 : 0;
+      if (!no8 && !gated && K >= 1024 && (eff256 >= 0.9 || (rounds == 1 && eff256 >= 0.7))) cfg = 8;
       else if (t128 >= 400) cfg = 2;
       else if (t64x128 >= 400 || gated) cfg = 4;
       else cfg = 5;
@@ -551,6 +587,14 @@ static int gemm_dispatch(const void* A, long long lda, const void* W, long long 
   if (cfg == 7) {  // 256x128 tile, 4 waves of 128x64, BK = 32, 3-stage ring (72 KB): two blocks per CU at 0.75 KB of LDS reads per MFMA
     if (gated) return launch_tile<256, 128, 2, 2, false, true, 32, 3>(a, stream);
     return out_f32 ? launch_tile<256, 128, 2, 2, true, false, 32, 3>(a, stream) : launch_tile<256, 128, 2, 2, false, false, 32, 3>(a, stream);
+  }
+  if (cfg == 8) {  // 256x256, 16 waves of 64x64 (4 waves per SIMD), one persistent block per CU
+    if (gated) return launch_tile<256, 256, 4, 4, false, true>(a, stream);
+    return out_f32 ? launch_tile<256, 256, 4, 4, true, false>(a, stream) : launch_tile<256, 256, 4, 4, false, false>(a, stream);
+  }
+  if (cfg == 9) {  // 128x128 with 8 waves of 32x64, two blocks per CU (4 waves per SIMD): measured = cfg 2, not auto-selected
+    if (gated) return launch_tile<128, 128, 4, 2, false, true>(a, stream);
+    return out_f32 ? launch_tile<128, 128, 4, 2, true, false>(a, stream) : launch_tile<128, 128, 4, 2, false, false>(a, stream);
   }
   if (cfg == 4) {
     if (gated) return launch_tile<64, 128, 2, 2, false, true>(a, stream);

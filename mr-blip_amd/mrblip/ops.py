@@ -12,7 +12,7 @@ from typing import Optional, Sequence
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libmrblip_hip.so")
+LIB_PATH = os.environ.get("MRBLIP_LIB") or os.path.join(os.path.dirname(_HERE), "csrc", "libmrblip_hip.so")  # (override: A/B of experimental builds)
 
 
 class MrblipError(RuntimeError):

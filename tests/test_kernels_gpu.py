@@ -37,7 +37,7 @@ def keep_mask(shape, seed, site, p):
     return dropout_keep(shape, seed, site, p).to(dev())
 
 
-@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 7])
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 7, 8, 9])
 @pytest.mark.parametrize("M,N,K", [(300, 264, 128), (64, 520, 192), (513, 1408, 576), (33, 264, 2304)])
 def test_gemm_plain(ops, cfg, M, N, K):
     torch.manual_seed(0)
@@ -51,7 +51,7 @@ def test_gemm_plain(ops, cfg, M, N, K):
         assert rel(out.float(), ref) < tol, (cfg, dt)
 
 
-@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 7])
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 7, 8, 9])
 def test_gemm_epilogues(ops, cfg):
     torch.manual_seed(1)
     M, N, K = 200, 328, 256
@@ -77,7 +77,7 @@ def test_gemm_epilogues(ops, cfg):
     assert rel(x, res + base * mask / 0.9) < 2e-6
 
 
-@pytest.mark.parametrize("cfg", [1, 2, 4, 7])
+@pytest.mark.parametrize("cfg", [1, 2, 4, 7, 8, 9])
 def test_gemm_gated(ops, cfg):
     torch.manual_seed(2)
     M, Nh, K = 300, 200, 128
@@ -423,7 +423,7 @@ def test_lora_fused_launches(ops, M):
     acatt[:, :24] = acat.t()
     res = torch.randn(M, K, device=dev())
     want = dy.float() @ wt.float().t() + res + (g[:, :24].float() @ acat.float()) * mask / (1 - p)
-    for cfg in ([3] if M <= 64 else [2, 4, 5, 1, 7]):
+    for cfg in ([3] if M <= 64 else [2, 4, 5, 1, 7, 8, 9]):
         dx = torch.full((M, K), float("nan"), device=dev())
         ops.lora_dx(dy, wt, g, acatt, dx, N, residual=res, drop=drop, tile_cfg=cfg)
         assert rel(dx, want) < 1e-5, cfg
