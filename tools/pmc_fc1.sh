@@ -16,7 +16,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for f in files:
         for row in csv.DictReader(open(f)):
             name = row.get("Kernel_Name", "")
-            if "gemm_tile_kernel" in name and row.get("Counter_Name") == c and int(float(row.get("Grid_Size", row.get("Grid_Size_X", 0)))) == 1486848:
+            if "gemm_tile_kernel" in name and row.get("Counter_Name") == c and int(float(row.get("Grid_Size", row.get("Grid_Size_X", 0)))) == 262144:
                 vals.append(float(row["Counter_Value"]))
     out[c] = dict(n=len(vals), mean=(sum(vals) / len(vals) if vals else None), files=len(files))
 json.dump(out, open("gpurun_out/pmc_fc1.json", "w"), indent=1)
