@@ -562,7 +562,10 @@ static int gemm_dispatch(const void* A, long long lda, const void* W, long long 
       static int no8 = -1;
       if (no8 < 0) no8 = getenv("MRB_NO_CFG8") ? 1 : 0;
       if (!no8 && !gated && K >= 1024 && (eff256 >= 0.9 || (rounds == 1 && eff256 >= 0.7))) cfg = 8;
-      else if (t128 >= 400) cfg = 2;
+      // (256x128 with 16 waves, cfg 10, is 5-15 % faster than 128x128 at the ViT qkv shape standalone, but in the step it made things
+      // worse: one more persistent 16-wave block per CU starves the small kernels of the clip that shares the GPU with the look-ahead)
+      if (cfg != 0) {
+      } else if (t128 >= 400) cfg = 2;
       else if (t64x128 >= 400 || gated) cfg = 4;
       else cfg = 5;
     }
@@ -595,6 +598,14 @@ static int gemm_dispatch(const void* A, long long lda, const void* W, long long 
   if (cfg == 9) {  // 128x128 with 8 waves of 32x64, two blocks per CU (4 waves per SIMD): measured = cfg 2, not auto-selected
     if (gated) return launch_tile<128, 128, 4, 2, false, true>(a, stream);
     return out_f32 ? launch_tile<128, 128, 4, 2, true, false>(a, stream) : launch_tile<128, 128, 4, 2, false, false>(a, stream);
+  }
+  if (cfg == 10) {  // 256x128, 16 waves of 64x32, one persistent block per CU
+    MRB_REQUIRE(!gated, "gemm: cfg 10 has no gated epilogue");
+    return out_f32 ? launch_tile<256, 128, 4, 4, true, false>(a, stream) : launch_tile<256, 128, 4, 4, false, false>(a, stream);
+  }
+  if (cfg == 11) {  // 128x256, 16 waves of 32x64 (measured <= cfg 10, not auto-selected)
+    MRB_REQUIRE(!gated, "gemm: cfg 11 has no gated epilogue");
+    return out_f32 ? launch_tile<128, 256, 4, 4, true, false>(a, stream) : launch_tile<128, 256, 4, 4, false, false>(a, stream);
   }
   if (cfg == 4) {
     if (gated) return launch_tile<64, 128, 2, 2, false, true>(a, stream);

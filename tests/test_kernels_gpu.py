@@ -37,7 +37,7 @@ def keep_mask(shape, seed, site, p):
     return dropout_keep(shape, seed, site, p).to(dev())
 
 
-@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 7, 8, 9])
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 7, 8, 9, 10, 11])
 @pytest.mark.parametrize("M,N,K", [(300, 264, 128), (64, 520, 192), (513, 1408, 576), (33, 264, 2304)])
 def test_gemm_plain(ops, cfg, M, N, K):
     torch.manual_seed(0)
@@ -51,7 +51,7 @@ def test_gemm_plain(ops, cfg, M, N, K):
         assert rel(out.float(), ref) < tol, (cfg, dt)
 
 
-@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 7, 8, 9])
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 7, 8, 9, 10, 11])
 def test_gemm_epilogues(ops, cfg):
     torch.manual_seed(1)
     M, N, K = 200, 328, 256
