@@ -33,6 +33,8 @@ struct GemmArgs {
   // (then holding only its product) are masked in registers before the main K loop adds to them
   int ext_first;
   DropoutArg ext_drop;
+  int m_rows_per_block;  // skinny kernel only: 32, or 16 / 8 when few output columns leave most CUs without a block (more blocks stream
+                         // the tall operand in parallel: one CU sustains only ~10 B/clk from HBM)
   DropoutArg a_drop;  // skinny kernel only: dropout of the A operand as it is loaded (zeroing; the 1/(1-p) is applied to the result)
 };
 
@@ -357,8 +359,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const GemmArgs p) 
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int hi = lane >> 5, l31 = lane & 31;
   const int n_row = blockIdx.x * 32 + l31;  // W row (MFMA A-operand row)
-  const int m_row = blockIdx.y * 32 + l31;  // X row (MFMA B-operand column)
-  const bool n_ok = n_row < p.N, m_ok = m_row < p.M;
+  const int m_row = blockIdx.y * p.m_rows_per_block + l31;  // X row (MFMA B-operand column)
+  const bool n_ok = n_row < p.N, m_ok = m_row < p.M && l31 < p.m_rows_per_block;
   const int nkb = p.K >> 6;  // 64-wide k blocks of the main segment
   f32x16 acc;
 #pragma unroll
@@ -521,6 +523,7 @@ static int gemm_dispatch(const void* A, long long lda, const void* W, long long 
   MRB_REQUIRE(!gated || (!out_f32 && !bias && !residual && act == 0 && (N % 16) == 0), "gemm: gated mode takes no bias/residual/act");
   GemmArgs a;
   a.ext_first = ext_first;
+  a.m_rows_per_block = 32;
   mk_drop_arg(a.ext_drop, seed_ptr, ext_site, ext_p);
   mk_drop_arg(a.a_drop, seed_ptr, a_site, a_p);
   MRB_REQUIRE(!(ext_p > 0.f || a_p > 0.f) || seed_ptr, "gemm: dropout needs a device seed pointer");
@@ -572,7 +575,13 @@ static int gemm_dispatch(const void* A, long long lda, const void* W, long long 
   }
   if (cfg == 3) {
     MRB_REQUIRE(!gated, "gemm: skinny kernel has no gated epilogue");
-    dim3 grid((N + 31) / 32, (M + 31) / 32);
+    // rows of the tall operand per block: 32, fewer when the grid would leave most CUs idle (LoRA down / g products at M = 2012)
+    int rpb = 32;
+    static int rpb32 = -1;
+    if (rpb32 < 0) rpb32 = getenv("MRB_SKINNY_RPB32") ? 1 : 0;
+    while (!rpb32 && rpb > 8 && (long long)((N + 31) / 32) * ((M + rpb - 1) / rpb) < 192 && M > rpb) rpb >>= 1;
+    a.m_rows_per_block = rpb;
+    dim3 grid((N + 31) / 32, (M + rpb - 1) / rpb);
     // (a 16-wave K-split changes nothing here: with one lane per operand row these launches are bound by the number of row-gather
     // load instructions one CU's address unit can retire, not by a wave's sequential load rounds)
     if (out_f32) hipLaunchKernelGGL((gemm_skinny_kernel<true, 4>), grid, dim3(256), 0, stream, a);
