@@ -115,6 +115,32 @@ __device__ __forceinline__ void epilogue_gated8(const GemmArgs& p, int m, int n0
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
+// One K-tile of operands: CA + CW LDS-DMA pieces per wave (1 KiB each, lane-linear in LDS); per-piece source offsets come in VGPRs,
+// the only per-K-tile scalar is the byte offset along k.  (A device function, not a lambda: the buffer-resource type does not
+// exist in the host pass, and a kernel lambda holding one silently loses its host stub.)
+template <int CA, int CW, int NW_, int PIECE_BYTES>
+__device__ __forceinline__ void gemm_stage_dma(char* dstA, char* dstW, const void* pa, uint32_t bytes_a, const void* pw, uint32_t bytes_w,
+                                               const uint32_t* va, const uint32_t* vw, int w, uint32_t koff) {
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(pa), 0, (int)bytes_a, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(pw), 0, (int)bytes_w, 0x00020000);
+#pragma unroll
+  for (int j = 0; j < CA; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr_t)(dstA + (j * NW_ + w) * PIECE_BYTES), 16, va[j], koff, 0, 0);
+#pragma unroll
+  for (int j = 0; j < CW; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(dstW + (j * NW_ + w) * PIECE_BYTES), 16, vw[j], koff, 0, 0);
+}
+// (same body under a second name: two call sites of ONE function get merged into a call with selected array pointers, which sends
+// the offset arrays through scratch memory)
+template <int CA, int CW, int NW_, int PIECE_BYTES>
+__device__ __forceinline__ void gemm_stage_dma_ext(char* dstA, char* dstW, const void* pa, uint32_t bytes_a, const void* pw, uint32_t bytes_w,
+                                               const uint32_t* va, const uint32_t* vw, int w, uint32_t koff) {
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(pa), 0, (int)bytes_a, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(pw), 0, (int)bytes_w, 0x00020000);
+#pragma unroll
+  for (int j = 0; j < CA; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr_t)(dstA + (j * NW_ + w) * PIECE_BYTES), 16, va[j], koff, 0, 0);
+#pragma unroll
+  for (int j = 0; j < CW; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(dstW + (j * NW_ + w) * PIECE_BYTES), 16, vw[j], koff, 0, 0);
+}
+
 // blocks per CU the register allocation must allow: what the LDS footprint permits (160 KB per CU), at most 16 waves per CU
 constexpr int gemm_min_blocks(int lds_bytes, int nwaves) {
   int b = lds_bytes <= 40 * 1024 ? 4 : lds_bytes <= 53 * 1024 ? 3 : lds_bytes <= 80 * 1024 ? 2 : 1;
@@ -168,28 +194,40 @@ __global__ __launch_bounds__(WGM* WGN * 64, gemm_min_blocks(NS * (BM + BN) * BK 
     return bn * BN + tr;
   };
 
-  auto stage = [&](int kt, int buf) __attribute__((always_inline)) {
-    char* base = smem + buf * STAGE;
-    // main segment or K extension: everything that differs is selected as a plain scalar / vector VALUE (uniform condition) and the
-    // buffer resources are rebuilt from the selected base pointers — selecting between the resource objects themselves would force
-    // them (and the offsets) through scratch memory, and a scratch reload between two LDS-DMA loads serialises them on vmcnt.
-    const bool ext = kt >= nk_main;
-    const long long ld_a = ext ? p.ldaext : p.lda, ld_w = ext ? p.ldwext : p.ldw;
-    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(ext ? p.Aext : p.A), 0, (int)(uint32_t)((long long)p.M * ld_a * 2), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)(ext ? p.Wext : p.W), 0, (int)(uint32_t)((long long)p.N * ld_w * 2), 0x00020000);
-    const uint32_t va = ext ? vAe : vA, vw = ext ? vWe : vW;
-    const uint32_t koff = (uint32_t)(ext ? kt - nk_main : kt) * (uint32_t)RB;
+  // Per-piece source offsets live in VGPRs (computed once per tile: row base of the piece + the lane's row / swizzled chunk) and the only
+  // scalar that changes per K-tile is the byte offset along k (the buffer instruction's soffset).  The kernel is far beyond the 106
+  // SGPRs (the compiler parks ~100 scalars in VGPR lanes): recomputing row_base * ld per piece and per K-tile from spilled scalars put
+  // a dozen v_readlane / s_mul / s_nop in front of every LDS-DMA instruction of the main loop.  Having the row offset in voffset also
+  // puts it under the resource's range check (rows >= M / N read as zero whatever the hardware does with soffset).
+  uint32_t vpa[JA], vpw[JW];      // main segment (the K extension computes its own on the fly: one or two tiles of the loop)
+  auto tile_offsets = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < JA; ++j) {
       const int tr = (j * NW + w) * RPI;
-      const uint32_t so = (uint32_t)((long long)(bm * BM + tr) * ld_a * 2) + koff;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr_t)(base + tr * RB), 16, va, so, 0, 0);
+      vpa[j] = vA + (uint32_t)((long long)(bm * BM + tr) * p.lda * 2);
     }
 #pragma unroll
-    for (int j = 0; j < JW; ++j) {
-      const int tr = (j * NW + w) * RPI;
-      const uint32_t so = (uint32_t)((long long)w_row_base(j) * ld_w * 2) + koff;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(base + A_BYTES + tr * RB), 16, vw, so, 0, 0);
+    for (int j = 0; j < JW; ++j) vpw[j] = vW + (uint32_t)((long long)w_row_base(j) * p.ldw * 2);
+  };
+  auto stage = [&](int kt, int buf) __attribute__((always_inline)) {
+    char* base = smem + buf * STAGE;
+    const bool ext = kt >= nk_main;  // uniform; the K extension is one or two tiles of the whole loop
+    if (!ext) {
+#ifdef EXP_SAMEK
+      const uint32_t koff = 0;  // EXPERIMENT (wrong results): every K-tile re-loads the first one (cache-resident fill)
+#else
+      const uint32_t koff = (uint32_t)kt * (uint32_t)RB;
+#endif
+      gemm_stage_dma<JA, JW, NW, RPI * RB>(base, base + A_BYTES, p.A, (uint32_t)((long long)p.M * p.lda * 2), p.W, (uint32_t)((long long)p.N * p.ldw * 2),
+                                           vpa, vpw, w, koff);
+    } else {
+      uint32_t ea[JA], ew[JW];
+#pragma unroll
+      for (int j = 0; j < JA; ++j) ea[j] = vAe + (uint32_t)((long long)(bm * BM + (j * NW + w) * RPI) * p.ldaext * 2);
+#pragma unroll
+      for (int j = 0; j < JW; ++j) ew[j] = vWe + (uint32_t)((long long)w_row_base(j) * p.ldwext * 2);
+      gemm_stage_dma_ext<JA, JW, NW, RPI * RB>(base, base + A_BYTES, p.Aext, (uint32_t)((long long)p.M * p.ldaext * 2), p.Wext,
+                                               (uint32_t)((long long)p.N * p.ldwext * 2), ea, ew, w, (uint32_t)(kt - nk_main) * (uint32_t)RB);
     }
   };
 
@@ -218,6 +256,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, gemm_min_blocks(NS * (BM + BN) * BK 
     bm = first_m + (bid % per_group) % gsize;
     bn = (bid % per_group) / gsize;
   }
+  tile_offsets();
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
