@@ -112,6 +112,7 @@ class BLIP2_MR(BaseModel):
                               no_task_prompt="no_task_prompt" in self.task)
 
     _staged_next = None  # (host tensor of the next batch's frames, its device copy): see forward()
+    generate_cross_cache = True  # project the decoder's cross-attention K/V once per clip (False: per step and beam, for the A/B test)
 
     def forward(self, samples):
         """samples: the reference's dict (blip2_mr.py:433-445).  Optional extra key ``next_video``: the NEXT batch's frames (the train
@@ -135,8 +136,9 @@ class BLIP2_MR(BaseModel):
     @torch.no_grad()
     def generate(self, samples, use_nucleus_sampling=False, num_beams=5, max_length=50, min_length=1, top_p=0.9, repetition_penalty=1.0,
                  length_penalty=1.0, num_captions=1, temperature=1, output_attentions=False):
-        """Beam search over the HIP decoder (blip2_mr.py:826-946).  The decoder is re-run on the growing prefix each step
-        (no KV cache yet — SURVEY.md §8f row 1)."""
+        """Beam search over the HIP decoder (blip2_mr.py:826-946).  The encoder runs once; the cross-attention K/V of all 24 decoder
+        layers are projected once per clip and shared by every step and every beam (engine.t5_cross_kv); the short decoder prefix
+        (<= max_length tokens x beams) is re-run each step."""
         eng = self.engine
         was_training = eng.training
         eng.training = False
@@ -155,16 +157,20 @@ class BLIP2_MR(BaseModel):
             ops.row_copy(eng.emb, L["emb_src"], inp, L["emb_dst"])
             enc = eng.t5_encoder_forward(inp, B, S, L["mask"])
             K = max(1, int(num_beams))
-            # replicate encoder rows per beam: [B*K sequences]
-            enc_k = enc.view(B, S, -1).repeat_interleave(K, 0).reshape(B * K * S, -1).contiguous()
-            mask_k = None if L["mask"] is None else L["mask"].repeat_interleave(K, 0).contiguous()
+            cross = eng.t5_cross_kv(enc, B, S) if self.generate_cross_cache else None
+            if cross is None:  # reference-shaped fallback (kept for the A/B test): replicate the encoder rows per beam
+                enc_k = enc.view(B, S, -1).repeat_interleave(K, 0).reshape(B * K * S, -1).contiguous()
+                mask_k = None if L["mask"] is None else L["mask"].repeat_interleave(K, 0).contiguous()
+            else:
+                enc_k, mask_k = enc, L["mask"]
             seqs = torch.zeros(B * K, 1, dtype=torch.long)
             scores = torch.zeros(B, K)
             scores[:, 1:] = -1e9
             finished = [[] for _ in range(B)]
             for step in range(max_length):
                 Ld = seqs.shape[1]
-                _, logits = eng.t5_decoder_forward(seqs, torch.ones(B * K, Ld, dtype=torch.int32), enc_k, B * K, S, mask_k, labels=None)
+                _, logits = eng.t5_decoder_forward(seqs, torch.ones(B * K, Ld, dtype=torch.int32), enc_k, B * K, S, mask_k, labels=None,
+                                                   cross_cache=cross, cross_batch=B if cross is not None else None)
                 lp = torch.log_softmax(logits.view(B * K, Ld, -1)[:, -1].float().cpu() / float(temperature), -1)
                 if step + 1 < min_length:
                     lp[:, 1] = -1e9

@@ -772,8 +772,29 @@ class MrBlipEngine:
 
     # ---- decoder + LM head + loss (forward and backward) ---------------------------------------------------------
     @torch.no_grad()
+    def t5_cross_kv(self, enc: torch.Tensor, Be: int, S: int):
+        """Cross-attention K / V^T of every decoder layer for a fixed encoder output (inference: computed once per clip and reused by
+        every decoding step and every beam).  Returns a list of (k4 view [Be,S,H,dk], V^T [Be,H,dkp,Sp]) per layer."""
+        c = self.cfg
+        H, dk = c.t5_heads, c.d_kv
+        inner = H * dk
+        Me = Be * S
+        cache = []
+        for i, L in enumerate(self.t5["dec"]):
+            ukv = self.buf(f"g{i}_u_ckv", (Me, 64), bf16)
+            ckv = self.buf(f"g{i}_ckv", (Me, 2 * inner), bf16, zero=False)
+            self.lg_fwd(L["ckv"], enc, ukv, ckv)
+            vt = self.buf(f"g{i}_vt_c", (Be, H, ops.rup32(dk), ops.rup32(S)), bf16)
+            ops.head_transpose(self.v4(ckv, Be, S, H, dk, inner), out=vt)
+            cache.append((self.v4(ckv, Be, S, H, dk, 0), vt))
+        return cache
+
+    @torch.no_grad()
     def t5_decoder_forward(self, dec_ids: torch.Tensor, dec_mask: torch.Tensor, enc: torch.Tensor, B: int, S: int, kmask: torch.Tensor,
-                           labels: Optional[torch.Tensor] = None, want_grad: bool = True):
+                           labels: Optional[torch.Tensor] = None, want_grad: bool = True, cross_cache=None, cross_batch: Optional[int] = None):
+        """cross_cache (inference only): the output of t5_cross_kv for ``cross_batch`` encoder sequences; the B decoder sequences are
+        then cross_batch groups of B / cross_batch beams, and — cross-attention having no causal structure — the beams of a group are
+        simply more query rows against ITS encoder's keys: no per-beam copy of the encoder output, no K/V re-projection per step."""
         c = self.cfg
         d, H, dk, ff, p, V = c.d_model, c.t5_heads, c.d_kv, c.d_ff, c.t5_dropout, c.vocab
         inner = H * dk
@@ -786,7 +807,7 @@ class MrBlipEngine:
         x = self.buf("d_x0", (R, d), f32, zero=False)
         ops.cast_dropout(x0, out_f32=x, drop=self.drop(self.t5["sites"][2], p))
         vt_s = self.buf("d_vt_s", (B, H, ops.rup32(dk), ops.rup32(Ld)), bf16)
-        vt_c = self.buf("d_vt_c", (B, H, ops.rup32(dk), ops.rup32(S)), bf16)
+        vt_c = self.buf("d_vt_c", (B, H, ops.rup32(dk), ops.rup32(S)), bf16) if cross_cache is None else None
         dmask = self.pad_mask(dec_mask)
         for i, L in enumerate(self.t5["dec"]):
             xn = self.buf(f"d{i}_xn", (R, pad64(d)), bf16)
@@ -808,14 +829,20 @@ class MrBlipEngine:
             ucq = self.buf(f"d{i}_u_cq", (R, 64), bf16)
             cq = self.buf(f"d{i}_cq", (R, inner), bf16, zero=False)
             self.lg_fwd(L["cq"], xn1, ucq, cq)
-            ukv = self.buf(f"d{i}_u_ckv", (Me, 64), bf16)
-            ckv = self.buf(f"d{i}_ckv", (Me, 2 * inner), bf16, zero=False)
-            self.lg_fwd(L["ckv"], enc, ukv, ckv)
-            ck4, cv4 = self.v4(ckv, B, S, H, dk, 0), self.v4(ckv, B, S, H, dk, inner)
-            ops.head_transpose(cv4, out=vt_c)
             co = self.buf(f"d{i}_co", (R, pad64(inner)), bf16)
-            lsec = self.buf(f"d{i}_lsec", (B, H, ops.rup32(Ld)), f32)
-            ops.attention_fwd(self.v4(cq, B, Ld, H, dk), ck4, vt_c, self.v4(co, B, Ld, H, dk), lsec, scale=1.0, kmask=kmask, drop=self.drop(L["sites"][2], p))
+            if cross_cache is None:
+                ukv = self.buf(f"d{i}_u_ckv", (Me, 64), bf16)
+                ckv = self.buf(f"d{i}_ckv", (Me, 2 * inner), bf16, zero=False)
+                self.lg_fwd(L["ckv"], enc, ukv, ckv)
+                ck4, cv4 = self.v4(ckv, B, S, H, dk, 0), self.v4(ckv, B, S, H, dk, inner)
+                ops.head_transpose(cv4, out=vt_c)
+                lsec = self.buf(f"d{i}_lsec", (B, H, ops.rup32(Ld)), f32)
+                ops.attention_fwd(self.v4(cq, B, Ld, H, dk), ck4, vt_c, self.v4(co, B, Ld, H, dk), lsec, scale=1.0, kmask=kmask, drop=self.drop(L["sites"][2], p))
+            else:
+                Bc = cross_batch
+                rows = (B // Bc) * Ld  # query rows per encoder sequence: beams x positions
+                ck4, vt_i = cross_cache[i]
+                ops.attention_fwd(self.v4(cq, Bc, rows, H, dk), ck4, vt_i, self.v4(co, Bc, rows, H, dk), None, scale=1.0, kmask=kmask)
             uco = self.buf(f"d{i}_u_co", (R, 64), bf16)
             x2 = self.buf(f"d{i}_x2", (R, d), f32, zero=False)
             self.lg_fwd(L["co"], co, uco, x2, residual=x1, drop=self.drop(L["sites"][3], p))

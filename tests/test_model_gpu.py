@@ -219,3 +219,41 @@ def test_vit_lookahead_is_transparent():
     for a, b in zip(la, lb):
         assert abs(a - b) < 2e-4 * abs(a), (la, lb)
     assert relerr(pb, pa) < 1e-4
+
+
+@pytest.mark.gpu
+def test_decoder_cross_kv_cache_matches_replicated_encoder():
+    """generate's cross-attention K/V cache: beams folded into the query rows of ONE encoder copy give the logits of the
+    reference-shaped path (encoder output replicated per beam, K/V projected inside the decoder call)."""
+    from mrblip import prompt as P
+    from mrblip.tokenizer import FixtureTokenizer
+
+    g = load_golden("mr_tiny")
+    tok = FixtureTokenizer()
+    repl = P.annoying_replacement_dict(P.find_annoying_numbers(tok, 200)[0])
+    samples = _samples(g)
+    eng = _engine(_peft_sd(golden_state_dict(g)))
+    eng.training = False
+    lay = P.build_layout(tok, samples, repl, 8, T=3)
+    video = samples["video"].cuda()
+    B, S, d = video.shape[0], lay.S, eng.cfg.d_model
+    fr, img, xv, qb = eng.frames_forward(video)
+    L = eng._layout_dev(lay)
+    from mrblip import ops
+    inp = eng.buf("inputs_embeds", (B * S, d), torch.float32, zero=False)
+    ops.row_copy(fr, L["frame_src"], inp, L["frame_dst"])
+    ops.row_copy(eng.emb, L["emb_src"], inp, L["emb_dst"])
+    enc = eng.t5_encoder_forward(inp, B, S, L["mask"]).clone()
+    K, Ld = 3, 5
+    torch.manual_seed(3)
+    seqs = torch.randint(2, 300, (B * K, Ld))
+    seqs[:, 0] = 0
+    ones = torch.ones(B * K, Ld, dtype=torch.int32)
+    enc_k = enc.view(B, S, -1).repeat_interleave(K, 0).reshape(B * K * S, -1).contiguous()
+    mask_k = None if L["mask"] is None else L["mask"].repeat_interleave(K, 0).contiguous()
+    _, ref = eng.t5_decoder_forward(seqs, ones, enc_k, B * K, S, mask_k, labels=None)
+    ref = ref.clone()
+    cache = eng.t5_cross_kv(enc, B, S)
+    _, got = eng.t5_decoder_forward(seqs, ones, enc, B * K, S, L["mask"], labels=None, cross_cache=cache, cross_batch=B)
+    assert relerr(got, ref) < 2e-3
+    assert torch.equal(got.argmax(-1), ref.argmax(-1))

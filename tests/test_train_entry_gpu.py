@@ -68,3 +68,8 @@ def test_forward_backward_bridge_and_generate():
         assert abs(m2(samples)["loss"].item() - l0) < 1e-4
     res = model.generate(samples, num_beams=2, max_length=6)
     assert set(res) == {"duration", "prediction", "raw_prediction", "answer", "qid"} and len(res["prediction"]) == 2
+    # the cross-attention K/V cache (default) and the replicate-per-beam path decode the same text
+    model.generate_cross_cache = False
+    res2 = model.generate(samples, num_beams=2, max_length=6)
+    model.generate_cross_cache = True
+    assert res2["raw_prediction"] == res["raw_prediction"]
