@@ -178,6 +178,15 @@ class MrBlipEngine:
             self.ws[name] = t
         return t
 
+    def h2d(self, t: torch.Tensor, dtype=None) -> torch.Tensor:
+        """small host tensor -> device WITHOUT stalling the host on the stream (a pageable copy makes the host wait until the stream
+        reaches it, i.e. until everything enqueued so far has run): pinned staging buffer + non_blocking copy"""
+        if t.is_cuda:
+            return t if dtype is None else t.to(dtype)
+        if dtype is not None:
+            t = t.to(dtype)
+        return t.contiguous().pin_memory().to(self.dev, non_blocking=True)
+
     def new_site(self) -> int:
         self._site += 1
         return self._site
@@ -800,7 +809,7 @@ class MrBlipEngine:
         inner = H * dk
         Ld = dec_ids.shape[1]
         R, Me = B * Ld, B * S
-        ids32 = dec_ids.reshape(-1).to(self.dev, torch.int32)
+        ids32 = self.h2d(dec_ids.reshape(-1), torch.int32)
         rows = torch.arange(R, dtype=torch.int32, device=self.dev)
         x0 = self.buf("d_emb", (R, d), f32, zero=False)
         ops.row_copy(self.emb, ids32, x0, rows)
@@ -868,7 +877,7 @@ class MrBlipEngine:
         self.lg_fwd(self.t5["lm"], seq, ulm, logits)
         if labels is None:  # generation: logits only
             return None, logits
-        lab = labels.reshape(-1).to(self.dev, torch.int32)
+        lab = self.h2d(labels.reshape(-1), torch.int32)
         n_valid = int((labels != -100).sum())
         loss = self.buf("loss", (1,), f32)
         loss.zero_()
@@ -1089,8 +1098,16 @@ class MrBlipEngine:
 
     def _layout_dev(self, layout: EncoderLayout):
         dev = self.dev
-        return dict(frame_src=layout.frame_src.to(dev), frame_dst=layout.frame_dst.to(dev), emb_src=layout.emb_src.to(dev),
-                    emb_dst=layout.emb_dst.to(dev), mask=self.pad_mask(layout.attention_mask))
+        cached = getattr(layout, "_dev_cache", None)  # a layout object is immutable: its device index maps are uploaded once
+        if cached is not None and cached[0] is self:
+            return cached[1]
+        d = dict(frame_src=self.h2d(layout.frame_src), frame_dst=self.h2d(layout.frame_dst), emb_src=self.h2d(layout.emb_src),
+                 emb_dst=self.h2d(layout.emb_dst), mask=self.pad_mask(layout.attention_mask))
+        try:
+            layout._dev_cache = (self, d)
+        except AttributeError:
+            pass
+        return d
 
     def pad_mask(self, m: torch.Tensor) -> Optional[torch.Tensor]:
         """[B,S] 0/1 mask -> int32 [B, rup32(S)] on the device (the attention kernels read the key mask 16 B at a time)."""
@@ -1098,7 +1115,7 @@ class MrBlipEngine:
             return None  # nothing is masked: the attention kernels run their mask-free specialisation
         B, S = m.shape
         out = torch.zeros(B, ops.rup32(S), dtype=torch.int32, device=self.dev)
-        out[:, :S] = m.to(self.dev, torch.int32)
+        out[:, :S] = self.h2d(m, torch.int32)
         return out
 
     def dropout_site_map(self) -> Dict[str, tuple]:
@@ -1139,7 +1156,7 @@ class MrBlipEngine:
         """AdamW(beta=(0.9,0.999), wd on >=2-D non-bias/ln params) as in runner_base.py:102-132."""
         self.opt_step += 1
         t = self.opt_step
-        self.hyper.copy_(torch.tensor([lr, 1.0 / (1 - beta1 ** t), 1.0 / math.sqrt(1 - beta2 ** t), grad_scale], dtype=f32))
+        self.hyper.copy_(torch.tensor([lr, 1.0 / (1 - beta1 ** t), 1.0 / math.sqrt(1 - beta2 ** t), grad_scale], dtype=f32).pin_memory(), non_blocking=True)
         nd = self.n_decay
         ops.adamw(self.flat[:nd], self.grad[:nd], self.adam_m[:nd], self.adam_v[:nd], self.hyper, beta1, beta2, eps, weight_decay)
         ops.adamw(self.flat[nd:], self.grad[nd:], self.adam_m[nd:], self.adam_v[nd:], self.hyper, beta1, beta2, eps, 0.0)
