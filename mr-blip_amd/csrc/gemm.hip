@@ -578,7 +578,7 @@ static int gemm_dispatch(const void* A, long long lda, const void* W, long long 
   MRB_REQUIRE(!(p_drop > 0.f) || seed_ptr, "gemm: dropout needs a device seed pointer");
   // tile_cfg: 0 auto, 1 = 256x256 (8 waves, persistent), 2 = 128x128, 3 = skinny, 4 = 64x128, 5 = 64x64; measured and not auto-selected:
   // 6 = 256x256 with 4 waves of 128x128 (1 wave/SIMD: 0.7x), 7 = 256x128 BK=32 3-stage (= 128x128), [128x128 BK=32 at 3-4 blocks/CU: 0.8x,
-  // 256x128 / 128x256 BK=64 with one 4-wave block per CU: 0.6x]
+  // 256x128 / 128x256 BK=64 with one 4-wave block per CU: 0.6x; 256x128 / 128x256 BK=32 with 8 waves of 64x64, two blocks per CU: 0.7x]
   int cfg = tile_cfg;
   if (cfg == 0) {
     if (M <= 64 && !gated) cfg = 3;

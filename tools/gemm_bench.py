@@ -42,7 +42,7 @@ def main():
         out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
         row = dict(name=name, M=M, N=N, K=K)
         fl = 2.0 * M * N * K
-        cfgs = [3] if (M <= 64 or N <= 64) else [2, 8]
+        cfgs = [3] if (M <= 64 or N <= 64) else [2, 4, 8]
         for cfg in cfgs:
             t = timeit(lambda: ops.gemm(a, w, out, tile_cfg=cfg))
             row[f"cfg{cfg}_us"] = round(t * 1e6, 1)
