@@ -72,6 +72,10 @@ int mrblip_head_transpose(const void* src, const long long* strides, void* dst, 
 
 /* frames fp32 [F,3,IMG,IMG] -> bf16 patch rows [F*(IMG/P)^2, Kpad] in Conv2d weight order (eva_vit.py:196-203) */
 int mrblip_patchify(const float* video, void* out_bf16, int F, int IMG, int P, int Kpad, mrblip_stream_t stream);
+/* the same from uint8 frames [F,3,IMG,IMG] with the processor's ToTensor + Normalize(mean3, std3) applied on the fly
+ * (blip_processors.py:63-66; mean3 / std3 are HOST arrays of 3 floats); bit-identical to normalising first */
+int mrblip_patchify_u8(const uint8_t* video, const float* mean3, const float* std3, void* out_bf16, int F, int IMG, int P, int Kpad,
+                       mrblip_stream_t stream);
 /* x = [cls ; patches] + pos  (eva_vit.py:328-331) */
 int mrblip_vit_assemble(const float* patch, const float* cls, const float* pos, float* x, int F, int NP, int D, mrblip_stream_t stream);
 /* dst[dst_idx[i],:] (=|+=) src[src_idx[i],:]; src_idx<0 -> zeros.  Embedding gathers and the frame/timestamp

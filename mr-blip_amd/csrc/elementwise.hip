@@ -27,6 +27,30 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__
   }
 }
 
+// The same from uint8 frames: the processor's ToTensor + Normalize (blip_processors.py:63-66: x/255, then (x - mean)/std per
+// channel, all fp32, correctly rounded divisions) is applied on the fly -> bit-identical patches from a quarter of the bytes.
+__global__ __launch_bounds__(256) void patchify_u8_kernel(const uint8_t* __restrict__ img, bf16_t* __restrict__ out, int IMG, int P, int G, int Kpad,
+                                                          float m0, float m1, float m2, float s0, float s1, float s2) {
+  const int f = blockIdx.y, gy = blockIdx.x;
+  const int K = 3 * P * P;
+  bf16_t* orow = out + ((long long)(f * G + gy) * G) * Kpad;
+  for (int c = 0; c < 3; ++c) {
+    const float mean = c == 0 ? m0 : c == 1 ? m1 : m2, stdv = c == 0 ? s0 : c == 1 ? s1 : s2;
+    for (int py = 0; py < P; ++py) {
+      const uint8_t* src = img + (((long long)f * 3 + c) * IMG + gy * P + py) * IMG;
+      for (int x = threadIdx.x; x < G * P; x += 256) {
+        const int gx = x / P, px = x % P;
+        const float v = __fdiv_rn(__fsub_rn(__fdiv_rn((float)src[x], 255.0f), mean), stdv);
+        orow[(long long)gx * Kpad + c * P * P + py * P + px] = f2bf(v);
+      }
+    }
+  }
+  for (int i = threadIdx.x; i < G * (Kpad - K); i += 256) {
+    const int gx = i / (Kpad - K), k = K + i % (Kpad - K);
+    orow[(long long)gx * Kpad + k] = 0;
+  }
+}
+
 // x[f,0,:] = cls + pos[0]; x[f,1+p,:] = patch[f*NP+p,:] + pos[1+p]   (eva_vit.py:328-331), fp32 residual stream
 __global__ __launch_bounds__(256) void vit_assemble_kernel(const float* __restrict__ patch, const float* __restrict__ cls,
                                                            const float* __restrict__ pos, float* __restrict__ x, int NP, int D) {
@@ -308,6 +332,14 @@ extern "C" int mrblip_patchify(const float* video, void* out_bf16, int F, int IM
   const int G = IMG / P;
   hipLaunchKernelGGL(patchify_kernel, dim3(G, F), dim3(256), 0, stream, video, (bf16_t*)out_bf16, IMG, P, G, Kpad);
   return mrblip_check_launch("patchify");
+}
+extern "C" int mrblip_patchify_u8(const uint8_t* video, const float* mean3, const float* std3, void* out_bf16, int F, int IMG, int P, int Kpad,
+                                  hipStream_t stream) {
+  MRB_REQUIRE(F > 0 && P > 0 && IMG % P == 0 && Kpad >= 3 * P * P && Kpad % 64 == 0 && mean3 && std3, "patchify_u8: bad arguments");
+  const int G = IMG / P;
+  hipLaunchKernelGGL(patchify_u8_kernel, dim3(G, F), dim3(256), 0, stream, video, (bf16_t*)out_bf16, IMG, P, G, Kpad, mean3[0], mean3[1], mean3[2],
+                     std3[0], std3[1], std3[2]);
+  return mrblip_check_launch("patchify_u8");
 }
 extern "C" int mrblip_vit_assemble(const float* patch, const float* cls, const float* pos, float* x, int F, int NP, int D, hipStream_t stream) {
   MRB_REQUIRE(F > 0 && NP > 0 && D % 4 == 0, "vit_assemble: bad shape");

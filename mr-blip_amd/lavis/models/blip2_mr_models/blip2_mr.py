@@ -111,6 +111,11 @@ class BLIP2_MR(BaseModel):
         return P.build_layout(self.t5_tokenizer, samples, self.annoying_numbers_replacement_dict, n, T, self.max_txt_len,
                               no_task_prompt="no_task_prompt" in self.task)
 
+    def _frames_to_device(self, v):
+        """fp32 frames already normalised by the processor (the reference's contract), or raw uint8 frames [B,T,3,H,W]: those stay uint8 —
+        a quarter of the H2D bytes — and ToTensor + Normalize(CLIP mean/std) is fused into the patch-embed load."""
+        return v.to(self._device) if v.dtype == torch.uint8 else v.to(self._device, torch.float32)
+
     _staged_next = None  # (host tensor of the next batch's frames, its device copy): see forward()
     generate_cross_cache = True  # project the decoder's cross-attention K/V once per clip (False: per step and beam, for the A/B test)
 
@@ -121,14 +126,14 @@ class BLIP2_MR(BaseModel):
         if self._staged_next is not None and self._staged_next[0] is src:
             video = self._staged_next[1]  # the device copy whose ViT features were prefetched during the previous step
         else:
-            video = src.to(self._device, torch.float32)
+            video = self._frames_to_device(src)
         self._staged_next = None
         layout = self._layout(samples)
         need_grad = torch.is_grad_enabled() and (self.trainable_decay.requires_grad or self.trainable_no_decay.requires_grad)
         nxt = samples.get("next_video") if need_grad else None
         nxt_dev = None
         if nxt is not None:
-            nxt_dev = nxt.to(self._device, torch.float32)
+            nxt_dev = self._frames_to_device(nxt)
             self._staged_next = (nxt, nxt_dev)
         loss = _TrainStep.apply(self.trainable_decay, self.trainable_no_decay, self, video, layout, need_grad, nxt_dev)
         return {"loss": loss}
@@ -143,7 +148,7 @@ class BLIP2_MR(BaseModel):
         was_training = eng.training
         eng.training = False
         try:
-            video = samples["video"].to(self._device, torch.float32)
+            video = self._frames_to_device(samples["video"])
             s2 = dict(samples)
             s2.setdefault("relevant_windows", ["[[0, 0]]"] * video.shape[0])
             s2["relevant_windows"] = [str(w) for w in s2["relevant_windows"]]

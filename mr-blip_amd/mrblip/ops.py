@@ -59,6 +59,7 @@ _lora_down = _sig("mrblip_gemm_lora_down", vp, ll, vp, ll, i32, i32, i32, vp, ll
 _gemm_lora_dx = _sig("mrblip_gemm_lora_dx", vp, ll, vp, ll, vp, ll, vp, ll, i32, i32, i32, vp, ll, i32, vp, ll, vp, u32, f32, i32, vp)
 _drop_b16 = _sig("mrblip_dropout_bf16", vp, ll, vp, ll, i32, i32, vp, u32, f32, vp)
 _patchify = _sig("mrblip_patchify", vp, vp, i32, i32, i32, i32, vp)
+_patchify_u8 = _sig("mrblip_patchify_u8", vp, C.POINTER(C.c_float), C.POINTER(C.c_float), vp, i32, i32, i32, i32, vp)
 _vit_asm = _sig("mrblip_vit_assemble", vp, vp, vp, vp, i32, i32, i32, vp)
 _row_copy = _sig("mrblip_row_copy", vp, ll, vp, vp, ll, vp, i32, i32, i32, vp)
 _mean_pool = _sig("mrblip_mean_pool", vp, vp, i32, i32, i32, vp)
@@ -77,7 +78,7 @@ EXPORTS = [
     "mrblip_patchify", "mrblip_vit_assemble", "mrblip_row_copy", "mrblip_mean_pool", "mrblip_mean_pool_bwd",
     "mrblip_cast_dropout", "mrblip_gelu_bwd", "mrblip_gated_gelu_bwd", "mrblip_cross_entropy", "mrblip_adamw",
     "mrblip_seed_bump", "mrblip_lora_dx_add", "mrblip_dropout_bf16", "mrblip_colsum", "mrblip_lora_pack", "mrblip_lora_tn",
-    "mrblip_lora_grads", "mrblip_gemm_lora_down", "mrblip_gemm_lora_dx",
+    "mrblip_lora_grads", "mrblip_gemm_lora_down", "mrblip_gemm_lora_dx", "mrblip_patchify_u8",
 ]
 
 
@@ -254,9 +255,16 @@ def attention_bwd(q, k, v, o, do, kt, qt, dot, lse, delta, dq, dk, dv, *, scale=
 
 
 # ------------------------------------------------------------------------------------------------ side kernels
-def patchify(video: torch.Tensor, out: torch.Tensor, patch: int):
+CLIP_MEAN, CLIP_STD = (0.48145466, 0.4578275, 0.40821073), (0.26862954, 0.26130258, 0.27577711)  # blip_processors.py:63-66
+
+
+def patchify(video: torch.Tensor, out: torch.Tensor, patch: int, mean=CLIP_MEAN, std=CLIP_STD):
+    """video: fp32 normalised frames, or uint8 frames (normalisation fused into the load)"""
     F_, _, IMG, _ = video.shape
-    _chk(_patchify(_p(video), _p(out), F_, IMG, patch, out.shape[1], _stream()))
+    if video.dtype == torch.uint8:
+        _chk(_patchify_u8(_p(video), (C.c_float * 3)(*mean), (C.c_float * 3)(*std), _p(out), F_, IMG, patch, out.shape[1], _stream()))
+    else:
+        _chk(_patchify(_p(video), _p(out), F_, IMG, patch, out.shape[1], _stream()))
 
 
 def vit_assemble(patch, cls, pos, x):

@@ -272,6 +272,16 @@ def test_patchify_assemble_rowcopy_meanpool(ops):
     ops.patchify(video, out, P)
     ref = video.reshape(F_, 3, G, P, G, P).permute(0, 2, 4, 1, 3, 5).reshape(F_ * G * G, 3 * P * P)
     assert torch.equal(out[:, :588], ref.bfloat16()) and out[:, 588:].abs().max() == 0
+    # uint8 frames with the processor's ToTensor + Normalize fused into the load: bit-identical to normalising first
+    u8 = torch.randint(0, 256, (F_, 3, IMG, IMG), device=dev(), dtype=torch.uint8)
+    mean = torch.tensor(ops.CLIP_MEAN, device=dev()).view(1, 3, 1, 1)
+    std = torch.tensor(ops.CLIP_STD, device=dev()).view(1, 3, 1, 1)
+    norm = (u8.float() / 255.0 - mean) / std
+    a = torch.full((F_ * G * G, 640), 7.0, dtype=torch.bfloat16, device=dev())
+    b = torch.full_like(a, 5.0)
+    ops.patchify(norm.contiguous(), a, P)
+    ops.patchify(u8, b, P)
+    assert torch.equal(a, b)
     patch = torch.randn(F_ * G * G, D, device=dev())
     cls, pos = torch.randn(D, device=dev()), torch.randn(G * G + 1, D, device=dev())
     x = torch.empty(F_, G * G + 1, D, device=dev())

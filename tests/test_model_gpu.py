@@ -257,3 +257,26 @@ def test_decoder_cross_kv_cache_matches_replicated_encoder():
     _, got = eng.t5_decoder_forward(seqs, ones, enc, B * K, S, L["mask"], labels=None, cross_cache=cache, cross_batch=B)
     assert relerr(got, ref) < 2e-3
     assert torch.equal(got.argmax(-1), ref.argmax(-1))
+
+
+@pytest.mark.gpu
+def test_uint8_frames_equal_normalised_frames():
+    """raw uint8 frames (normalisation fused into the patch-embed load) give the step of the fp32 frames the processor would have made"""
+    from mrblip import ops, prompt as P
+    from mrblip.tokenizer import FixtureTokenizer
+
+    g = load_golden("mr_tiny")
+    tok = FixtureTokenizer()
+    repl = P.annoying_replacement_dict(P.find_annoying_numbers(tok, 200)[0])
+    samples = _samples(g)
+    eng = _engine(_peft_sd(golden_state_dict(g)))
+    eng.training = False
+    lay = P.build_layout(tok, samples, repl, 8, T=3)
+    shape = samples["video"].shape
+    torch.manual_seed(11)
+    u8 = torch.randint(0, 256, shape, dtype=torch.uint8).cuda()
+    mean = torch.tensor(ops.CLIP_MEAN).view(1, 1, 3, 1, 1).cuda()
+    std = torch.tensor(ops.CLIP_STD).view(1, 1, 3, 1, 1).cuda()
+    l_f = eng.forward_backward(((u8.float() / 255.0 - mean) / std).contiguous(), lay, backward=False).item()
+    l_u = eng.forward_backward(u8, lay, backward=False).item()
+    assert l_f == l_u
