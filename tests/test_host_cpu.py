@@ -73,3 +73,45 @@ def test_bias_lut_matches_bucket_golden():
         ref = orc.t5_bias(table, 300, 300, bidir)[0]                       # [H, q, k]
         rel = (torch.arange(300)[None, :] - torch.arange(300)[:, None]).clamp(-128, 128) + 128
         assert torch.equal(lut[:, rel], ref)
+
+
+def test_interleave_layout_edge_cases_against_oracle():
+    """Ragged and extreme inputs of the prompt builder against the reference-pinned oracle restatement (bit-exact rows, masks, labels):
+    one frame; batches whose clips differ in timestamp-token counts (multi-token 'annoying' integers are remapped, durations are not
+    all equal -> left zero padding with mask 1); queries of very different lengths (right padding with mask 0); a query beyond
+    max_txt_len = 200 tokens (truncation); empty target; many target windows."""
+    torch.manual_seed(0)
+    tok = FixtureTokenizer()
+    repl = P.annoying_replacement_dict(P.find_annoying_numbers(tok, 200)[0])
+    d = 16
+    emb = torch.randn(tok.vocab_size if hasattr(tok, "vocab_size") else 32128, d)
+    orc = O.Oracle({"t5_model.shared.weight": emb}, TINY_CFG)
+    long_q = "Query: " + " ".join(["word%d" % i for i in range(300)]) + "\n"
+    cases = [
+        dict(T=1, n=4, dur=[7.0], q=["Query: a\n"], w=["[[0, 1]]"]),
+        dict(T=3, n=2, dur=[150.0, 9.49, 1234.5], q=["Query: a dog\n", "Query: a much longer query about several different things\n", "Query: b\n"],
+             w=["[[8, 16]]", "[[0, 2], [4, 6], [100, 120]]", ""]),
+        dict(T=5, n=1, dur=[30.0, 30.0], q=[long_q, "Query: short\n"], w=["[[1, 2]]", "[[3, 4]]"]),
+        dict(T=4, n=8, dur=[199.5, 0.4], q=["Query: x\n", "Query: y\n"], w=["[[0, 199]]", "[[0, 0]]"]),
+    ]
+    for c in cases:
+        B, T, n = len(c["dur"]), c["T"], c["n"]
+        dur = torch.tensor(c["dur"])
+        ts = torch.stack([torch.tensor([round((i + 0.5) * float(x) / T, 2) for i in range(T)]) for x in c["dur"]])
+        samples = dict(video=torch.zeros(B, T, 3, 2, 2), timestamps=ts, duration=dur, query_prompt=c["q"],
+                       task_prompt=["Given the video and the query, find the relevant windows.\nRelevant windows: "] * B,
+                       video_prompt_end=["<extra_id_0>"] * B, relevant_windows=c["w"])
+        frames = torch.randn(B, T * n, d)
+        embs, atts = orc.prompt_concatenation(tok, ts, dur, frames, samples["video_prompt_end"], samples["query_prompt"], samples["task_prompt"], repl, n)
+        lay = P.build_layout(tok, samples, repl, n, T=T)
+        assert lay.S == embs.shape[1], (c["T"], lay.S, embs.shape)
+        assert torch.equal(lay.attention_mask.long(), atts)
+        inp = torch.full((B * lay.S, d), float("nan"))
+        inp[lay.frame_dst.long()] = frames.reshape(-1, d)[lay.frame_src.long()]
+        src = lay.emb_src.long()
+        inp[lay.emb_dst.long()] = torch.where((src >= 0)[:, None], emb[src.clamp_min(0)], torch.zeros(1, d))
+        assert not torch.isnan(inp).any()
+        assert torch.equal(inp.reshape(B, lay.S, d), embs)
+        ans = tok(samples["relevant_windows"], padding="longest", truncation=True, max_length=200, return_tensors="pt")
+        labels = ans.input_ids.masked_fill(ans.input_ids == tok.pad_token_id, -100)
+        assert torch.equal(lay.labels, labels) and torch.equal(lay.decoder_input_ids, O.shift_right(labels))
