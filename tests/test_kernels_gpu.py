@@ -38,7 +38,7 @@ def keep_mask(shape, seed, site, p):
 
 
 @pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 7, 8, 9, 10, 11])
-@pytest.mark.parametrize("M,N,K", [(300, 264, 128), (64, 520, 192), (513, 1408, 576), (33, 264, 2304)])
+@pytest.mark.parametrize("M,N,K", [(300, 264, 128), (64, 520, 192), (513, 1408, 576), (33, 264, 2304), (1, 8, 64), (257, 8, 128)])
 def test_gemm_plain(ops, cfg, M, N, K):
     torch.manual_seed(0)
     a = bf(torch.randn(M, K, device=dev()))
@@ -151,7 +151,8 @@ def _lut_bias(lut, Sq, Sk):
     return lut[:, rel_]  # [H,Sq,Sk]
 
 
-@pytest.mark.parametrize("B,H,Sq,Sk,D", [(2, 3, 257, 257, 88), (1, 2, 32, 257, 64), (2, 4, 300, 300, 64), (1, 2, 12, 333, 16), (2, 2, 17, 17, 24)])
+@pytest.mark.parametrize("B,H,Sq,Sk,D", [(2, 3, 257, 257, 88), (1, 2, 32, 257, 64), (2, 4, 300, 300, 64), (1, 2, 12, 333, 16), (2, 2, 17, 17, 24),
+                                         (1, 1, 1, 1, 64), (1, 1, 33, 65, 64), (1, 2, 65, 1, 64), (3, 1, 64, 64, 88)])
 def test_attention_fwd(ops, B, H, Sq, Sk, D):
     torch.manual_seed(4)
     scale = D ** -0.5
