@@ -104,11 +104,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if os.environ.get("MRB_BENCH_SHARE_GPU"):  # test hook: several ranks on ONE GPU (gloo) to exercise the N > 1 code path on a 1-GPU box
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)  # "nccl" == RCCL on ROCm
+        if os.environ.get("MRB_BENCH_SHARE_GPU"):
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)  # "nccl" == RCCL on ROCm
 
     from mrblip.engine import EngineConfig, MrBlipEngine, RandomSource
     from mrblip import ops, prompt as P

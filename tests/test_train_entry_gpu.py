@@ -73,3 +73,22 @@ def test_forward_backward_bridge_and_generate():
     res2 = model.generate(samples, num_beams=2, max_length=6)
     model.generate_cross_cache = True
     assert res2["raw_prediction"] == res["raw_prediction"]
+
+
+def test_bench_two_ranks_share_one_gpu():
+    """bench.py's N > 1 path (process group, per-rank clips, gradient all-reduce of the flat buffer, barrier-bracketed timing, max over
+    ranks, rank-0 JSON line) with two ranks on ONE GPU over gloo — the RCCL run itself needs the multi-GPU node."""
+    import json
+    import subprocess
+    import sys
+
+    env = dict(os.environ, MRB_BENCH_SHARE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29633",
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert abs(d["value"] - 2 * 1e3 / d["ms_per_step"]) < 1e-2 * d["value"]
+    assert d["roofline"]["bound"] == "mfma" and 0 < d["roofline"]["frac"] < 1
