@@ -11,6 +11,7 @@ Frozen: ViT, Q-Former, query_tokens, T5 base weights.  Trainable: LoRA A/B, t5_p
 """
 from __future__ import annotations
 
+import contextlib
 import math
 import os
 from dataclasses import dataclass, field
@@ -816,8 +817,33 @@ class MrBlipEngine:
         x = self.buf("d_x0", (R, d), f32, zero=False)
         ops.cast_dropout(x0, out_f32=x, drop=self.drop(self.t5["sites"][2], p))
         vt_s = self.buf("d_vt_s", (B, H, ops.rup32(dk), ops.rup32(Ld)), bf16)
-        vt_c = self.buf("d_vt_c", (B, H, ops.rup32(dk), ops.rup32(S)), bf16) if cross_cache is None else None
         dmask = self.pad_mask(dec_mask)
+        # Cross-attention K / V of all layers depend only on the encoder output: they are projected (LoRA included), and V^T / K^T
+        # (for the backward) transposed, on the side stream while the main stream walks the decoder's serial chain; each layer waits
+        # for its own event.  Per-layer buffers (the projections are kept for the backward anyway).
+        ckv_side = []
+        if cross_cache is None:
+            use_side = self.grad_side_stream_enabled and want_grad and labels is not None and os.environ.get("MRB_DEC_FWD_SIDE", "1") == "1"
+            st = self._grad_stream() if use_side else None
+            if use_side:
+                ev0 = torch.cuda.Event()
+                ev0.record()
+                st.wait_event(ev0)
+            for i, L in enumerate(self.t5["dec"]):
+                ukv = self.buf(f"d{i}_u_ckv", (Me, 64), bf16)
+                ckv = self.buf(f"d{i}_ckv", (Me, 2 * inner), bf16, zero=False)
+                vt_i = self.buf(f"d{i}_vt_c", (B, H, ops.rup32(dk), ops.rup32(S)), bf16)
+                kt_i = self.buf(f"d{i}_kt_c", (B, H, ops.rup32(dk), ops.rup32(S)), bf16) if want_grad else None
+                with torch.cuda.stream(st) if use_side else contextlib.nullcontext():
+                    self.lg_fwd(L["ckv"], enc, ukv, ckv)
+                    ops.head_transpose(self.v4(ckv, B, S, H, dk, inner), out=vt_i)
+                    if kt_i is not None:
+                        ops.head_transpose(self.v4(ckv, B, S, H, dk, 0), out=kt_i)
+                    ready = None
+                    if use_side:
+                        ready = torch.cuda.Event()
+                        ready.record()
+                ckv_side.append((self.v4(ckv, B, S, H, dk, 0), vt_i, ready))
         for i, L in enumerate(self.t5["dec"]):
             xn = self.buf(f"d{i}_xn", (R, pad64(d)), bf16)
             ops.rmsnorm_fwd(x, L["ln0"], c.t5_eps, out_bf16=xn)
@@ -840,13 +866,11 @@ class MrBlipEngine:
             self.lg_fwd(L["cq"], xn1, ucq, cq)
             co = self.buf(f"d{i}_co", (R, pad64(inner)), bf16)
             if cross_cache is None:
-                ukv = self.buf(f"d{i}_u_ckv", (Me, 64), bf16)
-                ckv = self.buf(f"d{i}_ckv", (Me, 2 * inner), bf16, zero=False)
-                self.lg_fwd(L["ckv"], enc, ukv, ckv)
-                ck4, cv4 = self.v4(ckv, B, S, H, dk, 0), self.v4(ckv, B, S, H, dk, inner)
-                ops.head_transpose(cv4, out=vt_c)
+                ck4, vt_i, ready = ckv_side[i]
+                if ready is not None:
+                    torch.cuda.current_stream().wait_event(ready)
                 lsec = self.buf(f"d{i}_lsec", (B, H, ops.rup32(Ld)), f32)
-                ops.attention_fwd(self.v4(cq, B, Ld, H, dk), ck4, vt_c, self.v4(co, B, Ld, H, dk), lsec, scale=1.0, kmask=kmask, drop=self.drop(L["sites"][2], p))
+                ops.attention_fwd(self.v4(cq, B, Ld, H, dk), ck4, vt_i, self.v4(co, B, Ld, H, dk), lsec, scale=1.0, kmask=kmask, drop=self.drop(L["sites"][2], p))
             else:
                 Bc = cross_batch
                 rows = (B // Bc) * Ld  # query rows per encoder sequence: beams x positions
@@ -894,7 +918,8 @@ class MrBlipEngine:
         R, Me = B * Ld, B * S
         dmask = self.pad_mask(dec_mask)
         gb = self.buf("db_g", (R, 64), bf16)
-        gbe = self.buf("db_ge", (Me, 64), bf16)
+        dside = self.grad_side_stream_enabled and os.environ.get("MRB_DEC_SIDE", "1") == "1"
+        gbs = [self.buf(f"db_g{j}", (R, 64), bf16) for j in range(6)]  # one g buffer per LoRA group of a layer (side-stream readers)
         dseq = self.buf("db_dseq", (R, d), f32, zero=False)
         self.lg_bwd(self.t5["lm"], self.ws["d_dlogits"], self.ws["d_seq"], self.ws["d_u_lm"], gb, dseq)
         t = self.buf("db_t", (R, d), f32, zero=False)
@@ -904,45 +929,58 @@ class MrBlipEngine:
         ops.rmsnorm_bwd(t, self.ws["d_xfinal_in"], self.t5["dec_final"], c.t5_eps, dx)
         denc = self.buf("db_denc", (Me, d), f32)
         denc.zero_()
-        dyb = self.buf("db_dyb", (R, pad64(d)), bf16)
+        dybs = [self.buf(f"db_dyb{j}", (R, pad64(d)), bf16) for j in range(3)]
         dyact = self.buf("db_dyact", (R, ff), bf16, zero=False)
         dh = self.buf("db_dh", (R, 2 * ff), bf16, zero=False)
         dxn = self.buf("db_dxn", (R, d), f32, zero=False)
         do = self.buf("db_do", (R, inner), bf16, zero=False)
         dqkv = self.buf("db_dqkv", (R, 3 * inner), bf16, zero=False)
         dcq = self.buf("db_dcq", (R, inner), bf16, zero=False)
-        dckv = self.buf("db_dckv", (Me, 2 * inner), bf16, zero=False)
         rl, rs = ops.rup32(Ld), ops.rup32(S)
         kt_s, qt_s, dot_s = (self.buf(n, (B, H, ops.rup32(dk), rl), bf16) for n in ("db_kt_s", "db_qt_s", "db_dot_s"))
-        kt_c = self.buf("db_kt_c", (B, H, ops.rup32(dk), rs), bf16)
         delta = self.buf("db_delta", (B, H, rl), f32)
         for i in reversed(range(len(self.t5["dec"]))):
             L = self.t5["dec"][i]
+            # side stream (see the encoder backward): the LoRA weight-gradient launches of this layer, and the WHOLE backward of the
+            # cross-attention K/V projection (it only feeds denc, which nobody reads before the encoder backward; per-layer dckv / g
+            # buffers, the accumulation into denc stays in order on that stream).  One join per layer for the buffers written once per layer.
+            self.side_join()
+            dyb = dybs[0]
             ops.cast_dropout(dx, out_bf16=dyb, drop=self.drop(L["sites"][5], p))
-            self.lg_bwd(L["wo"], dyb, self.ws[f"d{i}_y"], self.ws[f"d{i}_u_wo"], gb, dyact)
+            self.lg_bwd(L["wo"], dyb, self.ws[f"d{i}_y"], self.ws[f"d{i}_u_wo"], gbs[0], dyact, side=dside)
             ops.gated_gelu_bwd(dyact, self.ws[f"d{i}_h"], dh, drop=self.drop(L["sites"][4], p))
-            self.lg_bwd(L["wi"], dh, self.ws[f"d{i}_xn2"], self.ws[f"d{i}_u_wi"], gb, dxn)
+            self.lg_bwd(L["wi"], dh, self.ws[f"d{i}_xn2"], self.ws[f"d{i}_u_wi"], gbs[1], dxn, side=dside)
             ops.rmsnorm_bwd(dxn, self.ws[f"d{i}_x2"], L["ln2"], c.t5_eps, other, dx_add=dx)
             dx, other = other, dx
             # cross attention
+            dyb = dybs[1]
             ops.cast_dropout(dx, out_bf16=dyb, drop=self.drop(L["sites"][3], p))
-            self.lg_bwd(L["co"], dyb, self.ws[f"d{i}_co"], self.ws[f"d{i}_u_co"], gb, do)
+            self.lg_bwd(L["co"], dyb, self.ws[f"d{i}_co"], self.ws[f"d{i}_u_co"], gbs[2], do, side=dside)
+            dckv = self.buf(f"db_dckv{i}", (Me, 2 * inner), bf16, zero=False)
             cq, ckv, co = self.ws[f"d{i}_cq"], self.ws[f"d{i}_ckv"], self.ws[f"d{i}_co"]
             q4, k4, v4 = self.v4(cq, B, Ld, H, dk), self.v4(ckv, B, S, H, dk, 0), self.v4(ckv, B, S, H, dk, inner)
             do4 = self.v4(do, B, Ld, H, dk)
-            ops.head_transpose(k4, out=kt_c)
+            kt_c = self.ws[f"d{i}_kt_c"]  # made beside the forward (t5_decoder_forward)
             ops.head_transpose(q4, out=qt_s)
             ops.head_transpose(do4, out=dot_s)
             ops.attention_bwd(q4, k4, v4, self.v4(co, B, Ld, H, dk), do4, kt_c, qt_s, dot_s, self.ws[f"d{i}_lsec"], delta,
                               self.v4(dcq, B, Ld, H, dk), self.v4(dckv, B, S, H, dk, 0), self.v4(dckv, B, S, H, dk, inner),
                               scale=1.0, kmask=kmask, drop=self.drop(L["sites"][2], p))
-            self.lg_bwd(L["ckv"], dckv, enc, self.ws[f"d{i}_u_ckv"], gbe, denc, residual=denc)
-            self.lg_bwd(L["cq"], dcq, self.ws[f"d{i}_xn1"], self.ws[f"d{i}_u_cq"], gb, dxn)
+            if dside:
+                st, ev = self._grad_stream(), torch.cuda.Event()
+                ev.record()
+                with torch.cuda.stream(st):
+                    st.wait_event(ev)
+                    self.lg_bwd(L["ckv"], dckv, enc, self.ws[f"d{i}_u_ckv"], self.buf(f"db_ge{i}", (Me, 64), bf16), denc, residual=denc)
+            else:
+                self.lg_bwd(L["ckv"], dckv, enc, self.ws[f"d{i}_u_ckv"], self.buf(f"db_ge{i}", (Me, 64), bf16), denc, residual=denc)
+            self.lg_bwd(L["cq"], dcq, self.ws[f"d{i}_xn1"], self.ws[f"d{i}_u_cq"], gbs[3], dxn, side=dside)
             ops.rmsnorm_bwd(dxn, self.ws[f"d{i}_x1"], L["ln1"], c.t5_eps, other, dx_add=dx)
             dx, other = other, dx
             # self attention
+            dyb = dybs[2]
             ops.cast_dropout(dx, out_bf16=dyb, drop=self.drop(L["sites"][1], p))
-            self.lg_bwd(L["o"], dyb, self.ws[f"d{i}_o"], self.ws[f"d{i}_u_o"], gb, do)
+            self.lg_bwd(L["o"], dyb, self.ws[f"d{i}_o"], self.ws[f"d{i}_u_o"], gbs[4], do, side=dside)
             qkv, o = self.ws[f"d{i}_qkv"], self.ws[f"d{i}_o"]
             q4, k4, v4 = self.v4(qkv, B, Ld, H, dk, 0), self.v4(qkv, B, Ld, H, dk, inner), self.v4(qkv, B, Ld, H, dk, 2 * inner)
             do4 = self.v4(do, B, Ld, H, dk)
@@ -952,10 +990,11 @@ class MrBlipEngine:
             ops.attention_bwd(q4, k4, v4, self.v4(o, B, Ld, H, dk), do4, kt_s, qt_s, dot_s, self.ws[f"d{i}_lse"], delta,
                               self.v4(dqkv, B, Ld, H, dk, 0), self.v4(dqkv, B, Ld, H, dk, inner), self.v4(dqkv, B, Ld, H, dk, 2 * inner),
                               scale=1.0, bias_lut=self.lut_dec, kmask=dmask, causal=True, drop=self.drop(L["sites"][0], p))
-            self.lg_bwd(L["qkv"], dqkv, self.ws[f"d{i}_xn"], self.ws[f"d{i}_u_qkv"], gb, dxn)
+            self.lg_bwd(L["qkv"], dqkv, self.ws[f"d{i}_xn"], self.ws[f"d{i}_u_qkv"], gbs[5], dxn, side=dside)
             ops.rmsnorm_bwd(dxn, self.ws[f"d{i}_xin"], L["ln0"], c.t5_eps, other, dx_add=dx)
             dx, other = other, dx
         # the decoder embeddings are frozen: nothing flows below dx
+        self.side_join()  # denc (and the decoder adapters' gradients) are complete
         return denc
 
     # ------------------------------------------------------------------------------------------ whole step
