@@ -38,53 +38,60 @@ struct GemmArgs {
   DropoutArg a_drop;  // skinny kernel only: dropout of the A operand as it is loaded (zeroing; the 1/(1-p) is applied to the result)
 };
 
-// v: 4 consecutive columns n0..n0+3 of row m (raw accumulator). Applies bias -> (pre-activation copy) -> GELU -> dropout -> residual.
-__device__ __forceinline__ void epilogue_apply4(const GemmArgs& p, int m, int n0, float v[4], int ncols, uint2* pre_out) {
+// v0..v3: 4 consecutive columns n0..n0+3 of row m (raw accumulator). Applies bias -> (pre-activation copy) -> GELU -> dropout -> residual.
+// (scalars by reference and `pre` always produced: a float[4] handed over by pointer, or `flag ? &local : nullptr`, makes the
+// compiler keep the values in scratch memory)
+__device__ __forceinline__ void epilogue_apply4(const GemmArgs& p, int m, int n0, float& v0, float& v1, float& v2, float& v3, int ncols, uint2& pre) {
   if (p.bias) {
     const float4 b = *reinterpret_cast<const float4*>(p.bias + n0);
-    v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+    v0 += b.x; v1 += b.y; v2 += b.z; v3 += b.w;
   }
-  if (pre_out) *pre_out = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+  pre = make_uint2(pack2bf(v0, v1), pack2bf(v2, v3));
   if (p.act == 1) {
-    gelu_erf2(v[0], v[1]);
-    gelu_erf2(v[2], v[3]);
+    gelu_erf2(v0, v1);
+    gelu_erf2(v2, v3);
   }
   if (p.drop.seed_ptr) {
     const uint32_t seed = *p.drop.seed_ptr;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      v[i] = mrb_keep((uint32_t)m * (uint32_t)ncols + (uint32_t)(n0 + i), seed, p.drop.site, p.drop.thresh24) ? v[i] * p.drop.inv_keep : 0.f;
+    const uint32_t e = (uint32_t)m * (uint32_t)ncols + (uint32_t)n0;
+    v0 = mrb_keep(e, seed, p.drop.site, p.drop.thresh24) ? v0 * p.drop.inv_keep : 0.f;
+    v1 = mrb_keep(e + 1, seed, p.drop.site, p.drop.thresh24) ? v1 * p.drop.inv_keep : 0.f;
+    v2 = mrb_keep(e + 2, seed, p.drop.site, p.drop.thresh24) ? v2 * p.drop.inv_keep : 0.f;
+    v3 = mrb_keep(e + 3, seed, p.drop.site, p.drop.thresh24) ? v3 * p.drop.inv_keep : 0.f;
   }
   if (p.residual) {
     const float4 r = *reinterpret_cast<const float4*>(p.residual + (long long)m * p.ldr + n0);
-    v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+    v0 += r.x; v1 += r.y; v2 += r.z; v3 += r.w;
   }
 }
 
-__device__ __forceinline__ void epilogue_store4(const GemmArgs& p, bool out_f32, int m, int n0, float v[4], int ncols) {
+__device__ __forceinline__ void epilogue_store4(const GemmArgs& p, bool out_f32, int m, int n0, float v0, float v1, float v2, float v3, int ncols) {
   uint2 pre;
-  epilogue_apply4(p, m, n0, v, ncols, p.out2 ? &pre : nullptr);
+  epilogue_apply4(p, m, n0, v0, v1, v2, v3, ncols, pre);
   if (p.out2) *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out2) + (long long)m * p.ldo2 + n0) = pre;
   if (out_f32) {
-    *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + (long long)m * p.ldo + n0) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + (long long)m * p.ldo + n0) = make_float4(v0, v1, v2, v3);
   } else {
-    *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + (long long)m * p.ldo + n0) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+    *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + (long long)m * p.ldo + n0) = make_uint2(pack2bf(v0, v1), pack2bf(v2, v3));
   }
 }
 
 // 8 consecutive columns of one row: 16-B bf16 stores (half the store instructions of the 4-wide form), 2 x 16 B for fp32
-__device__ __forceinline__ void epilogue_store8(const GemmArgs& p, bool out_f32, int m, int n0, float v[8], int ncols) {
+__device__ __forceinline__ void epilogue_store8(const GemmArgs& p, bool out_f32, int m, int n0, float4 a, float4 b, int ncols) {
   uint2 pre0, pre1;
-  epilogue_apply4(p, m, n0, v, ncols, p.out2 ? &pre0 : nullptr);
-  epilogue_apply4(p, m, n0 + 4, v + 4, ncols, p.out2 ? &pre1 : nullptr);
+  epilogue_apply4(p, m, n0, a.x, a.y, a.z, a.w, ncols, pre0);
+  epilogue_apply4(p, m, n0 + 4, b.x, b.y, b.z, b.w, ncols, pre1);
   if (p.out2) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.out2) + (long long)m * p.ldo2 + n0) = make_uint4(pre0.x, pre0.y, pre1.x, pre1.y);
   if (out_f32) {
     float4* o = reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + (long long)m * p.ldo + n0);
-    o[0] = make_float4(v[0], v[1], v[2], v[3]);
-    o[1] = make_float4(v[4], v[5], v[6], v[7]);
+    o[0] = a;
+    o[1] = b;
   } else {
+#ifdef EXP_NOSTORE
+    if (a.x == 12345.678f)  // EXPERIMENT (wrong results): epilogue math without the global stores
+#endif
     *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.out) + (long long)m * p.ldo + n0) =
-        make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+        make_uint4(pack2bf(a.x, a.y), pack2bf(a.z, a.w), pack2bf(b.x, b.y), pack2bf(b.z, b.w));
   }
 }
 
@@ -241,6 +248,12 @@ __global__ __launch_bounds__(WGM* WGN * 64, gemm_min_blocks(NS * (BM + BN) * BK 
   for (int nt = 0; nt < TN; ++nt)
     w_row_off[nt] = A_BYTES + (GATED ? (nt * (BN / 2) + wn * 32 + l31) : (wn * (BN / WGN) + nt * 32 + l31)) * RB;
 
+#ifdef EXP_STAGGER
+  if (blockIdx.x >= 256 && blockIdx.x < 512) {  // EXPERIMENT: the second resident block of every CU starts EXP_STAGGER x 10 ns late
+    const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < (uint64_t)(EXP_STAGGER)) __builtin_amdgcn_s_sleep(32);
+  }
+#endif
   // ---- persistent tile loop: grid = resident blocks; a block's epilogue stores drain while it already stages the next tile
   const int ntiles = p.tiles_m * p.tiles_n;
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -267,11 +280,14 @@ __global__ __launch_bounds__(WGM* WGN * 64, gemm_min_blocks(NS * (BM + BN) * BK 
   const bool ext_first = p.ext_first != 0;  // uniform
   auto kmap = [&](int i) __attribute__((always_inline)) { return ext_first ? (i < NEXT ? nk_main + i : i - NEXT) : i; };
   stage(kmap(0), 0);
-  if (NS == 3 && 1 < nk) stage(kmap(1), 1);
+#pragma unroll
+  for (int i = 1; i < NS - 1; ++i)
+    if (i < nk) stage(kmap(i), i);
   for (int kt = 0; kt < nk; ++kt) {
-    // stage kt must have landed; with a 3-deep ring the newest stage (issued one iteration ago) may still be in flight
+    // stage kt must have landed; with a deeper ring the NS - 2 newest stages may still be in flight (LDS-DMA loads retire in order)
 #ifndef EXP_NOSYNC
-    if (NS == 3 && kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(JA + JW) : "memory");
+    if (NS >= 4 && kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (JA + JW)) : "memory");
+    else if (NS >= 3 && kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(JA + JW) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 #endif
@@ -344,6 +360,9 @@ __global__ __launch_bounds__(WGM* WGN * 64, gemm_min_blocks(NS * (BM + BN) * BK 
   __syncthreads();                                 // every wave is done reading the staging buffers
   char* slab = smem + w * (32 * RS);
   const int ncols = GATED ? Nh : p.N;
+#ifdef EXP_NOEPI
+  if (p.M == -12345)  // EXPERIMENT (wrong results): no epilogue at all
+#endif
 #pragma unroll
   for (int mt = 0; mt < TM; ++mt) {
 #pragma unroll
@@ -373,10 +392,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, gemm_min_blocks(NS * (BM + BN) * BK 
         const int idx = i * 64 + lane, r = idx / GPR, c = (idx % GPR) * 2;
         const float4 a0 = *reinterpret_cast<const float4*>(slab + r * RS + c * 16), a1 = *reinterpret_cast<const float4*>(slab + r * RS + (c + 1) * 16);
         const int m = m_base + r, n0 = bn * BN + wn * (BN / WGN) + c * 4;
-        if (m < p.M && n0 < p.N) {
-          float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-          epilogue_store8(p, OUT_F32, m, n0, v, ncols);
-        }
+        if (m < p.M && n0 < p.N) epilogue_store8(p, OUT_F32, m, n0, a0, a1, ncols);
       }
     }
   }
@@ -384,6 +400,278 @@ __global__ __launch_bounds__(WGM* WGN * 64, gemm_min_blocks(NS * (BM + BN) * BK 
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   }  // persistent tile loop
+}
+
+// one LDS-DMA piece (1 KiB, lane-linear in LDS) of an operand tile
+__device__ __forceinline__ void gemm_dma_piece(char* dst, const void* ptr, uint32_t bytes, uint32_t voff, uint32_t koff) {
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ptr), 0, (int)bytes, 0x00020000);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)dst, 16, voff, koff, 0, 0);
+}
+
+typedef uint32_t mrb_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ mrb_u32x4 gemm_load_piece(const void* ptr, uint32_t bytes, uint32_t voff, uint32_t koff) {
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ptr), 0, (int)bytes, 0x00020000);
+  return __builtin_amdgcn_raw_buffer_load_b128(r, voff, koff, 0);
+}
+
+// ---- 256x256x64 tile, FOUR waves of 128x128 (one wave per SIMD, 256 accumulator registers in AGPRs), one persistent block per CU.
+// Half the LDS fragment traffic per MFMA of the 16-wave form (a wave re-uses each 16-B fragment against four tiles of the other
+// operand).  With one wave per SIMD nothing hides a wave's own latencies, so the K loop is software-pipelined by hand: the fragments of
+// k-slice kk+1 are read from LDS while the 16 MFMAs of slice kk run, and the stage hand-over (wait for the LDS-DMA of K-tile kt+1,
+// barrier, issue the LDS-DMA of K-tile kt+2, first fragments of kt+1) sits in front of the LAST slice of K-tile kt, whose MFMAs cover it.
+// Plain epilogues only (bias / GELU / fp32 residual): the frozen-ViT GEMMs.
+// ACT (0 | 1 = GELU) and RES (fp32 residual) are compile-time: with one wave per SIMD the run-time flag tests of the shared epilogue
+// helpers (and the scratch copies of their by-pointer arrays) cost more than the epilogue's real work.
+template <bool OUT_F32, int ACT, bool RES>
+__global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
+  constexpr int BM = 256, BN = 256, RB = 128, NW = 4, RPI = 8;
+  constexpr int A_BYTES = BM * RB, STAGE = 2 * A_BYTES;
+  constexpr int J = BM / RPI / NW;  // 8 LDS-DMA pieces per wave per operand
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = w >> 1, wn = w & 1;
+  const int hi = lane >> 5, l31 = lane & 31;
+  const int chunk = (lane & 7) ^ ((w * 4 + (lane >> 4)) & 7);
+  const uint32_t vA = (uint32_t)((long long)(lane >> 3) * p.lda * 2) + chunk * 16;
+  const uint32_t vW = (uint32_t)((long long)(lane >> 3) * p.ldw * 2) + chunk * 16;
+  const int nk = p.K / 64;
+  const int swz = (lane >> 1) & 7;
+  const int a_off = (wm * 128 + l31) * RB;
+  const int w_off = A_BYTES + (wn * 128 + l31) * RB;
+  const uint32_t bytes_a = (uint32_t)((long long)p.M * p.lda * 2), bytes_w = (uint32_t)((long long)p.N * p.ldw * 2);
+  int bm = 0, bn = 0;
+  uint32_t vpa[J], vpw[J];
+  f32x16 acc[4][4];
+
+#ifdef EXP_W4_NOLDS
+#define W4_LDS_GUARD if (p.M == -12345)
+#else
+#define W4_LDS_GUARD
+#endif
+#ifdef EXP_W4_NOSYNC
+#define W4_SYNC
+#else
+#define W4_SYNC asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier();
+#endif
+#ifdef EXP_W4_NODMA
+#define W4_DO_DMA false
+#else
+#define W4_DO_DMA true
+#endif
+  // fragment i of a k-slice, in the order the MFMAs below first need them: A0, W0, W1, W2, W3, A1, A2, A3
+#define W4_FRAG(FA, FB, BASE, KK, I)                                                                                     \
+  W4_LDS_GUARD {                                                                                                         \
+    const int coff_ = ((((KK) * 2 + hi) ^ swz) << 4);                                                                    \
+    if ((I) == 0) FA[0] = *reinterpret_cast<const bf16x8*>((BASE) + a_off + coff_);                                      \
+    else if ((I) <= 4) FB[(I) - 1] = *reinterpret_cast<const bf16x8*>((BASE) + w_off + ((I) - 1) * 32 * RB + coff_);     \
+    else FA[(I) - 4] = *reinterpret_cast<const bf16x8*>((BASE) + a_off + ((I) - 4) * 32 * RB + coff_);                   \
+  }
+  // one k-slice: MFMA j = (mt, nt) = (j / 4, j % 4) on (FA, FB); every second slot issues one fragment read of the NEXT slice
+  // into (GA, GB) and (hand-over slice only) every slot issues one LDS-DMA piece of K-tile kt + 2.  sched_barrier pins the order.
+#ifdef EXP_W4_REG
+  // EXPERIMENT: operands travel global -> VGPR -> LDS (ds_write_b128) instead of LDS-DMA: WR = write the held stage (kt + 2) into the
+  // buffer the barrier just freed, LD = load stage kt + 3 into the holding registers
+#define W4_SLICE(FA, FB, GA, GB, NBASE, NKK, NEXT, WR, LD)                                                               \
+  _Pragma("unroll") for (int j_ = 0; j_ < 16; ++j_) {                                                                    \
+    if (WR) {                                                                                                            \
+      char* nb_ = smem + (kt & 1) * STAGE + (j_ < 8 ? 0 : A_BYTES) + ((j_ & 7) * NW + w) * (RPI * RB) + lane * 16;      \
+      *reinterpret_cast<mrb_u32x4*>(nb_) = pre[j_];                                                                      \
+    }                                                                                                                    \
+    if (LD) {                                                                                                            \
+      const uint32_t ko_ = (uint32_t)(kt + 3) * (uint32_t)RB;                                                            \
+      pre[j_] = j_ < 8 ? gemm_load_piece(p.A, bytes_a, vpa[j_ & 7], ko_) : gemm_load_piece(p.W, bytes_w, vpw[j_ & 7], ko_); \
+    }                                                                                                                    \
+    if ((NEXT) && (j_ & 1) == 0) W4_FRAG(GA, GB, NBASE, NKK, j_ >> 1)                                                    \
+    acc[j_ >> 2][j_ & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FB[j_ & 3], FA[j_ >> 2], acc[j_ >> 2][j_ & 3], 0, 0, 0); \
+    __builtin_amdgcn_sched_barrier(0);                                                                                   \
+  }
+#define W4_KTILE(WR, LD, NEXT)                                                                                           \
+  {                                                                                                                      \
+    const char* base = smem + (kt & 1) * STAGE;                                                                          \
+    const char* nbase = smem + ((kt + 1) & 1) * STAGE;                                                                   \
+    W4_SLICE(fa0, fb0, fa1, fb1, base, 1, true, false, false)                                                            \
+    W4_SLICE(fa1, fb1, fa0, fb0, base, 2, true, false, false)                                                            \
+    W4_SLICE(fa0, fb0, fa1, fb1, base, 3, true, false, false)                                                            \
+    W4_SYNC                                                                                                              \
+    W4_SLICE(fa1, fb1, fa0, fb0, nbase, 0, NEXT, WR, LD)                                                                 \
+  }
+#else
+  // one k-slice: MFMA j = (mt, nt) = (j / 4, j % 4) on (FA, FB); every second slot issues one fragment read of the NEXT slice into
+  // (GA, GB).  The LDS-DMA of a stage is spread over two slices (all four waves pass the hand-over together: sixteen pieces per
+  // wave at once would queue up in front of the address unit and stall the MFMA issue behind them): DMA_A = the A pieces of K-tile
+  // kt + 2 (hand-over slice, into the buffer the barrier just freed), DMA_W = the W pieces of K-tile kt + 1 (first slice of the
+  // following K-tile).  sched_barrier pins the order.
+#define W4_SLICE(FA, FB, GA, GB, NBASE, NKK, NEXT, DMA_A, DMA_W)                                                         \
+  _Pragma("unroll") for (int j_ = 0; j_ < 16; ++j_) {                                                                    \
+    if ((DMA_A) && W4_DO_DMA && (j_ & 1) == 0)                                                                           \
+      gemm_dma_piece(smem + (kt & 1) * STAGE + ((j_ >> 1) * NW + w) * (RPI * RB), p.A, bytes_a, vpa[j_ >> 1],            \
+                     (uint32_t)(kt + 2) * (uint32_t)RB);                                                                 \
+    if ((DMA_W) && W4_DO_DMA && (j_ & 1) == 1)                                                                           \
+      gemm_dma_piece(smem + ((kt + 1) & 1) * STAGE + A_BYTES + ((j_ >> 1) * NW + w) * (RPI * RB), p.W, bytes_w, vpw[j_ >> 1], \
+                     (uint32_t)(kt + 1) * (uint32_t)RB);                                                                 \
+    if ((NEXT) && (j_ & 1) == 0) W4_FRAG(GA, GB, NBASE, NKK, j_ >> 1)                                                    \
+    acc[j_ >> 2][j_ & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FB[j_ & 3], FA[j_ >> 2], acc[j_ >> 2][j_ & 3], 0, 0, 0); \
+    __builtin_amdgcn_sched_barrier(0);                                                                                   \
+  }
+#define W4_KTILE(DMA, NEXT)                                                                                              \
+  {                                                                                                                      \
+    const char* base = smem + (kt & 1) * STAGE;                                                                          \
+    const char* nbase = smem + ((kt + 1) & 1) * STAGE;                                                                   \
+    W4_SLICE(fa0, fb0, fa1, fb1, base, 1, true, false, NEXT)                                                             \
+    W4_SLICE(fa1, fb1, fa0, fb0, base, 2, true, false, false)                                                            \
+    W4_SLICE(fa0, fb0, fa1, fb1, base, 3, true, false, false)                                                            \
+    W4_SYNC                                                                                                              \
+    W4_SLICE(fa1, fb1, fa0, fb0, nbase, 0, NEXT, DMA, false)                                                             \
+  }
+#endif
+
+  const int ntiles = p.tiles_m * p.tiles_n;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    {
+      int bid = tile;
+      const int q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, idx = bid >> 3;
+      bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+      constexpr int GROUP_M = 8;
+      const int per_group = GROUP_M * p.tiles_n;
+      const int gid = bid / per_group;
+      const int first_m = gid * GROUP_M;
+      const int gsize = min(p.tiles_m - first_m, GROUP_M);
+      bm = first_m + (bid % per_group) % gsize;
+      bn = (bid % per_group) / gsize;
+    }
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      const int tr = (j * NW + w) * RPI;
+      vpa[j] = vA + (uint32_t)((long long)(bm * BM + tr) * p.lda * 2);
+      vpw[j] = vW + (uint32_t)((long long)(bn * BN + tr) * p.ldw * 2);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    gemm_stage_dma<J, J, NW, RPI * RB>(smem, smem + A_BYTES, p.A, bytes_a, p.W, bytes_w, vpa, vpw, w, 0u);
+#ifdef EXP_W4_REG
+    if (nk > 1) {
+      gemm_stage_dma<J, J, NW, RPI * RB>(smem + STAGE, smem + STAGE + A_BYTES, p.A, bytes_a, p.W, bytes_w, vpa, vpw, w, (uint32_t)RB);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * J) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+#else
+    if (nk > 1) {  // the A pieces of K-tile 1 (its W pieces go out in the first slice of K-tile 0)
+#pragma unroll
+      for (int j = 0; j < J; ++j) gemm_dma_piece(smem + STAGE + (j * NW + w) * (RPI * RB), p.A, bytes_a, vpa[j], (uint32_t)RB);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(J) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+#endif
+    __builtin_amdgcn_s_barrier();
+    bf16x8 fa0[4], fb0[4], fa1[4], fb1[4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) W4_FRAG(fa0, fb0, smem, 0, i)
+    int kt = 0;
+#ifdef EXP_W4_REG
+    mrb_u32x4 pre[16];
+    if (nk > 2) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j)
+        pre[j] = j < 8 ? gemm_load_piece(p.A, bytes_a, vpa[j & 7], 2u * RB) : gemm_load_piece(p.W, bytes_w, vpw[j & 7], 2u * RB);
+    }
+    for (; kt < nk - 3; ++kt) W4_KTILE(true, true, true)
+    if (kt < nk - 2) {
+      W4_KTILE(true, false, true)
+      ++kt;
+    }
+    if (kt < nk - 1) {
+      W4_KTILE(false, false, true)
+      ++kt;
+    }
+    W4_KTILE(false, false, false)
+#else
+    for (; kt < nk - 2; ++kt) W4_KTILE(true, true)
+    if (kt < nk - 1) {
+      W4_KTILE(false, true)
+      ++kt;
+    }
+    W4_KTILE(false, false)
+#endif
+#undef W4_KTILE
+#undef W4_SLICE
+#undef W4_FRAG
+
+    // ---- epilogue: 32-row x 128-column fp32 slabs per wave through LDS (the transposition of gemm_tile_kernel), then 16 lanes
+    // cover one row and every lane owns the SAME 8 columns in all passes: its bias values are loaded once per tile.
+    constexpr int RS = 128 * 4 + 16;
+    __syncthreads();
+    char* slab = smem + w * (32 * RS);
+    const int c8 = (lane & 15) * 8;                       // the lane's 8 columns inside the wave's 128
+    const int n0 = bn * BN + wn * 128 + c8;
+    const bool n_ok = n0 < p.N;
+    float bias8[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) bias8[i] = 0.f;
+    if (p.bias && n_ok) {
+      const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n0), b1 = *reinterpret_cast<const float4*>(p.bias + n0 + 4);
+      bias8[0] = b0.x; bias8[1] = b0.y; bias8[2] = b0.z; bias8[3] = b0.w; bias8[4] = b1.x; bias8[5] = b1.y; bias8[6] = b1.z; bias8[7] = b1.w;
+    }
+#ifdef EXP_NOEPI
+    if (p.M == -12345)
+#endif
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<float4*>(slab + l31 * RS + (nt * 32 + 8 * g + 4 * hi) * 4) =
+              make_float4(acc[mt][nt][4 * g], acc[mt][nt][4 * g + 1], acc[mt][nt][4 * g + 2], acc[mt][nt][4 * g + 3]);
+      const int m_base = bm * BM + wm * 128 + mt * 32 + (lane >> 4);
+      float4 x0[8], x1[8], r0[8], r1[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {  // row 4 i + lane / 16 of the slab
+        const char* sp = slab + (i * 4 + (lane >> 4)) * RS + c8 * 4;
+        x0[i] = *reinterpret_cast<const float4*>(sp);
+        x1[i] = *reinterpret_cast<const float4*>(sp + 16);
+        if (RES) {
+          const int m = m_base + i * 4;
+          if (m < p.M && n_ok) {
+            const float* rp = p.residual + (long long)m * p.ldr + n0;
+            r0[i] = *reinterpret_cast<const float4*>(rp);
+            r1[i] = *reinterpret_cast<const float4*>(rp + 4);
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int m = m_base + i * 4;
+        float v[8] = {x0[i].x + bias8[0], x0[i].y + bias8[1], x0[i].z + bias8[2], x0[i].w + bias8[3],
+                      x1[i].x + bias8[4], x1[i].y + bias8[5], x1[i].z + bias8[6], x1[i].w + bias8[7]};
+        if (ACT == 1) {
+          gelu_erf2(v[0], v[1]); gelu_erf2(v[2], v[3]); gelu_erf2(v[4], v[5]); gelu_erf2(v[6], v[7]);
+        }
+        if (RES) {
+          v[0] += r0[i].x; v[1] += r0[i].y; v[2] += r0[i].z; v[3] += r0[i].w; v[4] += r1[i].x; v[5] += r1[i].y; v[6] += r1[i].z; v[7] += r1[i].w;
+        }
+        if (m < p.M && n_ok) {
+          if (OUT_F32) {
+            float4* o = reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + (long long)m * p.ldo + n0);
+            o[0] = make_float4(v[0], v[1], v[2], v[3]);
+            o[1] = make_float4(v[4], v[5], v[6], v[7]);
+          } else {
+            *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.out) + (long long)m * p.ldo + n0) =
+                make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+          }
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
 }
 
 // ---- skinny-M kernel (decoder rows, M <= a few 32-row tiles): weight-streaming bound.  One block = 32 output
@@ -496,10 +784,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const GemmArgs p) 
       for (int g = 0; g < 4; ++g) {
         const int n0 = blockIdx.x * 32 + 8 * g + 4 * hi;
         if (n0 < p.N) {
-          float v[4];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) v[i] = acc[4 * g + i];
-          epilogue_store4(p, OUT_F32, m_row, n0, v, p.N);
+          epilogue_store4(p, OUT_F32, m_row, n0, acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3], p.N);
         }
       }
     }
@@ -576,7 +861,8 @@ static int gemm_dispatch(const void* A, long long lda, const void* W, long long 
   a.drop.thresh24 = (uint32_t)(p_drop * 65536.0f + 0.5f);
   a.drop.inv_keep = 1.0f / (1.0f - p_drop);
   MRB_REQUIRE(!(p_drop > 0.f) || seed_ptr, "gemm: dropout needs a device seed pointer");
-  // tile_cfg: 0 auto, 1 = 256x256 (8 waves, persistent), 2 = 128x128, 3 = skinny, 4 = 64x128, 5 = 64x64; measured and not auto-selected:
+  // tile_cfg: 0 auto, 1 = 256x256 (8 waves, persistent), 2 = 128x128, 3 = skinny, 4 = 64x128, 5 = 64x64, 8 = 256x256 with 16 waves,
+  // 13 = 256x256 with 4 waves (plain epilogues); measured and not auto-selected:
   // 6 = 256x256 with 4 waves of 128x128 (1 wave/SIMD: 0.7x), 7 = 256x128 BK=32 3-stage (= 128x128), [128x128 BK=32 at 3-4 blocks/CU: 0.8x,
   // 256x128 / 128x256 BK=64 with one 4-wave block per CU: 0.6x; 256x128 / 128x256 BK=32 with 8 waves of 64x64, two blocks per CU: 0.7x]
   int cfg = tile_cfg;
@@ -604,6 +890,12 @@ static int gemm_dispatch(const void* A, long long lda, const void* W, long long 
       static int no8 = -1;
       if (no8 < 0) no8 = getenv("MRB_NO_CFG8") ? 1 : 0;
       if (!no8 && !gated && K >= 1024 && (eff256 >= 0.9 || (rounds == 1 && eff256 >= 0.7))) cfg = 8;
+      // plain-epilogue GEMMs with many 256x256 tiles or a long K (the frozen ViT's qkv / fc1 / fc2): four waves of 128x128 with the
+      // hand-pipelined K loop (cfg 13) - 10-20 % faster than every other form standalone, ~1 ms per step in the train step
+      static int no13 = -1;
+      if (no13 < 0) no13 = getenv("MRB_NO_CFG13") ? 1 : 0;
+      if (!no13 && !gated && !Aext && !out2 && !(p_drop > 0.f) && (act == 0 || act == 1) && M >= 4096 && (t256 >= 2 * ncu || (t256 >= ncu && K >= 4096)))
+        cfg = 13;
       // (256x128 with 16 waves, cfg 10, is 5-15 % faster than 128x128 at the ViT qkv shape standalone, but in the step it made things
       // worse: one more persistent 16-wave block per CU starves the small kernels of the clip that shares the GPU with the look-ahead)
       if (cfg != 0) {
@@ -654,6 +946,52 @@ static int gemm_dispatch(const void* A, long long lda, const void* W, long long 
   if (cfg == 11) {  // 128x256, 16 waves of 32x64 (measured <= cfg 10, not auto-selected)
     MRB_REQUIRE(!gated, "gemm: cfg 11 has no gated epilogue");
     return out_f32 ? launch_tile<128, 256, 4, 4, true, false>(a, stream) : launch_tile<128, 256, 4, 4, false, false>(a, stream);
+  }
+  if (cfg == 12) {  // 256x192, 8 waves of 64x96, one persistent block per CU: N = 1408 (ViT proj / fc2) is 7.3 x 192 -> 488 tiles = 1.9 rounds
+    MRB_REQUIRE(!gated, "gemm: cfg 12 has no gated epilogue");
+    return out_f32 ? launch_tile<256, 192, 4, 2, true, false>(a, stream) : launch_tile<256, 192, 4, 2, false, false>(a, stream);
+  }
+  if (cfg == 13) {  // 256x256, 4 waves of 128x128, hand-pipelined K loop (plain epilogues)
+    MRB_REQUIRE(!gated && !Aext && !out2 && !(p_drop > 0.f), "gemm: cfg 13 takes plain epilogues only");
+    a.tiles_m = (M + 255) / 256;
+    a.tiles_n = (N + 255) / 256;
+    constexpr int LDS = 2 * 2 * 256 * 128;
+    static int ncu13 = 0;
+    if (ncu13 == 0) {
+      int dev = 0;
+      hipDeviceProp_t prop;
+      ncu13 = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+    }
+    const int nt13 = a.tiles_m * a.tiles_n;
+    const int grid = nt13 < ncu13 ? nt13 : ncu13;
+    MRB_REQUIRE(act == 0 || act == 1, "gemm: cfg 13 knows act 0 / 1");
+    const int variant = (out_f32 ? 4 : 0) | (act == 1 ? 2 : 0) | (residual ? 1 : 0);
+    static bool attr_set13[8] = {false, false, false, false, false, false, false, false};
+#define MRB_W4_LAUNCH(V, F32, ACT_, RES_)                                                                                          \
+  case V: {                                                                                                                        \
+    auto k = gemm_w4_kernel<F32, ACT_, RES_>;                                                                                      \
+    if (!attr_set13[V]) {                                                                                                          \
+      if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {                    \
+        mrblip_set_error("gemm: cannot raise dynamic LDS to %d", LDS);                                                             \
+        return MRBLIP_ELAUNCH;                                                                                                     \
+      }                                                                                                                            \
+      attr_set13[V] = true;                                                                                                        \
+    }                                                                                                                              \
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), LDS, stream, a);                                                                  \
+    break;                                                                                                                         \
+  }
+    switch (variant) {
+      MRB_W4_LAUNCH(0, false, 0, false)
+      MRB_W4_LAUNCH(1, false, 0, true)
+      MRB_W4_LAUNCH(2, false, 1, false)
+      MRB_W4_LAUNCH(3, false, 1, true)
+      MRB_W4_LAUNCH(4, true, 0, false)
+      MRB_W4_LAUNCH(5, true, 0, true)
+      MRB_W4_LAUNCH(6, true, 1, false)
+      MRB_W4_LAUNCH(7, true, 1, true)
+    }
+#undef MRB_W4_LAUNCH
+    return mrblip_check_launch("gemm_w4");
   }
   if (cfg == 4) {
     if (gated) return launch_tile<64, 128, 2, 2, false, true>(a, stream);

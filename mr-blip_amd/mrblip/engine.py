@@ -29,6 +29,10 @@ def pad64(n: int) -> int:
     return (n + 63) // 64 * 64
 
 
+# tile configs of the ViT qkv / proj / fc2 / fc1 GEMMs (0 = the library's own choice); MRB_VIT_CFG="q,p,f2,f1" overrides for experiments
+_VIT_CFG = (tuple(int(x) for x in os.environ.get("MRB_VIT_CFG", "0,0,0,0").split(",")) + (0, 0, 0, 0))[:4]
+
+
 @dataclass
 class EngineConfig:
     # ViT (eva_vit.py:415-428)
@@ -285,19 +289,19 @@ class MrBlipEngine:
         probe = getattr(self, "probe", None)
         for blk in v["blocks"][b0:b1]:
             ops.layernorm_fwd(x, blk["n1w"], blk["n1b"], 1e-6, out_bf16=h)
-            ops.gemm(h, blk["qkv_w"], qkv, bias=blk["qkv_b"])
+            ops.gemm(h, blk["qkv_w"], qkv, bias=blk["qkv_b"], tile_cfg=_VIT_CFG[0])
             ops.head_transpose(v4, out=vt)
             ops.attention_fwd(q4, k4, vt, o4, None, scale=scale)
-            ops.gemm(o, blk["proj_w"], x, bias=blk["proj_b"], residual=x)
+            ops.gemm(o, blk["proj_w"], x, bias=blk["proj_b"], residual=x, tile_cfg=_VIT_CFG[1])
             ops.layernorm_fwd(x, blk["n2w"], blk["n2b"], 1e-6, out_bf16=h)
             if probe is not None:  # HIP events around the dominant kernel's launch (bench.py roofline.achieved)
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 ev[0].record()
-            ops.gemm(h, blk["fc1_w"], f, bias=blk["fc1_b"], act=1)
+            ops.gemm(h, blk["fc1_w"], f, bias=blk["fc1_b"], act=1, tile_cfg=_VIT_CFG[3])
             if probe is not None:
                 ev[1].record()
                 probe.append(ev)
-            ops.gemm(f, blk["fc2_w"], x, bias=blk["fc2_b"], residual=x)
+            ops.gemm(f, blk["fc2_w"], x, bias=blk["fc2_b"], residual=x, tile_cfg=_VIT_CFG[2])
 
     # ------------------------------------------------------------------------------------------ Q-Former (frozen weights, dX needed)
     def _build_qformer(self, src):
@@ -1046,10 +1050,33 @@ class MrBlipEngine:
             self._vit_stream.wait_event(start)
             F_ = next_video.shape[0] * next_video.shape[1]
             nb = c.vit_depth if self.vit_lookahead_blocks is None else max(1, min(c.vit_depth, int(self.vit_lookahead_blocks)))
+            nb = max(1, nb - int(self.vit_tail_blocks))
             xv = self.vit_forward(next_video.reshape(F_, 3, c.img, c.img), slot=slot, blocks=(0, nb))
             done = torch.cuda.Event()
             done.record()
         self._vit_ready = (self._video_key(next_video), xv, done, slot, nb)
+        self._vit_next = next_video
+
+    vit_tail_blocks = int(os.environ.get("MRB_VIT_TAIL", "5"))  # look-ahead blocks held back for prefetch_vit_tail()
+
+    @torch.no_grad()
+    def prefetch_vit_tail(self):
+        """Second leg of the look-ahead: the ViT blocks the first leg left out are issued (same side stream) when the Q-Former backward
+        starts — a short-kernel phase at the end of the step with idle CUs."""
+        r = self._vit_ready
+        if r is None or r[4] >= self.cfg.vit_depth:
+            return
+        c = self.cfg
+        start = torch.cuda.Event()
+        start.record()
+        v = self._vit_next
+        with torch.cuda.stream(self._vit_stream):
+            self._vit_stream.wait_event(start)
+            F_ = v.shape[0] * v.shape[1]
+            self.vit_forward(v.reshape(F_, 3, c.img, c.img), slot=r[3], blocks=(r[4], c.vit_depth))
+            done = torch.cuda.Event()
+            done.record()
+        self._vit_ready = (r[0], r[1], done, r[3], c.vit_depth)
 
     def _take_prefetched_vit(self, video: torch.Tensor):
         r, self._vit_ready = self._vit_ready, None
@@ -1122,6 +1149,8 @@ class MrBlipEngine:
         ops.gemm(dft, qbt, self.dproj_w, residual=self.dproj_w, K=mp)
         dq_last = self.buf("dq_last", (Mq, Dq), f32, zero=False)
         ops.gemm(dfb, self.proj_wtb, dq_last, K=pad64(d))
+        if next_video is not None:
+            self.prefetch_vit_tail()
         dimg = self.qformer_backward(dq_last, img, F_)
         ops.layernorm_bwd(dimg, xv, self.lnv_w, self.ln_vision_eps, None, dgamma=self.dlnv_w, dbeta=self.dlnv_b)
         self._mark("t5_proj + Q-Former backward")

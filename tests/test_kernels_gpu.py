@@ -37,7 +37,7 @@ def keep_mask(shape, seed, site, p):
     return dropout_keep(shape, seed, site, p).to(dev())
 
 
-@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 7, 8, 9, 10, 11])
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 7, 8, 9, 10, 11, 12, 13])
 @pytest.mark.parametrize("M,N,K", [(300, 264, 128), (64, 520, 192), (513, 1408, 576), (33, 264, 2304), (1, 8, 64), (257, 8, 128)])
 def test_gemm_plain(ops, cfg, M, N, K):
     torch.manual_seed(0)
@@ -51,7 +51,7 @@ def test_gemm_plain(ops, cfg, M, N, K):
         assert rel(out.float(), ref) < tol, (cfg, dt)
 
 
-@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 7, 8, 9, 10, 11])
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 7, 8, 9, 10, 11, 12])
 def test_gemm_epilogues(ops, cfg):
     torch.manual_seed(1)
     M, N, K = 200, 328, 256
@@ -75,6 +75,28 @@ def test_gemm_epilogues(ops, cfg):
     mask = keep_mask((M, N), 1234567, 17, 0.1)
     assert 0.85 < mask.mean().item() < 0.95
     assert rel(x, res + base * mask / 0.9) < 2e-6
+
+
+def test_gemm_four_wave_tile_epilogues(ops):
+    """cfg 13 (256x256, four waves of 128x128, hand-pipelined K loop) takes the plain epilogues of the frozen-ViT GEMMs only."""
+    torch.manual_seed(5)
+    M, N, K = 700, 520, 320  # 3 x 3 tiles with ragged edges, 5 K-tiles (prologue + steady state + both tail forms)
+    a = bf(torch.randn(M, K, device=dev()))
+    w = bf(torch.randn(N, K, device=dev()) * 0.1)
+    bias = torch.randn(N, device=dev())
+    res = torch.randn(M, N, device=dev())
+    base = a.float() @ w.float().t() + bias
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=dev())
+    ops.gemm(a, w, out, bias=bias, act=1, tile_cfg=13)
+    assert rel(out.float(), torch.nn.functional.gelu(base)) < 3e-3
+    x = res.clone()
+    ops.gemm(a, w, x, bias=bias, residual=x, tile_cfg=13)
+    assert rel(x, res + base) < 2e-6
+    for k in (64, 128):  # one and two K-tiles
+        ops.gemm(a[:, :k].contiguous(), w[:, :k].contiguous(), x, tile_cfg=13)
+        assert rel(x, a[:, :k].float() @ w[:, :k].float().t()) < 2e-6
+    with pytest.raises(ops.MrblipError):
+        ops.gemm(a, w, out, gated=True, tile_cfg=13)
 
 
 @pytest.mark.parametrize("cfg", [1, 2, 4, 7, 8, 9])

@@ -37,12 +37,14 @@ def main():
     dev = torch.device("cuda:0")
     res = []
     for name, M, N, K in SHAPES:
+        if os.environ.get("ONLY") and not name.startswith(os.environ["ONLY"]):
+            continue
         a = torch.randn(M, K, device=dev).bfloat16()
         w = (torch.randn(N, K, device=dev) * 0.05).bfloat16()
         out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
         row = dict(name=name, M=M, N=N, K=K)
         fl = 2.0 * M * N * K
-        cfgs = [3] if (M <= 64 or N <= 64) else [2, 4, 8]
+        cfgs = [3] if (M <= 64 or N <= 64) else [int(c) for c in os.environ.get("CFGS", "2,4,8").split(",")]
         for cfg in cfgs:
             t = timeit(lambda: ops.gemm(a, w, out, tile_cfg=cfg))
             row[f"cfg{cfg}_us"] = round(t * 1e6, 1)

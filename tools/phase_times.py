@@ -22,6 +22,10 @@ for it in range(5):
     eng.phase_events = [] if it >= 2 else None
     eng.zero_grad()
     eng.forward_backward(samples["video"], layout, backward=True, next_video=samples["video"] if LOOKAHEAD else None)
+    vit_done = None
+    if LOOKAHEAD and eng.phase_events is not None:  # everything of the look-ahead is enqueued by now: an event on its stream marks its end
+        vit_done = torch.cuda.Event(enable_timing=True)
+        vit_done.record(eng._vit_stream)
     eng._mark("fwd/bwd done") if eng.phase_events is not None else None
     eng.optimizer_step(lr=3e-4, weight_decay=0.05)
     if eng.phase_events is not None:
@@ -34,3 +38,5 @@ for it in range(5):
             for n, t in rows:
                 print(f"{n:60s} {t:8.3f} ms  {100 * t / tot:5.1f}%")
             print(f"{'total':60s} {tot:8.3f} ms")
+            if vit_done is not None:
+                print(f"{'look-ahead ViT finished at':60s} {ev[0][1].elapsed_time(vit_done):8.3f} ms after the step's first mark")

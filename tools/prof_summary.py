@@ -2,12 +2,15 @@
 import re
 import sqlite3
 import sys
+import os
+
+NAMELEN = int(os.environ.get("NAMELEN", "90"))
 
 
 def short(name):
     name = re.sub(r"\(.*$", "", name)
     name = re.sub(r"^void ", "", name)
-    return name[:110]
+    return name[:NAMELEN + 20]
 
 
 def main(db, out=None, skip_first_frac=0.0, by_grid=False):
@@ -17,7 +20,7 @@ def main(db, out=None, skip_first_frac=0.0, by_grid=False):
     gcol = next((c for c in ("grid_x", "grid_size_x", "grid_size") if c in cols), None)
     if by_grid and gcol:  # one row per (kernel, grid): separates the GEMM shapes
         rows = cur.execute(f"select name, {gcol}, start, end from kernels order by start").fetchall()
-        rows = [(f"{short(n)[:90]} grid={g}", s, e) for n, g, s, e in rows]
+        rows = [(f"{short(n)[:NAMELEN]} grid={g}", s, e) for n, g, s, e in rows]
     else:
         if by_grid:
             print("# no grid column among", cols)
