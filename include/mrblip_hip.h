@@ -70,6 +70,11 @@ int mrblip_attention_bwd(const void* Q, const long long* q_strides, const void* 
 int mrblip_head_transpose(const void* src, const long long* strides, void* dst, int B, int H, int S, int D, int Spad,
                           const uint32_t* seed_ptr, uint32_t site, float p_drop, mrblip_stream_t stream);
 
+/* CUs (a multiple of 8: one per XCD) that the persistent GEMM kernels (tile_cfg 13 / 14, the frozen-ViT GEMMs) launched from now on
+ * leave to other streams; returns the previous value.  No reference counterpart: the reference runs the ViT forward in line with the
+ * rest of forward_mr (blip2_mr.py:287-289); here it runs one clip ahead on a second stream and must not starve the clip being trained. */
+int mrblip_gemm_set_cu_reserve(int n_cus);
+
 /* frames fp32 [F,3,IMG,IMG] -> bf16 patch rows [F*(IMG/P)^2, Kpad] in Conv2d weight order (eva_vit.py:196-203) */
 int mrblip_patchify(const float* video, void* out_bf16, int F, int IMG, int P, int Kpad, mrblip_stream_t stream);
 /* the same from uint8 frames [F,3,IMG,IMG] with the processor's ToTensor + Normalize(mean3, std3) applied on the fly

@@ -36,6 +36,7 @@ struct GemmArgs {
   int m_rows_per_block;  // skinny kernel only: 32, or 16 / 8 when few output columns leave most CUs without a block (more blocks stream
                          // the tall operand in parallel: one CU sustains only ~10 B/clk from HBM)
   DropoutArg a_drop;  // skinny kernel only: dropout of the A operand as it is loaded (zeroing; the 1/(1-p) is applied to the result)
+  uint32_t* sched;    // gemm_w4_kernel only: [0..7] per-XCD tile counters, [8] finished-block counter (all zero between launches)
 };
 
 // v0..v3: 4 consecutive columns n0..n0+3 of row m (raw accumulator). Applies bias -> (pre-activation copy) -> GELU -> dropout -> residual.
@@ -414,19 +415,21 @@ __device__ __forceinline__ mrb_u32x4 gemm_load_piece(const void* ptr, uint32_t b
   return __builtin_amdgcn_raw_buffer_load_b128(r, voff, koff, 0);
 }
 
-// ---- 256x256x64 tile, FOUR waves of 128x128 (one wave per SIMD, 256 accumulator registers in AGPRs), one persistent block per CU.
-// Half the LDS fragment traffic per MFMA of the 16-wave form (a wave re-uses each 16-B fragment against four tiles of the other
-// operand).  With one wave per SIMD nothing hides a wave's own latencies, so the K loop is software-pipelined by hand: the fragments of
-// k-slice kk+1 are read from LDS while the 16 MFMAs of slice kk run, and the stage hand-over (wait for the LDS-DMA of K-tile kt+1,
-// barrier, issue the LDS-DMA of K-tile kt+2, first fragments of kt+1) sits in front of the LAST slice of K-tile kt, whose MFMAs cover it.
-// Plain epilogues only (bias / GELU / fp32 residual): the frozen-ViT GEMMs.
-// ACT (0 | 1 = GELU) and RES (fp32 residual) are compile-time: with one wave per SIMD the run-time flag tests of the shared epilogue
-// helpers (and the scratch copies of their by-pointer arrays) cost more than the epilogue's real work.
-template <bool OUT_F32, int ACT, bool RES>
+// ---- 256 x (64 TN) x 64 tile, FOUR waves of 128 x (32 TN) (one wave per SIMD, the accumulators in AGPRs), one persistent block per CU.
+// TN = 4: 256x256, half the LDS fragment traffic per MFMA of the 16-wave form (a wave re-uses each 16-B fragment against four tiles
+// of the other operand).  TN = 3: 256x192 for outputs whose 256-wide tiling leaves the last round mostly empty (ViT fc2 / proj,
+// N = 1408: 366 tiles = 1.43 rounds of 256 CUs, against 488 = 1.9 rounds).
+// With one wave per SIMD nothing hides a wave's own latencies, so the K loop is software-pipelined by hand: the fragments of k-slice
+// kk+1 are read from LDS while the MFMAs of slice kk run, and the stage hand-over (wait for the LDS-DMA of K-tile kt+1, barrier,
+// LDS-DMA of K-tile kt+2, first fragments of kt+1) sits in front of the LAST slice of K-tile kt, whose MFMAs cover it.
+// Plain epilogues only (bias / GELU / fp32 residual): the frozen-ViT GEMMs.  ACT (0 | 1 = GELU) and RES (fp32 residual) are
+// compile-time: with one wave per SIMD the run-time flag tests of the shared epilogue helpers cost more than the epilogue's real work.
+template <bool OUT_F32, int ACT, bool RES, int TN>
 __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
-  constexpr int BM = 256, BN = 256, RB = 128, NW = 4, RPI = 8;
-  constexpr int A_BYTES = BM * RB, STAGE = 2 * A_BYTES;
-  constexpr int J = BM / RPI / NW;  // 8 LDS-DMA pieces per wave per operand
+  constexpr int BM = 256, BN = 64 * TN, WN = BN / 2, RB = 128, NW = 4, RPI = 8;
+  constexpr int A_BYTES = BM * RB, W_BYTES = BN * RB, STAGE = A_BYTES + W_BYTES;
+  constexpr int JA = BM / RPI / NW, JW = BN / RPI / NW;  // LDS-DMA pieces per wave: 8 of A, 8 / 6 of W
+  constexpr int NSLOT = 4 * TN, NFRAG = 4 + TN;          // MFMAs and fragment reads per k-slice
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -438,17 +441,12 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
   const int nk = p.K / 64;
   const int swz = (lane >> 1) & 7;
   const int a_off = (wm * 128 + l31) * RB;
-  const int w_off = A_BYTES + (wn * 128 + l31) * RB;
+  const int w_off = A_BYTES + (wn * WN + l31) * RB;
   const uint32_t bytes_a = (uint32_t)((long long)p.M * p.lda * 2), bytes_w = (uint32_t)((long long)p.N * p.ldw * 2);
   int bm = 0, bn = 0;
-  uint32_t vpa[J], vpw[J];
-  f32x16 acc[4][4];
+  uint32_t vpa[JA], vpw[JW];
+  f32x16 acc[4][TN];
 
-#ifdef EXP_W4_NOLDS
-#define W4_LDS_GUARD if (p.M == -12345)
-#else
-#define W4_LDS_GUARD
-#endif
 #ifdef EXP_W4_NOSYNC
 #define W4_SYNC
 #else
@@ -459,59 +457,37 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
 #else
 #define W4_DO_DMA true
 #endif
-  // fragment i of a k-slice, in the order the MFMAs below first need them: A0, W0, W1, W2, W3, A1, A2, A3
+  // fragment I of a k-slice, in the order the MFMAs below first need them: A0, W0 .. W(TN-1), A1, A2, A3
 #define W4_FRAG(FA, FB, BASE, KK, I)                                                                                     \
-  W4_LDS_GUARD {                                                                                                         \
+  {                                                                                                                      \
     const int coff_ = ((((KK) * 2 + hi) ^ swz) << 4);                                                                    \
     if ((I) == 0) FA[0] = *reinterpret_cast<const bf16x8*>((BASE) + a_off + coff_);                                      \
-    else if ((I) <= 4) FB[(I) - 1] = *reinterpret_cast<const bf16x8*>((BASE) + w_off + ((I) - 1) * 32 * RB + coff_);     \
-    else FA[(I) - 4] = *reinterpret_cast<const bf16x8*>((BASE) + a_off + ((I) - 4) * 32 * RB + coff_);                   \
+    else if ((I) <= TN) FB[(I) - 1] = *reinterpret_cast<const bf16x8*>((BASE) + w_off + ((I) - 1) * 32 * RB + coff_);    \
+    else FA[(I) - TN] = *reinterpret_cast<const bf16x8*>((BASE) + a_off + ((I) - TN) * 32 * RB + coff_);                 \
   }
-  // one k-slice: MFMA j = (mt, nt) = (j / 4, j % 4) on (FA, FB); every second slot issues one fragment read of the NEXT slice
-  // into (GA, GB) and (hand-over slice only) every slot issues one LDS-DMA piece of K-tile kt + 2.  sched_barrier pins the order.
-#ifdef EXP_W4_REG
-  // EXPERIMENT: operands travel global -> VGPR -> LDS (ds_write_b128) instead of LDS-DMA: WR = write the held stage (kt + 2) into the
-  // buffer the barrier just freed, LD = load stage kt + 3 into the holding registers
-#define W4_SLICE(FA, FB, GA, GB, NBASE, NKK, NEXT, WR, LD)                                                               \
-  _Pragma("unroll") for (int j_ = 0; j_ < 16; ++j_) {                                                                    \
-    if (WR) {                                                                                                            \
-      char* nb_ = smem + (kt & 1) * STAGE + (j_ < 8 ? 0 : A_BYTES) + ((j_ & 7) * NW + w) * (RPI * RB) + lane * 16;      \
-      *reinterpret_cast<mrb_u32x4*>(nb_) = pre[j_];                                                                      \
-    }                                                                                                                    \
-    if (LD) {                                                                                                            \
-      const uint32_t ko_ = (uint32_t)(kt + 3) * (uint32_t)RB;                                                            \
-      pre[j_] = j_ < 8 ? gemm_load_piece(p.A, bytes_a, vpa[j_ & 7], ko_) : gemm_load_piece(p.W, bytes_w, vpw[j_ & 7], ko_); \
-    }                                                                                                                    \
-    if ((NEXT) && (j_ & 1) == 0) W4_FRAG(GA, GB, NBASE, NKK, j_ >> 1)                                                    \
-    acc[j_ >> 2][j_ & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FB[j_ & 3], FA[j_ >> 2], acc[j_ >> 2][j_ & 3], 0, 0, 0); \
-    __builtin_amdgcn_sched_barrier(0);                                                                                   \
-  }
-#define W4_KTILE(WR, LD, NEXT)                                                                                           \
-  {                                                                                                                      \
-    const char* base = smem + (kt & 1) * STAGE;                                                                          \
-    const char* nbase = smem + ((kt + 1) & 1) * STAGE;                                                                   \
-    W4_SLICE(fa0, fb0, fa1, fb1, base, 1, true, false, false)                                                            \
-    W4_SLICE(fa1, fb1, fa0, fb0, base, 2, true, false, false)                                                            \
-    W4_SLICE(fa0, fb0, fa1, fb1, base, 3, true, false, false)                                                            \
-    W4_SYNC                                                                                                              \
-    W4_SLICE(fa1, fb1, fa0, fb0, nbase, 0, NEXT, WR, LD)                                                                 \
-  }
-#else
-  // one k-slice: MFMA j = (mt, nt) = (j / 4, j % 4) on (FA, FB); every second slot issues one fragment read of the NEXT slice into
-  // (GA, GB).  The LDS-DMA of a stage is spread over two slices (all four waves pass the hand-over together: sixteen pieces per
-  // wave at once would queue up in front of the address unit and stall the MFMA issue behind them): DMA_A = the A pieces of K-tile
-  // kt + 2 (hand-over slice, into the buffer the barrier just freed), DMA_W = the W pieces of K-tile kt + 1 (first slice of the
-  // following K-tile).  sched_barrier pins the order.
+  // one k-slice: MFMA j = (mt, nt) = (j / TN, j % TN) on (FA, FB); the NFRAG fragment reads of the NEXT slice (into GA, GB) are spread
+  // evenly over its slots.  The LDS-DMA of a stage is spread over two slices (all four waves pass the hand-over together: all pieces
+  // at once would queue up in front of the address unit and stall the MFMA issue behind them): DMA_A = the A pieces of K-tile kt + 2
+  // (hand-over slice, into the buffer the barrier just freed), DMA_W = the W pieces of K-tile kt + 1 (first slice of the following
+  // K-tile).  sched_barrier pins the order.
 #define W4_SLICE(FA, FB, GA, GB, NBASE, NKK, NEXT, DMA_A, DMA_W)                                                         \
-  _Pragma("unroll") for (int j_ = 0; j_ < 16; ++j_) {                                                                    \
-    if ((DMA_A) && W4_DO_DMA && (j_ & 1) == 0)                                                                           \
-      gemm_dma_piece(smem + (kt & 1) * STAGE + ((j_ >> 1) * NW + w) * (RPI * RB), p.A, bytes_a, vpa[j_ >> 1],            \
-                     (uint32_t)(kt + 2) * (uint32_t)RB);                                                                 \
-    if ((DMA_W) && W4_DO_DMA && (j_ & 1) == 1)                                                                           \
-      gemm_dma_piece(smem + ((kt + 1) & 1) * STAGE + A_BYTES + ((j_ >> 1) * NW + w) * (RPI * RB), p.W, bytes_w, vpw[j_ >> 1], \
-                     (uint32_t)(kt + 1) * (uint32_t)RB);                                                                 \
-    if ((NEXT) && (j_ & 1) == 0) W4_FRAG(GA, GB, NBASE, NKK, j_ >> 1)                                                    \
-    acc[j_ >> 2][j_ & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FB[j_ & 3], FA[j_ >> 2], acc[j_ >> 2][j_ & 3], 0, 0, 0); \
+  _Pragma("unroll") for (int j_ = 0; j_ < NSLOT; ++j_) {                                                                 \
+    if ((DMA_A) && W4_DO_DMA) {                                                                                          \
+      _Pragma("unroll") for (int q_ = 0; q_ < JA; ++q_)                                                                  \
+        if (j_ == q_ * NSLOT / JA)                                                                                       \
+          gemm_dma_piece(smem + (kt & 1) * STAGE + (q_ * NW + w) * (RPI * RB), p.A, bytes_a, vpa[q_], (uint32_t)(kt + 2) * (uint32_t)RB); \
+    }                                                                                                                    \
+    if ((DMA_W) && W4_DO_DMA) {                                                                                          \
+      _Pragma("unroll") for (int q_ = 0; q_ < JW; ++q_)                                                                  \
+        if (j_ == q_ * NSLOT / JW + 1)                                                                                   \
+          gemm_dma_piece(smem + ((kt + 1) & 1) * STAGE + A_BYTES + (q_ * NW + w) * (RPI * RB), p.W, bytes_w, vpw[q_],    \
+                         (uint32_t)(kt + 1) * (uint32_t)RB);                                                             \
+    }                                                                                                                    \
+    if (NEXT) {                                                                                                          \
+      _Pragma("unroll") for (int f_ = 0; f_ < NFRAG; ++f_)                                                               \
+        if (j_ == f_ * NSLOT / NFRAG) W4_FRAG(GA, GB, NBASE, NKK, f_)                                                    \
+    }                                                                                                                    \
+    acc[j_ / TN][j_ % TN] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FB[j_ % TN], FA[j_ / TN], acc[j_ / TN][j_ % TN], 0, 0, 0); \
     __builtin_amdgcn_sched_barrier(0);                                                                                   \
   }
 #define W4_KTILE(DMA, NEXT)                                                                                              \
@@ -524,10 +500,25 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
     W4_SYNC                                                                                                              \
     W4_SLICE(fa1, fb1, fa0, fb0, nbase, 0, NEXT, DMA, false)                                                             \
   }
-#endif
 
+  // Tiles are handed out at run time, one queue per XCD (tile ids congruent to the block's XCD mod 8, so the XCD-contiguous
+  // remap below still lands neighbouring tiles in one L2): in the train step this kernel shares the GPU with another stream, its
+  // blocks (a whole CU each) start whenever a CU drains, and a static tile -> block assignment lets one late block hold two tiles
+  // while the others idle (measured: the 256x192 form, 1.9 rounds, was 15 % faster standalone and 2 ms slower in the step).
+  // Thread 0 draws the NEXT tile while the current one is being worked on; the id travels through the last LDS word.
   const int ntiles = p.tiles_m * p.tiles_n;
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  const int my_xcd = blockIdx.x & 7;
+  const int my_count = (ntiles - my_xcd + 7) >> 3;       // tiles in this XCD's queue
+  int* tile_slot = reinterpret_cast<int*>(smem + 2 * STAGE);
+  int draw = 0;
+  if (threadIdx.x == 0) draw = (int)atomicAdd(p.sched + my_xcd, 1u);
+  draw = __builtin_amdgcn_readfirstlane(draw);
+  if (threadIdx.x == 0) *tile_slot = draw;
+  __syncthreads();
+  int cur = *tile_slot;
+  while (cur < my_count) {
+    const int tile = cur * 8 + my_xcd;
+    if (threadIdx.x == 0) draw = (int)atomicAdd(p.sched + my_xcd, 1u);  // consumed at the end of this tile
     {
       int bid = tile;
       const int q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, idx = bid >> 3;
@@ -541,77 +532,50 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
       bn = (bid % per_group) / gsize;
     }
 #pragma unroll
-    for (int j = 0; j < J; ++j) {
-      const int tr = (j * NW + w) * RPI;
-      vpa[j] = vA + (uint32_t)((long long)(bm * BM + tr) * p.lda * 2);
-      vpw[j] = vW + (uint32_t)((long long)(bn * BN + tr) * p.ldw * 2);
-    }
+    for (int j = 0; j < JA; ++j) vpa[j] = vA + (uint32_t)((long long)(bm * BM + (j * NW + w) * RPI) * p.lda * 2);
+#pragma unroll
+    for (int j = 0; j < JW; ++j) vpw[j] = vW + (uint32_t)((long long)(bn * BN + (j * NW + w) * RPI) * p.ldw * 2);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    gemm_stage_dma<J, J, NW, RPI * RB>(smem, smem + A_BYTES, p.A, bytes_a, p.W, bytes_w, vpa, vpw, w, 0u);
-#ifdef EXP_W4_REG
-    if (nk > 1) {
-      gemm_stage_dma<J, J, NW, RPI * RB>(smem + STAGE, smem + STAGE + A_BYTES, p.A, bytes_a, p.W, bytes_w, vpa, vpw, w, (uint32_t)RB);
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * J) : "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-#else
+    gemm_stage_dma<JA, JW, NW, RPI * RB>(smem, smem + A_BYTES, p.A, bytes_a, p.W, bytes_w, vpa, vpw, w, 0u);
     if (nk > 1) {  // the A pieces of K-tile 1 (its W pieces go out in the first slice of K-tile 0)
 #pragma unroll
-      for (int j = 0; j < J; ++j) gemm_dma_piece(smem + STAGE + (j * NW + w) * (RPI * RB), p.A, bytes_a, vpa[j], (uint32_t)RB);
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(J) : "memory");
+      for (int j = 0; j < JA; ++j) gemm_dma_piece(smem + STAGE + (j * NW + w) * (RPI * RB), p.A, bytes_a, vpa[j], (uint32_t)RB);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(JA) : "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-#endif
     __builtin_amdgcn_s_barrier();
-    bf16x8 fa0[4], fb0[4], fa1[4], fb1[4];
+    bf16x8 fa0[4], fb0[TN], fa1[4], fb1[TN];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) W4_FRAG(fa0, fb0, smem, 0, i)
+    for (int i = 0; i < NFRAG; ++i) W4_FRAG(fa0, fb0, smem, 0, i)
     int kt = 0;
-#ifdef EXP_W4_REG
-    mrb_u32x4 pre[16];
-    if (nk > 2) {
-#pragma unroll
-      for (int j = 0; j < 16; ++j)
-        pre[j] = j < 8 ? gemm_load_piece(p.A, bytes_a, vpa[j & 7], 2u * RB) : gemm_load_piece(p.W, bytes_w, vpw[j & 7], 2u * RB);
-    }
-    for (; kt < nk - 3; ++kt) W4_KTILE(true, true, true)
-    if (kt < nk - 2) {
-      W4_KTILE(true, false, true)
-      ++kt;
-    }
-    if (kt < nk - 1) {
-      W4_KTILE(false, false, true)
-      ++kt;
-    }
-    W4_KTILE(false, false, false)
-#else
     for (; kt < nk - 2; ++kt) W4_KTILE(true, true)
     if (kt < nk - 1) {
       W4_KTILE(false, true)
       ++kt;
     }
     W4_KTILE(false, false)
-#endif
 #undef W4_KTILE
 #undef W4_SLICE
 #undef W4_FRAG
 
-    // ---- epilogue: 32-row x 128-column fp32 slabs per wave through LDS (the transposition of gemm_tile_kernel), then 16 lanes
-    // cover one row and every lane owns the SAME 8 columns in all passes: its bias values are loaded once per tile.
-    constexpr int RS = 128 * 4 + 16;
+    // ---- epilogue: 32-row x WN-column fp32 slabs per wave through LDS (the transposition of gemm_tile_kernel), then LPR lanes cover
+    // one row and every lane owns the SAME 8 columns in all passes: its bias values are loaded once per tile.
+    constexpr int RS = WN * 4 + 16;
+    constexpr int LPR = WN / 8, ROWS = 64 / LPR, PASSES = (32 + ROWS - 1) / ROWS;  // 16 lanes x 4 rows x 8 | 12 lanes x 5 rows x 7
     __syncthreads();
     char* slab = smem + w * (32 * RS);
-    const int c8 = (lane & 15) * 8;                       // the lane's 8 columns inside the wave's 128
-    const int n0 = bn * BN + wn * 128 + c8;
-    const bool n_ok = n0 < p.N;
+    const bool lane_on = lane < LPR * ROWS;
+    const int lrow = lane / LPR;
+    const int c8 = (lane % LPR) * 8;                      // the lane's 8 columns inside the wave's WN
+    const int n0 = bn * BN + wn * WN + c8;
+    const bool n_ok = lane_on && n0 < p.N;
     float bias8[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) bias8[i] = 0.f;
@@ -625,30 +589,29 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
+      for (int nt = 0; nt < TN; ++nt)
 #pragma unroll
         for (int g = 0; g < 4; ++g)
           *reinterpret_cast<float4*>(slab + l31 * RS + (nt * 32 + 8 * g + 4 * hi) * 4) =
               make_float4(acc[mt][nt][4 * g], acc[mt][nt][4 * g + 1], acc[mt][nt][4 * g + 2], acc[mt][nt][4 * g + 3]);
-      const int m_base = bm * BM + wm * 128 + mt * 32 + (lane >> 4);
-      float4 x0[8], x1[8], r0[8], r1[8];
+      const int m_base = bm * BM + wm * 128 + mt * 32;
+      float4 x0[PASSES], x1[PASSES], r0[PASSES], r1[PASSES];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {  // row 4 i + lane / 16 of the slab
-        const char* sp = slab + (i * 4 + (lane >> 4)) * RS + c8 * 4;
+      for (int i = 0; i < PASSES; ++i) {  // row ROWS i + lane / LPR of the slab
+        const int r = i * ROWS + lrow;
+        const bool ok = n_ok && r < 32 && m_base + r < p.M;
+        const char* sp = slab + (r < 32 ? r : 0) * RS + c8 * 4;
         x0[i] = *reinterpret_cast<const float4*>(sp);
         x1[i] = *reinterpret_cast<const float4*>(sp + 16);
-        if (RES) {
-          const int m = m_base + i * 4;
-          if (m < p.M && n_ok) {
-            const float* rp = p.residual + (long long)m * p.ldr + n0;
-            r0[i] = *reinterpret_cast<const float4*>(rp);
-            r1[i] = *reinterpret_cast<const float4*>(rp + 4);
-          }
+        if (RES && ok) {
+          const float* rp = p.residual + (long long)(m_base + r) * p.ldr + n0;
+          r0[i] = *reinterpret_cast<const float4*>(rp);
+          r1[i] = *reinterpret_cast<const float4*>(rp + 4);
         }
       }
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int m = m_base + i * 4;
+      for (int i = 0; i < PASSES; ++i) {
+        const int r = i * ROWS + lrow, m = m_base + r;
         float v[8] = {x0[i].x + bias8[0], x0[i].y + bias8[1], x0[i].z + bias8[2], x0[i].w + bias8[3],
                       x1[i].x + bias8[4], x1[i].y + bias8[5], x1[i].z + bias8[6], x1[i].w + bias8[7]};
         if (ACT == 1) {
@@ -657,7 +620,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
         if (RES) {
           v[0] += r0[i].x; v[1] += r0[i].y; v[2] += r0[i].z; v[3] += r0[i].w; v[4] += r1[i].x; v[5] += r1[i].y; v[6] += r1[i].z; v[7] += r1[i].w;
         }
-        if (m < p.M && n_ok) {
+        if (n_ok && r < 32 && m < p.M) {
           if (OUT_F32) {
             float4* o = reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + (long long)m * p.ldo + n0);
             o[0] = make_float4(v[0], v[1], v[2], v[3]);
@@ -669,8 +632,16 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
         }
       }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    if (threadIdx.x == 0) *tile_slot = draw;
+    __syncthreads();  // every wave is done with the slabs (the next tile's LDS-DMA overwrites them) and sees the next tile id
+    cur = *tile_slot;
+  }
+  // the last block to finish re-arms the counters for the next launch (every block has made its final draw before it counts itself)
+  if (threadIdx.x == 0) {
+    if (atomicAdd(p.sched + 8, 1u) == gridDim.x - 1) {
+#pragma unroll
+      for (int i = 0; i < 9; ++i) __hip_atomic_store(p.sched + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 }
 
@@ -830,6 +801,17 @@ static void mk_drop_arg(DropoutArg& d, const uint32_t* seed_ptr, uint32_t site, 
   d.inv_keep = 1.0f / (1.0f - p);
 }
 
+static int g_cu_reserve = getenv("MRB_W4_RESERVE") ? atoi(getenv("MRB_W4_RESERVE")) / 8 * 8 : 0;
+
+// Number of CUs (rounded down to a multiple of 8, one per XCD) that the persistent GEMM kernels (tile configs 13 / 14) launched from
+// now on leave to other streams; returns the previous value.  Host-side state read at launch time: it applies to the launches the
+// calling thread enqueues until it is changed again.
+extern "C" int mrblip_gemm_set_cu_reserve(int n_cus) {
+  const int prev = g_cu_reserve;
+  g_cu_reserve = n_cus < 0 ? 0 : n_cus / 8 * 8;
+  return prev;
+}
+
 // shared by the C entry points: validation, tile selection, launch.  ext_first / ext_* / a_* : see GemmArgs.
 static int gemm_dispatch(const void* A, long long lda, const void* W, long long ldw, const void* Aext, long long ldaext,
                          const void* Wext, long long ldwext, int M, int N, int K, void* out, long long ldo, int out_f32,
@@ -856,6 +838,7 @@ static int gemm_dispatch(const void* A, long long lda, const void* W, long long 
   a.out = out; a.out2 = out2; a.bias = bias; a.residual = residual;
   a.lda = lda; a.ldw = ldw; a.ldaext = Aext ? ldaext : 0; a.ldwext = Wext ? ldwext : 0; a.ldo = ldo; a.ldo2 = ldo2; a.ldr = ldr;
   a.M = M; a.N = N; a.K = K; a.act = act; a.tiles_m = a.tiles_n = 0;
+  a.sched = nullptr;
   a.drop.seed_ptr = (p_drop > 0.f) ? seed_ptr : nullptr;
   a.drop.site = site;
   a.drop.thresh24 = (uint32_t)(p_drop * 65536.0f + 0.5f);
@@ -951,11 +934,15 @@ static int gemm_dispatch(const void* A, long long lda, const void* W, long long 
     MRB_REQUIRE(!gated, "gemm: cfg 12 has no gated epilogue");
     return out_f32 ? launch_tile<256, 192, 4, 2, true, false>(a, stream) : launch_tile<256, 192, 4, 2, false, false>(a, stream);
   }
-  if (cfg == 13) {  // 256x256, 4 waves of 128x128, hand-pipelined K loop (plain epilogues)
-    MRB_REQUIRE(!gated && !Aext && !out2 && !(p_drop > 0.f), "gemm: cfg 13 takes plain epilogues only");
+  if (cfg == 13 || cfg == 14) {  // four waves of 128 x 128 (cfg 13, 256x256 tile) / 128 x 96 (cfg 14, 256x192), hand-pipelined K loop
+    MRB_REQUIRE(!gated && !Aext && !out2 && !(p_drop > 0.f), "gemm: cfg 13 / 14 take plain epilogues only");
+    MRB_REQUIRE(act == 0 || act == 1, "gemm: cfg 13 / 14 know act 0 / 1");
+    const int bn13 = cfg == 13 ? 256 : 192;
     a.tiles_m = (M + 255) / 256;
-    a.tiles_n = (N + 255) / 256;
-    constexpr int LDS = 2 * 2 * 256 * 128;
+    a.tiles_n = (N + bn13 - 1) / bn13;
+    static int lds_pad = -1;
+    if (lds_pad < 0) lds_pad = getenv("MRB_W4_LDS_PAD") ? atoi(getenv("MRB_W4_LDS_PAD")) : 0;
+    const int LDS = 2 * (256 + bn13) * 128 + 16 + (cfg == 14 ? lds_pad : 0);  // + the tile-id word
     static int ncu13 = 0;
     if (ncu13 == 0) {
       int dev = 0;
@@ -963,13 +950,35 @@ static int gemm_dispatch(const void* A, long long lda, const void* W, long long 
       ncu13 = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
     }
     const int nt13 = a.tiles_m * a.tiles_n;
-    const int grid = nt13 < ncu13 ? nt13 : ncu13;
-    MRB_REQUIRE(act == 0 || act == 1, "gemm: cfg 13 knows act 0 / 1");
-    const int variant = (out_f32 ? 4 : 0) | (act == 1 ? 2 : 0) | (residual ? 1 : 0);
-    static bool attr_set13[8] = {false, false, false, false, false, false, false, false};
-#define MRB_W4_LAUNCH(V, F32, ACT_, RES_)                                                                                          \
+    // g_cu_reserve: CUs this persistent kernel leaves alone (mrblip_gemm_set_cu_reserve).  Its blocks hold a whole CU each for the
+    // whole launch (all 512 registers of every SIMD), so kernels of another stream can only start on CUs it does not occupy: the
+    // frozen-ViT look-ahead of the train step gives the clip that is being trained a quarter of the chip this way.
+    const int reserve = g_cu_reserve;
+    const int cus = ncu13 - reserve > 8 ? ncu13 - reserve : 8;
+    const int grid = nt13 < cus ? (nt13 + 7) / 8 * 8 : cus;  // (a multiple of 8: every XCD's queue has blocks)
+    {  // tile-queue counters, one set per stream (launches on one stream are ordered; the kernel leaves them zeroed)
+      struct Sched { hipStream_t st; uint32_t* p; };
+      static Sched tab[16];
+      static int ntab = 0;
+      uint32_t* sp = nullptr;
+      for (int i = 0; i < ntab; ++i)
+        if (tab[i].st == stream) sp = tab[i].p;
+      if (!sp) {
+        MRB_REQUIRE(ntab < 16, "gemm: cfg 13 / 14 used from more than 16 streams");
+        if (hipMalloc((void**)&sp, 64) != hipSuccess || hipMemset(sp, 0, 64) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+          mrblip_set_error("gemm: cannot allocate the tile-queue counters");
+          return MRBLIP_ELAUNCH;
+        }
+        tab[ntab].st = stream;
+        tab[ntab++].p = sp;
+      }
+      a.sched = sp;
+    }
+    const int variant = (cfg == 14 ? 8 : 0) | (out_f32 ? 4 : 0) | (act == 1 ? 2 : 0) | (residual ? 1 : 0);
+    static bool attr_set13[16] = {};
+#define MRB_W4_LAUNCH(V, F32, ACT_, RES_, TN_)                                                                                     \
   case V: {                                                                                                                        \
-    auto k = gemm_w4_kernel<F32, ACT_, RES_>;                                                                                      \
+    auto k = gemm_w4_kernel<F32, ACT_, RES_, TN_>;                                                                                 \
     if (!attr_set13[V]) {                                                                                                          \
       if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {                    \
         mrblip_set_error("gemm: cannot raise dynamic LDS to %d", LDS);                                                             \
@@ -981,14 +990,22 @@ static int gemm_dispatch(const void* A, long long lda, const void* W, long long 
     break;                                                                                                                         \
   }
     switch (variant) {
-      MRB_W4_LAUNCH(0, false, 0, false)
-      MRB_W4_LAUNCH(1, false, 0, true)
-      MRB_W4_LAUNCH(2, false, 1, false)
-      MRB_W4_LAUNCH(3, false, 1, true)
-      MRB_W4_LAUNCH(4, true, 0, false)
-      MRB_W4_LAUNCH(5, true, 0, true)
-      MRB_W4_LAUNCH(6, true, 1, false)
-      MRB_W4_LAUNCH(7, true, 1, true)
+      MRB_W4_LAUNCH(0, false, 0, false, 4)
+      MRB_W4_LAUNCH(1, false, 0, true, 4)
+      MRB_W4_LAUNCH(2, false, 1, false, 4)
+      MRB_W4_LAUNCH(3, false, 1, true, 4)
+      MRB_W4_LAUNCH(4, true, 0, false, 4)
+      MRB_W4_LAUNCH(5, true, 0, true, 4)
+      MRB_W4_LAUNCH(6, true, 1, false, 4)
+      MRB_W4_LAUNCH(7, true, 1, true, 4)
+      MRB_W4_LAUNCH(8, false, 0, false, 3)
+      MRB_W4_LAUNCH(9, false, 0, true, 3)
+      MRB_W4_LAUNCH(10, false, 1, false, 3)
+      MRB_W4_LAUNCH(11, false, 1, true, 3)
+      MRB_W4_LAUNCH(12, true, 0, false, 3)
+      MRB_W4_LAUNCH(13, true, 0, true, 3)
+      MRB_W4_LAUNCH(14, true, 1, false, 3)
+      MRB_W4_LAUNCH(15, true, 1, true, 3)
     }
 #undef MRB_W4_LAUNCH
     return mrblip_check_launch("gemm_w4");

@@ -71,6 +71,7 @@ _ce = _sig("mrblip_cross_entropy", vp, ll, vp, i32, i32, f32, vp, vp, ll, vp)
 _adamw = _sig("mrblip_adamw", vp, vp, vp, vp, ll, vp, f32, f32, f32, f32, vp)
 _seed_bump = _sig("mrblip_seed_bump", vp, vp)
 _lora_dx = _sig("mrblip_lora_dx_add", vp, ll, i32, vp, ll, vp, i32, i32, i32, vp, u32, f32, vp)
+_cu_reserve = _sig("mrblip_gemm_set_cu_reserve", i32)
 
 EXPORTS = [
     "mrblip_last_error", "mrblip_abi_version", "mrblip_gemm_bf16", "mrblip_layernorm_fwd", "mrblip_rmsnorm_fwd",
@@ -79,6 +80,7 @@ EXPORTS = [
     "mrblip_cast_dropout", "mrblip_gelu_bwd", "mrblip_gated_gelu_bwd", "mrblip_cross_entropy", "mrblip_adamw",
     "mrblip_seed_bump", "mrblip_lora_dx_add", "mrblip_dropout_bf16", "mrblip_colsum", "mrblip_lora_pack", "mrblip_lora_tn",
     "mrblip_lora_grads", "mrblip_gemm_lora_down", "mrblip_gemm_lora_dx", "mrblip_patchify_u8",
+    "mrblip_gemm_set_cu_reserve",
 ]
 
 
@@ -132,6 +134,21 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, aext=None, wext
                1 if out.dtype == torch.float32 else 0, _p(out2), _ld(out2), _p(bias), _p(residual), _ld(residual), act,
                1 if gated else 0, sp, site, p, tile_cfg, _stream()))
     return out
+
+
+class gemm_cu_reserve:
+    """``with gemm_cu_reserve(n):`` the persistent GEMM kernels launched inside leave n CUs (a multiple of 8) to other streams."""
+
+    def __init__(self, n: int):
+        self.n = int(n)
+
+    def __enter__(self):
+        self.prev = _cu_reserve(self.n)
+        return self
+
+    def __exit__(self, *exc):
+        _cu_reserve(self.prev)
+        return False
 
 
 # ------------------------------------------------------------------------------------------------ norms
