@@ -194,13 +194,19 @@ def main():
             avg = sum(durs) / len(durs)
             ach = 2.0 * m * n * k / avg / 1e12
             roof = dict(bound="mfma", achieved=round(ach, 1), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_BF16_TFLOPS, 4),
-                        traffic=traffic, kernel="gemm_tile_kernel (ViT fc1 %dx%dx%d)" % (m, n, k), launches=len(durs), avg_us=round(avg * 1e6, 1))
+                        traffic=traffic, kernel="gemm_w4_kernel<bf16 out, bias+GELU> (ViT fc1 %dx%dx%d)" % (m, n, k), launches=len(durs),
+                        avg_us=round(avg * 1e6, 1))
+            if not args.no_lookahead:
+                # the timed launches are the look-ahead's: persistent blocks on (CUs - reserve) CUs, the rest is left to the other stream
+                roof["cus"] = torch.cuda.get_device_properties(dev).multi_processor_count - eng.vit_lookahead_reserve
+                roof["note"] = ("timed launches run on %d of %d CUs beside the clip being trained (look-ahead CU reserve); frac is against the "
+                                "whole chip's peak" % (roof["cus"], torch.cuda.get_device_properties(dev).multi_processor_count))
             if excl:
                 ea = sum(a.elapsed_time(b) * 1e-3 for a, b in excl) / len(excl)
                 roof["exclusive"] = dict(avg_us=round(ea * 1e6, 1), achieved=round(2.0 * m * n * k / ea / 1e12, 1),
                                          frac=round(2.0 * m * n * k / ea / 1e12 / PEAK_BF16_TFLOPS, 4),
-                                         note="same launches with the GPU to themselves (untimed extra ViT pass); the timed ones run beside the "
-                                              "previous clip's decoder/backward kernels (frozen-ViT look-ahead on a second stream)")
+                                         note="same launches with the GPU to themselves, all CUs (untimed extra ViT pass); the timed ones run "
+                                              "beside the previous clip's decoder/backward kernels (frozen-ViT look-ahead on a second stream)")
         else:
             roof = None
         out = {

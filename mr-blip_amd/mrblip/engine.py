@@ -1062,6 +1062,7 @@ class MrBlipEngine:
     # launch; without a reserve the other stream's short, latency-bound kernels (the decoder chain above all) queue behind them
     # (QVH, B = 1: 85.0 ms per step with 0, 80.3 with 32, 78.3 with 64, 80.3 with 96, 84.1 with 128 reserved CUs).
     vit_lookahead_reserve = int(os.environ.get("MRB_VIT_RESERVE", "64"))
+    vit_lookahead_early = os.environ.get("MRB_VIT_EARLY", "0") == "1"  # start beside the encoder forward instead of after it
 
     vit_tail_blocks = int(os.environ.get("MRB_VIT_TAIL", "5"))  # look-ahead blocks held back for prefetch_vit_tail()
 
@@ -1122,9 +1123,11 @@ class MrBlipEngine:
         ops.row_copy(fr, L["frame_src"], inp, L["frame_dst"])
         ops.row_copy(self.emb, L["emb_src"], inp, L["emb_dst"])
         kmask = L["mask"]
+        if next_video is not None and self.vit_lookahead_early:
+            self.prefetch_vit(next_video)
         enc = self.t5_encoder_forward(inp, Bv, S, kmask)
         self._mark("t5_encoder_forward")
-        if next_video is not None:  # (starting it earlier, beside the encoder forward, measured the same)
+        if next_video is not None and not self.vit_lookahead_early:
             self.prefetch_vit(next_video)
         loss, logits = self.t5_decoder_forward(layout.decoder_input_ids, layout.decoder_mask, enc, Bv, S, kmask, layout.labels, want_grad=backward)
         self._mark("t5_decoder_forward + loss")
