@@ -510,15 +510,17 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
   const int my_xcd = blockIdx.x & 7;
   const int my_count = (ntiles - my_xcd + 7) >> 3;       // tiles in this XCD's queue
   int* tile_slot = reinterpret_cast<int*>(smem + 2 * STAGE);
-  int draw = 0;
-  if (threadIdx.x == 0) draw = (int)atomicAdd(p.sched + my_xcd, 1u);
+  const bool queued = p.sched != nullptr;                // else: one tile per block (grid = tiles), the block leaves its CU after it
+  int draw = blockIdx.x >> 3;
+  if (queued && threadIdx.x == 0) draw = (int)atomicAdd(p.sched + my_xcd, 1u);
   draw = __builtin_amdgcn_readfirstlane(draw);
   if (threadIdx.x == 0) *tile_slot = draw;
   __syncthreads();
   int cur = *tile_slot;
   while (cur < my_count) {
     const int tile = cur * 8 + my_xcd;
-    if (threadIdx.x == 0) draw = (int)atomicAdd(p.sched + my_xcd, 1u);  // consumed at the end of this tile
+    draw = my_count;
+    if (queued && threadIdx.x == 0) draw = (int)atomicAdd(p.sched + my_xcd, 1u);  // consumed at the end of this tile
     {
       int bid = tile;
       const int q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, idx = bid >> 3;
@@ -637,7 +639,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
     cur = *tile_slot;
   }
   // the last block to finish re-arms the counters for the next launch (every block has made its final draw before it counts itself)
-  if (threadIdx.x == 0) {
+  if (queued && threadIdx.x == 0) {
     if (atomicAdd(p.sched + 8, 1u) == gridDim.x - 1) {
 #pragma unroll
       for (int i = 0; i < 9; ++i) __hip_atomic_store(p.sched + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -955,8 +957,11 @@ static int gemm_dispatch(const void* A, long long lda, const void* W, long long 
     // frozen-ViT look-ahead of the train step gives the clip that is being trained a quarter of the chip this way.
     const int reserve = g_cu_reserve;
     const int cus = ncu13 - reserve > 8 ? ncu13 - reserve : 8;
-    const int grid = nt13 < cus ? (nt13 + 7) / 8 * 8 : cus;  // (a multiple of 8: every XCD's queue has blocks)
-    {  // tile-queue counters, one set per stream (launches on one stream are ordered; the kernel leaves them zeroed)
+    static int nonpersist = -1;
+    if (nonpersist < 0) nonpersist = getenv("MRB_W4_NONPERSIST") ? atoi(getenv("MRB_W4_NONPERSIST")) : 0;
+    const bool one_tile_blocks = nonpersist == 1 || (nonpersist == 2 && reserve > 0);
+    const int grid = (nt13 < cus || one_tile_blocks) ? (nt13 + 7) / 8 * 8 : cus;  // (a multiple of 8: every XCD's queue has blocks)
+    if (!one_tile_blocks) {  // tile-queue counters, one set per stream (launches on one stream are ordered; the kernel leaves them zeroed)
       struct Sched { hipStream_t st; uint32_t* p; };
       static Sched tab[16];
       static int ntab = 0;
