@@ -509,7 +509,9 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
   const int ntiles = p.tiles_m * p.tiles_n;
   const int my_xcd = blockIdx.x & 7;
   const int my_count = (ntiles - my_xcd + 7) >> 3;       // tiles in this XCD's queue
-  int* tile_slot = reinterpret_cast<int*>(smem + 2 * STAGE);
+  constexpr int SLAB_BYTES = NW * 32 * (WN * 4 + 16);
+  constexpr int LDS_MAIN = 2 * STAGE > STAGE + SLAB_BYTES ? 2 * STAGE : STAGE + SLAB_BYTES;  // the epilogue slabs sit behind buffer 0
+  int* tile_slot = reinterpret_cast<int*>(smem + LDS_MAIN);
   const bool queued = p.sched != nullptr;                // else: one tile per block (grid = tiles), the block leaves its CU after it
   int draw = blockIdx.x >> 3;
   if (queued && threadIdx.x == 0) draw = (int)atomicAdd(p.sched + my_xcd, 1u);
@@ -517,26 +519,29 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
   if (threadIdx.x == 0) *tile_slot = draw;
   __syncthreads();
   int cur = *tile_slot;
+  // tile id -> (bm, bn) and the per-piece source offsets, then the LDS-DMA of its first K-tile into buffer 0
+#define W4_OPEN_TILE(T)                                                                                                   \
+  {                                                                                                                      \
+    int bid = (T) * 8 + my_xcd;                                                                                          \
+    const int q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, idx = bid >> 3;                                            \
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;                                                 \
+    constexpr int GROUP_M = 8;                                                                                           \
+    const int per_group = GROUP_M * p.tiles_n;                                                                           \
+    const int gid = bid / per_group;                                                                                     \
+    const int first_m = gid * GROUP_M;                                                                                   \
+    const int gsize = min(p.tiles_m - first_m, GROUP_M);                                                                 \
+    bm = first_m + (bid % per_group) % gsize;                                                                            \
+    bn = (bid % per_group) / gsize;                                                                                      \
+    _Pragma("unroll") for (int j = 0; j < JA; ++j) vpa[j] = vA + (uint32_t)((long long)(bm * BM + (j * NW + w) * RPI) * p.lda * 2); \
+    _Pragma("unroll") for (int j = 0; j < JW; ++j) vpw[j] = vW + (uint32_t)((long long)(bn * BN + (j * NW + w) * RPI) * p.ldw * 2); \
+    gemm_stage_dma<JA, JW, NW, RPI * RB>(smem, smem + A_BYTES, p.A, bytes_a, p.W, bytes_w, vpa, vpw, w, 0u);             \
+  }
+  if (cur < my_count) W4_OPEN_TILE(cur)
   while (cur < my_count) {
-    const int tile = cur * 8 + my_xcd;
+    // (bm, bn), the piece offsets and the LDS-DMA of K-tile 0 were set up by W4_OPEN_TILE: before the loop, or under the previous
+    // tile's epilogue, whose slabs lie behind buffer 0
     draw = my_count;
     if (queued && threadIdx.x == 0) draw = (int)atomicAdd(p.sched + my_xcd, 1u);  // consumed at the end of this tile
-    {
-      int bid = tile;
-      const int q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, idx = bid >> 3;
-      bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-      constexpr int GROUP_M = 8;
-      const int per_group = GROUP_M * p.tiles_n;
-      const int gid = bid / per_group;
-      const int first_m = gid * GROUP_M;
-      const int gsize = min(p.tiles_m - first_m, GROUP_M);
-      bm = first_m + (bid % per_group) % gsize;
-      bn = (bid % per_group) / gsize;
-    }
-#pragma unroll
-    for (int j = 0; j < JA; ++j) vpa[j] = vA + (uint32_t)((long long)(bm * BM + (j * NW + w) * RPI) * p.lda * 2);
-#pragma unroll
-    for (int j = 0; j < JW; ++j) vpw[j] = vW + (uint32_t)((long long)(bn * BN + (j * NW + w) * RPI) * p.ldw * 2);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -544,7 +549,6 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    gemm_stage_dma<JA, JW, NW, RPI * RB>(smem, smem + A_BYTES, p.A, bytes_a, p.W, bytes_w, vpa, vpw, w, 0u);
     if (nk > 1) {  // the A pieces of K-tile 1 (its W pieces go out in the first slice of K-tile 0)
 #pragma unroll
       for (int j = 0; j < JA; ++j) gemm_dma_piece(smem + STAGE + (j * NW + w) * (RPI * RB), p.A, bytes_a, vpa[j], (uint32_t)RB);
@@ -571,12 +575,16 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
     // one row and every lane owns the SAME 8 columns in all passes: its bias values are loaded once per tile.
     constexpr int RS = WN * 4 + 16;
     constexpr int LPR = WN / 8, ROWS = 64 / LPR, PASSES = (32 + ROWS - 1) / ROWS;  // 16 lanes x 4 rows x 8 | 12 lanes x 5 rows x 7
-    __syncthreads();
-    char* slab = smem + w * (32 * RS);
+    if (threadIdx.x == 0) *tile_slot = draw;
+    __syncthreads();  // every wave is done with both stage buffers and sees the next tile id
+    const int nxt = *tile_slot;
+    const int bm_e = bm, bn_e = bn;
+    if (nxt < my_count) W4_OPEN_TILE(nxt)  // the next tile's first K-tile flies into buffer 0 under this epilogue
+    char* slab = smem + STAGE + w * (32 * RS);
     const bool lane_on = lane < LPR * ROWS;
     const int lrow = lane / LPR;
     const int c8 = (lane % LPR) * 8;                      // the lane's 8 columns inside the wave's WN
-    const int n0 = bn * BN + wn * WN + c8;
+    const int n0 = bn_e * BN + wn * WN + c8;
     const bool n_ok = lane_on && n0 < p.N;
     float bias8[8];
 #pragma unroll
@@ -596,7 +604,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
         for (int g = 0; g < 4; ++g)
           *reinterpret_cast<float4*>(slab + l31 * RS + (nt * 32 + 8 * g + 4 * hi) * 4) =
               make_float4(acc[mt][nt][4 * g], acc[mt][nt][4 * g + 1], acc[mt][nt][4 * g + 2], acc[mt][nt][4 * g + 3]);
-      const int m_base = bm * BM + wm * 128 + mt * 32;
+      const int m_base = bm_e * BM + wm * 128 + mt * 32;
       float4 x0[PASSES], x1[PASSES], r0[PASSES], r1[PASSES];
 #pragma unroll
       for (int i = 0; i < PASSES; ++i) {  // row ROWS i + lane / LPR of the slab
@@ -634,10 +642,10 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
         }
       }
     }
-    if (threadIdx.x == 0) *tile_slot = draw;
-    __syncthreads();  // every wave is done with the slabs (the next tile's LDS-DMA overwrites them) and sees the next tile id
-    cur = *tile_slot;
+    __syncthreads();  // every wave is done with the slabs: the next tile's K-tile 1 goes into buffer 1, which they overlap
+    cur = nxt;
   }
+#undef W4_OPEN_TILE
   // the last block to finish re-arms the counters for the next launch (every block has made its final draw before it counts itself)
   if (queued && threadIdx.x == 0) {
     if (atomicAdd(p.sched + 8, 1u) == gridDim.x - 1) {
@@ -942,9 +950,8 @@ static int gemm_dispatch(const void* A, long long lda, const void* W, long long 
     const int bn13 = cfg == 13 ? 256 : 192;
     a.tiles_m = (M + 255) / 256;
     a.tiles_n = (N + bn13 - 1) / bn13;
-    static int lds_pad = -1;
-    if (lds_pad < 0) lds_pad = getenv("MRB_W4_LDS_PAD") ? atoi(getenv("MRB_W4_LDS_PAD")) : 0;
-    const int LDS = 2 * (256 + bn13) * 128 + 16 + (cfg == 14 ? lds_pad : 0);  // + the tile-id word
+    const int stage13 = (256 + bn13) * 128, slab13 = 4 * 32 * (bn13 / 2 * 4 + 16);
+    const int LDS = (2 * stage13 > stage13 + slab13 ? 2 * stage13 : stage13 + slab13) + 16;  // + the tile-id word
     static int ncu13 = 0;
     if (ncu13 == 0) {
       int dev = 0;
