@@ -37,7 +37,7 @@ def keep_mask(shape, seed, site, p):
     return dropout_keep(shape, seed, site, p).to(dev())
 
 
-@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 7, 8, 9, 10, 11, 12, 13])
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 7, 8, 9, 10, 11, 12, 13, 14])
 @pytest.mark.parametrize("M,N,K", [(300, 264, 128), (64, 520, 192), (513, 1408, 576), (33, 264, 2304), (1, 8, 64), (257, 8, 128)])
 def test_gemm_plain(ops, cfg, M, N, K):
     torch.manual_seed(0)
@@ -87,16 +87,42 @@ def test_gemm_four_wave_tile_epilogues(ops):
     res = torch.randn(M, N, device=dev())
     base = a.float() @ w.float().t() + bias
     out = torch.empty(M, N, dtype=torch.bfloat16, device=dev())
-    ops.gemm(a, w, out, bias=bias, act=1, tile_cfg=13)
-    assert rel(out.float(), torch.nn.functional.gelu(base)) < 3e-3
-    x = res.clone()
-    ops.gemm(a, w, x, bias=bias, residual=x, tile_cfg=13)
-    assert rel(x, res + base) < 2e-6
-    for k in (64, 128):  # one and two K-tiles
-        ops.gemm(a[:, :k].contiguous(), w[:, :k].contiguous(), x, tile_cfg=13)
-        assert rel(x, a[:, :k].float() @ w[:, :k].float().t()) < 2e-6
-    with pytest.raises(ops.MrblipError):
-        ops.gemm(a, w, out, gated=True, tile_cfg=13)
+    for cfg in (13, 14):
+        ops.gemm(a, w, out, bias=bias, act=1, tile_cfg=cfg)
+        assert rel(out.float(), torch.nn.functional.gelu(base)) < 3e-3
+        x = res.clone()
+        ops.gemm(a, w, x, bias=bias, residual=x, tile_cfg=cfg)
+        assert rel(x, res + base) < 2e-6
+        for k in (64, 128):  # one and two K-tiles
+            ops.gemm(a[:, :k].contiguous(), w[:, :k].contiguous(), x, tile_cfg=cfg)
+            assert rel(x, a[:, :k].float() @ w[:, :k].float().t()) < 2e-6
+        with pytest.raises(ops.MrblipError):
+            ops.gemm(a, w, out, gated=True, tile_cfg=cfg)
+
+
+@pytest.mark.parametrize("cfg", [13, 14])
+def test_gemm_cu_reserve_keeps_results(ops, cfg):
+    """mrblip_gemm_set_cu_reserve only changes how many persistent blocks draw from the tile queues: same bits with 0, 64 and 248 CUs
+    reserved (8 blocks walk all 48 tiles), the previous value comes back, and the counters are left re-armed for the next launch."""
+    torch.manual_seed(6)
+    M, N, K = 1500, 1800, 256
+    a = bf(torch.randn(M, K, device=dev()))
+    w = bf(torch.randn(N, K, device=dev()) * 0.1)
+    bias = torch.randn(N, device=dev())
+    ref = torch.empty(M, N, dtype=torch.bfloat16, device=dev())
+    ops.gemm(a, w, ref, bias=bias, act=1, tile_cfg=cfg)
+    assert rel(ref.float(), torch.nn.functional.gelu(a.float() @ w.float().t() + bias)) < 3e-3
+    for r in (64, 248, 250):
+        with ops.gemm_cu_reserve(r):
+            for _ in range(2):  # twice: the second launch starts from the counters the first one re-armed
+                out = torch.full_like(ref, float("nan"))
+                ops.gemm(a, w, out, bias=bias, act=1, tile_cfg=cfg)
+                assert torch.equal(out, ref), (cfg, r)
+    with ops.gemm_cu_reserve(32) as g:
+        assert g.prev == 0
+    out = torch.full_like(ref, float("nan"))
+    ops.gemm(a, w, out, bias=bias, act=1, tile_cfg=cfg)
+    assert torch.equal(out, ref)
 
 
 @pytest.mark.parametrize("cfg", [1, 2, 4, 7, 8, 9])
