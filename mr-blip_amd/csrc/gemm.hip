@@ -36,7 +36,6 @@ struct GemmArgs {
   int m_rows_per_block;  // skinny kernel only: 32, or 16 / 8 when few output columns leave most CUs without a block (more blocks stream
                          // the tall operand in parallel: one CU sustains only ~10 B/clk from HBM)
   DropoutArg a_drop;  // skinny kernel only: dropout of the A operand as it is loaded (zeroing; the 1/(1-p) is applied to the result)
-  uint32_t* sched;    // gemm_w4_kernel only: [0..7] per-XCD tile counters, [8] finished-block counter (all zero between launches)
 };
 
 // v0..v3: 4 consecutive columns n0..n0+3 of row m (raw accumulator). Applies bias -> (pre-activation copy) -> GELU -> dropout -> residual.
@@ -501,24 +500,13 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
     W4_SLICE(fa1, fb1, fa0, fb0, nbase, 0, NEXT, DMA, false)                                                             \
   }
 
-  // Tiles are handed out at run time, one queue per XCD (tile ids congruent to the block's XCD mod 8, so the XCD-contiguous
-  // remap below still lands neighbouring tiles in one L2): in the train step this kernel shares the GPU with another stream, its
-  // blocks (a whole CU each) start whenever a CU drains, and a static tile -> block assignment lets one late block hold two tiles
-  // while the others idle (measured: the 256x192 form, 1.9 rounds, was 15 % faster standalone and 2 ms slower in the step).
-  // Thread 0 draws the NEXT tile while the current one is being worked on; the id travels through the last LDS word.
+  // Persistent walk: block b works on the tiles b, b + grid, ... ; tile ids congruent mod 8 stay on one XCD (blocks are dealt to the
+  // XCDs round-robin) and the XCD-contiguous remap below lands neighbouring tiles in one L2.  (Drawing tiles at run time from per-XCD
+  // atomic counters instead measured the same, alone and in the train step, and needed device-side state: dropped.)
   const int ntiles = p.tiles_m * p.tiles_n;
   const int my_xcd = blockIdx.x & 7;
   const int my_count = (ntiles - my_xcd + 7) >> 3;       // tiles in this XCD's queue
-  constexpr int SLAB_BYTES = NW * 32 * (WN * 4 + 16);
-  constexpr int LDS_MAIN = 2 * STAGE > STAGE + SLAB_BYTES ? 2 * STAGE : STAGE + SLAB_BYTES;  // the epilogue slabs sit behind buffer 0
-  int* tile_slot = reinterpret_cast<int*>(smem + LDS_MAIN);
-  const bool queued = p.sched != nullptr;                // else: one tile per block (grid = tiles), the block leaves its CU after it
-  int draw = blockIdx.x >> 3;
-  if (queued && threadIdx.x == 0) draw = (int)atomicAdd(p.sched + my_xcd, 1u);
-  draw = __builtin_amdgcn_readfirstlane(draw);
-  if (threadIdx.x == 0) *tile_slot = draw;
-  __syncthreads();
-  int cur = *tile_slot;
+  int cur = blockIdx.x >> 3;                             // position in this XCD's list
   // tile id -> (bm, bn) and the per-piece source offsets, then the LDS-DMA of its first K-tile into buffer 0
 #define W4_OPEN_TILE(T)                                                                                                   \
   {                                                                                                                      \
@@ -540,8 +528,6 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
   while (cur < my_count) {
     // (bm, bn), the piece offsets and the LDS-DMA of K-tile 0 were set up by W4_OPEN_TILE: before the loop, or under the previous
     // tile's epilogue, whose slabs lie behind buffer 0
-    draw = my_count;
-    if (queued && threadIdx.x == 0) draw = (int)atomicAdd(p.sched + my_xcd, 1u);  // consumed at the end of this tile
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -575,9 +561,8 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
     // one row and every lane owns the SAME 8 columns in all passes: its bias values are loaded once per tile.
     constexpr int RS = WN * 4 + 16;
     constexpr int LPR = WN / 8, ROWS = 64 / LPR, PASSES = (32 + ROWS - 1) / ROWS;  // 16 lanes x 4 rows x 8 | 12 lanes x 5 rows x 7
-    if (threadIdx.x == 0) *tile_slot = draw;
-    __syncthreads();  // every wave is done with both stage buffers and sees the next tile id
-    const int nxt = *tile_slot;
+    __syncthreads();  // every wave is done with both stage buffers
+    const int nxt = cur + (int)(gridDim.x >> 3);
     const int bm_e = bm, bn_e = bn;
     if (nxt < my_count) W4_OPEN_TILE(nxt)  // the next tile's first K-tile flies into buffer 0 under this epilogue
     char* slab = smem + STAGE + w * (32 * RS);
@@ -646,13 +631,6 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
     cur = nxt;
   }
 #undef W4_OPEN_TILE
-  // the last block to finish re-arms the counters for the next launch (every block has made its final draw before it counts itself)
-  if (queued && threadIdx.x == 0) {
-    if (atomicAdd(p.sched + 8, 1u) == gridDim.x - 1) {
-#pragma unroll
-      for (int i = 0; i < 9; ++i) __hip_atomic_store(p.sched + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
 }
 
 // ---- skinny-M kernel (decoder rows, M <= a few 32-row tiles): weight-streaming bound.  One block = 32 output
@@ -848,7 +826,6 @@ static int gemm_dispatch(const void* A, long long lda, const void* W, long long 
   a.out = out; a.out2 = out2; a.bias = bias; a.residual = residual;
   a.lda = lda; a.ldw = ldw; a.ldaext = Aext ? ldaext : 0; a.ldwext = Wext ? ldwext : 0; a.ldo = ldo; a.ldo2 = ldo2; a.ldr = ldr;
   a.M = M; a.N = N; a.K = K; a.act = act; a.tiles_m = a.tiles_n = 0;
-  a.sched = nullptr;
   a.drop.seed_ptr = (p_drop > 0.f) ? seed_ptr : nullptr;
   a.drop.site = site;
   a.drop.thresh24 = (uint32_t)(p_drop * 65536.0f + 0.5f);
@@ -951,7 +928,7 @@ static int gemm_dispatch(const void* A, long long lda, const void* W, long long 
     a.tiles_m = (M + 255) / 256;
     a.tiles_n = (N + bn13 - 1) / bn13;
     const int stage13 = (256 + bn13) * 128, slab13 = 4 * 32 * (bn13 / 2 * 4 + 16);
-    const int LDS = (2 * stage13 > stage13 + slab13 ? 2 * stage13 : stage13 + slab13) + 16;  // + the tile-id word
+    const int LDS = 2 * stage13 > stage13 + slab13 ? 2 * stage13 : stage13 + slab13;
     static int ncu13 = 0;
     if (ncu13 == 0) {
       int dev = 0;
@@ -964,28 +941,7 @@ static int gemm_dispatch(const void* A, long long lda, const void* W, long long 
     // frozen-ViT look-ahead of the train step gives the clip that is being trained a quarter of the chip this way.
     const int reserve = g_cu_reserve;
     const int cus = ncu13 - reserve > 8 ? ncu13 - reserve : 8;
-    static int nonpersist = -1;
-    if (nonpersist < 0) nonpersist = getenv("MRB_W4_NONPERSIST") ? atoi(getenv("MRB_W4_NONPERSIST")) : 0;
-    const bool one_tile_blocks = nonpersist == 1 || (nonpersist == 2 && reserve > 0);
-    const int grid = (nt13 < cus || one_tile_blocks) ? (nt13 + 7) / 8 * 8 : cus;  // (a multiple of 8: every XCD's queue has blocks)
-    if (!one_tile_blocks) {  // tile-queue counters, one set per stream (launches on one stream are ordered; the kernel leaves them zeroed)
-      struct Sched { hipStream_t st; uint32_t* p; };
-      static Sched tab[16];
-      static int ntab = 0;
-      uint32_t* sp = nullptr;
-      for (int i = 0; i < ntab; ++i)
-        if (tab[i].st == stream) sp = tab[i].p;
-      if (!sp) {
-        MRB_REQUIRE(ntab < 16, "gemm: cfg 13 / 14 used from more than 16 streams");
-        if (hipMalloc((void**)&sp, 64) != hipSuccess || hipMemset(sp, 0, 64) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
-          mrblip_set_error("gemm: cannot allocate the tile-queue counters");
-          return MRBLIP_ELAUNCH;
-        }
-        tab[ntab].st = stream;
-        tab[ntab++].p = sp;
-      }
-      a.sched = sp;
-    }
+    const int grid = nt13 < cus ? (nt13 + 7) / 8 * 8 : cus;  // (a multiple of 8: the same number of blocks on every XCD)
     const int variant = (cfg == 14 ? 8 : 0) | (out_f32 ? 4 : 0) | (act == 1 ? 2 : 0) | (residual ? 1 : 0);
     static bool attr_set13[16] = {};
 #define MRB_W4_LAUNCH(V, F32, ACT_, RES_, TN_)                                                                                     \

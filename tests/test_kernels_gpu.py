@@ -102,8 +102,8 @@ def test_gemm_four_wave_tile_epilogues(ops):
 
 @pytest.mark.parametrize("cfg", [13, 14])
 def test_gemm_cu_reserve_keeps_results(ops, cfg):
-    """mrblip_gemm_set_cu_reserve only changes how many persistent blocks draw from the tile queues: same bits with 0, 64 and 248 CUs
-    reserved (8 blocks walk all 48 tiles), the previous value comes back, and the counters are left re-armed for the next launch."""
+    """mrblip_gemm_set_cu_reserve only changes how many persistent blocks walk the tiles: same bits with 0, 64 and 248 CUs reserved
+    (8 blocks walk all 48 tiles) and the previous value comes back."""
     torch.manual_seed(6)
     M, N, K = 1500, 1800, 256
     a = bf(torch.randn(M, K, device=dev()))
@@ -114,7 +114,7 @@ def test_gemm_cu_reserve_keeps_results(ops, cfg):
     assert rel(ref.float(), torch.nn.functional.gelu(a.float() @ w.float().t() + bias)) < 3e-3
     for r in (64, 248, 250):
         with ops.gemm_cu_reserve(r):
-            for _ in range(2):  # twice: the second launch starts from the counters the first one re-armed
+            for _ in range(2):
                 out = torch.full_like(ref, float("nan"))
                 ops.gemm(a, w, out, bias=bias, act=1, tile_cfg=cfg)
                 assert torch.equal(out, ref), (cfg, r)
