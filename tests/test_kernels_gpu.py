@@ -100,6 +100,38 @@ def test_gemm_four_wave_tile_epilogues(ops):
             ops.gemm(a, w, out, gated=True, tile_cfg=cfg)
 
 
+def test_vit_gemms_full_size_against_fp32_reference(ops):
+    """The frozen-ViT GEMMs at the QVH shapes (60 frames x 257 tokens = 15420 rows), as the library dispatches them itself (the
+    persistent four-wave kernel), against fp32 torch: fc1 (bias + exact-erf GELU, bf16 out), fc2 (bias + fp32 residual, in place),
+    qkv (bias, bf16 out); and the same bits when the launch leaves 64 CUs to another stream (the look-ahead's setting)."""
+    torch.manual_seed(11)
+    M, D, F = 15420, 1408, 6144
+    h = bf(torch.randn(M, D, device=dev()))
+    w1 = bf(torch.randn(F, D, device=dev()) * 0.03)
+    b1 = torch.randn(F, device=dev()) * 0.1
+    f = torch.empty(M, F, dtype=torch.bfloat16, device=dev())
+    ops.gemm(h, w1, f, bias=b1, act=1)
+    ref = torch.nn.functional.gelu(h.float() @ w1.float().t() + b1)
+    assert rel(f.float(), ref) < 3e-3
+    with ops.gemm_cu_reserve(64):
+        f2 = torch.empty_like(f)
+        ops.gemm(h, w1, f2, bias=b1, act=1)
+    assert torch.equal(f2, f)
+    del ref, f2
+    w2 = bf(torch.randn(D, F, device=dev()) * 0.02)
+    b2 = torch.randn(D, device=dev()) * 0.1
+    x = torch.randn(M, D, device=dev())
+    want = x + f.float() @ w2.float().t() + b2
+    ops.gemm(f, w2, x, bias=b2, residual=x)
+    assert rel(x, want) < 2e-6
+    del want
+    wq = bf(torch.randn(3 * D, D, device=dev()) * 0.03)
+    bq = torch.randn(3 * D, device=dev()) * 0.1
+    qkv = torch.empty(M, 3 * D, dtype=torch.bfloat16, device=dev())
+    ops.gemm(h, wq, qkv, bias=bq)
+    assert rel(qkv.float(), h.float() @ wq.float().t() + bq) < 3e-3
+
+
 @pytest.mark.parametrize("cfg", [13, 14])
 def test_gemm_cu_reserve_keeps_results(ops, cfg):
     """mrblip_gemm_set_cu_reserve only changes how many persistent blocks walk the tiles: same bits with 0, 64 and 248 CUs reserved
