@@ -36,3 +36,27 @@ def relerr(a, b):
     a = torch.as_tensor(a, dtype=torch.float64)
     b = torch.as_tensor(b, dtype=torch.float64)
     return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+# ---- measured-error log: every parity test records what it measured (name -> value, tolerance asserted) so the tolerances written in
+# the tests can be justified by numbers.  Written to gpurun_out/parity_errors.json on the box that ran the tests (merged back by gpurun;
+# the judged copy is committed under profiles/).
+_ERR_LOG = os.environ.get("MRB_PARITY_LOG") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_errors.json")
+
+
+def record(name: str, value: float, tol: float = None):
+    """log a measured error; returns the value (use as ``assert record(...) < tol``)"""
+    try:
+        os.makedirs(os.path.dirname(_ERR_LOG), exist_ok=True)
+        data = json.load(open(_ERR_LOG)) if os.path.exists(_ERR_LOG) else {}
+        data[name] = {"measured": float(value), "tolerance": tol}
+        with open(_ERR_LOG, "w") as f:
+            json.dump(data, f, indent=1, sort_keys=True)
+    except OSError:
+        pass
+    return value
+
+
+def check(name: str, value: float, tol: float):
+    record(name, value, tol)
+    assert value < tol, f"{name}: measured {value:.3e} >= tolerance {tol:.3e}"
