@@ -49,7 +49,7 @@ class BLIP2_MR(BaseModel):
                  num_query_token=32, t5_model="google/flan-t5-xl", num_beams=5, prompt="", max_txt_len=200, apply_lemmatizer=False,
                  input_time_format="seconds_integers", interleave_data=False, frame_token_aggregation=None, task="lora",
                  num_frames_for_answer=4, resample_frames=False, engine_config: Optional[EngineConfig] = None, weights=None,
-                 tokenizer=None, device=None, seed=42):
+                 tokenizer=None, device=None, seed=42, synthetic_weights=False):
         super().__init__()
         if not freeze_vit:
             raise NotImplementedError("the MI355X engine keeps the ViT frozen (every Mr. BLIP config sets freeze_vit: True)")
@@ -69,12 +69,20 @@ class BLIP2_MR(BaseModel):
         self._device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
         cfg = engine_config or EngineConfig(img=img_size, num_query=num_query_token)
         cfg.mean_pool = frame_token_aggregation == "mean"
-        self.t5_tokenizer = tokenizer or load_tokenizer(t5_model)
+        self.t5_tokenizer = tokenizer or load_tokenizer(t5_model, allow_fixture=bool(synthetic_weights))
         self.annoying_numbers, _ = P.find_annoying_numbers(self.t5_tokenizer, 200)
         self.annoying_numbers_replacement_dict = P.annoying_replacement_dict(self.annoying_numbers)
-        src = weights if weights is not None else RandomSource(self._device, seed=1234)
-        if isinstance(src, dict):
-            src = StateDictSource(src)
+        if weights is None:
+            # the reference downloads eva_vit_g / BLIP-2 / flan-t5 here (blip2_mr.py:127-151); without them the only honest options are
+            # an explicit synthetic run or an error — never a silently random backbone
+            if not synthetic_weights:
+                raise RuntimeError("blip2_mr: no backbone weights.  Give model.vit_weights (eva_vit_g.pth), model.pretrained (BLIP-2 stage-2 "
+                                   "checkpoint) and model.t5_weights (HF flan-t5 directory), or pass weights=<state dict>; set "
+                                   "model.synthetic_weights: True for a random-weight (benchmark / plumbing) run")
+            logging.warning("blip2_mr: synthetic_weights — ViT, Q-Former and T5 are RANDOM (seeded); only throughput/plumbing is meaningful")
+            src = RandomSource(self._device, seed=1234)
+        else:
+            src = StateDictSource(weights) if isinstance(weights, dict) else weights
         self.engine = MrBlipEngine(cfg, src, self._device, seed=seed)
         nd = self.engine.n_decay
         # the trainable tensors as two flat Parameters that ALIAS the engine's buffer (AdamW decay / no-decay groups)
@@ -88,6 +96,27 @@ class BLIP2_MR(BaseModel):
         ecfg = None
         if cfg.get("engine"):
             ecfg = EngineConfig(**dict(cfg.engine))
+        # frozen backbones: the reference's three downloads as local paths (checkpoint.py); `pretrained` keeps its reference meaning
+        # (the BLIP-2 stage-2 file with Q-Former / query_tokens / ln_vision / t5_proj, blip2.py:86-104)
+        weights = None
+        paths = dict(vit=cfg.get("vit_weights") or None, blip2=cfg.get("pretrained") or None, t5=cfg.get("t5_weights") or None)
+        if any(paths.values()):
+            from mrblip import checkpoint as CK
+            probe = ecfg or EngineConfig(img=cfg.get("image_size", 224), num_query=cfg.get("num_query_token", 32))
+            weights, report = CK.assemble_state_dict(probe, **paths)
+            logging.info("Missing keys {}".format(report["missing"]))  # (the reference's non-strict log line, blip2.py:100)
+            if report["unexpected"]:
+                logging.info("unexpected keys (ignored) %s", CK.describe(dict(unexpected=report["unexpected"])))
+            if report["bad_shape"]:
+                raise RuntimeError("checkpoint tensors with the wrong shape: %s" % CK.describe(dict(bad_shape=report["bad_shape"])))
+            backbone_missing = [k for k in report["missing"] if not (k.startswith("t5_proj.") or k.startswith("ln_vision."))]
+            if backbone_missing:
+                raise RuntimeError("incomplete backbone weights (vit_weights / pretrained / t5_weights): %s" % CK.describe(dict(missing=backbone_missing)))
+            if "t5_proj.weight" in report["missing"]:   # a BLIP-2 file without t5_proj: the reference keeps its fresh nn.Linear init (blip2_mr.py:270-272)
+                lin = torch.nn.Linear(probe.qf_dim, probe.d_model)
+                weights["t5_proj.weight"], weights["t5_proj.bias"] = lin.weight.detach(), lin.bias.detach()
+            if "ln_vision.weight" in report["missing"]:
+                weights["ln_vision.weight"], weights["ln_vision.bias"] = torch.ones(probe.vit_dim), torch.zeros(probe.vit_dim)
         model = cls(
             img_size=cfg.get("image_size", 224), num_query_token=cfg.get("num_query_token", 32), t5_model=cfg.get("t5_model", "google/flan-t5-xl"),
             num_beams=cfg.get("num_beams", 5), drop_path_rate=cfg.get("drop_path_rate", 0), use_grad_checkpoint=cfg.get("use_grad_checkpoint", False),
@@ -96,6 +125,7 @@ class BLIP2_MR(BaseModel):
             input_time_format=cfg.get("input_time_format", "seconds_integers"), interleave_data=cfg.get("interleave_data", False),
             frame_token_aggregation=cfg.get("frame_token_aggregation", None), task=cfg.get("task", "lora"),
             num_frames_for_answer=cfg.get("num_frames_for_answer", 4), resample_frames=cfg.get("resample_frames", False), engine_config=ecfg,
+            weights=weights, synthetic_weights=cfg.get("synthetic_weights", False), seed=cfg.get("seed", 42),
         )
         model.load_checkpoint_from_config(cfg)
         return model
@@ -246,5 +276,8 @@ class BLIP2_MR(BaseModel):
         return torch.nn.modules.module._IncompatibleKeys(missing, unexpected)
 
     def load_from_pretrained(self, url_or_filename):
-        logging.info("frozen backbone weights are packed at construction (weights=...); loading trainable tensors from %s", url_or_filename)
-        return self.load_checkpoint(url_or_filename)
+        """blip2.py:86-104: non-strict load of checkpoint["model"].  The frozen tensors of that file were packed into the engine when the
+        model was built (from_config reads the same path as ``pretrained``); what is (re)loaded here are the trainable ones it holds
+        (t5_proj, ln_vision — and LoRA tensors if it is a fine-tuned file)."""
+        msg = self.load_checkpoint(url_or_filename)
+        return msg

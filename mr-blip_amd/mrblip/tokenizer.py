@@ -195,14 +195,25 @@ class FixtureTokenizer:
         return [self.decode(s, skip_special_tokens=skip_special_tokens) for s in seqs]
 
 
-def load_tokenizer(name_or_path: str = "google/flan-t5-xl"):
-    """Real ``T5TokenizerFast`` if its files are available locally, else the fixture tokenizer.
+def load_tokenizer(name_or_path: str = "google/flan-t5-xl", allow_fixture: bool = False):
+    """The real ``T5TokenizerFast`` from local files (mirrors ``T5TokenizerFast.from_pretrained(t5_model)`` at ``blip2_mr.py:143``; no
+    network here).  ``name_or_path == "fixture"`` or ``allow_fixture=True`` (synthetic / test configurations only) selects the
+    deterministic ``FixtureTokenizer``; otherwise a missing vocabulary is an ERROR: a run that silently tokenised prompts and labels
+    with a fake vocabulary would produce checkpoints and metrics that are incompatible with the reference."""
+    import logging
 
-    Mirrors ``T5TokenizerFast.from_pretrained(t5_model)`` at ``blip2_mr.py:143`` without network access.
-    """
+    if name_or_path == "fixture":
+        return FixtureTokenizer()
     try:
         from transformers import T5TokenizerFast  # type: ignore
 
         return T5TokenizerFast.from_pretrained(name_or_path, local_files_only=True)
-    except Exception:
-        return FixtureTokenizer()
+    except Exception as e:  # noqa: BLE001
+        if allow_fixture:
+            logging.warning("tokenizer %r is not available locally (%s: %s): using the FixtureTokenizer — token ids, the "
+                            "'annoying numbers' set and every checkpoint/metric of this run are NOT comparable with the reference",
+                            name_or_path, type(e).__name__, e)
+            return FixtureTokenizer()
+        raise RuntimeError(f"tokenizer {name_or_path!r} is not available locally ({type(e).__name__}: {e}).  Put the flan-t5 tokenizer files in a "
+                           "local directory and pass it as model.t5_model, or set model.synthetic_weights: True / t5_model: fixture for "
+                           "synthetic runs") from e

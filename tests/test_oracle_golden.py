@@ -112,3 +112,27 @@ def test_lr_schedule():
         for it in range(20):
             lrs.append(O.lr_at(ep, ep * 20 + it, st, max_epoch=5, min_lr=0.0, init_lr=3e-4, warmup_steps=30, warmup_start_lr=1e-8))
     assert np.allclose(lrs, g["lrs"], rtol=1e-12, atol=0)
+
+
+def test_c1_real_depth_oracle_matches_reference():
+    """BASELINE.json configs[0] at real depth/width (ViT-g 39 blocks x 1408, bert-base Q-Former, T5-base-sized 12 + 12 layers, 4
+    frames): the fp32 oracle against tests/golden/mr_c1.npz, which make_golden_c1.py captured from the reference's own forward_mr."""
+    from weights import seeded_array, seeded_state_dict
+    from test_fullsize_gpu import C1_CFG, _c1_samples
+
+    g = load_golden("mr_c1")
+    sd = seeded_state_dict(g["manifest"], wscale=g["strings"]["wscale"], fast=True)
+    for k in ("t5_proj.weight", "t5_proj.bias", "ln_vision.weight", "ln_vision.bias"):
+        sd[k].requires_grad_(True)
+    tok = FixtureTokenizer()
+    repl = O.annoying_replacement_dict(O.find_annoying_numbers(tok, 200)[0])
+    samples = _c1_samples(g)
+    ref = O.Oracle(sd, C1_CFG).forward_mr(tok, samples, repl)
+    assert np.array_equal(ref["inputs_atts"].numpy(), g["inputs_atts"]) and np.array_equal(ref["labels"].numpy(), g["labels"])
+    assert relerr(ref["inputs_embs"].detach()[..., ::4], g["inputs_embs_sub"]) < 1e-4
+    assert relerr(ref["enc"].detach()[..., ::4], g["enc_sub"]) < 1e-4
+    assert relerr(ref["logits"].detach()[..., ::64], g["logits_sub"]) < 1e-4
+    assert abs(ref["loss"].item() - float(g["loss"])) < 1e-5 * float(g["loss"])
+    ref["loss"].backward()
+    assert relerr(sd["t5_proj.weight"].grad[::4], g["grad__t5_proj__weight"]) < 1e-3
+    assert relerr(sd["ln_vision.weight"].grad, g["grad__ln_vision__weight"]) < 1e-3
