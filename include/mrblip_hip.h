@@ -27,7 +27,12 @@ int mrblip_abi_version(void);
  *   v = acc + bias;  out2 = bf16(v) (optional pre-activation);  v = gelu_erf(v) if act==1;  v = dropout(v);
  *   out = residual + v   (fp32 or bf16 out).
  * gated != 0: W = [wi_0; wi_1] stacked ([N = 2*Nh, K]); out[M,Nh] = dropout(gelu(h0) * h1), out2 = [h0 | h1].
- * tile_cfg: 0 auto, 1 = 256x256x64 / 8 waves, 2 = 128x128x64 / 4 waves, 3 = skinny-M weight-streaming kernel.
+ * tile_cfg bits 0..7 = tile form: 0 auto; 1 = 256x256 / 8 waves; 2 = 128x128 / 4 waves; 3 = skinny-M weight-streaming kernel; 4 = 64x128;
+ *   5 = 64x64; 6 = 256x256 / 4 waves (compiler-scheduled); 7 = 256x128 BK=32 3-stage; 8 = 256x256 / 16 waves (persistent); 9 = 128x128 / 8 waves;
+ *   10 = 256x128 / 16 waves; 11 = 128x256 / 16 waves; 12 = 256x192 / 8 waves; 13 = 256x256 / 4 waves of 128x128, hand-pipelined K loop
+ *   (plain epilogues: the frozen-ViT GEMMs); 14 = the same at 256x192.
+ * tile_cfg bits 8..16 = CU reserve of the persistent forms 13 / 14: CUs (a multiple of 8, one per XCD) this launch leaves to other
+ *   streams (per-call; 0 = the calling thread's default, see mrblip_gemm_set_cu_reserve).
  * Replaces F.linear / nn.Linear / Conv2d(k=s=14): eva_vit.py:120-126,146,54-61,196-203; Qformer.py:141-147,
  * 285-289,349-375; modeling_t5.py:323-329,536-560,1870; blip2_mr.py:491 (t5_proj); peft LoRA Linear. */
 int mrblip_gemm_bf16(const void* A, long long lda, const void* W, long long ldw, const void* Aext, long long ldaext,
@@ -70,8 +75,8 @@ int mrblip_attention_bwd(const void* Q, const long long* q_strides, const void* 
 int mrblip_head_transpose(const void* src, const long long* strides, void* dst, int B, int H, int S, int D, int Spad,
                           const uint32_t* seed_ptr, uint32_t site, float p_drop, mrblip_stream_t stream);
 
-/* CUs (a multiple of 8: one per XCD) that the persistent GEMM kernels (tile_cfg 13 / 14, the frozen-ViT GEMMs) launched from now on
- * leave to other streams; returns the previous value.  No reference counterpart: the reference runs the ViT forward in line with the
+/* Per-THREAD default (thread_local; the library has no process-global mutable state) of the CU reserve that mrblip_gemm_bf16 otherwise
+ * takes per call in tile_cfg bits 8..16; returns the calling thread's previous default.  No reference counterpart: the reference runs the ViT forward in line with the
  * rest of forward_mr (blip2_mr.py:287-289); here it runs one clip ahead on a second stream and must not starve the clip being trained. */
 int mrblip_gemm_set_cu_reserve(int n_cus);
 

@@ -789,11 +789,12 @@ static void mk_drop_arg(DropoutArg& d, const uint32_t* seed_ptr, uint32_t site, 
   d.inv_keep = 1.0f / (1.0f - p);
 }
 
-static int g_cu_reserve = getenv("MRB_W4_RESERVE") ? atoi(getenv("MRB_W4_RESERVE")) / 8 * 8 : 0;
+// CU reserve of the persistent GEMM kernels (tile configs 13 / 14): the number of CUs (a multiple of 8, one per XCD) a launch leaves to
+// other streams.  It is a PER-CALL argument: bits 8..16 of tile_cfg (tile_cfg = cfg | reserve << 8).  The setter below only provides a
+// per-THREAD default for callers that cannot pass it (thread_local: no process-global mutable state, so the forward thread and the
+// autograd thread can enqueue GEMMs with different reserves concurrently); returns the calling thread's previous default.
+static thread_local int g_cu_reserve = 0;
 
-// Number of CUs (rounded down to a multiple of 8, one per XCD) that the persistent GEMM kernels (tile configs 13 / 14) launched from
-// now on leave to other streams; returns the previous value.  Host-side state read at launch time: it applies to the launches the
-// calling thread enqueues until it is changed again.
 extern "C" int mrblip_gemm_set_cu_reserve(int n_cus) {
   const int prev = g_cu_reserve;
   g_cu_reserve = n_cus < 0 ? 0 : n_cus / 8 * 8;
@@ -835,7 +836,8 @@ static int gemm_dispatch(const void* A, long long lda, const void* W, long long 
   // 13 = 256x256 with 4 waves (plain epilogues); measured and not auto-selected:
   // 6 = 256x256 with 4 waves of 128x128 (1 wave/SIMD: 0.7x), 7 = 256x128 BK=32 3-stage (= 128x128), [128x128 BK=32 at 3-4 blocks/CU: 0.8x,
   // 256x128 / 128x256 BK=64 with one 4-wave block per CU: 0.6x; 256x128 / 128x256 BK=32 with 8 waves of 64x64, two blocks per CU: 0.7x]
-  int cfg = tile_cfg;
+  const int reserve_arg = (tile_cfg >> 8) & 0x1ff;   // per-call CU reserve (see mrblip_gemm_set_cu_reserve)
+  int cfg = tile_cfg & 0xff;
   if (cfg == 0) {
     if (M <= 64 && !gated) cfg = 3;
     else {
@@ -939,7 +941,7 @@ static int gemm_dispatch(const void* A, long long lda, const void* W, long long 
     // g_cu_reserve: CUs this persistent kernel leaves alone (mrblip_gemm_set_cu_reserve).  Its blocks hold a whole CU each for the
     // whole launch (all 512 registers of every SIMD), so kernels of another stream can only start on CUs it does not occupy: the
     // frozen-ViT look-ahead of the train step gives the clip that is being trained a quarter of the chip this way.
-    const int reserve = g_cu_reserve;
+    const int reserve = reserve_arg ? reserve_arg / 8 * 8 : g_cu_reserve;
     const int cus = ncu13 - reserve > 8 ? ncu13 - reserve : 8;
     const int grid = nt13 < cus ? (nt13 + 7) / 8 * 8 : cus;  // (a multiple of 8: the same number of blocks on every XCD)
     const int variant = (cfg == 14 ? 8 : 0) | (out_f32 ? 4 : 0) | (act == 1 ? 2 : 0) | (residual ? 1 : 0);

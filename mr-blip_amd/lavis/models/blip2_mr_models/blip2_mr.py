@@ -21,19 +21,35 @@ from mrblip.tokenizer import load_tokenizer
 
 
 class _TrainStep(torch.autograd.Function):
-    """forward = whole HIP train step (loss AND gradients); backward = hand the flat gradients to autograd."""
+    """forward = whole HIP train step (loss AND gradients); backward = hand the flat gradients to autograd.
+
+    Two modes.  Generic (any caller, any upstream scale g): the engine's gradient buffer holds THIS micro-step only and backward()
+    returns g * grad; autograd accumulates it into the two flat Parameters' .grad, which are views of ONE buffer (model.flat_grad) —
+    one all-reduce per optimizer step.  Fused accumulation (``model.begin_accumulation``; the LAVIS train loop of this package): the
+    engine accumulates straight into its own flat buffer across the window's micro-steps (the Parameters' .grad alias it) and the
+    upstream scale must be the announced one (1: the reference calls loss.backward() unscaled, moment_retrieval.py:219-223); it is
+    applied once, inside AdamW, together with 1/world — no extra passes over the 78 MB buffer, and the exchange of the window's last
+    micro-step overlaps with its t5_proj / Q-Former backward."""
 
     @staticmethod
     def forward(ctx, decay, no_decay, model, video, layout, need_grad, next_video=None):
         eng = model.engine  # (grad mode is always off inside Function.forward, hence the explicit flag)
-        eng.zero_grad()
+        if model._fused_scale is None:
+            eng.zero_grad()
         loss = eng.forward_backward(video, layout, backward=need_grad, next_video=next_video)
-        ctx.eng = eng
+        ctx.model = model
         return loss.clone().reshape(())
 
     @staticmethod
     def backward(ctx, g):
-        eng = ctx.eng
+        model = ctx.model
+        eng = model.engine
+        if model._fused_scale is not None:
+            got = float(g)
+            if abs(got - model._fused_scale) > 1e-6 * abs(model._fused_scale):
+                raise RuntimeError(f"fused gradient accumulation expects the loss scale {model._fused_scale}, got {got}; "
+                                   "call model.end_accumulation() to use arbitrary loss scaling")
+            return None, None, None, None, None, None, None
         nd = eng.n_decay
         return eng.grad[:nd] * g, eng.grad[nd:] * g, None, None, None, None, None
 
@@ -49,7 +65,7 @@ class BLIP2_MR(BaseModel):
                  num_query_token=32, t5_model="google/flan-t5-xl", num_beams=5, prompt="", max_txt_len=200, apply_lemmatizer=False,
                  input_time_format="seconds_integers", interleave_data=False, frame_token_aggregation=None, task="lora",
                  num_frames_for_answer=4, resample_frames=False, engine_config: Optional[EngineConfig] = None, weights=None,
-                 tokenizer=None, device=None, seed=42, synthetic_weights=False):
+                 tokenizer=None, device=None, seed=None, synthetic_weights=False):
         super().__init__()
         if not freeze_vit:
             raise NotImplementedError("the MI355X engine keeps the ViT frozen (every Mr. BLIP config sets freeze_vit: True)")
@@ -88,7 +104,39 @@ class BLIP2_MR(BaseModel):
         # the trainable tensors as two flat Parameters that ALIAS the engine's buffer (AdamW decay / no-decay groups)
         self.trainable_decay = nn.Parameter(self.engine.flat[:nd])
         self.trainable_no_decay = nn.Parameter(self.engine.flat[nd:])
+        # ONE flat gradient buffer behind both Parameters (generic mode: autograd accumulates g * engine.grad into it)
+        self.flat_grad = torch.zeros_like(self.engine.flat)
+        self._fused_scale = None
+        self._bind_grads(self.flat_grad)
         self.post_process = post_process
+
+    # ------------------------------------------------------------------ gradients: one flat buffer
+    def _bind_grads(self, buf):
+        nd = self.engine.n_decay
+        self.trainable_decay.grad = buf[:nd]
+        self.trainable_no_decay.grad = buf[nd:]
+
+    def zero_grad(self, set_to_none: bool = False):
+        """keeps the flat views (set_to_none would un-alias them)"""
+        self.grad_buffer().zero_()
+
+    def grad_buffer(self) -> torch.Tensor:
+        """the flat fp32 gradient of every trainable tensor: the only thing data-parallel ranks exchange"""
+        return self.engine.grad if self._fused_scale is not None else self.flat_grad
+
+    def grad_scale(self) -> float:
+        """factor AdamW applies to grad_buffer() (fused mode: the loss scale the engine did not apply)"""
+        return self._fused_scale if self._fused_scale is not None else 1.0
+
+    def begin_accumulation(self, loss_scale: float = 1.0):
+        """fused mode (see _TrainStep): micro-step gradients accumulate in the engine's buffer; every loss.backward() of the window
+        must come with the upstream scale ``loss_scale``"""
+        self._fused_scale = float(loss_scale)
+        self._bind_grads(self.engine.grad)
+
+    def end_accumulation(self):
+        self._fused_scale = None
+        self._bind_grads(self.flat_grad)
 
     # ------------------------------------------------------------------ reference surface
     @classmethod
@@ -125,7 +173,8 @@ class BLIP2_MR(BaseModel):
             input_time_format=cfg.get("input_time_format", "seconds_integers"), interleave_data=cfg.get("interleave_data", False),
             frame_token_aggregation=cfg.get("frame_token_aggregation", None), task=cfg.get("task", "lora"),
             num_frames_for_answer=cfg.get("num_frames_for_answer", 4), resample_frames=cfg.get("resample_frames", False), engine_config=ecfg,
-            weights=weights, synthetic_weights=cfg.get("synthetic_weights", False), seed=cfg.get("seed", 42),
+            weights=weights, synthetic_weights=cfg.get("synthetic_weights", False),
+            seed=cfg.get("seed", None),  # None: the engine's dropout stream follows torch's seed = run.seed + rank (train.py setup_seeds)
         )
         model.load_checkpoint_from_config(cfg)
         return model

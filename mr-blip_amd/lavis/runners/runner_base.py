@@ -16,41 +16,46 @@ from mrblip import ops
 
 
 class FlatAdamW:
-    """torch.optim.AdamW semantics (betas (0.9, 0.999), weight decay on the decay group only; runner_base.py:102-132) executed by
-    the fused HIP kernel over the model's two flat parameters."""
+    """torch.optim.AdamW semantics (betas (0.9, 0.999), weight decay on the >= 2-D non-bias/ln tensors only; runner_base.py:102-132)
+    executed by the fused HIP kernel over the model's flat parameter / gradient buffers (decay segment | no-decay segment).
+    ``grad_scale`` (1/world after a SUM all-reduce, x the model's own loss scale) is applied inside the kernel."""
 
     def __init__(self, model, lr, weight_decay, betas=(0.9, 0.999), eps=1e-8):
         self.model, self.lr, self.wd, self.betas, self.eps = model, lr, weight_decay, betas, eps
-        self.params = [(model.trainable_decay, weight_decay), (model.trainable_no_decay, 0.0)]
-        self.m = [torch.zeros_like(p.data) for p, _ in self.params]
-        self.v = [torch.zeros_like(p.data) for p, _ in self.params]
+        flat = model.engine.flat
+        self.m, self.v = torch.zeros_like(flat), torch.zeros_like(flat)
         self.t = 0
-        self.hyper = torch.zeros(4, device=model.trainable_decay.device)
+        self.grad_scale = 1.0
+        self.hyper = torch.zeros(4, device=flat.device)
 
     def set_lr(self, lr):
         self.lr = lr
 
     def zero_grad(self):
-        for p, _ in self.params:
-            p.grad = None
+        self.model.zero_grad()
 
     @torch.no_grad()
     def step(self):
         self.t += 1
         b1, b2 = self.betas
-        self.hyper.copy_(torch.tensor([self.lr, 1.0 / (1 - b1 ** self.t), 1.0 / math.sqrt(1 - b2 ** self.t), 1.0]))
-        for (p, wd), m, v in zip(self.params, self.m, self.v):
-            if p.grad is not None:
-                ops.adamw(p.data, p.grad.contiguous(), m, v, self.hyper, b1, b2, self.eps, wd)
-        self.model.engine.refresh_trainable()
+        eng = self.model.engine
+        scale = self.grad_scale * self.model.grad_scale()
+        self.hyper.copy_(torch.tensor([self.lr, 1.0 / (1 - b1 ** self.t), 1.0 / math.sqrt(1 - b2 ** self.t), scale]).pin_memory(), non_blocking=True)
+        g, nd = self.model.grad_buffer(), eng.n_decay
+        ops.adamw(eng.flat[:nd], g[:nd], self.m[:nd], self.v[:nd], self.hyper, b1, b2, self.eps, self.wd)
+        ops.adamw(eng.flat[nd:], g[nd:], self.m[nd:], self.v[nd:], self.hyper, b1, b2, self.eps, 0.0)
+        eng.refresh_trainable()
 
     def state_dict(self):
         return {"t": self.t, "m": self.m, "v": self.v, "lr": self.lr}
 
     def load_state_dict(self, sd):
         self.t, self.lr = sd["t"], sd["lr"]
-        for dst, src in zip(self.m + self.v, sd["m"] + sd["v"]):
-            dst.copy_(src)
+        m, v = sd["m"], sd["v"]
+        if isinstance(m, (list, tuple)):  # round-1 checkpoints kept the two segments apart
+            m, v = torch.cat([x.reshape(-1) for x in m]), torch.cat([x.reshape(-1) for x in v])
+        self.m.copy_(m)
+        self.v.copy_(v)
 
 
 @registry.register_runner("runner_base")
@@ -69,6 +74,13 @@ class RunnerBase:
         self.lr_scheduler = sched_cls(optimizer=self.optimizer, max_epoch=run.max_epoch, min_lr=float(run.min_lr), init_lr=float(run.init_lr),
                                       decay_rate=run.get("lr_decay_rate", None), warmup_start_lr=float(run.get("warmup_lr", -1)),
                                       warmup_steps=run.get("warmup_steps", 0))
+        # data parallel: fused accumulation (the gradients of a window's micro-steps add up in the engine's flat buffer) + ONE overlapped exchange
+        self.exchange = None
+        if hasattr(model, "begin_accumulation"):
+            model.begin_accumulation(1.0)
+            if is_dist_avail_and_initialized() and get_world_size() > 1:
+                from mrblip.dist import GradExchange
+                self.exchange = GradExchange(model.engine)
         if run.get("resume_ckpt_path"):
             self._load_checkpoint(run.resume_ckpt_path)
 
@@ -87,14 +99,17 @@ class RunnerBase:
                           collate_fn=getattr(ds, "collater", None), drop_last=is_train)
 
     def _reduce_grads(self):
-        """ONE all-reduce(SUM)/world of the flat gradients per optimizer step (the reference's DDP does it per micro-step)."""
-        if not is_dist_avail_and_initialized():
+        """ONE flat-buffer exchange per optimizer step (the reference's DDP reduces on every micro-step, runner_base.py:89-96): finishes the
+        all-reduce that the last micro-step's backward started beside its t5_proj / Q-Former backward (mrblip/dist.py) — or does it now —
+        and hands 1/world to AdamW as its gradient scale."""
+        if self.exchange is None:
             return
-        w = get_world_size()
-        for p in (self.model.trainable_decay, self.model.trainable_no_decay):
-            if p.grad is not None:
-                dist.all_reduce(p.grad, op=dist.ReduceOp.SUM)
-                p.grad.div_(w)
+        self.optimizer.grad_scale = self.exchange.finish()
+
+    def _arm_exchange(self):
+        """called by the task before the last micro-step of an accumulation window"""
+        if self.exchange is not None:
+            self.exchange.arm()
 
     # ---- loops
     def train(self):
@@ -105,11 +120,14 @@ class RunnerBase:
         for epoch in range(self.start_epoch, run.max_epoch):
             if not run.get("evaluate", False):
                 loader = self._loader(train_splits[0], True)
+                assert loader is not None, (f"no dataset provides the train split {train_splits[0]!r}: check datasets.<name>.build_info "
+                                            "(annotation files) of the run config")
                 if hasattr(loader.sampler, "set_epoch"):
                     loader.sampler.set_epoch(epoch)
                 stats = self.task.train_epoch(epoch=epoch, model=self.model, data_loader=loader, optimizer=self.optimizer,
                                               lr_scheduler=self.lr_scheduler, log_freq=run.get("log_freq", 50),
-                                              accum_grad_iters=run.get("accum_grad_iters", 1), reduce_grads=self._reduce_grads)
+                                              accum_grad_iters=run.get("accum_grad_iters", 1), reduce_grads=self._reduce_grads,
+                                              arm_exchange=self._arm_exchange)
                 self.log_stats(stats, "train")
             for split in run.get("valid_splits", []):
                 m = self.eval_epoch(split, epoch)

@@ -68,19 +68,23 @@ class MomentRetrievalTask(BaseTask):
         logging.info(metrics)
         return metrics
 
-    def train_epoch(self, epoch, model, data_loader, optimizer, lr_scheduler, log_freq=50, accum_grad_iters=1, reduce_grads=None, **kwargs):
-        """one epoch: lr step -> forward/backward (HIP) -> every accum_grad_iters: all-reduce grads once, AdamW, zero_grad"""
+    def train_epoch(self, epoch, model, data_loader, optimizer, lr_scheduler, log_freq=50, accum_grad_iters=1, reduce_grads=None,
+                    arm_exchange=None, **kwargs):
+        """one epoch: lr step -> forward/backward (HIP) -> every accum_grad_iters: all-reduce grads once, AdamW, zero_grad.  Like the
+        reference (moment_retrieval.py:205-232): loss.backward() is NOT divided by accum_grad_iters, and there is NO zero_grad at the
+        start of an epoch — micro-steps left over when len(loader) % accum_grad_iters != 0 carry into the next epoch's first step."""
         metric_logger = MetricLogger(delimiter="  ")
         iters_per_epoch = len(data_loader)
         model.train()
-        optimizer.zero_grad()
         for i, (samples, nxt) in enumerate(_with_next(metric_logger.log_every(data_loader, log_freq, f"Train: data epoch: [{epoch}]"))):
             samples.update({"epoch": epoch, "num_iters_per_epoch": iters_per_epoch, "iters": i})
             if nxt is not None:  # one-batch look-ahead: the model overlaps the next clip's frozen-ViT forward with this step's decoder
                 samples["next_video"] = nxt["video"]
             lr_scheduler.step(cur_epoch=epoch, cur_step=i)
+            if arm_exchange is not None and (i + 1) % accum_grad_iters == 0:
+                arm_exchange()  # this micro-step closes the window: its backward starts the (overlapped) gradient all-reduce
             loss = self.train_step(model=model, samples=samples)
-            (loss / accum_grad_iters).backward()
+            loss.backward()
             if (i + 1) % accum_grad_iters == 0:
                 if reduce_grads is not None:
                     reduce_grads()

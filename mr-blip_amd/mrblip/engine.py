@@ -156,7 +156,11 @@ class LoraGroup:
 
 class MrBlipEngine:
     @torch.no_grad()
-    def __init__(self, cfg: EngineConfig, src, device, lora_init: Optional[Callable] = None, seed: int = 42):
+    def __init__(self, cfg: EngineConfig, src, device, lora_init: Optional[Callable] = None, seed: Optional[int] = 42):
+        """seed: dropout stream of THIS rank (the reference seeds every RNG with run.seed + rank, train.py:57-65); None = derive it
+        from torch's current seed, which train.py's setup_seeds has already offset by the rank."""
+        if seed is None:
+            seed = int(torch.initial_seed()) & 0x7FFFFFFF
         self.cfg, self.dev = cfg, device
         self.ws: Dict[str, torch.Tensor] = {}
         self.training = True
@@ -550,6 +554,7 @@ class MrBlipEngine:
         self.adam_m = torch.zeros_like(self.flat)
         self.adam_v = torch.zeros_like(self.flat)
         self.n_decay = n_decay
+        self.n_lora = n_lora   # [0, n_lora): every LoRA A / B^T gradient — complete when the T5 encoder backward has been issued
         off = 0
         desc = []
         n_wext_rows = sum(g.N for g in groups)
@@ -1027,6 +1032,7 @@ class MrBlipEngine:
     # step computes.  It is enqueued on a second HIP stream once the T5 encoder forward has been issued and runs beside the T5
     # decoder, whose ~1700 launches on 12 tokens leave most of the CUs idle.  Its output goes to the other of two buffers (the current
     # one is still needed by this step's ln_vision backward); the next step picks it up after waiting on the completion event.
+    grad_ready_hook: Optional[Callable[[str], None]] = None  # called with "lora" / "all" from forward_backward (see there)
     _vit_slot = 0
     _vit_ready = None
     _vit_stream = None
@@ -1138,6 +1144,10 @@ class MrBlipEngine:
         self._mark("t5_decoder_backward")
         dinp = self.t5_encoder_backward(denc, Bv, S, kmask)
         self._mark("t5_encoder_backward")
+        if self.grad_ready_hook is not None:
+            # every LoRA gradient (92 % of the trainable floats) is final here: a data-parallel caller starts their all-reduce now and it
+            # runs beside the t5_proj / Q-Former backward below (mrblip/dist.py: GradExchange)
+            self.grad_ready_hook("lora")
         # interleave backward: only frame-token rows carry gradient (embeddings are frozen)
         dfr = self.buf("dframes", (F_ * n, d), f32)
         ops.row_copy(dinp, L["frame_dst"], dfr, L["frame_src"])
@@ -1164,6 +1174,8 @@ class MrBlipEngine:
         dimg = self.qformer_backward(dq_last, img, F_)
         ops.layernorm_bwd(dimg, xv, self.lnv_w, self.ln_vision_eps, None, dgamma=self.dlnv_w, dbeta=self.dlnv_b)
         self._mark("t5_proj + Q-Former backward")
+        if self.grad_ready_hook is not None:
+            self.grad_ready_hook("all")
         return loss
 
     def _mark(self, name: str):

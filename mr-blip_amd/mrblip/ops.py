@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 from typing import Optional, Sequence
 
 import torch
@@ -123,31 +124,39 @@ def _d(d: Optional[Dropout]):
 
 # ------------------------------------------------------------------------------------------------ GEMM
 def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, aext=None, wext=None, out2=None, bias=None, residual=None,
-         act: int = 0, gated: bool = False, drop: Optional[Dropout] = None, tile_cfg: int = 0, K: Optional[int] = None):
-    """out[M,N] = a[M,K] @ w[N,K]^T (+ aext @ wext^T) with the fused epilogue of mrblip_gemm_bf16."""
+         act: int = 0, gated: bool = False, drop: Optional[Dropout] = None, tile_cfg: int = 0, K: Optional[int] = None,
+         cu_reserve: Optional[int] = None):
+    """out[M,N] = a[M,K] @ w[N,K]^T (+ aext @ wext^T) with the fused epilogue of mrblip_gemm_bf16.  cu_reserve: CUs a persistent
+    tile kernel leaves to other streams (None = the calling thread's ``gemm_cu_reserve`` context, default 0)."""
     _req(a, torch.bfloat16, "gemm.a"); _req(w, torch.bfloat16, "gemm.w")
     M = a.shape[0]
     N = w.shape[0]
     K = a.shape[1] if K is None else K
     sp, site, p = _d(drop)
+    reserve = getattr(_tls, "cu_reserve", 0) if cu_reserve is None else cu_reserve
     _chk(_gemm(_p(a), _ld(a), _p(w), _ld(w), _p(aext), _ld(aext), _p(wext), _ld(wext), M, N, K, _p(out), _ld(out),
                1 if out.dtype == torch.float32 else 0, _p(out2), _ld(out2), _p(bias), _p(residual), _ld(residual), act,
-               1 if gated else 0, sp, site, p, tile_cfg, _stream()))
+               1 if gated else 0, sp, site, p, (tile_cfg & 0xff) | ((int(reserve) & 0x1ff) << 8), _stream()))
     return out
 
 
+_tls = threading.local()
+
+
 class gemm_cu_reserve:
-    """``with gemm_cu_reserve(n):`` the persistent GEMM kernels launched inside leave n CUs (a multiple of 8) to other streams."""
+    """``with gemm_cu_reserve(n):`` the persistent GEMM kernels this THREAD launches inside leave n CUs (a multiple of 8) to other
+    streams.  The value travels with each call (bits 8..16 of the C entry's tile_cfg): the library keeps no process-global state."""
 
     def __init__(self, n: int):
         self.n = int(n)
 
     def __enter__(self):
-        self.prev = _cu_reserve(self.n)
+        self.prev = getattr(_tls, "cu_reserve", 0)
+        _tls.cu_reserve = self.n
         return self
 
     def __exit__(self, *exc):
-        _cu_reserve(self.prev)
+        _tls.cu_reserve = self.prev
         return False
 
 

@@ -1,0 +1,51 @@
+"""Worker of tests/test_dp_gpu.py: one data-parallel rank of the REAL (tiny) engine.  Several ranks share GPU 0 over gloo (the RCCL run
+itself needs the multi-GPU node); each takes clip[rank] of the mr_tiny fixture, runs the HIP train step with the overlapped gradient
+exchange armed (mrblip/dist.py) and rank 0 saves the exchanged, 1/world-scaled flat gradient."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (os.path.join(ROOT, "mr-blip_amd"), ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")):
+    sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+
+def main(out_path, overlap):
+    from mrblip import prompt as P
+    from mrblip.dist import GradExchange
+    from mrblip.engine import EngineConfig, MrBlipEngine, StateDictSource
+    from mrblip.tokenizer import FixtureTokenizer
+    from util import load_golden, golden_state_dict
+    from test_model_gpu import _peft_sd, _samples
+
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo")
+    g = load_golden("mr_tiny")
+    tok = FixtureTokenizer()
+    repl = P.annoying_replacement_dict(P.find_annoying_numbers(tok, 200)[0])
+    s = _samples(g)
+    s["relevant_windows"] = ["[[8, 16]]"] * 2          # equal label lengths: the 2-clip batch mean == the mean of the per-clip means
+    mine = {k: (v[rank:rank + 1] if torch.is_tensor(v) else v[rank:rank + 1]) for k, v in s.items()}
+    eng = MrBlipEngine(EngineConfig.tiny(), StateDictSource(_peft_sd(golden_state_dict(g))), torch.device("cuda:0"), seed=42 + rank)
+    eng.training = False
+    lay = P.build_layout(tok, mine, repl, 8, T=3)
+    ex = GradExchange(eng, overlap=bool(int(overlap)))
+    eng.zero_grad()
+    ex.arm()
+    loss = eng.forward_backward(mine["video"].cuda(), lay, backward=True)
+    scale = ex.finish()
+    torch.cuda.synchronize()
+    assert eng.grad_ready_hook is None and scale == 1.0 / world
+    losses = [torch.zeros(1) for _ in range(world)]
+    dist.all_gather(losses, loss.detach().cpu().reshape(1))
+    if rank == 0:
+        torch.save({"grad": (eng.grad * scale).cpu(), "losses": torch.cat(losses), "n_lora": eng.n_lora}, out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])

@@ -92,13 +92,26 @@ def _ddp_worker(rank, world, port, q):
     run = Node({"dist_url": "env://"})
     init_distributed_mode(run)
     assert run.distributed and get_world_size() == world and get_rank() == rank and dist.get_backend() == "gloo"
-    # the data-parallel exchange: ONE all-reduce of the flat gradients, averaged over ranks
-    model = types.SimpleNamespace(trainable_decay=torch.nn.Parameter(torch.zeros(10)), trainable_no_decay=torch.nn.Parameter(torch.zeros(3)))
-    model.trainable_decay.grad = torch.full((10,), float(rank + 1))
-    model.trainable_no_decay.grad = torch.arange(3.0) * (rank + 1)
+    # the data-parallel exchange (mrblip/dist.py) as the runner drives it: armed before the window's last micro-step, the LoRA segment's
+    # all-reduce issued from inside the backward ("lora" hook), the tail at its end ("all"), finish() -> 1/world for AdamW's grad_scale
+    from mrblip.dist import GradExchange
+    eng = types.SimpleNamespace(grad=torch.cat([torch.full((10,), float(rank + 1)), torch.arange(3.0) * (rank + 1)]), n_lora=10, grad_ready_hook=None)
     runner = RunnerBase.__new__(RunnerBase)
-    runner.model = model
+    runner.exchange = GradExchange(eng)
+    runner.optimizer = types.SimpleNamespace(grad_scale=1.0)
+    runner._arm_exchange()
+    assert eng.grad_ready_hook is not None
+    eng.grad_ready_hook("lora")
+    eng.grad_ready_hook("all")
     runner._reduce_grads()
+    assert eng.grad_ready_hook is None and runner.optimizer.grad_scale == 1.0 / world
+    avg = eng.grad * runner.optimizer.grad_scale
+    model = types.SimpleNamespace(trainable_decay=types.SimpleNamespace(grad=avg[:10]), trainable_no_decay=types.SimpleNamespace(grad=avg[10:]))
+    # a caller whose backward never reaches the hooks (accumulated elsewhere): finish() exchanges the whole buffer
+    eng2 = types.SimpleNamespace(grad=torch.full((13,), float(rank + 1)), n_lora=10, grad_ready_hook=None)
+    ex2 = GradExchange(eng2, overlap=False)
+    ex2.arm()
+    assert ex2.finish() == 0.5 and eng2.grad.tolist() == [3.0] * 13 and eng2.grad_ready_hook is None
     # clips are sharded over ranks with no overlap (DistributedSampler, seed + rank)
     ds = SyntheticMomentRetrievalDataset(n_items=8, n_frms=2, image_size=14)
     idx = list(DistributedSampler(ds, num_replicas=world, rank=rank, shuffle=False))
