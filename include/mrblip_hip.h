@@ -129,6 +129,17 @@ int mrblip_lora_grads(const void* dY, long long lddy, const void* U, long long l
 /* LoRA "down" product with the lora_dropout fused into the operand load: U[M,N] = dropout(X)[M,K] Acat[N,K]^T (bf16; peft lora_A(lora_dropout(x))) */
 int mrblip_gemm_lora_down(const void* X, long long ldx, const void* Acat, long long lda, int M, int N, int K, void* U, long long ldu,
                           const uint32_t* seed_ptr, uint32_t site, float p_drop, mrblip_stream_t stream);
+/* The same product (and the backward's g = dY B: p_drop = 0) as a ROW kernel: the R <= 32 thin vectors A[R,K] live in LDS, one wavefront
+ * reads a row of X once in full 16-B pieces, masks it in registers and takes R dot products (v_dot2c_f32_bf16); U[M, 0:R] bf16.
+ * Replaces peft's lora_A(lora_dropout(x)) / grad_output @ lora_B.weight of every adapted Linear (blip2_mr.py:182-200).
+ * seg: NULL, or 2 * R/8 ints [k0, k1) per 8-row group of A outside of which those rows are zero (block-diagonal B^T of a fused group). */
+int mrblip_lora_rows(const void* X, long long ldx, const void* A, long long lda, int M, int R, int K, void* U, long long ldu,
+                     const int* seg, const uint32_t* seed_ptr, uint32_t site, float p_drop, mrblip_stream_t stream);
+/* T5LayerNorm (modeling_t5.py:254-277) fused with the LoRA "down" product of its output: out_bf16 = bf16(x * rsqrt(mean(x^2) + eps) * weight),
+ * U[M, 0:R] = dropout(out_bf16) A[R,D]^T — one launch for the norm-fed adapted projections (q/k/v, wi_0/wi_1, EncDecAttention.q). */
+int mrblip_rmsnorm_lora_fwd(const float* x, long long ldx, const float* weight, int M, int D, float eps, void* out_bf16, long long ldob,
+                            const void* A, long long lda, int R, void* U, long long ldu, const uint32_t* seed_ptr, uint32_t site, float p_drop,
+                            mrblip_stream_t stream);
 /* LoRA backward input gradient in one launch: dX[M,N] = dY[M,K] Wt[N,K]^T (+ residual) + mask(site,p) * (G[M,64] AcatT[N,64]^T);
  * N = in_features, K = out_features padded to 64, mask = the forward's lora_dropout keep mask scaled by 1/(1-p) */
 int mrblip_gemm_lora_dx(const void* dY, long long lddy, const void* Wt, long long ldwt, const void* G, long long ldg, const void* AcatT,

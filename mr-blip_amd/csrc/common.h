@@ -67,37 +67,38 @@ struct DropoutArg {
   float inv_keep;  // 1 / (1 - p)
 };
 
-// erf(x) ~ clamp(t * P(t^2), -1, 1), t = clamp(x, -3.4, 3.4), P of degree 8 in t^2 (weighted least-squares minimax fit,
-// max abs error 8.8e-5 in fp32 => exact-erf GELU to 1.5e-4 abs, far below the bf16 resolution of the activations it feeds).
-// Pure FMA/min/max: no v_rcp/v_exp (quarter rate), and the 2-wide form lowers to v_pk_fma_f32 / v_pk_mul_f32 (two elements
-// per instruction) — the GELU epilogue of the ViT fc1 GEMM is VALU time that no MFMA overlaps.
+// erf(x) ~ clamp(t * P(t^2), -1, 1), t = clamp(x, -3, 3), P of degree 7 in t^2 (iteratively re-weighted least-squares minimax fit,
+// max abs error 8.1e-5 in fp32 => exact-erf GELU to 1.6e-4 abs, far below the bf16 resolution of the activations it feeds).
+// Pure FMA / v_med3: no v_rcp / v_exp (quarter rate); the 2-wide form lowers to v_pk_fma_f32 / v_pk_mul_f32 (two elements per
+// instruction) and each clamp is ONE v_med3_f32 — the GELU epilogue of the ViT fc1 GEMM is VALU time that no MFMA overlaps
+// (tools/w4_stamps.py: 11 us of a 57 us tile with the previous degree-8 / min+max form).
 typedef float mrb_f2 __attribute__((ext_vector_type(2)));
-#define MRB_ERF_L 3.4f
+#define MRB_ERF_L 3.0f
 #define MRB_ERF_HORNER(P, T2)                                                                           \
-  P = 1.707467945e-08f;                                                                                 \
-  P = P * T2 + (-1.003492571e-06f); P = P * T2 + 2.565830255e-05f; P = P * T2 + (-3.775734804e-04f);   \
-  P = P * T2 + 3.578934120e-03f;    P = P * T2 + (-2.328029275e-02f); P = P * T2 + 1.084162071e-01f;   \
-  P = P * T2 + (-3.735867441e-01f); P = P * T2 + 1.127946496e+00f;
+  P = -4.055320281e-07f;                                                                                \
+  P = P * T2 + 1.715970865e-05f;    P = P * T2 + (-3.145938746e-04f); P = P * T2 + 3.318701084e-03f;   \
+  P = P * T2 + (-2.268576619e-02f); P = P * T2 + 1.077177701e-01f;    P = P * T2 + (-3.732313514e-01f); \
+  P = P * T2 + 1.127895752e+00f;
 __device__ __forceinline__ float fast_erf(float x) {
-  const float t = fminf(fmaxf(x, -MRB_ERF_L), MRB_ERF_L);
+  const float t = __builtin_amdgcn_fmed3f(x, -MRB_ERF_L, MRB_ERF_L);
   const float t2 = t * t;
   float p;
   MRB_ERF_HORNER(p, t2)
-  return fminf(fmaxf(t * p, -1.0f), 1.0f);
+  return __builtin_amdgcn_fmed3f(t * p, -1.0f, 1.0f);
 }
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752440f)); }
 // two elements at once (packed fp32 math)
 __device__ __forceinline__ void gelu_erf2(float& a, float& b) {
   mrb_f2 x = {a, b};
   mrb_f2 t = x * 0.70710678118654752440f;
-  t[0] = fminf(fmaxf(t[0], -MRB_ERF_L), MRB_ERF_L);
-  t[1] = fminf(fmaxf(t[1], -MRB_ERF_L), MRB_ERF_L);
+  t[0] = __builtin_amdgcn_fmed3f(t[0], -MRB_ERF_L, MRB_ERF_L);
+  t[1] = __builtin_amdgcn_fmed3f(t[1], -MRB_ERF_L, MRB_ERF_L);
   const mrb_f2 t2 = t * t;
   mrb_f2 p;
   MRB_ERF_HORNER(p, t2)
   mrb_f2 r = t * p;
-  r[0] = fminf(fmaxf(r[0], -1.0f), 1.0f);
-  r[1] = fminf(fmaxf(r[1], -1.0f), 1.0f);
+  r[0] = __builtin_amdgcn_fmed3f(r[0], -1.0f, 1.0f);
+  r[1] = __builtin_amdgcn_fmed3f(r[1], -1.0f, 1.0f);
   const mrb_f2 h = x * 0.5f;
   const mrb_f2 y = h * r + h;
   a = y[0];
@@ -112,6 +113,20 @@ __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
+}
+// wave64 sum with DPP adds only (no LDS crossbar): four in-row butterfly steps (quad_perm, quad_perm, row_half_mirror, row_mirror: every
+// lane then holds its 16-lane row's sum), row_bcast:15 into rows 1 / 3, row_bcast:31 into rows 2 / 3 — lane 63 holds the total, read
+// back as a wave-uniform scalar.  ~6 dependent VALU ops against 6 dependent ds_bpermute round trips of wave_sum().
+#define MRB_DPP_STEP(V, CTRL, ROWMASK) \
+  V += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, V), CTRL, ROWMASK, 0xf, false))
+__device__ __forceinline__ float wave_sum_uniform(float v) {
+  MRB_DPP_STEP(v, 0xB1, 0xf);   // quad_perm [1,0,3,2]
+  MRB_DPP_STEP(v, 0x4E, 0xf);   // quad_perm [2,3,0,1]
+  MRB_DPP_STEP(v, 0x141, 0xf);  // row_half_mirror
+  MRB_DPP_STEP(v, 0x140, 0xf);  // row_mirror
+  MRB_DPP_STEP(v, 0x142, 0xa);  // row_bcast:15 -> rows 1, 3
+  MRB_DPP_STEP(v, 0x143, 0xc);  // row_bcast:31 -> rows 2, 3
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll

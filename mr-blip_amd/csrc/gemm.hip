@@ -423,6 +423,17 @@ __device__ __forceinline__ mrb_u32x4 gemm_load_piece(const void* ptr, uint32_t b
 // LDS-DMA of K-tile kt+2, first fragments of kt+1) sits in front of the LAST slice of K-tile kt, whose MFMAs cover it.
 // Plain epilogues only (bias / GELU / fp32 residual): the frozen-ViT GEMMs.  ACT (0 | 1 = GELU) and RES (fp32 residual) are
 // compile-time: with one wave per SIMD the run-time flag tests of the shared epilogue helpers cost more than the epilogue's real work.
+#ifdef EXP_W4_STAMPS
+// EXPERIMENT: wall-clock stamps (s_memrealtime, 100 MHz) of every tile a block works on: [block][tile][tile start, K loop start, K loop
+// end, epilogue end]; read back with mrblip_debug_w4_stamps (tools/w4_stamps.py)
+__device__ unsigned long long w4_stamps[256 * 8 * 4];
+extern "C" int mrblip_debug_w4_stamps(unsigned long long* host_dst) {
+  return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(w4_stamps), sizeof(w4_stamps)) == hipSuccess ? 0 : -1;
+}
+#define W4_STAMP(I) if (threadIdx.x == 0 && stamp_tile < 8) w4_stamps[(blockIdx.x * 8 + stamp_tile) * 4 + (I)] = __builtin_amdgcn_s_memrealtime();
+#else
+#define W4_STAMP(I)
+#endif
 template <bool OUT_F32, int ACT, bool RES, int TN>
 __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
   constexpr int BM = 256, BN = 64 * TN, WN = BN / 2, RB = 128, NW = 4, RPI = 8;
@@ -524,8 +535,19 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
     _Pragma("unroll") for (int j = 0; j < JW; ++j) vpw[j] = vW + (uint32_t)((long long)(bn * BN + (j * NW + w) * RPI) * p.ldw * 2); \
     gemm_stage_dma<JA, JW, NW, RPI * RB>(smem, smem + A_BYTES, p.A, bytes_a, p.W, bytes_w, vpa, vpw, w, 0u);             \
   }
+#ifdef EXP_W4_STAGGER
+  {  // EXPERIMENT: 8 phase groups of 32 CUs (4 per XCD) start EXP_W4_STAGGER x 10 ns apart, so the epilogue store bursts of a round interleave
+    const uint64_t wait = (uint64_t)((blockIdx.x >> 3) & 7) * (uint64_t)(EXP_W4_STAGGER);
+    const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(8);
+  }
+#endif
   if (cur < my_count) W4_OPEN_TILE(cur)
+#ifdef EXP_W4_STAMPS
+  int stamp_tile = 0;
+#endif
   while (cur < my_count) {
+    W4_STAMP(0)
     // (bm, bn), the piece offsets and the LDS-DMA of K-tile 0 were set up by W4_OPEN_TILE: before the loop, or under the previous
     // tile's epilogue, whose slabs lie behind buffer 0
 #pragma unroll
@@ -546,6 +568,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
     bf16x8 fa0[4], fb0[TN], fa1[4], fb1[TN];
 #pragma unroll
     for (int i = 0; i < NFRAG; ++i) W4_FRAG(fa0, fb0, smem, 0, i)
+    W4_STAMP(1)
     int kt = 0;
     for (; kt < nk - 2; ++kt) W4_KTILE(true, true)
     if (kt < nk - 1) {
@@ -561,6 +584,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
     // one row and every lane owns the SAME 8 columns in all passes: its bias values are loaded once per tile.
     constexpr int RS = WN * 4 + 16;
     constexpr int LPR = WN / 8, ROWS = 64 / LPR, PASSES = (32 + ROWS - 1) / ROWS;  // 16 lanes x 4 rows x 8 | 12 lanes x 5 rows x 7
+    W4_STAMP(2)
     __syncthreads();  // every wave is done with both stage buffers
     const int nxt = cur + (int)(gridDim.x >> 3);
     const int bm_e = bm, bn_e = bn;
@@ -628,6 +652,10 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
       }
     }
     __syncthreads();  // every wave is done with the slabs: the next tile's K-tile 1 goes into buffer 1, which they overlap
+    W4_STAMP(3)
+#ifdef EXP_W4_STAMPS
+    ++stamp_tile;
+#endif
     cur = nxt;
   }
 #undef W4_OPEN_TILE

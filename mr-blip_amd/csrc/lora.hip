@@ -1,0 +1,317 @@
+// LoRA rank-8 "thin" products of the T5 path (peft Linear.forward / backward; configured at blip2_mr.py:182-200: r = 8, alpha = 8,
+// lora_dropout = 0.05 on every q/k/v/o/wi_0/wi_1/wo/lm_head):
+//     forward   u[m, r]  = sum_k dropout(x)[m, k] * (s A)[r, k]        (lora_A(lora_dropout(x)); the "up" product rides in the main GEMM)
+//     backward  g[m, r]  = sum_n dy[m, n]         * (s B^T)[r, n]
+// Both are [M x K] x [K x R] with R = 8 * adapters-of-the-group <= 32: 0.1-0.6 GFLOP per launch, i.e. nothing — what they cost is the
+// launch and the operand traffic.  Shape of the kernels here: the R thin vectors live in LDS (<= 128 KB per 2048-wide K chunk), one
+// wave owns a row, reads it ONCE in full 16-B pieces (coalesced: a wave instruction covers 1 KB of one row), applies the lora_dropout
+// mask from the counter hash in registers, and accumulates R dot products with v_dot2c_f32_bf16 against ds_read_b128 fragments; one
+// wave reduction per (row, r) at the very end.  (The MFMA skinny kernel they replace gathers 32 different rows per load instruction and
+// was bound by the address unit: 13-22 us at M = 2012, 16 us for the decoder's single-block launches.)
+//
+// rmsnorm_lora_fwd additionally fuses T5LayerNorm (modeling_t5.py:254-277): the normalised row is still in registers when its LoRA
+// projection is taken, so `xn` and `u` of the norm-fed projections (q/k/v, wi_0/wi_1, EncDecAttention.q) cost one launch.
+#include "common.h"
+
+typedef __bf16 mrb_bf2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float dot2bf(uint32_t a, uint32_t b, float c) {
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(mrb_bf2, a), __builtin_bit_cast(mrb_bf2, b), c, false);
+}
+
+struct LoraRowsArgs {
+  const bf16_t* X; long long ldx;   // [M, K] rows (bf16)
+  const bf16_t* A; long long lda;   // [R, K] thin vectors (bf16, already scaled)
+  bf16_t* U; long long ldu;         // [M, >= R] out (bf16): columns 0..R-1 are written
+  int M, K, R;
+  // rows [8j, 8j+8) of A are non-zero only in columns [seg_k0[j], seg_k1[j]) — the block-diagonal s*B^T of a fused q/k/v or wi_0/wi_1
+  // group in the backward's g = dy B; chunks outside a group's range skip its staging and its dot products.  Dense A: [0, K) for all.
+  int seg_k0[4], seg_k1[4];
+  DropoutArg drop;                  // mask of X (element index m * K + k, pair-hashed); the kept values' 1/(1-p) is applied to the result
+};
+
+#define LORA_KC 2048  // K chunk held in LDS: R x (up to) 2048 bf16
+
+typedef __attribute__((address_space(3))) void* lora_lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* lora_glb_ptr_t;
+
+// stage A[:, kc0 : kc0 + kcw] into LDS as [R][kcw] by LDS-DMA (global_load ... lds, 16 B per lane, every piece in flight at once: a
+// register-staged copy loop was the whole run time of the first version of these kernels).  The LDS image is linear in the piece
+// index (piece i = row i / (kcw/8), 16-B column i % (kcw/8)), which is what the DMA's "wave base + lane * 16" addressing needs.
+__device__ __forceinline__ void lora_fill(char* smem, const bf16_t* A, long long lda, int R, int kcw, int kc0, uint32_t active = 0xfu) {
+  const int per_row = kcw >> 3, n16 = R * per_row;
+  const int wv = threadIdx.x >> 6;
+  for (int base = 0; base < n16; base += 256) {
+    const int idx = base + (int)threadIdx.x;
+    const int r = idx / per_row;
+    if (idx < n16 && ((active >> (r >> 3)) & 1u)) {
+      const int c = (idx - r * per_row) << 3;
+      const bf16_t* src = A + (long long)r * lda + kc0 + c;
+      __builtin_amdgcn_global_load_lds((lora_glb_ptr_t)src, (lora_lds_ptr_t)(smem + (long long)(base + wv * 64) * 16), 16, 0, 0);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// Blocks walk row groups of 4 * RPW rows (one wave = RPW rows).  K <= 2048 (one chunk): the grid is capped at the CU count and the thin
+// vectors are staged ONCE per block; longer K: one row group per block, the chunk loop re-stages.
+template <int NR, int RPW>  // NR = R / 8, RPW = rows per wave
+__global__ __launch_bounds__(256) void lora_rows_kernel(const LoraRowsArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int R = NR * 8;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint32_t seed = p.drop.seed_ptr ? *p.drop.seed_ptr : 0u;
+  const float post = p.drop.seed_ptr ? p.drop.inv_keep : 1.0f;
+  const int nrg = (p.M + 4 * RPW - 1) / (4 * RPW);
+  const bool one_chunk = p.K <= LORA_KC;
+  bool staged = false;
+  for (int rg = blockIdx.x; rg < nrg; rg += gridDim.x) {
+    const int row0 = (rg * 4 + wv) * RPW;
+    float acc[RPW][R];
+#pragma unroll
+    for (int i = 0; i < RPW; ++i)
+#pragma unroll
+      for (int r = 0; r < R; ++r) acc[i][r] = 0.f;
+    for (int kc0 = 0; kc0 < p.K; kc0 += LORA_KC) {
+      const int kcw = min(LORA_KC, p.K - kc0);
+      uint32_t active = 0u;  // row groups of A that are non-zero somewhere in this chunk (block-uniform)
+#pragma unroll
+      for (int j = 0; j < NR; ++j) active |= (kc0 < p.seg_k1[j] && kc0 + kcw > p.seg_k0[j]) ? (1u << j) : 0u;
+      if (!(one_chunk && staged)) {
+        if (staged) __syncthreads();  // every wave is done with the previous chunk
+        lora_fill(smem, p.A, p.lda, R, kcw, kc0, active);
+        __syncthreads();
+        staged = true;
+      }
+#pragma unroll
+      for (int i = 0; i < RPW; ++i) {
+        const int row = row0 + i;
+        if (row >= p.M) break;  // wave-uniform
+        const bf16_t* xr = p.X + (long long)row * p.ldx + kc0;
+        uint4 xv[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int c = (it * 64 + lane) * 8;
+          xv[it] = (c < kcw) ? *reinterpret_cast<const uint4*>(xr + c) : make_uint4(0u, 0u, 0u, 0u);
+        }
+        if (p.drop.seed_ptr) {
+#pragma unroll
+          for (int it = 0; it < 4; ++it) {
+            const uint32_t e = (uint32_t)row * (uint32_t)p.K + (uint32_t)(kc0 + (it * 64 + lane) * 8);
+            uint32_t* d = reinterpret_cast<uint32_t*>(&xv[it]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              bool k0, k1;
+              mrb_keep2(e + 2 * q, seed, p.drop.site, p.drop.thresh24, k0, k1);
+              d[q] = (k0 ? d[q] & 0xffffu : 0u) | (k1 ? d[q] & 0xffff0000u : 0u);
+            }
+          }
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int c = (it * 64 + lane) * 8;
+          if (c < kcw) {
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+              if (!((active >> j) & 1u)) continue;  // uniform
+#pragma unroll
+              for (int r8 = 0; r8 < 8; ++r8) {
+                const int r = j * 8 + r8;
+                const uint4 av = *reinterpret_cast<const uint4*>(smem + ((long long)r * kcw + c) * 2);
+                float a = acc[i][r];
+                a = dot2bf(xv[it].x, av.x, a); a = dot2bf(xv[it].y, av.y, a); a = dot2bf(xv[it].z, av.z, a); a = dot2bf(xv[it].w, av.w, a);
+                acc[i][r] = a;
+              }
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+      const int row = row0 + i;
+      if (row >= p.M) break;
+      float mine = 0.f;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const float s = wave_sum_uniform(acc[i][r]);
+        if (lane == r) mine = s;
+      }
+      if (lane < R) p.U[(long long)row * p.ldu + lane] = f2bf(mine * post);
+    }
+  }
+}
+
+static int lora_num_cu() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+  }
+  return n;
+}
+
+template <int NR>
+static int launch_rows(const LoraRowsArgs& a, hipStream_t st) {
+  const int kcw = a.K < LORA_KC ? a.K : LORA_KC;
+  const int LDS = NR * 8 * kcw * 2;
+  constexpr int LDS_MAX = NR * 8 * LORA_KC * 2;
+  const int ncu = lora_num_cu();
+  // rows per wave.  One chunk: 1 (the blocks loop over their row groups, nothing is re-staged).  Several chunks: every block re-stages
+  // all of A, so fewer, taller blocks — about one per CU.
+  const int rpw = a.K <= LORA_KC ? 1 : (a.M <= 4 * ncu ? 1 : a.M <= 8 * ncu ? 2 : 4);
+  const int nrg = (a.M + 4 * rpw - 1) / (4 * rpw);
+  const int grid = a.K <= LORA_KC ? (nrg < ncu ? nrg : ncu) : nrg;
+  static bool attr[3] = {};
+#define MRB_LR_LAUNCH(I, RPW_)                                                                                                     \
+  {                                                                                                                                \
+    auto k = lora_rows_kernel<NR, RPW_>;                                                                                           \
+    if (!attr[I]) {                                                                                                                \
+      if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX) != hipSuccess) {                \
+        mrblip_set_error("lora_rows: cannot raise dynamic LDS to %d", LDS_MAX);                                                    \
+        return MRBLIP_ELAUNCH;                                                                                                     \
+      }                                                                                                                            \
+      attr[I] = true;                                                                                                              \
+    }                                                                                                                              \
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), LDS, st, a);                                                                      \
+  }
+  if (rpw == 1) MRB_LR_LAUNCH(0, 1)
+  else if (rpw == 2) MRB_LR_LAUNCH(1, 2)
+  else MRB_LR_LAUNCH(2, 4)
+#undef MRB_LR_LAUNCH
+  return mrblip_check_launch("lora_rows");
+}
+
+// U[M, 0:R] = dropout(X)[M, K] A[R, K]^T (bf16 in / out, fp32 accumulate).  p_drop = 0 (or seed_ptr NULL): no mask (the backward's g = dy B).
+// seg (optional, 2 * R/8 ints: [k0_0, k1_0, k0_1, k1_1, ...]): the column range in which rows [8j, 8j+8) of A are non-zero.
+extern "C" int mrblip_lora_rows(const void* X, long long ldx, const void* A, long long lda, int M, int R, int K, void* U, long long ldu,
+                                const int* seg, const uint32_t* seed_ptr, uint32_t site, float p_drop, hipStream_t stream) {
+  MRB_REQUIRE(M > 0 && K > 0 && (K % 8) == 0 && R > 0 && R <= 32 && (R % 8) == 0, "lora_rows: bad shape (M=%d R=%d K=%d)", M, R, K);
+  MRB_REQUIRE((ldx % 8) == 0 && (lda % 8) == 0 && ((uintptr_t)X % 16) == 0 && ((uintptr_t)A % 16) == 0 && ldu >= R, "lora_rows: 16-B alignment");
+  MRB_REQUIRE(!(p_drop > 0.f) || seed_ptr, "lora_rows: dropout needs a device seed pointer");
+  LoraRowsArgs a;
+  a.X = (const bf16_t*)X; a.ldx = ldx; a.A = (const bf16_t*)A; a.lda = lda; a.U = (bf16_t*)U; a.ldu = ldu; a.M = M; a.K = K; a.R = R;
+  for (int j = 0; j < 4; ++j) {
+    a.seg_k0[j] = (seg && j < R / 8) ? seg[2 * j] : 0;
+    a.seg_k1[j] = (seg && j < R / 8) ? seg[2 * j + 1] : K;
+  }
+  a.drop.seed_ptr = (p_drop > 0.f) ? seed_ptr : nullptr;
+  a.drop.site = site;
+  a.drop.thresh24 = (uint32_t)(p_drop * 65536.0f + 0.5f);
+  a.drop.inv_keep = 1.0f / (1.0f - p_drop);
+  switch (R / 8) {
+    case 1: return launch_rows<1>(a, stream);
+    case 2: return launch_rows<2>(a, stream);
+    case 3: return launch_rows<3>(a, stream);
+    default: return launch_rows<4>(a, stream);
+  }
+}
+
+// ---- T5 RMSNorm + LoRA "down" of the normalised row in one launch -------------------------------------------------------------
+struct NormLoraArgs {
+  const float* x; long long ldx;     // fp32 residual stream [M, D]
+  const float* gamma;
+  bf16_t* xn; long long ldn;          // bf16 normalised rows (the GEMM operand)
+  const bf16_t* A; long long lda;     // [R, D]
+  bf16_t* U; long long ldu;
+  int M, D, R;
+  float eps;
+  DropoutArg drop;
+};
+
+template <int NR>
+__global__ __launch_bounds__(256) void rmsnorm_lora_kernel(const NormLoraArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [R][D] bf16
+  constexpr int R = NR * 8;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int nv = p.D >> 2;
+  lora_fill(smem, p.A, p.lda, R, p.D, 0);
+  __syncthreads();
+  const uint32_t seed = p.drop.seed_ptr ? *p.drop.seed_ptr : 0u;
+  const float post = p.drop.seed_ptr ? p.drop.inv_keep : 1.0f;
+  for (int row = blockIdx.x * 4 + wv; row < p.M; row += gridDim.x * 4) {
+    const float4* xr = reinterpret_cast<const float4*>(p.x + (long long)row * p.ldx);
+    float4 v[8];
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int i = lane + 64 * j;
+      v[j] = (i < nv) ? xr[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      q += v[j].x * v[j].x + v[j].y * v[j].y + v[j].z * v[j].z + v[j].w * v[j].w;
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)p.D + p.eps);
+    float acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int i = lane + 64 * j;
+      if (i < nv) {
+        const float4 g = reinterpret_cast<const float4*>(p.gamma)[i];
+        uint2 o = make_uint2(pack2bf(v[j].x * rstd * g.x, v[j].y * rstd * g.y), pack2bf(v[j].z * rstd * g.z, v[j].w * rstd * g.w));
+        reinterpret_cast<uint2*>(p.xn + (long long)row * p.ldn)[i] = o;
+        if (p.drop.seed_ptr) {
+          const uint32_t e = (uint32_t)row * (uint32_t)p.D + (uint32_t)(i * 4);
+          bool k0, k1, k2, k3;
+          mrb_keep2(e, seed, p.drop.site, p.drop.thresh24, k0, k1);
+          mrb_keep2(e + 2, seed, p.drop.site, p.drop.thresh24, k2, k3);
+          o.x = (k0 ? o.x & 0xffffu : 0u) | (k1 ? o.x & 0xffff0000u : 0u);
+          o.y = (k2 ? o.y & 0xffffu : 0u) | (k3 ? o.y & 0xffff0000u : 0u);
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const uint2 av = *reinterpret_cast<const uint2*>(smem + ((long long)r * p.D + i * 4) * 2);
+          acc[r] = dot2bf(o.y, av.y, dot2bf(o.x, av.x, acc[r]));
+        }
+      }
+    }
+    float mine = 0.f;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const float s = wave_sum_uniform(acc[r]);
+      if (lane == r) mine = s;
+    }
+    if (lane < R) p.U[(long long)row * p.ldu + lane] = f2bf(mine * post);
+  }
+}
+
+// xn = bf16(RMSNorm(x) * gamma);  U[:, 0:R] = dropout(xn) A^T.   D <= 2048, D % 8 == 0.
+extern "C" int mrblip_rmsnorm_lora_fwd(const float* x, long long ldx, const float* weight, int M, int D, float eps, void* out_bf16, long long ldob,
+                                       const void* A, long long lda, int R, void* U, long long ldu, const uint32_t* seed_ptr, uint32_t site,
+                                       float p_drop, hipStream_t stream) {
+  MRB_REQUIRE(M > 0 && D > 0 && D <= 2048 && (D % 8) == 0, "rmsnorm_lora: need 0 < D <= 2048, D %% 8 == 0 (M=%d D=%d)", M, D);
+  MRB_REQUIRE(R > 0 && R <= 32 && (R % 8) == 0 && ldu >= R && (lda % 8) == 0 && (ldx % 4) == 0 && (ldob % 4) == 0, "rmsnorm_lora: bad shape (R=%d)", R);
+  MRB_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)A % 16) == 0 && ((uintptr_t)out_bf16 % 8) == 0, "rmsnorm_lora: alignment");
+  MRB_REQUIRE(!(p_drop > 0.f) || seed_ptr, "rmsnorm_lora: dropout needs a device seed pointer");
+  NormLoraArgs a;
+  a.x = x; a.ldx = ldx; a.gamma = weight; a.xn = (bf16_t*)out_bf16; a.ldn = ldob; a.A = (const bf16_t*)A; a.lda = lda; a.U = (bf16_t*)U; a.ldu = ldu;
+  a.M = M; a.D = D; a.R = R; a.eps = eps;
+  a.drop.seed_ptr = (p_drop > 0.f) ? seed_ptr : nullptr;
+  a.drop.site = site;
+  a.drop.thresh24 = (uint32_t)(p_drop * 65536.0f + 0.5f);
+  a.drop.inv_keep = 1.0f / (1.0f - p_drop);
+  const int LDS = R * D * 2;
+  const int grid = (M + 3) / 4 < 256 ? (M + 3) / 4 : 256;  // every block stages the thin vectors once and walks its rows
+  static bool attr[5] = {};
+#define MRB_NL_LAUNCH(NR_)                                                                                                         \
+  case NR_: {                                                                                                                      \
+    auto k = rmsnorm_lora_kernel<NR_>;                                                                                             \
+    if (!attr[NR_]) {                                                                                                              \
+      if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, NR_ * 8 * 2048 * 2) != hipSuccess) {      \
+        mrblip_set_error("rmsnorm_lora: cannot raise dynamic LDS");                                                               \
+        return MRBLIP_ELAUNCH;                                                                                                     \
+      }                                                                                                                            \
+      attr[NR_] = true;                                                                                                            \
+    }                                                                                                                              \
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), LDS, stream, a);                                                                  \
+    break;                                                                                                                         \
+  }
+  switch (R / 8) {
+    MRB_NL_LAUNCH(1)
+    MRB_NL_LAUNCH(2)
+    MRB_NL_LAUNCH(3)
+    MRB_NL_LAUNCH(4)
+  }
+#undef MRB_NL_LAUNCH
+  return mrblip_check_launch("rmsnorm_lora");
+}

@@ -48,26 +48,45 @@ class SyntheticMomentRetrievalDataset(_MRBase):
         return self._sample(video, ts, self.dur, "a person opens the red door and walks into the kitchen", [[s, s + 8]], f"syn{i}")
 
 
-class MomentRetrievalDataset(_MRBase):
-    """annotation JSON of {video, qid, query, duration, relevant_windows}; frames decoded by a pluggable ``frame_loader``
-    (decord/av are not in this image: a clear error is raised unless a loader is supplied)."""
+def default_frame_loader(path, n_frms, size, sampling="uniform", clip_proposal=None):
+    """decord / av / torchvision (whichever is installed) or a .npy / .npz frame dump -> (uint8 [T,3,size,size], indices, fps)"""
+    from lavis.datasets.data_utils import load_video
 
-    def __init__(self, ann_path, vis_root, n_frms=60, image_size=224, frame_loader=None):
+    return load_video(path, n_frms=n_frms, height=size, width=size, sampling=sampling, clip_proposal=clip_proposal)
+
+
+class MomentRetrievalDataset(_MRBase):
+    """annotation JSON of {video, qid, query, duration, relevant_windows[, start, end]} (moment_retrieval_dataset.py:17-60).  Frames are
+    decoded by ``frame_loader`` (default: lavis.datasets.data_utils.load_video) and handed on as **uint8** — the processor's
+    ToTensor + Normalize is fused into the patch-embed load on the GPU (a quarter of the H2D bytes)."""
+
+    def __init__(self, ann_path, vis_root, n_frms=60, image_size=224, frame_loader=None, sampling="uniform", video_ext=".mp4"):
         self.ann = json.load(open(ann_path))
-        self.vis_root, self.T, self.img, self.frame_loader = vis_root, n_frms, image_size, frame_loader
+        self.vis_root, self.T, self.img = vis_root, n_frms, image_size
+        self.frame_loader = frame_loader or default_frame_loader
+        self.sampling, self.ext = sampling, video_ext
 
     def __len__(self):
         return len(self.ann)
 
+    def _path(self, name):
+        p = os.path.join(self.vis_root, name)
+        if os.path.exists(p):
+            return p
+        for ext in (self.ext, ".npz", ".npy"):
+            if os.path.exists(p + ext):
+                return p + ext
+        return p + self.ext   # (the reference appends ".mp4" unconditionally: moment_retrieval_dataset.py:30)
+
     def __getitem__(self, i):
         a = self.ann[i]
-        if self.frame_loader is None:
-            raise RuntimeError("no video decoder available (decord/av not installed): pass frame_loader=callable(path, n_frms, size) -> (uint8 [T,3,H,W], fps indices)")
-        u8, idx, fps = self.frame_loader(os.path.join(self.vis_root, a["video"]), self.T, self.img)
-        mean, std = torch.tensor(CLIP_MEAN).view(1, 3, 1, 1), torch.tensor(CLIP_STD).view(1, 3, 1, 1)
-        video = (u8.float() / 255.0 - mean) / std
-        ts = torch.tensor([round(k / fps, 2) for k in idx], dtype=torch.float32)
-        return self._sample(video, ts, a["duration"], a["query"], a["relevant_windows"], a["qid"])
+        clip = [float(a["start"]), float(a["end"])] if "start" in a else None
+        try:
+            u8, idx, fps = self.frame_loader(self._path(a["video"]), self.T, self.img, sampling=self.sampling, clip_proposal=clip)
+        except TypeError:  # a user-supplied loader with the short signature
+            u8, idx, fps = self.frame_loader(self._path(a["video"]), self.T, self.img)
+        ts = torch.tensor([round(float(k / fps), 2) for k in idx])
+        return self._sample(u8, ts, a["duration"], a["query"], a["relevant_windows"], a["qid"])
 
 
 class _Builder:
@@ -103,5 +122,9 @@ class QVHBuilder(_Builder):
         out = {}
         for split, ann in info.annotations.items():
             if os.path.isfile(str(ann.storage)):
-                out[split] = MomentRetrievalDataset(ann.storage, info.videos.storage, n_frms=vp.get("n_frms", 60), image_size=vp.get("image_size", 224))
+                out[split] = MomentRetrievalDataset(ann.storage, info.videos.storage, n_frms=vp.get("n_frms", 60), image_size=vp.get("image_size", 224),
+                                                    sampling="random" if split == "train" else "uniform")
+        if not out:
+            import logging
+            logging.warning("qvh builder: none of the annotation files %s exists — no dataset was built", {k: str(v.storage) for k, v in info.annotations.items()})
         return out

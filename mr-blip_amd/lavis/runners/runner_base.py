@@ -95,8 +95,14 @@ class RunnerBase:
             return None
         sampler = DistributedSampler(ds, shuffle=is_train, num_replicas=get_world_size(), rank=get_rank()) if is_dist_avail_and_initialized() else None
         bs = run.batch_size_train if is_train else run.batch_size_eval
-        return DataLoader(ds, batch_size=bs, num_workers=run.get("num_workers", 0), shuffle=(sampler is None and is_train), sampler=sampler,
-                          collate_fn=getattr(ds, "collater", None), drop_last=is_train)
+        nw = run.get("num_workers", 0)
+        loader = DataLoader(ds, batch_size=bs, num_workers=nw, shuffle=(sampler is None and is_train), sampler=sampler,
+                            collate_fn=getattr(ds, "collater", None), drop_last=is_train, pin_memory=torch.cuda.is_available(),
+                            persistent_workers=nw > 0)
+        if torch.cuda.is_available() and run.get("prefetch_to_device", True):
+            from lavis.datasets.dataloader_utils import PrefetchLoader
+            loader = PrefetchLoader(loader, device=getattr(self.model, "device", None))   # dataloader_utils.py:46-125 (side-stream H2D)
+        return loader
 
     def _reduce_grads(self):
         """ONE flat-buffer exchange per optimizer step (the reference's DDP reduces on every micro-step, runner_base.py:89-96): finishes the

@@ -12,12 +12,7 @@ from lavis.common.logger import MetricLogger
 from lavis.common.registry import registry
 from lavis.models.blip2_mr_models.utils import moment_str_to_list
 from lavis.tasks.base_task import BaseTask
-
-
-def temporal_iou(a, b):
-    inter = max(0.0, min(a[1], b[1]) - max(a[0], b[0]))
-    union = max(a[1], b[1]) - min(a[0], b[0])
-    return inter / union if union > 0 else 0.0
+from lavis.tasks.mr_eval import eval_submission
 
 
 def _with_next(it):
@@ -47,24 +42,18 @@ class MomentRetrievalTask(BaseTask):
         return self._report_metrics(f, split_name)
 
     def _report_metrics(self, eval_result_file, split_name):
-        """R1@IoU{0.5,0.7}, mIoU and agg_metrics = mean R1 over IoU 0.5:0.05:0.95 of the top-1 window (moment_retrieval.py:115-152)."""
+        """R1@IoU, mAP@IoU, mIoU, invalid-prediction rate and agg_metrics = R1 averaged over IoU 0.5:0.05:0.95, computed by the
+        evaluator of lavis/tasks/mr_eval.py exactly as the reference does (moment_retrieval.py:115-152)."""
         if not is_main_process():
             return None
         results = json.load(open(eval_result_file))
-        thresholds = np.arange(0.5, 0.96, 0.05)
-        ious, invalid = [], 0
-        for r in results:
-            pred = moment_str_to_list(r["prediction"])
-            gt = moment_str_to_list(str(r["target"]))
-            if pred == [[-1, -1]]:
-                invalid += 1
-                ious.append(0.0)
-                continue
-            ious.append(max(temporal_iou(pred[0], g) for g in gt))
-        ious = np.array(ious) if ious else np.zeros(1)
-        r1 = {float(round(t, 2)): float((ious >= t).mean() * 100) for t in thresholds}
-        metrics = {"r1": r1, "mIoU": float(ious.mean() * 100), "invalid_predictions": invalid / max(len(results), 1), "total": len(results),
-                   "agg_metrics": float(np.mean(list(r1.values())))}
+        total = len(results)
+        interpreted = [{"qid": r["qid"], "pred_relevant_windows": moment_str_to_list(r["prediction"]),
+                        "relevant_windows": moment_str_to_list(str(r["target"]))} for r in results]
+        allm = eval_submission(interpreted, interpreted, verbose=False)
+        metrics = {"agg_metrics": allm["brief"]["MR-full-R1-avg"], "r1": allm["full"]["MR-R1"], "mAP": allm["full"]["MR-mAP"],
+                   "mIoU": allm["brief"]["MR-full-mIoU"], "invalid_predictions": allm["brief"]["MR-full-invalid_pred_num"] / max(total, 1),
+                   "total": total}
         logging.info(metrics)
         return metrics
 

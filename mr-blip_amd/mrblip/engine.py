@@ -185,6 +185,12 @@ class MrBlipEngine:
         if t is None or tuple(t.shape) != shape or t.dtype != dtype:
             t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.dev)
             self.ws[name] = t
+            if zero:
+                # the zero fill runs on the CURRENT stream, but workspaces are shared by the engine's streams (gradient side stream,
+                # ViT look-ahead stream): a buffer created on the main stream and first written on a side stream could be zeroed AFTER
+                # that write (seen as a wrong first-step loss when two ranks shared one GPU).  Creation happens once per buffer
+                # (first step / shape change), so simply let the fill finish before anything else is enqueued.
+                torch.cuda.current_stream().synchronize()
         return t
 
     def h2d(self, t: torch.Tensor, dtype=None) -> torch.Tensor:
@@ -631,11 +637,38 @@ class MrBlipEngine:
         self.transpose2d(self.proj_wb, c.qf_dim, self.proj_wtb)
 
     # ---- LoRA-group forward / backward -------------------------------------------------------------------------
-    def lg_fwd(self, g: LoraGroup, x: torch.Tensor, u: torch.Tensor, out: torch.Tensor, **kw):
-        """out = x W^T + u B^T with u = dropout(x) (scale*A)^T:  the rank-8 "down" product is a thin GEMM on the MFMA kernel,
-        the "up" product rides in the main GEMM as a 64-wide K extension."""
-        ops.lora_down(x, g.acat, u, g.K, drop=self.drop(g.site, self.cfg.lora_dropout))
+    def lg_fwd(self, g: LoraGroup, x: torch.Tensor, u: torch.Tensor, out: torch.Tensor, u_ready: bool = False, **kw):
+        """out = x W^T + u B^T with u = dropout(x) (scale*A)^T:  the rank-8 "down" product is the row kernel of csrc/lora.hip (or was
+        already produced by the fused RMSNorm launch: u_ready), the "up" product rides in the main GEMM as a 64-wide K extension."""
+        if not u_ready:
+            self.lora_thin(x, g.acat, u, g.K, drop=self.drop(g.site, self.cfg.lora_dropout))
         ops.gemm(x, g.W, out, aext=u, wext=g.wext, **kw)
+
+    # rows of the tall operand up to which the thin LoRA products take the row kernel of csrc/lora.hip (decoder: 8-12 rows -> 10 us
+    # instead of 12-22 us, and the RMSNorm fusion saves a launch); taller inputs (encoder, M = 2012 / 8048) keep the MFMA skinny
+    # kernel: there every CU re-stages the thin vectors (same lines from the same L2 channels) and the row kernel is no faster
+    # (tools/lora_rows_bench.py: 15.7 vs 12.6 us at M = 2012, 47 vs 15 us at M = 8048).
+    lora_rows_max_m = int(os.environ.get("MRB_LORA_ROWS_MAX_M", "256"))
+
+    def lora_thin(self, x, a, u, K, drop=None, seg=None):
+        """u[:, :R] = dropout(x)[:, :K] @ a^T for a thin a ([R <= 32, K])"""
+        if x.shape[0] <= self.lora_rows_max_m:
+            ops.lora_rows(x, a, u, K, drop=drop, seg=seg)
+        elif drop is not None:
+            ops.lora_down(x, a, u, K, drop=drop)
+        else:
+            ops.gemm(x, a, u, tile_cfg=3, K=K)
+
+    def norm_lg_fwd(self, x: torch.Tensor, ln: torch.Tensor, g: LoraGroup, xn: torch.Tensor, u: torch.Tensor, out: torch.Tensor, **kw):
+        """T5 RMSNorm + the LoRA "down" product of its output in ONE launch, then the main GEMM (q/k/v, wi_0/wi_1, EncDecAttention.q)"""
+        if self.fuse_norm_lora and x.shape[0] <= self.lora_rows_max_m:
+            ops.rmsnorm_lora_fwd(x, ln, self.cfg.t5_eps, xn, g.acat, u, drop=self.drop(g.site, self.cfg.lora_dropout))
+            self.lg_fwd(g, xn, u, out, u_ready=True, **kw)
+        else:
+            ops.rmsnorm_fwd(x, ln, self.cfg.t5_eps, out_bf16=xn)
+            self.lg_fwd(g, xn, u, out, **kw)
+
+    fuse_norm_lora = os.environ.get("MRB_FUSE_NORM_LORA", "1") == "1"
 
     def lg_bwd(self, g: LoraGroup, dy: torch.Tensor, x: torch.Tensor, u: torch.Tensor, gbuf: torch.Tensor, dx: Optional[torch.Tensor],
                residual: Optional[torch.Tensor] = None, side: bool = False):
@@ -644,7 +677,8 @@ class MrBlipEngine:
         side=True: the weight-gradient launch goes to the gradient side stream and runs beside the dX GEMM (the caller guarantees
         that dy / gbuf are not overwritten before its next side_join_layer())."""
         drop = self.drop(g.site, self.cfg.lora_dropout)
-        ops.gemm(dy, g.bblk, gbuf, tile_cfg=3, K=g.N)                      # g' = scale * dy @ B      [M, 8*nad]
+        seg = [v for a in g.adapters for v in (a.row0, a.row0 + a.out)] if len(g.adapters) > 1 else None
+        self.lora_thin(dy, g.bblk, gbuf, g.N, seg=seg)                      # g' = scale * dy @ B      [M, 8*nad]
         ads = g.adapters
         if side and self.grad_side_stream_enabled:
             st = self._grad_stream()
@@ -687,10 +721,9 @@ class MrBlipEngine:
         vt = self.buf("e_vt", (B, H, ops.rup32(dk), ops.rup32(S)), bf16)
         for i, L in enumerate(self.t5["enc"]):
             xn = self.buf(f"e{i}_xn", (M, pad64(d)), bf16)
-            ops.rmsnorm_fwd(x, L["ln0"], c.t5_eps, out_bf16=xn)
             u = self.buf(f"e{i}_u_qkv", (M, 64), bf16)
             qkv = self.buf(f"e{i}_qkv", (M, 3 * inner), bf16, zero=False)
-            self.lg_fwd(L["qkv"], xn, u, qkv)
+            self.norm_lg_fwd(x, L["ln0"], L["qkv"], xn, u, qkv)
             q4, k4, v4 = self.v4(qkv, B, S, H, dk, 0), self.v4(qkv, B, S, H, dk, inner), self.v4(qkv, B, S, H, dk, 2 * inner)
             ops.head_transpose(v4, out=vt)
             o = self.buf(f"e{i}_o", (M, pad64(inner)), bf16)
@@ -702,11 +735,10 @@ class MrBlipEngine:
             xm = self.buf(f"e{i}_xm", (M, d), f32, zero=False)
             self.lg_fwd(L["o"], o, uo, xm, residual=x, drop=self.drop(L["sites"][1], p))
             xn2 = self.buf(f"e{i}_xn2", (M, pad64(d)), bf16)
-            ops.rmsnorm_fwd(xm, L["ln1"], c.t5_eps, out_bf16=xn2)
             uw = self.buf(f"e{i}_u_wi", (M, 64), bf16)
             y = self.buf(f"e{i}_y", (M, pad64(ff)), bf16)
             h = self.buf(f"e{i}_h", (M, 2 * ff), bf16, zero=False)
-            self.lg_fwd(L["wi"], xn2, uw, y, out2=h, gated=True, drop=self.drop(L["sites"][2], p))
+            self.norm_lg_fwd(xm, L["ln1"], L["wi"], xn2, uw, y, out2=h, gated=True, drop=self.drop(L["sites"][2], p))
             uwo = self.buf(f"e{i}_u_wo", (M, 64), bf16)
             xo = self.buf(f"e{i + 1}_x" if i + 1 < len(self.t5["enc"]) else "e_xlast", (M, d), f32, zero=False)
             self.lg_fwd(L["wo"], y, uwo, xo, residual=xm, drop=self.drop(L["sites"][3], p))
@@ -855,10 +887,9 @@ class MrBlipEngine:
                 ckv_side.append((self.v4(ckv, B, S, H, dk, 0), vt_i, ready))
         for i, L in enumerate(self.t5["dec"]):
             xn = self.buf(f"d{i}_xn", (R, pad64(d)), bf16)
-            ops.rmsnorm_fwd(x, L["ln0"], c.t5_eps, out_bf16=xn)
             u = self.buf(f"d{i}_u_qkv", (R, 64), bf16)
             qkv = self.buf(f"d{i}_qkv", (R, 3 * inner), bf16, zero=False)
-            self.lg_fwd(L["qkv"], xn, u, qkv)
+            self.norm_lg_fwd(x, L["ln0"], L["qkv"], xn, u, qkv)
             q4, k4, v4 = self.v4(qkv, B, Ld, H, dk, 0), self.v4(qkv, B, Ld, H, dk, inner), self.v4(qkv, B, Ld, H, dk, 2 * inner)
             ops.head_transpose(v4, out=vt_s)
             o = self.buf(f"d{i}_o", (R, pad64(inner)), bf16)
@@ -869,10 +900,9 @@ class MrBlipEngine:
             self.lg_fwd(L["o"], o, uo, x1, residual=x, drop=self.drop(L["sites"][1], p))
             # cross attention
             xn1 = self.buf(f"d{i}_xn1", (R, pad64(d)), bf16)
-            ops.rmsnorm_fwd(x1, L["ln1"], c.t5_eps, out_bf16=xn1)
             ucq = self.buf(f"d{i}_u_cq", (R, 64), bf16)
             cq = self.buf(f"d{i}_cq", (R, inner), bf16, zero=False)
-            self.lg_fwd(L["cq"], xn1, ucq, cq)
+            self.norm_lg_fwd(x1, L["ln1"], L["cq"], xn1, ucq, cq)
             co = self.buf(f"d{i}_co", (R, pad64(inner)), bf16)
             if cross_cache is None:
                 ck4, vt_i, ready = ckv_side[i]
@@ -890,11 +920,10 @@ class MrBlipEngine:
             self.lg_fwd(L["co"], co, uco, x2, residual=x1, drop=self.drop(L["sites"][3], p))
             # FFN
             xn2 = self.buf(f"d{i}_xn2", (R, pad64(d)), bf16)
-            ops.rmsnorm_fwd(x2, L["ln2"], c.t5_eps, out_bf16=xn2)
             uw = self.buf(f"d{i}_u_wi", (R, 64), bf16)
             y = self.buf(f"d{i}_y", (R, pad64(ff)), bf16)
             h = self.buf(f"d{i}_h", (R, 2 * ff), bf16, zero=False)
-            self.lg_fwd(L["wi"], xn2, uw, y, out2=h, gated=True, drop=self.drop(L["sites"][4], p), tile_cfg=2)
+            self.norm_lg_fwd(x2, L["ln2"], L["wi"], xn2, uw, y, out2=h, gated=True, drop=self.drop(L["sites"][4], p), tile_cfg=2)
             uwo = self.buf(f"d{i}_u_wo", (R, 64), bf16)
             x3 = self.buf(f"d{i}_x3", (R, d), f32, zero=False)
             self.lg_fwd(L["wo"], y, uwo, x3, residual=x2, drop=self.drop(L["sites"][5], p))

@@ -73,6 +73,8 @@ _adamw = _sig("mrblip_adamw", vp, vp, vp, vp, ll, vp, f32, f32, f32, f32, vp)
 _seed_bump = _sig("mrblip_seed_bump", vp, vp)
 _lora_dx = _sig("mrblip_lora_dx_add", vp, ll, i32, vp, ll, vp, i32, i32, i32, vp, u32, f32, vp)
 _cu_reserve = _sig("mrblip_gemm_set_cu_reserve", i32)
+_lora_rows = _sig("mrblip_lora_rows", vp, ll, vp, ll, i32, i32, i32, vp, ll, vp, vp, u32, f32, vp)
+_rms_lora = _sig("mrblip_rmsnorm_lora_fwd", vp, ll, vp, i32, i32, f32, vp, ll, vp, ll, i32, vp, ll, vp, u32, f32, vp)
 
 EXPORTS = [
     "mrblip_last_error", "mrblip_abi_version", "mrblip_gemm_bf16", "mrblip_layernorm_fwd", "mrblip_rmsnorm_fwd",
@@ -81,7 +83,7 @@ EXPORTS = [
     "mrblip_cast_dropout", "mrblip_gelu_bwd", "mrblip_gated_gelu_bwd", "mrblip_cross_entropy", "mrblip_adamw",
     "mrblip_seed_bump", "mrblip_lora_dx_add", "mrblip_dropout_bf16", "mrblip_colsum", "mrblip_lora_pack", "mrblip_lora_tn",
     "mrblip_lora_grads", "mrblip_gemm_lora_down", "mrblip_gemm_lora_dx", "mrblip_patchify_u8",
-    "mrblip_gemm_set_cu_reserve",
+    "mrblip_gemm_set_cu_reserve", "mrblip_lora_rows", "mrblip_rmsnorm_lora_fwd",
 ]
 
 
@@ -238,6 +240,26 @@ def lora_down(x, acat, u, K, drop: Optional[Dropout] = None):
     M = x.shape[0]
     sp, site, p = _d(drop)
     _chk(_lora_down(_p(x), _ld(x), _p(acat), _ld(acat), M, acat.shape[0], K, _p(u), _ld(u), sp, site, p, _stream()))
+
+
+def lora_rows(x, a, u, K, drop: Optional[Dropout] = None, seg: Optional[Sequence[int]] = None):
+    """u[:, :R] = dropout(x[:, :K]) @ a^T  (a: bf16 [R, >= K], R <= 32) — the row kernel (csrc/lora.hip).  seg: [k0, k1) per 8-row
+    group of ``a`` outside of which the group is zero (the block-diagonal s*B^T of a fused LoRA group): skipped work, same result."""
+    sp, site, p = _d(drop)
+    R = a.shape[0]
+    segp = None
+    if seg is not None:
+        assert len(seg) == 2 * (R // 8)
+        segp = (i32 * len(seg))(*[int(v) for v in seg])
+    _chk(_lora_rows(_p(x), _ld(x), _p(a), _ld(a), x.shape[0], R, K, _p(u), _ld(u), segp, sp, site, p, _stream()))
+
+
+def rmsnorm_lora_fwd(x, weight, eps, out_bf16, a, u, drop: Optional[Dropout] = None):
+    """T5 RMSNorm -> bf16 rows, and u[:, :R] = dropout(rows) @ a^T in the same launch"""
+    _req(x, torch.float32, "rmsnorm_lora.x")
+    M, D = x.shape
+    sp, site, p = _d(drop)
+    _chk(_rms_lora(_p(x), _ld(x), _p(weight), M, D, eps, _p(out_bf16), _ld(out_bf16), _p(a), _ld(a), a.shape[0], _p(u), _ld(u), sp, site, p, _stream()))
 
 
 def lora_dx(dy, wt, g, acatt, dx, K, residual=None, drop: Optional[Dropout] = None, tile_cfg=0):

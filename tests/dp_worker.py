@@ -12,6 +12,22 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 
+def equal_layout_clips(s):
+    """two DIFFERENT clips with the SAME prompt / timestamps / answer, so that batching them needs no padding: the reference left-pads the
+    shorter video prompt of a batch with zero vectors that stay attended (blip2_mr.py:744-753), which makes a clip's gradient depend on
+    its batch mates — only equal-length clips make "N ranks x 1 clip" comparable with "1 rank x N clips"."""
+    out = {}
+    for k, v in s.items():
+        if k == "video":
+            out[k] = v
+        elif torch.is_tensor(v):
+            out[k] = torch.cat([v[:1], v[:1]])
+        else:
+            out[k] = [v[0], v[0]]
+    out["relevant_windows"] = ["[[8, 16]]"] * 2
+    return out
+
+
 def main(out_path, overlap):
     from mrblip import prompt as P
     from mrblip.dist import GradExchange
@@ -27,8 +43,8 @@ def main(out_path, overlap):
     tok = FixtureTokenizer()
     repl = P.annoying_replacement_dict(P.find_annoying_numbers(tok, 200)[0])
     s = _samples(g)
-    s["relevant_windows"] = ["[[8, 16]]"] * 2          # equal label lengths: the 2-clip batch mean == the mean of the per-clip means
-    mine = {k: (v[rank:rank + 1] if torch.is_tensor(v) else v[rank:rank + 1]) for k, v in s.items()}
+    s = equal_layout_clips(s)
+    mine = {k: v[rank:rank + 1] for k, v in s.items()}
     eng = MrBlipEngine(EngineConfig.tiny(), StateDictSource(_peft_sd(golden_state_dict(g))), torch.device("cuda:0"), seed=42 + rank)
     eng.training = False
     lay = P.build_layout(tok, mine, repl, 8, T=3)
@@ -36,8 +52,14 @@ def main(out_path, overlap):
     eng.zero_grad()
     ex.arm()
     loss = eng.forward_backward(mine["video"].cuda(), lay, backward=True)
+    if os.environ.get("MRB_DP_DEBUG"):
+        print("DPDBG rank", rank, "overlap", overlap, "loss right after the step", loss.item(), "hook", eng.grad_ready_hook, flush=True)
     scale = ex.finish()
     torch.cuda.synchronize()
+    if os.environ.get("MRB_DP_DEBUG"):
+        l_fin = loss.item()
+        l_again = eng.forward_backward(mine["video"].cuda(), lay, backward=False).item()
+        print("DPDBG rank", rank, "loss after finish", l_fin, "fresh forward", l_again, flush=True)
     assert eng.grad_ready_hook is None and scale == 1.0 / world
     losses = [torch.zeros(1) for _ in range(world)]
     dist.all_gather(losses, loss.detach().cpu().reshape(1))

@@ -167,7 +167,7 @@ def test_full_size_step_runs_and_is_sane(xl, name, T, dur, mean):
     for seg, t in (("lora+t5_proj.weight", gr[:nd]), ("t5_proj.bias", eng.dproj_b), ("ln_vision.weight", eng.dlnv_w), ("ln_vision.bias", eng.dlnv_b)):
         record(name + ": |grad| " + seg, t.norm().item())
         assert t.norm().item() > 0
-    # eval mode: deterministic (two passes give the same loss bit for bit) and different from the training-mode loss (dropout was on).
+    # eval mode: deterministic (two passes give the same loss up to the atomic summation order) and different from the training-mode loss (dropout was on).
     # (No descent check here: with N(0, 0.02) random weights the T5 residual stream is ~0.02 in scale, RMSNorm amplifies by 1/rms and
     # the gradient norm is ~1e6 — any representable step leaves the linear regime.  Gradient CORRECTNESS at real width is what the C1
     # test (vs the reference's autograd) and the C3 test (batch vs accumulation) establish.)
@@ -175,5 +175,5 @@ def test_full_size_step_runs_and_is_sane(xl, name, T, dur, mean):
     le0 = eng.forward_backward(samples["video"], lay, backward=False).item()
     le1 = eng.forward_backward(samples["video"], lay, backward=False).item()
     record(name + ": eval loss", le0)
-    assert le0 == le1 and math.isfinite(le0) and le0 != l0
+    assert abs(le0 - le1) <= 1e-6 * abs(le0) and math.isfinite(le0) and le0 != l0   # (the loss reduction is an fp32 atomic sum: last-bit order effects)
     eng.cfg.mean_pool = False

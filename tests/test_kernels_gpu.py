@@ -607,3 +607,63 @@ def test_lora_tn_weight_gradients(ops):
     xd = (x.float() * keep_mask((M, K), 31, 5, 0.05) / 0.95).bfloat16().float()
     for j in range(3):
         assert rel(dA[j], u[:, 8 * j: 8 * j + 8].float().t() @ xd) < 1e-5, j
+
+
+@pytest.mark.parametrize("M,K,R", [(12, 2048, 24), (2012, 2048, 24), (2012, 5120, 8), (333, 64, 16), (8, 32128, 8), (1100, 10240, 16), (70, 768, 32)])
+def test_lora_rows_kernel(ops, M, K, R):
+    """u = dropout(x) A^T (csrc/lora.hip) against fp32 torch with the oracle's restatement of the mask, and against the MFMA skinny
+    kernel it replaces (same operands, same mask: equal up to the summation order)."""
+    from oracle.mrblip_oracle import dropout_keep
+    from util import check
+    torch.manual_seed(21)
+    p = 0.05
+    ldx = K + 64
+    xbuf = bf(torch.randn(M, ldx, device=dev()))
+    x = xbuf[:, :K]
+    a = bf(torch.randn(R, K, device=dev()) * 0.05)
+    seed = torch.tensor([555], dtype=torch.int32, device=dev())
+    for drop in (None, ops.Dropout(seed, 9, p)):
+        u = torch.zeros(M, 64, dtype=torch.bfloat16, device=dev())
+        ops.lora_rows(xbuf, a, u, K, drop=drop)
+        xf = x.float()
+        if drop is not None:
+            xf = xf * dropout_keep((M, K), 555, 9, p).to(dev()) / (1 - p)
+        ref = xf @ a.float().t()
+        tag = "lora_rows M=%d K=%d R=%d %s: " % (M, K, R, "drop" if drop else "plain")
+        check(tag + "vs fp32 torch", rel(u[:, :R].float(), ref), 4e-3)
+        assert u[:, R:].abs().sum() == 0
+        if K % 64 == 0:
+            u2 = torch.zeros(M, 64, dtype=torch.bfloat16, device=dev())
+            ops.lora_down(xbuf, a, u2, K, drop=drop)
+            check(tag + "vs the MFMA skinny kernel", rel(u[:, :R].float(), u2[:, :R].float()), 4e-3)
+    if R >= 16 and K % (R // 8) == 0:  # block-diagonal A (the backward's s*B^T of a fused group): segment skipping == dense evaluation
+        ng, w = R // 8, K // (R // 8)
+        ad = torch.zeros_like(a)
+        for j in range(ng):
+            ad[8 * j: 8 * j + 8, j * w: (j + 1) * w] = a[8 * j: 8 * j + 8, j * w: (j + 1) * w]
+        ud, us = torch.zeros(M, 64, dtype=torch.bfloat16, device=dev()), torch.zeros(M, 64, dtype=torch.bfloat16, device=dev())
+        ops.lora_rows(xbuf, ad, ud, K)
+        ops.lora_rows(xbuf, ad, us, K, seg=[v for j in range(ng) for v in (j * w, (j + 1) * w)])
+        assert torch.equal(ud, us)
+        assert rel(us[:, :R].float(), x.float() @ ad.float().t()) < 4e-3
+
+
+@pytest.mark.parametrize("M,D,R", [(12, 2048, 24), (2012, 2048, 16), (77, 768, 24), (5, 64, 8)])
+def test_rmsnorm_lora_fused(ops, M, D, R):
+    """fused T5 RMSNorm + LoRA down == rmsnorm_fwd followed by lora_rows (bit-identical xn; u identical: same arithmetic order per row)"""
+    torch.manual_seed(22)
+    x = torch.randn(M, D, device=dev()) * 1.7
+    w = torch.randn(D, device=dev()) * 0.1 + 1
+    a = bf(torch.randn(R, D, device=dev()) * 0.05)
+    seed = torch.tensor([777], dtype=torch.int32, device=dev())
+    Dp = (D + 63) // 64 * 64
+    for drop in (None, ops.Dropout(seed, 3, 0.05)):
+        xn1 = torch.zeros(M, Dp, dtype=torch.bfloat16, device=dev())
+        u1 = torch.zeros(M, 64, dtype=torch.bfloat16, device=dev())
+        ops.rmsnorm_fwd(x, w, 1e-6, out_bf16=xn1)
+        ops.lora_rows(xn1, a, u1, D, drop=drop)
+        xn2 = torch.zeros_like(xn1)
+        u2 = torch.zeros_like(u1)
+        ops.rmsnorm_lora_fwd(x, w, 1e-6, xn2, a, u2, drop=drop)
+        assert torch.equal(xn1, xn2)
+        assert rel(u2.float(), u1.float()) < 4e-3 and u2[:, R:].abs().sum() == 0
