@@ -33,6 +33,9 @@ int mrblip_abi_version(void);
  *   (plain epilogues: the frozen-ViT GEMMs); 14 = the same at 256x192.
  * tile_cfg bits 8..16 = CU reserve of the persistent forms 13 / 14: CUs (a multiple of 8, one per XCD) this launch leaves to other
  *   streams (per-call; 0 = the calling thread's default, see mrblip_gemm_set_cu_reserve).
+ * tile_cfg bits 17..20 = K split of the skinny form (M <= 32 rows, fp32 out, no residual / out2 / act): that many blocks share an
+ *   output tile along K and atomically ADD their partial products (bias once, the output dropout mask on every partial) to `out`,
+ *   which the caller pre-initialised (mrblip_lora_rows_init) — puts every CU on the weight stream of a 12-token decoder GEMM.
  * Replaces F.linear / nn.Linear / Conv2d(k=s=14): eva_vit.py:120-126,146,54-61,196-203; Qformer.py:141-147,
  * 285-289,349-375; modeling_t5.py:323-329,536-560,1870; blip2_mr.py:491 (t5_proj); peft LoRA Linear. */
 int mrblip_gemm_bf16(const void* A, long long lda, const void* W, long long ldw, const void* Aext, long long ldaext,
@@ -135,6 +138,11 @@ int mrblip_gemm_lora_down(const void* X, long long ldx, const void* Acat, long l
  * seg: NULL, or 2 * R/8 ints [k0, k1) per 8-row group of A outside of which those rows are zero (block-diagonal B^T of a fused group). */
 int mrblip_lora_rows(const void* X, long long ldx, const void* A, long long lda, int M, int R, int K, void* U, long long ldu,
                      const int* seg, const uint32_t* seed_ptr, uint32_t site, float p_drop, mrblip_stream_t stream);
+/* mrblip_lora_rows plus a side job over the same M rows: init_dst[m, 0:init_n] = init_src ? init_src[m, :] : 0 (fp32) — the pre-initialised
+ * output (residual or zero) that a following K-split mrblip_gemm_bf16 adds its partial products to; no launch of its own. */
+int mrblip_lora_rows_init(const void* X, long long ldx, const void* A, long long lda, int M, int R, int K, void* U, long long ldu,
+                          const int* seg, const uint32_t* seed_ptr, uint32_t site, float p_drop, float* init_dst, long long ld_idst,
+                          const float* init_src, long long ld_isrc, int init_n, mrblip_stream_t stream);
 /* T5LayerNorm (modeling_t5.py:254-277) fused with the LoRA "down" product of its output: out_bf16 = bf16(x * rsqrt(mean(x^2) + eps) * weight),
  * U[M, 0:R] = dropout(out_bf16) A[R,D]^T — one launch for the norm-fed adapted projections (q/k/v, wi_0/wi_1, EncDecAttention.q). */
 int mrblip_rmsnorm_lora_fwd(const float* x, long long ldx, const float* weight, int M, int D, float eps, void* out_bf16, long long ldob,

@@ -36,6 +36,10 @@ struct GemmArgs {
   int m_rows_per_block;  // skinny kernel only: 32, or 16 / 8 when few output columns leave most CUs without a block (more blocks stream
                          // the tall operand in parallel: one CU sustains only ~10 B/clk from HBM)
   DropoutArg a_drop;  // skinny kernel only: dropout of the A operand as it is loaded (zeroing; the 1/(1-p) is applied to the result)
+  // skinny kernel only: gridDim.z blocks share one output tile along K and ADD their partial products into the fp32 output with atomics
+  // (the caller pre-initialised it: residual or zero).  With M <= 32 rows a [32 x N] output has only N / 32 tiles — 64 for the T5
+  // d_model — and one CU streams ~20 GB/s of weights: the K split puts every CU on the weight stream.
+  int k_splits;
 };
 
 // v0..v3: 4 consecutive columns n0..n0+3 of row m (raw accumulator). Applies bias -> (pre-activation copy) -> GELU -> dropout -> residual.
@@ -683,8 +687,11 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const GemmArgs p) 
   const bf16_t* wp = p.W + (long long)n_row * p.ldw + hi * 32;
   const bf16_t* xp = p.A + (long long)m_row * p.lda + hi * 32;
   // each of the NW waves owns a contiguous share of the k blocks; UNR blocks (8 independent 16-B loads per lane each) are in flight
-  const int per = (nkb + NW - 1) / NW;
-  const int kb_beg = w * per, kb_end = min(nkb, kb_beg + per);
+  const int zs = p.k_splits > 1 ? (int)blockIdx.z : 0;
+  const int per_z = p.k_splits > 1 ? (nkb + p.k_splits - 1) / p.k_splits : nkb;
+  const int z_beg = zs * per_z, z_end = min(nkb, z_beg + per_z);
+  const int per = (max(z_end - z_beg, 0) + NW - 1) / NW;
+  const int kb_beg = z_beg + w * per, kb_end = min(z_end, kb_beg + per);
 #pragma unroll 1
   for (int kb0 = kb_beg; kb0 < kb_end; kb0 += UNR) {
     bf16x8 wf[UNR][4], xf[UNR][4];
@@ -722,7 +729,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const GemmArgs p) 
 #pragma unroll
       for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[u][s], xf[u][s], acc, 0, 0, 0);
   }
-  if (p.Aext && w == NW - 1) {  // K-extension segment (one 64-wide block), taken by the last wave
+  if (p.Aext && w == NW - 1 && zs == 0) {  // K-extension segment (one 64-wide block), taken by the last wave (of the first K split)
     const bf16_t* wpe = p.Wext + (long long)n_row * p.ldwext + hi * 32;
     const bf16_t* xpe = p.Aext + (long long)m_row * p.ldaext + hi * 32;
     f32x16 e;
@@ -766,7 +773,25 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const GemmArgs p) 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] *= p.a_drop.inv_keep;
     }
-    if (m_ok) {
+    if (m_ok && OUT_F32 && p.k_splits > 1) {
+      // K-split form: this block's partial product (bias by the first split, the output dropout mask on every partial: it is linear)
+      // is added to the pre-initialised fp32 output
+      const uint32_t seed = p.drop.seed_ptr ? *p.drop.seed_ptr : 0u;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n0 = blockIdx.x * 32 + 8 * g + 4 * hi;
+        if (n0 < p.N) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            float v = acc[4 * g + i];
+            if (p.bias && zs == 0) v += p.bias[n0 + i];
+            if (p.drop.seed_ptr)
+              v = mrb_keep((uint32_t)m_row * (uint32_t)p.N + (uint32_t)(n0 + i), seed, p.drop.site, p.drop.thresh24) ? v * p.drop.inv_keep : 0.f;
+            atomicAdd(reinterpret_cast<float*>(p.out) + (long long)m_row * p.ldo + n0 + i, v);
+          }
+        }
+      }
+    } else if (m_ok) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int n0 = blockIdx.x * 32 + 8 * g + 4 * hi;
@@ -847,6 +872,7 @@ static int gemm_dispatch(const void* A, long long lda, const void* W, long long 
   GemmArgs a;
   a.ext_first = ext_first;
   a.m_rows_per_block = 32;
+  a.k_splits = 1;
   mk_drop_arg(a.ext_drop, seed_ptr, ext_site, ext_p);
   mk_drop_arg(a.a_drop, seed_ptr, a_site, a_p);
   MRB_REQUIRE(!(ext_p > 0.f || a_p > 0.f) || seed_ptr, "gemm: dropout needs a device seed pointer");
@@ -865,6 +891,7 @@ static int gemm_dispatch(const void* A, long long lda, const void* W, long long 
   // 6 = 256x256 with 4 waves of 128x128 (1 wave/SIMD: 0.7x), 7 = 256x128 BK=32 3-stage (= 128x128), [128x128 BK=32 at 3-4 blocks/CU: 0.8x,
   // 256x128 / 128x256 BK=64 with one 4-wave block per CU: 0.6x; 256x128 / 128x256 BK=32 with 8 waves of 64x64, two blocks per CU: 0.7x]
   const int reserve_arg = (tile_cfg >> 8) & 0x1ff;   // per-call CU reserve (see mrblip_gemm_set_cu_reserve)
+  const int k_splits = (tile_cfg >> 17) & 0xf;        // skinny kernel: K split with atomic accumulation into a pre-initialised fp32 output
   int cfg = tile_cfg & 0xff;
   if (cfg == 0) {
     if (M <= 64 && !gated) cfg = 3;
@@ -913,6 +940,11 @@ static int gemm_dispatch(const void* A, long long lda, const void* W, long long 
     while (!rpb32 && rpb > 8 && (long long)((N + 31) / 32) * ((M + rpb - 1) / rpb) < 192 && M > rpb) rpb >>= 1;
     a.m_rows_per_block = rpb;
     dim3 grid((N + 31) / 32, (M + rpb - 1) / rpb);
+    if (k_splits > 1) {
+      MRB_REQUIRE(out_f32 && !residual && !out2 && act == 0, "gemm: the K-split form adds into a pre-initialised fp32 output (no residual / out2 / act)");
+      a.k_splits = k_splits;
+      grid.z = k_splits;
+    }
     // (a 16-wave K-split changes nothing here: with one lane per operand row these launches are bound by the number of row-gather
     // load instructions one CU's address unit can retire, not by a wave's sequential load rounds)
     if (out_f32) hipLaunchKernelGGL((gemm_skinny_kernel<true, 4>), grid, dim3(256), 0, stream, a);

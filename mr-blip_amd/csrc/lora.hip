@@ -27,6 +27,9 @@ struct LoraRowsArgs {
   // group in the backward's g = dy B; chunks outside a group's range skip its staging and its dot products.  Dense A: [0, K) for all.
   int seg_k0[4], seg_k1[4];
   DropoutArg drop;                  // mask of X (element index m * K + k, pair-hashed); the kept values' 1/(1-p) is applied to the result
+  // optional side job for the K-split GEMM that follows on the stream (gemm.hip, k_splits): init_dst[m, 0:init_n] = init_src[m, :] (or 0)
+  // for the same rows — the fp32 output its blocks then add their partial products to; costs no launch of its own
+  float* init_dst; const float* init_src; long long ld_idst, ld_isrc; int init_n;
 };
 
 #define LORA_KC 2048  // K chunk held in LDS: R x (up to) 2048 bf16
@@ -86,6 +89,12 @@ __global__ __launch_bounds__(256) void lora_rows_kernel(const LoraRowsArgs p) {
       for (int i = 0; i < RPW; ++i) {
         const int row = row0 + i;
         if (row >= p.M) break;  // wave-uniform
+        if (p.init_dst && kc0 == 0) {
+          for (int c = lane * 4; c < p.init_n; c += 256) {
+            const float4 v = p.init_src ? *reinterpret_cast<const float4*>(p.init_src + (long long)row * p.ld_isrc + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(p.init_dst + (long long)row * p.ld_idst + c) = v;
+          }
+        }
         const bf16_t* xr = p.X + (long long)row * p.ldx + kc0;
         uint4 xv[4];
 #pragma unroll
@@ -184,8 +193,9 @@ static int launch_rows(const LoraRowsArgs& a, hipStream_t st) {
 
 // U[M, 0:R] = dropout(X)[M, K] A[R, K]^T (bf16 in / out, fp32 accumulate).  p_drop = 0 (or seed_ptr NULL): no mask (the backward's g = dy B).
 // seg (optional, 2 * R/8 ints: [k0_0, k1_0, k0_1, k1_1, ...]): the column range in which rows [8j, 8j+8) of A are non-zero.
-extern "C" int mrblip_lora_rows(const void* X, long long ldx, const void* A, long long lda, int M, int R, int K, void* U, long long ldu,
-                                const int* seg, const uint32_t* seed_ptr, uint32_t site, float p_drop, hipStream_t stream) {
+static int lora_rows_impl(const void* X, long long ldx, const void* A, long long lda, int M, int R, int K, void* U, long long ldu, const int* seg,
+                          const uint32_t* seed_ptr, uint32_t site, float p_drop, float* init_dst, long long ld_idst, const float* init_src,
+                          long long ld_isrc, int init_n, hipStream_t stream) {
   MRB_REQUIRE(M > 0 && K > 0 && (K % 8) == 0 && R > 0 && R <= 32 && (R % 8) == 0, "lora_rows: bad shape (M=%d R=%d K=%d)", M, R, K);
   MRB_REQUIRE((ldx % 8) == 0 && (lda % 8) == 0 && ((uintptr_t)X % 16) == 0 && ((uintptr_t)A % 16) == 0 && ldu >= R, "lora_rows: 16-B alignment");
   MRB_REQUIRE(!(p_drop > 0.f) || seed_ptr, "lora_rows: dropout needs a device seed pointer");
@@ -199,12 +209,28 @@ extern "C" int mrblip_lora_rows(const void* X, long long ldx, const void* A, lon
   a.drop.site = site;
   a.drop.thresh24 = (uint32_t)(p_drop * 65536.0f + 0.5f);
   a.drop.inv_keep = 1.0f / (1.0f - p_drop);
+  MRB_REQUIRE(!init_dst || ((init_n % 4) == 0 && (ld_idst % 4) == 0 && (!init_src || (ld_isrc % 4) == 0)), "lora_rows: init job needs 16-B rows");
+  a.init_dst = init_dst; a.init_src = init_src; a.ld_idst = ld_idst; a.ld_isrc = ld_isrc; a.init_n = init_dst ? init_n : 0;
   switch (R / 8) {
     case 1: return launch_rows<1>(a, stream);
     case 2: return launch_rows<2>(a, stream);
     case 3: return launch_rows<3>(a, stream);
     default: return launch_rows<4>(a, stream);
   }
+}
+
+extern "C" int mrblip_lora_rows(const void* X, long long ldx, const void* A, long long lda, int M, int R, int K, void* U, long long ldu,
+                                const int* seg, const uint32_t* seed_ptr, uint32_t site, float p_drop, hipStream_t stream) {
+  return lora_rows_impl(X, ldx, A, lda, M, R, K, U, ldu, seg, seed_ptr, site, p_drop, nullptr, 0, nullptr, 0, 0, stream);
+}
+
+// mrblip_lora_rows + the side job  init_dst[m, 0:init_n] = init_src ? init_src[m, :] : 0  over the same M rows (fp32): prepares the
+// output that a following K-split mrblip_gemm_bf16 (tile_cfg bits 17..20) accumulates into.
+extern "C" int mrblip_lora_rows_init(const void* X, long long ldx, const void* A, long long lda, int M, int R, int K, void* U, long long ldu,
+                                     const int* seg, const uint32_t* seed_ptr, uint32_t site, float p_drop, float* init_dst, long long ld_idst,
+                                     const float* init_src, long long ld_isrc, int init_n, hipStream_t stream) {
+  MRB_REQUIRE(init_dst && init_n > 0, "lora_rows_init: no destination");
+  return lora_rows_impl(X, ldx, A, lda, M, R, K, U, ldu, seg, seed_ptr, site, p_drop, init_dst, ld_idst, init_src, ld_isrc, init_n, stream);
 }
 
 // ---- T5 RMSNorm + LoRA "down" of the normalised row in one launch -------------------------------------------------------------

@@ -71,9 +71,9 @@ class BLIP2_MR(BaseModel):
             raise NotImplementedError("the MI355X engine keeps the ViT frozen (every Mr. BLIP config sets freeze_vit: True)")
         if "QA" in task:
             raise NotImplementedError("video-QA variants (forward_QA) are outside the moment-retrieval hot path")
-        if input_time_format != "seconds_integers":
-            raise NotImplementedError(f"input_time_format={input_time_format!r}: only 'seconds_integers' (every shipped config) is implemented; "
-                                      "the reference's relative_*/framenumbers formats are broken upstream (SURVEY.md §8c)")
+        if input_time_format not in ("seconds_integers", "seconds_floats"):
+            raise NotImplementedError(f"input_time_format={input_time_format!r}: 'seconds_integers' (every shipped config) and 'seconds_floats' are "
+                                      "implemented; the reference's relative_*/framenumbers formats are broken upstream (SURVEY.md §8c)")
         if not interleave_data:
             raise NotImplementedError("interleave_data: False (non-interleaved prompt) is not on the benchmarked path")
         if "lora" not in task or "qformer_freeze" not in task:
@@ -188,7 +188,7 @@ class BLIP2_MR(BaseModel):
         T = samples["video"].shape[1]
         n = 1 if self.engine.cfg.mean_pool else self.engine.cfg.num_query
         return P.build_layout(self.t5_tokenizer, samples, self.annoying_numbers_replacement_dict, n, T, self.max_txt_len,
-                              no_task_prompt="no_task_prompt" in self.task)
+                              no_task_prompt="no_task_prompt" in self.task, time_format=self.input_time_format)
 
     def _frames_to_device(self, v):
         """fp32 frames already normalised by the processor (the reference's contract), or raw uint8 frames [B,T,3,H,W]: those stay uint8 —
@@ -223,6 +223,12 @@ class BLIP2_MR(BaseModel):
         """Beam search over the HIP decoder (blip2_mr.py:826-946).  The encoder runs once; the cross-attention K/V of all 24 decoder
         layers are projected once per clip and shared by every step and every beam (engine.t5_cross_kv); the short decoder prefix
         (<= max_length tokens x beams) is re-run each step."""
+        if use_nucleus_sampling:
+            raise NotImplementedError("generate: nucleus sampling (do_sample=True, top_p) is not implemented on the MI355X engine; every Mr. BLIP "
+                                      "evaluation config decodes with beam search")
+        if float(repetition_penalty) != 1.0 or int(num_captions) != 1:
+            raise NotImplementedError("generate: repetition_penalty != 1 / num_captions != 1 are not implemented")
+        # (temperature only warps logits when sampling in HF generate: with do_sample=False it is ignored, as here)
         eng = self.engine
         was_training = eng.training
         eng.training = False
@@ -247,45 +253,19 @@ class BLIP2_MR(BaseModel):
                 mask_k = None if L["mask"] is None else L["mask"].repeat_interleave(K, 0).contiguous()
             else:
                 enc_k, mask_k = enc, L["mask"]
-            seqs = torch.zeros(B * K, 1, dtype=torch.long)
-            scores = torch.zeros(B, K)
-            scores[:, 1:] = -1e9
-            finished = [[] for _ in range(B)]
-            for step in range(max_length):
+            # HF beam search semantics (mrblip/search.py, pinned against transformers' generate in tests/test_search_cpu.py); the step
+            # function re-runs the short decoder prefix on the HIP decoder (weight-streaming bound: <= 64 rows cost what one row costs)
+            from mrblip.search import beam_search
+
+            def step_fn(seqs):
                 Ld = seqs.shape[1]
                 _, logits = eng.t5_decoder_forward(seqs, torch.ones(B * K, Ld, dtype=torch.int32), enc_k, B * K, S, mask_k, labels=None,
                                                    cross_cache=cross, cross_batch=B if cross is not None else None)
-                lp = torch.log_softmax(logits.view(B * K, Ld, -1)[:, -1].float().cpu() / float(temperature), -1)
-                if step + 1 < min_length:
-                    lp[:, 1] = -1e9
-                V = lp.shape[-1]
-                cand = (scores.view(B * K, 1) + lp).view(B, K * V)
-                top, idx = cand.topk(2 * K, -1)
-                new_seqs, new_scores = [], torch.full((B, K), -1e9)
-                for b in range(B):
-                    kept = 0
-                    for sc, ix in zip(top[b].tolist(), idx[b].tolist()):
-                        beam, tok = ix // V, ix % V
-                        seq = torch.cat([seqs[b * K + beam], torch.tensor([tok])])
-                        if tok == 1:  # </s>
-                            finished[b].append((sc / (len(seq) - 1) ** length_penalty, seq))
-                            continue
-                        new_seqs.append(seq)
-                        new_scores[b, kept] = sc
-                        kept += 1
-                        if kept == K:
-                            break
-                    while kept < K:
-                        new_seqs.append(torch.cat([seqs[b * K], torch.tensor([0])]))
-                        kept += 1
-                seqs, scores = torch.stack(new_seqs), new_scores
-                if all(len(f) >= K and max(x[0] for x in f) >= scores[b].max().item() / (seqs.shape[1]) ** length_penalty for b, f in enumerate(finished)):
-                    break
-            out_text = []
-            for b in range(B):
-                cands = finished[b] or [(scores[b, 0].item() / seqs.shape[1] ** length_penalty, seqs[b * K])]
-                best = max(cands, key=lambda x: x[0])[1]
-                out_text.append(self.t5_tokenizer.decode(best[1:], skip_special_tokens=True))
+                return torch.log_softmax(logits.view(B * K, Ld, -1)[:, -1].float(), -1).cpu()
+
+            best = beam_search(step_fn, B, K, int(max_length), min_length=int(min_length), length_penalty=float(length_penalty),
+                               eos_id=1, pad_id=0, start_id=0)
+            out_text = [self.t5_tokenizer.decode(seq[1:], skip_special_tokens=True) for seq in best]
             raw = list(out_text)
             pred = [self.post_process(t) for t in out_text]
             return {"duration": [float(x) for x in samples["duration"]], "prediction": pred, "raw_prediction": raw,

@@ -65,6 +65,8 @@ class MomentRetrievalTask(BaseTask):
         metric_logger = MetricLogger(delimiter="  ")
         iters_per_epoch = len(data_loader)
         model.train()
+        pending_loss = None  # the loss is read ONE step late: loss.item() right after the step (the reference's loop, :234) drains the
+        #                      stream, and with ~2900 launches per step the host would then re-fill the queue while the GPU idles
         for i, (samples, nxt) in enumerate(_with_next(metric_logger.log_every(data_loader, log_freq, f"Train: data epoch: [{epoch}]"))):
             samples.update({"epoch": epoch, "num_iters_per_epoch": iters_per_epoch, "iters": i})
             if nxt is not None:  # one-batch look-ahead: the model overlaps the next clip's frozen-ViT forward with this step's decoder
@@ -79,7 +81,12 @@ class MomentRetrievalTask(BaseTask):
                     reduce_grads()
                 optimizer.step()
                 optimizer.zero_grad()
-            metric_logger.update(loss=loss.item(), lr=optimizer.lr)
+            if pending_loss is not None:
+                metric_logger.update(loss=pending_loss.item())
+            pending_loss = loss.detach()
+            metric_logger.update(lr=optimizer.lr)
+        if pending_loss is not None:
+            metric_logger.update(loss=pending_loss.item())
         metric_logger.synchronize_between_processes()
         logging.info("Averaged stats: " + metric_logger.global_avg())
         return {k: "{:.3f}".format(m.global_avg) for k, m in metric_logger.meters.items()}

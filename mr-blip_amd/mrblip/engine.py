@@ -640,9 +640,29 @@ class MrBlipEngine:
     def lg_fwd(self, g: LoraGroup, x: torch.Tensor, u: torch.Tensor, out: torch.Tensor, u_ready: bool = False, **kw):
         """out = x W^T + u B^T with u = dropout(x) (scale*A)^T:  the rank-8 "down" product is the row kernel of csrc/lora.hip (or was
         already produced by the fused RMSNorm launch: u_ready), the "up" product rides in the main GEMM as a 64-wide K extension."""
+        ks = self.k_splits_for(x.shape[0], g.N, g.K, out)
+        if ks > 1 and not u_ready and kw.get("residual", None) is not None and not kw.get("gated") and kw.get("out2") is None:
+            # 12-token decoder rows: a [M x 2048] output has 64 tiles of the skinny kernel; ks blocks per tile share K and add their
+            # partial products atomically into `out`, which the LoRA "down" launch pre-initialises with the residual on its way
+            res = kw.pop("residual")
+            ops.lora_rows(x, g.acat, u, g.K, drop=self.drop(g.site, self.cfg.lora_dropout), init_dst=out, init_src=res)
+            ops.gemm(x, g.W, out, aext=u, wext=g.wext, k_splits=ks, **kw)
+            return
         if not u_ready:
             self.lora_thin(x, g.acat, u, g.K, drop=self.drop(g.site, self.cfg.lora_dropout))
         ops.gemm(x, g.W, out, aext=u, wext=g.wext, **kw)
+
+    # Opt-in (MRB_KSPLIT=1).  Measured on the QVH step: 76.6 vs 77.0 ms — the decoder chain is not what bounds the step once the
+    # frozen-ViT look-ahead runs beside it — and the fp32 atomics make the summation order, hence the last bits, run-dependent.
+    ksplit_enabled = os.environ.get("MRB_KSPLIT", "0") == "1"
+
+    def k_splits_for(self, M: int, N: int, K: int, out: torch.Tensor) -> int:
+        """K split of the skinny GEMM (csrc/gemm.hip): only for <= 32 rows, fp32 output, few output tiles and a long enough K"""
+        if not self.ksplit_enabled or M > 32 or out.dtype != f32 or N > 4096 or K < 1024:
+            return 1
+        tiles = (N + 31) // 32
+        ks = max(1, min(8, 256 // tiles, K // 256))
+        return ks if ks > 1 else 1
 
     # rows of the tall operand up to which the thin LoRA products take the row kernel of csrc/lora.hip (decoder: 8-12 rows -> 10 us
     # instead of 12-22 us, and the RMSNorm fusion saves a launch); taller inputs (encoder, M = 2012 / 8048) keep the MFMA skinny
@@ -650,10 +670,10 @@ class MrBlipEngine:
     # (tools/lora_rows_bench.py: 15.7 vs 12.6 us at M = 2012, 47 vs 15 us at M = 8048).
     lora_rows_max_m = int(os.environ.get("MRB_LORA_ROWS_MAX_M", "256"))
 
-    def lora_thin(self, x, a, u, K, drop=None, seg=None):
+    def lora_thin(self, x, a, u, K, drop=None, seg=None, init_dst=None, init_src=None):
         """u[:, :R] = dropout(x)[:, :K] @ a^T for a thin a ([R <= 32, K])"""
         if x.shape[0] <= self.lora_rows_max_m:
-            ops.lora_rows(x, a, u, K, drop=drop, seg=seg)
+            ops.lora_rows(x, a, u, K, drop=drop, seg=seg, init_dst=init_dst, init_src=init_src)
         elif drop is not None:
             ops.lora_down(x, a, u, K, drop=drop)
         else:
@@ -678,7 +698,11 @@ class MrBlipEngine:
         that dy / gbuf are not overwritten before its next side_join_layer())."""
         drop = self.drop(g.site, self.cfg.lora_dropout)
         seg = [v for a in g.adapters for v in (a.row0, a.row0 + a.out)] if len(g.adapters) > 1 else None
-        self.lora_thin(dy, g.bblk, gbuf, g.N, seg=seg)                      # g' = scale * dy @ B      [M, 8*nad]
+        ks = self.k_splits_for(dy.shape[0], g.K, pad64(g.N), dx) if dx is not None else 1
+        if ks > 1:   # dX by the K-split skinny GEMM: this launch also pre-initialises dx (residual or zero)
+            self.lora_thin(dy, g.bblk, gbuf, g.N, seg=seg, init_dst=dx, init_src=residual)
+        else:
+            self.lora_thin(dy, g.bblk, gbuf, g.N, seg=seg)                  # g' = scale * dy @ B      [M, 8*nad]
         ads = g.adapters
         if side and self.grad_side_stream_enabled:
             st = self._grad_stream()
@@ -690,7 +714,10 @@ class MrBlipEngine:
         else:
             ops.lora_grads(dy, u, x, gbuf, [a.dBt for a in ads], [a.row0 for a in ads], [a.out for a in ads], [a.dA for a in ads], g.K, drop=drop)
         if dx is not None:
-            ops.lora_dx(dy, g.Wt, gbuf, g.acatt, dx, pad64(g.N), residual=residual, drop=drop)
+            if ks > 1:
+                ops.lora_dx(dy, g.Wt, gbuf, g.acatt, dx, pad64(g.N), residual=None, drop=drop, k_splits=ks)
+            else:
+                ops.lora_dx(dy, g.Wt, gbuf, g.acatt, dx, pad64(g.N), residual=residual, drop=drop)
 
     grad_side_stream_enabled = os.environ.get("MRB_GRAD_SIDE", "1") == "1"
     _gstream = None

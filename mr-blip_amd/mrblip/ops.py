@@ -74,6 +74,7 @@ _seed_bump = _sig("mrblip_seed_bump", vp, vp)
 _lora_dx = _sig("mrblip_lora_dx_add", vp, ll, i32, vp, ll, vp, i32, i32, i32, vp, u32, f32, vp)
 _cu_reserve = _sig("mrblip_gemm_set_cu_reserve", i32)
 _lora_rows = _sig("mrblip_lora_rows", vp, ll, vp, ll, i32, i32, i32, vp, ll, vp, vp, u32, f32, vp)
+_lora_rows_init = _sig("mrblip_lora_rows_init", vp, ll, vp, ll, i32, i32, i32, vp, ll, vp, vp, u32, f32, vp, ll, vp, ll, i32, vp)
 _rms_lora = _sig("mrblip_rmsnorm_lora_fwd", vp, ll, vp, i32, i32, f32, vp, ll, vp, ll, i32, vp, ll, vp, u32, f32, vp)
 
 EXPORTS = [
@@ -83,7 +84,7 @@ EXPORTS = [
     "mrblip_cast_dropout", "mrblip_gelu_bwd", "mrblip_gated_gelu_bwd", "mrblip_cross_entropy", "mrblip_adamw",
     "mrblip_seed_bump", "mrblip_lora_dx_add", "mrblip_dropout_bf16", "mrblip_colsum", "mrblip_lora_pack", "mrblip_lora_tn",
     "mrblip_lora_grads", "mrblip_gemm_lora_down", "mrblip_gemm_lora_dx", "mrblip_patchify_u8",
-    "mrblip_gemm_set_cu_reserve", "mrblip_lora_rows", "mrblip_rmsnorm_lora_fwd",
+    "mrblip_gemm_set_cu_reserve", "mrblip_lora_rows", "mrblip_rmsnorm_lora_fwd", "mrblip_lora_rows_init",
 ]
 
 
@@ -127,9 +128,10 @@ def _d(d: Optional[Dropout]):
 # ------------------------------------------------------------------------------------------------ GEMM
 def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, aext=None, wext=None, out2=None, bias=None, residual=None,
          act: int = 0, gated: bool = False, drop: Optional[Dropout] = None, tile_cfg: int = 0, K: Optional[int] = None,
-         cu_reserve: Optional[int] = None):
+         cu_reserve: Optional[int] = None, k_splits: int = 0):
     """out[M,N] = a[M,K] @ w[N,K]^T (+ aext @ wext^T) with the fused epilogue of mrblip_gemm_bf16.  cu_reserve: CUs a persistent
-    tile kernel leaves to other streams (None = the calling thread's ``gemm_cu_reserve`` context, default 0)."""
+    tile kernel leaves to other streams (None = the calling thread's ``gemm_cu_reserve`` context, default 0).  k_splits > 1 (M <= 32,
+    fp32 out, no residual): the skinny kernel's blocks split K and ADD into ``out``, which the caller pre-initialised."""
     _req(a, torch.bfloat16, "gemm.a"); _req(w, torch.bfloat16, "gemm.w")
     M = a.shape[0]
     N = w.shape[0]
@@ -138,7 +140,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, aext=None, wext
     reserve = getattr(_tls, "cu_reserve", 0) if cu_reserve is None else cu_reserve
     _chk(_gemm(_p(a), _ld(a), _p(w), _ld(w), _p(aext), _ld(aext), _p(wext), _ld(wext), M, N, K, _p(out), _ld(out),
                1 if out.dtype == torch.float32 else 0, _p(out2), _ld(out2), _p(bias), _p(residual), _ld(residual), act,
-               1 if gated else 0, sp, site, p, (tile_cfg & 0xff) | ((int(reserve) & 0x1ff) << 8), _stream()))
+               1 if gated else 0, sp, site, p, (tile_cfg & 0xff) | ((int(reserve) & 0x1ff) << 8) | ((int(k_splits) & 0xf) << 17), _stream()))
     return out
 
 
@@ -242,7 +244,7 @@ def lora_down(x, acat, u, K, drop: Optional[Dropout] = None):
     _chk(_lora_down(_p(x), _ld(x), _p(acat), _ld(acat), M, acat.shape[0], K, _p(u), _ld(u), sp, site, p, _stream()))
 
 
-def lora_rows(x, a, u, K, drop: Optional[Dropout] = None, seg: Optional[Sequence[int]] = None):
+def lora_rows(x, a, u, K, drop: Optional[Dropout] = None, seg: Optional[Sequence[int]] = None, init_dst=None, init_src=None):
     """u[:, :R] = dropout(x[:, :K]) @ a^T  (a: bf16 [R, >= K], R <= 32) — the row kernel (csrc/lora.hip).  seg: [k0, k1) per 8-row
     group of ``a`` outside of which the group is zero (the block-diagonal s*B^T of a fused LoRA group): skipped work, same result."""
     sp, site, p = _d(drop)
@@ -251,7 +253,12 @@ def lora_rows(x, a, u, K, drop: Optional[Dropout] = None, seg: Optional[Sequence
     if seg is not None:
         assert len(seg) == 2 * (R // 8)
         segp = (i32 * len(seg))(*[int(v) for v in seg])
-    _chk(_lora_rows(_p(x), _ld(x), _p(a), _ld(a), x.shape[0], R, K, _p(u), _ld(u), segp, sp, site, p, _stream()))
+    if init_dst is None:
+        _chk(_lora_rows(_p(x), _ld(x), _p(a), _ld(a), x.shape[0], R, K, _p(u), _ld(u), segp, sp, site, p, _stream()))
+    else:  # + init_dst[m, :] = init_src[m, :] (or 0): the fp32 output a following K-split gemm(..., k_splits=n) accumulates into
+        _req(init_dst, torch.float32, "lora_rows.init_dst")
+        _chk(_lora_rows_init(_p(x), _ld(x), _p(a), _ld(a), x.shape[0], R, K, _p(u), _ld(u), segp, sp, site, p, _p(init_dst), _ld(init_dst),
+                             _p(init_src), _ld(init_src), init_dst.shape[1], _stream()))
 
 
 def rmsnorm_lora_fwd(x, weight, eps, out_bf16, a, u, drop: Optional[Dropout] = None):
@@ -262,13 +269,14 @@ def rmsnorm_lora_fwd(x, weight, eps, out_bf16, a, u, drop: Optional[Dropout] = N
     _chk(_rms_lora(_p(x), _ld(x), _p(weight), M, D, eps, _p(out_bf16), _ld(out_bf16), _p(a), _ld(a), a.shape[0], _p(u), _ld(u), sp, site, p, _stream()))
 
 
-def lora_dx(dy, wt, g, acatt, dx, K, residual=None, drop: Optional[Dropout] = None, tile_cfg=0):
+def lora_dx(dy, wt, g, acatt, dx, K, residual=None, drop: Optional[Dropout] = None, tile_cfg=0, k_splits: int = 0):
     """dx = dy[:, :K] @ wt^T (+ residual) + mask(drop) * (g @ acatt^T);  wt: bf16 [N_in, >=K], acatt: bf16 [N_in, 64]"""
     M = dy.shape[0]
     N = wt.shape[0]
     sp, site, p = _d(drop)
     _chk(_gemm_lora_dx(_p(dy), _ld(dy), _p(wt), _ld(wt), _p(g), _ld(g), _p(acatt), _ld(acatt), M, N, K, _p(dx), _ld(dx),
-                  1 if dx.dtype == torch.float32 else 0, _p(residual), _ld(residual) if residual is not None else 0, sp, site, p, tile_cfg, _stream()))
+                  1 if dx.dtype == torch.float32 else 0, _p(residual), _ld(residual) if residual is not None else 0, sp, site, p,
+                  (tile_cfg & 0xff) | ((int(k_splits) & 0xf) << 17), _stream()))
 
 
 def dropout_bf16(x, out, drop: Optional[Dropout] = None):

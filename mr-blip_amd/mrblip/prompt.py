@@ -52,7 +52,18 @@ def seconds_integers(timestamps: torch.Tensor, durations: torch.Tensor, repl: Di
     return ts_out, d_out
 
 
-def clean_number_tokens(tokenizer, values: Sequence[int]) -> List[List[int]]:
+def seconds_floats(timestamps: torch.Tensor, durations: torch.Tensor):
+    """input_time_format "seconds_floats" (utils.py:464-485): each timestamp is round(t, 2) stored back into a float32 tensor and later
+    printed with str(tensor_element.item()) (blip2_mr.py:1576-1578) — i.e. the float64 expansion of the float32 value ("22.49" becomes
+    "22.489999771118164"; a reference quirk the tokens depend on).  Durations are NOT rounded: str(float32 duration)."""
+    import numpy as np
+
+    ts_out = [[str(float(np.float32(round(x, 2)))) for x in row] for row in timestamps.tolist()]
+    d_out = [str(float(np.float32(d))) for d in durations.tolist()]
+    return ts_out, d_out
+
+
+def clean_number_tokens(tokenizer, values: Sequence) -> List[List[int]]:
     toks = tokenizer([str(v) for v in values], add_special_tokens=False)["input_ids"]
     return [t[1:] if (len(t) > 0 and t[0] == 3) else t for t in toks]
 
@@ -79,10 +90,15 @@ def shift_right(labels: torch.Tensor, start_id: int = 0, pad_id: int = 0) -> tor
 
 
 def build_layout(tokenizer, samples: dict, repl: Dict[int, int], n_per_frame: int, T: int, max_txt_len: int = 200,
-                 no_task_prompt: bool = False) -> EncoderLayout:
+                 no_task_prompt: bool = False, time_format: str = "seconds_integers") -> EncoderLayout:
     """[ f_0(n) | ts_0 | f_1(n) | ts_1 | ... | ">" | duration | video_prompt_end | text(right padded) ], shorter video
     prompts LEFT padded with zero vectors whose attention mask stays 1 (reference quirk, blip2_mr.py:744-753, 769-774)."""
-    ts, durs = seconds_integers(samples["timestamps"], samples["duration"], repl)
+    if time_format == "seconds_integers":
+        ts, durs = seconds_integers(samples["timestamps"], samples["duration"], repl)
+    elif time_format == "seconds_floats":
+        ts, durs = seconds_floats(samples["timestamps"], samples["duration"])
+    else:  # relative_* / framenumbers are broken in the reference itself (undefined helper / str + float: SURVEY.md §8c)
+        raise ValueError("Invalid input_time_format, please choose from ['seconds_integers', 'seconds_floats']")
     B = len(ts)
     end_tok = tokenizer(list(samples["video_prompt_end"]), padding="longest", add_special_tokens=False, truncation=True,
                         max_length=max_txt_len, return_tensors="pt")

@@ -107,6 +107,14 @@ def timestamps_as_seconds_integers(timestamps: Tensor, durations: Tensor, repl: 
     return new_ts, new_d, prompts
 
 
+def timestamps_as_seconds_floats(timestamps: Tensor, durations: Tensor):
+    """utils.py:464-485: round(t, 2) stored into a float32 tensor; durations untouched.  (The tokens are later taken from
+    str(tensor_element.item()), blip2_mr.py:1576-1578 — see clean_timestamp_tokens.)"""
+    new_ts = [torch.tensor([round(x.item(), 2) for x in t]) for t in timestamps]
+    prompts = [">".join(str(round(x.item(), 2)) for x in t) + ">" + str(round(d.item())) for t, d in zip(timestamps, durations)]
+    return new_ts, durations, prompts
+
+
 def clean_timestamp_tokens(tokenizer, values) -> List[List[int]]:
     """blip2_mr.py:1576-1581: tokenise str(v) without specials, strip a leading id 3."""
     toks = tokenizer([str(v.item() if torch.is_tensor(v) else v) for v in values], add_special_tokens=False)["input_ids"]
@@ -370,9 +378,12 @@ class Oracle:
 
     # ---- prompt construction (blip2_mr.py:572-783, interleave branch) -----------------------------------
     def prompt_concatenation(self, tok, timestamps, durations, frames_for_t5, video_prompt_end, query_prompt,
-                             task_prompt, repl: Dict[int, int], n_per_frame: int):
+                             task_prompt, repl: Dict[int, int], n_per_frame: int, time_format: str = "seconds_integers"):
         emb = self._t5p("shared.weight")
-        ts_int, dur_int, _ = timestamps_as_seconds_integers(timestamps, durations, repl)
+        if time_format == "seconds_floats":
+            ts_int, dur_int, _ = timestamps_as_seconds_floats(timestamps, durations)
+        else:
+            ts_int, dur_int, _ = timestamps_as_seconds_integers(timestamps, durations, repl)
         end_tok = tok(video_prompt_end, padding="longest", add_special_tokens=False, truncation=True, max_length=200, return_tensors="pt")
         text_tok = tok([q + t for q, t in zip(query_prompt, task_prompt)], padding="longest", truncation=True, max_length=200, return_tensors="pt")
         dur_tokens = clean_timestamp_tokens(tok, dur_int)
@@ -395,7 +406,7 @@ class Oracle:
         return embs, atts
 
     # ---- whole train-step forward (blip2_mr.py:433-570) -------------------------------------------------
-    def forward_mr(self, tok, samples: dict, repl: Dict[int, int], mean_pool: bool = False):
+    def forward_mr(self, tok, samples: dict, repl: Dict[int, int], mean_pool: bool = False, time_format: str = "seconds_integers"):
         video = samples["video"]
         b, t = video.shape[:2]
         with torch.no_grad():
@@ -409,7 +420,7 @@ class Oracle:
         f = f.reshape(b, t * n, -1)
         embs, atts = self.prompt_concatenation(tok, samples["timestamps"], samples["duration"], f,
                                                samples["video_prompt_end"], samples["query_prompt"],
-                                               samples["task_prompt"], repl, n)
+                                               samples["task_prompt"], repl, n, time_format=time_format)
         ans = tok(samples["relevant_windows"], padding="longest", truncation=True, max_length=200, return_tensors="pt")
         labels = ans.input_ids.masked_fill(ans.input_ids == tok.pad_token_id, -100)
         loss, logits, enc = self.t5_loss(embs, atts, labels, ans.attention_mask)

@@ -1,6 +1,7 @@
 """Host-side integer logic of the product (mrblip.prompt) against the golden vectors and the pinned oracle: bit-exact
 timestamp-token indexing, interleave index map, masks, labels, relative-position LUT.  CPU only."""
 import numpy as np
+import pytest
 import torch
 
 from oracle import mrblip_oracle as O
@@ -115,3 +116,32 @@ def test_interleave_layout_edge_cases_against_oracle():
         ans = tok(samples["relevant_windows"], padding="longest", truncation=True, max_length=200, return_tensors="pt")
         labels = ans.input_ids.masked_fill(ans.input_ids == tok.pad_token_id, -100)
         assert torch.equal(lay.labels, labels) and torch.equal(lay.decoder_input_ids, O.shift_right(labels))
+
+
+def test_seconds_floats_layout_matches_reference_golden():
+    """input_time_format="seconds_floats" (utils.py:464-485): product layout and oracle against the reference's own forward_mr
+    (tests/golden/mr_tiny_floats.npz): mask and every embedding / zero-pad row of the interleaved encoder input, incl. the reference's
+    float32 -> str quirk ("22.49" is tokenised as "22.489999771118164")."""
+    g = load_golden("mr_tiny_floats")
+    tok = FixtureTokenizer()
+    sd = golden_state_dict(g)
+    s = g["strings"]
+    samples = dict(video=torch.from_numpy(g["video"]), timestamps=torch.from_numpy(g["timestamps"]), duration=torch.from_numpy(g["duration"]),
+                   query_prompt=s["query_prompt"], task_prompt=s["task_prompt"], video_prompt_end=s["video_prompt_end"],
+                   relevant_windows=s["relevant_windows"])
+    assert P.seconds_floats(samples["timestamps"], samples["duration"])[0][0][1] == "22.489999771118164"
+    lay = P.build_layout(tok, samples, {}, 8, T=3, time_format="seconds_floats")
+    assert lay.S == g["inputs_embs"].shape[1]
+    assert torch.equal(lay.attention_mask.long(), torch.from_numpy(g["inputs_atts"]))
+    emb = sd["t5_model.shared.weight"]
+    gold = torch.from_numpy(g["inputs_embs"]).reshape(-1, emb.shape[1])
+    src = lay.emb_src.long()
+    rows = torch.where((src >= 0)[:, None], emb[src.clamp_min(0)], torch.zeros(1, emb.shape[1]))
+    assert torch.equal(gold[lay.emb_dst.long()], rows)                       # every timestamp / text / pad row: bit-exact
+    assert len(set(lay.frame_dst.tolist()) | set(lay.emb_dst.tolist())) == 2 * lay.S
+    orc = O.Oracle(sd, TINY_CFG)
+    with torch.no_grad():
+        out = orc.forward_mr(tok, samples, {}, time_format="seconds_floats")
+    assert np.allclose(out["inputs_embs"].numpy(), g["inputs_embs"], rtol=0, atol=2e-5) and abs(out["loss"].item() - float(g["loss"])) < 1e-4
+    with pytest.raises(ValueError):
+        P.build_layout(tok, samples, {}, 8, T=3, time_format="relative_floats")

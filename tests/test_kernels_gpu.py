@@ -667,3 +667,44 @@ def test_rmsnorm_lora_fused(ops, M, D, R):
         ops.rmsnorm_lora_fwd(x, w, 1e-6, xn2, a, u2, drop=drop)
         assert torch.equal(xn1, xn2)
         assert rel(u2.float(), u1.float()) < 4e-3 and u2[:, R:].abs().sum() == 0
+
+
+@pytest.mark.parametrize("M,N,K,ks", [(8, 2048, 2048, 4), (12, 2048, 5120, 4), (32, 768, 2048, 8), (5, 2048, 10240, 4), (8, 96, 1024, 2)])
+def test_gemm_k_split_skinny_with_preinitialised_output(ops, M, N, K, ks):
+    """decoder-row GEMMs: lora_rows pre-initialises the fp32 output with the residual (side job of the LoRA "down" launch), the K-split
+    skinny GEMM adds its partial products atomically (bias once, LoRA K-extension once, output dropout on every partial) — equal to the
+    one-block-per-tile form up to the fp32 summation order."""
+    from util import check
+    torch.manual_seed(31)
+    x = bf(torch.randn(M, K, device=dev()))
+    w = bf(torch.randn(N, K, device=dev()) * 0.03)
+    acat = bf(torch.randn(16, K, device=dev()) * 0.05)
+    wext = torch.zeros(N, 64, dtype=torch.bfloat16, device=dev())
+    wext[:, :16] = bf(torch.randn(N, 16, device=dev()) * 0.05)
+    res = torch.randn(M, N, device=dev())
+    bias = torch.randn(N, device=dev())
+    seed = torch.tensor([99], dtype=torch.int32, device=dev())
+    ldrop, odrop = ops.Dropout(seed, 4, 0.05), ops.Dropout(seed, 8, 0.1)
+    # reference: the unsplit path
+    u0 = torch.zeros(M, 64, dtype=torch.bfloat16, device=dev())
+    ops.lora_rows(x, acat, u0, K, drop=ldrop)
+    ref = torch.empty(M, N, device=dev())
+    ops.gemm(x, w, ref, aext=u0, wext=wext, bias=bias, residual=res, drop=odrop)
+    # split path
+    u1 = torch.zeros_like(u0)
+    out = torch.full((M, N), 7.0, device=dev())
+    ops.lora_rows(x, acat, u1, K, drop=ldrop, init_dst=out, init_src=res)
+    assert torch.equal(u0, u1)
+    ops.gemm(x, w, out, aext=u1, wext=wext, bias=bias, drop=odrop, k_splits=ks)
+    check("gemm k-split M=%d N=%d K=%d ks=%d vs unsplit" % (M, N, K, ks), rel(out, ref), 1e-5)
+    # zero initialisation + the LoRA backward form (masked K-extension first)
+    g = torch.zeros(M, 64, dtype=torch.bfloat16, device=dev())
+    g[:, :16] = bf(torch.randn(M, 16, device=dev()))
+    acatt = torch.zeros(N, 64, dtype=torch.bfloat16, device=dev())
+    acatt[:, :16] = bf(torch.randn(N, 16, device=dev()) * 0.05)
+    ref2 = torch.empty(M, N, device=dev())
+    ops.lora_dx(x, w, g, acatt, ref2, K, residual=None, drop=ldrop)
+    out2 = torch.full((M, N), -3.0, device=dev())
+    ops.lora_rows(x, acat, u1, K, init_dst=out2, init_src=None)
+    ops.lora_dx(x, w, g, acatt, out2, K, residual=None, drop=ldrop, k_splits=ks)
+    check("lora_dx k-split M=%d N=%d K=%d ks=%d vs unsplit" % (M, N, K, ks), rel(out2, ref2), 1e-5)

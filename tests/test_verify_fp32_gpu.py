@@ -1,0 +1,79 @@
+"""The north star's "fp logits within 1e-3 relative" against the reference's fp32 CPU run, shown on the engine's OWN forward path fed
+with fp32-accurate (split-bf16) operands — tests/verify_fp32.py.  If the bf16 gap of the product path (measured ~1e-2, tests/
+test_model_gpu.py / test_fullsize_gpu.py) came from a logic error, it would still be there with 16-bit-mantissa operands; it is not."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from util import check, load_golden, golden_state_dict, relerr  # noqa: E402
+
+
+def _run(eng, video, lay):
+    from verify_fp32 import Fp32Verify
+
+    with Fp32Verify(eng):
+        loss = eng.forward_backward(video, lay, backward=False).item()
+        logits = eng.ws["d_logits"].clone()
+        emb = eng.ws["inputs_embeds"].clone()
+        xv = eng.ws["vit_x"].clone()
+        qf = eng._qf_last_f32.clone()
+    return loss, logits, emb, xv, qf
+
+
+@pytest.mark.parametrize("tag,mean", [("mr_tiny", False), ("mr_tiny_mean", True)])
+def test_fp32_operand_mode_tiny(tag, mean):
+    from mrblip import prompt as P
+    from mrblip.engine import EngineConfig, MrBlipEngine, StateDictSource
+    from mrblip.tokenizer import FixtureTokenizer
+    from test_model_gpu import _samples
+
+    g = load_golden(tag)
+    sd = golden_state_dict(g)
+    tok = FixtureTokenizer()
+    repl = P.annoying_replacement_dict(P.find_annoying_numbers(tok, 200)[0])
+    samples = _samples(g)
+    eng = MrBlipEngine(EngineConfig.tiny(mean_pool=mean), StateDictSource(sd), torch.device("cuda:0"))   # LoRA: peft init, B = 0
+    eng.training = False
+    eng._verify_src = StateDictSource(sd)
+    lay = P.build_layout(tok, samples, repl, 1 if mean else 8, T=3)
+    l_bf16 = eng.forward_backward(samples["video"].cuda(), lay, backward=False).item()
+    lg_bf16 = eng.ws["d_logits"].clone()
+    loss, logits, emb, xv, qf = _run(eng, samples["video"].cuda(), lay)
+    lg = logits.cpu().view(g["logits_sub"].shape[0], g["logits_sub"].shape[1], -1)
+    check(tag + ".verify-fp32: logits vs reference-fp32", relerr(lg[..., ::64], g["logits_sub"]), 1e-3)
+    check(tag + ".verify-fp32: logits_lse vs reference-fp32", relerr(torch.logsumexp(lg, -1), g["logits_lse"]), 1e-4)
+    check(tag + ".verify-fp32: loss vs reference-fp32 (rel)", abs(loss - float(g["loss"])) / abs(float(g["loss"])), 1e-4)
+    check(tag + ".verify-fp32: inputs_embeds vs reference-fp32", relerr(emb.cpu().view(g["inputs_embs"].shape), g["inputs_embs"]), 1e-3)
+    # and the product (bf16-operand) path on the same engine, for the record: same code, only the operand precision differs
+    check(tag + ".product-bf16: logits vs reference-fp32", relerr(lg_bf16.cpu().view(lg.shape)[..., ::64], g["logits_sub"]), 3e-2)
+    # leaving the mode restores the product path bit for bit
+    l_again = eng.forward_backward(samples["video"].cuda(), lay, backward=False).item()
+    assert abs(l_again - l_bf16) <= 1e-6 * abs(l_bf16)   # (atomic loss reduction: last-bit order effects)
+
+
+def test_fp32_operand_mode_c1_real_depth():
+    """39 ViT blocks + 12 Q-Former layers + 12 + 12 T5 layers at real width (BASELINE configs[0]) against the reference's own fp32 run"""
+    from weights import seeded_state_dict
+    from mrblip import prompt as P
+    from mrblip.engine import EngineConfig, MrBlipEngine, StateDictSource
+    from mrblip.tokenizer import FixtureTokenizer
+    from test_fullsize_gpu import _c1_samples
+
+    g = load_golden("mr_c1")
+    sd = seeded_state_dict(g["manifest"], wscale=g["strings"]["wscale"], fast=True)
+    tok = FixtureTokenizer()
+    repl = P.annoying_replacement_dict(P.find_annoying_numbers(tok, 200)[0])
+    samples = _c1_samples(g)
+    cfg = EngineConfig(d_model=768, d_kv=64, t5_heads=12, d_ff=2048, t5_layers=12, t5_dec_layers=12)
+    eng = MrBlipEngine(cfg, StateDictSource(sd), torch.device("cuda:0"))
+    eng.training = False
+    eng._verify_src = StateDictSource(sd)
+    lay = P.build_layout(tok, samples, repl, 32, T=4)
+    loss, logits, emb, xv, qf = _run(eng, samples["video"].cuda(), lay)
+    lg = logits.cpu().view(1, -1, 32128)
+    check("c1.verify-fp32: vit.out (39 blocks) vs reference-fp32", relerr(xv.view(4, 257, 1408)[:, ::8, ::4].cpu(), g["vit_sub"]), 1e-3)
+    check("c1.verify-fp32: qformer.out vs reference-fp32", relerr(qf.view(4, 32, 768)[:, :, ::2].cpu(), g["qf_out"]), 1e-3)
+    check("c1.verify-fp32: inputs_embeds vs reference-fp32", relerr(emb.view(1, lay.S, 768)[..., ::4].cpu(), g["inputs_embs_sub"]), 1e-3)
+    check("c1.verify-fp32: logits vs reference-fp32", relerr(lg[..., ::64], g["logits_sub"]), 1e-3)
+    check("c1.verify-fp32: loss vs reference-fp32 (rel)", abs(loss - float(g["loss"])) / abs(float(g["loss"])), 1e-4)
