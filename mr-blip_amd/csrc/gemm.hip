@@ -665,6 +665,262 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
 #undef W4_OPEN_TILE
 }
 
+// ---- the same 256 x 256 x 64 four-wave tile with a DEFERRED epilogue (bf16 output, bias, optional exact-erf GELU: ViT qkv / fc1).
+// tools/w4_stamps.py showed where gemm_w4_kernel's time goes: 6 us (bias) to 15.5 us (bias + GELU) of every 40-57 us tile are an
+// epilogue during which the MFMA pipe idles — with one wave per SIMD nothing else can run.  Here a finished tile leaves the
+// accumulators at once: bf16(acc) (the bias was folded into the accumulator start value) is parked in 128 VGPRs, and while the NEXT
+// tile's K loop runs, one 32 x 32 block of it per K-tile is activated (GELU in fp32), re-packed and stored in the shadow of that
+// K-tile's 64 MFMAs.  No LDS staging: a v_permlane32_swap pair gives every lane 8 consecutive output columns (lanes l / l + 32 hold
+// the two 4-column halves of one row), i.e. 16-B stores.  The parked registers form a FIFO (block 0 is always regs 0..7; the rest
+// shift down by 8 per K-tile: 120 v_mov in MFMA shadow), so the loop body needs no dynamic register indexing.
+// Numerics: identical to gemm_w4_kernel for ACT = 0; with GELU the pre-activation is rounded to bf16 before the activation (as the
+// reference's autocast path does with its fp16 fc1 output) instead of after it.
+#ifndef W4D_NPARK
+#define W4D_NPARK 16
+#endif
+// slot (0 .. 63 = MFMA slots of one K-tile; the stage hand-over with its vmcnt(0) sits in front of slot 48) of the lane exchange, of the
+// two stores, of the first FIFO-shift step, and registers moved per shift step
+#ifdef EXP_W4D_NOSTORE
+#define W4D_STORE_GUARD && p.K == -7
+#else
+#define W4D_STORE_GUARD
+#endif
+#ifndef W4D_S_SWAP
+#define W4D_S_SWAP 24
+#define W4D_S_STORE 25
+#define W4D_S_SHIFT 26
+#define W4D_SHIFT_PER 4
+#endif
+template <int ACT>
+__global__ __launch_bounds__(256, 1) void gemm_w4d_kernel(const GemmArgs p) {
+  constexpr int TN = 4, BM = 256, BN = 256, WN = 128, RB = 128, NW = 4, RPI = 8;
+  constexpr int A_BYTES = BM * RB, W_BYTES = BN * RB, STAGE = A_BYTES + W_BYTES;
+  constexpr int JA = BM / RPI / NW, JW = BN / RPI / NW;
+  constexpr int NSLOT = 4 * TN, NFRAG = 4 + TN;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = w >> 1, wn = w & 1;
+  const int hi = lane >> 5, l31 = lane & 31;
+  const int chunk = (lane & 7) ^ ((w * 4 + (lane >> 4)) & 7);
+  const uint32_t vA = (uint32_t)((long long)(lane >> 3) * p.lda * 2) + chunk * 16;
+  const uint32_t vW = (uint32_t)((long long)(lane >> 3) * p.ldw * 2) + chunk * 16;
+  const int nk = p.K / 64;
+  const int swz = (lane >> 1) & 7;
+  const int a_off = (wm * 128 + l31) * RB;
+  const int w_off = A_BYTES + (wn * WN + l31) * RB;
+  const uint32_t bytes_a = (uint32_t)((long long)p.M * p.lda * 2), bytes_w = (uint32_t)((long long)p.N * p.ldw * 2);
+  int bm = 0, bn = 0;
+  uint32_t vpa0 = 0, vpw0 = 0;   // source offset of piece 0 of the tile's A / W rows (pieces are NW * RPI rows apart: a uniform stride)
+  const uint32_t strA = (uint32_t)((long long)NW * RPI * p.lda * 2), strW = (uint32_t)((long long)NW * RPI * p.ldw * 2);
+  f32x16 acc[4][TN];
+  constexpr int NPARK = W4D_NPARK;  // blocks parked per tile; the other 16 - NPARK are finished at once (register budget: 8 VGPRs per block)
+  uint32_t stash[8 * NPARK];    // FIFO of the previous tile's bf16 results: block b = regs 8b .. 8b+7 = (g, pair) of rows l31
+  uint32_t imm[8];
+  int blk_cur = 0;
+  int st_left = 0;              // blocks of the parked tile not yet stored
+  int st_row = 0, st_col = 0;   // parked tile: first row / column of this WAVE's 128 x 128 part
+  // scratch of the block in flight (kept across the MFMA slots of one K-tile)
+  mrb_f2 dx, dt, dt2, dp;
+
+#define W4D_SYNC asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier();
+#define W4D_FRAG(FA, FB, BASE, KK, I)                                                                                    \
+  {                                                                                                                      \
+    const int coff_ = ((((KK) * 2 + hi) ^ swz) << 4);                                                                    \
+    if ((I) == 0) FA[0] = *reinterpret_cast<const bf16x8*>((BASE) + a_off + coff_);                                      \
+    else if ((I) <= TN) FB[(I) - 1] = *reinterpret_cast<const bf16x8*>((BASE) + w_off + ((I) - 1) * 32 * RB + coff_);    \
+    else FA[(I) - TN] = *reinterpret_cast<const bf16x8*>((BASE) + a_off + ((I) - TN) * 32 * RB + coff_);                 \
+  }
+  // deferred-epilogue step S (0 .. 63) of the block at the head of the FIFO.  Steps 3i / 3i+1 / 3i+2 (i < 8): value pair i
+  // (unpack + clamp | Horner | finish + pack); 24: lane exchange; 25: the two 16-B stores; 26 .. 55: FIFO shift, 4 registers per step.
+#define W4D_STEP_ON(ARR, S, NSH)                                                                                                    \
+  {                                                                                                                      \
+    if ((S) < 24) {                                                                                                      \
+      const int i_ = (S) / 3, ph_ = (S) % 3;                                                                             \
+      if (ACT == 1) {                                                                                                    \
+        if (ph_ == 0) {                                                                                                  \
+          dx[0] = __uint_as_float(ARR[i_] << 16); dx[1] = __uint_as_float(ARR[i_] & 0xffff0000u);                    \
+          dt = dx * 0.70710678118654752440f;                                                                             \
+          dt[0] = __builtin_amdgcn_fmed3f(dt[0], -MRB_ERF_L, MRB_ERF_L); dt[1] = __builtin_amdgcn_fmed3f(dt[1], -MRB_ERF_L, MRB_ERF_L); \
+          dt2 = dt * dt;                                                                                                 \
+        } else if (ph_ == 1) {                                                                                           \
+          MRB_ERF_HORNER(dp, dt2)                                                                                        \
+        } else {                                                                                                         \
+          mrb_f2 r_ = dt * dp;                                                                                           \
+          r_[0] = __builtin_amdgcn_fmed3f(r_[0], -1.0f, 1.0f); r_[1] = __builtin_amdgcn_fmed3f(r_[1], -1.0f, 1.0f);      \
+          const mrb_f2 h_ = dx * 0.5f;                                                                                   \
+          const mrb_f2 y_ = h_ * r_ + h_;                                                                                \
+          ARR[i_] = pack2bf(y_[0], y_[1]);                                                                             \
+        }                                                                                                                \
+      }                                                                                                                  \
+    } else if ((S) == W4D_S_SWAP) {                                                                                        \
+      _Pragma("unroll") for (int gp_ = 0; gp_ < 2; ++gp_)                                                                \
+        _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_) {                                                               \
+          auto r_ = __builtin_amdgcn_permlane32_swap(ARR[(2 * gp_) * 2 + h_], ARR[(2 * gp_ + 1) * 2 + h_], false, false); \
+          ARR[(2 * gp_) * 2 + h_] = r_[0];                                                                                \
+          ARR[(2 * gp_ + 1) * 2 + h_] = r_[1];                                                                            \
+        }                                                                                                                \
+    } else if ((S) == W4D_S_STORE) {                                                                                        \
+      const int blk_ = blk_cur;                           /* (mt, nt) = (blk / 4, blk % 4) */                            \
+      const int row_ = st_row + (blk_ >> 2) * 32 + l31;                                                                  \
+      const int col_ = st_col + (blk_ & 3) * 32 + 8 * hi;                                                                \
+      if (row_ < p.M W4D_STORE_GUARD) {                                                                                  \
+        bf16_t* o_ = reinterpret_cast<bf16_t*>(p.out) + (long long)row_ * p.ldo + col_;                                  \
+        if (col_ < p.N) *reinterpret_cast<uint4*>(o_) = make_uint4(ARR[0], ARR[1], ARR[2], ARR[3]);                          \
+        if (col_ + 16 < p.N) *reinterpret_cast<uint4*>(o_ + 16) = make_uint4(ARR[4], ARR[5], ARR[6], ARR[7]);                \
+      }                                                                                                                  \
+    } else if ((S) >= W4D_S_SHIFT && (NSH) > 0) {                                                                        \
+      _Pragma("unroll") for (int m_ = 0; m_ < W4D_SHIFT_PER; ++m_) {                                                     \
+        const int b_ = ((S) - W4D_S_SHIFT) * W4D_SHIFT_PER + m_;                                                         \
+        if (b_ < 8 * (NPARK - 1)) stash[b_] = stash[b_ + 8];                                                             \
+      }                                                                                                                  \
+    }                                                                                                                    \
+  }
+#define W4D_STEP(S) W4D_STEP_ON(stash, S, 1)
+#define W4D_SLICE(FA, FB, GA, GB, NBASE, NKK, NEXT, DMA_A, DMA_W, DEFER, SL)                                             \
+  _Pragma("unroll") for (int j_ = 0; j_ < NSLOT; ++j_) {                                                                 \
+    if ((DMA_A)) {                                                                                                       \
+      _Pragma("unroll") for (int q_ = 0; q_ < JA; ++q_)                                                                  \
+        if (j_ == q_ * NSLOT / JA)                                                                                       \
+          gemm_dma_piece(smem + (kt & 1) * STAGE + (q_ * NW + w) * (RPI * RB), p.A, bytes_a, vpa0 + (uint32_t)q_ * strA, (uint32_t)(kt + 2) * (uint32_t)RB); \
+    }                                                                                                                    \
+    if ((DMA_W)) {                                                                                                       \
+      _Pragma("unroll") for (int q_ = 0; q_ < JW; ++q_)                                                                  \
+        if (j_ == q_ * NSLOT / JW + 1)                                                                                   \
+          gemm_dma_piece(smem + ((kt + 1) & 1) * STAGE + A_BYTES + (q_ * NW + w) * (RPI * RB), p.W, bytes_w, vpw0 + (uint32_t)q_ * strW, \
+                         (uint32_t)(kt + 1) * (uint32_t)RB);                                                             \
+    }                                                                                                                    \
+    if (NEXT) {                                                                                                          \
+      _Pragma("unroll") for (int f_ = 0; f_ < NFRAG; ++f_)                                                               \
+        if (j_ == f_ * NSLOT / NFRAG) W4D_FRAG(GA, GB, NBASE, NKK, f_)                                                   \
+    }                                                                                                                    \
+    acc[j_ / TN][j_ % TN] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FB[j_ % TN], FA[j_ / TN], acc[j_ / TN][j_ % TN], 0, 0, 0); \
+    if (DEFER) {                                                                                                         \
+      _Pragma("unroll") for (int s_ = 0; s_ < 64; ++s_)                                                                  \
+        if (s_ == (SL) * NSLOT + j_) W4D_STEP(s_)                                                                        \
+    }                                                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                                   \
+  }
+#define W4D_KTILE(DMA, NEXT, DEFER)                                                                                      \
+  {                                                                                                                      \
+    const char* base = smem + (kt & 1) * STAGE;                                                                          \
+    const char* nbase = smem + ((kt + 1) & 1) * STAGE;                                                                   \
+    W4D_SLICE(fa0, fb0, fa1, fb1, base, 1, true, false, NEXT, DEFER, 0)                                                  \
+    W4D_SLICE(fa1, fb1, fa0, fb0, base, 2, true, false, false, DEFER, 1)                                                 \
+    W4D_SLICE(fa0, fb0, fa1, fb1, base, 3, true, false, false, DEFER, 2)                                                 \
+    W4D_SYNC                                                                                                             \
+    W4D_SLICE(fa1, fb1, fa0, fb0, nbase, 0, NEXT, DMA, false, DEFER, 3)                                                  \
+  }
+  // every step of the head block back to back (no MFMAs to hide behind): the tail of a launch, or a K too short for 16 K-tiles
+#define W4D_FLUSH_ONE                                                                                                    \
+  {                                                                                                                      \
+    blk_cur = NPARK - st_left;                                                                                           \
+    _Pragma("unroll") for (int s_ = 0; s_ < 64; ++s_) W4D_STEP(s_)                                                       \
+    --st_left;                                                                                                           \
+  }
+
+  const int ntiles = p.tiles_m * p.tiles_n;
+  const int my_xcd = blockIdx.x & 7;
+  const int my_count = (ntiles - my_xcd + 7) >> 3;
+  int cur = blockIdx.x >> 3;
+#define W4D_OPEN_TILE(T)                                                                                                  \
+  {                                                                                                                      \
+    int bid = (T) * 8 + my_xcd;                                                                                          \
+    const int q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, idx = bid >> 3;                                            \
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;                                                 \
+    constexpr int GROUP_M = 8;                                                                                           \
+    const int per_group = GROUP_M * p.tiles_n;                                                                           \
+    const int gid = bid / per_group;                                                                                     \
+    const int first_m = gid * GROUP_M;                                                                                   \
+    const int gsize = min(p.tiles_m - first_m, GROUP_M);                                                                 \
+    bm = first_m + (bid % per_group) % gsize;                                                                            \
+    bn = (bid % per_group) / gsize;                                                                                      \
+    vpa0 = vA + (uint32_t)((long long)(bm * BM + w * RPI) * p.lda * 2);                                                  \
+    vpw0 = vW + (uint32_t)((long long)(bn * BN + w * RPI) * p.ldw * 2);                                                  \
+    _Pragma("unroll") for (int j = 0; j < JA; ++j) gemm_dma_piece(smem + (j * NW + w) * (RPI * RB), p.A, bytes_a, vpa0 + (uint32_t)j * strA, 0u); \
+    _Pragma("unroll") for (int j = 0; j < JW; ++j) gemm_dma_piece(smem + A_BYTES + (j * NW + w) * (RPI * RB), p.W, bytes_w, vpw0 + (uint32_t)j * strW, 0u); \
+  }
+  if (cur < my_count) W4D_OPEN_TILE(cur)
+  while (cur < my_count) {
+    // accumulators start at the bias of their column (4 consecutive columns per accumulator group): the bias add costs nothing
+#pragma unroll
+    for (int nt = 0; nt < TN; ++nt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int c0 = bn * BN + wn * WN + nt * 32 + 8 * g + 4 * hi;
+        float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.bias && c0 < p.N) b = *reinterpret_cast<const float4*>(p.bias + c0);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          acc[mt][nt][4 * g] = b.x; acc[mt][nt][4 * g + 1] = b.y; acc[mt][nt][4 * g + 2] = b.z; acc[mt][nt][4 * g + 3] = b.w;
+        }
+      }
+    if (nk > 1) {
+#pragma unroll
+      for (int j = 0; j < JA; ++j) gemm_dma_piece(smem + STAGE + (j * NW + w) * (RPI * RB), p.A, bytes_a, vpa0 + (uint32_t)j * strA, (uint32_t)RB);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(JA) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    bf16x8 fa0[4], fb0[TN], fa1[4], fb1[TN];
+#pragma unroll
+    for (int i = 0; i < NFRAG; ++i) W4D_FRAG(fa0, fb0, smem, 0, i)
+    int kt = 0;
+    for (; kt < nk - 2 && st_left > 0; ++kt) {   // K-tiles that also retire one parked block each
+      blk_cur = NPARK - st_left;
+      W4D_KTILE(true, true, true)
+      --st_left;
+    }
+    for (; kt < nk - 2; ++kt) W4D_KTILE(true, true, false)
+    if (kt < nk - 1) {
+      W4D_KTILE(false, true, false)
+      ++kt;
+    }
+    W4D_KTILE(false, false, false)
+    while (st_left > 0) W4D_FLUSH_ONE   // (only when nk - 2 < 16)
+
+    // ---- this tile: park bf16(acc) and move on
+    __syncthreads();  // every wave is done with both stage buffers
+    const int nxt = cur + (int)(gridDim.x >> 3);
+    st_row = bm * BM + wm * 128;
+    st_col = bn * BN + wn * WN;
+    if (nxt < my_count) W4D_OPEN_TILE(nxt)  // the next tile's first K-tile flies while the accumulators are parked
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < TN; ++nt) {
+        if (mt * 4 + nt < NPARK) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            stash[((mt * 4 + nt) * 4 + g) * 2] = pack2bf(acc[mt][nt][4 * g], acc[mt][nt][4 * g + 1]);
+            stash[((mt * 4 + nt) * 4 + g) * 2 + 1] = pack2bf(acc[mt][nt][4 * g + 2], acc[mt][nt][4 * g + 3]);
+          }
+        } else {  // not parked: finished here (the part of the epilogue that stays exposed)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            imm[g * 2] = pack2bf(acc[mt][nt][4 * g], acc[mt][nt][4 * g + 1]);
+            imm[g * 2 + 1] = pack2bf(acc[mt][nt][4 * g + 2], acc[mt][nt][4 * g + 3]);
+          }
+          blk_cur = mt * 4 + nt;
+#pragma unroll
+          for (int s_ = 0; s_ < 64; ++s_) W4D_STEP_ON(imm, s_, 0)
+        }
+      }
+    st_left = NPARK;
+    cur = nxt;
+  }
+  while (st_left > 0) W4D_FLUSH_ONE
+#undef W4D_OPEN_TILE
+#undef W4D_FLUSH_ONE
+#undef W4D_KTILE
+#undef W4D_SLICE
+#undef W4D_STEP
+#undef W4D_STEP_ON
+#undef W4D_FRAG
+#undef W4D_SYNC
+}
+
 // ---- skinny-M kernel (decoder rows, M <= a few 32-row tiles): weight-streaming bound.  One block = 32 output
 // columns x 32 rows; its 4 waves split K, each lane streams 64 contiguous bytes of one W row per 64-wide k block
 // (the contraction order inside a k block is permuted identically for W and X so both load 16-B vectors from full
@@ -982,6 +1238,39 @@ static int gemm_dispatch(const void* A, long long lda, const void* W, long long 
   if (cfg == 12) {  // 256x192, 8 waves of 64x96, one persistent block per CU: N = 1408 (ViT proj / fc2) is 7.3 x 192 -> 488 tiles = 1.9 rounds
     MRB_REQUIRE(!gated, "gemm: cfg 12 has no gated epilogue");
     return out_f32 ? launch_tile<256, 192, 4, 2, true, false>(a, stream) : launch_tile<256, 192, 4, 2, false, false>(a, stream);
+  }
+  if (cfg == 15) {  // cfg 13's tile with the deferred epilogue (bf16 out, bias, optional GELU, no residual): ViT qkv / fc1
+    MRB_REQUIRE(!gated && !Aext && !out2 && !(p_drop > 0.f) && !out_f32 && !residual && (act == 0 || act == 1), "gemm: cfg 15 = bf16 out, bias, optional GELU only");
+    a.tiles_m = (M + 255) / 256;
+    a.tiles_n = (N + 255) / 256;
+    const int LDS = 2 * (256 + 256) * 128;
+    static int ncu15 = 0;
+    if (ncu15 == 0) {
+      int dev = 0;
+      hipDeviceProp_t prop;
+      ncu15 = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+    }
+    const int nt15 = a.tiles_m * a.tiles_n;
+    const int reserve = reserve_arg ? reserve_arg / 8 * 8 : g_cu_reserve;
+    const int cus = ncu15 - reserve > 8 ? ncu15 - reserve : 8;
+    const int grid = nt15 < cus ? (nt15 + 7) / 8 * 8 : cus;
+    static bool attr15[2] = {};
+    if (act == 1) {
+      auto k = gemm_w4d_kernel<1>;
+      if (!attr15[1]) {
+        if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) { mrblip_set_error("gemm: cannot raise dynamic LDS to %d", LDS); return MRBLIP_ELAUNCH; }
+        attr15[1] = true;
+      }
+      hipLaunchKernelGGL(k, dim3(grid), dim3(256), LDS, stream, a);
+    } else {
+      auto k = gemm_w4d_kernel<0>;
+      if (!attr15[0]) {
+        if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) { mrblip_set_error("gemm: cannot raise dynamic LDS to %d", LDS); return MRBLIP_ELAUNCH; }
+        attr15[0] = true;
+      }
+      hipLaunchKernelGGL(k, dim3(grid), dim3(256), LDS, stream, a);
+    }
+    return mrblip_check_launch("gemm_w4d");
   }
   if (cfg == 13 || cfg == 14) {  // four waves of 128 x 128 (cfg 13, 256x256 tile) / 128 x 96 (cfg 14, 256x192), hand-pipelined K loop
     MRB_REQUIRE(!gated && !Aext && !out2 && !(p_drop > 0.f), "gemm: cfg 13 / 14 take plain epilogues only");

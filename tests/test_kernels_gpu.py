@@ -708,3 +708,34 @@ def test_gemm_k_split_skinny_with_preinitialised_output(ops, M, N, K, ks):
     ops.lora_rows(x, acat, u1, K, init_dst=out2, init_src=None)
     ops.lora_dx(x, w, g, acatt, out2, K, residual=None, drop=ldrop, k_splits=ks)
     check("lora_dx k-split M=%d N=%d K=%d ks=%d vs unsplit" % (M, N, K, ks), rel(out2, ref2), 1e-5)
+
+
+@pytest.mark.parametrize("M,N,K", [(700, 520, 320), (513, 1408, 1408), (300, 264, 128), (1200, 1024, 2560), (257, 8, 64), (2000, 776, 1152)])
+def test_gemm_deferred_epilogue_tile(ops, M, N, K):
+    """cfg 15 = cfg 13's tile with the deferred epilogue (results parked as bf16 in VGPRs, activated / stored in the shadow of the NEXT
+    tile's MFMAs, FIFO of 16 blocks).  bias only: cfg 13's result (up to the summation order of the bias).  bias + GELU: the pre-activation is rounded to bf16 before
+    the GELU, so compare with fp32 torch on that rounding (exact restatement) and loosely with the un-rounded GELU."""
+    torch.manual_seed(12)
+    a = bf(torch.randn(M, K, device=dev()))
+    w = bf(torch.randn(N, K, device=dev()) * 0.05)
+    bias = torch.randn(N, device=dev())
+    base = a.float() @ w.float().t() + bias
+    o13 = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev())
+    o15 = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev())
+    ops.gemm(a, w, o13, bias=bias, tile_cfg=13)
+    ops.gemm(a, w, o15, bias=bias, tile_cfg=15)
+    # (cfg 15 starts its accumulators AT the bias, cfg 13 adds it last: same value up to the fp32 summation order, i.e. a rare last-bit
+    # flip of the bf16 result)
+    assert rel(o15.float(), o13.float()) < 2e-4 and rel(o15.float(), base) < 3e-3
+    assert (o15.float() - o13.float()).abs().max() <= 0.0079 * base.abs().max()
+    ops.gemm(a, w, o15, tile_cfg=15)                       # no bias
+    assert rel(o15.float(), a.float() @ w.float().t()) < 3e-3
+    ops.gemm(a, w, o15, bias=bias, act=1, tile_cfg=15)
+    want = torch.nn.functional.gelu(base.bfloat16().float())
+    assert rel(o15.float(), want) < 3e-3 and rel(o15.float(), torch.nn.functional.gelu(base)) < 5e-3
+    with ops.gemm_cu_reserve(64):
+        o2 = torch.empty_like(o15)
+        ops.gemm(a, w, o2, bias=bias, act=1, tile_cfg=15)
+    assert torch.equal(o2, o15)
+    with pytest.raises(ops.MrblipError):
+        ops.gemm(a, w, torch.empty(M, N, device=dev()), bias=bias, tile_cfg=15)     # fp32 out is cfg 13's job
