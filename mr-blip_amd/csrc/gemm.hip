@@ -418,6 +418,9 @@ __device__ __forceinline__ mrb_u32x4 gemm_load_piece(const void* ptr, uint32_t b
   return __builtin_amdgcn_raw_buffer_load_b128(r, voff, koff, 0);
 }
 
+#ifndef W4_GROUP_M
+#define W4_GROUP_M 8
+#endif
 // ---- 256 x (64 TN) x 64 tile, FOUR waves of 128 x (32 TN) (one wave per SIMD, the accumulators in AGPRs), one persistent block per CU.
 // TN = 4: 256x256, half the LDS fragment traffic per MFMA of the 16-wave form (a wave re-uses each 16-B fragment against four tiles
 // of the other operand).  TN = 3: 256x192 for outputs whose 256-wide tiling leaves the last round mostly empty (ViT fc2 / proj,
@@ -528,7 +531,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
     int bid = (T) * 8 + my_xcd;                                                                                          \
     const int q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, idx = bid >> 3;                                            \
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;                                                 \
-    constexpr int GROUP_M = 8;                                                                                           \
+    constexpr int GROUP_M = W4_GROUP_M;                                                                                  \
     const int per_group = GROUP_M * p.tiles_n;                                                                           \
     const int gid = bid / per_group;                                                                                     \
     const int first_m = gid * GROUP_M;                                                                                   \
@@ -828,7 +831,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4d_kernel(const GemmArgs p) {
     int bid = (T) * 8 + my_xcd;                                                                                          \
     const int q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, idx = bid >> 3;                                            \
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;                                                 \
-    constexpr int GROUP_M = 8;                                                                                           \
+    constexpr int GROUP_M = W4_GROUP_M;                                                                                  \
     const int per_group = GROUP_M * p.tiles_n;                                                                           \
     const int gid = bid / per_group;                                                                                     \
     const int first_m = gid * GROUP_M;                                                                                   \
@@ -1460,6 +1463,14 @@ __global__ __launch_bounds__(512) void lora_tn_kernel(const TnArgs2 q) {
   }
 }
 
+// (A VALU form of these products - one lane per Y column, the row's U values as wave-uniform scalar loads, M split over 8 waves and
+// merged through LDS - was built and measured: 130-270 us per launch against 23-30 us here.  With 2-byte loads per lane and 4 waves per
+// CU it keeps ~0.5 MB in flight where the HBM pipe needs ~16 MB; the MFMA form's 16-B row loads win by an order of magnitude.)
+static int launch_tn(const TnArgs2& q, int blocks, hipStream_t stream) {
+  hipLaunchKernelGGL(lora_tn_kernel, dim3(blocks), dim3(512), 0, stream, q);
+  return mrblip_check_launch("lora_tn");
+}
+
 static int tn_fill(TnArgs& a, const void* Y, long long ldy, const void* U, long long ldu, int M, int C, int R, float* const* outs, const int* col0,
                    const int* ncols, const long long* lds, const uint32_t* seed_ptr, uint32_t site, float p_drop) {
   MRB_REQUIRE(M > 0 && C > 0 && R > 0 && R <= 32 && (R % 8) == 0, "lora_tn: bad shape (M=%d C=%d R=%d)", M, C, R);
@@ -1480,8 +1491,7 @@ extern "C" int mrblip_lora_tn(const void* Y, long long ldy, const void* U, long 
   if (int e = tn_fill(q.a, Y, ldy, U, ldu, M, C, R, outs, col0, ncols, lds, seed_ptr, site, p_drop)) return e;
   q.b = q.a;
   q.blocks_a = (C + 31) / 32;
-  hipLaunchKernelGGL(lora_tn_kernel, dim3(q.blocks_a), dim3(512), 0, stream, q);
-  return mrblip_check_launch("lora_tn");
+  return launch_tn(q, q.blocks_a, stream);
 }
 
 // Both LoRA weight gradients of a fused group in ONE launch:
@@ -1495,6 +1505,5 @@ extern "C" int mrblip_lora_grads(const void* dY, long long lddy, const void* U, 
   if (int e = tn_fill(q.a, dY, lddy, U, ldu, M, N, R, dBt, b_col0, b_ncols, b_lds, nullptr, 0, 0.f)) return e;
   if (int e = tn_fill(q.b, X, ldx, G, ldg, M, K, R, dA, nullptr, nullptr, a_lds, seed_ptr, site, p_drop)) return e;
   q.blocks_a = (N + 31) / 32;
-  hipLaunchKernelGGL(lora_tn_kernel, dim3(q.blocks_a + (K + 31) / 32), dim3(512), 0, stream, q);
-  return mrblip_check_launch("lora_grads");
+  return launch_tn(q, q.blocks_a + (K + 31) / 32, stream);
 }
