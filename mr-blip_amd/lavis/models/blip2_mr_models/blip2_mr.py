@@ -197,6 +197,7 @@ class BLIP2_MR(BaseModel):
 
     _staged_next = None  # (host tensor of the next batch's frames, its device copy): see forward()
     generate_cross_cache = True  # project the decoder's cross-attention K/V once per clip (False: per step and beam, for the A/B test)
+    generate_self_cache = True   # self-attention K/V cache: one new position per decoding step (False: re-run the prefix, for the A/B test)
 
     def forward(self, samples):
         """samples: the reference's dict (blip2_mr.py:433-445).  Optional extra key ``next_video``: the NEXT batch's frames (the train
@@ -221,8 +222,9 @@ class BLIP2_MR(BaseModel):
     def generate(self, samples, use_nucleus_sampling=False, num_beams=5, max_length=50, min_length=1, top_p=0.9, repetition_penalty=1.0,
                  length_penalty=1.0, num_captions=1, temperature=1, output_attentions=False):
         """Beam search over the HIP decoder (blip2_mr.py:826-946).  The encoder runs once; the cross-attention K/V of all 24 decoder
-        layers are projected once per clip and shared by every step and every beam (engine.t5_cross_kv); the short decoder prefix
-        (<= max_length tokens x beams) is re-run each step."""
+        layers are projected once per clip and shared by every step and every beam (engine.t5_cross_kv); each step runs ONE new
+        position per beam against a self-attention K/V cache (engine.t5_decode_step).  ``generate_self_cache = False`` re-runs the
+        whole decoder prefix each step instead (kept for the A/B test)."""
         if use_nucleus_sampling:
             raise NotImplementedError("generate: nucleus sampling (do_sample=True, top_p) is not implemented on the MI355X engine; every Mr. BLIP "
                                       "evaluation config decodes with beam search")
@@ -257,11 +259,22 @@ class BLIP2_MR(BaseModel):
             # function re-runs the short decoder prefix on the HIP decoder (weight-streaming bound: <= 64 rows cost what one row costs)
             from mrblip.search import beam_search
 
-            def step_fn(seqs):
-                Ld = seqs.shape[1]
-                _, logits = eng.t5_decoder_forward(seqs, torch.ones(B * K, Ld, dtype=torch.int32), enc_k, B * K, S, mask_k, labels=None,
-                                                   cross_cache=cross, cross_batch=B if cross is not None else None)
-                return torch.log_softmax(logits.view(B * K, Ld, -1)[:, -1].float(), -1).cpu()
+            if cross is not None and self.generate_self_cache and int(max_length) < 128:
+                # incremental decoding (HF use_cache=True): one new position per step against the self-attention K/V cache, which the
+                # search re-orders through `parents` (HF's _reorder_cache)
+                state = eng.t5_decode_begin(B * K, int(max_length) + 1)
+
+                def step_fn(seqs, parents):
+                    logits = eng.t5_decode_step(state, seqs[:, -1], parents, cross, B, mask_k)
+                    return torch.log_softmax(logits.float(), -1).cpu()
+
+                step_fn.takes_parents = True
+            else:
+                def step_fn(seqs):
+                    Ld = seqs.shape[1]
+                    _, logits = eng.t5_decoder_forward(seqs, torch.ones(B * K, Ld, dtype=torch.int32), enc_k, B * K, S, mask_k, labels=None,
+                                                       cross_cache=cross, cross_batch=B if cross is not None else None)
+                    return torch.log_softmax(logits.view(B * K, Ld, -1)[:, -1].float(), -1).cpu()
 
             best = beam_search(step_fn, B, K, int(max_length), min_length=int(min_length), length_penalty=float(length_penalty),
                                eos_id=1, pad_id=0, start_id=0)

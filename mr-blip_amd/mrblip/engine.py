@@ -974,6 +974,71 @@ class MrBlipEngine:
         ops.cross_entropy(logits, lab, 1.0 / max(n_valid, 1), loss, dlog)
         return loss, logits
 
+    # ---- incremental decoding (generate): self-attention K / V cache, one new position per call
+    @torch.no_grad()
+    def t5_decode_begin(self, R: int, max_len: int) -> dict:
+        """State of an incremental decode of R sequences (beams x clips) of at most ``max_len`` positions: the self-attention keys and
+        values of every decoder layer, row-major like the qkv buffer they are cut from: [2 (k, v), layers, R, Lmax, H * d_kv] bf16."""
+        c = self.cfg
+        assert max_len <= 128, "incremental decode: the shifted relative-position LUT covers 128 positions"
+        inner = c.t5_heads * c.d_kv
+        Lmax = ops.rup32(max_len)
+        kv = self.buf("g_self_kv", (2, len(self.t5["dec"]), R, Lmax, inner), bf16)
+        if getattr(self, "lut_dec_pad", None) is None:
+            # the kernels index the bias LUT with clamp(key - query_row, -128, 128) + 128 and the one query of a step is row 0 of ITS
+            # launch but position t of the sequence: a base pointer moved back by t gives lut[(key - t) + 128] (no clamp can trigger
+            # below 128 positions); 128 floats of front padding keep the moved pointer inside the allocation
+            self.lut_dec_pad = torch.cat([torch.zeros(128, dtype=f32, device=self.dev), self.lut_dec.reshape(-1)])
+        return {"kv": kv, "t": 0, "R": R, "Lmax": Lmax}
+
+    @torch.no_grad()
+    def t5_decode_step(self, state: dict, tokens: torch.Tensor, parents: Optional[torch.Tensor], cross_cache, cross_batch: int, kmask):
+        """One decoder position for R sequences: tokens [R] (the newest token of each), parents [R] (row of the previous call each
+        sequence extends; None = unchanged order) -> fp32 logits [R, vocab] of the next token.  modeling_t5.py:747-826 with
+        use_cache=True: the new position's K / V are appended to the cache, the query attends to positions 0..t (nothing to mask: the
+        causal mask of the last row is empty), cross-attention reads the per-clip K / V of t5_cross_kv."""
+        c = self.cfg
+        d, H, dk, ff, V = c.d_model, c.t5_heads, c.d_kv, c.d_ff, c.vocab
+        inner = H * dk
+        R, t, kv, Lmax = state["R"], state["t"], state["kv"], state["Lmax"]
+        assert not self.training and tokens.numel() == R and t < Lmax
+        if parents is not None and t > 0 and not torch.equal(parents, torch.arange(R)):
+            kv[:, :, :, :t] = kv[:, :, :, :t].index_select(2, self.h2d(parents, torch.int64))
+        rows = torch.arange(R, dtype=torch.int32, device=self.dev)
+        x = self.buf("s_x", (R, d), f32, zero=False)
+        ops.row_copy(self.emb, self.h2d(tokens.reshape(-1), torch.int32), x, rows)
+        lut = self.lut_dec_pad[128 - t:]
+        xn = self.buf("s_xn", (R, pad64(d)), bf16)
+        u = {k: self.buf("s_u_" + k, (R, 64), bf16) for k in ("qkv", "o", "cq", "co", "wi", "wo", "lm")}
+        qkv = self.buf("s_qkv", (R, 3 * inner), bf16, zero=False)
+        o = self.buf("s_o", (R, pad64(inner)), bf16)
+        cq = self.buf("s_cq", (R, inner), bf16, zero=False)
+        co = self.buf("s_co", (R, pad64(inner)), bf16)
+        y = self.buf("s_y", (R, pad64(ff)), bf16)
+        xa, xb = self.buf("s_xa", (R, d), f32, zero=False), self.buf("s_xb", (R, d), f32, zero=False)
+        vt = self.buf("s_vt", (R, H, ops.rup32(dk), ops.rup32(t + 1)), bf16)
+        Bc = cross_batch
+        for i, L in enumerate(self.t5["dec"]):
+            self.norm_lg_fwd(x, L["ln0"], L["qkv"], xn, u["qkv"], qkv)
+            kv[:, i, :, t] = qkv[:, inner:].view(R, 2, inner).transpose(0, 1)
+            k4 = torch.as_strided(kv, (R, t + 1, H, dk), (Lmax * inner, inner, dk, 1), kv[0, i].storage_offset())
+            v4 = torch.as_strided(kv, (R, t + 1, H, dk), (Lmax * inner, inner, dk, 1), kv[1, i].storage_offset())
+            ops.head_transpose(v4, out=vt)
+            ops.attention_fwd(self.v4(qkv, R, 1, H, dk, 0), k4, vt, self.v4(o, R, 1, H, dk), None, scale=1.0, bias_lut=lut)
+            self.lg_fwd(L["o"], o, u["o"], xa, residual=x)
+            self.norm_lg_fwd(xa, L["ln1"], L["cq"], xn, u["cq"], cq)
+            ck4, vt_c = cross_cache[i]
+            ops.attention_fwd(self.v4(cq, Bc, R // Bc, H, dk), ck4, vt_c, self.v4(co, Bc, R // Bc, H, dk), None, scale=1.0, kmask=kmask)
+            self.lg_fwd(L["co"], co, u["co"], xb, residual=xa)
+            self.norm_lg_fwd(xb, L["ln2"], L["wi"], xn, u["wi"], y, gated=True, tile_cfg=2)
+            self.lg_fwd(L["wo"], y, u["wo"], x, residual=xb)
+        nf = self.buf("s_nf", (R, pad64(d)), bf16)
+        ops.rmsnorm_fwd(x, self.t5["dec_final"], c.t5_eps, out_bf16=nf)
+        logits = self.buf("s_logits", (R, V), f32, zero=False)
+        self.lg_fwd(self.t5["lm"], nf, u["lm"], logits)
+        state["t"] = t + 1
+        return logits
+
     @torch.no_grad()
     def t5_decoder_backward(self, enc: torch.Tensor, B: int, S: int, Ld: int, kmask: torch.Tensor, dec_mask: torch.Tensor) -> torch.Tensor:
         """Backward from d_dlogits.  Returns fp32 grad of the encoder output [B*S, d]."""

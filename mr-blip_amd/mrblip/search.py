@@ -18,6 +18,9 @@ import torch
 def beam_search(step_fn: Callable[[torch.Tensor], torch.Tensor], batch: int, num_beams: int, max_new_tokens: int, min_length: int = 1,
                 length_penalty: float = 1.0, eos_id: int = 1, pad_id: int = 0, start_id: int = 0) -> List[torch.Tensor]:
     """step_fn(seqs [batch * K, L] int64) -> log-probabilities [batch * K, V] (float32, CPU) of the next token.
+    A step function with a truthy ``takes_parents`` attribute is called as step_fn(seqs, parents): parents [batch * K] int64 names, for
+    every row of ``seqs``, the row of the PREVIOUS call it extends (None on the first call) — what an incremental decoder needs to
+    re-order its self-attention K/V cache (HF's ``_reorder_cache(beam_idx)``).
     Returns one 1-D tensor per batch item: start token, generated tokens, EOS if the hypothesis ended with one."""
     B, K = batch, max(1, int(num_beams))
     seqs = torch.full((B * K, 1), start_id, dtype=torch.long)
@@ -35,9 +38,11 @@ def beam_search(step_fn: Callable[[torch.Tensor], torch.Tensor], batch: int, num
                 pools[b].remove(min(pools[b], key=lambda t: t[0]))
             worst[b] = min(s for s, _ in pools[b])
 
+    takes_parents = bool(getattr(step_fn, "takes_parents", False))
+    parents = None
     for _ in range(max_new_tokens):
         cur_len = seqs.shape[1]                                  # includes the start token
-        lp = step_fn(seqs).float()
+        lp = (step_fn(seqs, parents) if takes_parents else step_fn(seqs)).float()
         V = lp.shape[-1]
         if cur_len < min_length:
             lp[:, eos_id] = -float("inf")
@@ -45,6 +50,7 @@ def beam_search(step_fn: Callable[[torch.Tensor], torch.Tensor], batch: int, num
         top, idx = cand.topk(min(2 * K, K * V), dim=-1)
         new_seqs = torch.full((B * K, cur_len + 1), pad_id, dtype=torch.long)
         new_scores = torch.zeros(B, K)
+        parents = torch.arange(B * K)
         for b in range(B):
             if done[b]:                                          # padded beams with score 0, like HF
                 new_seqs[b * K:(b + 1) * K, :cur_len] = seqs[b * K:(b + 1) * K]
@@ -60,6 +66,7 @@ def beam_search(step_fn: Callable[[torch.Tensor], torch.Tensor], batch: int, num
                 new_seqs[b * K + kept, :cur_len] = seqs[b * K + beam]
                 new_seqs[b * K + kept, cur_len] = tok
                 new_scores[b, kept] = sc
+                parents[b * K + kept] = b * K + beam
                 kept += 1
                 if kept == K:
                     break

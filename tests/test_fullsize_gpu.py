@@ -65,19 +65,19 @@ def test_c1_real_depth_against_reference_and_oracle():
     # split-bf16 verification test (tests/test_verify_fp32_gpu.py) shows the same kernels reach < 1e-3 when fed fp32-accurate operands)
     Tv = 257
     xv = eng.ws["vit_x"].view(4, Tv, 1408)[:, ::8, ::4].cpu()
-    check("c1.vit.out (39 blocks) vs reference-fp32", relerr(xv, g["vit_sub"]), 3e-2)
+    check("c1.vit.out (39 blocks) vs reference-fp32", relerr(xv, g["vit_sub"]), 1.3e-2)
     ln = eng.ws["img"].view(4, Tv, -1)[:, ::8, :1408:4].float().cpu()
-    check("c1.ln_vision vs reference-fp32", relerr(ln, g["ln_sub"]), 3e-2)
+    check("c1.ln_vision vs reference-fp32", relerr(ln, g["ln_sub"]), 1.3e-2)
     qo = eng._qf_last_f32.view(4, 32, 768)[:, :, ::2].cpu()
-    check("c1.qformer.out (12 layers) vs reference-fp32", relerr(qo, g["qf_out"]), 3e-2)
+    check("c1.qformer.out (12 layers) vs reference-fp32", relerr(qo, g["qf_out"]), 1.2e-2)
     emb = eng.ws["inputs_embeds"].view(1, lay.S, 768)[..., ::4].cpu()
-    check("c1.inputs_embeds vs reference-fp32", relerr(emb, g["inputs_embs_sub"]), 3e-2)
+    check("c1.inputs_embeds vs reference-fp32", relerr(emb, g["inputs_embs_sub"]), 1.2e-2)
     enc = eng.ws["e_out"][:, :768].float().view(1, lay.S, 768)[..., ::4].cpu()
-    check("c1.t5.enc_out (12 layers) vs reference-fp32", relerr(enc, g["enc_sub"]), 3e-2)
+    check("c1.t5.enc_out (12 layers) vs reference-fp32", relerr(enc, g["enc_sub"]), 2.5e-2)
     logits = eng.ws["d_logits"].view(1, -1, 32128).cpu()
-    check("c1.logits vs reference-fp32", relerr(logits[..., ::64], g["logits_sub"]), 3e-2)
-    check("c1.logits_lse vs reference-fp32", relerr(torch.logsumexp(logits, -1), g["logits_lse"]), 2e-3)
-    check("c1.loss vs reference-fp32 (rel)", abs(loss.item() - float(g["loss"])) / abs(float(g["loss"])), 2e-3)
+    check("c1.logits vs reference-fp32", relerr(logits[..., ::64], g["logits_sub"]), 2.4e-2)
+    check("c1.logits_lse vs reference-fp32", relerr(torch.logsumexp(logits, -1), g["logits_lse"]), 2e-5)
+    check("c1.loss vs reference-fp32 (rel)", abs(loss.item() - float(g["loss"])) / abs(float(g["loss"])), 1e-3)
     check("c1.grad t5_proj.weight vs reference-fp32 autograd", relerr(eng.dproj_w.cpu()[::4], g["grad__t5_proj__weight"]), 5e-2)
     check("c1.grad t5_proj.bias vs reference-fp32 autograd", relerr(eng.dproj_b.cpu(), g["grad__t5_proj__bias"]), 5e-2)
     check("c1.grad ln_vision.weight vs reference-fp32 autograd", relerr(eng.dlnv_w.cpu(), g["grad__ln_vision__weight"]), 5e-2)
@@ -89,10 +89,10 @@ def test_c1_real_depth_against_reference_and_oracle():
     ref = orc.forward_mr(tok, samples, repl)
     ref["loss"].backward()
     check("c1.logits vs emu-oracle", relerr(logits, ref["logits"].detach()), 1.5e-2)
-    check("c1.loss vs emu-oracle (rel)", abs(loss.item() - ref["loss"].item()) / abs(ref["loss"].item()), 1e-3)
+    check("c1.loss vs emu-oracle (rel)", abs(loss.item() - ref["loss"].item()) / abs(ref["loss"].item()), 3e-4)
     check("c1.t5.enc_out vs emu-oracle", relerr(eng.ws["e_out"][:, :768].float().cpu().view(1, lay.S, 768), ref["enc"].detach()), 1.5e-2)
-    check("c1.grad t5_proj.weight vs emu-oracle autograd", relerr(eng.dproj_w.cpu(), sd["t5_proj.weight"].grad), 4e-2)
-    check("c1.grad ln_vision.weight vs emu-oracle autograd", relerr(eng.dlnv_w.cpu(), sd["ln_vision.weight"].grad), 4e-2)
+    check("c1.grad t5_proj.weight vs emu-oracle autograd", relerr(eng.dproj_w.cpu(), sd["t5_proj.weight"].grad), 3.6e-2)
+    check("c1.grad ln_vision.weight vs emu-oracle autograd", relerr(eng.dlnv_w.cpu(), sd["ln_vision.weight"].grad), 3.6e-2)
 
 
 @pytest.fixture(scope="module")
@@ -138,9 +138,9 @@ def test_c3_batch4_step_equals_four_accumulated_single_clip_steps(xl):
     ls = [eng.forward_backward(video[i:i + 1].contiguous(), lay1, backward=True).item() for i in range(4)]
     g1 = eng.grad.clone() / 4
     assert math.isfinite(l4) and all(math.isfinite(x) for x in ls)
-    check("c3.loss B=4 vs mean of 4 x B=1 (rel)", abs(l4 - sum(ls) / 4) / abs(l4), 2e-4)
-    check("c3.flat-grad B=4 vs 4 accumulated B=1 steps", relerr(g4, g1), 2e-2)
-    check("c3.grad-norm B=4 vs accumulated (rel)", abs(g4.norm().item() - g1.norm().item()) / g1.norm().item(), 5e-3)
+    check("c3.loss B=4 vs mean of 4 x B=1 (rel)", abs(l4 - sum(ls) / 4) / abs(l4), 1e-6)
+    check("c3.flat-grad B=4 vs 4 accumulated B=1 steps", relerr(g4, g1), 5e-6)
+    check("c3.grad-norm B=4 vs accumulated (rel)", abs(g4.norm().item() - g1.norm().item()) / g1.norm().item(), 1e-5)
     assert len(set(round(x, 3) for x in ls)) > 1  # the clips really differ
 
 

@@ -380,10 +380,10 @@ def test_attention_full_size_t5_encoder(ops, H, S, masked):
             num[nm] += (got.float() - want).double().pow(2).sum().item()
             den[nm] += want.double().pow(2).sum().item()
     tag = "attn.t5enc S=%d H=%d %s: " % (S, H, "masked" if masked else "no-mask")
-    check(tag + "o vs fp32 torch", (num["o"] / den["o"]) ** 0.5, 6e-3)
-    check(tag + "dq vs fp32 autograd", (num["dq"] / den["dq"]) ** 0.5, 1.5e-2)
-    check(tag + "dk vs fp32 autograd", (num["dk"] / den["dk"]) ** 0.5, 1.5e-2)
-    check(tag + "dv vs fp32 autograd", (num["dv"] / den["dv"]) ** 0.5, 1.5e-2)
+    check(tag + "o vs fp32 torch", (num["o"] / den["o"]) ** 0.5, 4e-3)
+    check(tag + "dq vs fp32 autograd", (num["dq"] / den["dq"]) ** 0.5, 5.5e-3)
+    check(tag + "dk vs fp32 autograd", (num["dk"] / den["dk"]) ** 0.5, 5.5e-3)
+    check(tag + "dv vs fp32 autograd", (num["dv"] / den["dv"]) ** 0.5, 5.5e-3)
 
 
 def test_attention_strided_qkv_buffer(ops):
@@ -635,7 +635,7 @@ def test_lora_rows_kernel(ops, M, K, R):
         if K % 64 == 0:
             u2 = torch.zeros(M, 64, dtype=torch.bfloat16, device=dev())
             ops.lora_down(xbuf, a, u2, K, drop=drop)
-            check(tag + "vs the MFMA skinny kernel", rel(u[:, :R].float(), u2[:, :R].float()), 4e-3)
+            check(tag + "vs the MFMA skinny kernel", rel(u[:, :R].float(), u2[:, :R].float()), 2e-4)
     if R >= 16 and K % (R // 8) == 0:  # block-diagonal A (the backward's s*B^T of a fused group): segment skipping == dense evaluation
         ng, w = R // 8, K // (R // 8)
         ad = torch.zeros_like(a)
@@ -696,7 +696,7 @@ def test_gemm_k_split_skinny_with_preinitialised_output(ops, M, N, K, ks):
     ops.lora_rows(x, acat, u1, K, drop=ldrop, init_dst=out, init_src=res)
     assert torch.equal(u0, u1)
     ops.gemm(x, w, out, aext=u1, wext=wext, bias=bias, drop=odrop, k_splits=ks)
-    check("gemm k-split M=%d N=%d K=%d ks=%d vs unsplit" % (M, N, K, ks), rel(out, ref), 1e-5)
+    check("gemm k-split M=%d N=%d K=%d ks=%d vs unsplit" % (M, N, K, ks), rel(out, ref), 1e-6)
     # zero initialisation + the LoRA backward form (masked K-extension first)
     g = torch.zeros(M, 64, dtype=torch.bfloat16, device=dev())
     g[:, :16] = bf(torch.randn(M, 16, device=dev()))
@@ -707,7 +707,7 @@ def test_gemm_k_split_skinny_with_preinitialised_output(ops, M, N, K, ks):
     out2 = torch.full((M, N), -3.0, device=dev())
     ops.lora_rows(x, acat, u1, K, init_dst=out2, init_src=None)
     ops.lora_dx(x, w, g, acatt, out2, K, residual=None, drop=ldrop, k_splits=ks)
-    check("lora_dx k-split M=%d N=%d K=%d ks=%d vs unsplit" % (M, N, K, ks), rel(out2, ref2), 1e-5)
+    check("lora_dx k-split M=%d N=%d K=%d ks=%d vs unsplit" % (M, N, K, ks), rel(out2, ref2), 1e-6)
 
 
 @pytest.mark.parametrize("M,N,K", [(700, 520, 320), (513, 1408, 1408), (300, 264, 128), (1200, 1024, 2560), (257, 8, 64), (2000, 776, 1152)])

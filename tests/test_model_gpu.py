@@ -58,14 +58,14 @@ def test_vit_and_qformer_forward():
     img = torch.from_numpy(g["image"])
     x = eng.vit_forward(img.cuda())
     ref = orc.vit(img)
-    check("tiny.vit.out vs emu-oracle", relerr(x.cpu().reshape(ref.shape), ref), 1e-2)
+    check("tiny.vit.out vs emu-oracle", relerr(x.cpu().reshape(ref.shape), ref), 3e-3)
     # against the reference's own fp32 output (weights of this golden are keyed identically)
     sd_v = golden_state_dict(g)
     eng_v = _engine({**sd, **sd_v})
     xv = eng_v.vit_forward(img.cuda())
-    check("tiny.vit.out vs reference-fp32", relerr(xv.cpu().reshape(g["out"].shape), g["out"]), 3e-2)
+    check("tiny.vit.out vs reference-fp32", relerr(xv.cpu().reshape(g["out"].shape), g["out"]), 7e-3)
     x1 = eng_v.vit_forward(img.cuda(), n_blocks=1)
-    check("tiny.vit.block0 vs reference-fp32", relerr(x1.cpu().reshape(g["block0"].shape), g["block0"]), 2e-2)
+    check("tiny.vit.block0 vs reference-fp32", relerr(x1.cpu().reshape(g["block0"].shape), g["block0"]), 6e-3)
     # ---- a8: ln_vision + Q-Former query branch directly against the reference's golden (Qformer.py:804-965).  The golden's Q-Former
     # saw the REFERENCE's fp32 ViT output; feed exactly that (not the HIP ViT's) so the comparison isolates ln_vision + Q-Former.
     from mrblip import ops
@@ -79,11 +79,11 @@ def test_vit_and_qformer_forward():
     check("tiny.ln_vision vs reference-fp32", relerr(imgb[:, :c.vit_dim].float().cpu().reshape(gq["ln_out"].shape), gq["ln_out"]), 4e-3)
     eng_q.qformer_forward(imgb, F_)
     qo = eng_q._qf_last_f32.cpu().reshape(gq["out"].shape)
-    check("tiny.qformer.out vs reference-fp32", relerr(qo, gq["out"]), 3e-2)
+    check("tiny.qformer.out vs reference-fp32", relerr(qo, gq["out"]), 7e-3)
     orc_q = O.Oracle({**sd, **sd_q}, TINY_CFG, emu_bf16=True)
     with torch.no_grad():
         ref_q = orc_q.qformer(orc_q.ln_vision(torch.from_numpy(gq["vit_out"])))
-    check("tiny.qformer.out vs emu-oracle", relerr(qo, ref_q), 1e-2)
+    check("tiny.qformer.out vs emu-oracle", relerr(qo, ref_q), 5e-3)
 
 
 def _samples(g):
@@ -112,12 +112,12 @@ def test_train_step_forward_backward(tag, mean):
     with torch.no_grad():
         ref = orc.forward_mr(tok, samples, repl, mean_pool=mean)
     logits = eng.ws["d_logits"].cpu().reshape(ref["logits"].shape)
-    check(tag + ".inputs_embeds vs emu-oracle", relerr(eng.ws["inputs_embeds"].cpu().reshape(ref["inputs_embs"].shape), ref["inputs_embs"]), 1e-2)
+    check(tag + ".inputs_embeds vs emu-oracle", relerr(eng.ws["inputs_embeds"].cpu().reshape(ref["inputs_embs"].shape), ref["inputs_embs"]), 5.5e-3)
     check(tag + ".enc_out vs emu-oracle", relerr(eng.ws["e_out"].cpu()[:, :64].reshape(ref["enc"].shape), ref["enc"]), 1e-2)
     check(tag + ".logits vs emu-oracle", relerr(logits, ref["logits"]), 1e-2)
-    check(tag + ".loss vs emu-oracle (rel)", abs(loss.item() - ref["loss"].item()) / abs(ref["loss"].item()), 2e-3)
-    check(tag + ".loss vs reference-fp32 (rel)", abs(loss.item() - float(g["loss"])) / abs(float(g["loss"])), 1e-2)   # vs the reference's fp32 run
-    check(tag + ".logits vs reference-fp32", relerr(logits[..., ::64], g["logits_sub"]), 3e-2)
+    check(tag + ".loss vs emu-oracle (rel)", abs(loss.item() - ref["loss"].item()) / abs(ref["loss"].item()), 1.5e-4)
+    check(tag + ".loss vs reference-fp32 (rel)", abs(loss.item() - float(g["loss"])) / abs(float(g["loss"])), 4e-4)   # vs the reference's fp32 run
+    check(tag + ".logits vs reference-fp32", relerr(logits[..., ::64], g["logits_sub"]), 1.4e-2)
     # ---- 2. with LoRA (peft naming), gradients of every trainable tensor against the oracle's autograd
     sdl = _peft_sd(sd)
     for k, v in sdl.items():
@@ -127,7 +127,7 @@ def test_train_step_forward_backward(tag, mean):
     loss = eng.forward_backward(samples["video"].cuda(), lay, backward=True)
     orc = O.Oracle(sdl, TINY_CFG, emu_bf16=True, lora=dict(r=8, alpha=8))
     ref = orc.forward_mr(tok, samples, repl, mean_pool=mean)
-    check(tag + ".lora.loss vs emu-oracle (rel)", abs(loss.item() - ref["loss"].item()) / abs(ref["loss"].item()), 2e-3)
+    check(tag + ".lora.loss vs emu-oracle (rel)", abs(loss.item() - ref["loss"].item()) / abs(ref["loss"].item()), 1.2e-4)
     ref["loss"].backward()
     check(tag + ".grad t5_proj.weight vs emu-oracle autograd", relerr(eng.dproj_w.cpu(), sdl["t5_proj.weight"].grad), 3e-2)
     check(tag + ".grad t5_proj.bias vs emu-oracle autograd", relerr(eng.dproj_b.cpu(), sdl["t5_proj.bias"].grad), 3e-2)
@@ -184,14 +184,14 @@ def test_training_mode_dropout_parity():
     orc = O.Oracle(sdl, TINY_CFG, emu_bf16=True, lora=dict(r=8, alpha=8), dropout=provider)
     ref = orc.forward_mr(tok, samples, repl)
     assert len(used) > 60 and any(k.startswith("lora:") for k in used) and "t5.dec.1.cross.attn" in used
-    check("train-mode.loss vs emu-oracle, same masks (rel)", abs(loss.item() - ref["loss"].item()) / abs(ref["loss"].item()), 3e-3)
+    check("train-mode.loss vs emu-oracle, same masks (rel)", abs(loss.item() - ref["loss"].item()) / abs(ref["loss"].item()), 1e-4)
     # dropout really happened (the eval-mode loss differs)
     eng.training = False
     l_eval = eng.forward_backward(samples["video"].cuda(), lay, backward=False).item()
     assert abs(l_eval - ref["loss"].item()) > 1e-3
     ref["loss"].backward()
-    check("train-mode.grad t5_proj.weight", relerr(eng.dproj_w.cpu(), sdl["t5_proj.weight"].grad), 4e-2)
-    check("train-mode.grad ln_vision.weight", relerr(eng.dlnv_w.cpu(), sdl["ln_vision.weight"].grad), 4e-2)
+    check("train-mode.grad t5_proj.weight", relerr(eng.dproj_w.cpu(), sdl["t5_proj.weight"].grad), 3e-2)
+    check("train-mode.grad ln_vision.weight", relerr(eng.dlnv_w.cpu(), sdl["ln_vision.weight"].grad), 3e-2)
     worst = 0.0
     for a in eng.adapters:
         base = "t5_model.base_model.model." + a.name

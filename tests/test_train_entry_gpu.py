@@ -73,6 +73,56 @@ def test_forward_backward_bridge_and_generate():
     res2 = model.generate(samples, num_beams=2, max_length=6)
     model.generate_cross_cache = True
     assert res2["raw_prediction"] == res["raw_prediction"]
+    # ... and so does the prefix re-run without the self-attention K/V cache
+    model.generate_self_cache = False
+    res3 = model.generate(samples, num_beams=3, max_length=9)
+    model.generate_self_cache = True
+    assert res3["raw_prediction"] == model.generate(samples, num_beams=3, max_length=9)["raw_prediction"]
+
+
+def test_incremental_decode_matches_prefix_rerun():
+    """engine.t5_decode_step (self-attention K/V cache, shifted relative-position LUT, cache re-ordering by `parents`) against the
+    full-prefix decoder forward on the same token sequences: next-token logits of every step, beams permuted between steps."""
+    import lavis  # noqa: F401
+    from lavis.common.registry import registry
+    from lavis.common.config import load_yaml
+    from lavis.datasets import SyntheticMomentRetrievalDataset, collate
+    from mrblip import ops
+    from util import check
+
+    cls = registry.get_model_class("blip2_mr")
+    mcfg = load_yaml(cls.default_config_path("tiny_synthetic")).model
+    mcfg.update(dict(task="qformer_freeze_lora", input_time_format="seconds_integers", interleave_data=True))
+    model = cls.from_config(mcfg).eval()
+    eng = model.engine
+    eng.training = False
+    ds = SyntheticMomentRetrievalDataset(n_items=2, n_frms=4, image_size=56, duration=60.0)
+    samples = collate([ds[0], ds[1]])
+    video = model._frames_to_device(samples["video"])
+    layout = model._layout(dict(samples, relevant_windows=[str(w) for w in samples["relevant_windows"]]))
+    B, S, d, K = 2, layout.S, eng.cfg.d_model, 3
+    fr = eng.frames_forward(video)[0]
+    L = eng._layout_dev(layout)
+    inp = eng.buf("inputs_embeds", (B * S, d), torch.float32, zero=False)
+    ops.row_copy(fr, L["frame_src"], inp, L["frame_dst"])
+    ops.row_copy(eng.emb, L["emb_src"], inp, L["emb_dst"])
+    enc = eng.t5_encoder_forward(inp, B, S, L["mask"])
+    cross = eng.t5_cross_kv(enc, B, S)
+    R, steps = B * K, 7
+    g = torch.Generator().manual_seed(5)
+    state = eng.t5_decode_begin(R, steps + 1)
+    seqs = torch.zeros(R, 1, dtype=torch.long)
+    parents, worst = None, 0.0
+    for t in range(steps):
+        inc = eng.t5_decode_step(state, seqs[:, -1], parents, cross, B, L["mask"]).float().clone()
+        _, full = eng.t5_decoder_forward(seqs, torch.ones(R, t + 1, dtype=torch.int32), enc, R, S, L["mask"], labels=None, cross_cache=cross, cross_batch=B)
+        ref = full.view(R, t + 1, -1)[:, -1].float()
+        worst = max(worst, ((inc - ref).norm() / ref.norm()).item())
+        assert (inc.argmax(-1) == ref.argmax(-1)).all()
+        # next step: every sequence extends a random beam of ITS clip with a random token (what the search does through `parents`)
+        parents = torch.cat([b * K + torch.randint(0, K, (K,), generator=g) for b in range(B)])
+        seqs = torch.cat([seqs[parents], torch.randint(2, eng.cfg.vocab, (R, 1), generator=g)], 1)
+    check("generate.incremental_vs_prefix_logits", worst, 1e-6)   # measured: bit-identical (same kernels, same operands)
 
 
 def test_bench_two_ranks_share_one_gpu():

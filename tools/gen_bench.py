@@ -1,5 +1,5 @@
 """Evaluation-path timing at the QVH shape: encoder once, then beam-search decoding steps (5 beams, growing prefix) with the
-cross-attention K/V cache vs the replicate-per-beam path."""
+cross-attention K/V cache vs the replicate-per-beam path, and one-position steps against the self-attention K/V cache."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "mr-blip_amd")); sys.path.insert(0, ROOT)
@@ -21,7 +21,7 @@ layout = P.build_layout(tok, samples, repl, cfg.num_query, T=wl["T"])
 B, S, d, K, STEPS = 1, layout.S, cfg.d_model, 5, 12
 
 
-def run(cache_on):
+def run(cache_on, self_cache=False):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     fr, img, xv, qb = eng.frames_forward(samples["video"])
     L = eng._layout_dev(layout)
@@ -36,6 +36,13 @@ def run(cache_on):
         enc_k = enc.view(B, S, -1).repeat_interleave(K, 0).reshape(B * K * S, -1).contiguous()
         mask_k = None if L["mask"] is None else L["mask"].repeat_interleave(K, 0).contiguous()
     seqs = torch.zeros(B * K, 1, dtype=torch.long)
+    if self_cache:
+        state = eng.t5_decode_begin(B * K, STEPS + 1)
+        for step in range(STEPS):
+            logits = eng.t5_decode_step(state, seqs[:, -1], None if step == 0 else torch.arange(B * K).flip(0), cross, B, mask_k)
+            seqs = torch.cat([seqs.flip(0) if step else seqs, logits.argmax(-1).cpu()[:, None]], 1)
+        torch.cuda.synchronize(); t2 = time.perf_counter()
+        return (t1 - t0) * 1e3, (t2 - t1) * 1e3
     for step in range(STEPS):
         Ld = seqs.shape[1]
         _, logits = eng.t5_decoder_forward(seqs, torch.ones(B * K, Ld, dtype=torch.int32), enc_k, B * K, S, mask_k, labels=None,
@@ -46,6 +53,6 @@ def run(cache_on):
     return (t1 - t0) * 1e3, (t2 - t1) * 1e3
 
 
-for on in (True, False, True, False):
-    e, dcd = run(on)
-    print(f"cross K/V cache {'on ' if on else 'off'}: encode {e:7.1f} ms, {STEPS} decoding steps x {K} beams {dcd:8.1f} ms, clip {e + dcd:8.1f} ms")
+for on, sc in ((True, True), (True, False), (False, False), (True, True), (True, False), (False, False)):
+    e, dcd = run(on, sc)
+    print(f"self K/V cache {'on ' if sc else 'off'} cross K/V cache {'on ' if on else 'off'}: encode {e:7.1f} ms, {STEPS} decoding steps x {K} beams {dcd:8.1f} ms, clip {e + dcd:8.1f} ms")

@@ -1,7 +1,7 @@
 # which PyTorch-native kernels run inside the step (full names):  bash tools/prof_native.sh
 cd /tmp && export TMPDIR=/tmp
 rm -rf $GRAFT_REPO_ROOT/gpurun_out/prof
-timeout 600 rocprofv3 --kernel-trace -d $GRAFT_REPO_ROOT/gpurun_out/prof -- python $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 2 --no-cpu-baseline > /dev/null 2>&1 < /dev/null
+timeout 600 rocprofv3 --kernel-trace -d $GRAFT_REPO_ROOT/gpurun_out/prof -- python $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-hbm-kernels > $GRAFT_REPO_ROOT/gpurun_out/native_bench.json 2> $GRAFT_REPO_ROOT/gpurun_out/native_bench.err < /dev/null
 cd $GRAFT_REPO_ROOT
 DB=$(find gpurun_out/prof -name "*.db" | head -1)
 python - "$DB" <<'PY'
@@ -13,7 +13,7 @@ if not rows:
     g = next(c for c in ("grid_size_x", "grid_size", "grid_x") if c in cols)
     rows = con.execute(f"select name, {g}, start, end from kernels order by start").fetchall()
 t0, t1 = rows[0][2], rows[-1][3]
-cut = t0 + (t1 - t0) * 0.6   # the last steps only (skip model construction)
+cut = t1 - 3.2 * 80e6   # the last ~3 steps only (80 ms each; skips model construction and the first-step workspace fills)
 agg = collections.defaultdict(lambda: [0, 0.0])
 for n, g, s, e in rows:
     if s < cut or ("at::" not in n and "rocclr" not in n):
