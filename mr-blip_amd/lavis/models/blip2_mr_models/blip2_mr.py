@@ -7,6 +7,7 @@ trainable tensors (LoRA in peft naming, t5_proj, ln_vision).  The frozen backbon
 packed bf16 operands; ``loss.backward()`` hands autograd the gradient the HIP backward already produced.
 """
 import logging
+from collections import OrderedDict
 from typing import Optional
 
 import torch
@@ -50,6 +51,7 @@ class _TrainStep(torch.autograd.Function):
                 raise RuntimeError(f"fused gradient accumulation expects the loss scale {model._fused_scale}, got {got}; "
                                    "call model.end_accumulation() to use arbitrary loss scaling")
             return None, None, None, None, None, None, None
+        model._ensure_named_grads()
         nd = eng.n_decay
         return eng.grad[:nd] * g, eng.grad[nd:] * g, None, None, None, None, None
 
@@ -107,14 +109,72 @@ class BLIP2_MR(BaseModel):
         # ONE flat gradient buffer behind both Parameters (generic mode: autograd accumulates g * engine.grad into it)
         self.flat_grad = torch.zeros_like(self.engine.flat)
         self._fused_scale = None
+        self._named = None                                   # reference-named per-tensor Parameters, built on first use
+        self._flat_version = self.engine.flat._version       # torch-side writes to the trainable buffer bump it (see forward)
         self._bind_grads(self.flat_grad)
         self.post_process = post_process
+
+    # ------------------------------------------------------------------ parameters under the reference's names
+    per_tensor_parameters = True   # named_parameters() / parameters(): reference names (False: the two flat Parameters)
+
+    def _trainable_views(self, buf):
+        """reference parameter name -> view of ``buf``, a flat fp32 buffer laid out like the engine's trainable buffer.  LoRA in peft's
+        naming (blip2_mr.py:182-200 wraps t5_model in a PeftModel): lora_A.default.weight [r, in], lora_B.default.weight [out, r] —
+        the engine stores B transposed, so that one is a transposed (non-contiguous) view."""
+        eng = self.engine
+        base = eng.flat.data_ptr()
+
+        def like(t, transpose=False):
+            off = (t.data_ptr() - base) // 4
+            v = buf[off: off + t.numel()].view(t.shape)
+            return v.t() if transpose else v
+
+        out = OrderedDict()
+        out["ln_vision.weight"], out["ln_vision.bias"] = like(eng.lnv_w), like(eng.lnv_b)
+        for a in eng.adapters:
+            name = "t5_model.base_model.model." + a.name
+            out[name + ".lora_A.default.weight"] = like(a.A)
+            out[name + ".lora_B.default.weight"] = like(a.Bt, True)
+        out["t5_proj.weight"], out["t5_proj.bias"] = like(eng.proj_w), like(eng.proj_b)
+        return out
+
+    def reference_named_parameters(self):
+        """The trainable tensors as individual ``nn.Parameter``s under the reference's ``named_parameters()`` names, ALIASING the flat
+        buffer the engine trains (and their ``.grad`` aliasing the flat gradient): anything that selects parameters by name — the
+        reference's weight-decay grouping (runner_base.py:111-122: ``p.ndim < 2 or "bias" in n or "ln" in n or "bn" in n``), gradient
+        clipping, a stock ``torch.optim`` optimizer — works on the engine's own memory.  forward() notices torch-side updates of the
+        buffer (tensor version counter) and re-derives the bf16 operand copies."""
+        if self._named is None:
+            self._named = OrderedDict((n, nn.Parameter(v)) for n, v in self._trainable_views(self.engine.flat).items())
+            self._rebind_named_grads()
+        return self._named
+
+    def _rebind_named_grads(self):
+        if self._named is not None:
+            for p, g in zip(self._named.values(), self._trainable_views(self.grad_buffer()).values()):
+                p.grad = g
+
+    def _ensure_named_grads(self):
+        """``optimizer.zero_grad(set_to_none=True)`` on the per-tensor Parameters drops their aliases of the flat gradient WITHOUT
+        zeroing it: do what the caller meant (zero the buffer) and re-alias"""
+        if self._named is not None and next(iter(self._named.values())).grad is None:
+            if self._fused_scale is None:
+                self.flat_grad.zero_()
+            self._rebind_named_grads()
+
+    def named_parameters(self, prefix: str = "", recurse: bool = True, remove_duplicate: bool = True):
+        if not self.per_tensor_parameters:
+            yield from super().named_parameters(prefix=prefix, recurse=recurse, remove_duplicate=remove_duplicate)
+            return
+        for n, p in self.reference_named_parameters().items():
+            yield (prefix + "." if prefix else "") + n, p
 
     # ------------------------------------------------------------------ gradients: one flat buffer
     def _bind_grads(self, buf):
         nd = self.engine.n_decay
         self.trainable_decay.grad = buf[:nd]
         self.trainable_no_decay.grad = buf[nd:]
+        self._rebind_named_grads()
 
     def zero_grad(self, set_to_none: bool = False):
         """keeps the flat views (set_to_none would un-alias them)"""
@@ -210,6 +270,13 @@ class BLIP2_MR(BaseModel):
         self._staged_next = None
         layout = self._layout(samples)
         need_grad = torch.is_grad_enabled() and (self.trainable_decay.requires_grad or self.trainable_no_decay.requires_grad)
+        if self.engine.flat._version != self._flat_version:
+            # a torch-side optimizer / load wrote the trainable buffer through one of its aliases (the engine's own AdamW kernel does
+            # not go through torch and re-packs by itself): re-derive the bf16 GEMM operand copies of LoRA A / B and t5_proj
+            self.engine.refresh_trainable()
+            self._flat_version = self.engine.flat._version
+        if need_grad:
+            self._ensure_named_grads()
         nxt = samples.get("next_video") if need_grad else None
         nxt_dev = None
         if nxt is not None:
