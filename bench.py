@@ -334,8 +334,8 @@ def main():
         F_ = min(B * wl["T"], eng.vit_chunk)
         m, n, k = F_ * 257, cfg.vit_mlp, cfg.vit_dim
         traffic = None  # HBM-side bytes per launch of the same kernel from the committed PMC pass (tools/pmc_fc1.sh), QVH B=1 shape only
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_fc1.json")
-        if os.path.exists(pmc) and args.workload == "qvh" and B == 1 and F_ == 60:
+        pmc = next((q for q in (os.path.join(ROOT, "profiles", n) for n in ("r02_pmc_fc1.json", "r01_pmc_fc1.json")) if os.path.exists(q)), None)
+        if pmc and args.workload == "qvh" and B == 1 and F_ == 60:
             traffic = json.load(open(pmc)).get("traffic_bytes_per_launch")
         step_tf = step_tflop_per_clip(cfg, wl["T"], layout.S, layout.labels.shape[1], wl["mean_pool"])  # at the run's actual S / L_dec
         if durs:
