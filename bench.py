@@ -333,10 +333,16 @@ def main():
         durs = [s.elapsed_time(e) * 1e-3 for s, e in probe_events]
         F_ = min(B * wl["T"], eng.vit_chunk)
         m, n, k = F_ * 257, cfg.vit_mlp, cfg.vit_dim
+        traffic_note = None
         traffic = None  # HBM-side bytes per launch of the same kernel from the committed PMC pass (tools/pmc_fc1.sh), QVH B=1 shape only
         pmc = next((q for q in (os.path.join(ROOT, "profiles", n) for n in ("r02_pmc_fc1.json", "r01_pmc_fc1.json")) if os.path.exists(q)), None)
         if pmc and args.workload == "qvh" and B == 1 and F_ == 60:
-            traffic = json.load(open(pmc)).get("traffic_bytes_per_launch")
+            pj = json.load(open(pmc))
+            traffic = pj.get("traffic_bytes_per_launch")
+            traffic = int(traffic) if traffic else None
+            traffic_note = ("bytes per launch at the L2s' memory side (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, %s): writes = algorithmic; reads are "
+                            "L2 misses INCLUDING Infinity-Cache hits - each XCD's 4 MB L2 re-fetches the activation / weight panels its 32 CUs "
+                            "share (algorithmic: %d B)" % (os.path.basename(pmc), pj.get("algorithmic_bytes_per_launch", 0)))
         step_tf = step_tflop_per_clip(cfg, wl["T"], layout.S, layout.labels.shape[1], wl["mean_pool"])  # at the run's actual S / L_dec
         if durs:
             avg = sum(durs) / len(durs)
@@ -344,6 +350,8 @@ def main():
             roof = dict(bound="mfma", achieved=round(ach, 1), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_BF16_TFLOPS, 4),
                         traffic=traffic, kernel="gemm_w4_kernel<bf16 out, bias+GELU> (ViT fc1 %dx%dx%d)" % (m, n, k), launches=len(durs),
                         avg_us=round(avg * 1e6, 1))
+            if traffic_note:
+                roof["traffic_note"] = traffic_note
             if not args.no_lookahead:
                 # the timed launches are the look-ahead's: persistent blocks on (CUs - reserve) CUs, the rest is left to the other stream
                 roof["cus"] = torch.cuda.get_device_properties(dev).multi_processor_count - eng.vit_lookahead_reserve
