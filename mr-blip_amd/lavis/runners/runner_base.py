@@ -120,7 +120,9 @@ class RunnerBase:
     # ---- loops
     def train(self):
         run = self.config.run_cfg
-        best, best_epoch = -1.0, 0
+        best, best_epoch = -1.0, 0   # (the reference starts at 0: a run whose validation score stays 0 saves NO checkpoint and then
+        #                               crashes in its testing phase on the missing checkpoint_best.pth; here the first epoch always counts)
+        epoch = self.start_epoch
         t0 = time.time()
         train_splits = run.get("train_splits", ["train"])
         for epoch in range(self.start_epoch, run.max_epoch):
@@ -148,16 +150,38 @@ class RunnerBase:
                 break
             if is_dist_avail_and_initialized():
                 dist.barrier()
+        # testing phase (runner_base.py:413-415): the test splits, on the best validation checkpoint when there was a validation
+        test_epoch = "best" if run.get("valid_splits") else epoch
+        self.evaluate(cur_epoch=test_epoch, skip_reload=bool(run.get("evaluate", False)))
         logging.info("Training time {:.0f}s".format(time.time() - t0))
 
     def evaluate(self, cur_epoch="best", skip_reload=False):
-        return {s: self.eval_epoch(s, cur_epoch) for s in self.config.run_cfg.get("test_splits", [])}
+        return {s: self.eval_epoch(s, cur_epoch, skip_reload=skip_reload) for s in self.config.run_cfg.get("test_splits", [])}
+
+    def _reload_best_model(self, model):
+        """runner_base.py:602-620: load checkpoint_best.pth; a strict load that fails (only part of the model is saved) falls back to
+        strict=False.  A run whose validation never beat 0 has no such file: the current weights are kept, with a warning."""
+        path = os.path.join(self.output_dir, "checkpoint_best.pth")
+        if not os.path.isfile(path):
+            logging.warning("no %s (validation never produced a best checkpoint): evaluating the current weights", path)
+            return model
+        logging.info("Loading checkpoint from {}.".format(path))
+        ck = torch.load(path, map_location="cpu")
+        try:
+            model.load_state_dict(ck["model"], strict=True)
+        except RuntimeError:
+            logging.warning("Key mismatch when loading checkpoint. This is expected if only part of the model is saved. "
+                            "Trying to load the model with strict=False.")
+            model.load_state_dict(ck["model"], strict=False)
+        return model
 
     @torch.no_grad()
-    def eval_epoch(self, split_name, cur_epoch):
+    def eval_epoch(self, split_name, cur_epoch, skip_reload=False):
         loader = self._loader(split_name, False)
         if loader is None:
             return None
+        if not skip_reload and cur_epoch == "best":
+            self._reload_best_model(self.model)
         self.model.eval()
         results = self.task.evaluation(self.model, loader)
         return self.task.after_evaluation(val_result=results, split_name=split_name, epoch=cur_epoch)

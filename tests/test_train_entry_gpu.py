@@ -29,6 +29,8 @@ def test_train_py_synthetic_tiny(tmp_path):
     assert MrBlipEngine.vit_prefetch_hits > hits0 and MrBlipEngine.vit_prefetch_misses == miss0
     ck = glob.glob(os.path.join(out, "checkpoint_*.pth"))
     assert ck
+    # the testing phase reloaded checkpoint_best.pth and scored the test split with it (runner_base.py:413-415, 602-620)
+    assert os.path.isfile(os.path.join(out, "checkpoint_best.pth")) and os.path.isfile(os.path.join(out, "result", "val_epochbest.json"))
     sd = torch.load(ck[0], map_location="cpu")["model"]
     # trainable tensors only, reference key names (peft naming for LoRA)
     assert "t5_proj.weight" in sd and "ln_vision.bias" in sd
