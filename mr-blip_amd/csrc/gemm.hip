@@ -441,6 +441,32 @@ extern "C" int mrblip_debug_w4_stamps(unsigned long long* host_dst) {
 #else
 #define W4_STAMP(I)
 #endif
+// Where the 1-KB LDS-DMA pieces of a stage are issued.  A stage (K-tile s) may be written from the hand-over slice of K-tile s - 2
+// (phase 3: its buffer was just released by the barrier) through slice 2 of K-tile s - 1 (phases 0, 1, 2), and must have landed at the
+// barrier that ends that slice.  W4_DIST = pieces per phase in the order 3, 0, 1, 2 (the wave's JA A pieces first, then its JW W
+// pieces); inside a slice they are spread evenly over the MFMA slots.  The four waves of the block pass the same slots together and the
+// CU's address unit takes ~16 clocks per piece: 8 pieces per wave in one 16-MFMA slice keep it 100 % busy and every piece queues behind
+// the other waves' (60-185 clocks of issue stall per piece, MI355X_MICROARCH.md), which is why the load is spread.
+#ifndef W4_DIST
+#define W4_DIST 8, 8, 0, 0
+#endif
+__device__ constexpr int w4_dist(int ph_idx) { constexpr int d[4] = {W4_DIST}; return d[ph_idx]; }              // ph_idx: 0 -> phase 3, 1..3 -> phases 0..2
+__device__ constexpr int w4_piece_phidx(int i, int total) {                                                       // scaled to the kernel's piece count
+  const int sum = w4_dist(0) + w4_dist(1) + w4_dist(2) + w4_dist(3);
+  int acc = 0;
+  for (int q = 0; q < 4; ++q) {
+    acc += w4_dist(q);
+    if (i * sum < acc * total) return q;
+  }
+  return 3;
+}
+__device__ constexpr int w4_piece_first(int phidx, int total) { int i = 0; while (i < total && w4_piece_phidx(i, total) != phidx) ++i; return i; }
+__device__ constexpr int w4_piece_count(int phidx, int total) { int n = 0; for (int i = 0; i < total; ++i) n += (w4_piece_phidx(i, total) == phidx); return n; }
+__device__ constexpr int w4_piece_slot(int i, int total, int nslot) {
+  const int q = w4_piece_phidx(i, total), n = w4_piece_count(q, total), j = i - w4_piece_first(q, total);
+  const int off = (q != 0 && 2 * n <= nslot) ? 1 : 0;   // phases 0..2 start one slot late (slot 0 carries the first fragment read)
+  return j * nslot / n + off;
+}
 template <bool OUT_F32, int ACT, bool RES, int TN>
 __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
   constexpr int BM = 256, BN = 64 * TN, WN = BN / 2, RB = 128, NW = 4, RPI = 8;
@@ -487,18 +513,18 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
   // at once would queue up in front of the address unit and stall the MFMA issue behind them): DMA_A = the A pieces of K-tile kt + 2
   // (hand-over slice, into the buffer the barrier just freed), DMA_W = the W pieces of K-tile kt + 1 (first slice of the following
   // K-tile).  sched_barrier pins the order.
-#define W4_SLICE(FA, FB, GA, GB, NBASE, NKK, NEXT, DMA_A, DMA_W)                                                         \
+#define W4_SLICE(FA, FB, GA, GB, NBASE, NKK, NEXT, PHIDX, PACTIVE)                                                        \
   _Pragma("unroll") for (int j_ = 0; j_ < NSLOT; ++j_) {                                                                 \
-    if ((DMA_A) && W4_DO_DMA) {                                                                                          \
-      _Pragma("unroll") for (int q_ = 0; q_ < JA; ++q_)                                                                  \
-        if (j_ == q_ * NSLOT / JA)                                                                                       \
-          gemm_dma_piece(smem + (kt & 1) * STAGE + (q_ * NW + w) * (RPI * RB), p.A, bytes_a, vpa[q_], (uint32_t)(kt + 2) * (uint32_t)RB); \
-    }                                                                                                                    \
-    if ((DMA_W) && W4_DO_DMA) {                                                                                          \
-      _Pragma("unroll") for (int q_ = 0; q_ < JW; ++q_)                                                                  \
-        if (j_ == q_ * NSLOT / JW + 1)                                                                                   \
-          gemm_dma_piece(smem + ((kt + 1) & 1) * STAGE + A_BYTES + (q_ * NW + w) * (RPI * RB), p.W, bytes_w, vpw[q_],    \
-                         (uint32_t)(kt + 1) * (uint32_t)RB);                                                             \
+    if ((PACTIVE) && W4_DO_DMA) {                                                                                        \
+      _Pragma("unroll") for (int i_ = 0; i_ < JA + JW; ++i_)                                                             \
+        if (w4_piece_phidx(i_, JA + JW) == (PHIDX) && j_ == w4_piece_slot(i_, JA + JW, NSLOT)) {                         \
+          const int st_ = (PHIDX) == 0 ? kt + 2 : kt + 1;                                                                \
+          if (i_ < JA)                                                                                                   \
+            gemm_dma_piece(smem + (st_ & 1) * STAGE + (i_ * NW + w) * (RPI * RB), p.A, bytes_a, vpa[i_ < JA ? i_ : 0], (uint32_t)st_ * (uint32_t)RB); \
+          else                                                                                                           \
+            gemm_dma_piece(smem + (st_ & 1) * STAGE + A_BYTES + ((i_ - JA) * NW + w) * (RPI * RB), p.W, bytes_w,         \
+                           vpw[i_ >= JA ? i_ - JA : 0], (uint32_t)st_ * (uint32_t)RB);                                   \
+        }                                                                                                                \
     }                                                                                                                    \
     if (NEXT) {                                                                                                          \
       _Pragma("unroll") for (int f_ = 0; f_ < NFRAG; ++f_)                                                               \
@@ -511,11 +537,11 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
   {                                                                                                                      \
     const char* base = smem + (kt & 1) * STAGE;                                                                          \
     const char* nbase = smem + ((kt + 1) & 1) * STAGE;                                                                   \
-    W4_SLICE(fa0, fb0, fa1, fb1, base, 1, true, false, NEXT)                                                             \
-    W4_SLICE(fa1, fb1, fa0, fb0, base, 2, true, false, false)                                                            \
-    W4_SLICE(fa0, fb0, fa1, fb1, base, 3, true, false, false)                                                            \
+    W4_SLICE(fa0, fb0, fa1, fb1, base, 1, true, 1, NEXT)                                                                 \
+    W4_SLICE(fa1, fb1, fa0, fb0, base, 2, true, 2, NEXT)                                                                 \
+    W4_SLICE(fa0, fb0, fa1, fb1, base, 3, true, 3, NEXT)                                                                 \
     W4_SYNC                                                                                                              \
-    W4_SLICE(fa1, fb1, fa0, fb0, nbase, 0, NEXT, DMA, false)                                                             \
+    W4_SLICE(fa1, fb1, fa0, fb0, nbase, 0, NEXT, 0, DMA)                                                                 \
   }
 
   // Persistent walk: block b works on the tiles b, b + grid, ... ; tile ids congruent mod 8 stay on one XCD (blocks are dealt to the
@@ -564,10 +590,15 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    if (nk > 1) {  // the A pieces of K-tile 1 (its W pieces go out in the first slice of K-tile 0)
+    if (nk > 1) {  // the pieces of K-tile 1 a hand-over slice would have issued (the rest go out in the slices of K-tile 0)
+      constexpr int N3 = w4_piece_count(0, JA + JW);
 #pragma unroll
-      for (int j = 0; j < JA; ++j) gemm_dma_piece(smem + STAGE + (j * NW + w) * (RPI * RB), p.A, bytes_a, vpa[j], (uint32_t)RB);
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(JA) : "memory");
+      for (int i = 0; i < JA + JW; ++i)
+        if (w4_piece_phidx(i, JA + JW) == 0) {
+          if (i < JA) gemm_dma_piece(smem + STAGE + (i * NW + w) * (RPI * RB), p.A, bytes_a, vpa[i < JA ? i : 0], (uint32_t)RB);
+          else gemm_dma_piece(smem + STAGE + A_BYTES + ((i - JA) * NW + w) * (RPI * RB), p.W, bytes_w, vpw[i >= JA ? i - JA : 0], (uint32_t)RB);
+        }
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N3) : "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
