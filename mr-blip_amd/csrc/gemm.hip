@@ -1237,6 +1237,9 @@ static int gemm_dispatch(const void* A, long long lda, const void* W, long long 
     }
     // (a 16-wave K-split changes nothing here: with one lane per operand row these launches are bound by the number of row-gather
     // load instructions one CU's address unit can retire, not by a wave's sequential load rounds)
+    // (measured and dropped for the tall-and-thin LoRA products of the encoder, M = 2012, N <= 32: one block per 32 rows with 16 waves
+    // splitting K - all lanes of every load and dropout hash valid, 4 waves per CU - 10.9 vs 12.4 us at K = 2048 but 38 vs 25 us at
+    // K = 10240, +0.4 ms per step: profiles/r02_skinny_tall16.txt)
     if (out_f32) hipLaunchKernelGGL((gemm_skinny_kernel<true, 4>), grid, dim3(256), 0, stream, a);
     else hipLaunchKernelGGL((gemm_skinny_kernel<false, 4>), grid, dim3(256), 0, stream, a);
     return mrblip_check_launch("gemm_skinny");
