@@ -30,8 +30,10 @@ int mrblip_abi_version(void);
  * tile_cfg bits 0..7 = tile form: 0 auto; 1 = 256x256 / 8 waves; 2 = 128x128 / 4 waves; 3 = skinny-M weight-streaming kernel; 4 = 64x128;
  *   5 = 64x64; 6 = 256x256 / 4 waves (compiler-scheduled); 7 = 256x128 BK=32 3-stage; 8 = 256x256 / 16 waves (persistent); 9 = 128x128 / 8 waves;
  *   10 = 256x128 / 16 waves; 11 = 128x256 / 16 waves; 12 = 256x192 / 8 waves; 13 = 256x256 / 4 waves of 128x128, hand-pipelined K loop
- *   (plain epilogues: the frozen-ViT GEMMs); 14 = the same at 256x192.
- * tile_cfg bits 8..16 = CU reserve of the persistent forms 13 / 14: CUs (a multiple of 8, one per XCD) this launch leaves to other
+ *   (plain epilogues: the frozen-ViT GEMMs); 14 = the same at 256x192; 15 = 13 with the epilogue deferred into the next tile's MFMA
+ *   shadow (bf16 out, bias, optional GELU); 16 = 13's tile on 16x16x32 MFMAs (bit-identical results).  Auto picks among 2-5, 8, 13;
+ *   the others are measured variants kept selectable.
+ * tile_cfg bits 8..16 = CU reserve of the persistent forms 13 - 16: CUs (a multiple of 8, one per XCD) this launch leaves to other
  *   streams (per-call; 0 = the calling thread's default, see mrblip_gemm_set_cu_reserve).
  * tile_cfg bits 17..20 = K split of the skinny form (M <= 32 rows, fp32 out, no residual / out2 / act): that many blocks share an
  *   output tile along K and atomically ADD their partial products (bias once, the output dropout mask on every partial) to `out`,

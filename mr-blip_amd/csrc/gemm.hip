@@ -699,6 +699,180 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
 #undef W4_OPEN_TILE
 }
 
+// ---- the same 256x256x64 tile on v_mfma_f32_16x16x32_bf16 (cfg 16): four waves of 128x128 = 8 x 8 accumulator tiles of 16x16, two k-slices
+// of 32 per K-tile (64 MFMAs of 16 clocks each), 16 fragment reads per slice spread one per 4 MFMAs.  Same LDS image, LDS-DMA fill and
+// persistent tile walk as gemm_w4_kernel; hipBLASLt's asm kernel for this tile is built on this instruction (its main loop: 128 MFMAs,
+// 32 ds_read_b128, 16 buffer_load ... lds per K-tile).  Swapped operands: lane (m = l & 15, g = l >> 4) owns output row m and the four
+// consecutive columns 4 g .. 4 g + 3 of every 16x16 tile.
+template <bool OUT_F32, int ACT, bool RES>
+__global__ __launch_bounds__(256, 1) void gemm_w16_kernel(const GemmArgs p) {
+  constexpr int BM = 256, BN = 256, RB = 128, NW = 4, RPI = 8;
+  constexpr int A_BYTES = BM * RB, W_BYTES = BN * RB, STAGE = A_BYTES + W_BYTES;
+  constexpr int JA = BM / RPI / NW, JW = BN / RPI / NW;  // 8 + 8 LDS-DMA pieces per wave and K-tile
+  constexpr int NSLOT = 64, NFRAG = 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = w >> 1, wn = w & 1;
+  const int l15 = lane & 15, kg = lane >> 4;
+  const int chunk = (lane & 7) ^ ((w * 4 + (lane >> 4)) & 7);
+  const uint32_t vA = (uint32_t)((long long)(lane >> 3) * p.lda * 2) + chunk * 16;
+  const uint32_t vW = (uint32_t)((long long)(lane >> 3) * p.ldw * 2) + chunk * 16;
+  const int nk = p.K / 64;
+  const int swz = l15 >> 1;                                // ((row >> 1) & 7) of row = 16 i + l15
+  const int a_off = (wm * 128 + l15) * RB;
+  const int w_off = A_BYTES + (wn * 128 + l15) * RB;
+  const uint32_t bytes_a = (uint32_t)((long long)p.M * p.lda * 2), bytes_w = (uint32_t)((long long)p.N * p.ldw * 2);
+  int bm = 0, bn = 0;
+  uint32_t vpa[JA], vpw[JW];
+  f32x4 acc[8][8];
+
+  // fragment I of a k-slice in the order the MFMAs first need them: A0, W0 .. W7, A1 .. A7   (k chunk of the lane: 4 KK + kg)
+#define W16_FRAG(FA, FB, BASE, KK, I)                                                                                    \
+  {                                                                                                                      \
+    const int coff_ = ((((KK) * 4 + kg) ^ swz) << 4);                                                                    \
+    if ((I) == 0) FA[0] = *reinterpret_cast<const bf16x8*>((BASE) + a_off + coff_);                                      \
+    else if ((I) <= 8) FB[(I) - 1] = *reinterpret_cast<const bf16x8*>((BASE) + w_off + ((I) - 1) * 16 * RB + coff_);     \
+    else FA[(I) - 8] = *reinterpret_cast<const bf16x8*>((BASE) + a_off + ((I) - 8) * 16 * RB + coff_);                   \
+  }
+  // one k-slice of 64 MFMAs: j = (mt, nt) = (j / 8, j % 8).  PIECES: 0 none, 1 = all sixteen pieces of K-tile kt + 2 (into the buffer the
+  // barrier in front of this slice released), one per four MFMAs
+#define W16_ROW(MT, FA, FB, GA, GB, NBASE, NKK, NEXT, PIECES)                                                             \
+  _Pragma("unroll") for (int nt_ = 0; nt_ < 8; ++nt_) {                                                                  \
+    constexpr int mt_c = (MT);                                                                                           \
+    const int j_ = mt_c * 8 + nt_;                                                                                       \
+    if ((PIECES) && W4_DO_DMA) {                                                                                         \
+      _Pragma("unroll") for (int i_ = 0; i_ < JA + JW; ++i_)                                                             \
+        if (j_ == i_ * NSLOT / (JA + JW)) {                                                                              \
+          if (i_ < JA)                                                                                                   \
+            gemm_dma_piece(smem + (kt & 1) * STAGE + (i_ * NW + w) * (RPI * RB), p.A, bytes_a, vpa[i_ < JA ? i_ : 0], (uint32_t)(kt + 2) * (uint32_t)RB); \
+          else                                                                                                           \
+            gemm_dma_piece(smem + (kt & 1) * STAGE + A_BYTES + ((i_ - JA) * NW + w) * (RPI * RB), p.W, bytes_w,          \
+                           vpw[i_ >= JA ? i_ - JA : 0], (uint32_t)(kt + 2) * (uint32_t)RB);                              \
+        }                                                                                                                \
+    }                                                                                                                    \
+    if (NEXT) {                                                                                                          \
+      _Pragma("unroll") for (int f_ = 0; f_ < NFRAG; ++f_)                                                               \
+        if (j_ == f_ * NSLOT / NFRAG + 1) W16_FRAG(GA, GB, NBASE, NKK, f_)                                               \
+    }                                                                                                                    \
+    acc[mt_c][nt_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB[nt_], FA[mt_c], acc[mt_c][nt_], 0, 0, 0);                \
+    __builtin_amdgcn_sched_barrier(0);                                                                                   \
+  }
+  // (eight explicit rows of eight MFMAs: a single 64-trip loop exceeds the unroller's budget and comes back as a RUN-TIME loop whose
+  // slot tests and fragment indices are dynamic - 7000 basic blocks and the fragments in scratch memory)
+#define W16_SLICE(FA, FB, GA, GB, NBASE, NKK, NEXT, PIECES)                                                              \
+  W16_ROW(0, FA, FB, GA, GB, NBASE, NKK, NEXT, PIECES) W16_ROW(1, FA, FB, GA, GB, NBASE, NKK, NEXT, PIECES)              \
+  W16_ROW(2, FA, FB, GA, GB, NBASE, NKK, NEXT, PIECES) W16_ROW(3, FA, FB, GA, GB, NBASE, NKK, NEXT, PIECES)              \
+  W16_ROW(4, FA, FB, GA, GB, NBASE, NKK, NEXT, PIECES) W16_ROW(5, FA, FB, GA, GB, NBASE, NKK, NEXT, PIECES)              \
+  W16_ROW(6, FA, FB, GA, GB, NBASE, NKK, NEXT, PIECES) W16_ROW(7, FA, FB, GA, GB, NBASE, NKK, NEXT, PIECES)
+#define W16_KTILE(DMA, NEXT)                                                                                             \
+  {                                                                                                                      \
+    const char* base = smem + (kt & 1) * STAGE;                                                                          \
+    const char* nbase = smem + ((kt + 1) & 1) * STAGE;                                                                   \
+    W16_SLICE(fa0, fb0, fa1, fb1, base, 1, true, false)                                                                  \
+    W4_SYNC                                                                                                              \
+    W16_SLICE(fa1, fb1, fa0, fb0, nbase, 0, NEXT, DMA)                                                                   \
+  }
+
+  const int ntiles = p.tiles_m * p.tiles_n;
+  const int my_xcd = blockIdx.x & 7;
+  const int my_count = (ntiles - my_xcd + 7) >> 3;
+  int cur = blockIdx.x >> 3;
+#define W16_OPEN_TILE(T)                                                                                                  \
+  {                                                                                                                      \
+    int bid = (T) * 8 + my_xcd;                                                                                          \
+    const int q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, idx = bid >> 3;                                            \
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;                                                 \
+    constexpr int GROUP_M = W4_GROUP_M;                                                                                  \
+    const int per_group = GROUP_M * p.tiles_n;                                                                           \
+    const int gid = bid / per_group;                                                                                     \
+    const int first_m = gid * GROUP_M;                                                                                   \
+    const int gsize = min(p.tiles_m - first_m, GROUP_M);                                                                 \
+    bm = first_m + (bid % per_group) % gsize;                                                                            \
+    bn = (bid % per_group) / gsize;                                                                                      \
+    _Pragma("unroll") for (int j = 0; j < JA; ++j) vpa[j] = vA + (uint32_t)((long long)(bm * BM + (j * NW + w) * RPI) * p.lda * 2); \
+    _Pragma("unroll") for (int j = 0; j < JW; ++j) vpw[j] = vW + (uint32_t)((long long)(bn * BN + (j * NW + w) * RPI) * p.ldw * 2); \
+    gemm_stage_dma<JA, JW, NW, RPI * RB>(smem, smem + A_BYTES, p.A, bytes_a, p.W, bytes_w, vpa, vpw, w, 0u);             \
+  }
+  if (cur < my_count) W16_OPEN_TILE(cur)
+  while (cur < my_count) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (nk > 1) {  // K-tile 1 goes out before the loop (inside it, K-tile kt + 2 is fetched in the second slice of K-tile kt)
+      gemm_stage_dma_ext<JA, JW, NW, RPI * RB>(smem + STAGE, smem + STAGE + A_BYTES, p.A, bytes_a, p.W, bytes_w, vpa, vpw, w, (uint32_t)RB);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(JA + JW) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    bf16x8 fa0[8], fb0[8], fa1[8], fb1[8];
+#pragma unroll
+    for (int i = 0; i < NFRAG; ++i) W16_FRAG(fa0, fb0, smem, 0, i)
+    int kt = 0;
+    for (; kt < nk - 2; ++kt) W16_KTILE(true, true)
+    if (kt < nk - 1) {
+      W16_KTILE(false, true)
+      ++kt;
+    }
+    W16_KTILE(false, false)
+#undef W16_KTILE
+#undef W16_SLICE
+#undef W16_ROW
+#undef W16_FRAG
+
+    // ---- epilogue (first form): straight from the accumulators, 4 consecutive columns per lane and tile; branch-free: rows / columns
+    // outside the matrix get an out-of-range buffer offset, which the bounds-checked loads / stores drop
+    __syncthreads();
+    const int nxt = cur + (int)(gridDim.x >> 3);
+    const int bm_e = bm, bn_e = bn;
+    if (nxt < my_count) W16_OPEN_TILE(nxt)
+    {
+      const uint32_t esz = OUT_F32 ? 4u : 2u;
+      const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)((long long)p.M * p.ldo * esz), 0x00020000);
+      const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(RES ? p.residual : p.bias), 0,
+                                                                          RES ? (int)((long long)p.M * p.ldr * 4) : 16, 0x00020000);
+      const int m_base = bm_e * BM + wm * 128 + l15;
+      const int n_base = bn_e * BN + wn * 128 + 4 * kg;
+#pragma unroll
+      for (int nt = 0; nt < 8; ++nt) {
+        const int n0 = n_base + nt * 16;
+        const bool n_ok = n0 < p.N;
+        float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.bias) b4 = *reinterpret_cast<const float4*>(p.bias + (n_ok ? n0 : 0));
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) {
+          const int m = m_base + mt * 16;
+          const bool ok = n_ok && m < p.M;
+          float v0 = acc[mt][nt][0] + b4.x, v1 = acc[mt][nt][1] + b4.y, v2 = acc[mt][nt][2] + b4.z, v3 = acc[mt][nt][3] + b4.w;
+          if (ACT == 1) {
+            gelu_erf2(v0, v1);
+            gelu_erf2(v2, v3);
+          }
+          if (RES) {
+            const uint32_t roff = ok ? (uint32_t)(((long long)m * p.ldr + n0) * 4) : 0xfffffff0u;
+            const mrb_u32x4 r4 = __builtin_amdgcn_raw_buffer_load_b128(rr, roff, 0, 0);
+            v0 += __uint_as_float(r4[0]); v1 += __uint_as_float(r4[1]); v2 += __uint_as_float(r4[2]); v3 += __uint_as_float(r4[3]);
+          }
+          const uint32_t ooff = ok ? (uint32_t)(((long long)m * p.ldo + n0) * esz) : 0xfffffff0u;
+          if (OUT_F32) {
+            mrb_u32x4 o4 = {__float_as_uint(v0), __float_as_uint(v1), __float_as_uint(v2), __float_as_uint(v3)};
+            __builtin_amdgcn_raw_buffer_store_b128(o4, ro, ooff, 0, 0);
+          } else {
+            typedef uint32_t mrb_u32x2 __attribute__((ext_vector_type(2)));
+            mrb_u32x2 o2 = {pack2bf(v0, v1), pack2bf(v2, v3)};
+            __builtin_amdgcn_raw_buffer_store_b64(o2, ro, ooff, 0, 0);
+          }
+        }
+      }
+    }
+    __syncthreads();
+    cur = nxt;
+  }
+#undef W16_OPEN_TILE
+}
+
 // ---- the same 256 x 256 x 64 four-wave tile with a DEFERRED epilogue (bf16 output, bias, optional exact-erf GELU: ViT qkv / fc1).
 // tools/w4_stamps.py showed where gemm_w4_kernel's time goes: 6 us (bias) to 15.5 us (bias + GELU) of every 40-57 us tile are an
 // epilogue during which the MFMA pipe idles — with one wave per SIMD nothing else can run.  Here a finished tile leaves the
@@ -1308,6 +1482,49 @@ static int gemm_dispatch(const void* A, long long lda, const void* W, long long 
       hipLaunchKernelGGL(k, dim3(grid), dim3(256), LDS, stream, a);
     }
     return mrblip_check_launch("gemm_w4d");
+  }
+  if (cfg == 16) {  // cfg 13's tile on 16x16x32 MFMAs
+    MRB_REQUIRE(!gated && !Aext && !out2 && !(p_drop > 0.f) && (act == 0 || act == 1), "gemm: cfg 16 takes plain epilogues only");
+    a.tiles_m = (M + 255) / 256;
+    a.tiles_n = (N + 255) / 256;
+    const int LDS = 2 * (256 + 256) * 128;
+    static int ncu16 = 0;
+    if (ncu16 == 0) {
+      int dev = 0;
+      hipDeviceProp_t prop;
+      ncu16 = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+    }
+    const int nt16 = a.tiles_m * a.tiles_n;
+    const int reserve = reserve_arg ? reserve_arg / 8 * 8 : g_cu_reserve;
+    const int cus = ncu16 - reserve > 8 ? ncu16 - reserve : 8;
+    const int grid = nt16 < cus ? (nt16 + 7) / 8 * 8 : cus;
+    const int variant = (out_f32 ? 4 : 0) | (act == 1 ? 2 : 0) | (residual ? 1 : 0);
+    static bool attr_set16[8] = {};
+#define MRB_W16_LAUNCH(V, F32, ACT_, RES_)                                                                                         \
+  case V: {                                                                                                                        \
+    auto k = gemm_w16_kernel<F32, ACT_, RES_>;                                                                                     \
+    if (!attr_set16[V]) {                                                                                                          \
+      if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {                    \
+        mrblip_set_error("gemm: cannot raise dynamic LDS to %d", LDS);                                                             \
+        return MRBLIP_ELAUNCH;                                                                                                     \
+      }                                                                                                                            \
+      attr_set16[V] = true;                                                                                                        \
+    }                                                                                                                              \
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), LDS, stream, a);                                                                  \
+    break;                                                                                                                         \
+  }
+    switch (variant) {
+      MRB_W16_LAUNCH(0, false, 0, false)
+      MRB_W16_LAUNCH(1, false, 0, true)
+      MRB_W16_LAUNCH(2, false, 1, false)
+      MRB_W16_LAUNCH(3, false, 1, true)
+      MRB_W16_LAUNCH(4, true, 0, false)
+      MRB_W16_LAUNCH(5, true, 0, true)
+      MRB_W16_LAUNCH(6, true, 1, false)
+      MRB_W16_LAUNCH(7, true, 1, true)
+    }
+#undef MRB_W16_LAUNCH
+    return mrblip_check_launch("gemm_w16");
   }
   if (cfg == 13 || cfg == 14) {  // four waves of 128 x 128 (cfg 13, 256x256 tile) / 128 x 96 (cfg 14, 256x192), hand-pipelined K loop
     MRB_REQUIRE(!gated && !Aext && !out2 && !(p_drop > 0.f), "gemm: cfg 13 / 14 take plain epilogues only");

@@ -739,3 +739,27 @@ def test_gemm_deferred_epilogue_tile(ops, M, N, K):
     assert torch.equal(o2, o15)
     with pytest.raises(ops.MrblipError):
         ops.gemm(a, w, torch.empty(M, N, device=dev()), bias=bias, tile_cfg=15)     # fp32 out is cfg 13's job
+
+
+@pytest.mark.parametrize("M,N,K", [(700, 520, 320), (513, 1408, 1408), (300, 264, 128), (1200, 1024, 2560), (257, 8, 64), (2000, 776, 1152)])
+def test_gemm_16x16x32_tile(ops, M, N, K):
+    """cfg 16 = cfg 13's 256x256x64 tile on v_mfma_f32_16x16x32_bf16 (64 accumulator tiles of 16x16 per wave): the same products in the
+    same k order, so every epilogue form equals cfg 13 bit for bit — ragged M / N, bias, GELU, fp32 residual, CU reserve."""
+    torch.manual_seed(13)
+    a = bf(torch.randn(M, K, device=dev()))
+    w = bf(torch.randn(N, K, device=dev()) * 0.05)
+    bias = torch.randn(N, device=dev())
+    res = torch.randn(M, N, device=dev())
+    for kw, dt in ((dict(bias=bias), torch.bfloat16), (dict(), torch.bfloat16), (dict(bias=bias, act=1), torch.bfloat16),
+                   (dict(bias=bias, residual=res), torch.float32), (dict(residual=res), torch.float32), (dict(bias=bias), torch.float32)):
+        o13 = torch.full((M, N), float("nan"), dtype=dt, device=dev())
+        o16 = torch.full((M, N), float("nan"), dtype=dt, device=dev())
+        ops.gemm(a, w, o13, tile_cfg=13, **kw)
+        ops.gemm(a, w, o16, tile_cfg=16, **kw)
+        assert torch.equal(o13, o16), kw.keys()
+    with ops.gemm_cu_reserve(64):
+        o2 = torch.empty(M, N, dtype=torch.bfloat16, device=dev())
+        ops.gemm(a, w, o2, bias=bias, act=1, tile_cfg=16)
+    o13b = torch.empty(M, N, dtype=torch.bfloat16, device=dev())
+    ops.gemm(a, w, o13b, bias=bias, act=1, tile_cfg=13)
+    assert torch.equal(o2, o13b)
