@@ -1,7 +1,10 @@
 """MrBlipEngine — the MI355X-native train step of Mr. BLIP / Chrono: ViT-g frame encoding -> ln_vision -> Q-Former ->
 t5_proj (-> 32->1 mean pool) -> frame/timestamp interleave -> Flan-T5 encoder/decoder with LoRA -> CE loss, and the
 hand-written backward (dX through T5, t5_proj, Q-Former; dW for LoRA A/B, t5_proj, ln_vision), all as launches of
-the gfx950 kernels in libmrblip_hip.so on ONE stream with static workspaces (hipGraph-capturable).
+the gfx950 kernels in libmrblip_hip.so over static workspaces: the dependency chain on the caller's stream, the next clip's frozen-ViT
+forward on a look-ahead stream, weight-gradient / transposition work on a gradient side stream.  (Nothing synchronises or allocates
+after the first step, so the chain could be captured in a hipGraph — measured to buy nothing: the pre-queued eager stream already runs
+dependent launches 2.3 us apart, tools/graph_gap_probe.py.)
 
 Follows the behaviour of ``BLIP2_MR.forward_mr`` (blip2_mr.py:433-570) and the modules it calls (eva_vit.py:324-340,
 Qformer.py:804-965, modeling_t5.py:1734-1893, peft LoRA r=8).  Residual streams are fp32, GEMM/attention operands bf16,
