@@ -385,6 +385,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(full_c2=args.cpu_baseline_c2)
         print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()   # leave together: rank 0 still ran its untimed exclusive-ViT pass and printed the line
         dist.destroy_process_group()
 
 
