@@ -158,6 +158,15 @@ def cpu_baseline(budget_s=25.0, full_c2=False):
         r2 = run(EngineConfig(), 60, 150.0, 1, 1e9)
         out["c2"] = r2
         out["c2"]["note"] = "ONE whole QVH clip step (T=60, Flan-T5-XL dims), no warm-up"
+    else:
+        # not live: the one-off --cpu-baseline-c2 run committed with the round's profiles (a whole QVH clip step of the oracle on a
+        # GPU box's host: minutes), shown beside the live C1 sample so the scale-up by FLOPs can be judged
+        ref = os.path.join(ROOT, "profiles", "r02_cpu_baseline_c2.json")
+        if os.path.exists(ref):
+            c2 = json.load(open(ref)).get("c2")
+            if c2:
+                out["c2_committed_run"] = dict(clips_per_s=round(c2["clips_per_s"], 5), fwd_s=c2["fwd_s"], bwd_s=c2["bwd_s"],
+                                               source="profiles/r02_cpu_baseline_c2.json (python bench.py --cpu-baseline-c2, earlier box, not this run)")
     return out
 
 
