@@ -324,8 +324,11 @@ __device__ __forceinline__ void attn_stage_dma(char* dstA, char* dstB, const voi
   for (int j = 0; j < CNT_B; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (attn_lds_ptr_t)(dstB + (j * 256 + w * 64) * 16), 16, vB[j], sB, 0, 0);
 }
 
+#ifndef ATTN96_BLOCKS
+#define ATTN96_BLOCKS 2   // resident blocks per CU the ViT form (DP = 96) is compiled for (3 = 168 VGPRs with 36 spilled dwords: measured, see DESIGN)
+#endif
 template <int DP, int FLAGS>
-__global__ __launch_bounds__(256, 2) void attn_fwd_lds_kernel(const AttnArgs p) {
+__global__ __launch_bounds__(256, (DP == 96 ? ATTN96_BLOCKS : 2)) void attn_fwd_lds_kernel(const AttnArgs p) {
   constexpr int KS = DP / 16, MT = DP / 32;
   constexpr bool LUT = FLAGS & F_LUT, MASK = FLAGS & F_MASK, DROP = FLAGS & F_DROP, DBITS = FLAGS & F_DBITS;
   constexpr int KROW = DP * 2, KCPR = DP / 8;                 // K row bytes, 16-B chunks per K row

@@ -20,6 +20,8 @@ for name, B, H, Sq, Sk, D, lut_on, drop_on, causal in [
     ("t5enc_nodrop", 1, 32, 2012, 2012, 64, True, False, False),
     ("t5enc_plain", 1, 32, 2012, 2012, 64, False, False, False), ("vit", 60, 16, 257, 257, 88, False, False, False),
     ("qf_cross", 60, 12, 32, 257, 64, False, True, False), ("dec_cross", 1, 32, 8, 2012, 64, False, True, False)]:
+    if os.environ.get("ATTN_ONLY") and name not in os.environ["ATTN_ONLY"].split(","):
+        continue
     kmask = None
     if name in ("t5enc_masked", "dec_cross"):
         kmask = torch.zeros(B, ops.rup32(Sk), dtype=torch.int32, device=dev); kmask[:, :Sk] = 1
