@@ -37,6 +37,13 @@ def test_train_py_synthetic_tiny(tmp_path):
     assert "t5_model.base_model.model.encoder.block.0.layer.0.SelfAttention.q.lora_A.default.weight" in sd
     assert sd["t5_model.base_model.model.lm_head.lora_B.default.weight"].shape == (32128, 8)
     assert not any(k.startswith("visual_encoder") or k.startswith("Qformer") for k in sd)
+    # evaluate.py's path (evaluate.py:65-119): same config + the fine-tuned checkpoint -> RunnerBase.evaluate(skip_reload=True) over the
+    # test splits: metrics of the reference's evaluator, one result file per split
+    best = os.path.join(out, "checkpoint_best.pth")
+    logs = train.main(["--cfg-path", cfg, "--options", f"run.output_dir={tmp_path}/eval", "run.evaluate=True", "model.load_finetuned=True",
+                       f"model.finetuned={best}"], evaluate=True)
+    assert set(logs) == {"val"} and {"agg_metrics", "r1", "mAP", "mIoU", "invalid_predictions", "total"} <= set(logs["val"])
+    assert logs["val"]["total"] == 2
 
 
 def test_forward_backward_bridge_and_generate():
