@@ -69,6 +69,12 @@ int mrblip_attention_fwd(const void* Q, const long long* q_strides, const void* 
                          void* O, const long long* o_strides, float* LSE, int B, int H, int Sq, int Sk, int D, float scale,
                          const float* bias_lut, const int* kmask, int causal, const uint32_t* seed_ptr, uint32_t site,
                          float p_drop, uint32_t* drop_bits, mrblip_stream_t stream);
+/* The plain (frozen-ViT) forward with V read ROW-major, straight from the fused qkv projection output — no transposed copy of V
+ * (the V^T fragments are gathered from the row-major LDS image with ds_read_b64_tr_b16).  head_dim in (64, 96], Sq > 32, no bias /
+ * mask / dropout.  eva_vit.py:128-145 (Attention.forward: q, k, v = qkv[0], qkv[1], qkv[2]; softmax(q k^T * scale) v). */
+int mrblip_attention_fwd_rowv(const void* Q, const long long* q_strides, const void* K, const long long* k_strides, const void* V,
+                              const long long* v_strides, void* O, const long long* o_strides, float* LSE, int B, int H, int Sq, int Sk,
+                              int D, float scale, mrblip_stream_t stream);
 int mrblip_attention_bwd(const void* Q, const long long* q_strides, const void* K, const long long* k_strides, const void* V,
                          const long long* v_strides, const void* O, const long long* o_strides, const void* dO,
                          const long long* do_strides, const void* Kt, const void* Qt, const void* dOt, const float* LSE,

@@ -41,7 +41,7 @@ struct AttnArgs {
                        // written by the LDS forward kernel and read back by the LDS backward kernels instead of re-hashing
 };
 
-enum { F_LUT = 1, F_MASK = 2, F_CAUSAL = 4, F_DROP = 8, F_SPLIT = 16, F_DBITS = 32 };
+enum { F_LUT = 1, F_MASK = 2, F_CAUSAL = 4, F_DROP = 8, F_SPLIT = 16, F_DBITS = 32, F_VROW = 64 };
 
 // attention-probability dropout draws: one 32-bit hash per (row, key pair): index = row * ceil(Sk/2) + key/2, the low 16 bits
 // serve the even key and the high 16 bits the odd key -> 8 hashes per 16 scores where a lane owns consecutive keys.
@@ -331,9 +331,12 @@ template <int DP, int FLAGS>
 __global__ __launch_bounds__(256, (DP == 96 ? ATTN96_BLOCKS : 2)) void attn_fwd_lds_kernel(const AttnArgs p) {
   constexpr int KS = DP / 16, MT = DP / 32;
   constexpr bool LUT = FLAGS & F_LUT, MASK = FLAGS & F_MASK, DROP = FLAGS & F_DROP, DBITS = FLAGS & F_DBITS;
+  // VROW: V is staged ROW-major straight from the projection output (like K) and the V^T fragments of the second product are
+  // gathered with the LDS transpose read (ds_read_b64_tr_b16, two per 32 x 16 fragment): no transposed copy of V in HBM
+  constexpr bool VROW = FLAGS & F_VROW;
   constexpr int KROW = DP * 2, KCPR = DP / 8;                 // K row bytes, 16-B chunks per K row
   constexpr int K_BYTES = 64 * KROW, V_BYTES = DP * 128, STAGE = K_BYTES + V_BYTES;
-  constexpr int NJK = 64 * KCPR / 256, NJV = DP * 8 / 256;    // DMA instructions per thread per stage
+  constexpr int NJK = 64 * KCPR / 256, NJV = DP * 8 / 256;    // DMA instructions per thread per stage (VROW: 64 rows x KCPR chunks = the same count)
   // everything lives in the dynamic region (a static array in front of it would shift its base off 16-B alignment)
   extern __shared__ __attribute__((aligned(16))) char sm[];  // 2 * STAGE bytes + 257-float bias LUT
   float* lut = reinterpret_cast<float*>(sm + 2 * STAGE);
@@ -363,9 +366,10 @@ __global__ __launch_bounds__(256, (DP == 96 ? ATTN96_BLOCKS : 2)) void attn_fwd_
   // ---- staging: buffer resources span from this head's first element to the end of the tensor (reads past the head's rows stay
   // inside the tensor or return 0; whatever they return is finite and meets P == 0 / zero-padded Q)
   const bf16_t* kbase = p.K.ptr + b * p.K.bs + h * p.K.hs;
-  const bf16_t* vtbase = p.Vt.ptr + b * p.Vt.bs + h * p.Vt.hs;
+  const bf16_t* vtbase = VROW ? p.V.ptr + b * p.V.bs + h * p.V.hs : p.Vt.ptr + b * p.Vt.bs + h * p.Vt.hs;
   const long long k_rem = ((long long)(p.B - 1 - b) * p.K.bs + (long long)(p.H - 1 - h) * p.K.hs + (long long)(p.Sk - 1) * p.K.rs + p.D) * 2;
-  const long long v_rem = ((long long)(p.B - 1 - b) * p.Vt.bs + (long long)(p.H - h) * p.Vt.hs) * 2;
+  const long long v_rem = VROW ? ((long long)(p.B - 1 - b) * p.V.bs + (long long)(p.H - 1 - h) * p.V.hs + (long long)(p.Sk - 1) * p.V.rs + p.D) * 2
+                               : ((long long)(p.B - 1 - b) * p.Vt.bs + (long long)(p.H - h) * p.Vt.hs) * 2;
   const uint32_t k_bytes = (uint32_t)(k_rem > 0xffffffffLL ? 0xffffffffLL : k_rem), v_bytes = (uint32_t)(v_rem > 0xffffffffLL ? 0xffffffffLL : v_rem);
   auto ksw = [](int row) { return DP == 64 ? ((row >> 1) & 7) : ((row >> 2) & 3); };
   uint32_t vK[NJK], vV[NJV];
@@ -377,12 +381,18 @@ __global__ __launch_bounds__(256, (DP == 96 ? ATTN96_BLOCKS : 2)) void attn_fwd_
 #pragma unroll
   for (int j = 0; j < NJV; ++j) {
     const int g = j * 256 + tid, d = g >> 3, c = g & 7;
-    vV[j] = (uint32_t)((long long)d * p.Vt.ds * 2) + (uint32_t)((c ^ ((d >> 1) & 7)) * 16);
+    if (VROW) vV[j] = (uint32_t)((long long)(g / KCPR) * p.V.rs * 2) + (uint32_t)((g % KCPR) * 16);   // row-major image, no swizzle (see vtr)
+    else vV[j] = (uint32_t)((long long)d * p.Vt.ds * 2) + (uint32_t)((c ^ ((d >> 1) & 7)) * 16);
   }
   auto stage = [&](int st, int buf) {
     attn_stage_dma<NJK, NJV>(sm + buf * STAGE, sm + buf * STAGE + K_BYTES, kbase, k_bytes, vtbase, v_bytes, vK, vV, w, (uint32_t)((long long)st * 64 * p.K.rs * 2),
-                             (uint32_t)(st * 128));
+                             VROW ? (uint32_t)((long long)st * 64 * p.V.rs * 2) : (uint32_t)(st * 128));
   };
+  // VROW fragment gather: each 16-lane group reads a [4 keys][16 d] block, lane i supplying the address of 4 contiguous d of key i / 4;
+  // the hardware hands lane c the 4 keys of column c (tools/probes/tr_probe.hip checks exactly this map).  Lane (d = 32 mt + l31, hi)
+  // needs keys 32 sub + 16 hf + 8 hi + 0..7: two reads 4 rows apart, the (sub, hf, mt) part is an immediate offset.  With 192-B rows
+  // (head_dim 88 -> 96) the four rows of a block start 48 banks apart: conflict-free without a swizzle.
+  const int vtr = K_BYTES + (8 * hi + ((lane & 15) >> 2)) * KROW + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
 
   // fragment addresses inside a stage (bytes)
   const int krow = perm23(l31);
@@ -463,8 +473,19 @@ __global__ __launch_bounds__(256, (DP == 96 ? ATTN96_BLOCKS : 2)) void attn_fwd_
     const bf16x8 pf0 = pack8(pv), pf1 = pack8(pv + 8);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-      o[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(base + v_off[mt][sub][0]), pf0, o[mt], 0, 0, 0);
-      o[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(base + v_off[mt][sub][1]), pf1, o[mt], 0, 0, 0);
+      if (VROW) {
+        typedef short v4s_t __attribute__((ext_vector_type(4)));
+        typedef __attribute__((address_space(3))) v4s_t* tr_ptr_t;
+        const char* vb = base + vtr + (32 * sub) * KROW + mt * 64;
+        const v4s_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr_t)(vb)), a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr_t)(vb + 4 * KROW));
+        const v4s_t b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr_t)(vb + 16 * KROW)), b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr_t)(vb + 20 * KROW));
+        const bf16x8 vf0 = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]}, vf1 = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+        o[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf0, pf0, o[mt], 0, 0, 0);
+        o[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf1, pf1, o[mt], 0, 0, 0);
+      } else {
+        o[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(base + v_off[mt][sub][0]), pf0, o[mt], 0, 0, 0);
+        o[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(base + v_off[mt][sub][1]), pf1, o[mt], 0, 0, 0);
+      }
     }
   };
 
@@ -1244,7 +1265,8 @@ static void dkv_lds64(const AttnArgs& a, dim3 grid, hipStream_t stream) {
   else hipLaunchKernelGGL((attn_bwd_dkv_lds_kernel<FL>), grid, dim3(256), LDS, stream, a);
 }
 static void fwd_lds96(const AttnArgs& a, dim3 grid, hipStream_t stream) {
-  hipLaunchKernelGGL((attn_fwd_lds_kernel<96, 0>), grid, dim3(256), 2 * (64 * 192 + 96 * 128) + 1040, stream, a);
+  if (a.V.ptr) hipLaunchKernelGGL((attn_fwd_lds_kernel<96, F_VROW>), grid, dim3(256), 2 * (64 * 192 + 96 * 128) + 1040, stream, a);
+  else hipLaunchKernelGGL((attn_fwd_lds_kernel<96, 0>), grid, dim3(256), 2 * (64 * 192 + 96 * 128) + 1040, stream, a);
 }
 
 template <int DP>
@@ -1305,6 +1327,21 @@ extern "C" int mrblip_attention_fwd(const void* Q, const long long* q_strides, c
   if (Sq > 32) fwd_lds96(a, dim3((Sq + 127) / 128, H, B), stream);
   else hipLaunchKernelGGL((attn_fwd_kernel<96, 0>), dim3((Sq + 127) / 128, H, B), dim3(256), 0, stream, a);
   return mrblip_check_launch("attention_fwd");
+}
+
+// The plain (ViT) forward reading V ROW-major, i.e. straight from the fused qkv projection output: no mrblip_head_transpose of V.
+// head_dim in (64, 96], Sq > 32, no bias / mask / dropout (eva_vit.py:128-145).  v_strides like q_strides.
+extern "C" int mrblip_attention_fwd_rowv(const void* Q, const long long* q_strides, const void* K, const long long* k_strides, const void* V,
+                                         const long long* v_strides, void* O, const long long* o_strides, float* LSE, int B, int H, int Sq,
+                                         int Sk, int D, float scale, hipStream_t stream) {
+  AttnArgs a = {};
+  if (int e = attn_fill(a, Q, q_strides, K, k_strides, V, v_strides, B, H, Sq, Sk, D)) return e;
+  MRB_REQUIRE(D > 64 && D <= 96 && Sq > 32, "attention_fwd_rowv: the row-major-V form covers head_dim in (64, 96] with more than 32 queries (the ViT)");
+  MRB_REQUIRE(V != nullptr && (v_strides[2] % 8) == 0 && ((uintptr_t)V % 16) == 0, "attention_fwd_rowv: V rows must be 16-B aligned");
+  a.O = T4{(const bf16_t*)O, o_strides[0], o_strides[1], o_strides[2]};
+  a.LSE = LSE; a.scale = scale;
+  fwd_lds96(a, dim3((Sq + 127) / 128, H, B), stream);
+  return mrblip_check_launch("attention_fwd_rowv");
 }
 
 // Backward.  Needs the forward's O and LSE, the transposed copies Kt [B,H,DP,Skpad], Qt / dOt [B,H,DP,Sqpad];

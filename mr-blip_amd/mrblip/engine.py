@@ -303,8 +303,11 @@ class MrBlipEngine:
         for blk in v["blocks"][b0:b1]:
             ops.layernorm_fwd(x, blk["n1w"], blk["n1b"], 1e-6, out_bf16=h)
             ops.gemm(h, blk["qkv_w"], qkv, bias=blk["qkv_b"], tile_cfg=_VIT_CFG[0])
-            ops.head_transpose(v4, out=vt)
-            ops.attention_fwd(q4, k4, vt, o4, None, scale=scale)
+            if self.vit_rowv and hd > 64 and T > 32:   # V read row-major from the qkv buffer (LDS transpose reads): no V^T copy
+                ops.attention_fwd_rowv(q4, k4, v4, o4, None, scale=scale)
+            else:
+                ops.head_transpose(v4, out=vt)
+                ops.attention_fwd(q4, k4, vt, o4, None, scale=scale)
             ops.gemm(o, blk["proj_w"], x, bias=blk["proj_b"], residual=x, tile_cfg=_VIT_CFG[1])
             ops.layernorm_fwd(x, blk["n2w"], blk["n2b"], 1e-6, out_bf16=h)
             if probe is not None:  # HIP events around the dominant kernel's launch (bench.py roofline.achieved)
@@ -722,6 +725,7 @@ class MrBlipEngine:
             else:
                 ops.lora_dx(dy, g.Wt, gbuf, g.acatt, dx, pad64(g.N), residual=residual, drop=drop)
 
+    vit_rowv = os.environ.get("MRB_VIT_ROWV", "1") == "1"   # (0: the transposed-copy path, for A/B)
     grad_side_stream_enabled = os.environ.get("MRB_GRAD_SIDE", "1") == "1"
     _gstream = None
 

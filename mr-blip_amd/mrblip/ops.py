@@ -49,6 +49,7 @@ _rms_fwd = _sig("mrblip_rmsnorm_fwd", vp, ll, vp, i32, i32, f32, vp, ll, vp, ll,
 _ln_bwd = _sig("mrblip_layernorm_bwd", vp, ll, vp, ll, vp, i32, i32, f32, vp, ll, vp, ll, vp, vp, vp)
 _rms_bwd = _sig("mrblip_rmsnorm_bwd", vp, ll, vp, ll, vp, i32, i32, f32, vp, ll, vp, ll, vp)
 _attn_fwd = _sig("mrblip_attention_fwd", vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp, vp, i32, vp, u32, f32, vp, vp)
+_attn_fwd_rowv = _sig("mrblip_attention_fwd_rowv", vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp)
 _attn_bwd = _sig("mrblip_attention_bwd", vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
                  i32, i32, i32, i32, i32, f32, vp, vp, i32, vp, u32, f32, vp, vp)
 _head_t = _sig("mrblip_head_transpose", vp, vp, vp, i32, i32, i32, i32, i32, vp, u32, f32, vp)
@@ -79,7 +80,7 @@ _rms_lora = _sig("mrblip_rmsnorm_lora_fwd", vp, ll, vp, i32, i32, f32, vp, ll, v
 
 EXPORTS = [
     "mrblip_last_error", "mrblip_abi_version", "mrblip_gemm_bf16", "mrblip_layernorm_fwd", "mrblip_rmsnorm_fwd",
-    "mrblip_layernorm_bwd", "mrblip_rmsnorm_bwd", "mrblip_attention_fwd", "mrblip_attention_bwd", "mrblip_head_transpose",
+    "mrblip_layernorm_bwd", "mrblip_rmsnorm_bwd", "mrblip_attention_fwd", "mrblip_attention_fwd_rowv", "mrblip_attention_bwd", "mrblip_head_transpose",
     "mrblip_patchify", "mrblip_vit_assemble", "mrblip_row_copy", "mrblip_mean_pool", "mrblip_mean_pool_bwd",
     "mrblip_cast_dropout", "mrblip_gelu_bwd", "mrblip_gated_gelu_bwd", "mrblip_cross_entropy", "mrblip_adamw",
     "mrblip_seed_bump", "mrblip_lora_dx_add", "mrblip_dropout_bf16", "mrblip_colsum", "mrblip_lora_pack", "mrblip_lora_tn",
@@ -298,6 +299,14 @@ def attention_fwd(q, k, vt, o, lse=None, *, scale=1.0, bias_lut=None, kmask=None
     sp, site, p = _d(drop)
     _chk(_attn_fwd(_p(q), _strides3(q), _p(k), _strides3(k), _p(vt), _p(o), _strides3(o), _p(lse), B, H, Sq, Sk, D, scale,
                    _p(bias_lut), _p(kmask), 1 if causal else 0, sp, site, p, _p(drop_bits), _stream()))
+
+
+def attention_fwd_rowv(q, k, v, o, lse=None, *, scale=1.0):
+    """the plain ViT forward with v as a row-major [B,S,H,D] view (a column slice of the fused qkv buffer): no head_transpose of V"""
+    B, Sq, H, D = q.shape
+    Sk = k.shape[1]
+    _chk(_attn_fwd_rowv(_p(q), _strides3(q), _p(k), _strides3(k), _p(v), _strides3(v), _p(o), _strides3(o), _p(lse), B, H, Sq, Sk, D, scale,
+                        _stream()))
 
 
 def attention_bwd(q, k, v, o, do, kt, qt, dot, lse, delta, dq, dk, dv, *, scale=1.0, bias_lut=None, kmask=None, causal=False,

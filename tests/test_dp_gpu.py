@@ -12,7 +12,7 @@ import torch
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-from util import check, load_golden, golden_state_dict, relerr  # noqa: E402
+from util import check, free_port, load_golden, golden_state_dict, relerr  # noqa: E402
 
 
 @pytest.mark.parametrize("overlap", [0, 1])
@@ -24,7 +24,7 @@ def test_two_rank_gradient_equals_single_rank_batch(tmp_path, overlap):
 
     out = str(tmp_path / "dp.pt")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
-           str(29641 + overlap), os.path.join(ROOT, "tests", "dp_worker.py"), out, str(overlap)]
+           str(free_port()), os.path.join(ROOT, "tests", "dp_worker.py"), out, str(overlap)]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-3000:])
     dp = torch.load(out)

@@ -763,3 +763,28 @@ def test_gemm_16x16x32_tile(ops, M, N, K):
     o13b = torch.empty(M, N, dtype=torch.bfloat16, device=dev())
     ops.gemm(a, w, o13b, bias=bias, act=1, tile_cfg=13)
     assert torch.equal(o2, o13b)
+
+
+@pytest.mark.parametrize("B,H,S,D", [(3, 16, 257, 88), (2, 4, 300, 88), (1, 2, 64, 72), (2, 3, 129, 96)])
+def test_attention_fwd_row_major_v(ops, B, H, S, D):
+    """mrblip_attention_fwd_rowv (V read row-major from the fused qkv buffer through LDS transpose reads) against the transposed-copy
+    path — the same bf16 products in the same order: bit-identical — and against fp32 torch; q / k / v are column slices of ONE
+    [B*S, 3*H*D] buffer, as in the ViT."""
+    torch.manual_seed(21)
+    qkv = bf(torch.randn(B * S, 3 * H * D, device=dev()))
+    view = lambda c0: torch.as_strided(qkv, (B, S, H, D), (S * 3 * H * D, 3 * H * D, D, 1), c0)  # noqa: E731
+    q, k, v = view(0), view(H * D), view(2 * H * D)
+    scale = D ** -0.5
+    o_ref = torch.full((B, S, H, D), float("nan"), dtype=torch.bfloat16, device=dev())
+    o_new = torch.full((B, S, H, D), float("nan"), dtype=torch.bfloat16, device=dev())
+    ops.attention_fwd(q, k, ops.head_transpose(v), o_ref, None, scale=scale)
+    lse = torch.zeros(B, H, ops.rup32(S), device=dev())
+    ops.attention_fwd_rowv(q, k, v, o_new, lse, scale=scale)
+    assert torch.equal(o_new, o_ref)
+    want = torch.nn.functional.scaled_dot_product_attention(q.float().permute(0, 2, 1, 3), k.float().permute(0, 2, 1, 3),
+                                                            v.float().permute(0, 2, 1, 3), scale=scale).permute(0, 2, 1, 3)
+    assert rel(o_new.float(), want) < 4e-3
+    s = (q.float().permute(0, 2, 1, 3) @ k.float().permute(0, 2, 3, 1)) * scale
+    assert rel(lse[:, :, :S], torch.logsumexp(s, -1)) < 1e-5
+    with pytest.raises(ops.MrblipError):      # head_dim <= 64 / few queries keep the transposed-copy entry
+        ops.attention_fwd_rowv(q[..., :64], k[..., :64], v[..., :64], o_new[..., :64], None, scale=scale)

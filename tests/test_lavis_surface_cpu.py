@@ -123,7 +123,8 @@ def _ddp_worker(rank, world, port, q):
 def test_data_parallel_gradient_exchange_gloo_world2():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 500)
+    from util import free_port
+    port = free_port()
     procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()

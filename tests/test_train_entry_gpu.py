@@ -140,9 +140,10 @@ def test_bench_two_ranks_share_one_gpu():
     import json
     import subprocess
     import sys
+    from util import free_port
 
     env = dict(os.environ, MRB_BENCH_SHARE_GPU="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29633",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
            os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]

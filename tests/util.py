@@ -64,3 +64,12 @@ def check(name: str, value: float, tol: float):
     verification rows ("verify-fp32": ~1e-5, i.e. 50-100x inside north_star's 1e-3 bar)."""
     record(name, value, tol)
     assert value < tol, f"{name}: measured {value:.3e} >= tolerance {tol:.3e}"
+
+
+def free_port() -> int:
+    """a TCP port nobody listens on right now (rendezvous of the multi-process tests: a fixed port can still be in TIME_WAIT from the previous test)"""
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]

@@ -89,14 +89,15 @@ class Fp32Verify(contextlib.AbstractContextManager):
         src = eng._verify_src
         self._pack_weights(src)
         # --- ops patches
-        for name in ("gemm", "layernorm_fwd", "rmsnorm_fwd", "cast_dropout", "attention_fwd", "head_transpose", "patchify", "lora_rows", "lora_down",
-                     "rmsnorm_lora_fwd"):
+        for name in ("gemm", "layernorm_fwd", "rmsnorm_fwd", "cast_dropout", "attention_fwd", "attention_fwd_rowv", "head_transpose", "patchify",
+                     "lora_rows", "lora_down", "rmsnorm_lora_fwd"):
             S["ops." + name] = getattr(ops, name)
         ops.gemm = self.gemm
         ops.layernorm_fwd = self.layernorm_fwd
         ops.rmsnorm_fwd = self.rmsnorm_fwd
         ops.cast_dropout = self.cast_dropout
         ops.attention_fwd = self.attention_fwd
+        ops.attention_fwd_rowv = self.attention_fwd_rowv
         ops.head_transpose = self.head_transpose
         ops.patchify = self.patchify
         ops.lora_rows = lambda *a, **k: None      # LoRA B = 0: the branch contributes exactly zero (u buffers stay zero)
@@ -231,7 +232,12 @@ class Fp32Verify(contextlib.AbstractContextManager):
 
     def attention_fwd(self, q, k, vt, o, lse=None, *, scale=1.0, bias_lut=None, kmask=None, causal=False, drop=None, drop_bits=None):
         assert drop is None
-        v = self.vsrc[vt.data_ptr()]
+        self._attention(q, k, self.vsrc[vt.data_ptr()], o, scale, bias_lut, kmask, causal)
+
+    def attention_fwd_rowv(self, q, k, v, o, lse=None, *, scale=1.0):
+        self._attention(q, k, v, o, scale, None, None, False)
+
+    def _attention(self, q, k, v, o, scale, bias_lut, kmask, causal):
 
         def full(t):
             return (t.float() + self.view_lo(t, self.find_base(t)).float()).permute(0, 2, 1, 3)  # [B,H,S,D]

@@ -17,6 +17,17 @@ for S in (257, 256, 300):
     for _ in range(20): ops.attention_fwd(q, k, vt, o, None, scale=D ** -0.5)
     e.record(); torch.cuda.synchronize()
     t = s.elapsed_time(e) / 20 * 1e3
+    o2 = torch.full_like(o, float("nan"))
+    for _ in range(3): ops.attention_fwd_rowv(q, k, v, o2, None, scale=D ** -0.5)
+    s.record()
+    for _ in range(20): ops.attention_fwd_rowv(q, k, v, o2, None, scale=D ** -0.5)
+    e.record(); torch.cuda.synchronize()
+    t2 = s.elapsed_time(e) / 20 * 1e3
+    s.record()
+    for _ in range(20): ops.head_transpose(v, out=vt)
+    e.record(); torch.cuda.synchronize()
+    t3 = s.elapsed_time(e) / 20 * 1e3
+    print(f"S={S}: row-major V {t2:.1f} us (equal to the V^T path: {torch.equal(o, o2)}); head_transpose(V) alone {t3:.1f} us")
     ref = torch.nn.functional.scaled_dot_product_attention(q.float().permute(0, 2, 1, 3), k.float().permute(0, 2, 1, 3), v.float().permute(0, 2, 1, 3)).permute(0, 2, 1, 3)
     err = ((o.float() - ref).norm() / ref.norm()).item()
     print(f"S={S}: {t:.1f} us  {4.0*B*H*S*S*D/t/1e6:.0f} TF  rel err {err:.2e}")
