@@ -416,6 +416,21 @@ __global__ __launch_bounds__(256, (DP == 96 ? ATTN96_BLOCKS : 2)) void attn_fwd_
 
   auto tile = [&](auto edge_c, int k0, const char* base, int sub, uint32_t vmask) {
     constexpr bool EDGE = decltype(edge_c)::value;
+    // VROW: the transpose reads of this tile's V fragments go out FIRST - their latency then lies under the QK^T MFMAs and the softmax
+    // arithmetic instead of in front of the second product (issued where they are consumed the waves sat parked 40 % longer)
+    typedef short v4s_t __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) v4s_t* tr_ptr_t;
+    v4s_t vtr_r[VROW ? MT : 1][4];
+    if (VROW) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const char* vb = base + vtr + (32 * sub) * KROW + mt * 64;
+        vtr_r[mt][0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr_t)(vb));
+        vtr_r[mt][1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr_t)(vb + 4 * KROW));
+        vtr_r[mt][2] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr_t)(vb + 16 * KROW));
+        vtr_r[mt][3] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr_t)(vb + 20 * KROW));
+      }
+    }
     f32x16 sacc;
     zero16(sacc);
 #pragma unroll
@@ -474,11 +489,7 @@ __global__ __launch_bounds__(256, (DP == 96 ? ATTN96_BLOCKS : 2)) void attn_fwd_
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       if (VROW) {
-        typedef short v4s_t __attribute__((ext_vector_type(4)));
-        typedef __attribute__((address_space(3))) v4s_t* tr_ptr_t;
-        const char* vb = base + vtr + (32 * sub) * KROW + mt * 64;
-        const v4s_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr_t)(vb)), a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr_t)(vb + 4 * KROW));
-        const v4s_t b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr_t)(vb + 16 * KROW)), b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr_t)(vb + 20 * KROW));
+        const v4s_t a0 = vtr_r[mt][0], a1 = vtr_r[mt][1], b0 = vtr_r[mt][2], b1 = vtr_r[mt][3];
         const bf16x8 vf0 = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]}, vf1 = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
         o[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf0, pf0, o[mt], 0, 0, 0);
         o[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf1, pf1, o[mt], 0, 0, 0);

@@ -36,6 +36,8 @@ for name, B, H, Sq, Sk, D, lut_on, drop_on, causal in [
     t = timeit(lambda: ops.attention_fwd(q, k, vt, o, lse, scale=scale, bias_lut=lut, kmask=kmask, causal=causal, drop=drop, drop_bits=dbits))
     fl = 4.0 * B * H * Sq * Sk * D
     row = dict(name=name, fwd_us=round(t * 1e6, 1), fwd_TF=round(fl / t / 1e12, 1))
+    if D > 64:
+        row["fwd_rowv_us"] = round(timeit(lambda: ops.attention_fwd_rowv(q, k, v, o, lse, scale=scale)) * 1e6, 1)
     if D <= 64:
         kt, qt, dot = ops.head_transpose(k), ops.head_transpose(q), ops.head_transpose(do)
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)

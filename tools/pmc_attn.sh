@@ -4,7 +4,7 @@ R=$GRAFT_REPO_ROOT
 i=0
 for C in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SALU GRBM_GUI_ACTIVE"; do
   i=$((i+1)); rm -rf $R/gpurun_out/pmca_$i
-  ATTN_ONLY=t5enc,vit timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $R/gpurun_out/pmca_$i -- python $R/tools/attn_bench.py > $R/gpurun_out/pmca_$i.log 2>&1
+  ATTN_ONLY=${ATTN_ONLY:-t5enc,vit} timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $R/gpurun_out/pmca_$i -- python $R/tools/attn_bench.py > $R/gpurun_out/pmca_$i.log 2>&1
 done
 cd $R
 python - <<'PY' > gpurun_out/pmc_attn.txt
