@@ -57,6 +57,12 @@ int mrblip_layernorm_bwd(const float* dy, long long lddy, const float* x, long l
                          float* dbeta, mrblip_stream_t stream);
 int mrblip_rmsnorm_bwd(const float* dy, long long lddy, const float* x, long long ldx, const float* weight, int M, int D,
                        float eps, const float* dx_add, long long ldadd, float* dx, long long lddx, mrblip_stream_t stream);
+/* mrblip_rmsnorm_bwd that additionally writes the next GEMM's bf16 operand: out_bf16 = bf16(dropout-backward(dx)) for the mask of
+ * (seed, site, p) over element index row * D + col (bit-identical to a following mrblip_cast_dropout launch).  The T5 block backward:
+ * T5LayerNorm backward (modeling_t5.py:239-262) followed by the previous sub-layer's nn.Dropout backward (:613-615, :345-347). */
+int mrblip_rmsnorm_bwd_cast(const float* dy, long long lddy, const float* x, long long ldx, const float* weight, int M, int D, float eps,
+                            const float* dx_add, long long ldadd, float* dx, long long lddx, void* out_bf16, long long ldob,
+                            const uint32_t* seed_ptr, uint32_t site, float p_drop, mrblip_stream_t stream);
 
 /* Fused softmax(Q K^T * scale + bias_lut[h][clamp(k-q,-128,128)+128] + masks) V, fp32 online softmax, bf16 I/O.
  * strides = {batch, head, row} in elements (rows are contiguous in head_dim).  Vt/Kt/Qt/dOt are

@@ -61,7 +61,8 @@ template <bool RMS>
 __global__ __launch_bounds__(256) void norm_bwd_kernel(const float* __restrict__ dy, long long lddy, const float* __restrict__ x,
                                                        long long ldx, const float* __restrict__ gamma, int M, int D, float eps,
                                                        const float* dx_add, long long ldadd, float* dx, long long lddx,
-                                                       float* dgamma, float* dbeta) {
+                                                       float* dgamma, float* dbeta, bf16_t* out_b = nullptr, long long ldob = 0,
+                                                       DropoutArg drop = DropoutArg{nullptr, 0u, 0u, 1.0f}) {
   __shared__ float red[2][4][64 * 4];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int nv = D >> 2;
@@ -125,6 +126,16 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const float* __restrict__
           o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
         }
         if (dx) reinterpret_cast<float4*>(dx + (long long)row * lddx)[i] = o;
+        if (out_b) {  // the consumer's bf16 GEMM operand = dropout-backward(dx) (what a separate mrblip_cast_dropout launch would write)
+          if (drop.seed_ptr) {
+            const uint32_t seed = *drop.seed_ptr, base = (uint32_t)row * (uint32_t)D + (uint32_t)(4 * i);
+            o.x = mrb_keep(base, seed, drop.site, drop.thresh24) ? o.x * drop.inv_keep : 0.f;
+            o.y = mrb_keep(base + 1, seed, drop.site, drop.thresh24) ? o.y * drop.inv_keep : 0.f;
+            o.z = mrb_keep(base + 2, seed, drop.site, drop.thresh24) ? o.z * drop.inv_keep : 0.f;
+            o.w = mrb_keep(base + 3, seed, drop.site, drop.thresh24) ? o.w * drop.inv_keep : 0.f;
+          }
+          reinterpret_cast<uint2*>(out_b + (long long)row * ldob)[i] = make_uint2(pack2bf(o.x, o.y), pack2bf(o.z, o.w));
+        }
       }
     }
   }
@@ -186,6 +197,24 @@ extern "C" int mrblip_layernorm_bwd(const float* dy, long long lddy, const float
   const int grid = min((M + 3) / 4, dgamma ? 512 : 2048);
   hipLaunchKernelGGL(norm_bwd_kernel<false>, dim3(grid), dim3(256), 0, stream, dy, lddy, x, ldx, gamma, M, D, eps, dx_add, ldadd, dx, lddx, dgamma, dbeta);
   return mrblip_check_launch("layernorm_bwd");
+}
+
+// rmsnorm_bwd that also writes the NEXT GEMM's operand: out_bf16 = bf16(dropout-backward(dx)) with the mask of (seed, site, p) over
+// element index row * D + col — bit-identical to mrblip_cast_dropout(dx) in a second launch (T5 sub-layer dropout, modeling_t5.py:613-615)
+extern "C" int mrblip_rmsnorm_bwd_cast(const float* dy, long long lddy, const float* x, long long ldx, const float* weight, int M, int D,
+                                       float eps, const float* dx_add, long long ldadd, float* dx, long long lddx, void* out_bf16,
+                                       long long ldob, const uint32_t* seed_ptr, uint32_t site, float p_drop, hipStream_t stream) {
+  if (int e = norm_check(M, D, x, ldx)) return e;
+  MRB_REQUIRE(out_bf16 && (ldob % 4) == 0, "rmsnorm_bwd_cast: bf16 output missing / unaligned");
+  DropoutArg d;
+  d.seed_ptr = (p_drop > 0.f) ? seed_ptr : nullptr;
+  d.site = site;
+  d.thresh24 = (uint32_t)(p_drop * 65536.0f + 0.5f);
+  d.inv_keep = 1.0f / (1.0f - p_drop);
+  const int grid = min((M + 3) / 4, 2048);
+  hipLaunchKernelGGL(norm_bwd_kernel<true>, dim3(grid), dim3(256), 0, stream, dy, lddy, x, ldx, weight, M, D, eps, dx_add, ldadd, dx, lddx, (float*)nullptr,
+                     (float*)nullptr, (bf16_t*)out_bf16, ldob, d);
+  return mrblip_check_launch("rmsnorm_bwd_cast");
 }
 
 extern "C" int mrblip_rmsnorm_bwd(const float* dy, long long lddy, const float* x, long long ldx, const float* weight, int M, int D,

@@ -726,6 +726,7 @@ class MrBlipEngine:
                 ops.lora_dx(dy, g.Wt, gbuf, g.acatt, dx, pad64(g.N), residual=residual, drop=drop)
 
     vit_rowv = os.environ.get("MRB_VIT_ROWV", "1") == "1"   # (0: the transposed-copy path, for A/B)
+    fuse_bwd_cast = os.environ.get("MRB_FUSE_BWD_CAST", "1") == "1"
     grad_side_stream_enabled = os.environ.get("MRB_GRAD_SIDE", "1") == "1"
     _gstream = None
 
@@ -796,7 +797,10 @@ class MrBlipEngine:
         ops.cast_dropout(denc, out_f32=t, drop=self.drop(self.t5["sites"][1], p))
         dx = self.buf("eb_dx_a", (M, d), f32, zero=False)
         ops.rmsnorm_bwd(t, self.ws["e_xfinal_in"], self.t5["enc_final"], c.t5_eps, dx)
-        dyb, dyb2 = self.buf("eb_dyb", (M, pad64(d)), bf16), self.buf("eb_dyb2", (M, pad64(d)), bf16)
+        # (dyb alternates between two buffers: the fused write of layer i - 1's operand happens at the END of layer i, when layer i's
+        # weight-gradient launch on the side stream may still be reading its own; the other buffer's readers were joined at the top of i)
+        dyb_pair = (self.buf("eb_dyb", (M, pad64(d)), bf16), self.buf("eb_dyb_alt", (M, pad64(d)), bf16))
+        dyb2 = self.buf("eb_dyb2", (M, pad64(d)), bf16)
         gb, gb2, gb3, gb4 = (self.buf(n, (M, 64), bf16) for n in ("eb_g", "eb_g2", "eb_g3", "eb_g4"))
         dyact = self.buf("eb_dyact", (M, ff), bf16, zero=False)
         dh = self.buf("eb_dh", (M, 2 * ff), bf16, zero=False)
@@ -807,8 +811,10 @@ class MrBlipEngine:
         kt, qt, dot = (self.buf(n, (B, H, ops.rup32(dk), rs), bf16) for n in ("eb_kt", "eb_qt", "eb_dot"))
         delta = self.buf("eb_delta", (B, H, rs), f32)
         other = self.buf("eb_dx_b", (M, d), f32, zero=False)
+        dyb_ready = False
         for i in reversed(range(len(self.t5["enc"]))):
             L = self.t5["enc"][i]
+            dyb = dyb_pair[i & 1]
             # the LoRA weight-gradient launches of this layer run on the side stream beside the dX GEMMs; their inputs (dyb/dyb2/dh/
             # dqkv and the four g buffers) are written once per layer, so one join per layer keeps every reader ahead of its next writer
             self.side_join()
@@ -825,14 +831,20 @@ class MrBlipEngine:
                     kq_ready = torch.cuda.Event()
                     kq_ready.record()
             # x_out = xm + drop(wo(y));  y = drop(gelu(wi_0 xn2) * wi_1 xn2)
-            ops.cast_dropout(dx, out_bf16=dyb, drop=self.drop(L["sites"][3], p))
+            # (the bf16 operands dyb / dyb2 = dropout-backward(dx) are written by the RMSNorm backward that produced dx — one launch
+            # and one 16 MB read fewer per sub-layer; only the top layer, whose dx comes from the decoder, casts on its own)
+            if not dyb_ready:
+                ops.cast_dropout(dx, out_bf16=dyb, drop=self.drop(L["sites"][3], p))
             self.lg_bwd(L["wo"], dyb, self.ws[f"e{i}_y"], self.ws[f"e{i}_u_wo"], gb, dyact, side=True)
             ops.gated_gelu_bwd(dyact, self.ws[f"e{i}_h"], dh, drop=self.drop(L["sites"][2], p))
             self.lg_bwd(L["wi"], dh, self.ws[f"e{i}_xn2"], self.ws[f"e{i}_u_wi"], gb2, dxn, side=True)
-            ops.rmsnorm_bwd(dxn, self.ws[f"e{i}_xm"], L["ln1"], c.t5_eps, other, dx_add=dx)
+            if self.fuse_bwd_cast:
+                ops.rmsnorm_bwd(dxn, self.ws[f"e{i}_xm"], L["ln1"], c.t5_eps, other, dx_add=dx, out_bf16=dyb2, out_drop=self.drop(L["sites"][1], p))
+            else:
+                ops.rmsnorm_bwd(dxn, self.ws[f"e{i}_xm"], L["ln1"], c.t5_eps, other, dx_add=dx)
+                ops.cast_dropout(other, out_bf16=dyb2, drop=self.drop(L["sites"][1], p))
             dx, other = other, dx
             # xm = x_in + drop(o(attn(qkv(xn))))
-            ops.cast_dropout(dx, out_bf16=dyb2, drop=self.drop(L["sites"][1], p))
             self.lg_bwd(L["o"], dyb2, self.ws[f"e{i}_o"], self.ws[f"e{i}_u_o"], gb3, do, side=True)
             qkv, o = self.ws[f"e{i}_qkv"], self.ws[f"e{i}_o"]
             q4, k4, v4 = self.v4(qkv, B, S, H, dk, 0), self.v4(qkv, B, S, H, dk, inner), self.v4(qkv, B, S, H, dk, 2 * inner)
@@ -848,7 +860,13 @@ class MrBlipEngine:
                               scale=1.0, bias_lut=self.lut_enc, kmask=kmask, drop=self.drop(L["sites"][0], p),
                               drop_bits=self.ws.get(f"e{i}_dbits") if self.drop(L["sites"][0], p) is not None else None)
             self.lg_bwd(L["qkv"], dqkv, self.ws[f"e{i}_xn"], self.ws[f"e{i}_u_qkv"], gb4, dxn, side=True)
-            ops.rmsnorm_bwd(dxn, self.ws[f"e{i}_xin"], L["ln0"], c.t5_eps, other, dx_add=dx)
+            if i > 0 and self.fuse_bwd_cast:   # ... and the layer below's first operand
+                ops.rmsnorm_bwd(dxn, self.ws[f"e{i}_xin"], L["ln0"], c.t5_eps, other, dx_add=dx, out_bf16=dyb_pair[(i - 1) & 1],
+                                out_drop=self.drop(self.t5["enc"][i - 1]["sites"][3], p))
+                dyb_ready = True
+            else:
+                ops.rmsnorm_bwd(dxn, self.ws[f"e{i}_xin"], L["ln0"], c.t5_eps, other, dx_add=dx)
+                dyb_ready = False
             dx, other = other, dx
         self.side_join()
         dinp = self.buf("eb_dinp", (M, d), f32, zero=False)

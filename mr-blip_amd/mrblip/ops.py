@@ -48,6 +48,7 @@ _ln_fwd = _sig("mrblip_layernorm_fwd", vp, ll, vp, vp, i32, i32, f32, vp, ll, vp
 _rms_fwd = _sig("mrblip_rmsnorm_fwd", vp, ll, vp, i32, i32, f32, vp, ll, vp, ll, vp)
 _ln_bwd = _sig("mrblip_layernorm_bwd", vp, ll, vp, ll, vp, i32, i32, f32, vp, ll, vp, ll, vp, vp, vp)
 _rms_bwd = _sig("mrblip_rmsnorm_bwd", vp, ll, vp, ll, vp, i32, i32, f32, vp, ll, vp, ll, vp)
+_rms_bwd_cast = _sig("mrblip_rmsnorm_bwd_cast", vp, ll, vp, ll, vp, i32, i32, f32, vp, ll, vp, ll, vp, ll, vp, u32, f32, vp)
 _attn_fwd = _sig("mrblip_attention_fwd", vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp, vp, i32, vp, u32, f32, vp, vp)
 _attn_fwd_rowv = _sig("mrblip_attention_fwd_rowv", vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp)
 _attn_bwd = _sig("mrblip_attention_bwd", vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
@@ -80,7 +81,7 @@ _rms_lora = _sig("mrblip_rmsnorm_lora_fwd", vp, ll, vp, i32, i32, f32, vp, ll, v
 
 EXPORTS = [
     "mrblip_last_error", "mrblip_abi_version", "mrblip_gemm_bf16", "mrblip_layernorm_fwd", "mrblip_rmsnorm_fwd",
-    "mrblip_layernorm_bwd", "mrblip_rmsnorm_bwd", "mrblip_attention_fwd", "mrblip_attention_fwd_rowv", "mrblip_attention_bwd", "mrblip_head_transpose",
+    "mrblip_layernorm_bwd", "mrblip_rmsnorm_bwd", "mrblip_rmsnorm_bwd_cast", "mrblip_attention_fwd", "mrblip_attention_fwd_rowv", "mrblip_attention_bwd", "mrblip_head_transpose",
     "mrblip_patchify", "mrblip_vit_assemble", "mrblip_row_copy", "mrblip_mean_pool", "mrblip_mean_pool_bwd",
     "mrblip_cast_dropout", "mrblip_gelu_bwd", "mrblip_gated_gelu_bwd", "mrblip_cross_entropy", "mrblip_adamw",
     "mrblip_seed_bump", "mrblip_lora_dx_add", "mrblip_dropout_bf16", "mrblip_colsum", "mrblip_lora_pack", "mrblip_lora_tn",
@@ -183,9 +184,16 @@ def layernorm_bwd(dy, x, gamma, eps, dx, dx_add=None, dgamma=None, dbeta=None):
     _chk(_ln_bwd(_p(dy), _ld(dy), _p(x), _ld(x), _p(gamma), M, D, eps, _p(dx_add), _ld(dx_add), _p(dx), _ld(dx), _p(dgamma), _p(dbeta), _stream()))
 
 
-def rmsnorm_bwd(dy, x, weight, eps, dx, dx_add=None):
+def rmsnorm_bwd(dy, x, weight, eps, dx, dx_add=None, out_bf16=None, out_drop: Optional["Dropout"] = None):
+    """out_bf16 (optional): also write bf16(dropout-backward(dx)) for the mask of ``out_drop`` — the next GEMM's operand, saving the
+    separate cast_dropout launch and its read of dx"""
     M, D = x.shape
-    _chk(_rms_bwd(_p(dy), _ld(dy), _p(x), _ld(x), _p(weight), M, D, eps, _p(dx_add), _ld(dx_add), _p(dx), _ld(dx), _stream()))
+    if out_bf16 is None:
+        _chk(_rms_bwd(_p(dy), _ld(dy), _p(x), _ld(x), _p(weight), M, D, eps, _p(dx_add), _ld(dx_add), _p(dx), _ld(dx), _stream()))
+    else:
+        sp, site, p = _d(out_drop)
+        _chk(_rms_bwd_cast(_p(dy), _ld(dy), _p(x), _ld(x), _p(weight), M, D, eps, _p(dx_add), _ld(dx_add), _p(dx), _ld(dx), _p(out_bf16), _ld(out_bf16),
+                           sp, site, p, _stream()))
 
 
 # ------------------------------------------------------------------------------------------------ attention

@@ -788,3 +788,27 @@ def test_attention_fwd_row_major_v(ops, B, H, S, D):
     assert rel(lse[:, :, :S], torch.logsumexp(s, -1)) < 1e-5
     with pytest.raises(ops.MrblipError):      # head_dim <= 64 / few queries keep the transposed-copy entry
         ops.attention_fwd_rowv(q[..., :64], k[..., :64], v[..., :64], o_new[..., :64], None, scale=scale)
+
+
+@pytest.mark.parametrize("D,p", [(2048, 0.1), (768, 0.1), (64, 0.0)])
+def test_rmsnorm_bwd_with_fused_operand_cast(ops, D, p):
+    """mrblip_rmsnorm_bwd_cast: dx as mrblip_rmsnorm_bwd writes it, plus bf16(dropout-backward(dx)) — bit for bit what a following
+    mrblip_cast_dropout launch produces (same element index, same hash, same rounding)."""
+    torch.manual_seed(31)
+    M = 301
+    x = torch.randn(M, D, device=dev()) * 1.5
+    w = torch.randn(D, device=dev()) * 0.1 + 1
+    dy = torch.randn(M, D, device=dev())
+    add = torch.randn(M, D, device=dev())
+    seed = torch.tensor([777], dtype=torch.int32, device=dev())
+    drop = ops.Dropout(seed, 23, p) if p > 0 else None
+    dx_ref = torch.empty_like(x)
+    ops.rmsnorm_bwd(dy, x, w, 1e-6, dx_ref, dx_add=add)
+    want = torch.zeros(M, D + 64, dtype=torch.bfloat16, device=dev())[:, :D]
+    ops.cast_dropout(dx_ref, out_bf16=want, drop=drop)
+    dx = torch.empty_like(x)
+    got = torch.zeros(M, D + 64, dtype=torch.bfloat16, device=dev())[:, :D]     # (row stride != D, like the padded operand buffers)
+    ops.rmsnorm_bwd(dy, x, w, 1e-6, dx, dx_add=add, out_bf16=got, out_drop=drop)
+    assert torch.equal(dx, dx_ref) and torch.equal(got, want)
+    if p > 0:
+        assert 0.85 < (got != 0).float().mean().item() < 0.95
