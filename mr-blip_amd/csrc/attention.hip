@@ -87,6 +87,22 @@ __device__ __forceinline__ bf16x8 pack8(const float* v) {
 __device__ __forceinline__ float ex2(float x) { return __builtin_amdgcn_exp2f(x); }
 template <bool V> struct BoolC { static constexpr bool value = V; };
 
+// Workgroups are dealt to the 8 XCDs round-robin by their linear id, and every XCD has its own L2: with (q-block, head, batch) taken
+// straight from blockIdx the q-blocks that share one head's K / V tiles land on DIFFERENT XCDs and each of them pulls the tiles through
+// its own L2.  This bijective remap (the tile GEMM's) gives XCD x the x-th contiguous eighth of the linear work list instead, so the
+// q-blocks of a head (and the heads of a frame) are neighbours in one L2.  MRB_ATTN_NO_XCD_REMAP (build flag) = identity, for A/B.
+__device__ __forceinline__ void attn_block(int& bx, int& by, int& bz) {
+#ifdef MRB_ATTN_NO_XCD_REMAP
+  bx = blockIdx.x; by = blockIdx.y; bz = blockIdx.z;
+#else
+  const int gx = gridDim.x, gy = gridDim.y, total = gx * gy * (int)gridDim.z;
+  int id = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+  const int q = total >> 3, r = total & 7, xcd = id & 7, idx = id >> 3;
+  id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  bx = id % gx; by = (id / gx) % gy; bz = id / (gx * gy);
+#endif
+}
+
 // sv[r] = sacc[r] * scale2 + lut[clamp(rel_r)] with rel_r = relbase + SGN * (16*(r>>3) + (r&7)); a tile whose every |rel| >= 128
 // shares one bucket (far_idx) -> one LUT read instead of sixteen.
 template <bool LUT, int SGN>
@@ -342,11 +358,12 @@ __global__ __launch_bounds__(256, (DP == 96 ? ATTN96_BLOCKS : 2)) void attn_fwd_
   float* lut = reinterpret_cast<float*>(sm + 2 * STAGE);
   const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int b = blockIdx.z, h = blockIdx.y;
+  int bx_, h, b;
+  attn_block(bx_, h, b);
   if (LUT) {
     for (int i = tid; i < 257; i += 256) lut[i] = p.lut[h * 257 + i] * MRB_LOG2E;
   }
-  const int q0 = (blockIdx.x * 4 + w) * 32;
+  const int q0 = (bx_ * 4 + w) * 32;
   const bool active = q0 < p.Sq;  // wave-uniform; inactive waves still stage and hit the barriers
   const int q = q0 + l31;
   const bool q_ok = q < p.Sq;
@@ -421,7 +438,12 @@ __global__ __launch_bounds__(256, (DP == 96 ? ATTN96_BLOCKS : 2)) void attn_fwd_
     typedef short v4s_t __attribute__((ext_vector_type(4)));
     typedef __attribute__((address_space(3))) v4s_t* tr_ptr_t;
     v4s_t vtr_r[VROW ? MT : 1][4];
-    if (VROW) {
+#ifdef EXP_VROW_OLDREAD   // ablation (wrong results): row-major staging, but the old 16-B fragment reads
+    constexpr bool VTR = false;
+#else
+    constexpr bool VTR = VROW;
+#endif
+    if (VTR) {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         const char* vb = base + vtr + (32 * sub) * KROW + mt * 64;
@@ -488,7 +510,7 @@ __global__ __launch_bounds__(256, (DP == 96 ? ATTN96_BLOCKS : 2)) void attn_fwd_
     const bf16x8 pf0 = pack8(pv), pf1 = pack8(pv + 8);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-      if (VROW) {
+      if (VTR) {
         const v4s_t a0 = vtr_r[mt][0], a1 = vtr_r[mt][1], b0 = vtr_r[mt][2], b1 = vtr_r[mt][3];
         const bf16x8 vf0 = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]}, vf1 = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
         o[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf0, pf0, o[mt], 0, 0, 0);
@@ -695,11 +717,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_lds_kernel(const AttnArgs 
   float* lut = reinterpret_cast<float*>(sm + 2 * STAGE);
   const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int b = blockIdx.z, h = blockIdx.y;
+  int bx_, h, b;
+  attn_block(bx_, h, b);
   if (LUT) {
     for (int i = tid; i < 257; i += 256) lut[i] = p.lut[h * 257 + i] * MRB_LOG2E;
   }
-  const int q0 = (blockIdx.x * 4 + w) * 32;
+  const int q0 = (bx_ * 4 + w) * 32;
   const bool active = q0 < p.Sq;
   const int q = q0 + l31;
   const bool q_ok = q < p.Sq;
@@ -1027,11 +1050,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_lds_kernel(const AttnArgs
   float* lut = reinterpret_cast<float*>(sm + 2 * STAGE);
   const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int b = blockIdx.z, h = blockIdx.y;
+  int bx_, h, b;
+  attn_block(bx_, h, b);
   if (LUT) {
     for (int i = tid; i < 257; i += 256) lut[i] = p.lut[h * 257 + i] * MRB_LOG2E;
   }
-  const int kb0 = (blockIdx.x * 4 + w) * 32;
+  const int kb0 = (bx_ * 4 + w) * 32;
   const bool active = kb0 < p.Sk;
   const int key = kb0 + l31;
   bool key_ok = key < p.Sk;
@@ -1044,7 +1068,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_lds_kernel(const AttnArgs
   for (int mt = 0; mt < MT; ++mt) { zero16(dk[mt]); zero16(dv[mt]); }
   const uint32_t drop_seed = DROP ? *p.drop.seed_ptr : 0u;
   const uint32_t bh_idx = (uint32_t)(b * p.H + h) * (uint32_t)p.Sq;
-  const int st0 = CAUSAL ? blockIdx.x * 2 : 0;  // first 64-query stage (block-uniform); the per-wave causal limit is applied below
+  const int st0 = CAUSAL ? bx_ * 2 : 0;  // first 64-query stage (block-uniform); the per-wave causal limit is applied below
   const float scale2 = p.scale * MRB_LOG2E;
   const float keep_scale = DROP ? p.drop.inv_keep : 1.0f;
 
