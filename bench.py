@@ -104,11 +104,11 @@ def _oracle_cfg(cfg):
                         num_heads=cfg.t5_heads, vocab_size=cfg.vocab, num_buckets=32, max_distance=128, eps=cfg.t5_eps))
 
 
-def cpu_baseline(budget_s=25.0, full_c2=False):
+def cpu_baseline(budget_s=30.0, full_c2=False):
     """The reference CPU path timed on THIS host: the oracle (oracle/mrblip_oracle.py — the fp32 PyTorch-CPU restatement pinned to the
     reference by tests/test_oracle_golden.py, incl. the real-depth C1 fixture) runs the WHOLE path — forward_mr and loss.backward() —
     on BASELINE.json configs[0] ("C1": 4 frames of 224x224, ViT-g/14 39 blocks + Q-Former(32) + Flan-T5-base dims, batch 1): one untimed
-    warm-up step, then whole steps until the budget is used.  `value` scales the measured rate to the metric's unit by algorithmic
+    warm-up step, then at least THREE timed whole steps (more until the budget is used).  `value` scales the measured rate to the metric's unit by algorithmic
     FLOPs (QVH clip step = 45.37 TFLOP at this bench's S/L_dec; C1 clip step = step_tflop_per_clip at its S/L_dec).  full_c2=True
     (--cpu-baseline-c2, minutes of CPU time and ~17 GB of RAM) additionally times ONE whole QVH clip step (T = 60, Flan-T5-XL dims)."""
     from mrblip import prompt as P
@@ -119,7 +119,7 @@ def cpu_baseline(budget_s=25.0, full_c2=False):
     tok = FixtureTokenizer()
     repl = P.annoying_replacement_dict(P.find_annoying_numbers(tok, 200)[0])
 
-    def run(cfg, T, duration, max_iters, budget):
+    def run(cfg, T, duration, max_iters, budget, min_iters=1):
         sd = _oracle_state_dict(cfg)
         for k in ("t5_proj.weight", "t5_proj.bias", "ln_vision.weight", "ln_vision.bias"):
             sd[k].requires_grad_(True)
@@ -136,7 +136,7 @@ def cpu_baseline(budget_s=25.0, full_c2=False):
             t2 = time.time()
             if it > 0 or max_iters == 1:
                 times.append((t1 - t0, t2 - t1))
-            if max_iters == 1 or (times and time.time() - t_start + (t2 - t0) > budget):
+            if max_iters == 1 or (len(times) >= min_iters and time.time() - t_start + (t2 - t0) > budget):
                 break
         tf = step_tflop_per_clip(cfg, T, lay.S, lay.labels.shape[1], False)
         # forward-only FLOPs of the timed function: the oracle's backward is dX through T5 / Q-Former + dW of t5_proj, ln_vision (as counted)
@@ -147,26 +147,31 @@ def cpu_baseline(budget_s=25.0, full_c2=False):
                     tflops=round(tf / (fwd + bwd), 4), S_enc=lay.S)
 
     c1 = EngineConfig(d_model=768, d_kv=64, t5_heads=12, d_ff=2048, t5_layers=12, t5_dec_layers=12)
-    r1 = run(c1, 4, 28.0, 8, budget_s)
+    r1 = run(c1, 4, 28.0, 8, budget_s, min_iters=3)
     qvh_tf = step_tflop_per_clip(EngineConfig(), 60, 2012, 8, False)
-    out = dict(value=round(r1["tflops"] / qvh_tf, 5), unit="clips/s", cores=torch.get_num_threads(), kind="port",
+    c1_scaled = round(r1["tflops"] / qvh_tf, 5)
+    out = dict(value=c1_scaled, unit="clips/s", cores=torch.get_num_threads(), kind="port", value_source="c1_scaled",
                sample=("oracle forward_mr + backward, BASELINE configs[0] (4 frames, ViT-g/14 + Q-Former(32) + T5-base dims, B=1, fp32): "
                        f"{r1['iters']} timed steps after 1 warm-up, {r1['fwd_s']} s fwd + {r1['bwd_s']} s bwd per step = {r1['clips_per_s']:.4f} C1-clips/s = "
-                       f"{r1['tflops']} TFLOP/s sustained; value = that rate / {qvh_tf:.2f} TFLOP per QVH clip step"),
-               c1=r1)
+                       f"{r1['tflops']} TFLOP/s sustained; c1_scaled = that rate / {qvh_tf:.2f} TFLOP per QVH clip step"),
+               c1=r1, c1_scaled_clips_per_s=c1_scaled)
     if full_c2:
         r2 = run(EngineConfig(), 60, 150.0, 1, 1e9)
         out["c2"] = r2
         out["c2"]["note"] = "ONE whole QVH clip step (T=60, Flan-T5-XL dims), no warm-up"
+        # the metric's own configuration was timed: THAT is the baseline value (the FLOP-scaled C1 sample stays beside it)
+        out["value"], out["value_source"] = round(r2["clips_per_s"], 5), "c2_live"
     else:
-        # not live: the one-off --cpu-baseline-c2 run committed with the round's profiles (a whole QVH clip step of the oracle on a
-        # GPU box's host: minutes), shown beside the live C1 sample so the scale-up by FLOPs can be judged
-        ref = os.path.join(ROOT, "profiles", "r02_cpu_baseline_c2.json")
-        if os.path.exists(ref):
-            c2 = json.load(open(ref)).get("c2")
-            if c2:
-                out["c2_committed_run"] = dict(clips_per_s=round(c2["clips_per_s"], 5), fwd_s=c2["fwd_s"], bwd_s=c2["bwd_s"],
-                                               source="profiles/r02_cpu_baseline_c2.json (python bench.py --cpu-baseline-c2, earlier box, not this run)")
+        # not live: the one-off --cpu-baseline-c2 run committed with the profiles (a whole QVH clip step of the oracle on a GPU box's host:
+        # minutes), shown beside the live C1 sample so the scale-up by FLOPs can be judged; `value` stays the live, C1-scaled number
+        for name in ("r03_cpu_baseline_c2.json", "r02_cpu_baseline_c2.json"):
+            ref = os.path.join(ROOT, "profiles", name)
+            if os.path.exists(ref):
+                c2 = json.load(open(ref)).get("c2")
+                if c2:
+                    out["c2_committed_run"] = dict(clips_per_s=round(c2["clips_per_s"], 5), fwd_s=c2["fwd_s"], bwd_s=c2["bwd_s"],
+                                                   source=f"profiles/{name} (python bench.py --cpu-baseline-c2, earlier box, not this run)")
+                    break
     return out
 
 
@@ -248,6 +253,8 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: one blocking all-reduce after the backward instead of the overlapped exchange")
     ap.add_argument("--no-lookahead", action="store_true", help="do not overlap the next clip's frozen-ViT forward with this step's decoder")
     ap.add_argument("--lookahead-blocks", type=int, default=0, help="ViT blocks run ahead beside the decoder (0 = engine default)")
+    ap.add_argument("--vary-text", action="store_true", help="cycle 8 queries of different token counts (S_enc changes every step, as in a real "
+                    "QVH epoch: blip2_mr.py:572-824) instead of one fixed prompt; the headline number keeps the fixed prompt")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -283,6 +290,18 @@ def main():
     samples = synthetic_samples(B, wl["T"], wl["duration"], dev, 1234 + rank)
     layout = P.build_layout(tok, samples, repl, 1 if wl["mean_pool"] else cfg.num_query, T=wl["T"])
     video = samples["video"]
+    layouts = [layout]
+    if args.vary_text:   # 8 queries, 3 .. 31 words: the encoder length changes on every step (workspaces are capacity-based views: engine.buf)
+        words = ("a person opens the red door and walks into the kitchen while the small dog sleeps on the sofa near the window and "
+                 "a child builds a tower of wooden blocks on the floor").split()
+        layouts = []
+        for nw, win in zip((3, 31, 11, 23, 7, 27, 15, 19), ("[[8, 16]]", "[[2, 10], [40, 52]]", "[[30, 44]]", "[[8, 16]]", "[[100, 120]]",
+                                                            "[[0, 6], [20, 28], [60, 70]]", "[[8, 16]]", "[[72, 96]]")):
+            s_i = dict(samples)
+            s_i["query_prompt"] = ["Query: " + " ".join(words[:nw]) + "\n"] * B
+            s_i["relevant_windows"] = [win] * B
+            layouts.append(P.build_layout(tok, s_i, repl, 1 if wl["mean_pool"] else cfg.num_query, T=wl["T"]))
+        eng.reserve(min(l.S for l in layouts), max(l.S for l in layouts), min(l.labels.shape[1] for l in layouts), max(l.labels.shape[1] for l in layouts))
 
     # HIP events around the dominant kernel's launches (ViT fc1: gemm_tile_kernel 15420x6144x1408 at T=60, B=1)
     probe_events = []
@@ -292,15 +311,28 @@ def main():
     from mrblip.dist import GradExchange
     exchange = GradExchange(eng, overlap=not args.no_overlap) if world > 1 else None
 
+    step_no = [0]
+    host_s = []      # host time spent enqueueing one step (the host never waits for the GPU inside a step)
+
     def step(lr=3e-4, record=False):
+        t_h = time.perf_counter()
         eng.zero_grad()
         eng.probe = probe_events if record else None
         if exchange is not None:
             exchange.arm()
-        loss = eng.forward_backward(video, layout, backward=True, next_video=None if args.no_lookahead else video)
+        lay = layouts[step_no[0] % len(layouts)]
+        step_no[0] += 1
+        loss = eng.forward_backward(video, lay, backward=True, next_video=None if args.no_lookahead else video)
         scale = exchange.finish() if exchange is not None else 1.0
         eng.optimizer_step(lr=lr, weight_decay=0.05, grad_scale=scale)
+        if record:
+            host_s.append(time.perf_counter() - t_h)
         return loss
+
+    selftest = None
+    if world > 1:   # start-up check of the collective path (RCCL when every rank has its own GPU): wrong sums or a wrong rank count stop the run here
+        from mrblip.dist import rccl_selftest
+        selftest = rccl_selftest(dev)
 
     # the step runs on a HIGH-priority stream, the look-ahead ViT on a default (low) priority one: the decoder's small kernels are
     # dispatched ahead of the thousands of GEMM workgroups they share the CUs with
@@ -313,10 +345,12 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    launches0, allocs0 = ops.launch_count, eng.ws_allocations
     t0 = time.perf_counter()
     with torch.cuda.stream(main_stream):
         for _ in range(args.steps):
             loss = step(record=True)
+    launches = (ops.launch_count - launches0) / max(args.steps, 1)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -344,7 +378,7 @@ def main():
         m, n, k = F_ * 257, cfg.vit_mlp, cfg.vit_dim
         traffic_note = None
         traffic = None  # HBM-side bytes per launch of the same kernel from the committed PMC pass (tools/pmc_fc1.sh), QVH B=1 shape only
-        pmc = next((q for q in (os.path.join(ROOT, "profiles", n) for n in ("r02_pmc_fc1.json", "r01_pmc_fc1.json")) if os.path.exists(q)), None)
+        pmc = next((q for q in (os.path.join(ROOT, "profiles", n) for n in ("r03_pmc_fc1.json", "r02_pmc_fc1.json", "r01_pmc_fc1.json")) if os.path.exists(q)), None)
         if pmc and args.workload == "qvh" and B == 1 and F_ == 60:
             pj = json.load(open(pmc))
             traffic = pj.get("traffic_bytes_per_launch")
@@ -352,12 +386,15 @@ def main():
             traffic_note = ("bytes per launch at the L2s' memory side (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, %s): writes = algorithmic; reads are "
                             "L2 misses INCLUDING Infinity-Cache hits - each XCD's 4 MB L2 re-fetches the activation / weight panels its 32 CUs "
                             "share (algorithmic: %d B)" % (os.path.basename(pmc), pj.get("algorithmic_bytes_per_launch", 0)))
-        step_tf = step_tflop_per_clip(cfg, wl["T"], layout.S, layout.labels.shape[1], wl["mean_pool"])  # at the run's actual S / L_dec
+        # at the run's actual S / L_dec (--vary-text: the mean over the timed steps' prompts)
+        used = [layouts[(args.warmup + i) % len(layouts)] for i in range(args.steps)]
+        step_tf = sum(step_tflop_per_clip(cfg, wl["T"], l.S, l.labels.shape[1], wl["mean_pool"]) for l in used) / len(used)
         if durs:
             avg = sum(durs) / len(durs)
             ach = 2.0 * m * n * k / avg / 1e12
             roof = dict(bound="mfma", achieved=round(ach, 1), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_BF16_TFLOPS, 4),
-                        traffic=traffic, kernel="gemm_w4_kernel<bf16 out, bias+GELU> (ViT fc1 %dx%dx%d)" % (m, n, k), launches=len(durs),
+                        traffic=traffic, traffic_source=("committed PMC pass profiles/%s (tools/pmc_fc1.sh; not measured in this run)" % os.path.basename(pmc)) if traffic else None,
+                        kernel="gemm_w4_kernel<bf16 out, bias+GELU> (ViT fc1 %dx%dx%d)" % (m, n, k), launches=len(durs),
                         avg_us=round(avg * 1e6, 1))
             if traffic_note:
                 roof["traffic_note"] = traffic_note
@@ -382,12 +419,19 @@ def main():
             "config": {"workload": f"{args.workload}: ViT-g/14 + Q-Former(32) + Flan-T5-XL LoRA r=8 train step, {wl['T']} frames, S_enc={layout.S}, "
                                    f"L_dec={layout.labels.shape[1]}, random-init weights, dropout {'on' if eng.training else 'off'}",
                        "global_batch": global_batch, "batch_per_gpu": B, "frames": wl["T"], "parallelism": f"dp{world}",
-                       "vit_lookahead": not args.no_lookahead},
+                       "vit_lookahead": not args.no_lookahead,
+                       "vary_text": ([l.S for l in layouts] if args.vary_text else False)},
+            "launches_per_step": round(launches, 1),     # C-ABI kernel launches per step (torch-native ones: ~10, profiles/r02_native_in_step.txt)
+            "host_enqueue_ms": round(1e3 * sum(host_s) / max(len(host_s), 1), 2),   # host time to enqueue one step; must stay below ms_per_step
+            "workspace_allocations_in_timed_region": eng.ws_allocations - allocs0,
             "step_tflop_per_clip": round(step_tf, 3),
             "step_mfu": round(clips_s * step_tf / (world * PEAK_BF16_TFLOPS), 4),
             "loss": round(loss_v, 4),
             "roofline": roof,
         }
+        if selftest is not None:
+            out["collective_selftest"] = selftest   # {"backend": "nccl" (= RCCL), "ranks": N, "ok": true, "allreduce_ms": ...}
+            out["rccl_ranks"] = selftest["ranks"] if selftest.get("backend") == "nccl" else 0
         if world == 1 and not args.no_hbm_kernels:
             out["hbm_kernels"] = {"peak_GBps": PEAK_HBM_GBPS, "unit": "GB/s", "rows": hbm_kernel_report(eng, video, layout)}
         if not args.no_cpu_baseline and world == 1:

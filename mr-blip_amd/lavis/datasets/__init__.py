@@ -58,13 +58,17 @@ def default_frame_loader(path, n_frms, size, sampling="uniform", clip_proposal=N
 class MomentRetrievalDataset(_MRBase):
     """annotation JSON of {video, qid, query, duration, relevant_windows[, start, end]} (moment_retrieval_dataset.py:17-60).  Frames are
     decoded by ``frame_loader`` (default: lavis.datasets.data_utils.load_video) and handed on as **uint8** — the processor's
-    ToTensor + Normalize is fused into the patch-embed load on the GPU (a quarter of the H2D bytes)."""
+    ToTensor + Normalize is fused into the patch-embed load on the GPU (a quarter of the H2D bytes).
 
-    def __init__(self, ann_path, vis_root, n_frms=60, image_size=224, frame_loader=None, sampling="uniform", video_ext=".mp4"):
+    ``crop_scale`` = (min_scale, max_scale) switches on the train processor's augmentation (Blip2VideoTrainProcessor,
+    blip_processors.py:287-312): one RandomResizedCrop per clip, bicubic, shared by all frames; None (eval splits) = frames as decoded."""
+
+    def __init__(self, ann_path, vis_root, n_frms=60, image_size=224, frame_loader=None, sampling="uniform", video_ext=".mp4", crop_scale=None):
         self.ann = json.load(open(ann_path))
         self.vis_root, self.T, self.img = vis_root, n_frms, image_size
         self.frame_loader = frame_loader or default_frame_loader
         self.sampling, self.ext = sampling, video_ext
+        self.crop_scale = tuple(float(x) for x in crop_scale) if crop_scale else None
 
     def __len__(self):
         return len(self.ann)
@@ -85,6 +89,9 @@ class MomentRetrievalDataset(_MRBase):
             u8, idx, fps = self.frame_loader(self._path(a["video"]), self.T, self.img, sampling=self.sampling, clip_proposal=clip)
         except TypeError:  # a user-supplied loader with the short signature
             u8, idx, fps = self.frame_loader(self._path(a["video"]), self.T, self.img)
+        if self.crop_scale is not None:
+            from lavis.datasets.data_utils import random_resized_crop_u8
+            u8 = random_resized_crop_u8(u8, self.img, scale=self.crop_scale)
         ts = torch.tensor([round(float(k / fps), 2) for k in idx])
         return self._sample(u8, ts, a["duration"], a["query"], a["relevant_windows"], a["qid"])
 
@@ -112,19 +119,41 @@ class SyntheticBuilder(_Builder):
                 "val": SyntheticMomentRetrievalDataset(n_items=c.get("n_val", 4), seed=2, **kw)}
 
 
-@registry.register_builder("qvh")
-class QVHBuilder(_Builder):
-    DATASET_CONFIG_DICT = {"default": "configs/datasets/qvh/defaults.yaml"}
+class MomentRetrievalBuilder(_Builder):
+    """lavis/datasets/builders/moment_retrieval_builder.py:16-23 + base_dataset_builder.py: one MomentRetrievalDataset per annotation
+    split; the TRAIN split gets the train processor (random frame per interval + one RandomResizedCrop per clip, scale
+    [min_scale, max_scale] = [0.5, 1.0] unless the vis_processor config says otherwise), every other split the eval processor
+    (middle frame per interval, no crop).  Splits whose annotation file does not exist are skipped with a warning."""
 
     def build_datasets(self):
         info = self.config.build_info
-        vp = self.config.get("vis_processor", {}).get("train", {})
+        vps = self.config.get("vis_processor", {})
         out = {}
         for split, ann in info.annotations.items():
-            if os.path.isfile(str(ann.storage)):
-                out[split] = MomentRetrievalDataset(ann.storage, info.videos.storage, n_frms=vp.get("n_frms", 60), image_size=vp.get("image_size", 224),
-                                                    sampling="random" if split == "train" else "uniform")
+            if not os.path.isfile(str(ann.storage)):
+                continue
+            is_train = split == "train"
+            vp = vps.get("train" if is_train else "eval", None) or vps.get("train", None) or vps.get("eval", None) or {}
+            crop = (vp.get("min_scale", 0.5), vp.get("max_scale", 1.0)) if is_train and vp.get("name", "blip2_video_train") == "blip2_video_train" else None
+            out[split] = MomentRetrievalDataset(ann.storage, info.videos.storage, n_frms=vp.get("n_frms", 60), image_size=vp.get("image_size", 224),
+                                                sampling="random" if is_train else "uniform", crop_scale=crop)
         if not out:
             import logging
-            logging.warning("qvh builder: none of the annotation files %s exists — no dataset was built", {k: str(v.storage) for k, v in info.annotations.items()})
+            logging.warning("%s builder: none of the annotation files %s exists — no dataset was built", type(self).__name__,
+                            {k: str(v.storage) for k, v in info.annotations.items()})
         return out
+
+
+@registry.register_builder("qvh")
+class QVHBuilder(MomentRetrievalBuilder):
+    DATASET_CONFIG_DICT = {"default": "configs/datasets/qvh/defaults.yaml"}
+
+
+@registry.register_builder("charades_sta")
+class Charades_STABuilder(MomentRetrievalBuilder):   # moment_retrieval_builder.py:51-55
+    DATASET_CONFIG_DICT = {"default": "configs/datasets/charades_sta/defaults.yaml"}
+
+
+@registry.register_builder("anet")
+class ANetBuilder(MomentRetrievalBuilder):           # moment_retrieval_builder.py:79-83
+    DATASET_CONFIG_DICT = {"default": "configs/datasets/anet/defaults.yaml"}

@@ -103,3 +103,48 @@ def load_video(video_path, n_frms=MAX_INT, height=-1, width=-1, sampling="unifor
     vlen, fps, get = _open(video_path, height, width)
     indices = sample_frame_indices(vlen, fps, n_frms, sampling, clip_proposal)
     return get(indices), indices, fps
+
+
+# ---- train-split augmentation of the reference's "blip2_video_train" processor (lavis/processors/blip_processors.py:287-312):
+# transforms_video.RandomResizedCropVideo(image_size, scale=(min_scale, max_scale), interpolation_mode="bicubic") — ONE crop per clip,
+# shared by all frames — then ToUint8 -> ToTensorVideo -> Normalize.  The crop + bicubic resize run here on the decoded frames; the
+# /255 + Normalize stay fused in the patch-embed load on the GPU (uint8 hand-over).
+def random_resized_crop_params(height: int, width: int, scale=(0.5, 1.0), ratio=(3.0 / 4.0, 4.0 / 3.0), rng=rnd):
+    """(i, j, h, w) of torchvision's RandomResizedCrop.get_params, which the reference's RandomResizedCropVideo inherits
+    (lavis/processors/transforms_video.py:53-83): ten attempts at area ~ U(scale) * H * W, log-uniform aspect ratio; else the central
+    crop with the ratio clamped into ``ratio``."""
+    import math
+
+    area = height * width
+    log_ratio = (math.log(ratio[0]), math.log(ratio[1]))
+    for _ in range(10):
+        target_area = area * rng.uniform(scale[0], scale[1])
+        aspect = math.exp(rng.uniform(log_ratio[0], log_ratio[1]))
+        w = int(round(math.sqrt(target_area * aspect)))
+        h = int(round(math.sqrt(target_area / aspect)))
+        if 0 < w <= width and 0 < h <= height:
+            i = rng.randint(0, height - h)
+            j = rng.randint(0, width - w)
+            return i, j, h, w
+    in_ratio = float(width) / float(height)
+    if in_ratio < min(ratio):
+        w = width
+        h = int(round(w / min(ratio)))
+    elif in_ratio > max(ratio):
+        h = height
+        w = int(round(h * max(ratio)))
+    else:
+        w, h = width, height
+    return (height - h) // 2, (width - w) // 2, h, w
+
+
+def random_resized_crop_u8(frames: torch.Tensor, size: int, scale=(0.5, 1.0), rng=rnd) -> torch.Tensor:
+    """uint8 [T, 3, H, W] -> uint8 [T, 3, size, size]: crop (i, j, h, w) of every frame, bicubic resize (align_corners=False, as
+    functional_video.resize), truncation to uint8 (the reference's ToUint8 is ``tensor.to(torch.uint8)``: truncation toward zero).
+    Deviation, deliberate: bicubic overshoot outside [0, 255] is clamped — the reference's bare cast wraps it around (a white pixel
+    overshooting to 256.3 becomes 0), which is an upstream accident, not a recipe."""
+    T, C, H, W = frames.shape
+    i, j, h, w = random_resized_crop_params(H, W, scale=scale, rng=rng)
+    crop = frames[:, :, i: i + h, j: j + w].float()
+    out = torch.nn.functional.interpolate(crop, size=(size, size), mode="bicubic", align_corners=False)
+    return out.clamp_(0, 255).to(torch.uint8)

@@ -21,7 +21,7 @@ class BaseModel(nn.Module):
         """checkpoint["model"] -> non-strict load (base_model.py:29-56).  URLs are not fetchable here (no network)."""
         if not os.path.isfile(url_or_filename):
             raise RuntimeError("checkpoint url or path is invalid")
-        checkpoint = torch.load(url_or_filename, map_location="cpu")
+        checkpoint = torch.load(url_or_filename, map_location="cpu", weights_only=True)  # tensors / plain containers only
         state_dict = checkpoint["model"] if "model" in checkpoint else checkpoint
         msg = self.load_state_dict(state_dict, strict=False)
         logging.info("Missing keys {}".format(msg.missing_keys))

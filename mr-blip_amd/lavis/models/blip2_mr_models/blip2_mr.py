@@ -46,10 +46,7 @@ class _TrainStep(torch.autograd.Function):
         model = ctx.model
         eng = model.engine
         if model._fused_scale is not None:
-            got = float(g)
-            if abs(got - model._fused_scale) > 1e-6 * abs(model._fused_scale):
-                raise RuntimeError(f"fused gradient accumulation expects the loss scale {model._fused_scale}, got {got}; "
-                                   "call model.end_accumulation() to use arbitrary loss scaling")
+            model._check_fused_scale(g)   # (device-side compare, read one step late: no host sync behind ~2900 queued launches)
             return None, None, None, None, None, None, None
         model._ensure_named_grads()
         nd = eng.n_decay
@@ -188,6 +185,52 @@ class BLIP2_MR(BaseModel):
         """factor AdamW applies to grad_buffer() (fused mode: the loss scale the engine did not apply)"""
         return self._fused_scale if self._fused_scale is not None else 1.0
 
+    # The upstream scale of loss.backward() must be the announced one in fused mode.  ``g`` lives on the device and the stream is ~2900
+    # launches deep at that point: float(g) would drain it (and the host would then re-fill the queue while the GPU idles).  The
+    # comparison therefore runs on the device, its verdict travels to pinned host memory behind the step, and it is READ one step late
+    # (or at end_accumulation / by check_fused_scale_now) — the same trick as the train loop's one-step-late loss.item().
+    _scale_flag_dev = None
+    _scale_flag_host = None
+    _scale_flag_event = None
+
+    def _check_fused_scale(self, g):
+        if not g.is_cuda:   # a host scalar costs nothing to read
+            if abs(float(g) - self._fused_scale) > 1e-6 * abs(self._fused_scale):
+                raise RuntimeError(self._fused_scale_message(float(g)))
+            return
+        self._raise_if_scale_violation(block=False)   # verdict of an EARLIER micro-step, if it has arrived
+        if self._scale_flag_dev is None:
+            self._scale_flag_dev = torch.zeros(2, dtype=torch.float32, device=g.device)
+            self._scale_flag_host = torch.zeros(2, dtype=torch.float32).pin_memory()
+        bad = ((g.detach().reshape(()).float() - self._fused_scale).abs() > 1e-6 * abs(self._fused_scale)).float()
+        self._scale_flag_dev[0] += bad                 # sticky: counts the violations of the run
+        self._scale_flag_dev[1] = torch.where(bad > 0, g.detach().reshape(()).float(), self._scale_flag_dev[1])
+        self._scale_flag_host.copy_(self._scale_flag_dev, non_blocking=True)
+        self._scale_flag_event = torch.cuda.Event()
+        self._scale_flag_event.record()
+
+    def _fused_scale_message(self, got):
+        return (f"fused gradient accumulation expects the loss scale {self._fused_scale}, got {got}; "
+                "call model.end_accumulation() to use arbitrary loss scaling")
+
+    def _raise_if_scale_violation(self, block: bool):
+        ev = self._scale_flag_event
+        if ev is None:
+            return
+        if block:
+            ev.synchronize()
+        elif not ev.query():
+            return
+        if float(self._scale_flag_host[0]) > 0:
+            got = float(self._scale_flag_host[1])
+            self._scale_flag_dev.zero_()
+            self._scale_flag_event = None
+            raise RuntimeError(self._fused_scale_message(got))
+
+    def check_fused_scale_now(self):
+        """blocking form of the deferred loss-scale check (tests; end of an epoch)"""
+        self._raise_if_scale_violation(block=True)
+
     def begin_accumulation(self, loss_scale: float = 1.0):
         """fused mode (see _TrainStep): micro-step gradients accumulate in the engine's buffer; every loss.backward() of the window
         must come with the upstream scale ``loss_scale``"""
@@ -195,6 +238,7 @@ class BLIP2_MR(BaseModel):
         self._bind_grads(self.engine.grad)
 
     def end_accumulation(self):
+        self._raise_if_scale_violation(block=True)
         self._fused_scale = None
         self._bind_grads(self.flat_grad)
 
@@ -221,8 +265,13 @@ class BLIP2_MR(BaseModel):
             if backbone_missing:
                 raise RuntimeError("incomplete backbone weights (vit_weights / pretrained / t5_weights): %s" % CK.describe(dict(missing=backbone_missing)))
             if "t5_proj.weight" in report["missing"]:   # a BLIP-2 file without t5_proj: the reference keeps its fresh nn.Linear init (blip2_mr.py:270-272)
-                lin = torch.nn.Linear(probe.qf_dim, probe.d_model)
-                weights["t5_proj.weight"], weights["t5_proj.bias"] = lin.weight.detach(), lin.bias.detach()
+                # nn.Linear's default init (kaiming_uniform(a=sqrt(5)) = U(-1/sqrt(in), 1/sqrt(in)) for weight and bias) from a FIXED-seed
+                # generator: the global RNG is seeded with run.seed + rank (train.py) and nothing broadcasts the trainable tensors from
+                # rank 0 as the reference's DDP wrapper does — data-parallel replicas must start from identical t5_proj weights
+                gen = torch.Generator().manual_seed(4322)
+                bound = 1.0 / (probe.qf_dim ** 0.5)
+                weights["t5_proj.weight"] = (torch.rand(probe.d_model, probe.qf_dim, generator=gen) * 2 - 1) * bound
+                weights["t5_proj.bias"] = (torch.rand(probe.d_model, generator=gen) * 2 - 1) * bound
             if "ln_vision.weight" in report["missing"]:
                 weights["ln_vision.weight"], weights["ln_vision.bias"] = torch.ones(probe.vit_dim), torch.zeros(probe.vit_dim)
         model = cls(
@@ -256,6 +305,7 @@ class BLIP2_MR(BaseModel):
         return v.to(self._device) if v.dtype == torch.uint8 else v.to(self._device, torch.float32)
 
     _staged_next = None  # (host tensor of the next batch's frames, its device copy): see forward()
+    _reserved = False    # engine workspaces sized for the longest step (first forward)
     generate_cross_cache = True  # project the decoder's cross-attention K/V once per clip (False: per step and beam, for the A/B test)
     generate_self_cache = True   # self-attention K/V cache: one new position per decoding step (False: re-run the prefix, for the A/B test)
 
@@ -269,6 +319,14 @@ class BLIP2_MR(BaseModel):
             video = self._frames_to_device(src)
         self._staged_next = None
         layout = self._layout(samples)
+        if not self._reserved:
+            # the encoder length follows the query's token count, the decoder length the answer's (blip2_mr.py:572-824): size every
+            # workspace ONCE for the longest step this configuration can produce (text truncated to max_txt_len tokens; timestamps of
+            # later clips may tokenise a little longer than this first one: +12 %), so that the epoch's stream of different lengths
+            # neither allocates nor synchronises (engine.buf / engine.reserve)
+            # (the decoder's few-row buffers are left to grow on demand — a longer answer than any seen so far costs one re-allocation)
+            self.engine.reserve(layout.S, int(layout.S * 1.12) + int(self.max_txt_len))
+            self._reserved = True
         need_grad = torch.is_grad_enabled() and (self.trainable_decay.requires_grad or self.trainable_no_decay.requires_grad)
         if self.engine.flat._version != self._flat_version:
             # a torch-side optimizer / load wrote the trainable buffer through one of its aliases (the engine's own AdamW kernel does

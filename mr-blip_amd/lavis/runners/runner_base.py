@@ -76,17 +76,28 @@ class RunnerBase:
                                       warmup_steps=run.get("warmup_steps", 0))
         # data parallel: fused accumulation (the gradients of a window's micro-steps add up in the engine's flat buffer) + ONE overlapped exchange
         self.exchange = None
+        self._loaders = {}
+        multi = is_dist_avail_and_initialized() and get_world_size() > 1
         if hasattr(model, "begin_accumulation"):
             model.begin_accumulation(1.0)
-            if is_dist_avail_and_initialized() and get_world_size() > 1:
-                from mrblip.dist import GradExchange
-                self.exchange = GradExchange(model.engine)
+            if multi:
+                from mrblip.dist import GradExchange, broadcast_trainable
+                # what the reference's DDP wrapper does at construction (runner_base.py:89-96): replicas start from rank 0's trainable tensors
+                broadcast_trainable(model.engine)
+                # the buffer AdamW reads: the engine's own flat gradient in fused mode (segments are then sent from inside the backward),
+                # model.flat_grad after end_accumulation() (one all-reduce at finish())
+                self.exchange = GradExchange(model.engine, buffer=model.grad_buffer)
+        elif multi:
+            raise RuntimeError("runner_base: data-parallel training needs a model with a flat gradient buffer (begin_accumulation / grad_buffer, "
+                               "i.e. blip2_mr on the MI355X engine); no generic per-parameter all-reduce is built")
         if run.get("resume_ckpt_path"):
             self._load_checkpoint(run.resume_ckpt_path)
 
     # ---- data
     def _loader(self, split, is_train):
         run = self.config.run_cfg
+        if (split, is_train) in self._loaders:   # one loader (worker pool + pinned-memory thread) per split for the whole run
+            return self._loaders[(split, is_train)]
         ds = None
         for name, splits in self.datasets.items():
             if split in splits:
@@ -102,6 +113,7 @@ class RunnerBase:
         if torch.cuda.is_available() and run.get("prefetch_to_device", True):
             from lavis.datasets.dataloader_utils import PrefetchLoader
             loader = PrefetchLoader(loader, device=getattr(self.model, "device", None))   # dataloader_utils.py:46-125 (side-stream H2D)
+        self._loaders[(split, is_train)] = loader
         return loader
 
     def _reduce_grads(self):
@@ -166,7 +178,7 @@ class RunnerBase:
             logging.warning("no %s (validation never produced a best checkpoint): evaluating the current weights", path)
             return model
         logging.info("Loading checkpoint from {}.".format(path))
-        ck = torch.load(path, map_location="cpu")
+        ck = torch.load(path, map_location="cpu", weights_only=True)   # tensors + plain containers only: never unpickle code from a path
         try:
             model.load_state_dict(ck["model"], strict=True)
         except RuntimeError:
@@ -195,7 +207,7 @@ class RunnerBase:
         torch.save(obj, path)
 
     def _load_checkpoint(self, path):
-        ck = torch.load(path, map_location="cpu")
+        ck = torch.load(path, map_location="cpu", weights_only=True)
         self.model.load_state_dict(ck["model"], strict=True)
         self.optimizer.load_state_dict(ck["optimizer"])
         self.start_epoch = ck["epoch"] + 1

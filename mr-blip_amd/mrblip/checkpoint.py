@@ -139,7 +139,7 @@ def load_file(path: str) -> Dict[str, torch.Tensor]:
         from safetensors.torch import load_file as st_load
 
         return st_load(path)
-    ck = torch.load(path, map_location="cpu")
+    ck = torch.load(path, map_location="cpu", weights_only=True)   # user-supplied path: tensors and plain containers only
     return ck["model"] if isinstance(ck, dict) and "model" in ck and isinstance(ck["model"], dict) else ck
 
 

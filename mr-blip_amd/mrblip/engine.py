@@ -166,6 +166,7 @@ class MrBlipEngine:
             seed = int(torch.initial_seed()) & 0x7FFFFFFF
         self.cfg, self.dev = cfg, device
         self.ws: Dict[str, torch.Tensor] = {}
+        self._store: Dict[str, torch.Tensor] = {}
         self.training = True
         self.seed = torch.tensor([seed & 0x7FFFFFFF], dtype=torch.int32, device=device)
         self.hyper = torch.tensor([0.0, 1.0, 1.0, 1.0], dtype=f32, device=device)
@@ -183,18 +184,49 @@ class MrBlipEngine:
 
     # ------------------------------------------------------------------------------------------ utilities
     def buf(self, name: str, shape, dtype, zero: bool = True) -> torch.Tensor:
-        t = self.ws.get(name)
+        """Named workspace of the step.  CAPACITY based: the backing store of a name is allocated once (zero-filled) for the largest
+        size asked for so far — times ``ws_headroom``, which the caller raises before the first step when it knows that later steps
+        will be longer (``reserve``) — and every request gets a contiguous VIEW of its leading elements.  The sequence length of the
+        T5 encoder follows the query's token count (blip2_mr.py:572-824), so S changes on nearly every step of a real run: no
+        allocation, no zero-fill and no host synchronisation happens after the longest shape has been seen.
+
+        Why views are safe for the zero-padded operands: padding is either COLUMN padding at fixed positions of a row (K padded to
+        64, the 8 n_adapter columns of the [M, 64] LoRA activations: never written, so they stay at their initial zeros whatever the
+        row count), or it is written by the producing kernel itself on every call (head_transpose writes the whole [DP, Spad] tile
+        with zeros outside the tensor; pad_mask builds a fresh mask), or it is never read (LSE / Delta / keep-bit rows past Sq)."""
         shape = tuple(int(s) for s in shape)
-        if t is None or tuple(t.shape) != shape or t.dtype != dtype:
-            t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.dev)
+        n = 1
+        for v in shape:
+            n *= v
+        store = self._store.get(name)
+        if store is None or store.dtype != dtype or store.numel() < n:
+            cap = max(n, int(n * self.ws_headroom)) if store is None else max(n, int(store.numel() * 1.25))
+            store = torch.zeros(cap, dtype=dtype, device=self.dev)
+            self._store[name] = store
+            self.ws_allocations += 1
+            # the zero fill runs on the CURRENT stream, but workspaces are shared by the engine's streams (gradient side stream,
+            # ViT look-ahead stream): a buffer created on the main stream and first written on a side stream could be zeroed AFTER
+            # that write (seen as a wrong first-step loss when two ranks shared one GPU); and a store that is REPLACED may still be
+            # read by queued kernels.  (Re)allocation happens once per buffer (first step / a new longest shape), so simply let
+            # everything finish before anything else is enqueued.
+            torch.cuda.synchronize(self.dev)
+        t = self.ws.get(name)
+        if t is None or tuple(t.shape) != shape or t.dtype != dtype or t.untyped_storage().data_ptr() != store.untyped_storage().data_ptr():
+            t = store[:n].view(shape)
             self.ws[name] = t
-            if zero:
-                # the zero fill runs on the CURRENT stream, but workspaces are shared by the engine's streams (gradient side stream,
-                # ViT look-ahead stream): a buffer created on the main stream and first written on a side stream could be zeroed AFTER
-                # that write (seen as a wrong first-step loss when two ranks shared one GPU).  Creation happens once per buffer
-                # (first step / shape change), so simply let the fill finish before anything else is enqueued.
-                torch.cuda.current_stream().synchronize()
         return t
+
+    ws_headroom = 1.0      # over-allocation factor of workspaces created from now on (see reserve)
+    ws_allocations = 0     # (re)allocations so far: constant after warm-up, also over a stream of different sequence lengths
+
+    def reserve(self, S: int, S_max: int, Ld: int = 1, Ld_max: int = 1):
+        """Call before the first step (whose encoder / decoder lengths are S / Ld) when later steps can be as long as S_max / Ld_max:
+        every workspace the first step creates is over-allocated so that the longest step fits.  Workspaces grow with S (rows), a
+        few with S^2 (attention keep bits) or S * Ld (cross-attention) — one factor covers them all; it multiplies ~3 GB of
+        activations of the QVH step by ~1.2 (max_txt_len 200 against a 40-token query), against 288 GB of HBM."""
+        rs = max(1.0, (S_max + 31) // 32 * 32 / max(S, 1))
+        rl = max(1.0, (Ld_max + 31) // 32 * 32 / max((Ld + 31) // 32 * 32, 1)) if Ld_max > Ld else 1.0
+        self.ws_headroom = max(self.ws_headroom, rs * rs, rs * rl) * 1.01
 
     def h2d(self, t: torch.Tensor, dtype=None) -> torch.Tensor:
         """small host tensor -> device WITHOUT stalling the host on the stream (a pageable copy makes the host wait until the stream
@@ -1256,14 +1288,26 @@ class MrBlipEngine:
         return r[1]
 
     @torch.no_grad()
-    def forward_backward(self, video: torch.Tensor, layout: EncoderLayout, backward: bool = True, next_video: Optional[torch.Tensor] = None):
+    def forward_backward(self, video: torch.Tensor, layout: EncoderLayout, backward: bool = True, next_video: Optional[torch.Tensor] = None,
+                         shard=None):
         """One micro-step: loss (device scalar) and, if ``backward``, gradients accumulated into self.grad.  ``next_video`` (optional):
-        the next step's clip, whose frozen-ViT forward is overlapped with this step's decoder (see prefetch_vit)."""
+        the next step's clip, whose frozen-ViT forward is overlapped with this step's decoder (see prefetch_vit).
+
+        ``shard`` (mrblip.dist.FrameShard, optional): frame-sharded long-video mode (blip2_mr.py:444-445 — [B, T] is
+        just a batch through ViT + Q-Former).  ``video`` then holds only THIS rank's frames [1, T_r, 3, IMG, IMG] of one clip whose
+        ``layout`` describes all T frames: ViT / ln_vision / Q-Former / t5_proj run on the local frames, ONE all-gather assembles the
+        [T * n, d_model] frame tokens on every rank, the T5 (replicated: same clip, same prompt, same dropout seed on every rank of
+        the group) runs in full, and each rank continues the backward with ITS rows of the frame-token gradient — the replicated T5
+        produced the same gradient everywhere, so the "reduce-scatter" of a sharded T5 degenerates to a slice.  The LoRA gradients
+        are then identical on all ranks; t5_proj / ln_vision gradients are partial sums over local frames (FrameShard.combine_grads)."""
         c = self.cfg
         Bv, T = video.shape[:2]
         F_ = Bv * T
         S, d = layout.S, c.d_model
         n = 1 if c.mean_pool else c.num_query
+        sharded = shard is not None and shard.world > 1
+        if sharded:
+            assert Bv == 1 and T == shard.counts[shard.rank], "frame-sharded mode: one clip, this rank's frames only"
         if self.training:
             ops.seed_bump(self.seed)
         self._mark("start")
@@ -1272,6 +1316,10 @@ class MrBlipEngine:
         dev = self.dev
         L = self._layout_dev(layout)
         inp = self.buf("inputs_embeds", (Bv * S, d), f32, zero=False)
+        if sharded:
+            fr_all = self.buf("frames_gathered", (shard.T * n, d), f32, zero=False)
+            shard.gather_rows(fr, n, fr_all)
+            fr = fr_all
         ops.row_copy(fr, L["frame_src"], inp, L["frame_dst"])
         ops.row_copy(self.emb, L["emb_src"], inp, L["emb_dst"])
         kmask = L["mask"]
@@ -1295,8 +1343,10 @@ class MrBlipEngine:
             # runs beside the t5_proj / Q-Former backward below (mrblip/dist.py: GradExchange)
             self.grad_ready_hook("lora")
         # interleave backward: only frame-token rows carry gradient (embeddings are frozen)
-        dfr = self.buf("dframes", (F_ * n, d), f32)
+        dfr = self.buf("dframes", ((shard.T if sharded else F_) * n, d), f32)
         ops.row_copy(dinp, L["frame_dst"], dfr, L["frame_src"])
+        if sharded:
+            dfr = shard.local_rows(dfr, n)
         if c.mean_pool:
             dfull = self.buf("dframes_full", (F_, c.num_query, d), f32, zero=False)
             ops.mean_pool_bwd(dfr, dfull)

@@ -90,7 +90,12 @@ EXPORTS = [
 ]
 
 
+launch_count = 0  # C-ABI calls so far (each is one kernel launch, mrblip_attention_bwd two): bench.py reports the per-step difference
+
+
 def _chk(rc: int):
+    global launch_count
+    launch_count += 1
     if rc != 0:
         raise MrblipError(_lib.mrblip_last_error().decode())
 

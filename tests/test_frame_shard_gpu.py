@@ -1,0 +1,49 @@
+"""SURVEY.md §8(f4), first half: ONE clip's frames split across ranks through ViT + ln_vision + Q-Former + t5_proj (blip2_mr.py:444-445:
+[B, T] is just a batch there), one all-gather of the [T * n, d_model] frame tokens, replicated T5.  Two ranks share the test box's GPU
+over gloo (tests/shard_worker.py); the sharded step must equal the unsharded step of the same clip: loss, LoRA gradients (computed
+identically on every rank) and the t5_proj / ln_vision gradients (summed over the ranks' local frames)."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+from util import check, free_port, load_golden, golden_state_dict, relerr  # noqa: E402
+
+
+@pytest.mark.parametrize("mean", [0, 1])
+def test_frame_sharded_step_equals_unsharded(tmp_path, mean):
+    from mrblip import prompt as P
+    from mrblip.engine import EngineConfig, MrBlipEngine, StateDictSource
+    from mrblip.tokenizer import FixtureTokenizer
+    from test_model_gpu import _peft_sd, _samples
+
+    out = str(tmp_path / "shard.pt")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+           str(free_port()), os.path.join(ROOT, "tests", "shard_worker.py"), out, str(mean)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-3000:])
+    sh = torch.load(out)
+    assert sh["counts"] == [2, 1]   # 3 frames over 2 ranks: the ragged split
+    g = load_golden("mr_tiny_mean" if mean else "mr_tiny")
+    tok = FixtureTokenizer()
+    repl = P.annoying_replacement_dict(P.find_annoying_numbers(tok, 200)[0])
+    s = {k: v[:1] for k, v in _samples(g).items()}
+    eng = MrBlipEngine(EngineConfig.tiny(mean_pool=bool(mean)), StateDictSource(_peft_sd(golden_state_dict(g))), torch.device("cuda:0"), seed=42)
+    eng.training = False
+    lay = P.build_layout(tok, s, repl, 1 if mean else 8, T=3)
+    eng.zero_grad()
+    loss = eng.forward_backward(s["video"].cuda(), lay, backward=True).item()
+    ref = eng.grad.cpu()
+    nl = sh["n_lora"]
+    tag = "frame-shard x2 (mean_pool=%d): " % mean
+    check(tag + "loss vs unsharded", abs(sh["loss"] - loss) / abs(loss), 2e-6)
+    check(tag + "LoRA grads vs unsharded", relerr(sh["grad"][:nl], ref[:nl]), 2e-5)
+    check(tag + "LoRA grads rank 1 vs rank 0 (replicated T5)", relerr(sh["grad_other"][:nl], sh["grad"][:nl]), 1e-7)
+    check(tag + "t5_proj / ln_vision grads (summed over ranks) vs unsharded", relerr(sh["grad"][nl:], ref[nl:]), 2e-5)
+    check(tag + "combined tail identical on both ranks", relerr(sh["grad_other"][nl:], sh["grad"][nl:]), 1e-7)
+    assert ref[nl:].abs().sum() > 0

@@ -55,3 +55,76 @@ def test_load_video_from_frame_dump_and_dataset_contract(tmp_path):
     assert tuple(b["video"].shape) == (2, 6, 3, 32, 32) and b["video"].dtype == torch.uint8 and tuple(b["timestamps"].shape) == (2, 6)
     with pytest.raises(FileNotFoundError):
         load_video(str(tmp_path / "missing.mp4"), n_frms=4)
+
+
+def test_train_split_random_resized_crop(tmp_path):
+    """ADVICE r2 / blip_processors.py:287-312: the train processor crops ONE random region per clip (scale 0.5..1 of the area, aspect
+    3/4..4/3), bicubic-resizes it to image_size and shares it across the frames; eval splits are not cropped."""
+    import lavis  # noqa: F401
+    from lavis.datasets import MomentRetrievalDataset
+    from lavis.datasets.data_utils import random_resized_crop_params, random_resized_crop_u8
+
+    rng = random.Random(3)
+    for _ in range(300):
+        H, W = rng.choice([(224, 224), (180, 320), (256, 144)])
+        i, j, h, w = random_resized_crop_params(H, W, scale=(0.5, 1.0), rng=rng)
+        assert 0 <= i and i + h <= H and 0 <= j and j + w <= W and h > 0 and w > 0
+        assert 0.49 <= h * w / (H * W) <= 1.0 + 1e-9, (h, w, H, W)
+        assert 0.73 <= w / h <= 1.37
+    # shared across frames: identical input frames give identical output frames, and a gradient image stays monotone after the crop
+    ramp = torch.arange(64, dtype=torch.float32).view(1, 1, 1, 64).expand(5, 3, 64, 64).mul(3).to(torch.uint8).contiguous()
+    out = random_resized_crop_u8(ramp, 32, rng=random.Random(1))
+    assert out.dtype == torch.uint8 and tuple(out.shape) == (5, 3, 32, 32)
+    assert all(torch.equal(out[0], out[k]) for k in range(1, 5))
+    assert (out[0, 0, 0, 1:].int() - out[0, 0, 0, :-1].int()).min() >= 0
+    assert not torch.equal(random_resized_crop_u8(ramp, 32, rng=random.Random(1)), random_resized_crop_u8(ramp, 32, rng=random.Random(2)))
+    # dataset: train split (crop_scale) differs from the eval decode of the same clip, eval is the plain resize
+    rs = np.random.RandomState(0)
+    np.savez(tmp_path / "v.npz", frames=rs.randint(0, 256, (40, 48, 48, 3), dtype=np.uint8), fps=np.float64(10.0))
+    json.dump([{"video": "v", "qid": 1, "query": "q", "duration": 4.0, "relevant_windows": [[1, 2]]}], open(tmp_path / "a.json", "w"))
+    ev = MomentRetrievalDataset(str(tmp_path / "a.json"), str(tmp_path), n_frms=4, image_size=32)
+    tr = MomentRetrievalDataset(str(tmp_path / "a.json"), str(tmp_path), n_frms=4, image_size=32, crop_scale=(0.5, 1.0))
+    random.seed(5)
+    a, b = ev[0]["video"], tr[0]["video"]
+    assert a.dtype == b.dtype == torch.uint8 and a.shape == b.shape == (4, 3, 32, 32) and not torch.equal(a, b)
+    assert torch.equal(ev[0]["video"], a)
+
+
+@pytest.mark.parametrize("name,builder,n_frms,bs,accum,world", [("charades", "charades_sta", 20, 8, 1, 4), ("anet", "anet", 60, 1, 4, 8), ("qvh", "qvh", 60, 1, 8, 8)])
+def test_project_configs_of_every_benchmark_dataset(tmp_path, name, builder, n_frms, bs, accum, world):
+    """BASELINE.json configs 2-5 through the real entry point: lavis/projects/mr_BLIP/{train,eval}/{qvh,charades,anet}.yaml resolve (builder
+    registered, dataset defaults merged, the reference's run values), and the builder gives the TRAIN split the train processor's crop."""
+    import argparse
+
+    import lavis  # noqa: F401
+    from lavis.common.config import Config
+    from lavis.common.registry import registry
+
+    rs = np.random.RandomState(1)
+    np.savez(tmp_path / "vid.npz", frames=rs.randint(0, 256, (70, 40, 40, 3), dtype=np.uint8), fps=np.float64(7.0))
+    ann = [{"video": "vid", "qid": k, "query": "someone opens a door", "duration": 10.0, "relevant_windows": [[2, 5]]} for k in range(3)]
+    for split in ("train", "val", "test"):
+        json.dump(ann, open(tmp_path / f"{split}.json", "w"))
+    for mode in ("train", "eval"):
+        path = os.path.join(ROOT, "mr-blip_amd", "lavis", "projects", "mr_BLIP", mode, name + ".yaml")
+        opts = [f"datasets.{builder}.build_info.annotations.{s}.storage={tmp_path}/{s}.json" for s in ("train", "val", "test")]
+        opts += [f"datasets.{builder}.build_info.videos.storage={tmp_path}"]
+        cfg = Config(argparse.Namespace(cfg_path=path, options=opts))
+        assert cfg.model_cfg.arch == "blip2_mr" and cfg.model_cfg.task == "qformer_freeze_lora" and cfg.model_cfg.freeze_vit is True
+        assert list(cfg.datasets_cfg) == [builder]
+        dcfg = cfg.datasets_cfg[builder]
+        assert dcfg.vis_processor.eval.n_frms == n_frms and dcfg.build_info.videos.storage == str(tmp_path)
+        if mode == "train":
+            r = cfg.run_cfg
+            assert (r.batch_size_train, r.accum_grad_iters, r.world_size, r.init_lr, r.weight_decay, r.num_beams) == (bs, accum, world, 3e-4, 0.05, 5)
+            assert dcfg.vis_processor.train.name == "blip2_video_train" and dcfg.vis_processor.train.n_frms == n_frms
+        dcfg.vis_processor.eval.image_size = 32     # (decode small: this test is about plumbing)
+        if "train" in dcfg.vis_processor:
+            dcfg.vis_processor.train.image_size = 32
+        ds = registry.get_builder_class(builder)(dcfg).build_datasets()
+        assert set(ds) == {"train", "val", "test"} and len(ds["train"]) == 3
+        if mode == "train":
+            assert ds["train"].crop_scale == (0.5, 1.0) and ds["train"].sampling == "random"
+        assert ds["val"].crop_scale is None and ds["val"].sampling == "uniform" and ds["test"].T == n_frms
+        s = ds["val"][0]
+        assert tuple(s["video"].shape) == (n_frms, 3, 32, 32) and s["video"].dtype == torch.uint8

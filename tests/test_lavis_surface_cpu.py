@@ -112,6 +112,30 @@ def _ddp_worker(rank, world, port, q):
     ex2 = GradExchange(eng2, overlap=False)
     ex2.arm()
     assert ex2.finish() == 0.5 and eng2.grad.tolist() == [3.0] * 13 and eng2.grad_ready_hook is None
+    # generic mode (the exchanged buffer is NOT the engine's own: model.grad_buffer() = flat_grad): nothing may be sent early, finish()
+    # reduces the buffer the optimizer will read
+    other = torch.full((13,), float(10 * (rank + 1)))
+    eng3 = types.SimpleNamespace(grad=torch.zeros(13), n_lora=10, grad_ready_hook=None)
+    ex3 = GradExchange(eng3, buffer=lambda: other)
+    ex3.arm()
+    assert eng3.grad_ready_hook is None
+    assert ex3.finish() == 0.5 and other.tolist() == [30.0] * 13 and eng3.grad.abs().sum() == 0
+    # start-up self-test of the collective path + DDP-style broadcast of the trainable tensors from rank 0
+    from mrblip.dist import FrameShard, broadcast_trainable, rccl_selftest
+    st = rccl_selftest(torch.device("cpu"), n=1024)
+    assert st["ok"] and st["ranks"] == world and st["backend"] == "gloo"
+    eng4 = types.SimpleNamespace(flat=torch.full((5,), float(rank + 7)), refresh_trainable=lambda: None)
+    broadcast_trainable(eng4)
+    assert eng4.flat.tolist() == [7.0] * 5
+    # frame sharding: 5 frames over 2 ranks = 3 + 2, 4 rows per frame; the gather restores frame order on every rank
+    fs = FrameShard(5)
+    assert fs.counts == [3, 2] and fs.starts == [0, 3] and (fs.t0, fs.t1) == ((0, 3) if rank == 0 else (3, 5))
+    full = torch.arange(5 * 4 * 2, dtype=torch.float32).view(20, 2)
+    got = fs.gather_rows(fs.local_rows(full, 4).clone(), 4, torch.zeros(20, 2))
+    assert torch.equal(got, full)
+    eng5 = types.SimpleNamespace(grad=torch.cat([torch.full((10,), 5.0), torch.full((3,), float(rank + 1))]), n_lora=10)
+    fs.combine_grads(eng5)
+    assert eng5.grad.tolist() == [5.0] * 10 + [3.0] * 3     # replicated LoRA segment untouched, local-frame segment summed
     # clips are sharded over ranks with no overlap (DistributedSampler, seed + rank)
     ds = SyntheticMomentRetrievalDataset(n_items=8, n_frms=2, image_size=14)
     idx = list(DistributedSampler(ds, num_replicas=world, rank=rank, shuffle=False))

@@ -199,3 +199,62 @@ def test_reference_named_parameters_with_a_stock_optimizer():
           max(abs(x - y) / abs(y) for x, y in zip(la, lb)), 4e-5)     # (two AdamW roundings + the bf16 re-pack of LoRA A/B: measured 1.5e-5)
     check("named-params: trainable buffer after 3 steps, torch AdamW vs fused AdamW",
           ((a.engine.flat - b.engine.flat).norm() / b.engine.flat.norm()).item(), 1e-4)
+
+
+@pytest.mark.parametrize("name,builder", [("charades", "charades_sta"), ("anet", "anet")])
+def test_train_py_charades_and_anet_configs(tmp_path, name, builder):
+    """BASELINE.json configs 4 / 5 through the REAL entry point (VERDICT r2 missing 3): train.py --cfg-path projects/mr_BLIP/train/{charades,anet}.yaml
+    with the annotation-JSON dataset on frame dumps (no codec / corpus in the image), tiny engine dimensions through --options; Charades additionally
+    with the 32 -> 1 mean-pool of configs[3].  One epoch of train + generate-based validation + checkpoint."""
+    import json
+
+    import numpy as np
+    import train
+    from lavis.common.registry import registry
+
+    rs = np.random.RandomState(7)
+    for v in range(2):
+        np.savez(tmp_path / f"vid{v}.npz", frames=rs.randint(0, 256, (48, 64, 64, 3), dtype=np.uint8), fps=np.float64(4.0))
+    ann = [{"video": f"vid{k % 2}", "qid": k, "query": ["a person opens the door", "someone sits down on a chair and reads"][k % 2], "duration": 12.0,
+            "relevant_windows": [[2 + k % 3, 6 + k % 3]]} for k in range(4)]
+    for split in ("train", "val", "test"):
+        json.dump(ann if split == "train" else ann[:2], open(tmp_path / f"{split}.json", "w"))
+    cfg = os.path.join(ROOT, "mr-blip_amd/lavis/projects/mr_BLIP/train", name + ".yaml")
+    opts = [f"datasets.{builder}.build_info.annotations.{s}.storage={tmp_path}/{s}.json" for s in ("train", "val", "test")]
+    opts += [f"datasets.{builder}.build_info.videos.storage={tmp_path}", "model.model_type=tiny_synthetic",
+             f"datasets.{builder}.vis_processor.train.n_frms=4", f"datasets.{builder}.vis_processor.eval.n_frms=4",
+             f"datasets.{builder}.vis_processor.train.image_size=56", f"datasets.{builder}.vis_processor.eval.image_size=56",
+             f"run.output_dir={tmp_path}/out", "run.max_epoch=1", "run.batch_size_train=2", "run.batch_size_eval=2", "run.num_workers=0",
+             "run.accum_grad_iters=1", "run.warmup_steps=1", "run.distributed=False", "run.max_len=8", "run.num_beams=2"]
+    if name == "charades":
+        opts.append("model.frame_token_aggregation=mean")
+    train.main(["--cfg-path", cfg, "--options"] + opts)
+    out = registry.get_path("output_dir")
+    log = open(os.path.join(out, "log.txt")).read().strip().splitlines()
+    assert any("train_loss" in l for l in log) and any("val_agg_metrics" in l for l in log)
+    loss = [float(json.loads(l)["train_loss"]) for l in log if "train_loss" in l][0]
+    assert 5.0 < loss < 14.0   # ~ln(32128) for random weights
+    assert os.path.isfile(os.path.join(out, "checkpoint_best.pth"))
+
+
+def test_fused_loss_scale_check_is_deferred_not_blocking():
+    """in fused-accumulation mode backward() must not read the upstream gradient on the host (a D2H sync behind the whole queued
+    step).  The comparison runs on the device and surfaces one step late / at end_accumulation."""
+    import lavis  # noqa: F401
+    from lavis.common.config import load_yaml
+    from lavis.common.registry import registry
+    from lavis.datasets import SyntheticMomentRetrievalDataset, collate
+
+    cls = registry.get_model_class("blip2_mr")
+    mcfg = load_yaml(cls.default_config_path("tiny_synthetic")).model
+    mcfg.update(dict(task="qformer_freeze_lora", input_time_format="seconds_integers", interleave_data=True))
+    model = cls.from_config(mcfg)
+    ds = SyntheticMomentRetrievalDataset(n_items=2, n_frms=4, image_size=56, duration=60.0)
+    samples = collate([ds[0], ds[1]])
+    model.train()
+    model.begin_accumulation(1.0)
+    model(samples)["loss"].backward()            # the announced scale: fine
+    model.check_fused_scale_now()
+    (model(samples)["loss"] * 0.5).backward()    # a different scale: NOT raised inside backward() ...
+    with pytest.raises(RuntimeError, match="expects the loss scale"):
+        model.end_accumulation()                 # ... but surfaced at the next blocking point

@@ -71,8 +71,8 @@ class Fp32Verify(contextlib.AbstractContextManager):
         eng = self.eng
         assert not eng.training, "verification mode is eval-mode only"
         S = self.saved
-        S["ws"] = eng.ws
-        eng.ws = {}
+        S["ws"], S["store"] = eng.ws, eng._store   # (views AND their backing stores: the wide buffers have their own row layout)
+        eng.ws, eng._store = {}, {}
         S["buf"] = eng.buf
         S["fuse"], S["rows_max"] = eng.fuse_norm_lora, eng.lora_rows_max_m
         eng.fuse_norm_lora = False
@@ -110,7 +110,7 @@ class Fp32Verify(contextlib.AbstractContextManager):
             if k.startswith("ops."):
                 setattr(ops, k[4:], v)
         eng.buf = S["buf"]
-        eng.ws = S["ws"]
+        eng.ws, eng._store = S["ws"], S["store"]
         eng.fuse_norm_lora, eng.lora_rows_max_m = S["fuse"], S["rows_max"]
         for obj, key, val in self._weight_restore:
             obj[key] = val
