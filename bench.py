@@ -253,6 +253,9 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: one blocking all-reduce after the backward instead of the overlapped exchange")
     ap.add_argument("--no-lookahead", action="store_true", help="do not overlap the next clip's frozen-ViT forward with this step's decoder")
     ap.add_argument("--lookahead-blocks", type=int, default=0, help="ViT blocks run ahead beside the decoder (0 = engine default)")
+    ap.add_argument("--shard-frames", action="store_true", help="N > 1: frame-sharded long-video mode (SURVEY.md 8(f4)) — ONE clip per step, its frames "
+                    "split across the ranks through ViT + Q-Former, one all-gather of the frame tokens, replicated T5 (strong scaling of a single clip; "
+                    "use with --workload anet)")
     ap.add_argument("--vary-text", action="store_true", help="cycle 8 queries of different token counts (S_enc changes every step, as in a real "
                     "QVH epoch: blip2_mr.py:572-824) instead of one fixed prompt; the headline number keeps the fixed prompt")
     args = ap.parse_args()
@@ -287,9 +290,18 @@ def main():
     tok = FixtureTokenizer()
     repl = P.annoying_replacement_dict(P.find_annoying_numbers(tok, 200)[0])
     B = args.batch_per_gpu
-    samples = synthetic_samples(B, wl["T"], wl["duration"], dev, 1234 + rank)
+    shard = None
+    if args.shard_frames and world > 1:
+        # every rank holds the SAME clip (same seed) and the same dropout stream (the T5 is replicated: its masks must agree), and keeps its frames
+        assert B == 1, "--shard-frames: one clip per step"
+        from mrblip.dist import FrameShard
+        shard = FrameShard(wl["T"])
+        eng.seed.fill_(42)
+    samples = synthetic_samples(B, wl["T"], wl["duration"], dev, 1234 + (0 if shard is not None else rank))
     layout = P.build_layout(tok, samples, repl, 1 if wl["mean_pool"] else cfg.num_query, T=wl["T"])
     video = samples["video"]
+    if shard is not None:
+        video = video[:, shard.t0: shard.t1].contiguous()
     layouts = [layout]
     if args.vary_text:   # 8 queries, 3 .. 31 words: the encoder length changes on every step (workspaces are capacity-based views: engine.buf)
         words = ("a person opens the red door and walks into the kitchen while the small dog sleeps on the sofa near the window and "
@@ -309,7 +321,7 @@ def main():
     # data parallel: ONE exchange of the flat gradient per step; the LoRA segment's all-reduce (92 % of the bytes) is issued from inside
     # the backward as soon as the T5 encoder backward is enqueued and runs beside the t5_proj / Q-Former backward (mrblip/dist.py)
     from mrblip.dist import GradExchange
-    exchange = GradExchange(eng, overlap=not args.no_overlap) if world > 1 else None
+    exchange = GradExchange(eng, overlap=not args.no_overlap) if (world > 1 and shard is None) else None
 
     step_no = [0]
     host_s = []      # host time spent enqueueing one step (the host never waits for the GPU inside a step)
@@ -317,15 +329,17 @@ def main():
     def step(lr=3e-4, record=False):
         t_h = time.perf_counter()
         eng.zero_grad()
-        eng.probe = probe_events if record else None
+        eng.probe = probe_events if record is True else None
         if exchange is not None:
             exchange.arm()
         lay = layouts[step_no[0] % len(layouts)]
         step_no[0] += 1
-        loss = eng.forward_backward(video, lay, backward=True, next_video=None if args.no_lookahead else video)
+        loss = eng.forward_backward(video, lay, backward=True, next_video=None if args.no_lookahead else video, shard=shard)
+        if shard is not None:
+            shard.combine_grads(eng)     # t5_proj / ln_vision gradients: sums over the ranks' local frames (LoRA gradients are replicated)
         scale = exchange.finish() if exchange is not None else 1.0
         eng.optimizer_step(lr=lr, weight_decay=0.05, grad_scale=scale)
-        if record:
+        if record == "host":
             host_s.append(time.perf_counter() - t_h)
         return loss
 
@@ -351,6 +365,7 @@ def main():
         for _ in range(args.steps):
             loss = step(record=True)
     launches = (ops.launch_count - launches0) / max(args.steps, 1)
+    allocs_timed = eng.ws_allocation_log[allocs0:]
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -361,6 +376,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
     loss_v = float(loss.item())
+    # host time to ENQUEUE one step, outside the timed region: inside it the host runs ahead of the GPU until the stream's queue is full
+    # and is then throttled to the GPU's pace, so a wall-clock bracket there reads the GPU time.  Two untimed steps, each started on an
+    # idle GPU (every rank takes them: the gradient exchange is collective).
+    for _ in range(2):
+        torch.cuda.synchronize()
+        with torch.cuda.stream(main_stream):
+            step(record="host")
+    torch.cuda.synchronize()
     # outside the timed region: the same kernel with the GPU to itself (one plain ViT pass on the main stream) — with the look-ahead
     # the timed launches share the CUs with the previous clip's decoder / encoder-backward kernels
     excl = []
@@ -371,10 +394,10 @@ def main():
         torch.cuda.synchronize()
 
     if rank == 0:
-        global_batch = B * world
+        global_batch = B * world if shard is None else B
         clips_s = global_batch * args.steps / elapsed
         durs = [s.elapsed_time(e) * 1e-3 for s, e in probe_events]
-        F_ = min(B * wl["T"], eng.vit_chunk)
+        F_ = min(B * (wl["T"] if shard is None else shard.counts[0]), eng.vit_chunk)   # frames in rank 0's ViT pass
         m, n, k = F_ * 257, cfg.vit_mlp, cfg.vit_dim
         traffic_note = None
         traffic = None  # HBM-side bytes per launch of the same kernel from the committed PMC pass (tools/pmc_fc1.sh), QVH B=1 shape only
@@ -414,18 +437,18 @@ def main():
         out = {
             "metric": "video-clips/sec (train step) QVH 60-frame BLIP-2+T5-XL @1/2/4/8 GPU" if args.workload == "qvh" else f"video-clips/sec (train step) {args.workload}",
             "value": round(clips_s, 4), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak" if shard is None else "strong", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"{args.workload}: ViT-g/14 + Q-Former(32) + Flan-T5-XL LoRA r=8 train step, {wl['T']} frames, S_enc={layout.S}, "
                                    f"L_dec={layout.labels.shape[1]}, random-init weights, dropout {'on' if eng.training else 'off'}",
-                       "global_batch": global_batch, "batch_per_gpu": B, "frames": wl["T"], "parallelism": f"dp{world}",
+                       "global_batch": global_batch, "batch_per_gpu": B, "frames": wl["T"], "parallelism": f"dp{world}" if shard is None else f"frame-shard{world} (ViT + Q-Former over T/{world} frames per rank, T5 replicated)",
                        "vit_lookahead": not args.no_lookahead,
                        "vary_text": ([l.S for l in layouts] if args.vary_text else False)},
             "launches_per_step": round(launches, 1),     # C-ABI kernel launches per step (torch-native ones: ~10, profiles/r02_native_in_step.txt)
-            "host_enqueue_ms": round(1e3 * sum(host_s) / max(len(host_s), 1), 2),   # host time to enqueue one step; must stay below ms_per_step
-            "workspace_allocations_in_timed_region": eng.ws_allocations - allocs0,
+            "host_enqueue_ms": round(1e3 * min(host_s), 2) if host_s else None,   # host time to enqueue one step onto an idle GPU (untimed extra steps); must stay below ms_per_step
+            "workspace_allocations_in_timed_region": [n for n, _ in allocs_timed],
             "step_tflop_per_clip": round(step_tf, 3),
-            "step_mfu": round(clips_s * step_tf / (world * PEAK_BF16_TFLOPS), 4),
+            "step_mfu": round(clips_s * step_tf / (world * PEAK_BF16_TFLOPS), 4),   # (frame-shard mode: algorithmic FLOPs of ONE clip; the replicated T5 work is not counted twice)
             "loss": round(loss_v, 4),
             "roofline": roof,
         }

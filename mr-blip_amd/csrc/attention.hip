@@ -43,28 +43,32 @@ struct AttnArgs {
 
 enum { F_LUT = 1, F_MASK = 2, F_CAUSAL = 4, F_DROP = 8, F_SPLIT = 16, F_DBITS = 32, F_VROW = 64 };
 
-// attention-probability dropout draws: one 32-bit hash per (row, key pair): index = row * ceil(Sk/2) + key/2, the low 16 bits
-// serve the even key and the high 16 bits the odd key -> 8 hashes per 16 scores where a lane owns consecutive keys.
-__device__ __forceinline__ uint32_t attn_drop_hash(uint32_t row, int key, int skh, uint32_t seed, uint32_t site) {
-  return mrb_hash(row * (uint32_t)skh + (uint32_t)(key >> 1), seed, site);
-}
+// Attention-probability dropout draws (v2, round 3).  ONE 32-bit hash serves a key QUAD: index = row * ceil(Sk / 4) + key / 4 with
+// row = (b * H + h) * Sq + q, hash = mrb_lin_fin(index * MRB_H1 + mrb_lin_base(seed, site)) (common.h), and key 4i + j takes the
+// 11-bit window of the hash at bit 7j (bits 0-10, 7-17, 14-24, 21-31): keep iff window >= round(p * 2048) (p = 0.1 -> 205 / 2048 =
+// 0.1001).  Windows of neighbouring keys share 4 bits — the LOW bits of one are the HIGH bits of the previous — which moves the
+// conditional drop probability of a neighbour from 0.1001 to 0.1016 (measured on the restatement: tests/test_host_cpu.py); independent
+// across quads and rows.  A lane of the query-owner kernels owns two runs of 8 consecutive keys per 32-key tile = 4
+// hashes (round 2: one hash per key PAIR with mrb_hash's two quarter-rate multiplies = 8 hashes, 38 % of the forward tile's VALU time).
 #define NEG_BIG (-1.0e30f)
-
-// dropout draws for the key-owner (dK/dV) kernels: lane owns one key, register j a query row.  The hash is shared by the key pair
-// (2i, 2i+1) = the lane pair (l, l^1), so each lane hashes 4 of the 8 rows and the pair swaps them through DPP (quad_perm 1,0,3,2).
-// draw[j] = 16-bit draw of (row rowbase + j, key), j < 8.
-__device__ __forceinline__ void drop_draws8_keyowner(uint32_t (&draw)[8], uint32_t rowbase, int key, int lane, int skh, uint32_t seed, uint32_t site) {
-  const bool odd = lane & 1;
-  const uint32_t sh = (key & 1) ? 16u : 0u;
-  uint32_t mine[4], other[4];
+__device__ __forceinline__ uint32_t attn_draw(uint32_t hash, int j) { return (hash >> (7 * j)) & 0x7ffu; }
+// key-owner (dK/dV) kernels: lane owns one key, register j a query row; no sharing (these forms only run where the forward's keep bits
+// are not stored: the 32-query Q-Former and the 12-token decoder)
+__device__ __forceinline__ void drop_draws8_keyowner(uint32_t (&draw)[8], uint32_t rowbase, int key, int skq, uint32_t dbase) {
 #pragma unroll
-  for (int j = 0; j < 4; ++j) mine[j] = attn_drop_hash(rowbase + (odd ? 4u : 0u) + (uint32_t)j, key, skh, seed, site);
+  for (int j = 0; j < 8; ++j)
+    draw[j] = attn_draw(mrb_lin_fin(((rowbase + (uint32_t)j) * (uint32_t)skq + (uint32_t)(key >> 2)) * MRB_H1 + dbase), key & 3);
+}
+// query-owner kernels (forward, dQ): lane (q, hi) owns keys k0 + 16c + 8hi + j (c < 2, j < 8) of a 32-key tile.  t_lane =
+// (row * skq + 2 * hi) * MRB_H1 + dbase is a lane constant; the tile term ((k0 >> 2) + 4c + qd) * MRB_H1 is wave-uniform.
+// keep bit of register r = 8c + 4qd + j  ->  bit r of the result.
+template <typename F>
+__device__ __forceinline__ void attn_keep16(uint32_t t_lane, int k0, uint32_t thresh, F&& apply) {  // apply(r, keep) for r = 0..15
 #pragma unroll
-  for (int j = 0; j < 4; ++j) other[j] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine[j], 0xB1, 0xF, 0xF, true);
+  for (int cq = 0; cq < 4; ++cq) {  // cq = 2c + qd
+    const uint32_t hsh = mrb_lin_fin(t_lane + (uint32_t)((k0 >> 2) + 4 * (cq >> 1) + (cq & 1)) * MRB_H1);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    draw[j] = ((odd ? other[j] : mine[j]) >> sh) & 0xffffu;
-    draw[4 + j] = ((odd ? mine[j] : other[j]) >> sh) & 0xffffu;
+    for (int j = 0; j < 4; ++j) apply(4 * cq + j, attn_draw(hsh, j) >= thresh);
   }
 }
 
@@ -188,7 +192,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs p) {
   const int* km = MASK ? p.kmask + (long long)b * p.Skpad : nullptr;
   const uint32_t drop_seed = DROP ? *p.drop.seed_ptr : 0u;
   const uint32_t row_id = (uint32_t)(b * p.H + h) * (uint32_t)p.Sq + (uint32_t)q;
-  const int skh = (p.Sk + 1) >> 1;
+  const uint32_t t_lane = DROP ? (row_id * (uint32_t)((p.Sk + 3) >> 2) + 2u * (uint32_t)hi) * MRB_H1 + mrb_lin_base(drop_seed, p.drop.site) : 0u;
   const int kstart = SPLIT ? w * 32 : 0, kstep = SPLIT ? 128 : 32;
   const float scale2 = p.scale * MRB_LOG2E;
 
@@ -247,12 +251,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs p) {
       psum += pv[r];
     }
     if (DROP) {  // the 1/(1-p) factor is applied once to O at the end
-#pragma unroll
-      for (int r = 0; r < 16; r += 2) {
-        const uint32_t hsh = attn_drop_hash(row_id, k0 + 16 * (r >> 3) + 8 * hi + (r & 7), skh, drop_seed, p.drop.site);
-        pv[r] = (hsh & 0xffffu) >= p.drop.thresh24 ? pv[r] : 0.f;
-        pv[r + 1] = (hsh >> 16) >= p.drop.thresh24 ? pv[r + 1] : 0.f;
-      }
+      attn_keep16(t_lane, k0, p.drop.thresh24, [&](int r, bool kp) { pv[r] = kp ? pv[r] : 0.f; });
     }
     l_run += psum;
     const bf16x8 pf0 = pack8(pv), pf1 = pack8(pv + 8);
@@ -340,6 +339,83 @@ __device__ __forceinline__ void attn_stage_dma(char* dstA, char* dstB, const voi
   for (int j = 0; j < CNT_B; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (attn_lds_ptr_t)(dstB + (j * 256 + w * 64) * 16), 16, vB[j], sB, 0, 0);
 }
 
+// ---- the ViT's 257th token.  257 = 2 * 128 + 1: the third query block of every (frame, head) owns ONE row, yet it used to stage
+// all 257 keys' K and V through LDS with the full barrier chain — measured: 69 us per ViT block at 256 tokens, 93 us at 257, i.e. a
+// quarter of the kernel for 0.4 % of the rows.  Blocks that own at most ATTN_TAIL_MAX rows take this path instead: plain VALU, no
+// staging.  Per row: thread t scores keys t, t + 256, ... (a 16-B-vectorised dot product against the query row kept in LDS), block-wide
+// softmax statistics, then lane pairs of dims accumulate sum_k p[k] V[k][d] over the wave's quarter of the keys (one coalesced 4-B load
+// per key row and lane) and the four waves meet in LDS.  P is rounded to bf16 before the second product, as on the MFMA path.
+#ifndef ATTN_TAIL_MAX
+#define ATTN_TAIL_MAX 4   // (-DATTN_TAIL_MAX=0: the old behaviour, for A/B)
+#endif
+template <int DP>
+__device__ __forceinline__ void attn_tail_rows(const AttnArgs& p, int b, int h, int q_first, int n_rows, char* sm) {
+  constexpr int MAXK = 1024;                                   // keys this path handles (the ViT has 257); LDS: p[MAXK] + q[DP] + red
+  float* pbuf = reinterpret_cast<float*>(sm);                  // [MAXK] scores -> probabilities
+  float* qrow = pbuf + MAXK;                                   // [DP] the query row, fp32
+  float* red = qrow + DP;                                      // [4 * DP] cross-wave partial sums / [8] statistics
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const bf16_t* kbase = p.K.ptr + b * p.K.bs + h * p.K.hs;
+  const bf16_t* vbase = p.V.ptr + b * p.V.bs + h * p.V.hs;
+  const float scale2 = p.scale * MRB_LOG2E;
+  for (int r = 0; r < n_rows; ++r) {
+    const int q = q_first + r;
+    const bf16_t* qp = p.Q.ptr + b * p.Q.bs + h * p.Q.hs + (long long)q * p.Q.rs;
+    for (int d = tid; d < DP; d += 256) qrow[d] = d < p.D ? bf2f(qp[d]) : 0.f;
+    __syncthreads();
+    float mx = NEG_BIG;
+    for (int k = tid; k < p.Sk; k += 256) {
+      const bf16_t* kp = kbase + (long long)k * p.K.rs;
+      float acc = 0.f;
+      for (int d0 = 0; d0 < p.D; d0 += 8) {
+        const bf16x8 kv = ld8(kp + d0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc += bf2f((bf16_t)kv[j]) * qrow[d0 + j];
+      }
+      acc *= scale2;
+      pbuf[k] = acc;
+      mx = fmaxf(mx, acc);
+    }
+    mx = wave_max(mx);
+    if (lane == 0) red[w] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sum = 0.f;
+    for (int k = tid; k < p.Sk; k += 256) {
+      const float e = ex2(pbuf[k] - mx);
+      sum += e;
+      pbuf[k] = bf2f(f2bf(e));                                   // bf16-rounded operand of the second product (the MFMA path packs P to bf16)
+    }
+    sum = wave_sum(sum);
+    __syncthreads();                                             // everybody has read red[0..3]
+    if (lane == 0) red[4 + w] = sum;
+    __syncthreads();
+    const float l_tot = red[4] + red[5] + red[6] + red[7];
+    // second product: lane l owns dims 2l, 2l + 1; wave w takes keys w, w + 4, ...
+    float o0 = 0.f, o1 = 0.f;
+    if (2 * lane < p.D) {
+      for (int k = w; k < p.Sk; k += 4) {
+        const uint32_t vv = *reinterpret_cast<const uint32_t*>(vbase + (long long)k * p.V.rs + 2 * lane);
+        const float pk = pbuf[k];
+        o0 += pk * bf2f((bf16_t)(vv & 0xffffu));
+        o1 += pk * bf2f((bf16_t)(vv >> 16));
+      }
+    }
+    __syncthreads();                                             // red[4..7] consumed
+    if (2 * lane < DP) { red[w * DP + 2 * lane] = o0; red[w * DP + 2 * lane + 1] = o1; }
+    __syncthreads();
+    if (w == 0 && 2 * lane < p.D) {
+      const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+      const float a0 = (red[2 * lane] + red[DP + 2 * lane] + red[2 * DP + 2 * lane] + red[3 * DP + 2 * lane]) * inv;
+      const float a1 = (red[2 * lane + 1] + red[DP + 2 * lane + 1] + red[2 * DP + 2 * lane + 1] + red[3 * DP + 2 * lane + 1]) * inv;
+      bf16_t* op = const_cast<bf16_t*>(p.O.ptr) + b * p.O.bs + h * p.O.hs + (long long)q * p.O.rs;
+      *reinterpret_cast<uint32_t*>(op + 2 * lane) = pack2bf(a0, a1);
+    }
+    if (p.LSE && tid == 0) p.LSE[((long long)(b * p.H + h)) * p.Sqpad + q] = mx * MRB_LN2 + __logf(fmaxf(l_tot, 1e-37f));
+    __syncthreads();                                             // pbuf / qrow / red are rewritten by the next row
+  }
+}
+
 #ifndef ATTN96_BLOCKS
 #define ATTN96_BLOCKS 2   // resident blocks per CU the ViT form (DP = 96) is compiled for (3 = 168 VGPRs with 36 spilled dwords: measured, see DESIGN)
 #endif
@@ -363,6 +439,13 @@ __global__ __launch_bounds__(256, (DP == 96 ? ATTN96_BLOCKS : 2)) void attn_fwd_
   if (LUT) {
     for (int i = tid; i < 257; i += 256) lut[i] = p.lut[h * 257 + i] * MRB_LOG2E;
   }
+  if (FLAGS == F_VROW) {  // (compile time: the plain ViT form) a block that owns only a few leftover rows — the ViT's 257th token
+    const int rows_here = p.Sq - bx_ * 128;
+    if (bx_ > 0 && rows_here <= ATTN_TAIL_MAX && p.Sk <= 1024) {
+      attn_tail_rows<DP>(p, b, h, bx_ * 128, rows_here, sm);
+      return;
+    }
+  }
   const int q0 = (bx_ * 4 + w) * 32;
   const bool active = q0 < p.Sq;  // wave-uniform; inactive waves still stage and hit the barriers
   const int q = q0 + l31;
@@ -376,7 +459,7 @@ __global__ __launch_bounds__(256, (DP == 96 ? ATTN96_BLOCKS : 2)) void attn_fwd_
   const int* km = MASK ? p.kmask + (long long)b * p.Skpad : nullptr;
   const uint32_t drop_seed = DROP ? *p.drop.seed_ptr : 0u;
   const uint32_t row_id = (uint32_t)(b * p.H + h) * (uint32_t)p.Sq + (uint32_t)q;
-  const int skh = (p.Sk + 1) >> 1;
+  const uint32_t t_lane = DROP ? (row_id * (uint32_t)((p.Sk + 3) >> 2) + 2u * (uint32_t)hi) * MRB_H1 + mrb_lin_base(drop_seed, p.drop.site) : 0u;
   const float scale2 = p.scale * MRB_LOG2E;
   uint32_t* dbits_row = DBITS ? p.dbits + (long long)(b * p.H + h) * (p.Skpad >> 5) * p.Sqpad + q : nullptr;
 
@@ -492,14 +575,10 @@ __global__ __launch_bounds__(256, (DP == 96 ? ATTN96_BLOCKS : 2)) void attn_fwd_
     }
     if (DROP) {
       uint32_t bits = 0;  // keep bit of register r at position 16*(r>>3) + (r&7); shifted by 8*hi it is the key's bit in the tile word
-#pragma unroll
-      for (int r = 0; r < 16; r += 2) {
-        const uint32_t hsh = attn_drop_hash(row_id, k0 + 16 * (r >> 3) + 8 * hi + (r & 7), skh, drop_seed, p.drop.site);
-        const bool k0_ = (hsh & 0xffffu) >= p.drop.thresh24, k1_ = (hsh >> 16) >= p.drop.thresh24;
-        pv[r] = k0_ ? pv[r] : 0.f;
-        pv[r + 1] = k1_ ? pv[r + 1] : 0.f;
-        if (DBITS) bits |= (k0_ ? 1u << (16 * (r >> 3) + (r & 7)) : 0u) | (k1_ ? 2u << (16 * (r >> 3) + (r & 7)) : 0u);
-      }
+      attn_keep16(t_lane, k0, p.drop.thresh24, [&](int r, bool kp) {
+        pv[r] = kp ? pv[r] : 0.f;
+        if (DBITS) bits |= kp ? 1u << (16 * (r >> 3) + (r & 7)) : 0u;
+      });
       if (DBITS) {
         uint32_t wbits = bits << (8 * hi);
         wbits |= (uint32_t)__shfl_xor((int)wbits, 32, 64);
@@ -608,7 +687,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
   const int* km = MASK ? p.kmask + (long long)b * p.Skpad : nullptr;
   const uint32_t drop_seed = DROP ? *p.drop.seed_ptr : 0u;
   const uint32_t row_id = (uint32_t)(b * p.H + h) * (uint32_t)p.Sq + (uint32_t)q;
-  const int skh = (p.Sk + 1) >> 1;
+  const uint32_t t_lane = DROP ? (row_id * (uint32_t)((p.Sk + 3) >> 2) + 2u * (uint32_t)hi) * MRB_H1 + mrb_lin_base(drop_seed, p.drop.site) : 0u;
   const int kstart = SPLIT ? w * 32 : 0, kstep = SPLIT ? 128 : 32;
 
   bf16x8 kcur[KS], vcur[KS];
@@ -642,12 +721,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) kf[r] = keep_scale;
     if (DROP) {
-#pragma unroll
-      for (int r = 0; r < 16; r += 2) {
-        const uint32_t hsh = attn_drop_hash(row_id, k0 + 16 * (r >> 3) + 8 * hi + (r & 7), skh, drop_seed, p.drop.site);
-        kf[r] = (hsh & 0xffffu) >= p.drop.thresh24 ? keep_scale : 0.f;
-        kf[r + 1] = (hsh >> 16) >= p.drop.thresh24 ? keep_scale : 0.f;
-      }
+      attn_keep16(t_lane, k0, p.drop.thresh24, [&](int r, bool kp) { kf[r] = kp ? keep_scale : 0.f; });
     }
     float ds[16];  // dS / scale (the scale is applied once to dQ at the end)
 #pragma unroll
@@ -751,7 +825,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_lds_kernel(const AttnArgs 
   const int* km = MASK ? p.kmask + (long long)b * p.Skpad : nullptr;
   const uint32_t drop_seed = DROP ? *p.drop.seed_ptr : 0u;
   const uint32_t row_id = (uint32_t)(b * p.H + h) * (uint32_t)p.Sq + (uint32_t)q;
-  const int skh = (p.Sk + 1) >> 1;
+  const uint32_t t_lane = DROP ? (row_id * (uint32_t)((p.Sk + 3) >> 2) + 2u * (uint32_t)hi) * MRB_H1 + mrb_lin_base(drop_seed, p.drop.site) : 0u;
 
   const bf16_t* kbase = p.K.ptr + b * p.K.bs + h * p.K.hs;
   const bf16_t* vbase = p.V.ptr + b * p.V.bs + h * p.V.hs;
@@ -814,12 +888,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_lds_kernel(const AttnArgs 
 #pragma unroll
       for (int r = 0; r < 16; ++r) kf[r] = (wsh & (1u << (16 * (r >> 3) + (r & 7)))) ? keep_scale : 0.f;
     } else if (DROP) {
-#pragma unroll
-      for (int r = 0; r < 16; r += 2) {
-        const uint32_t hsh = attn_drop_hash(row_id, k0 + 16 * (r >> 3) + 8 * hi + (r & 7), skh, drop_seed, p.drop.site);
-        kf[r] = (hsh & 0xffffu) >= p.drop.thresh24 ? keep_scale : 0.f;
-        kf[r + 1] = (hsh >> 16) >= p.drop.thresh24 ? keep_scale : 0.f;
-      }
+      attn_keep16(t_lane, k0, p.drop.thresh24, [&](int r, bool kp) { kf[r] = kp ? keep_scale : 0.f; });
     }
     float ds[16];  // dS / scale (the scale is applied once to dQ at the end)
 #pragma unroll
@@ -968,7 +1037,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
       uint32_t draw[8];
-      if (DROP) drop_draws8_keyowner(draw, bh_idx + (uint32_t)(q0 + 16 * c + 8 * hi), key, lane, (p.Sk + 1) >> 1, drop_seed, p.drop.site);
+      if (DROP) drop_draws8_keyowner(draw, bh_idx + (uint32_t)(q0 + 16 * c + 8 * hi), key, (p.Sk + 3) >> 2, mrb_lin_base(drop_seed, p.drop.site));
       float pd[8], ds[8];  // pd: dropped P (without 1/(1-p));  ds: dS / scale  — both factors are applied once at the end
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -1143,9 +1212,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_lds_kernel(const AttnArgs
         const uint4 w0 = *reinterpret_cast<const uint4*>(bp), w1 = *reinterpret_cast<const uint4*>(bp + 4);
         const uint32_t ws[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
 #pragma unroll
-        for (int j = 0; j < 8; ++j) draw[j] = ((ws[j] >> l31) & 1u) ? 0xffffu : 0u;  // >= thresh <=> keep
+        for (int j = 0; j < 8; ++j) draw[j] = ((ws[j] >> l31) & 1u) ? 0x7ffu : 0u;  // >= thresh <=> keep
       } else if (DROP) {
-        drop_draws8_keyowner(draw, bh_idx + (uint32_t)(q0 + 16 * c + 8 * hi), key, lane, (p.Sk + 1) >> 1, drop_seed, p.drop.site);
+        drop_draws8_keyowner(draw, bh_idx + (uint32_t)(q0 + 16 * c + 8 * hi), key, (p.Sk + 3) >> 2, mrb_lin_base(drop_seed, p.drop.site));
       }
       float pd[8], ds[8];  // pd: dropped P (without 1/(1-p));  ds: dS / scale  — both factors are applied once at the end
 #pragma unroll
@@ -1261,7 +1330,7 @@ static int attn_fill(AttnArgs& a, const void* Q, const long long* qs, const void
 static void attn_drop(AttnArgs& a, const uint32_t* seed_ptr, uint32_t site, float p_drop) {
   a.drop.seed_ptr = (p_drop > 0.f) ? seed_ptr : nullptr;
   a.drop.site = site;
-  a.drop.thresh24 = (uint32_t)(p_drop * 65536.0f + 0.5f);
+  a.drop.thresh24 = (uint32_t)(p_drop * 2048.0f + 0.5f);   // 11-bit draws (attn_draw)
   a.drop.inv_keep = 1.0f / (1.0f - p_drop);
 }
 
@@ -1418,6 +1487,7 @@ extern "C" int mrblip_head_transpose(const void* src, const long long* strides, 
   MRB_REQUIRE((D % 8) == 0 && (strides[2] % 8) == 0 && ((uintptr_t)src % 16) == 0, "head_transpose: rows must be 16-B aligned, D %% 8 == 0");
   AttnArgs tmp = {};
   attn_drop(tmp, seed_ptr, site, p_drop);
+  tmp.drop.thresh24 = (uint32_t)(p_drop * 65536.0f + 0.5f);   // element dropout of the SOURCE (mrb_keep: 16-bit draws), not attention draws
   hipLaunchKernelGGL(head_transpose_kernel, dim3(Spad / 32, H, B), dim3(256), 0, stream, s, (bf16_t*)dst, S, D, DP, Spad, tmp.drop);
   return mrblip_check_launch("head_transpose");
 }

@@ -60,10 +60,24 @@ __device__ __forceinline__ void mrb_keep2(uint32_t idx_even, uint32_t seed, uint
   k1 = (h >> 16) >= thresh16;
 }
 
+// LINEAR form of the counter hash for kernels that walk consecutive indices (attention-probability dropout): hash(idx) =
+// fin(idx * MRB_H1 + base), base = mrb_lin_base(seed, site).  idx * MRB_H1 is a Weyl sequence in idx, so a kernel evaluates it with
+// adds (a lane constant + a wave-uniform term computed on the scalar unit + a compile-time constant) and pays ONE quarter-rate
+// integer multiply per hash — the finaliser's — instead of mrb_hash's two.  Restated in the oracle (dropout_hash_lin).
+#define MRB_H1 0x9E3779B1u
+__device__ __forceinline__ uint32_t mrb_lin_base(uint32_t seed, uint32_t site) { return seed * MRB_H1 + site * 0x85EBCA77u; }
+__device__ __forceinline__ uint32_t mrb_lin_fin(uint32_t t) {
+  t ^= t >> 15;
+  t *= 0xC2B2AE3Du;
+  t ^= t >> 13;
+  return t;
+}
+
 struct DropoutArg {
   const uint32_t* seed_ptr;  // nullptr or p == 0 -> disabled
   uint32_t site;
-  uint32_t thresh24;  // 16-bit threshold round(p * 65536) (historic field name)
+  uint32_t thresh24;  // draw threshold (historic field name): round(p * 65536) for the 16-bit element draws, round(p * 2048) for the
+                      // 11-bit attention-probability draws (attention.hip: attn_drop)
   float inv_keep;  // 1 / (1 - p)
 };
 

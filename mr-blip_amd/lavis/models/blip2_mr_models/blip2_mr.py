@@ -403,6 +403,7 @@ class BLIP2_MR(BaseModel):
 
             best = beam_search(step_fn, B, K, int(max_length), min_length=int(min_length), length_penalty=float(length_penalty),
                                eos_id=1, pad_id=0, start_id=0)
+            self.last_sequences = [seq.clone() for seq in best]   # token ids of the winning hypotheses (start token first): parity tests
             out_text = [self.t5_tokenizer.decode(seq[1:], skip_special_tokens=True) for seq in best]
             raw = list(out_text)
             pred = [self.post_process(t) for t in out_text]

@@ -32,6 +32,10 @@ def pad64(n: int) -> int:
     return (n + 63) // 64 * 64
 
 
+# experiment knobs: tile configs of the T5 ENCODER's GEMMs (M = B * S_enc rows), forward "qkv,o,wi,wo" / backward dX "wo,wi,o,qkv" (0 = auto)
+_ENC_FWD_CFG = (tuple(int(x) for x in os.environ.get("MRB_ENC_FWD_CFG", "0,0,0,0").split(",")) + (0, 0, 0, 0))[:4]
+_ENC_BWD_CFG = (tuple(int(x) for x in os.environ.get("MRB_ENC_BWD_CFG", "0,0,0,0").split(",")) + (0, 0, 0, 0))[:4]
+
 # tile configs of the ViT qkv / proj / fc2 / fc1 GEMMs (0 = the library's own choice); MRB_VIT_CFG="q,p,f2,f1" overrides for experiments
 _VIT_CFG = (tuple(int(x) for x in os.environ.get("MRB_VIT_CFG", "0,0,0,0").split(",")) + (0, 0, 0, 0))[:4]
 
@@ -67,6 +71,11 @@ class EngineConfig:
     lora_r: int = 8
     lora_alpha: float = 8.0
     lora_dropout: float = 0.05
+    # peft draws one lora_dropout mask per ADAPTER (each LoRA Linear owns its nn.Dropout: blip2_mr.py:193-200 -> peft lora_dropout
+    # ModuleDict).  False (default): the adapters of a fused projection group (q/k/v, wi_0/wi_1, cross k/v) share ONE mask of their
+    # common input — same marginal distribution, one launch per group; True: a distinct mask per adapter, as peft, at the price of
+    # per-adapter thin launches (measured: DESIGN.md §4).
+    lora_mask_per_adapter: bool = False
     mean_pool: bool = False
 
     @staticmethod
@@ -167,6 +176,7 @@ class MrBlipEngine:
         self.cfg, self.dev = cfg, device
         self.ws: Dict[str, torch.Tensor] = {}
         self._store: Dict[str, torch.Tensor] = {}
+        self.ws_allocation_log: List[tuple] = []
         self.training = True
         self.seed = torch.tensor([seed & 0x7FFFFFFF], dtype=torch.int32, device=device)
         self.hyper = torch.tensor([0.0, 1.0, 1.0, 1.0], dtype=f32, device=device)
@@ -204,6 +214,7 @@ class MrBlipEngine:
             store = torch.zeros(cap, dtype=dtype, device=self.dev)
             self._store[name] = store
             self.ws_allocations += 1
+            self.ws_allocation_log.append((name, cap))
             # the zero fill runs on the CURRENT stream, but workspaces are shared by the engine's streams (gradient side stream,
             # ViT look-ahead stream): a buffer created on the main stream and first written on a side stream could be zeroed AFTER
             # that write (seen as a wrong first-step loss when two ranks shared one GPU); and a store that is REPLACED may still be
@@ -678,6 +689,13 @@ class MrBlipEngine:
     def lg_fwd(self, g: LoraGroup, x: torch.Tensor, u: torch.Tensor, out: torch.Tensor, u_ready: bool = False, **kw):
         """out = x W^T + u B^T with u = dropout(x) (scale*A)^T:  the rank-8 "down" product is the row kernel of csrc/lora.hip (or was
         already produced by the fused RMSNorm launch: u_ready), the "up" product rides in the main GEMM as a 64-wide K extension."""
+        per_adapter = self.cfg.lora_mask_per_adapter and len(g.adapters) > 1 and self.training and self.cfg.lora_dropout > 0
+        if per_adapter:   # peft-faithful: u_j = dropout_j(x) (s A_j)^T with adapter j's own mask (its own call-site id)
+            assert not u_ready
+            for j, a in enumerate(g.adapters):
+                self.lora_thin(x, g.acat[8 * j: 8 * j + 8], u[:, 8 * j:], g.K, drop=self.drop(a.site, self.cfg.lora_dropout))
+            ops.gemm(x, g.W, out, aext=u, wext=g.wext, **kw)
+            return
         ks = self.k_splits_for(x.shape[0], g.N, g.K, out)
         if ks > 1 and not u_ready and kw.get("residual", None) is not None and not kw.get("gated") and kw.get("out2") is None:
             # 12-token decoder rows: a [M x 2048] output has 64 tiles of the skinny kernel; ks blocks per tile share K and add their
@@ -719,7 +737,8 @@ class MrBlipEngine:
 
     def norm_lg_fwd(self, x: torch.Tensor, ln: torch.Tensor, g: LoraGroup, xn: torch.Tensor, u: torch.Tensor, out: torch.Tensor, **kw):
         """T5 RMSNorm + the LoRA "down" product of its output in ONE launch, then the main GEMM (q/k/v, wi_0/wi_1, EncDecAttention.q)"""
-        if self.fuse_norm_lora and x.shape[0] <= self.lora_rows_max_m:
+        per_adapter = self.cfg.lora_mask_per_adapter and len(g.adapters) > 1 and self.training and self.cfg.lora_dropout > 0
+        if self.fuse_norm_lora and x.shape[0] <= self.lora_rows_max_m and not per_adapter:
             ops.rmsnorm_lora_fwd(x, ln, self.cfg.t5_eps, xn, g.acat, u, drop=self.drop(g.site, self.cfg.lora_dropout))
             self.lg_fwd(g, xn, u, out, u_ready=True, **kw)
         else:
@@ -729,13 +748,31 @@ class MrBlipEngine:
     fuse_norm_lora = os.environ.get("MRB_FUSE_NORM_LORA", "1") == "1"
 
     def lg_bwd(self, g: LoraGroup, dy: torch.Tensor, x: torch.Tensor, u: torch.Tensor, gbuf: torch.Tensor, dx: Optional[torch.Tensor],
-               residual: Optional[torch.Tensor] = None, side: bool = False):
+               residual: Optional[torch.Tensor] = None, side: bool = False, tile_cfg: int = 0):
         """dy bf16 [M,N]; x the saved bf16 input; u the saved [M,64] LoRA activations.  Accumulates dA, dB of every adapter of the
         group (one launch) and (optionally) dx = dy W (+ residual) + mask * (g A) (one GEMM: the rank-8 term is its K-extension).
         side=True: the weight-gradient launch goes to the gradient side stream and runs beside the dX GEMM (the caller guarantees
         that dy / gbuf are not overwritten before its next side_join_layer())."""
         drop = self.drop(g.site, self.cfg.lora_dropout)
         seg = [v for a in g.adapters for v in (a.row0, a.row0 + a.out)] if len(g.adapters) > 1 else None
+        if self.cfg.lora_mask_per_adapter and len(g.adapters) > 1 and drop is not None:
+            # peft-faithful masks: the weight gradients and the rank-8 part of dX per adapter, each with ITS mask; the frozen-weight
+            # part of dX is one plain GEMM
+            self.lora_thin(dy, g.bblk, gbuf, g.N, seg=seg)
+            st = self._grad_stream() if (side and self.grad_side_stream_enabled) else None
+            if st is not None:
+                ev = torch.cuda.Event()
+                ev.record()
+            with torch.cuda.stream(st) if st is not None else contextlib.nullcontext():
+                if st is not None:
+                    st.wait_event(ev)
+                for j, a in enumerate(g.adapters):
+                    ops.lora_grads(dy, u[:, 8 * j:], x, gbuf[:, 8 * j:], [a.dBt], [a.row0], [a.out], [a.dA], g.K, drop=self.drop(a.site, self.cfg.lora_dropout))
+            if dx is not None:
+                ops.gemm(dy, g.Wt, dx, residual=residual, K=pad64(g.N))
+                for j, a in enumerate(g.adapters):
+                    ops.lora_dx_add(dx, gbuf[:, 8 * j: 8 * j + 8], g.acat[8 * j: 8 * j + 8], drop=self.drop(a.site, self.cfg.lora_dropout))
+            return
         ks = self.k_splits_for(dy.shape[0], g.K, pad64(g.N), dx) if dx is not None else 1
         if ks > 1:   # dX by the K-split skinny GEMM: this launch also pre-initialises dx (residual or zero)
             self.lora_thin(dy, g.bblk, gbuf, g.N, seg=seg, init_dst=dx, init_src=residual)
@@ -755,7 +792,7 @@ class MrBlipEngine:
             if ks > 1:
                 ops.lora_dx(dy, g.Wt, gbuf, g.acatt, dx, pad64(g.N), residual=None, drop=drop, k_splits=ks)
             else:
-                ops.lora_dx(dy, g.Wt, gbuf, g.acatt, dx, pad64(g.N), residual=residual, drop=drop)
+                ops.lora_dx(dy, g.Wt, gbuf, g.acatt, dx, pad64(g.N), residual=residual, drop=drop, tile_cfg=tile_cfg)
 
     vit_rowv = os.environ.get("MRB_VIT_ROWV", "1") == "1"   # (0: the transposed-copy path, for A/B)
     fuse_bwd_cast = os.environ.get("MRB_FUSE_BWD_CAST", "1") == "1"
@@ -790,7 +827,7 @@ class MrBlipEngine:
             xn = self.buf(f"e{i}_xn", (M, pad64(d)), bf16)
             u = self.buf(f"e{i}_u_qkv", (M, 64), bf16)
             qkv = self.buf(f"e{i}_qkv", (M, 3 * inner), bf16, zero=False)
-            self.norm_lg_fwd(x, L["ln0"], L["qkv"], xn, u, qkv)
+            self.norm_lg_fwd(x, L["ln0"], L["qkv"], xn, u, qkv, tile_cfg=_ENC_FWD_CFG[0])
             q4, k4, v4 = self.v4(qkv, B, S, H, dk, 0), self.v4(qkv, B, S, H, dk, inner), self.v4(qkv, B, S, H, dk, 2 * inner)
             ops.head_transpose(v4, out=vt)
             o = self.buf(f"e{i}_o", (M, pad64(inner)), bf16)
@@ -800,15 +837,15 @@ class MrBlipEngine:
             ops.attention_fwd(q4, k4, vt, self.v4(o, B, S, H, dk), lse, scale=1.0, bias_lut=self.lut_enc, kmask=kmask, drop=adrop, drop_bits=dbits)
             uo = self.buf(f"e{i}_u_o", (M, 64), bf16)
             xm = self.buf(f"e{i}_xm", (M, d), f32, zero=False)
-            self.lg_fwd(L["o"], o, uo, xm, residual=x, drop=self.drop(L["sites"][1], p))
+            self.lg_fwd(L["o"], o, uo, xm, residual=x, drop=self.drop(L["sites"][1], p), tile_cfg=_ENC_FWD_CFG[1])
             xn2 = self.buf(f"e{i}_xn2", (M, pad64(d)), bf16)
             uw = self.buf(f"e{i}_u_wi", (M, 64), bf16)
             y = self.buf(f"e{i}_y", (M, pad64(ff)), bf16)
             h = self.buf(f"e{i}_h", (M, 2 * ff), bf16, zero=False)
-            self.norm_lg_fwd(xm, L["ln1"], L["wi"], xn2, uw, y, out2=h, gated=True, drop=self.drop(L["sites"][2], p))
+            self.norm_lg_fwd(xm, L["ln1"], L["wi"], xn2, uw, y, out2=h, gated=True, drop=self.drop(L["sites"][2], p), tile_cfg=_ENC_FWD_CFG[2])
             uwo = self.buf(f"e{i}_u_wo", (M, 64), bf16)
             xo = self.buf(f"e{i + 1}_x" if i + 1 < len(self.t5["enc"]) else "e_xlast", (M, d), f32, zero=False)
-            self.lg_fwd(L["wo"], y, uwo, xo, residual=xm, drop=self.drop(L["sites"][3], p))
+            self.lg_fwd(L["wo"], y, uwo, xo, residual=xm, drop=self.drop(L["sites"][3], p), tile_cfg=_ENC_FWD_CFG[3])
             self.ws[f"e{i}_xin"] = x
             x = xo
         nf = self.buf("e_nf", (M, d), f32, zero=False)
@@ -867,9 +904,9 @@ class MrBlipEngine:
             # and one 16 MB read fewer per sub-layer; only the top layer, whose dx comes from the decoder, casts on its own)
             if not dyb_ready:
                 ops.cast_dropout(dx, out_bf16=dyb, drop=self.drop(L["sites"][3], p))
-            self.lg_bwd(L["wo"], dyb, self.ws[f"e{i}_y"], self.ws[f"e{i}_u_wo"], gb, dyact, side=True)
+            self.lg_bwd(L["wo"], dyb, self.ws[f"e{i}_y"], self.ws[f"e{i}_u_wo"], gb, dyact, side=True, tile_cfg=_ENC_BWD_CFG[0])
             ops.gated_gelu_bwd(dyact, self.ws[f"e{i}_h"], dh, drop=self.drop(L["sites"][2], p))
-            self.lg_bwd(L["wi"], dh, self.ws[f"e{i}_xn2"], self.ws[f"e{i}_u_wi"], gb2, dxn, side=True)
+            self.lg_bwd(L["wi"], dh, self.ws[f"e{i}_xn2"], self.ws[f"e{i}_u_wi"], gb2, dxn, side=True, tile_cfg=_ENC_BWD_CFG[1])
             if self.fuse_bwd_cast:
                 ops.rmsnorm_bwd(dxn, self.ws[f"e{i}_xm"], L["ln1"], c.t5_eps, other, dx_add=dx, out_bf16=dyb2, out_drop=self.drop(L["sites"][1], p))
             else:
@@ -877,7 +914,7 @@ class MrBlipEngine:
                 ops.cast_dropout(other, out_bf16=dyb2, drop=self.drop(L["sites"][1], p))
             dx, other = other, dx
             # xm = x_in + drop(o(attn(qkv(xn))))
-            self.lg_bwd(L["o"], dyb2, self.ws[f"e{i}_o"], self.ws[f"e{i}_u_o"], gb3, do, side=True)
+            self.lg_bwd(L["o"], dyb2, self.ws[f"e{i}_o"], self.ws[f"e{i}_u_o"], gb3, do, side=True, tile_cfg=_ENC_BWD_CFG[2])
             qkv, o = self.ws[f"e{i}_qkv"], self.ws[f"e{i}_o"]
             q4, k4, v4 = self.v4(qkv, B, S, H, dk, 0), self.v4(qkv, B, S, H, dk, inner), self.v4(qkv, B, S, H, dk, 2 * inner)
             do4 = self.v4(do, B, S, H, dk)
@@ -891,7 +928,7 @@ class MrBlipEngine:
                               self.v4(dqkv, B, S, H, dk, 0), self.v4(dqkv, B, S, H, dk, inner), self.v4(dqkv, B, S, H, dk, 2 * inner),
                               scale=1.0, bias_lut=self.lut_enc, kmask=kmask, drop=self.drop(L["sites"][0], p),
                               drop_bits=self.ws.get(f"e{i}_dbits") if self.drop(L["sites"][0], p) is not None else None)
-            self.lg_bwd(L["qkv"], dqkv, self.ws[f"e{i}_xn"], self.ws[f"e{i}_u_qkv"], gb4, dxn, side=True)
+            self.lg_bwd(L["qkv"], dqkv, self.ws[f"e{i}_xn"], self.ws[f"e{i}_u_qkv"], gb4, dxn, side=True, tile_cfg=_ENC_BWD_CFG[3])
             if i > 0 and self.fuse_bwd_cast:   # ... and the layer below's first operand
                 ops.rmsnorm_bwd(dxn, self.ws[f"e{i}_xin"], L["ln0"], c.t5_eps, other, dx_add=dx, out_bf16=dyb_pair[(i - 1) & 1],
                                 out_drop=self.drop(self.t5["enc"][i - 1]["sites"][3], p))
@@ -1428,7 +1465,8 @@ class MrBlipEngine:
                 m[f"t5.dec.{i}{k}"] = (L["sites"][j], p, kind)
         for g in self.groups:
             for a in g.adapters:
-                m["lora:" + a.name] = (g.site, c.lora_dropout, "2d")
+                per_adapter = c.lora_mask_per_adapter and len(g.adapters) > 1
+                m["lora:" + a.name] = (a.site if per_adapter else g.site, c.lora_dropout, "2d")
         return m
 
     # ------------------------------------------------------------------------------------------ optimizer

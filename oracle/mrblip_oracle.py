@@ -189,8 +189,18 @@ class Oracle:
         return None if self.dropout is None else self.dropout(name, tuple(shape))
 
     # ---- helpers
+    # bf16-operand emulation can be confined to some towers (error-budget experiments: which tower contributes how much of the
+    # product path's ~1e-2 logits error): emu_towers = None (all) or a set out of {"vit", "qf", "proj", "enc", "dec", "head"}, with
+    # "dec:<i>" naming one decoder layer; the forward methods below set the current tower.
+    emu_towers = None
+    _tower = None
+
     def rb(self, x: Tensor) -> Tensor:
-        return x.bfloat16().float() if self.emu else x
+        if not self.emu:
+            return x
+        if self.emu_towers is not None and self._tower not in self.emu_towers and (self._tower or "").split(":")[0] not in self.emu_towers:
+            return x
+        return x.bfloat16().float()
 
     def lin(self, x: Tensor, w: Tensor, b: Optional[Tensor] = None) -> Tensor:
         y = self.rb(x) @ self.rb(w).t()
@@ -201,6 +211,7 @@ class Oracle:
 
     # ---- ViT  (eva_vit.py:118-148, 173-180, 198-204, 324-340)
     def vit(self, image: Tensor, n_blocks: Optional[int] = None) -> Tensor:
+        self._tower = "vit"
         c = self.cfg["vit"]
         D, H = c["embed_dim"], c["num_heads"]
         hd = D // H
@@ -247,6 +258,7 @@ class Oracle:
 
     # ---- Q-Former, query branch only (Qformer.py:51-108, 111-289, 378-484, 487-589)
     def qformer(self, image_embeds: Tensor) -> Tensor:
+        self._tower = "qf"
         c = self.cfg["qf"]
         D, H = c["hidden_size"], c["num_attention_heads"]
         hd = D // H
@@ -334,6 +346,7 @@ class Oracle:
         return self.dm(x.reshape(-1, x.shape[-1]), name).reshape(x.shape)
 
     def t5_encoder(self, inputs_embeds: Tensor, attention_mask: Tensor) -> Tensor:
+        self._tower = "enc"
         c = self.cfg["t5"]
         eps = c.get("eps", 1e-6)
         x = self._d2(inputs_embeds, "t5.enc.emb")
@@ -349,6 +362,7 @@ class Oracle:
         return self._d2(self.rmsnorm(x, self._t5p("encoder.final_layer_norm.weight"), eps), "t5.enc.final")
 
     def t5_decoder(self, dec_ids: Tensor, dec_mask: Tensor, enc: Tensor, enc_mask: Tensor) -> Tensor:
+        self._tower = "dec"
         c = self.cfg["t5"]
         eps = c.get("eps", 1e-6)
         x = self._d2(self._t5p("shared.weight")[dec_ids], "t5.dec.emb")
@@ -361,6 +375,7 @@ class Oracle:
         for i in range(c["num_decoder_layers"]):
             b = f"decoder.block.{i}."
             t = f"t5.dec.{i}"
+            self._tower = f"dec:{i}"
             h = self.rmsnorm(x, self._t5p(b + "layer.0.layer_norm.weight"), eps)
             x = x + self._d2(self._t5_attn(b + "layer.0.SelfAttention", h, h, self_bias, t + ".self"), t + ".self_out")
             h = self.rmsnorm(x, self._t5p(b + "layer.1.layer_norm.weight"), eps)
@@ -372,6 +387,7 @@ class Oracle:
         """T5ForConditionalGeneration.forward (modeling_t5.py:1796-1877): untied lm_head, CE ignore_index=-100 mean."""
         enc = self.t5_encoder(inputs_embeds, attention_mask)
         dec = self.t5_decoder(shift_right(labels), dec_mask, enc, attention_mask)
+        self._tower = "head"
         logits = self.t5lin(dec, "lm_head")
         loss = F.cross_entropy(logits.reshape(-1, logits.shape[-1]).float(), labels.reshape(-1), ignore_index=-100)
         return loss, logits, enc
@@ -413,6 +429,7 @@ class Oracle:
             vit_out = self.vit(video.reshape(b * t, *video.shape[2:]))
         img = self.ln_vision(vit_out)
         q = self.qformer(img)
+        self._tower = "proj"
         f = self.lin(q, self.P("t5_proj.weight"), self.P("t5_proj.bias"))
         if mean_pool:
             f = f.mean(dim=1, keepdim=True)
@@ -425,6 +442,32 @@ class Oracle:
         labels = ans.input_ids.masked_fill(ans.input_ids == tok.pad_token_id, -100)
         loss, logits, enc = self.t5_loss(embs, atts, labels, ans.attention_mask)
         return dict(loss=loss, logits=logits, inputs_embs=embs, inputs_atts=atts, labels=labels, enc=enc, frames=f)
+
+
+    # ---- generate (blip2_mr.py:826-946): encoder once, then the decoder re-run on the growing prefix ---------
+    def encode_for_generate(self, tok, samples: dict, repl: Dict[int, int], mean_pool: bool = False, time_format: str = "seconds_integers"):
+        """the encoder side of BLIP2_MR.generate (blip2_mr.py:848-881: same frame encoding and prompt_concatenation as forward_mr, then
+        t5_model.generate(inputs_embeds=..., attention_mask=...)): returns (encoder output [B,S,d], attention mask [B,S])"""
+        video = samples["video"]
+        b, t = video.shape[:2]
+        f = self.lin(self.qformer(self.ln_vision(self.vit(video.reshape(b * t, *video.shape[2:])))), self.P("t5_proj.weight"), self.P("t5_proj.bias"))
+        if mean_pool:
+            f = f.mean(dim=1, keepdim=True)
+        n = f.shape[1]
+        embs, atts = self.prompt_concatenation(tok, samples["timestamps"], samples["duration"], f.reshape(b, t * n, -1), samples["video_prompt_end"],
+                                               samples["query_prompt"], samples["task_prompt"], repl, n, time_format=time_format)
+        return self.t5_encoder(embs, atts), atts
+
+    def next_token_logprobs(self, seqs: Tensor, enc: Tensor, atts: Tensor, beams_per_clip: int = 1) -> Tensor:
+        """log-probabilities of the next token for every row of ``seqs`` [B * K, L] (decoder start token first), rows b*K .. b*K+K-1
+        attending to clip b's encoder output — what HF's generate evaluates per step (modeling_t5.py:1796-1877 without labels; the
+        K/V cache HF uses is an optimisation of exactly this prefix re-run)."""
+        K = beams_per_clip
+        e, m = enc.repeat_interleave(K, 0), atts.repeat_interleave(K, 0)
+        dec = self.t5_decoder(seqs, torch.ones_like(seqs), e, m)
+        self._tower = "head"
+        logits = self.t5lin(dec[:, -1:], "lm_head")[:, 0]
+        return torch.log_softmax(logits.float(), -1)
 
 
 # ====================================================================================== dropout mask restatement
@@ -455,12 +498,25 @@ def dropout_keep(shape, seed: int, site: int, p: float) -> Tensor:
     return (draw >= thresh).reshape(shape).float()
 
 
+def dropout_hash_lin(idx: Tensor, seed: int, site: int) -> Tensor:
+    """Restates csrc/common.h mrb_lin_fin(idx * MRB_H1 + mrb_lin_base(seed, site)) — the linear-index form of the counter hash used
+    by the attention-probability dropout (uint32 arithmetic emulated in int64)."""
+    idx = idx.to(torch.int64)
+    base = _u32(_u32((seed & 0xFFFFFFFF) * 0x9E3779B1) + _u32((site & 0xFFFFFFFF) * 0x85EBCA77))
+    t = _u32(_u32(idx * 0x9E3779B1) + base)
+    t = t ^ (t >> 15)
+    t = _u32(t * 0xC2B2AE3D)
+    t = t ^ (t >> 13)
+    return t
+
+
 def dropout_keep_attn(B: int, H: int, Sq: int, Sk: int, seed: int, site: int, p: float) -> Tensor:
-    """keep mask [B,H,Sq,Sk] of the attention-probability dropout (csrc/attention.hip attn_drop_hash): one hash per
-    (row = (b*H+h)*Sq+q, key pair), low 16 bits -> even key, high 16 bits -> odd key."""
-    skh = (Sk + 1) // 2
+    """keep mask [B,H,Sq,Sk] of the attention-probability dropout (csrc/attention.hip, "draws v2"): one hash per
+    (row = (b*H+h)*Sq+q, key QUAD): index = row * ceil(Sk/4) + key/4; key 4i + j reads the 11-bit window of the hash at bit 7j;
+    keep iff window >= round(p * 2048)."""
+    skq = (Sk + 3) // 4
     row = torch.arange(B * H * Sq, dtype=torch.int64)[:, None]
     key = torch.arange(Sk, dtype=torch.int64)[None, :]
-    h = dropout_hash((row * skh + (key >> 1)) & 0xFFFFFFFF, seed, site)
-    draw = torch.where((key & 1) == 1, h >> 16, h & 0xFFFF)
-    return (draw >= int(p * 65536.0 + 0.5)).reshape(B, H, Sq, Sk).float()
+    h = dropout_hash_lin((row * skq + (key >> 2)) & 0xFFFFFFFF, seed, site)
+    draw = (h >> (7 * (key & 3))) & 0x7FF
+    return (draw >= int(p * 2048.0 + 0.5)).reshape(B, H, Sq, Sk).float()

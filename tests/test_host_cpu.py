@@ -145,3 +145,32 @@ def test_seconds_floats_layout_matches_reference_golden():
     assert np.allclose(out["inputs_embs"].numpy(), g["inputs_embs"], rtol=0, atol=2e-5) and abs(out["loss"].item() - float(g["loss"])) < 1e-4
     with pytest.raises(ValueError):
         P.build_layout(tok, samples, {}, 8, T=3, time_format="relative_floats")
+
+
+def test_attention_dropout_draws_statistics():
+    """csrc/attention.hip "draws v2" (restated by the oracle): one hash per key quad, four 11-bit windows 7 bits apart.  The drop rate
+    must be p (to the threshold's resolution: 205 / 2048 for p = 0.1) and neighbouring windows, which share 4 bits, must stay
+    (nearly) uncorrelated: P(drop k+1 | drop k) within a few percent of P(drop); keys of different quads / rows independent."""
+    import torch
+    from oracle import mrblip_oracle as O
+
+    p = 0.1
+    keep = O.dropout_keep_attn(2, 8, 256, 2012, seed=12345, site=77, p=p)      # 8.2 M draws
+    drop = 1.0 - keep
+    n = drop.numel()
+    rate = drop.mean().item()
+    target = int(p * 2048 + 0.5) / 2048
+    assert abs(rate - target) < 4 * (target * (1 - target) / n) ** 0.5 + 1e-4, rate
+    # adjacent keys inside a quad (overlapping windows), across quads, and across rows
+    d = drop.reshape(-1, 2012)
+    inside = (d[:, 0:2008:4] * d[:, 1:2008:4]).mean().item() / target            # P(drop k+1 | drop k), keys 4i, 4i+1
+    across = (d[:, 3:2007:4] * d[:, 4:2008:4]).mean().item() / target            # keys 4i+3, 4i+4: different hashes
+    rows = (d[:-1] * d[1:]).mean().item() / target
+    assert abs(across - target) < 3e-3 and abs(rows - target) < 3e-3, (across, rows)
+    assert abs(inside - target) < 4e-3, inside                                     # analytic value 0.1016 against 0.1001
+    # every window position has the same marginal rate
+    for j in range(4):
+        assert abs(d[:, j::4].mean().item() - target) < 2e-3
+    # a different seed or site gives a different mask
+    assert not torch.equal(keep, O.dropout_keep_attn(2, 8, 256, 2012, seed=12346, site=77, p=p))
+    assert not torch.equal(keep, O.dropout_keep_attn(2, 8, 256, 2012, seed=12345, site=78, p=p))

@@ -360,18 +360,13 @@ def test_attention_full_size_t5_encoder(ops, H, S, masked):
     delta = torch.zeros_like(lse)
     dq, dk, dv = torch.zeros_like(q), torch.zeros_like(k), torch.zeros_like(v)
     ops.attention_bwd(q, k, v, o, do, kt, qt, dot, lse, delta, dq, dk, dv, scale=1.0, bias_lut=lut, kmask=kmask, drop=drop, drop_bits=bits)
-    from oracle.mrblip_oracle import dropout_hash
+    from oracle.mrblip_oracle import dropout_keep_attn
     num = dict(o=0.0, dq=0.0, dk=0.0, dv=0.0)
     den = dict(o=0.0, dq=0.0, dk=0.0, dv=0.0)
+    keep_all = dropout_keep_attn(B, H, S, S, 31337, 77, p)   # the oracle's restatement of the kernels' draws (one hash per key quad)
     for h in range(H):  # one head at a time: [S, S] fp32 scores
         qr, kr, vr = (t[:, :, h].float().clone().requires_grad_(True) for t in (q, k, v))  # [B,S,D]
-        # the keep mask of head h: rows (b*H + h)*S + q of the [B*H*S] row space
-        skh = (S + 1) // 2
-        row = (torch.arange(S, dtype=torch.int64) + h * S)[:, None]
-        key = torch.arange(S, dtype=torch.int64)[None, :]
-        hh = dropout_hash((row * skh + (key >> 1)) & 0xFFFFFFFF, 31337, 77)
-        draw = torch.where((key & 1) == 1, hh >> 16, hh & 0xFFFF)
-        dmask = (draw >= int(p * 65536.0 + 0.5)).float().to(dev())[None]
+        dmask = keep_all[:, h].to(dev())
         bias = _lut_bias(lut[h:h + 1], S, S)
         mask = None if kmask is None else kmask[:, :S].bool()[:, None, :].expand(B, S, S)
         ref, _ = _attn_ref(qr, kr, vr, 1.0, bias, mask, dmask, p)
@@ -780,7 +775,13 @@ def test_attention_fwd_row_major_v(ops, B, H, S, D):
     ops.attention_fwd(q, k, ops.head_transpose(v), o_ref, None, scale=scale)
     lse = torch.zeros(B, H, ops.rup32(S), device=dev())
     ops.attention_fwd_rowv(q, k, v, o_new, lse, scale=scale)
-    assert torch.equal(o_new, o_ref)
+    # a last query block that owns <= 4 rows (the ViT's 257th token: 257 = 2 * 128 + 1) takes the VALU tail path of the row-major-V
+    # kernel (no K / V staging for one row): same bf16 operands, fp32 sums in a different order -> those rows to bf16 resolution
+    tail = S % 128 if 0 < S % 128 <= 4 and S > 128 else 0
+    body = S - tail
+    assert torch.equal(o_new[:, :body], o_ref[:, :body])
+    if tail:
+        assert rel(o_new[:, body:].float(), o_ref[:, body:].float()) < 6e-3 and not torch.isnan(o_new.float()).any()
     want = torch.nn.functional.scaled_dot_product_attention(q.float().permute(0, 2, 1, 3), k.float().permute(0, 2, 1, 3),
                                                             v.float().permute(0, 2, 1, 3), scale=scale).permute(0, 2, 1, 3)
     assert rel(o_new.float(), want) < 4e-3

@@ -148,10 +148,13 @@ def test_train_step_forward_backward(tag, mean):
     assert l2 < l1, (l1, l2)
 
 
-def test_training_mode_dropout_parity():
+@pytest.mark.parametrize("per_adapter", [False, True])
+def test_training_mode_dropout_parity(per_adapter):
     """Training mode (every dropout of the reference ON): the HIP step against the oracle fed with the SAME masks, rebuilt on the CPU
     from the engine's call-site ids and the oracle's restatement of the counter hash.  Checks that every backward kernel regenerates
-    exactly the mask its forward used (a wrong site id would leave the loss right and the gradients wrong)."""
+    exactly the mask its forward used (a wrong site id would leave the loss right and the gradients wrong).
+    per_adapter: ``lora_mask_per_adapter`` — peft's one lora_dropout mask per adapter (blip2_mr.py:193-200) instead of one per fused
+    projection group; the oracle draws each adapter's mask from the site id the engine reports for it either way."""
     from oracle import mrblip_oracle as O
     from mrblip import prompt as P
     from mrblip.tokenizer import FixtureTokenizer
@@ -163,13 +166,15 @@ def test_training_mode_dropout_parity():
     sdl = _peft_sd(golden_state_dict(g))
     for k, v in sdl.items():
         v.requires_grad_(("lora_" in k) or k.startswith("t5_proj") or k.startswith("ln_vision"))
-    eng = _engine(sdl)
+    eng = _engine(sdl, lora_mask_per_adapter=per_adapter)
     eng.training = True
     lay = P.build_layout(tok, samples, repl, 8, T=3)
     eng.zero_grad()
     loss = eng.forward_backward(samples["video"].cuda(), lay, backward=True)
     seed = int(eng.seed.item()) & 0xFFFFFFFF
     sites = eng.dropout_site_map()
+    qkv = [sites["lora:encoder.block.0.layer.0.SelfAttention." + x][0] for x in "qkv"]
+    assert len(set(qkv)) == (3 if per_adapter else 1)      # q / k / v: three masks (peft) or one shared mask of their common input
     used = set()
 
     def provider(name, shape):
@@ -184,14 +189,15 @@ def test_training_mode_dropout_parity():
     orc = O.Oracle(sdl, TINY_CFG, emu_bf16=True, lora=dict(r=8, alpha=8), dropout=provider)
     ref = orc.forward_mr(tok, samples, repl)
     assert len(used) > 60 and any(k.startswith("lora:") for k in used) and "t5.dec.1.cross.attn" in used
-    check("train-mode.loss vs emu-oracle, same masks (rel)", abs(loss.item() - ref["loss"].item()) / abs(ref["loss"].item()), 1e-4)
+    tg = "train-mode (per-adapter LoRA masks)" if per_adapter else "train-mode"
+    check(tg + ".loss vs emu-oracle, same masks (rel)", abs(loss.item() - ref["loss"].item()) / abs(ref["loss"].item()), 1e-4)
     # dropout really happened (the eval-mode loss differs)
     eng.training = False
     l_eval = eng.forward_backward(samples["video"].cuda(), lay, backward=False).item()
     assert abs(l_eval - ref["loss"].item()) > 1e-3
     ref["loss"].backward()
-    check("train-mode.grad t5_proj.weight", relerr(eng.dproj_w.cpu(), sdl["t5_proj.weight"].grad), 3e-2)
-    check("train-mode.grad ln_vision.weight", relerr(eng.dlnv_w.cpu(), sdl["ln_vision.weight"].grad), 3e-2)
+    check(tg + ".grad t5_proj.weight", relerr(eng.dproj_w.cpu(), sdl["t5_proj.weight"].grad), 3e-2)
+    check(tg + ".grad ln_vision.weight", relerr(eng.dlnv_w.cpu(), sdl["ln_vision.weight"].grad), 3e-2)
     worst = 0.0
     for a in eng.adapters:
         base = "t5_model.base_model.model." + a.name
@@ -199,7 +205,7 @@ def test_training_mode_dropout_parity():
         eb = relerr(a.dBt.cpu().t(), sdl[base + ".lora_B.default.weight"].grad)
         worst = max(worst, ea, eb)
         assert ea < 5e-2 and eb < 5e-2, (a.name, ea, eb)
-    record("train-mode.grad worst LoRA A/B vs emu-oracle autograd (same masks)", worst, 5e-2)
+    record(tg + ".grad worst LoRA A/B vs emu-oracle autograd (same masks)", worst, 5e-2)
 
 
 @pytest.mark.gpu

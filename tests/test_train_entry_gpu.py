@@ -154,6 +154,26 @@ def test_bench_two_ranks_share_one_gpu():
     assert d["roofline"]["bound"] == "mfma" and 0 < d["roofline"]["frac"] < 1
 
 
+def test_bench_frame_shard_two_ranks_share_one_gpu():
+    """bench.py --shard-frames: two ranks on ONE GPU over gloo split the frames of one Charades-shaped clip (the RCCL
+    all-gather itself needs the multi-GPU node); one clip per step whatever N, "strong" scaling, loss finite at the random-init level."""
+    import json
+    import subprocess
+    import sys
+    from util import free_port
+
+    env = dict(os.environ, MRB_BENCH_SHARE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--workload", "charades", "--shard-frames"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 1 and d["scaling"] == "strong" and "frame-shard2" in d["config"]["parallelism"]
+    assert 5.0 < d["loss"] < 14.0 and abs(d["value"] - 1e3 / d["ms_per_step"]) < 1e-2 * d["value"]
+    assert d["collective_selftest"]["ok"] and d["collective_selftest"]["ranks"] == 2
+
+
 def test_reference_named_parameters_with_a_stock_optimizer():
     """named_parameters() carries the reference's names (peft naming for LoRA) on Parameters that alias the engine's flat buffer: the
     reference's name-based weight-decay grouping (runner_base.py:111-122) + a stock torch.optim.AdamW, with the default

@@ -1,0 +1,27 @@
+#!/bin/bash
+# The multi-GPU scaling runs exactly as the round driver launches them (one process per GPU over RCCL/xGMI, weak scaling):
+#   bash tools/run_scale.sh [N ...]            default N = 1 2 4 8
+#   BATCH_PER_GPU=4 bash tools/run_scale.sh 8  (BASELINE.json configs[2]: QVH, global batch 32 on 8 GPUs)
+# Every line carries "collective_selftest" (start-up all-reduce check on the "nccl" = RCCL backend) and "rccl_ranks" (must equal N).
+# NCCL_DEBUG=INFO output of rank 0 goes to gpurun_out/scale_N<N>.rccl.log so the ring / channel set-up over xGMI can be read off.
+cd "$(dirname "$0")/.."
+mkdir -p gpurun_out
+export HSA_ENABLE_IPC_MODE_LEGACY=0   # dmabuf IPC (the host driver supports nothing else): RCCL's peer mappings fail without it
+NS=${@:-1 2 4 8}
+B=${BATCH_PER_GPU:-1}
+for N in $NS; do
+  PORT=$((29500 + N))
+  if [ "$N" = "1" ]; then
+    python bench.py --gpus 1 --steps 20 --warmup 5 --batch-per-gpu $B --no-cpu-baseline --no-hbm-kernels 2>gpurun_out/scale_N1.err | tee gpurun_out/scale_N1.json | python tools/bench_brief.py
+  else
+    NCCL_DEBUG=INFO NCCL_DEBUG_FILE=gpurun_out/scale_N${N}.rccl.%h.%p.log \
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port $PORT \
+      bench.py --gpus $N --steps 20 --warmup 5 --batch-per-gpu $B 2>gpurun_out/scale_N${N}.err | tee gpurun_out/scale_N${N}.json | python tools/bench_brief.py
+    python - <<PY
+import json
+d = json.loads([l for l in open("gpurun_out/scale_N${N}.json") if l.startswith("{")][-1])
+assert d["n_gpus"] == $N and d.get("rccl_ranks") == $N and d["collective_selftest"]["ok"], d.get("collective_selftest")
+print("N=$N: rccl_ranks", d["rccl_ranks"], "self-test all-reduce", d["collective_selftest"]["allreduce_ms"], "ms for", d["collective_selftest"]["bytes"], "B")
+PY
+  fi
+done
