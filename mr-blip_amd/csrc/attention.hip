@@ -339,83 +339,6 @@ __device__ __forceinline__ void attn_stage_dma(char* dstA, char* dstB, const voi
   for (int j = 0; j < CNT_B; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (attn_lds_ptr_t)(dstB + (j * 256 + w * 64) * 16), 16, vB[j], sB, 0, 0);
 }
 
-// ---- the ViT's 257th token.  257 = 2 * 128 + 1: the third query block of every (frame, head) owns ONE row, yet it used to stage
-// all 257 keys' K and V through LDS with the full barrier chain — measured: 69 us per ViT block at 256 tokens, 93 us at 257, i.e. a
-// quarter of the kernel for 0.4 % of the rows.  Blocks that own at most ATTN_TAIL_MAX rows take this path instead: plain VALU, no
-// staging.  Per row: thread t scores keys t, t + 256, ... (a 16-B-vectorised dot product against the query row kept in LDS), block-wide
-// softmax statistics, then lane pairs of dims accumulate sum_k p[k] V[k][d] over the wave's quarter of the keys (one coalesced 4-B load
-// per key row and lane) and the four waves meet in LDS.  P is rounded to bf16 before the second product, as on the MFMA path.
-#ifndef ATTN_TAIL_MAX
-#define ATTN_TAIL_MAX 4   // (-DATTN_TAIL_MAX=0: the old behaviour, for A/B)
-#endif
-template <int DP>
-__device__ __forceinline__ void attn_tail_rows(const AttnArgs& p, int b, int h, int q_first, int n_rows, char* sm) {
-  constexpr int MAXK = 1024;                                   // keys this path handles (the ViT has 257); LDS: p[MAXK] + q[DP] + red
-  float* pbuf = reinterpret_cast<float*>(sm);                  // [MAXK] scores -> probabilities
-  float* qrow = pbuf + MAXK;                                   // [DP] the query row, fp32
-  float* red = qrow + DP;                                      // [4 * DP] cross-wave partial sums / [8] statistics
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const bf16_t* kbase = p.K.ptr + b * p.K.bs + h * p.K.hs;
-  const bf16_t* vbase = p.V.ptr + b * p.V.bs + h * p.V.hs;
-  const float scale2 = p.scale * MRB_LOG2E;
-  for (int r = 0; r < n_rows; ++r) {
-    const int q = q_first + r;
-    const bf16_t* qp = p.Q.ptr + b * p.Q.bs + h * p.Q.hs + (long long)q * p.Q.rs;
-    for (int d = tid; d < DP; d += 256) qrow[d] = d < p.D ? bf2f(qp[d]) : 0.f;
-    __syncthreads();
-    float mx = NEG_BIG;
-    for (int k = tid; k < p.Sk; k += 256) {
-      const bf16_t* kp = kbase + (long long)k * p.K.rs;
-      float acc = 0.f;
-      for (int d0 = 0; d0 < p.D; d0 += 8) {
-        const bf16x8 kv = ld8(kp + d0);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc += bf2f((bf16_t)kv[j]) * qrow[d0 + j];
-      }
-      acc *= scale2;
-      pbuf[k] = acc;
-      mx = fmaxf(mx, acc);
-    }
-    mx = wave_max(mx);
-    if (lane == 0) red[w] = mx;
-    __syncthreads();
-    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    float sum = 0.f;
-    for (int k = tid; k < p.Sk; k += 256) {
-      const float e = ex2(pbuf[k] - mx);
-      sum += e;
-      pbuf[k] = bf2f(f2bf(e));                                   // bf16-rounded operand of the second product (the MFMA path packs P to bf16)
-    }
-    sum = wave_sum(sum);
-    __syncthreads();                                             // everybody has read red[0..3]
-    if (lane == 0) red[4 + w] = sum;
-    __syncthreads();
-    const float l_tot = red[4] + red[5] + red[6] + red[7];
-    // second product: lane l owns dims 2l, 2l + 1; wave w takes keys w, w + 4, ...
-    float o0 = 0.f, o1 = 0.f;
-    if (2 * lane < p.D) {
-      for (int k = w; k < p.Sk; k += 4) {
-        const uint32_t vv = *reinterpret_cast<const uint32_t*>(vbase + (long long)k * p.V.rs + 2 * lane);
-        const float pk = pbuf[k];
-        o0 += pk * bf2f((bf16_t)(vv & 0xffffu));
-        o1 += pk * bf2f((bf16_t)(vv >> 16));
-      }
-    }
-    __syncthreads();                                             // red[4..7] consumed
-    if (2 * lane < DP) { red[w * DP + 2 * lane] = o0; red[w * DP + 2 * lane + 1] = o1; }
-    __syncthreads();
-    if (w == 0 && 2 * lane < p.D) {
-      const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
-      const float a0 = (red[2 * lane] + red[DP + 2 * lane] + red[2 * DP + 2 * lane] + red[3 * DP + 2 * lane]) * inv;
-      const float a1 = (red[2 * lane + 1] + red[DP + 2 * lane + 1] + red[2 * DP + 2 * lane + 1] + red[3 * DP + 2 * lane + 1]) * inv;
-      bf16_t* op = const_cast<bf16_t*>(p.O.ptr) + b * p.O.bs + h * p.O.hs + (long long)q * p.O.rs;
-      *reinterpret_cast<uint32_t*>(op + 2 * lane) = pack2bf(a0, a1);
-    }
-    if (p.LSE && tid == 0) p.LSE[((long long)(b * p.H + h)) * p.Sqpad + q] = mx * MRB_LN2 + __logf(fmaxf(l_tot, 1e-37f));
-    __syncthreads();                                             // pbuf / qrow / red are rewritten by the next row
-  }
-}
-
 #ifndef ATTN96_BLOCKS
 #define ATTN96_BLOCKS 2   // resident blocks per CU the ViT form (DP = 96) is compiled for (3 = 168 VGPRs with 36 spilled dwords: measured, see DESIGN)
 #endif
@@ -439,17 +362,15 @@ __global__ __launch_bounds__(256, (DP == 96 ? ATTN96_BLOCKS : 2)) void attn_fwd_
   if (LUT) {
     for (int i = tid; i < 257; i += 256) lut[i] = p.lut[h * 257 + i] * MRB_LOG2E;
   }
-  if (FLAGS == F_VROW) {  // (compile time: the plain ViT form) a block that owns only a few leftover rows — the ViT's 257th token
-    const int rows_here = p.Sq - bx_ * 128;
-    if (bx_ > 0 && rows_here <= ATTN_TAIL_MAX && p.Sk <= 1024) {
-      attn_tail_rows<DP>(p, b, h, bx_ * 128, rows_here, sm);
-      return;
-    }
-  }
   const int q0 = (bx_ * 4 + w) * 32;
   const bool active = q0 < p.Sq;  // wave-uniform; inactive waves still stage and hit the barriers
   const int q = q0 + l31;
   const bool q_ok = q < p.Sq;
+  // (Measured in round 3 and not kept — the ViT's 257 = 2 * 128 + 1 = 4 * 64 + 1 tokens cost 87 us per block against 67 us at 256: (i) a
+  // VALU path for the third query block's single row instead of staging 257 keys for it: 88.2 -> 86.6 us; (ii) the 257th KEY folded in
+  // by a rank-1 update after four stages instead of a fifth stage: -1.6 us; (iii) no third block at all, the last full block appending
+  // the row: 99.6 us, the serial tail sits on the head's critical path.  What costs is the third BLOCK per head — dispatch + start /
+  // end latency at 216 VGPRs and 49 KB of LDS — not what it computes)
   bf16x8 qf[KS];
   load_rows<KS>(qf, p.Q.ptr + b * p.Q.bs + h * p.Q.hs, p.Q.rs, q, p.Sq, p.D, hi);
   float m_run = NEG_BIG, l_run = 0.f;

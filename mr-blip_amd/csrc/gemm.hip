@@ -1546,17 +1546,10 @@ static int gemm_dispatch(const void* A, long long lda, const void* W, long long 
     // frozen-ViT look-ahead of the train step gives the clip that is being trained a quarter of the chip this way.
     const int reserve = reserve_arg ? reserve_arg / 8 * 8 : g_cu_reserve;
     const int cus = ncu13 - reserve > 8 ? ncu13 - reserve : 8;
-    // (a multiple of 8: the same number of blocks on every XCD).  With a CU reserve the launch shares the chip with another stream: it
-    // then takes only as many CUs as its round count needs — ceil(tiles / rounds), e.g. ViT fc1 at 192 CUs: 1464 tiles = 8 rounds, which
-    // 184 CUs also finish in 8 rounds; qkv: 1037 tiles = 6 rounds on 176 CUs — and the clip being trained gets the rest for free.
-    int grid = nt13 < cus ? (nt13 + 7) / 8 * 8 : cus;
-    static int tight13 = -1;
-    if (tight13 < 0) tight13 = getenv("MRB_NO_TIGHT_GRID") ? 0 : 1;
-    if (tight13 && reserve > 0 && nt13 > cus) {
-      const int rounds = (nt13 + cus - 1) / cus;
-      const int need = ((nt13 + rounds - 1) / rounds + 7) / 8 * 8;
-      if (need < grid) grid = need;
-    }
+    // (a multiple of 8: the same number of blocks on every XCD.  Measured and dropped in round 3: shrinking the grid to the fewest CUs
+    // that keep the round count — ceil(tiles / rounds): ViT fc1 1464 tiles = 8 rounds on 184 CUs as on 192 — so that the other stream
+    // gets the difference: +0.3 ms per step; the CUs of a partly filled last round are not idle, they go to the other stream EARLIER.)
+    const int grid = nt13 < cus ? (nt13 + 7) / 8 * 8 : cus;
     const int variant = (cfg == 14 ? 8 : 0) | (out_f32 ? 4 : 0) | (act == 1 ? 2 : 0) | (residual ? 1 : 0);
     static bool attr_set13[16] = {};
 #define MRB_W4_LAUNCH(V, F32, ACT_, RES_, TN_)                                                                                     \

@@ -100,8 +100,14 @@ def _chk(rc: int):
         raise MrblipError(_lib.mrblip_last_error().decode())
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None) if os.environ.get("MRB_SLOW_STREAM_LOOKUP") is None else None
+
 def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+    """raw hipStream_t of torch's current stream.  ~2700 ops per step ask for it: torch's C accessor (no Stream object per call) takes
+    ~0.2 us against ~2.5 us for torch.cuda.current_stream().cuda_stream — 6 ms of host time per step"""
+    if _raw_stream is None:
+        return torch.cuda.current_stream().cuda_stream
+    return _raw_stream(torch.cuda.current_device())
 
 
 def _p(t: Optional[torch.Tensor]):

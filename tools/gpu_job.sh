@@ -13,11 +13,17 @@ case "$job" in
     for extra in "" "--vary-text"; do $B --steps 24 --warmup 8 $extra "$@" 2>/dev/null | python tools/bench_brief.py; done | tee gpurun_out/quick.log ;;
   workloads)    # Charades / ANet / B=4 lines
     for w in "--workload charades" "--workload anet" "--batch-per-gpu 4"; do $B --steps 10 --warmup 3 $w "$@" 2>/dev/null | python tools/bench_brief.py; done | tee gpurun_out/workloads.log ;;
-  ab)           # same-box A/B: each argument is "label:ENV=VAL,ENV=VAL" (MRBLIP_LIB=exp_libs/x.so selects a library); the list is run twice
+  ab)           # same-box A/B: each argument is "label:ENV=VAL;ENV=VAL" (MRBLIP_LIB=exp_libs/x.so selects a library); the list is run twice
     for rep in 1 2; do for spec in "$@"; do
       label=${spec%%:*}; envs=${spec#*:}; [ "$envs" = "$spec" ] && envs=""
-      line=$(env $(echo $envs | tr ',' ' ') $B --steps 24 --warmup 8 2>/dev/null | python tools/bench_brief.py)
+      line=$(env $(echo $envs | tr ';' ' ') $B --steps 24 --warmup 8 2>gpurun_out/ab_err.log | python tools/bench_brief.py)
+      [ -z "$line" ] && line="FAILED: $(tail -2 gpurun_out/ab_err.log | tr '\n' ' ' | cut -c1-300)"
       echo "$label | $line"
     done; done | tee gpurun_out/ab.log ;;
+  attn)         # standalone attention kernels at the hot-path shapes, per library:  attn exp_libs/base.so "" ...
+    for lib in "$@"; do
+      echo "== lib: ${lib:-default}"; env ${lib:+MRBLIP_LIB=$lib} ATTN_ONLY=t5enc,t5enc_masked,vit timeout 300 python tools/attn_bench.py 2>&1 | tail -4
+      env ${lib:+MRBLIP_LIB=$lib} timeout 200 python tools/attn_vit_bench.py 2>&1 | grep "S=" | grep -v "rel err"
+    done | tee gpurun_out/attn.log ;;
   *) echo "unknown job $job"; exit 2 ;;
 esac
