@@ -1647,9 +1647,16 @@ __global__ __launch_bounds__(512) void lora_tn_kernel(const TnArgs2 q) {
   const int bx = second ? blockIdx.x - q.blocks_a : blockIdx.x;
   // Each wave stages its own 16-row slices of Y (16 x 32 columns) and U (16 x 32) with ONE 16-B global load per lane each,
   // parks them in a wave-private LDS slot and gathers the k-major MFMA fragments from there with 2-byte LDS reads.
-  constexpr int UNROLL = 2;
+  // UNROLL 16-row slices are in flight per wave (one 16-B load per lane and operand each) and go through the wave's two LDS slots in
+  // pairs.  Round 3 measured 2 / 4 / 8 / 16 slices in flight (-DLORA_TN_UNROLL=): qkv group 27.3 / 26.9 / 27.6 / 39.2 us, wi group 29.5 /
+  // 31.1 / 36.6 / 56.7 us, step 76.0 / 76.1 / 76.9 / 79.5 ms — more bytes in flight do NOT help (the launch is not latency-bound; the
+  // registers they cost do hurt): 2 stays.  (profiles/r03_lora_tn_unroll.txt)
+#ifndef LORA_TN_UNROLL
+#define LORA_TN_UNROLL 2
+#endif
+  constexpr int UNROLL = LORA_TN_UNROLL, NSLOT = 2;
   __shared__ float red[7][16][64];
-  __shared__ __attribute__((aligned(16))) bf16_t slot[8][UNROLL][2][16 * 32];
+  __shared__ __attribute__((aligned(16))) bf16_t slot[8][NSLOT][2][16 * 32];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, hi = lane >> 5, l31 = lane & 31;
   const int c0 = bx * 32;
   const int c = c0 + l31;
@@ -1676,25 +1683,29 @@ __global__ __launch_bounds__(512) void lora_tn_kernel(const TnArgs2 q) {
       gu[u] = (ok && uchunk_ok) ? *reinterpret_cast<const bf16x8*>(p.U + mm * p.ldu + 8 * schunk) : zero;
     }
 #pragma unroll
-    for (int u = 0; u < UNROLL; ++u) {
-      *reinterpret_cast<bf16x8*>(&slot[w][u][0][srow * 32 + schunk * 8]) = gy[u];
-      *reinterpret_cast<bf16x8*>(&slot[w][u][1][srow * 32 + schunk * 8]) = gu[u];
-    }
+    for (int u0 = 0; u0 < UNROLL; u0 += NSLOT) {
 #pragma unroll
-    for (int u = 0; u < UNROLL; ++u) {
-      bf16x8 yf, uf;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        bf16_t yv = slot[w][u][0][(8 * hi + j) * 32 + l31];
-        if (p.drop.seed_ptr) {
-          const int m = (s0 + u) * 16 + 8 * hi + j;
-          const bool keep = mrb_keep((uint32_t)m * (uint32_t)p.C + (uint32_t)c, seed, p.drop.site, p.drop.thresh24);
-          yv = keep ? f2bf(bf2f(yv) * p.drop.inv_keep) : (bf16_t)0;
-        }
-        yf[j] = (short)yv;
-        uf[j] = (short)slot[w][u][1][(8 * hi + j) * 32 + l31];
+      for (int v = 0; v < NSLOT; ++v) {
+        *reinterpret_cast<bf16x8*>(&slot[w][v][0][srow * 32 + schunk * 8]) = gy[u0 + v];
+        *reinterpret_cast<bf16x8*>(&slot[w][v][1][srow * 32 + schunk * 8]) = gu[u0 + v];
       }
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uf, yf, acc, 0, 0, 0);
+#pragma unroll
+      for (int v = 0; v < NSLOT; ++v) {
+        const int u = u0 + v;
+        bf16x8 yf, uf;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          bf16_t yv = slot[w][v][0][(8 * hi + j) * 32 + l31];
+          if (p.drop.seed_ptr) {
+            const int m = (s0 + u) * 16 + 8 * hi + j;
+            const bool keep = mrb_keep((uint32_t)m * (uint32_t)p.C + (uint32_t)c, seed, p.drop.site, p.drop.thresh24);
+            yv = keep ? f2bf(bf2f(yv) * p.drop.inv_keep) : (bf16_t)0;
+          }
+          yf[j] = (short)yv;
+          uf[j] = (short)slot[w][v][1][(8 * hi + j) * 32 + l31];
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uf, yf, acc, 0, 0, 0);
+      }
     }
   }
   if (w > 0) {
