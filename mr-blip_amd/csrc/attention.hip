@@ -417,26 +417,22 @@ __global__ __launch_bounds__(256, (DP == 96 ? ATTN96_BLOCKS : 2)) void attn_fwd_
 
   // fragment addresses inside a stage (bytes)
   const int krow = perm23(l31);
-  int k_off[2][KS], v_off[MT][2][2];
+  // Offsets of sub-tile 0; sub-tile 1 (keys 32..63 of the stage) lies 32 K rows further (the row swizzle ignores bit 5 of the row) and
+  // in the other 64-B half of the V^T rows (chunk index ^ 4).  ONE instance of the tile body serves both sub-tiles and the edge tiles
+  // (round 3): with four unrolled instances (sub x edge) the compiler ping-ponged the O accumulators between two register sets and paid
+  // 16 v_mov_b64 per tile in the common no-rescale path.
+  int k_off[KS], v_off[MT][2];
 #pragma unroll
-  for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      const int row = 32 * sub + krow;
-      k_off[sub][s] = row * KROW + (((2 * s + hi) ^ ksw(row)) << 4);
-    }
+  for (int s = 0; s < KS; ++s) k_off[s] = krow * KROW + (((2 * s + hi) ^ ksw(krow)) << 4);
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-      for (int hf = 0; hf < 2; ++hf) {
-        const int d = mt * 32 + l31;
-        v_off[mt][sub][hf] = K_BYTES + d * 128 + (((4 * sub + 2 * hf + hi) ^ ((d >> 1) & 7)) << 4);
-      }
+    for (int hf = 0; hf < 2; ++hf) {
+      const int d = mt * 32 + l31;
+      v_off[mt][hf] = K_BYTES + d * 128 + (((2 * hf + hi) ^ ((d >> 1) & 7)) << 4);
+    }
 
-  auto tile = [&](auto edge_c, int k0, const char* base, int sub, uint32_t vmask) {
-    constexpr bool EDGE = decltype(edge_c)::value;
+  auto tile = [&](const bool EDGE, int k0, const char* base, int sub, uint32_t vmask) {
     // VROW: the transpose reads of this tile's V fragments go out FIRST - their latency then lies under the QK^T MFMAs and the softmax
     // arithmetic instead of in front of the second product (issued where they are consumed the waves sat parked 40 % longer)
     typedef short v4s_t __attribute__((ext_vector_type(4)));
@@ -450,7 +446,7 @@ __global__ __launch_bounds__(256, (DP == 96 ? ATTN96_BLOCKS : 2)) void attn_fwd_
     if (VTR) {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
-        const char* vb = base + vtr + (32 * sub) * KROW + mt * 64;
+        const char* vb = base + vtr + sub * (32 * KROW) + mt * 64;
         vtr_r[mt][0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr_t)(vb));
         vtr_r[mt][1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr_t)(vb + 4 * KROW));
         vtr_r[mt][2] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr_t)(vb + 16 * KROW));
@@ -461,7 +457,7 @@ __global__ __launch_bounds__(256, (DP == 96 ? ATTN96_BLOCKS : 2)) void attn_fwd_
     zero16(sacc);
 #pragma unroll
     for (int s = 0; s < KS; ++s)
-      sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(base + k_off[sub][s]), qf[s], sacc, 0, 0, 0);
+      sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(base + sub * (32 * KROW) + k_off[s]), qf[s], sacc, 0, 0, 0);
     // lane (q, hi), register r  <->  key k0 + 16*(r>>3) + 8*hi + (r&7)
     float sv[16];
     tile_scores<LUT, 1>(sv, sacc, scale2, lut, k0 - (q0 + 31) >= 128 || (q0 - (k0 + 31)) >= 128, k0 > q0 ? 256 : 0, k0 + 8 * hi - q);
@@ -516,34 +512,28 @@ __global__ __launch_bounds__(256, (DP == 96 ? ATTN96_BLOCKS : 2)) void attn_fwd_
         o[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf0, pf0, o[mt], 0, 0, 0);
         o[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf1, pf1, o[mt], 0, 0, 0);
       } else {
-        o[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(base + v_off[mt][sub][0]), pf0, o[mt], 0, 0, 0);
-        o[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(base + v_off[mt][sub][1]), pf1, o[mt], 0, 0, 0);
+        o[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(base + (v_off[mt][0] ^ (sub << 6))), pf0, o[mt], 0, 0, 0);
+        o[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(base + (v_off[mt][1] ^ (sub << 6))), pf1, o[mt], 0, 0, 0);
       }
     }
   };
 
-  const int nst = (p.Sk + 63) >> 6;
+  const int nst = (p.Sk + 63) >> 6, ntile = (p.Sk + 31) >> 5;
   stage(0, 0);
-  for (int st = 0; st < nst; ++st) {
-    uint32_t vm0 = 0xffffu, vm1 = 0xffffu;
-    if (MASK) {  // Skpad is a multiple of 32: the second half of the last stage may lie past the row
-      vm0 = mask_bits(km, st * 64, hi);
-      vm1 = st * 64 + 32 < p.Skpad ? mask_bits(km, st * 64 + 32, hi) : 0u;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();  // stage st has landed for every wave; every wave is done reading the other buffer
-    if (st + 1 < nst) stage(st + 1, (st + 1) & 1);
-    const char* base = sm + (st & 1) * STAGE;
-    if (active) {
-#pragma unroll
-      for (int sub = 0; sub < 2; ++sub) {
-        const int k0 = st * 64 + 32 * sub;
-        if (k0 < p.Sk) {
-          if (MASK || k0 + 32 > p.Sk) tile(BoolC<true>(), k0, base, sub, sub ? vm1 : vm0);
-          else tile(BoolC<false>(), k0, base, sub, 0xffffu);
-        }
+  uint32_t vm0 = 0xffffu, vm1 = 0xffffu;
+#pragma unroll 1
+  for (int t = 0; t < ntile; ++t) {  // one 32-key tile per trip; a new 64-key stage is handed over every second trip
+    const int st = t >> 1, sub = t & 1;
+    if (sub == 0) {
+      if (MASK) {  // Skpad is a multiple of 32: the second half of the last stage may lie past the row
+        vm0 = mask_bits(km, st * 64, hi);
+        vm1 = st * 64 + 32 < p.Skpad ? mask_bits(km, st * 64 + 32, hi) : 0u;
       }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();  // stage st has landed for every wave; every wave is done reading the other buffer
+      if (st + 1 < nst) stage(st + 1, (st + 1) & 1);
     }
+    if (active) tile(MASK || 32 * t + 32 > p.Sk, 32 * t, sm + (st & 1) * STAGE, sub, sub ? vm1 : vm0);
   }
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = l_tot > 0.f ? (DROP ? p.drop.inv_keep : 1.0f) / l_tot : 0.f;
@@ -771,33 +761,27 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_lds_kernel(const AttnArgs 
   };
 
   const int krow = perm23(l31);
-  int k_off[2][KS], t_off[MT][2][2];
+  // offsets of sub-tile 0; sub-tile 1: rows 32 further (+ 4096 B, the swizzle ignores bit 5), K^T chunk index ^ 4 (^ 64 B).  ONE
+  // instance of the tile body for both sub-tiles and the edge tiles (see attn_fwd_lds_kernel).
+  int k_off[KS], t_off[MT][2];
 #pragma unroll
-  for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      const int row = 32 * sub + krow;
-      k_off[sub][s] = row * 128 + (((2 * s + hi) ^ ((row >> 1) & 7)) << 4);
-    }
+  for (int s = 0; s < KS; ++s) k_off[s] = krow * 128 + (((2 * s + hi) ^ ((krow >> 1) & 7)) << 4);
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-      for (int hf = 0; hf < 2; ++hf) {
-        const int d = mt * 32 + l31;
-        t_off[mt][sub][hf] = 2 * T_BYTES + d * 128 + (((4 * sub + 2 * hf + hi) ^ ((d >> 1) & 7)) << 4);
-      }
+    for (int hf = 0; hf < 2; ++hf) {
+      const int d = mt * 32 + l31;
+      t_off[mt][hf] = 2 * T_BYTES + d * 128 + (((2 * hf + hi) ^ ((d >> 1) & 7)) << 4);
+    }
 
-  auto tile = [&](auto edge_c, int k0, const char* base, int sub, uint32_t vmask, uint32_t dword) {
-    constexpr bool EDGE = decltype(edge_c)::value;
+  auto tile = [&](const bool EDGE, int k0, const char* base, int sub, uint32_t vmask, uint32_t dword) {
     f32x16 sacc, dpacc;
     zero16(sacc);
     zero16(dpacc);
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-      sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(base + k_off[sub][s]), qf[s], sacc, 0, 0, 0);
-      dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(base + T_BYTES + k_off[sub][s]), dof[s], dpacc, 0, 0, 0);
+      sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(base + sub * 4096 + k_off[s]), qf[s], sacc, 0, 0, 0);
+      dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(base + T_BYTES + sub * 4096 + k_off[s]), dof[s], dpacc, 0, 0, 0);
     }
     float sv[16];
     tile_scores<LUT, 1>(sv, sacc, scale2, lut, k0 - (q0 + 31) >= 128 || (q0 - (k0 + 31)) >= 128, k0 > q0 ? 256 : 0, k0 + 8 * hi - q);
@@ -825,8 +809,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_lds_kernel(const AttnArgs 
     const bf16x8 f0 = pack8(ds), f1 = pack8(ds + 8);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-      dq[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(base + t_off[mt][sub][0]), f0, dq[mt], 0, 0, 0);
-      dq[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(base + t_off[mt][sub][1]), f1, dq[mt], 0, 0, 0);
+      dq[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(base + (t_off[mt][0] ^ (sub << 6))), f0, dq[mt], 0, 0, 0);
+      dq[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(base + (t_off[mt][1] ^ (sub << 6))), f1, dq[mt], 0, 0, 0);
     }
   };
 
@@ -858,12 +842,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_lds_kernel(const AttnArgs 
     const char* base = sm + (st & 1) * STAGE;
     if (active) {
 #pragma unroll
-      for (int sub = 0; sub < 2; ++sub) {
+      for (int sub = 0; sub < 2; ++sub) {   // (sub is a compile-time constant here: two instances, the edge test stays a run-time branch)
         const int k0 = st * 64 + 32 * sub;
-        if (k0 < p.Sk) {
-          if (MASK || k0 + 32 > p.Sk) tile(BoolC<true>(), k0, base, sub, sub ? vm1 : vm0, sub ? cw1 : cw0);
-          else tile(BoolC<false>(), k0, base, sub, 0xffffu, sub ? cw1 : cw0);
-        }
+        if (k0 < p.Sk) tile(MASK || k0 + 32 > p.Sk, k0, base, sub, sub ? vm1 : vm0, sub ? cw1 : cw0);
       }
     }
   }
@@ -1061,6 +1042,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_lds_kernel(const AttnArgs
   const int st0 = CAUSAL ? bx_ * 2 : 0;  // first 64-query stage (block-uniform); the per-wave causal limit is applied below
   const float scale2 = p.scale * MRB_LOG2E;
   const float keep_scale = DROP ? p.drop.inv_keep : 1.0f;
+  const uint32_t lane_bit = 1u << l31;   // this lane's key inside a stored keep-bit word
 
   const bf16_t* qbase = p.Q.ptr + b * p.Q.bs + h * p.Q.hs;
   const bf16_t* dobase = p.dO.ptr + b * p.dO.bs + h * p.dO.hs;
@@ -1095,21 +1077,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_lds_kernel(const AttnArgs
   };
 
   const int frow = perm23(l31);  // fragment row of the row tiles (the MFMA row permutation)
-  int r_off[KS], t_off[MT][2][2];  // rows of sub-tile 1 sit 32 * 128 B further: same swizzle ((row >> 1) & 7 ignores bit 5)
+  int r_off[KS], t_off[MT][2];  // rows of sub-tile 1 sit 32 * 128 B further (the swizzle (row >> 1) & 7 ignores bit 5); its Q^T / dO^T
+  // chunks have index ^ 4 (^ 64 B).  ONE instance of the tile body for both sub-tiles and the edge tiles (see attn_fwd_lds_kernel).
 #pragma unroll
   for (int s = 0; s < KS; ++s) r_off[s] = frow * 128 + (((2 * s + hi) ^ ((frow >> 1) & 7)) << 4);
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-      for (int hf = 0; hf < 2; ++hf) {
-        const int d = mt * 32 + l31;
-        t_off[mt][sub][hf] = 2 * T_BYTES + d * 128 + (((4 * sub + 2 * hf + hi) ^ ((d >> 1) & 7)) << 4);
-      }
+    for (int hf = 0; hf < 2; ++hf) {
+      const int d = mt * 32 + l31;
+      t_off[mt][hf] = 2 * T_BYTES + d * 128 + (((2 * hf + hi) ^ ((d >> 1) & 7)) << 4);
+    }
 
-  auto tile = [&](auto edge_c, int q0, const char* base, int sub) {
-    constexpr bool EDGE = decltype(edge_c)::value;
+  auto tile = [&](const bool EDGE, int q0, const char* base, int sub) {
     f32x16 sacc, dpacc;
     zero16(sacc);
     zero16(dpacc);
@@ -1127,15 +1107,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_lds_kernel(const AttnArgs
       const float4 a0 = *reinterpret_cast<const float4*>(sp), a1 = *reinterpret_cast<const float4*>(sp + 4);
       const float4 b0 = *reinterpret_cast<const float4*>(sp + 64), b1 = *reinterpret_cast<const float4*>(sp + 68);
       const float lse[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w}, del[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-      uint32_t draw[8];
+      bool keepb[8];
       if (DROP && DBITS) {  // stored keep bits: word j = query row q0 + 16c + 8hi + j, bit l31 = this lane's key
         const uint32_t* bp = reinterpret_cast<const uint32_t*>(base + 4 * T_BYTES + 512 + w * 256) + 32 * sub + 16 * c + 8 * hi;
         const uint4 w0 = *reinterpret_cast<const uint4*>(bp), w1 = *reinterpret_cast<const uint4*>(bp + 4);
         const uint32_t ws[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
 #pragma unroll
-        for (int j = 0; j < 8; ++j) draw[j] = ((ws[j] >> l31) & 1u) ? 0x7ffu : 0u;  // >= thresh <=> keep
+        for (int j = 0; j < 8; ++j) keepb[j] = (ws[j] & lane_bit) != 0u;
       } else if (DROP) {
+        uint32_t draw[8];
         drop_draws8_keyowner(draw, bh_idx + (uint32_t)(q0 + 16 * c + 8 * hi), key, (p.Sk + 3) >> 2, mrb_lin_base(drop_seed, p.drop.site));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) keepb[j] = draw[j] >= p.drop.thresh24;
       }
       float pd[8], ds[8];  // pd: dropped P (without 1/(1-p));  ds: dS / scale  — both factors are applied once at the end
 #pragma unroll
@@ -1150,9 +1133,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_lds_kernel(const AttnArgs
         }
         float kfr = keep_scale, prd = pr;
         if (DROP) {
-          const bool keep = draw[j] >= p.drop.thresh24;
-          kfr = keep ? keep_scale : 0.f;
-          prd = keep ? pr : 0.f;
+          kfr = keepb[j] ? keep_scale : 0.f;
+          prd = keepb[j] ? pr : 0.f;
         }
         pd[j] = prd;
         ds[j] = pr * (kfr * dpacc[r] - del[j]);
@@ -1160,8 +1142,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_lds_kernel(const AttnArgs
       const bf16x8 pc = pack8(pd), sc = pack8(ds);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
-        dv[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(base + T_BYTES + t_off[mt][sub][c]), pc, dv[mt], 0, 0, 0);
-        dk[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(base + t_off[mt][sub][c]), sc, dk[mt], 0, 0, 0);
+        dv[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(base + T_BYTES + (t_off[mt][c] ^ (sub << 6))), pc, dv[mt], 0, 0, 0);
+        dk[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(base + (t_off[mt][c] ^ (sub << 6))), sc, dk[mt], 0, 0, 0);
       }
     }
   };
@@ -1175,12 +1157,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_lds_kernel(const AttnArgs
     const char* base = sm + (it & 1) * STAGE;
     if (active) {
 #pragma unroll
-      for (int sub = 0; sub < 2; ++sub) {
+      for (int sub = 0; sub < 2; ++sub) {   // (sub is a compile-time constant here: two instances, the edge test stays a run-time branch)
         const int q0 = st * 64 + 32 * sub;
-        if (q0 < p.Sq && !(CAUSAL && q0 + 31 < kb0)) {
-          if (q0 + 32 > p.Sq || (CAUSAL && q0 < kb0 + 31)) tile(BoolC<true>(), q0, base, sub);
-          else tile(BoolC<false>(), q0, base, sub);
-        }
+        if (q0 < p.Sq && !(CAUSAL && q0 + 31 < kb0)) tile(q0 + 32 > p.Sq || (CAUSAL && q0 < kb0 + 31), q0, base, sub);
       }
     }
   }
