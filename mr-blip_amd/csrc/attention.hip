@@ -113,9 +113,11 @@ template <bool LUT, int SGN>
 __device__ __forceinline__ void tile_scores(float (&sv)[16], const f32x16& sacc, float scale2, const float* lut, bool far_tile, int far_idx, int relbase) {
   if (LUT) {
     if (far_tile) {
-      const float bconst = lut[far_idx];
+      // wave-uniform bucket: through the scalar unit, so that each score is ONE v_fma with the addend in an SGPR — left in a VGPR the
+      // compiler merged this arm with the near arm's fmac and paid 15 broadcast moves per tile
+      const float bconst = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, lut[far_idx])));
 #pragma unroll
-      for (int r = 0; r < 16; ++r) sv[r] = sacc[r] * scale2 + bconst;
+      for (int r = 0; r < 16; ++r) sv[r] = __builtin_fmaf(sacc[r], scale2, bconst);
     } else {
       float bias[16];
 #pragma unroll
@@ -789,9 +791,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_lds_kernel(const AttnArgs 
 #pragma unroll
     for (int r = 0; r < 16; ++r) kf[r] = keep_scale;
     if (DROP && DBITS) {  // keep bits stored by the forward
-      const uint32_t wsh = dword >> (8 * hi);
+      const int wsh = (int)(dword >> (8 * hi));
 #pragma unroll
-      for (int r = 0; r < 16; ++r) kf[r] = (wsh & (1u << (16 * (r >> 3) + (r & 7)))) ? keep_scale : 0.f;
+      for (int r = 0; r < 16; ++r)   // v_bfe_i32: the key's bit as 0 / -1, then one AND (instead of and + compare + select)
+        kf[r] = __builtin_bit_cast(float, __builtin_amdgcn_sbfe(wsh, 16 * (r >> 3) + (r & 7), 1) & __builtin_bit_cast(int, keep_scale));
     } else if (DROP) {
       attn_keep16(t_lane, k0, p.drop.thresh24, [&](int r, bool kp) { kf[r] = kp ? keep_scale : 0.f; });
     }
@@ -1042,7 +1045,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_lds_kernel(const AttnArgs
   const int st0 = CAUSAL ? bx_ * 2 : 0;  // first 64-query stage (block-uniform); the per-wave causal limit is applied below
   const float scale2 = p.scale * MRB_LOG2E;
   const float keep_scale = DROP ? p.drop.inv_keep : 1.0f;
-  const uint32_t lane_bit = 1u << l31;   // this lane's key inside a stored keep-bit word
 
   const bf16_t* qbase = p.Q.ptr + b * p.Q.bs + h * p.Q.hs;
   const bf16_t* dobase = p.dO.ptr + b * p.dO.bs + h * p.dO.hs;
@@ -1107,18 +1109,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_lds_kernel(const AttnArgs
       const float4 a0 = *reinterpret_cast<const float4*>(sp), a1 = *reinterpret_cast<const float4*>(sp + 4);
       const float4 b0 = *reinterpret_cast<const float4*>(sp + 64), b1 = *reinterpret_cast<const float4*>(sp + 68);
       const float lse[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w}, del[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-      bool keepb[8];
+      int keepm[8];   // 0 / -1 per query row: the dropped values are cleared with one AND each
       if (DROP && DBITS) {  // stored keep bits: word j = query row q0 + 16c + 8hi + j, bit l31 = this lane's key
         const uint32_t* bp = reinterpret_cast<const uint32_t*>(base + 4 * T_BYTES + 512 + w * 256) + 32 * sub + 16 * c + 8 * hi;
         const uint4 w0 = *reinterpret_cast<const uint4*>(bp), w1 = *reinterpret_cast<const uint4*>(bp + 4);
         const uint32_t ws[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
 #pragma unroll
-        for (int j = 0; j < 8; ++j) keepb[j] = (ws[j] & lane_bit) != 0u;
+        for (int j = 0; j < 8; ++j) keepm[j] = __builtin_amdgcn_sbfe((int)ws[j], l31, 1);
       } else if (DROP) {
         uint32_t draw[8];
         drop_draws8_keyowner(draw, bh_idx + (uint32_t)(q0 + 16 * c + 8 * hi), key, (p.Sk + 3) >> 2, mrb_lin_base(drop_seed, p.drop.site));
 #pragma unroll
-        for (int j = 0; j < 8; ++j) keepb[j] = draw[j] >= p.drop.thresh24;
+        for (int j = 0; j < 8; ++j) keepm[j] = draw[j] >= p.drop.thresh24 ? -1 : 0;
       }
       float pd[8], ds[8];  // pd: dropped P (without 1/(1-p));  ds: dS / scale  — both factors are applied once at the end
 #pragma unroll
@@ -1133,8 +1135,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_lds_kernel(const AttnArgs
         }
         float kfr = keep_scale, prd = pr;
         if (DROP) {
-          kfr = keepb[j] ? keep_scale : 0.f;
-          prd = keepb[j] ? pr : 0.f;
+          kfr = __builtin_bit_cast(float, keepm[j] & __builtin_bit_cast(int, keep_scale));
+          prd = __builtin_bit_cast(float, keepm[j] & __builtin_bit_cast(int, pr));
         }
         pd[j] = prd;
         ds[j] = pr * (kfr * dpacc[r] - del[j]);

@@ -724,7 +724,10 @@ class MrBlipEngine:
     # instead of 12-22 us, and the RMSNorm fusion saves a launch); taller inputs (encoder, M = 2012 / 8048) keep the MFMA skinny
     # kernel: there every CU re-stages the thin vectors (same lines from the same L2 channels) and the row kernel is no faster
     # (tools/lora_rows_bench.py: 15.7 vs 12.6 us at M = 2012, 47 vs 15 us at M = 8048).
-    lora_rows_max_m = int(os.environ.get("MRB_LORA_ROWS_MAX_M", "256"))
+    # Round 3: the threshold went from 256 to 2100 rows — in the QVH step (M = 2012) the row kernel + the fused RMSNorm launch are 0.2 ms
+    # per step AHEAD (74.0 vs 74.2 ms, 48 launches fewer, the normalised rows are not re-read) although each launch alone is slower than
+    # the skinny kernel (15.7 vs 12.6 us); from M = 3992 (ActivityNet) on the skinny kernel stays.
+    lora_rows_max_m = int(os.environ.get("MRB_LORA_ROWS_MAX_M", "2100"))
 
     def lora_thin(self, x, a, u, K, drop=None, seg=None, init_dst=None, init_src=None):
         """u[:, :R] = dropout(x)[:, :K] @ a^T for a thin a ([R <= 32, K])"""
