@@ -188,6 +188,13 @@ def test_c3_batch4_step_equals_four_accumulated_single_clip_steps(xl):
     eng = xl[0]
     eng.training = False
     eng.cfg.mean_pool = False
+    # The contract is exact only when both runs execute the SAME kernels.  The thin LoRA products are the one place where the kernel
+    # choice follows the row count with a different summation order (row kernel up to 2100 rows = one QVH clip, MFMA skinny kernel above
+    # = four clips): u then differs in its last bf16 bit (1e-4 relative), which this ill-conditioned random-weight XL model (T5 attention is
+    # unscaled: score std ~6.5 at d_model 2048 with N(0, 0.02) weights, see make_golden_c2.py) amplifies to 9e-3 in the loss through 48
+    # layers.  Pin the choice for this test; test_lora_rows_kernel checks the two kernels against each other.
+    rows_max = eng.lora_rows_max_m
+    eng.lora_rows_max_m = 256
     samples, lay4 = _layout(xl, 4, 60, 150.0)
     # four different clips (same prompt, hence the same layout / label length per clip)
     video = samples["video"]
@@ -206,6 +213,7 @@ def test_c3_batch4_step_equals_four_accumulated_single_clip_steps(xl):
     check("c3.flat-grad B=4 vs 4 accumulated B=1 steps", relerr(g4, g1), 5e-6)
     check("c3.grad-norm B=4 vs accumulated (rel)", abs(g4.norm().item() - g1.norm().item()) / g1.norm().item(), 1e-5)
     assert len(set(round(x, 3) for x in ls)) > 1  # the clips really differ
+    eng.lora_rows_max_m = rows_max
 
 
 @pytest.mark.parametrize("name,T,dur,mean", [("c5.anet T=120", 120, 120.0, False), ("c4.charades T=20 mean-pool", 20, 30.0, True),

@@ -651,7 +651,7 @@ def test_lora_rows_kernel(ops, M, K, R):
         assert rel(us[:, :R].float(), x.float() @ ad.float().t()) < 4e-3
 
 
-@pytest.mark.parametrize("M,D,R", [(12, 2048, 24), (2012, 2048, 16), (77, 768, 24), (5, 64, 8)])
+@pytest.mark.parametrize("M,D,R", [(12, 2048, 24), (2012, 2048, 16), (2012, 2048, 24), (2012, 2048, 8), (77, 768, 24), (5, 64, 8)])
 def test_rmsnorm_lora_fused(ops, M, D, R):
     """fused T5 RMSNorm + LoRA down == rmsnorm_fwd followed by lora_rows (bit-identical xn; u identical: same arithmetic order per row)"""
     torch.manual_seed(22)
