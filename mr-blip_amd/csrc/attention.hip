@@ -41,7 +41,7 @@ struct AttnArgs {
                        // written by the LDS forward kernel and read back by the LDS backward kernels instead of re-hashing
 };
 
-enum { F_LUT = 1, F_MASK = 2, F_CAUSAL = 4, F_DROP = 8, F_SPLIT = 16, F_DBITS = 32, F_VROW = 64 };
+enum { F_LUT = 1, F_MASK = 2, F_CAUSAL = 4, F_DROP = 8, F_SPLIT = 16, F_DBITS = 32, F_VROW = 64, F_KS2 = 128 };
 
 // Attention-probability dropout draws (v2, round 3).  ONE 32-bit hash serves a key QUAD: index = row * ceil(Sk / 4) + key / 4 with
 // row = (b * H + h) * Sq + q, hash = mrb_lin_fin(index * MRB_H1 + mrb_lin_base(seed, site)) (common.h), and key 4i + j takes the
@@ -329,31 +329,36 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs p) {
 typedef __attribute__((address_space(3))) void* attn_lds_ptr_t;
 
 // one stage of LDS-DMA: CNT_A + CNT_B instructions per thread, destinations lane-linear (16 B per lane, 1 KB per wave and instruction)
-template <int CNT_A, int CNT_B>
+template <int CNT_A, int CNT_B, int NT = 256>
 __device__ __forceinline__ void attn_stage_dma(char* dstA, char* dstB, const void* srcA, uint32_t bytesA, const void* srcB, uint32_t bytesB,
                                                const uint32_t* vA, const uint32_t* vB, int w, uint32_t sA, uint32_t sB) {
   // (the buffer resource type exists on the device side only: it cannot appear in a signature the host pass also parses)
   const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(srcA), 0, (int)bytesA, 0x00020000);
   const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(srcB), 0, (int)bytesB, 0x00020000);
 #pragma unroll
-  for (int j = 0; j < CNT_A; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (attn_lds_ptr_t)(dstA + (j * 256 + w * 64) * 16), 16, vA[j], sA, 0, 0);
+  for (int j = 0; j < CNT_A; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (attn_lds_ptr_t)(dstA + (j * NT + w * 64) * 16), 16, vA[j], sA, 0, 0);
 #pragma unroll
-  for (int j = 0; j < CNT_B; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (attn_lds_ptr_t)(dstB + (j * 256 + w * 64) * 16), 16, vB[j], sB, 0, 0);
+  for (int j = 0; j < CNT_B; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (attn_lds_ptr_t)(dstB + (j * NT + w * 64) * 16), 16, vB[j], sB, 0, 0);
 }
 
 #ifndef ATTN96_BLOCKS
 #define ATTN96_BLOCKS 2   // resident blocks per CU the ViT form (DP = 96) is compiled for (3 = 168 VGPRs with 36 spilled dwords: measured, see DESIGN)
 #endif
+// F_KS2 (round 3, head_dim 64): EIGHT waves per block; waves w and w + 4 share one 32-row query tile and split the keys — wave w takes
+// the first 32-key sub-tile of every 64-key stage, wave w + 4 the second — and merge their (m, l, O) through LDS at the end.  Same stages,
+// same LDS traffic, but twice the waves: at S = 2012 x 32 heads there are only 2016 query tiles, i.e. TWO waves per SIMD, and a
+// VALU-bound kernel with 2 waves per SIMD left the VALU pipe idle a third of the time (round-2 counters: 67 % busy).
 template <int DP, int FLAGS>
-__global__ __launch_bounds__(256, (DP == 96 ? ATTN96_BLOCKS : 2)) void attn_fwd_lds_kernel(const AttnArgs p) {
+__global__ __launch_bounds__((FLAGS & F_KS2) ? 512 : 256, (FLAGS & F_KS2) ? 1 : (DP == 96 ? ATTN96_BLOCKS : 2)) void attn_fwd_lds_kernel(const AttnArgs p) {
   constexpr int KS = DP / 16, MT = DP / 32;
-  constexpr bool LUT = FLAGS & F_LUT, MASK = FLAGS & F_MASK, DROP = FLAGS & F_DROP, DBITS = FLAGS & F_DBITS;
+  constexpr bool LUT = FLAGS & F_LUT, MASK = FLAGS & F_MASK, DROP = FLAGS & F_DROP, DBITS = FLAGS & F_DBITS, KS2 = FLAGS & F_KS2;
+  constexpr int NT = KS2 ? 512 : 256;
   // VROW: V is staged ROW-major straight from the projection output (like K) and the V^T fragments of the second product are
   // gathered with the LDS transpose read (ds_read_b64_tr_b16, two per 32 x 16 fragment): no transposed copy of V in HBM
   constexpr bool VROW = FLAGS & F_VROW;
   constexpr int KROW = DP * 2, KCPR = DP / 8;                 // K row bytes, 16-B chunks per K row
   constexpr int K_BYTES = 64 * KROW, V_BYTES = DP * 128, STAGE = K_BYTES + V_BYTES;
-  constexpr int NJK = 64 * KCPR / 256, NJV = DP * 8 / 256;    // DMA instructions per thread per stage (VROW: 64 rows x KCPR chunks = the same count)
+  constexpr int NJK = 64 * KCPR / NT, NJV = DP * 8 / NT;      // DMA instructions per thread per stage (VROW: 64 rows x KCPR chunks = the same count)
   // everything lives in the dynamic region (a static array in front of it would shift its base off 16-B alignment)
   extern __shared__ __attribute__((aligned(16))) char sm[];  // 2 * STAGE bytes + 257-float bias LUT
   float* lut = reinterpret_cast<float*>(sm + 2 * STAGE);
@@ -362,9 +367,10 @@ __global__ __launch_bounds__(256, (DP == 96 ? ATTN96_BLOCKS : 2)) void attn_fwd_
   int bx_, h, b;
   attn_block(bx_, h, b);
   if (LUT) {
-    for (int i = tid; i < 257; i += 256) lut[i] = p.lut[h * 257 + i] * MRB_LOG2E;
+    for (int i = tid; i < 257; i += NT) lut[i] = p.lut[h * 257 + i] * MRB_LOG2E;
   }
-  const int q0 = (bx_ * 4 + w) * 32;
+  const int wsub = KS2 ? (w >> 2) : 0;   // KS2: the 32-key half of every stage this wave takes
+  const int q0 = (bx_ * 4 + (w & 3)) * 32;
   const bool active = q0 < p.Sq;  // wave-uniform; inactive waves still stage and hit the barriers
   const int q = q0 + l31;
   const bool q_ok = q < p.Sq;
@@ -398,17 +404,17 @@ __global__ __launch_bounds__(256, (DP == 96 ? ATTN96_BLOCKS : 2)) void attn_fwd_
   uint32_t vK[NJK], vV[NJV];
 #pragma unroll
   for (int j = 0; j < NJK; ++j) {
-    const int g = j * 256 + tid, row = g / KCPR, c = g % KCPR;
+    const int g = j * NT + tid, row = g / KCPR, c = g % KCPR;
     vK[j] = (uint32_t)((long long)row * p.K.rs * 2) + (uint32_t)((c ^ ksw(row)) * 16);
   }
 #pragma unroll
   for (int j = 0; j < NJV; ++j) {
-    const int g = j * 256 + tid, d = g >> 3, c = g & 7;
+    const int g = j * NT + tid, d = g >> 3, c = g & 7;
     if (VROW) vV[j] = (uint32_t)((long long)(g / KCPR) * p.V.rs * 2) + (uint32_t)((g % KCPR) * 16);   // row-major image, no swizzle (see vtr)
     else vV[j] = (uint32_t)((long long)d * p.Vt.ds * 2) + (uint32_t)((c ^ ((d >> 1) & 7)) * 16);
   }
   auto stage = [&](int st, int buf) {
-    attn_stage_dma<NJK, NJV>(sm + buf * STAGE, sm + buf * STAGE + K_BYTES, kbase, k_bytes, vtbase, v_bytes, vK, vV, w, (uint32_t)((long long)st * 64 * p.K.rs * 2),
+    attn_stage_dma<NJK, NJV, NT>(sm + buf * STAGE, sm + buf * STAGE + K_BYTES, kbase, k_bytes, vtbase, v_bytes, vK, vV, w, (uint32_t)((long long)st * 64 * p.K.rs * 2),
                              VROW ? (uint32_t)((long long)st * 64 * p.V.rs * 2) : (uint32_t)(st * 128));
   };
   // VROW fragment gather: each 16-lane group reads a [4 keys][16 d] block, lane i supplying the address of 4 contiguous d of key i / 4;
@@ -524,9 +530,9 @@ __global__ __launch_bounds__(256, (DP == 96 ? ATTN96_BLOCKS : 2)) void attn_fwd_
   stage(0, 0);
   uint32_t vm0 = 0xffffu, vm1 = 0xffffu;
 #pragma unroll 1
-  for (int t = 0; t < ntile; ++t) {  // one 32-key tile per trip; a new 64-key stage is handed over every second trip
+  for (int t = KS2 ? wsub : 0; t < (KS2 ? 2 * nst : ntile); t += KS2 ? 2 : 1) {  // one 32-key tile per trip (KS2: this wave's half of the stage)
     const int st = t >> 1, sub = t & 1;
-    if (sub == 0) {
+    if (KS2 || sub == 0) {
       if (MASK) {  // Skpad is a multiple of 32: the second half of the last stage may lie past the row
         vm0 = mask_bits(km, st * 64, hi);
         vm1 = st * 64 + 32 < p.Skpad ? mask_bits(km, st * 64 + 32, hi) : 0u;
@@ -535,7 +541,29 @@ __global__ __launch_bounds__(256, (DP == 96 ? ATTN96_BLOCKS : 2)) void attn_fwd_
       __syncthreads();  // stage st has landed for every wave; every wave is done reading the other buffer
       if (st + 1 < nst) stage(st + 1, (st + 1) & 1);
     }
-    if (active) tile(MASK || 32 * t + 32 > p.Sk, 32 * t, sm + (st & 1) * STAGE, sub, sub ? vm1 : vm0);
+    if (active && 32 * t < p.Sk) tile(MASK || 32 * t + 32 > p.Sk, 32 * t, sm + (st & 1) * STAGE, sub, sub ? vm1 : vm0);
+  }
+  if (KS2) {  // merge the two key halves of every query tile: wave w + 4 hands (m, l, O) to wave w through the (now idle) stage buffers
+    float* mg = reinterpret_cast<float*>(sm) + (w & 3) * ((MT * 16 + 2) * 64);
+    __syncthreads();
+    if (wsub == 1) {
+      mg[lane] = m_run;
+      mg[64 + lane] = l_run;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mg[(2 + mt * 16 + r) * 64 + lane] = o[mt][r];
+    }
+    __syncthreads();
+    if (wsub == 1) return;
+    const float m1 = mg[lane], m_all = fmaxf(m_run, m1);
+    const float f0 = ex2(m_run - m_all), f1 = ex2(m1 - m_all);
+    l_run = l_run * f0 + mg[64 + lane] * f1;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[mt][r] = o[mt][r] * f0 + mg[(2 + mt * 16 + r) * 64 + lane] * f1;
+    m_run = m_all;
   }
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = l_tot > 0.f ? (DROP ? p.drop.inv_keep : 1.0f) / l_tot : 0.f;
@@ -1251,9 +1279,28 @@ static int attn_flags(const AttnArgs& a, int causal) {
 // decision, so the stored keep bits are either written and read or ignored by all of them
 static bool use_lds64(const AttnArgs& a, int flags) { return a.D == 64 && !(flags & F_CAUSAL) && a.Sq > 32; }
 
+static int attn_ks2_mode() {  // MRB_ATTN_KS2: 0 = never, 1 = always, unset = when there are too few query tiles to give every SIMD four waves
+  static int m = -2;
+  if (m == -2) {
+    const char* e = getenv("MRB_ATTN_KS2");
+    m = e ? atoi(e) : -1;
+  }
+  return m;
+}
 template <int FL>
 static void fwd_lds64(const AttnArgs& a, dim3 grid, hipStream_t stream) {
   constexpr int LDS = 2 * (64 * 128 + 64 * 128) + 1040;
+  constexpr int LDS2 = 4 * (2 * 16 + 2) * 64 * 4 > LDS ? 4 * (2 * 16 + 2) * 64 * 4 : LDS;   // KS2: the merge area (4 x 34 x 64 floats) reuses the stages
+  const long long qtiles = (long long)((a.Sq + 31) / 32) * a.H * a.B;
+  const int mode = attn_ks2_mode();
+  // 1024 SIMDs: fewer than 3 query tiles (= waves) each -> split the keys.  Not for the key-mask variants: their 148 VGPRs allow one
+  // 8-wave block per CU only (measured: 84.5 vs 97.4 us per layer without a mask, 152 vs 132 us with one)
+  const bool ks2 = mode == 1 || (mode < 0 && qtiles <= 3 * 1024 && a.Sk >= 256 && !(FL & F_MASK));
+  if (ks2) {
+    if ((FL & F_DROP) && a.dbits) hipLaunchKernelGGL((attn_fwd_lds_kernel<64, ((FL & F_DROP) ? (FL | F_DBITS) : FL) | F_KS2>), grid, dim3(512), LDS2, stream, a);
+    else hipLaunchKernelGGL((attn_fwd_lds_kernel<64, FL | F_KS2>), grid, dim3(512), LDS2, stream, a);
+    return;
+  }
   if ((FL & F_DROP) && a.dbits) hipLaunchKernelGGL((attn_fwd_lds_kernel<64, (FL & F_DROP) ? (FL | F_DBITS) : FL>), grid, dim3(256), LDS, stream, a);
   else hipLaunchKernelGGL((attn_fwd_lds_kernel<64, FL>), grid, dim3(256), LDS, stream, a);
 }
