@@ -1293,6 +1293,8 @@ static void fwd_lds64(const AttnArgs& a, dim3 grid, hipStream_t stream) {
   constexpr int LDS2 = 4 * (2 * 16 + 2) * 64 * 4 > LDS ? 4 * (2 * 16 + 2) * 64 * 4 : LDS;   // KS2: the merge area (4 x 34 x 64 floats) reuses the stages
   const long long qtiles = (long long)((a.Sq + 31) / 32) * a.H * a.B;
   const int mode = attn_ks2_mode();
+  // (The same split for the dQ kernel was built and measured: it needs <= 128 VGPRs for two 8-wave blocks per CU, has 142, and forced
+  // to 128 it spills 19 dwords: 246 vs 213 us per layer — not kept.  The dK/dV kernel holds 193.)
   // 1024 SIMDs: fewer than 3 query tiles (= waves) each -> split the keys.  Not for the key-mask variants: their 148 VGPRs allow one
   // 8-wave block per CU only (measured: 84.5 vs 97.4 us per layer without a mask, 152 vs 132 us with one)
   const bool ks2 = mode == 1 || (mode < 0 && qtiles <= 3 * 1024 && a.Sk >= 256 && !(FL & F_MASK));
