@@ -166,6 +166,27 @@ __device__ __forceinline__ uint32_t mask_bits(const int* km, int k0, int hi) {
   return bits;
 }
 
+// LDS kernels (round 3): the key mask as a BITMAP in LDS, word t = keys 32t .. 32t + 31, built once per block — per 32-key tile a lane
+// then needs one broadcast LDS read and two bit-field ops instead of four 16-B global loads and 32 compare / shift / or instructions.
+#define ATTN_MASK_WORDS 256   // 8192 keys
+__device__ __forceinline__ void attn_mask_bitmap(uint32_t* mb, const int* km, int skpad, int tid, int nt) {
+  for (int wd = tid; wd < (skpad >> 5); wd += nt) {
+    uint32_t bits = 0;
+    const int4* p4 = reinterpret_cast<const int4*>(km + 32 * wd);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int4 a = p4[j];
+      bits |= ((uint32_t)(a.x != 0) | ((uint32_t)(a.y != 0) << 1) | ((uint32_t)(a.z != 0) << 2) | ((uint32_t)(a.w != 0) << 3)) << (4 * j);
+    }
+    mb[wd] = bits;
+  }
+}
+// this lane's 16 valid-key bits of tile t (register order: bit 8c + j <-> key 32t + 16c + 8hi + j), as mask_bits() returns them
+__device__ __forceinline__ uint32_t mask_bits_lds(const uint32_t* mb, int t, int hi) {
+  const uint32_t wd = mb[t] >> (8 * hi);
+  return (wd & 0xffu) | ((wd >> 8) & 0xff00u);
+}
+
 template <int DP, int FLAGS>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs p) {
   constexpr int KS = DP / 16, MT = DP / 32;
@@ -362,6 +383,7 @@ __global__ __launch_bounds__((FLAGS & F_KS2) ? 512 : 256, (FLAGS & F_KS2) ? 1 : 
   // everything lives in the dynamic region (a static array in front of it would shift its base off 16-B alignment)
   extern __shared__ __attribute__((aligned(16))) char sm[];  // 2 * STAGE bytes + 257-float bias LUT
   float* lut = reinterpret_cast<float*>(sm + 2 * STAGE);
+  uint32_t* mbits = reinterpret_cast<uint32_t*>(sm + 2 * STAGE + 1040);   // [ATTN_MASK_WORDS] key-mask bitmap (MASK only)
   const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   int bx_, h, b;
@@ -386,6 +408,7 @@ __global__ __launch_bounds__((FLAGS & F_KS2) ? 512 : 256, (FLAGS & F_KS2) ? 1 : 
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) zero16(o[mt]);
   const int* km = MASK ? p.kmask + (long long)b * p.Skpad : nullptr;
+  if (MASK) attn_mask_bitmap(mbits, km, p.Skpad, tid, NT);   // (visible after the first stage barrier below)
   const uint32_t drop_seed = DROP ? *p.drop.seed_ptr : 0u;
   const uint32_t row_id = (uint32_t)(b * p.H + h) * (uint32_t)p.Sq + (uint32_t)q;
   const uint32_t t_lane = DROP ? (row_id * (uint32_t)((p.Sk + 3) >> 2) + 2u * (uint32_t)hi) * MRB_H1 + mrb_lin_base(drop_seed, p.drop.site) : 0u;
@@ -533,12 +556,12 @@ __global__ __launch_bounds__((FLAGS & F_KS2) ? 512 : 256, (FLAGS & F_KS2) ? 1 : 
   for (int t = KS2 ? wsub : 0; t < (KS2 ? 2 * nst : ntile); t += KS2 ? 2 : 1) {  // one 32-key tile per trip (KS2: this wave's half of the stage)
     const int st = t >> 1, sub = t & 1;
     if (KS2 || sub == 0) {
-      if (MASK) {  // Skpad is a multiple of 32: the second half of the last stage may lie past the row
-        vm0 = mask_bits(km, st * 64, hi);
-        vm1 = st * 64 + 32 < p.Skpad ? mask_bits(km, st * 64 + 32, hi) : 0u;
-      }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();  // stage st has landed for every wave; every wave is done reading the other buffer
+      if (MASK) {  // Skpad is a multiple of 32: the second half of the last stage may lie past the row
+        vm0 = mask_bits_lds(mbits, 2 * st, hi);
+        vm1 = st * 64 + 32 < p.Skpad ? mask_bits_lds(mbits, 2 * st + 1, hi) : 0u;
+      }
       if (st + 1 < nst) stage(st + 1, (st + 1) & 1);
     }
     if (active && 32 * t < p.Sk) tile(MASK || 32 * t + 32 > p.Sk, 32 * t, sm + (st & 1) * STAGE, sub, sub ? vm1 : vm0);
@@ -730,6 +753,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_lds_kernel(const AttnArgs 
   // everything lives in the dynamic region (a static array in front of it would shift its base off 16-B alignment)
   extern __shared__ __attribute__((aligned(16))) char sm[];  // 2 * STAGE bytes + 257-float bias LUT
   float* lut = reinterpret_cast<float*>(sm + 2 * STAGE);
+  uint32_t* mbits = reinterpret_cast<uint32_t*>(sm + 2 * STAGE + 1040);   // [ATTN_MASK_WORDS] key-mask bitmap (MASK only)
   const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   int bx_, h, b;
@@ -764,6 +788,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_lds_kernel(const AttnArgs 
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) zero16(dq[mt]);
   const int* km = MASK ? p.kmask + (long long)b * p.Skpad : nullptr;
+  if (MASK) attn_mask_bitmap(mbits, km, p.Skpad, tid, 256);
   const uint32_t drop_seed = DROP ? *p.drop.seed_ptr : 0u;
   const uint32_t row_id = (uint32_t)(b * p.H + h) * (uint32_t)p.Sq + (uint32_t)q;
   const uint32_t t_lane = DROP ? (row_id * (uint32_t)((p.Sk + 3) >> 2) + 2u * (uint32_t)hi) * MRB_H1 + mrb_lin_base(drop_seed, p.drop.site) : 0u;
@@ -856,12 +881,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_lds_kernel(const AttnArgs 
   }
   for (int st = 0; st < nst; ++st) {
     uint32_t vm0 = 0xffffu, vm1 = 0xffffu;
-    if (MASK) {
-      vm0 = mask_bits(km, st * 64, hi);
-      vm1 = st * 64 + 32 < p.Skpad ? mask_bits(km, st * 64 + 32, hi) : 0u;
-    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if (MASK) {
+      vm0 = mask_bits_lds(mbits, 2 * st, hi);
+      vm1 = st * 64 + 32 < p.Skpad ? mask_bits_lds(mbits, 2 * st + 1, hi) : 0u;
+    }
     const uint32_t cw0 = dw0, cw1 = dw1;
     if (st + 1 < nst) {
       stage(st + 1, (st + 1) & 1);
@@ -1277,27 +1302,25 @@ static int attn_flags(const AttnArgs& a, int causal) {
 
 // the LDS kernels of the head_dim-64, non-causal, Sq > 32 shapes (T5 encoder, Q-Former... ): all three passes take the same
 // decision, so the stored keep bits are either written and read or ignored by all of them
-static bool use_lds64(const AttnArgs& a, int flags) { return a.D == 64 && !(flags & F_CAUSAL) && a.Sq > 32; }
+static bool use_lds64(const AttnArgs& a, int flags) {
+  return a.D == 64 && !(flags & F_CAUSAL) && a.Sq > 32 && !((flags & F_MASK) && a.Skpad > 32 * ATTN_MASK_WORDS);   // (the LDS key-mask bitmap holds 8192 keys)
+}
 
 static int attn_ks2_mode() {  // MRB_ATTN_KS2: 0 = never, 1 = always, unset = when there are too few query tiles to give every SIMD four waves
-  static int m = -2;
-  if (m == -2) {
-    const char* e = getenv("MRB_ATTN_KS2");
-    m = e ? atoi(e) : -1;
-  }
-  return m;
+  const char* e = getenv("MRB_ATTN_KS2");   // (read per launch: tests pin the choice while they compare runs of different batch sizes)
+  return e ? atoi(e) : -1;
 }
 template <int FL>
 static void fwd_lds64(const AttnArgs& a, dim3 grid, hipStream_t stream) {
-  constexpr int LDS = 2 * (64 * 128 + 64 * 128) + 1040;
+  constexpr int LDS = 2 * (64 * 128 + 64 * 128) + 1040 + ((FL & F_MASK) ? 4 * ATTN_MASK_WORDS : 0);
   constexpr int LDS2 = 4 * (2 * 16 + 2) * 64 * 4 > LDS ? 4 * (2 * 16 + 2) * 64 * 4 : LDS;   // KS2: the merge area (4 x 34 x 64 floats) reuses the stages
   const long long qtiles = (long long)((a.Sq + 31) / 32) * a.H * a.B;
   const int mode = attn_ks2_mode();
   // (The same split for the dQ kernel was built and measured: it needs <= 128 VGPRs for two 8-wave blocks per CU, has 142, and forced
   // to 128 it spills 19 dwords: 246 vs 213 us per layer — not kept.  The dK/dV kernel holds 193.)
-  // 1024 SIMDs: fewer than 3 query tiles (= waves) each -> split the keys.  Not for the key-mask variants: their 148 VGPRs allow one
-  // 8-wave block per CU only (measured: 84.5 vs 97.4 us per layer without a mask, 152 vs 132 us with one)
-  const bool ks2 = mode == 1 || (mode < 0 && qtiles <= 3 * 1024 && a.Sk >= 256 && !(FL & F_MASK));
+  // 1024 SIMDs: fewer than 3 query tiles (= waves) each -> split the keys (measured: 84.5 vs 97.4 us per layer; the key-mask variants
+  // follow since their mask comes from the LDS bitmap: 148 -> 123 VGPRs, two 8-wave blocks per CU)
+  const bool ks2 = mode == 1 || (mode < 0 && qtiles <= 3 * 1024 && a.Sk >= 256);
   if (ks2) {
     if ((FL & F_DROP) && a.dbits) hipLaunchKernelGGL((attn_fwd_lds_kernel<64, ((FL & F_DROP) ? (FL | F_DBITS) : FL) | F_KS2>), grid, dim3(512), LDS2, stream, a);
     else hipLaunchKernelGGL((attn_fwd_lds_kernel<64, FL | F_KS2>), grid, dim3(512), LDS2, stream, a);
@@ -1308,7 +1331,7 @@ static void fwd_lds64(const AttnArgs& a, dim3 grid, hipStream_t stream) {
 }
 template <int FL>
 static void dq_lds64(const AttnArgs& a, dim3 grid, hipStream_t stream) {
-  constexpr int LDS = 2 * 3 * 64 * 128 + 1040;
+  constexpr int LDS = 2 * 3 * 64 * 128 + 1040 + ((FL & F_MASK) ? 4 * ATTN_MASK_WORDS : 0);
   if ((FL & F_DROP) && a.dbits) hipLaunchKernelGGL((attn_bwd_dq_lds_kernel<(FL & F_DROP) ? (FL | F_DBITS) : FL>), grid, dim3(256), LDS, stream, a);
   else hipLaunchKernelGGL((attn_bwd_dq_lds_kernel<FL>), grid, dim3(256), LDS, stream, a);
 }
