@@ -49,6 +49,13 @@ __device__ __forceinline__ uint32_t mrb_hash(uint32_t idx, uint32_t seed, uint32
 }
 // One 32-bit hash serves the element PAIR (idx & ~1, idx | 1): even index -> low 16 bits, odd index -> high 16 bits.
 // keep iff the 16-bit draw >= thresh16 = round(p * 65536)   (p = 0.1 -> 6554/65536 = 0.10001)
+// the step's dropout seed lives in device memory (written by the host-side engine before the step, never inside a kernel that reads it):
+// fetch it with ONE scalar load (constant address space -> s_load_dword through the scalar cache, which is invalidated at every kernel
+// start) instead of a per-use vector load
+__device__ __forceinline__ uint32_t mrb_seed_load(const uint32_t* p) {
+  return *reinterpret_cast<const __attribute__((address_space(4))) uint32_t*>(reinterpret_cast<uintptr_t>(p));
+}
+
 __device__ __forceinline__ bool mrb_keep(uint32_t idx, uint32_t seed, uint32_t site, uint32_t thresh16) {
   const uint32_t h = mrb_hash(idx >> 1, seed, site);
   return ((idx & 1u) ? (h >> 16) : (h & 0xffffu)) >= thresh16;

@@ -56,7 +56,7 @@ __device__ __forceinline__ void epilogue_apply4(const GemmArgs& p, int m, int n0
     gelu_erf2(v2, v3);
   }
   if (p.drop.seed_ptr) {
-    const uint32_t seed = *p.drop.seed_ptr;
+    const uint32_t seed = mrb_seed_load(p.drop.seed_ptr);
     const uint32_t e = (uint32_t)m * (uint32_t)ncols + (uint32_t)n0;
     v0 = mrb_keep(e, seed, p.drop.site, p.drop.thresh24) ? v0 * p.drop.inv_keep : 0.f;
     v1 = mrb_keep(e + 1, seed, p.drop.site, p.drop.thresh24) ? v1 * p.drop.inv_keep : 0.f;
@@ -99,8 +99,48 @@ __device__ __forceinline__ void epilogue_store8(const GemmArgs& p, bool out_f32,
   }
 }
 
+// ---- the same epilogue with the operands ALREADY LOADED (tile kernel).  Round 3, ISA reading of the run-time-flag helpers above inside
+// the tile kernel: every `if (p.bias) load`, `*p.drop.seed_ptr` (a VECTOR load of the seed) and `if (p.residual) load` sat in its own
+// branch, each followed by s_waitcnt vmcnt(0) — per 8-column item 2 seed + 2 residual round trips in series, 4 items per wave and
+// tile: ~10 us of exposed memory latency per [2012 x 2048] tile whose K loop takes ~25 us.  Now the kernel fetches the seed once with
+// a scalar load, and reads bias / residual of all its items up front through bounds-checked buffer resources (absent operand: zero
+// records -> zeros, no branch), so all loads of a slab are in flight together.
+__device__ __forceinline__ void epilogue_apply4v(const GemmArgs& p, uint32_t seed, int m, int n0, float& v0, float& v1, float& v2, float& v3, int ncols,
+                                                 uint2& pre, const float4 b, const float4 r) {
+  if (p.bias) { v0 += b.x; v1 += b.y; v2 += b.z; v3 += b.w; }
+  pre = make_uint2(pack2bf(v0, v1), pack2bf(v2, v3));
+  if (p.act == 1) {
+    gelu_erf2(v0, v1);
+    gelu_erf2(v2, v3);
+  }
+  if (p.drop.seed_ptr) {
+    const uint32_t e = (uint32_t)m * (uint32_t)ncols + (uint32_t)n0;
+    v0 = mrb_keep(e, seed, p.drop.site, p.drop.thresh24) ? v0 * p.drop.inv_keep : 0.f;
+    v1 = mrb_keep(e + 1, seed, p.drop.site, p.drop.thresh24) ? v1 * p.drop.inv_keep : 0.f;
+    v2 = mrb_keep(e + 2, seed, p.drop.site, p.drop.thresh24) ? v2 * p.drop.inv_keep : 0.f;
+    v3 = mrb_keep(e + 3, seed, p.drop.site, p.drop.thresh24) ? v3 * p.drop.inv_keep : 0.f;
+  }
+  if (p.residual) { v0 += r.x; v1 += r.y; v2 += r.z; v3 += r.w; }
+}
+
+__device__ __forceinline__ void epilogue_store8v(const GemmArgs& p, uint32_t seed, bool out_f32, int m, int n0, float4 a, float4 b, int ncols,
+                                                 const float4 b0, const float4 b1, const float4 r0, const float4 r1) {
+  uint2 pre0, pre1;
+  epilogue_apply4v(p, seed, m, n0, a.x, a.y, a.z, a.w, ncols, pre0, b0, r0);
+  epilogue_apply4v(p, seed, m, n0 + 4, b.x, b.y, b.z, b.w, ncols, pre1, b1, r1);
+  if (p.out2) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.out2) + (long long)m * p.ldo2 + n0) = make_uint4(pre0.x, pre0.y, pre1.x, pre1.y);
+  if (out_f32) {
+    float4* o = reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + (long long)m * p.ldo + n0);
+    o[0] = a;
+    o[1] = b;
+  } else {
+    *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.out) + (long long)m * p.ldo + n0) =
+        make_uint4(pack2bf(a.x, a.y), pack2bf(a.z, a.w), pack2bf(b.x, b.y), pack2bf(b.z, b.w));
+  }
+}
+
 // gated: y = dropout(gelu(h0) * h1) for 8 consecutive columns; optional out2 = [h0 | h1] stacked ([M, 2*nh])
-__device__ __forceinline__ void epilogue_gated8(const GemmArgs& p, int m, int n0, const float h0[8], const float h1[8], int nh) {
+__device__ __forceinline__ void epilogue_gated8(const GemmArgs& p, uint32_t seed, int m, int n0, const float h0[8], const float h1[8], int nh) {
   if (p.out2) {
     bf16_t* o2 = reinterpret_cast<bf16_t*>(p.out2) + (long long)m * p.ldo2;
     *reinterpret_cast<uint4*>(o2 + n0) = make_uint4(pack2bf(h0[0], h0[1]), pack2bf(h0[2], h0[3]), pack2bf(h0[4], h0[5]), pack2bf(h0[6], h0[7]));
@@ -115,7 +155,6 @@ __device__ __forceinline__ void epilogue_gated8(const GemmArgs& p, int m, int n0
     v[i + 1] = g1 * h1[i + 1];
   }
   if (p.drop.seed_ptr) {
-    const uint32_t seed = *p.drop.seed_ptr;
 #pragma unroll
     for (int i = 0; i < 8; ++i)
       v[i] = mrb_keep((uint32_t)m * (uint32_t)nh + (uint32_t)(n0 + i), seed, p.drop.site, p.drop.thresh24) ? v[i] * p.drop.inv_keep : 0.f;
@@ -125,6 +164,8 @@ __device__ __forceinline__ void epilogue_gated8(const GemmArgs& p, int m, int n0
 }
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef uint32_t mrb_u32x4 __attribute__((ext_vector_type(4)));
+typedef float mrb_f32x4 __attribute__((ext_vector_type(4)));
 
 // One K-tile of operands: CA + CW LDS-DMA pieces per wave (1 KiB each, lane-linear in LDS); per-piece source offsets come in VGPRs,
 // the only per-K-tile scalar is the byte offset along k.  (A device function, not a lambda: the buffer-resource type does not
@@ -183,6 +224,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, gemm_min_blocks(NS * (BM + BN) * BK 
   int bm = 0, bn = 0;  // current tile (persistent loop below)
 
   const int Nh = p.N >> 1;                    // GATED only
+  const uint32_t drop_seed = p.drop.seed_ptr ? mrb_seed_load(p.drop.seed_ptr) : 0u;  // one scalar load per block
   constexpr int BNO = GATED ? BN / 2 : BN;  // output columns per block
 
   // ---- operands are read through bounds-checked buffer resources (built in stage()): rows >= M / >= N read as zero, never fault
@@ -332,7 +374,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, gemm_min_blocks(NS * (BM + BN) * BK 
     }
 #endif
     if (!GATED && ext_first && kt == NEXT - 1 && p.ext_drop.seed_ptr) {  // acc == Aext Wext^T: apply the LoRA input-dropout mask to it
-      const uint32_t seed = *p.ext_drop.seed_ptr;
+      const uint32_t seed = mrb_seed_load(p.ext_drop.seed_ptr);
 #pragma unroll
       for (int mt = 0; mt < TM; ++mt) {
         const uint32_t m = (uint32_t)(bm * BM + wm * (BM / WGM) + mt * 32 + l31);
@@ -364,6 +406,11 @@ __global__ __launch_bounds__(WGM* WGN * 64, gemm_min_blocks(NS * (BM + BN) * BK 
   __syncthreads();                                 // every wave is done reading the staging buffers
   char* slab = smem + w * (32 * RS);
   const int ncols = GATED ? Nh : p.N;
+  // bias [N] and residual [M, ldr] as buffer resources: an absent operand gets zero records (every load returns 0), rows >= M lie
+  // beyond the residual's last byte
+  const __amdgpu_buffer_rsrc_t bias_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias), 0, p.bias ? p.N * 4 : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t res_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.residual), 0, p.residual ? (int)((((long long)p.M - 1) * p.ldr + p.N) * 4) : 0, 0x00020000);
 #ifdef EXP_NOEPI
   if (p.M == -12345)  // EXPERIMENT (wrong results): no epilogue at all
 #endif
@@ -386,17 +433,33 @@ __global__ __launch_bounds__(WGM* WGN * 64, gemm_min_blocks(NS * (BM + BN) * BK 
         const int m = m_base + r, n0 = bn * BNO + wn * 32 + c * 4;
         if (m < p.M && n0 < Nh) {
           const float h0[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w}, h1[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-          epilogue_gated8(p, m, n0, h0, h1, Nh);
+          epilogue_gated8(p, drop_seed, m, n0, h0, h1, Nh);
         }
       }
     } else {
       constexpr int GPR = CPR / 2;                 // 8-column groups per slab row
+      constexpr int NIT = 32 * GPR / 64;
+      // bias / residual of every item of this slab first (bounds-checked: rows >= M and absent operands read as zero), all in flight
+      mrb_f32x4 bq[NIT][2], rq[NIT][2];
 #pragma unroll
-      for (int i = 0; i < 32 * GPR / 64; ++i) {
+      for (int i = 0; i < NIT; ++i) {
+        const int idx = i * 64 + lane, r = idx / GPR, c = (idx % GPR) * 2;
+        const int m = m_base + r, n0 = bn * BN + wn * (BN / WGN) + c * 4;
+        const uint32_t ob = (uint32_t)n0 * 4u, orr = (uint32_t)(((long long)m * p.ldr + n0) * 4);
+        bq[i][0] = __builtin_bit_cast(mrb_f32x4, __builtin_amdgcn_raw_buffer_load_b128(bias_rsrc, ob, 0, 0));
+        bq[i][1] = __builtin_bit_cast(mrb_f32x4, __builtin_amdgcn_raw_buffer_load_b128(bias_rsrc, ob + 16u, 0, 0));
+        rq[i][0] = __builtin_bit_cast(mrb_f32x4, __builtin_amdgcn_raw_buffer_load_b128(res_rsrc, orr, 0, 0));
+        rq[i][1] = __builtin_bit_cast(mrb_f32x4, __builtin_amdgcn_raw_buffer_load_b128(res_rsrc, orr + 16u, 0, 0));
+      }
+#pragma unroll
+      for (int i = 0; i < NIT; ++i) {
         const int idx = i * 64 + lane, r = idx / GPR, c = (idx % GPR) * 2;
         const float4 a0 = *reinterpret_cast<const float4*>(slab + r * RS + c * 16), a1 = *reinterpret_cast<const float4*>(slab + r * RS + (c + 1) * 16);
         const int m = m_base + r, n0 = bn * BN + wn * (BN / WGN) + c * 4;
-        if (m < p.M && n0 < p.N) epilogue_store8(p, OUT_F32, m, n0, a0, a1, ncols);
+        if (m < p.M && n0 < p.N)
+          epilogue_store8v(p, drop_seed, OUT_F32, m, n0, a0, a1, ncols, make_float4(bq[i][0][0], bq[i][0][1], bq[i][0][2], bq[i][0][3]),
+                           make_float4(bq[i][1][0], bq[i][1][1], bq[i][1][2], bq[i][1][3]), make_float4(rq[i][0][0], rq[i][0][1], rq[i][0][2], rq[i][0][3]),
+                           make_float4(rq[i][1][0], rq[i][1][1], rq[i][1][2], rq[i][1][3]));
       }
     }
   }
@@ -1170,7 +1233,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const GemmArgs p) 
       }
     }
     if (p.a_drop.seed_ptr) {  // dropout(x) for the LoRA "down" product: element (m_row, k) of the [M, K] input, pair-hashed
-      const uint32_t seed = *p.a_drop.seed_ptr;
+      const uint32_t seed = mrb_seed_load(p.a_drop.seed_ptr);
 #pragma unroll
       for (int u = 0; u < UNR; ++u) {
         const uint32_t kbase = (uint32_t)m_row * (uint32_t)p.K + (uint32_t)(min(kb0 + u, kb_end - 1) * 64 + hi * 32);
@@ -1206,7 +1269,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const GemmArgs p) 
       e = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, e, 0, 0, 0);
     }
     if (p.ext_first && p.ext_drop.seed_ptr) {  // LoRA backward form: mask the extension product (see GemmArgs)
-      const uint32_t seed = *p.ext_drop.seed_ptr;
+      const uint32_t seed = mrb_seed_load(p.ext_drop.seed_ptr);
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const uint32_t n0 = (uint32_t)(blockIdx.x * 32 + 8 * g + 4 * hi);
@@ -1240,7 +1303,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const GemmArgs p) 
     if (m_ok && OUT_F32 && p.k_splits > 1) {
       // K-split form: this block's partial product (bias by the first split, the output dropout mask on every partial: it is linear)
       // is added to the pre-initialised fp32 output
-      const uint32_t seed = p.drop.seed_ptr ? *p.drop.seed_ptr : 0u;
+      const uint32_t seed = p.drop.seed_ptr ? mrb_seed_load(p.drop.seed_ptr) : 0u;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int n0 = blockIdx.x * 32 + 8 * g + 4 * hi;
@@ -1643,88 +1706,121 @@ struct TnArgs2 { TnArgs a, b; int blocks_a; };  // two independent problems in o
 
 __global__ __launch_bounds__(512) void lora_tn_kernel(const TnArgs2 q) {
   const bool second = (int)blockIdx.x >= q.blocks_a;  // block-uniform
-  const TnArgs& p = second ? q.b : q.a;
   const int bx = second ? blockIdx.x - q.blocks_a : blockIdx.x;
+  // The problem's scalars are copied out of the kernel arguments ONCE.  (Round 3, ISA reading: with `const TnArgs& p = second ? q.b : q.a`
+  // the compiler kept a run-time pointer into the kernarg segment and re-fetched p.Y / p.ldy / p.drop.* with s_load + s_waitcnt lgkmcnt(0)
+  // at every use — 40 scalar round trips per loop iteration, ~1 us per pair of slices.)
+#define TN_SEL(f) (second ? q.b.f : q.a.f)
+  const bf16_t* __restrict__ const Y = TN_SEL(Y);
+  const bf16_t* __restrict__ const U = TN_SEL(U);
+  const long long ldy = TN_SEL(ldy), ldu = TN_SEL(ldu);
+  const int M = TN_SEL(M), C = TN_SEL(C), R = TN_SEL(R);
+  const uint32_t* const seed_ptr = TN_SEL(drop.seed_ptr);
+  const uint32_t site = TN_SEL(drop.site), thresh24 = TN_SEL(drop.thresh24);
+  const float inv_keep = TN_SEL(drop.inv_keep);
+#undef TN_SEL
+  const bool has_drop = seed_ptr != nullptr;
   // Each wave stages its own 16-row slices of Y (16 x 32 columns) and U (16 x 32) with ONE 16-B global load per lane each,
   // parks them in a wave-private LDS slot and gathers the k-major MFMA fragments from there with 2-byte LDS reads.
   // UNROLL 16-row slices are in flight per wave (one 16-B load per lane and operand each) and go through the wave's two LDS slots in
-  // pairs.  Round 3 measured 2 / 4 / 8 / 16 slices in flight (-DLORA_TN_UNROLL=): qkv group 27.3 / 26.9 / 27.6 / 39.2 us, wi group 29.5 /
-  // 31.1 / 36.6 / 56.7 us, step 76.0 / 76.1 / 76.9 / 79.5 ms — more bytes in flight do NOT help (the launch is not latency-bound; the
-  // registers they cost do hurt): 2 stays.  (profiles/r03_lora_tn_unroll.txt)
+  // pairs.  (The 2 / 4 / 8 / 16 sweep of profiles/r03_lora_tn_unroll.txt — no gain from more slices in flight — was taken BEFORE the
+  // kernarg re-fetch above was found; see profiles/r03_lora_tn_v2.txt for the sweep after it.)
 #ifndef LORA_TN_UNROLL
 #define LORA_TN_UNROLL 2
 #endif
-  constexpr int UNROLL = LORA_TN_UNROLL, NSLOT = 2;
-  __shared__ float red[7][16][64];
-  __shared__ __attribute__((aligned(16))) bf16_t slot[8][NSLOT][2][16 * 32];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, hi = lane >> 5, l31 = lane & 31;
+  constexpr int UNROLL = LORA_TN_UNROLL;  // slices per iteration = LDS slots per wave
+  // LDS: the wave-private staging slots (8 waves x UNROLL x 2 KB) and, after the M loop, the cross-wave reduction buffer (32 KB) share
+  // one allocation
+  constexpr int SLOT_BYTES = 8 * UNROLL * 2 * 16 * 32 * 2, RED_BYTES = 8 * 16 * 64 * 4;
+  __shared__ __attribute__((aligned(16))) char tn_lds[SLOT_BYTES > RED_BYTES ? SLOT_BYTES : RED_BYTES];
+  typedef bf16_t slot_t[UNROLL][2][16 * 32];
+  slot_t* const slot = reinterpret_cast<slot_t*>(tn_lds);
+  typedef float red_t[16][64];
+  red_t* const red = reinterpret_cast<red_t*>(tn_lds);
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), hi = lane >> 5, l31 = lane & 31;
   const int c0 = bx * 32;
   const int c = c0 + l31;
-  const bool c_ok = c < p.C;
-  const uint32_t seed = p.drop.seed_ptr ? *p.drop.seed_ptr : 0u;
+  const bool c_ok = c < C;
+  const uint32_t seed = has_drop ? *seed_ptr : 0u;
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  const int steps = (p.M + 15) / 16;                 // 16 rows of M per MFMA
+  const int steps = (M + 15) / 16;                 // 16 rows of M per MFMA
   const int per = (steps + 7) / 8;
   const int s_beg = w * per, s_end = min(steps, s_beg + per);
   const int srow = lane >> 2, schunk = lane & 3;     // staging role: row of the 16-row slice, 8-column chunk
-  const bool ychunk_ok = c0 + 8 * schunk < p.C, uchunk_ok = 8 * schunk < p.R;
+  const bool ychunk_ok = c0 + 8 * schunk < C, uchunk_ok = 8 * schunk < R;
   const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll 1
-  for (int s0 = s_beg; s0 < s_end; s0 += UNROLL) {
-    bf16x8 gy[UNROLL], gu[UNROLL];
+  const bf16_t* const ysrc = Y + c0 + 8 * schunk;
+  const bf16_t* const usrc = U + 8 * schunk;
+  bf16x8 gy[UNROLL], gu[UNROLL];
+  // software pipeline: the global loads of iteration i+1 are issued as soon as iteration i's registers have been parked in LDS, and
+  // fly while iteration i's fragments are gathered and multiplied
+  auto fetch = [&](int s0) {
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
       const int m = (s0 + u) * 16 + srow;
-      const bool ok = (s0 + u < s_end) && m < p.M;
+      const bool ok = (s0 + u < s_end) && m < M;
       const long long mm = ok ? m : 0;
-      gy[u] = (ok && ychunk_ok) ? *reinterpret_cast<const bf16x8*>(p.Y + mm * p.ldy + c0 + 8 * schunk) : zero;
-      gu[u] = (ok && uchunk_ok) ? *reinterpret_cast<const bf16x8*>(p.U + mm * p.ldu + 8 * schunk) : zero;
+      gy[u] = (ok && ychunk_ok) ? *reinterpret_cast<const bf16x8*>(ysrc + mm * ldy) : zero;
+      gu[u] = (ok && uchunk_ok) ? *reinterpret_cast<const bf16x8*>(usrc + mm * ldu) : zero;
     }
+  };
+  if (s_beg < s_end) fetch(s_beg);
+#pragma unroll 1
+  for (int s0 = s_beg; s0 < s_end; s0 += UNROLL) {
 #pragma unroll
-    for (int u0 = 0; u0 < UNROLL; u0 += NSLOT) {
+    for (int v = 0; v < UNROLL; ++v) {
+      *reinterpret_cast<bf16x8*>(&slot[w][v][0][srow * 32 + schunk * 8]) = gy[v];
+      *reinterpret_cast<bf16x8*>(&slot[w][v][1][srow * 32 + schunk * 8]) = gu[v];
+    }
+    if (s0 + UNROLL < s_end) fetch(s0 + UNROLL);   // wave-uniform
 #pragma unroll
-      for (int v = 0; v < NSLOT; ++v) {
-        *reinterpret_cast<bf16x8*>(&slot[w][v][0][srow * 32 + schunk * 8]) = gy[u0 + v];
-        *reinterpret_cast<bf16x8*>(&slot[w][v][1][srow * 32 + schunk * 8]) = gu[u0 + v];
+    for (int v = 0; v < UNROLL; ++v) {
+      bf16x8 yf, uf;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        yf[j] = (short)slot[w][v][0][(8 * hi + j) * 32 + l31];
+        uf[j] = (short)slot[w][v][1][(8 * hi + j) * 32 + l31];
       }
-#pragma unroll
-      for (int v = 0; v < NSLOT; ++v) {
-        const int u = u0 + v;
-        bf16x8 yf, uf;
+      if (has_drop) {  // wave-uniform
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          bf16_t yv = slot[w][v][0][(8 * hi + j) * 32 + l31];
-          if (p.drop.seed_ptr) {
-            const int m = (s0 + u) * 16 + 8 * hi + j;
-            const bool keep = mrb_keep((uint32_t)m * (uint32_t)p.C + (uint32_t)c, seed, p.drop.site, p.drop.thresh24);
-            yv = keep ? f2bf(bf2f(yv) * p.drop.inv_keep) : (bf16_t)0;
-          }
-          yf[j] = (short)yv;
-          uf[j] = (short)slot[w][v][1][(8 * hi + j) * 32 + l31];
+          const int m = (s0 + v) * 16 + 8 * hi + j;
+          const bool keep = mrb_keep((uint32_t)m * (uint32_t)C + (uint32_t)c, seed, site, thresh24);
+          yf[j] = keep ? (short)f2bf(bf2f((bf16_t)yf[j]) * inv_keep) : (short)0;
         }
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uf, yf, acc, 0, 0, 0);
       }
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uf, yf, acc, 0, 0, 0);
     }
   }
-  if (w > 0) {
+  __syncthreads();  // every wave is done with its staging slots: the reduction buffer may overwrite them
 #pragma unroll
-    for (int r = 0; r < 16; ++r) red[w - 1][r][lane] = acc[r];
-  }
+  for (int r = 0; r < 16; ++r) red[w][r][lane] = acc[r];
   __syncthreads();
-  if (w == 0 && c_ok) {
+  // epilogue spread over the 8 waves: wave w owns accumulator rows r = 2w, 2w+1 (both in adapter segment w >> 1), sums the 8 partials in
+  // wave order (same order as ever: bit-identical) and does its two read-modify-writes with both loads in flight.  (Before: wave 0 did
+  // all 16 as a chain of load -> wait -> store round trips.)
+  {
+    const int sgi = w >> 1;
+    const TnSeg sg = second ? q.b.seg[sgi] : q.a.seg[sgi];
+    float v[2], old[2];
+    float* ptr[2];
+    bool ok[2];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      float v = acc[r];
-#pragma unroll
-      for (int j = 0; j < 7; ++j) v += red[j][r][lane];
+    for (int t = 0; t < 2; ++t) {
+      const int r = 2 * w + t;
       const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;   // D row (= LoRA rank index over the stacked adapters), column c = lane
-      if (row < p.R) {
-        const TnSeg sg = p.seg[row >> 3];
-        if (sg.out && c >= sg.col0 && c < sg.col0 + sg.ncols) sg.out[(long long)(row & 7) * sg.ld + (c - sg.col0)] += v;
-      }
+      v[t] = red[0][r][lane];
+#pragma unroll
+      for (int j = 1; j < 8; ++j) v[t] += red[j][r][lane];
+      ok[t] = c_ok && row < R && sg.out != nullptr && c >= sg.col0 && c < sg.col0 + sg.ncols;
+      ptr[t] = sg.out + ((long long)(row & 7) * sg.ld + (c - sg.col0));
+      old[t] = ok[t] ? *ptr[t] : 0.f;
     }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+      if (ok[t]) *ptr[t] = old[t] + v[t];
   }
 }
 

@@ -22,4 +22,4 @@ for name, outs, K in [("qkv", [2048, 2048, 2048], 2048), ("o", [2048], 2048), ("
     e.record(); torch.cuda.synchronize()
     t = s.elapsed_time(e) / 30 * 1e3
     mb = M * (N + K) * 2 / 1e6
-    print(f"{name}: {t:.1f} us for {mb:.1f} MB -> {mb / t / 1e3:.2f} TB/s")
+    print(f"{name}: {t:.1f} us for {mb:.1f} MB -> {mb / t:.2f} TB/s")
