@@ -12,6 +12,10 @@
 // rmsnorm_lora_fwd additionally fuses T5LayerNorm (modeling_t5.py:254-277): the normalised row is still in registers when its LoRA
 // projection is taken, so `xn` and `u` of the norm-fed projections (q/k/v, wi_0/wi_1, EncDecAttention.q) cost one launch.
 #include "common.h"
+#include <stdlib.h>
+
+extern "C" int mrblip_rmsnorm_fwd(const float* x, long long ldx, const float* weight, int M, int D, float eps, void* out_bf16,
+                                  long long ldob, float* out_f32, long long ldof, hipStream_t stream);  // norm.hip
 
 typedef __bf16 mrb_bf2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float dot2bf(uint32_t a, uint32_t b, float c) {
@@ -160,6 +164,133 @@ static int lora_num_cu() {
   return n;
 }
 
+// ---- the same product for TALL inputs (M >= LORA_THIN_MIN_M rows: the T5 encoder's M = 2012) on the matrix cores ------------------
+// Round 3: at M = 2012 the row kernel above is a chain of exposed latencies (stage A -> barrier -> a row's loads -> 32..96 KB of LDS
+// fragment reads per 4-KB row -> next row; 8-30 us per launch where the operand streams in 2-10 us, ~4.5 ms of main-stream time per step).
+// Here a block owns 16 rows, its 8 waves split K; every wave issues a whole batch of k-steps' operands as 16-B loads straight from
+// global memory into v_mfma_f32_16x16x32_bf16 fragments (x: lane (m = l & 15, kg = l >> 4) holds 8 consecutive k of row m, 16 rows x 64
+// contiguous bytes per instruction; A: the same lane map over r — A is 32..96 KB and L2 resident) — nothing is staged in LDS, every x
+// byte is fetched once, the structural zeros of a block-diagonal A cost nothing extra, and 8 x 8 KB are in flight per CU.  The 8
+// partial accumulators meet in LDS at the end (fixed order: deterministic).  Same dropout mask, same result up to fp32 summation order.
+typedef uint32_t lora_u32x4 __attribute__((ext_vector_type(4)));
+#define LORA_THIN_MIN_M 512
+
+template <int NT, int UB, int ROWS>  // NT = 16-wide r tiles (R <= 16 * NT), UB = k-steps per batch, ROWS = rows per block: 16, or 8 (the MFMA's
+                                     // other 8 rows idle, their lanes load nothing) when 16-row blocks would leave half of the CUs without one
+__global__ __launch_bounds__(512) void lora_thin_kernel(const LoraRowsArgs p) {
+  __shared__ f32x4 red[8][NT][64];
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int l15 = lane & 15, kg = lane >> 4;
+  const int m0 = blockIdx.x * ROWS, row = m0 + l15;
+  const bool row_ok = l15 < ROWS && row < p.M;
+  const bool has_drop = p.drop.seed_ptr != nullptr;
+  const uint32_t seed = has_drop ? mrb_seed_load(p.drop.seed_ptr) : 0u;
+  // bounds-checked operands: rows >= M of X and rows >= R of A lie beyond the last byte of their resource and read as zero
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.X), 0, (int)((((long long)p.M - 1) * p.ldx + p.K) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.A), 0, (int)((((long long)p.R - 1) * p.lda + p.K) * 2), 0x00020000);
+  const uint32_t xoff = (uint32_t)(((long long)row * p.ldx + kg * 8) * 2);
+  uint32_t aoff[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) aoff[t] = (uint32_t)(((long long)(t * 16 + l15) * p.lda + kg * 8) * 2);
+  const int nks = p.K >> 5;                       // k-steps of 32 (the launcher guarantees K % 32 == 0)
+  const int per = (nks + 7) >> 3;
+  const int ks0 = w * per, ks1 = min(nks, ks0 + per);
+  f32x4 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  lora_u32x4 xf[2][UB], af[2][UB][NT];
+  auto fetch = [&](int buf, int ks) {
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const bool k_ok = ks + u < ks1;               // past the wave's share: an out-of-range offset -> zeros, no memory traffic
+      const uint32_t kb = (uint32_t)(ks + u) * 64u;
+      xf[buf][u] = __builtin_amdgcn_raw_buffer_load_b128(rx, (k_ok && row_ok) ? xoff + kb : 0xfffffff0u, 0, 0);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) af[buf][u][t] = __builtin_amdgcn_raw_buffer_load_b128(ra, k_ok ? aoff[t] + kb : 0xfffffff0u, 0, 0);
+    }
+  };
+  auto consume = [&](int buf, int ks) {
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      lora_u32x4 x = xf[buf][u];
+      if (has_drop) {  // wave-uniform
+        const uint32_t e = (uint32_t)row * (uint32_t)p.K + (uint32_t)((ks + u) * 32 + kg * 8);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          bool k0, k1;
+          mrb_keep2(e + 2 * q, seed, p.drop.site, p.drop.thresh24, k0, k1);
+          x[q] = (k0 ? x[q] & 0xffffu : 0u) | (k1 ? x[q] & 0xffff0000u : 0u);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[buf][u][t]), __builtin_bit_cast(bf16x8, x), acc[t], 0, 0, 0);
+    }
+  };
+  // two batches of operands in flight: batch b+1 is requested before batch b is multiplied
+  // (the fetches are UNCONDITIONAL — past the wave's share they read out of range, which costs no memory traffic: a conditional fetch
+  // makes the compiler merge "loaded" and "not loaded" register sets with copies, i.e. wait for every load right after issuing it)
+  fetch(0, ks0);
+#pragma unroll 1
+  for (int ks = ks0; ks < ks1; ks += 2 * UB) {
+    fetch(1, ks + UB);
+    consume(0, ks);
+    fetch(0, ks + 2 * UB);
+    if (ks + UB < ks1) consume(1, ks + UB);
+  }
+  // side job (see LoraRowsArgs): the block's fp32 init rows, ROWS / 8 rows per wave
+  if (p.init_dst) {
+#pragma unroll
+    for (int i = 0; i < ROWS / 8; ++i) {
+      const int r = m0 + (ROWS / 8) * w + i;
+      if (r < p.M)
+        for (int c = lane * 4; c < p.init_n; c += 256) {
+          const float4 v = p.init_src ? *reinterpret_cast<const float4*>(p.init_src + (long long)r * p.ld_isrc + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+          *reinterpret_cast<float4*>(p.init_dst + (long long)r * p.ld_idst + c) = v;
+        }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < NT; ++t) red[w][t][lane] = acc[t];
+  __syncthreads();
+  if (w < NT) {  // wave t finishes r tile t: lane (m = l15, kg) holds r = 16 t + 4 kg .. + 3 of row m
+    f32x4 v = red[0][w][lane];
+#pragma unroll
+    for (int j = 1; j < 8; ++j) v += red[j][w][lane];
+    const float post = has_drop ? p.drop.inv_keep : 1.0f;
+    const int r0 = w * 16 + 4 * kg;
+    if (row_ok && r0 < p.R)
+      *reinterpret_cast<uint2*>(p.U + (long long)row * p.ldu + r0) = make_uint2(pack2bf(v[0] * post, v[1] * post), pack2bf(v[2] * post, v[3] * post));
+  }
+}
+
+static bool lora_thin_enabled() {
+  static int on = -1;
+  if (on < 0) {
+    const char* e = getenv("MRB_LORA_THIN");
+    on = (e && e[0] == '0') ? 0 : 1;
+  }
+  return on == 1;
+}
+
+static int launch_thin(const LoraRowsArgs& a, hipStream_t st) {
+  // 8-row blocks (MRB_LORA_THIN_ROWS=8; M = 2012: 252 blocks instead of 126) are FASTER stand-alone (enc g wi 17.8 vs 21.1 us, g qkv 14.4 vs
+  // 16.3) and SLOWER in the train step (71.95 vs 71.36 ms; row kernel: 72.55): the 126-block form leaves half of the CUs to the
+  // gradient side stream and the look-ahead ViT that run beside it.  16 rows is the default.
+  static int rows8 = -1;
+  if (rows8 < 0) { const char* e = getenv("MRB_LORA_THIN_ROWS"); rows8 = (e && atoi(e) == 8) ? 1 : 0; }
+  const bool half = rows8 && (a.M + 15) / 16 < lora_num_cu();
+  const int grid = half ? (a.M + 7) / 8 : (a.M + 15) / 16;
+  if (a.R <= 16) {
+    if (half) hipLaunchKernelGGL((lora_thin_kernel<1, 8, 8>), dim3(grid), dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((lora_thin_kernel<1, 8, 16>), dim3(grid), dim3(512), 0, st, a);
+  } else {
+    if (half) hipLaunchKernelGGL((lora_thin_kernel<2, 4, 8>), dim3(grid), dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((lora_thin_kernel<2, 4, 16>), dim3(grid), dim3(512), 0, st, a);
+  }
+  return mrblip_check_launch("lora_thin");
+}
+
 template <int NR>
 static int launch_rows(const LoraRowsArgs& a, hipStream_t st) {
   const int kcw = a.K < LORA_KC ? a.K : LORA_KC;
@@ -211,6 +342,8 @@ static int lora_rows_impl(const void* X, long long ldx, const void* A, long long
   a.drop.inv_keep = 1.0f / (1.0f - p_drop);
   MRB_REQUIRE(!init_dst || ((init_n % 4) == 0 && (ld_idst % 4) == 0 && (!init_src || (ld_isrc % 4) == 0)), "lora_rows: init job needs 16-B rows");
   a.init_dst = init_dst; a.init_src = init_src; a.ld_idst = ld_idst; a.ld_isrc = ld_isrc; a.init_n = init_dst ? init_n : 0;
+  if (M >= LORA_THIN_MIN_M && (K % 32) == 0 && (ldu % 4) == 0 && ((uintptr_t)U % 8) == 0 && (long long)M * ldx * 2 < (1ll << 31) && lora_thin_enabled())
+    return launch_thin(a, stream);
   switch (R / 8) {
     case 1: return launch_rows<1>(a, stream);
     case 2: return launch_rows<2>(a, stream);
@@ -309,6 +442,11 @@ extern "C" int mrblip_rmsnorm_lora_fwd(const float* x, long long ldx, const floa
   MRB_REQUIRE(R > 0 && R <= 32 && (R % 8) == 0 && ldu >= R && (lda % 8) == 0 && (ldx % 4) == 0 && (ldob % 4) == 0, "rmsnorm_lora: bad shape (R=%d)", R);
   MRB_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)A % 16) == 0 && ((uintptr_t)out_bf16 % 8) == 0, "rmsnorm_lora: alignment");
   MRB_REQUIRE(!(p_drop > 0.f) || seed_ptr, "rmsnorm_lora: dropout needs a device seed pointer");
+  if (M >= LORA_THIN_MIN_M && (D % 32) == 0 && (ldob % 8) == 0 && ((uintptr_t)out_bf16 % 16) == 0 && lora_thin_enabled()) {
+    // tall inputs: the norm at HBM speed, then the matrix-core thin product on the rows it just wrote (they are still in the L2 / MALL)
+    if (int e = mrblip_rmsnorm_fwd(x, ldx, weight, M, D, eps, out_bf16, ldob, nullptr, 0, stream)) return e;
+    return lora_rows_impl(out_bf16, ldob, A, lda, M, R, D, U, ldu, nullptr, seed_ptr, site, p_drop, nullptr, 0, nullptr, 0, 0, stream);
+  }
   NormLoraArgs a;
   a.x = x; a.ldx = ldx; a.gamma = weight; a.xn = (bf16_t*)out_bf16; a.ldn = ldob; a.A = (const bf16_t*)A; a.lda = lda; a.U = (bf16_t*)U; a.ldu = ldu;
   a.M = M; a.D = D; a.R = R; a.eps = eps;

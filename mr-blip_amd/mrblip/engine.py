@@ -727,7 +727,11 @@ class MrBlipEngine:
     # Round 3: the threshold went from 256 to 2100 rows — in the QVH step (M = 2012) the row kernel + the fused RMSNorm launch are 0.2 ms
     # per step AHEAD (74.0 vs 74.2 ms, 48 launches fewer, the normalised rows are not re-read) although each launch alone is slower than
     # the skinny kernel (15.7 vs 12.6 us); from M = 3992 (ActivityNet) on the skinny kernel stays.
-    lora_rows_max_m = int(os.environ.get("MRB_LORA_ROWS_MAX_M", "2100"))
+    # Round 3, later: mrblip_lora_rows itself switches to the matrix-core thin kernel from 512 rows on (csrc/lora.hip lora_thin_kernel:
+    # 16 rows per block, the 8 waves split K, operands straight from global memory into 16x16x32 fragments; 7 / 14 / 21 us where the row
+    # kernel took 8-16 / 20 / 30), and the fused RMSNorm launch becomes norm + thin product there — the QVH step went 72.55 -> 71.36 ms —
+    # so the row entry point now serves every M; MRB_LORA_ROWS_MAX_M restores a threshold above which the MFMA skinny GEMM is used.
+    lora_rows_max_m = int(os.environ.get("MRB_LORA_ROWS_MAX_M", str(1 << 30)))
 
     def lora_thin(self, x, a, u, K, drop=None, seg=None, init_dst=None, init_src=None):
         """u[:, :R] = dropout(x)[:, :K] @ a^T for a thin a ([R <= 32, K])"""
