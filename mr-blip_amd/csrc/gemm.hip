@@ -13,6 +13,13 @@
 // (A-operand = W tile, B-operand = X tile) so each lane owns one output row and 4 consecutive columns per
 // accumulator group -> 16-B (fp32) / 8-B (bf16) row-major stores.
 #include "common.h"
+#include <type_traits>
+// TILE_PIPE (experiment, off): 1 = fragments of k-step kk+1 requested before the MFMAs of kk AND the next stage's LDS-DMA pieces spread over
+// the k-steps (64x128 tile, K = 10240: 129.7 us against 107.3 us — pieces issued later land later, the 2-stage ring waits for them);
+// 2 = the fragment prefetch alone (107.5 us: equal).  The compiler's own schedule stays.
+#ifndef TILE_PIPE
+#define TILE_PIPE 0
+#endif
 #include <stdlib.h>
 
 struct GemmArgs {
@@ -170,27 +177,33 @@ typedef float mrb_f32x4 __attribute__((ext_vector_type(4)));
 // One K-tile of operands: CA + CW LDS-DMA pieces per wave (1 KiB each, lane-linear in LDS); per-piece source offsets come in VGPRs,
 // the only per-K-tile scalar is the byte offset along k.  (A device function, not a lambda: the buffer-resource type does not
 // exist in the host pass, and a kernel lambda holding one silently loses its host stub.)
-template <int CA, int CW, int NW_, int PIECE_BYTES>
+// PARTS / PART: issue only the pieces whose running index (A pieces first, then W) is PART modulo PARTS — the pipelined K loop spreads
+// a stage's pieces over the k-steps of the K-tile that is being multiplied (PARTS = 1: all of them)
+template <int CA, int CW, int NW_, int PIECE_BYTES, int PARTS = 1, int PART = 0>
 __device__ __forceinline__ void gemm_stage_dma(char* dstA, char* dstW, const void* pa, uint32_t bytes_a, const void* pw, uint32_t bytes_w,
                                                const uint32_t* va, const uint32_t* vw, int w, uint32_t koff) {
   const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(pa), 0, (int)bytes_a, 0x00020000);
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(pw), 0, (int)bytes_w, 0x00020000);
 #pragma unroll
-  for (int j = 0; j < CA; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr_t)(dstA + (j * NW_ + w) * PIECE_BYTES), 16, va[j], koff, 0, 0);
+  for (int j = 0; j < CA; ++j)
+    if (j % PARTS == PART) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr_t)(dstA + (j * NW_ + w) * PIECE_BYTES), 16, va[j], koff, 0, 0);
 #pragma unroll
-  for (int j = 0; j < CW; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(dstW + (j * NW_ + w) * PIECE_BYTES), 16, vw[j], koff, 0, 0);
+  for (int j = 0; j < CW; ++j)
+    if ((CA + j) % PARTS == PART) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(dstW + (j * NW_ + w) * PIECE_BYTES), 16, vw[j], koff, 0, 0);
 }
 // (same body under a second name: two call sites of ONE function get merged into a call with selected array pointers, which sends
 // the offset arrays through scratch memory)
-template <int CA, int CW, int NW_, int PIECE_BYTES>
+template <int CA, int CW, int NW_, int PIECE_BYTES, int PARTS = 1, int PART = 0>
 __device__ __forceinline__ void gemm_stage_dma_ext(char* dstA, char* dstW, const void* pa, uint32_t bytes_a, const void* pw, uint32_t bytes_w,
                                                const uint32_t* va, const uint32_t* vw, int w, uint32_t koff) {
   const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(pa), 0, (int)bytes_a, 0x00020000);
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(pw), 0, (int)bytes_w, 0x00020000);
 #pragma unroll
-  for (int j = 0; j < CA; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr_t)(dstA + (j * NW_ + w) * PIECE_BYTES), 16, va[j], koff, 0, 0);
+  for (int j = 0; j < CA; ++j)
+    if (j % PARTS == PART) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr_t)(dstA + (j * NW_ + w) * PIECE_BYTES), 16, va[j], koff, 0, 0);
 #pragma unroll
-  for (int j = 0; j < CW; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(dstW + (j * NW_ + w) * PIECE_BYTES), 16, vw[j], koff, 0, 0);
+  for (int j = 0; j < CW; ++j)
+    if ((CA + j) % PARTS == PART) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(dstW + (j * NW_ + w) * PIECE_BYTES), 16, vw[j], koff, 0, 0);
 }
 
 // blocks per CU the register allocation must allow: what the LDS footprint permits (160 KB per CU), at most 16 waves per CU
@@ -262,7 +275,9 @@ __global__ __launch_bounds__(WGM* WGN * 64, gemm_min_blocks(NS * (BM + BN) * BK 
 #pragma unroll
     for (int j = 0; j < JW; ++j) vpw[j] = vW + (uint32_t)((long long)w_row_base(j) * p.ldw * 2);
   };
-  auto stage = [&](int kt, int buf) __attribute__((always_inline)) {
+  // parts / part (compile-time, handed over as integral constants): see gemm_stage_dma
+  auto stage_part = [&](int kt, int buf, auto parts_c, auto part_c) __attribute__((always_inline)) {
+    constexpr int PARTS = decltype(parts_c)::value, PART = decltype(part_c)::value;
     char* base = smem + buf * STAGE;
     const bool ext = kt >= nk_main;  // uniform; the K extension is one or two tiles of the whole loop
     if (!ext) {
@@ -271,18 +286,19 @@ __global__ __launch_bounds__(WGM* WGN * 64, gemm_min_blocks(NS * (BM + BN) * BK 
 #else
       const uint32_t koff = (uint32_t)kt * (uint32_t)RB;
 #endif
-      gemm_stage_dma<JA, JW, NW, RPI * RB>(base, base + A_BYTES, p.A, (uint32_t)((long long)p.M * p.lda * 2), p.W, (uint32_t)((long long)p.N * p.ldw * 2),
-                                           vpa, vpw, w, koff);
+      gemm_stage_dma<JA, JW, NW, RPI * RB, PARTS, PART>(base, base + A_BYTES, p.A, (uint32_t)((long long)p.M * p.lda * 2), p.W,
+                                                        (uint32_t)((long long)p.N * p.ldw * 2), vpa, vpw, w, koff);
     } else {
       uint32_t ea[JA], ew[JW];
 #pragma unroll
       for (int j = 0; j < JA; ++j) ea[j] = vAe + (uint32_t)((long long)(bm * BM + (j * NW + w) * RPI) * p.ldaext * 2);
 #pragma unroll
       for (int j = 0; j < JW; ++j) ew[j] = vWe + (uint32_t)((long long)w_row_base(j) * p.ldwext * 2);
-      gemm_stage_dma_ext<JA, JW, NW, RPI * RB>(base, base + A_BYTES, p.Aext, (uint32_t)((long long)p.M * p.ldaext * 2), p.Wext,
-                                               (uint32_t)((long long)p.N * p.ldwext * 2), ea, ew, w, (uint32_t)(kt - nk_main) * (uint32_t)RB);
+      gemm_stage_dma_ext<JA, JW, NW, RPI * RB, PARTS, PART>(base, base + A_BYTES, p.Aext, (uint32_t)((long long)p.M * p.ldaext * 2), p.Wext,
+                                                            (uint32_t)((long long)p.N * p.ldwext * 2), ea, ew, w, (uint32_t)(kt - nk_main) * (uint32_t)RB);
     }
   };
+  auto stage = [&](int kt, int buf) __attribute__((always_inline)) { stage_part(kt, buf, std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}); };
 
   f32x16 acc[TM][TN];
 
@@ -337,10 +353,41 @@ __global__ __launch_bounds__(WGM* WGN * 64, gemm_min_blocks(NS * (BM + BN) * BK 
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 #endif
-#ifndef EXP_NODMA
+#if !defined(EXP_NODMA) && TILE_PIPE != 1
     if (kt + NS - 1 < nk) stage(kmap(kt + NS - 1), (kt + NS - 1) % NS);
 #endif
     const char* base = smem + (kt % NS) * STAGE;
+#if TILE_PIPE
+    // Round 3: software-pipelined K-tile.  The compiler's own schedule of the plain loop below issues the whole next stage (6-8 LDS-DMA
+    // pieces, each an issue stall) right behind the barrier and then reads every fragment just in time (ds_read -> s_waitcnt lgkmcnt(0)
+    // -> MFMA): with one or two waves per SIMD nothing covers either.  Here the fragments of k-step kk+1 are requested before the MFMAs
+    // of k-step kk, and the stage's pieces are spread over the k-steps; sched_barrier pins that order.
+    {
+      const bool do_stage = kt + NS - 1 < nk;   // uniform
+      const int skt = kmap(kt + NS - 1), sbuf = (kt + NS - 1) % NS;
+      bf16x8 xf[2][TM], wf[2][TN];
+      auto loadf = [&](int b, int kk) __attribute__((always_inline)) {
+        const int coff = (((kk * 2 + hi) ^ swz) << 4);
+#pragma unroll
+        for (int mt = 0; mt < TM; ++mt) xf[b][mt] = *reinterpret_cast<const bf16x8*>(base + a_row_off + mt * 32 * RB + coff);
+#pragma unroll
+        for (int nt = 0; nt < TN; ++nt) wf[b][nt] = *reinterpret_cast<const bf16x8*>(base + w_row_off[nt] + coff);
+      };
+      loadf(0, 0);
+#define TILE_PIPE_STEP(KKI)                                                                                                \
+      if (KKI < KK) {                                                                                                      \
+        if (KKI + 1 < KK) loadf((KKI + 1) & 1, KKI + 1);                                                                    \
+        if (TILE_PIPE == 1 && do_stage) stage_part(skt, sbuf, std::integral_constant<int, KK>{}, std::integral_constant<int, (KKI < KK ? KKI : 0)>{});  \
+        __builtin_amdgcn_sched_barrier(0);                                                                                \
+        _Pragma("unroll") for (int mt = 0; mt < TM; ++mt)                                                                  \
+          _Pragma("unroll") for (int nt = 0; nt < TN; ++nt)                                                                \
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[KKI & 1][nt], xf[KKI & 1][mt], acc[mt][nt], 0, 0, 0); \
+        __builtin_amdgcn_sched_barrier(0);                                                                                \
+      }
+      TILE_PIPE_STEP(0) TILE_PIPE_STEP(1) TILE_PIPE_STEP(2) TILE_PIPE_STEP(3)
+#undef TILE_PIPE_STEP
+    }
+#else
 #ifdef EXP_NOLDS
     {  // EXPERIMENT (wrong results): fragments read once per K-tile
       const int coff = (((0 * 2 + hi) ^ swz) << 4);
@@ -373,6 +420,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, gemm_min_blocks(NS * (BM + BN) * BK 
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nt], xf[mt], acc[mt][nt], 0, 0, 0);
     }
 #endif
+#endif  // TILE_PIPE
     if (!GATED && ext_first && kt == NEXT - 1 && p.ext_drop.seed_ptr) {  // acc == Aext Wext^T: apply the LoRA input-dropout mask to it
       const uint32_t seed = mrb_seed_load(p.ext_drop.seed_ptr);
 #pragma unroll
@@ -1649,6 +1697,9 @@ static int gemm_dispatch(const void* A, long long lda, const void* W, long long 
 #undef MRB_W4_LAUNCH
     return mrblip_check_launch("gemm_w4");
   }
+  // (round 3, measured at the T5 [2012 x 2048] outputs and removed again: 128x128 tiles — one per CU, 2/3 of the L2->LDS traffic of
+  // 64x128 — with a 3- or 4-stage ring, or with 8 waves of 64x32: K = 10240: 115.9 / 114.6 / 112.5 us against 120.6 us for the plain
+  // 128x128 and 105.1 us for 64x128 at two blocks per CU; profiles/r03_gemm_t5_tiles.txt)
   if (cfg == 4) {
     if (gated) return launch_tile<64, 128, 2, 2, false, true>(a, stream);
     return out_f32 ? launch_tile<64, 128, 2, 2, true, false>(a, stream) : launch_tile<64, 128, 2, 2, false, false>(a, stream);
