@@ -7,6 +7,8 @@
 #include "common.h"
 
 #define NORM_MAXV 8  // float4 per lane -> D <= 64*4*8 = 2048
+// s_waitcnt vmcnt(0) as an instruction the compiler's wait-count pass sees (gfx9 encoding: vmcnt 0, expcnt 7, lgkmcnt 15)
+#define MRB_ALL_LOADS_DONE() __builtin_amdgcn_s_waitcnt(0x0F70)
 
 template <bool RMS>
 __global__ __launch_bounds__(256) void norm_fwd_kernel(const float* __restrict__ x, long long ldx, const float* __restrict__ gamma,
@@ -14,6 +16,18 @@ __global__ __launch_bounds__(256) void norm_fwd_kernel(const float* __restrict__
                                                        long long ldob, float* out_f, long long ldof) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int nv = D >> 2;
+  // gamma / beta: the lane's columns are the same for every row it visits — fetched ONCE, before the row loop, all loads in flight
+  // together.  (Round 3, ISA reading: loaded inside the per-column `if` of the store loop, each was a load + s_waitcnt vmcnt(0) pair —
+  // up to 16 L2 round trips in series per row — and every column's block then also waited for the previous column's STORES, because
+  // the compiler must assume loads pending at the join of the skipped branches: MRB_ALL_LOADS_DONE() tells it there are none.)
+  float4 g4[NORM_MAXV], b4[NORM_MAXV];
+#pragma unroll
+  for (int j = 0; j < NORM_MAXV; ++j) {
+    const int i = lane + 64 * j;
+    const int ic = i < nv ? i : 0;   // clamped: unconditional load, value unused past the row's end
+    g4[j] = reinterpret_cast<const float4*>(gamma)[ic];
+    b4[j] = (!RMS && beta) ? reinterpret_cast<const float4*>(beta)[ic] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   for (int row = blockIdx.x * 4 + wv; row < M; row += gridDim.x * 4) {
     const float4* xr = reinterpret_cast<const float4*>(x + (long long)row * ldx);
     float4 v[NORM_MAXV];
@@ -36,16 +50,17 @@ __global__ __launch_bounds__(256) void norm_fwd_kernel(const float* __restrict__
       }
     }
     const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+    MRB_ALL_LOADS_DONE();
 #pragma unroll
     for (int j = 0; j < NORM_MAXV; ++j) {
       const int i = lane + 64 * j;
       if (i < nv) {
-        const float4 g = reinterpret_cast<const float4*>(gamma)[i];
+        const float4 g = g4[j];
         float4 o;
         o.x = (v[j].x - mean) * rstd * g.x; o.y = (v[j].y - mean) * rstd * g.y;
         o.z = (v[j].z - mean) * rstd * g.z; o.w = (v[j].w - mean) * rstd * g.w;
         if (!RMS && beta) {
-          const float4 b = reinterpret_cast<const float4*>(beta)[i];
+          const float4 b = b4[j];
           o.x += b.x; o.y += b.y; o.z += b.z; o.w += b.w;
         }
         if (out_f) reinterpret_cast<float4*>(out_f + (long long)row * ldof)[i] = o;
@@ -68,6 +83,7 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const float* __restrict__
   const int nv = D >> 2;
   float4 ag[NORM_MAXV], ab[NORM_MAXV];
   const bool want_dw = dgamma != nullptr;
+  const uint32_t seed = drop.seed_ptr ? mrb_seed_load(drop.seed_ptr) : 0u;
   if (want_dw) {
 #pragma unroll
     for (int j = 0; j < NORM_MAXV; ++j) ag[j] = ab[j] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -82,8 +98,20 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const float* __restrict__
       const int i = lane + 64 * j;
       v[j] = (i < nv) ? xr[i] : make_float4(0.f, 0.f, 0.f, 0.f);
       g[j] = (i < nv) ? dr[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-      if (!RMS) s += v[j].x + v[j].y + v[j].z + v[j].w;
     }
+    // gamma and the dx_add rows ride with them (round 3, ISA reading: loaded inside the loops that use them, each of these — and the
+    // dropout seed — was a load + s_waitcnt vmcnt(0) pair per column: ~24 round trips in series per row, the kernel's whole 24 us)
+    float4 wq[NORM_MAXV], aq[NORM_MAXV];
+#pragma unroll
+    for (int j = 0; j < NORM_MAXV; ++j) {
+      const int i = lane + 64 * j;
+      const int ic = i < nv ? i : 0;
+      wq[j] = reinterpret_cast<const float4*>(gamma)[ic];
+      aq[j] = dx_add ? reinterpret_cast<const float4*>(dx_add + (long long)row * ldadd)[ic] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int j = 0; j < NORM_MAXV; ++j)
+      if (!RMS) s += v[j].x + v[j].y + v[j].z + v[j].w;
     float mean = 0.f;
     if (!RMS) mean = wave_sum(s) / (float)D;
     float q = 0.f;
@@ -106,7 +134,7 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const float* __restrict__
           ag[j].x += g[j].x * v[j].x; ag[j].y += g[j].y * v[j].y; ag[j].z += g[j].z * v[j].z; ag[j].w += g[j].w * v[j].w;
           ab[j].x += g[j].x; ab[j].y += g[j].y; ab[j].z += g[j].z; ab[j].w += g[j].w;
         }
-        const float4 w = reinterpret_cast<const float4*>(gamma)[i];
+        const float4 w = wq[j];
         g[j].x *= w.x; g[j].y *= w.y; g[j].z *= w.z; g[j].w *= w.w;
         sg += g[j].x + g[j].y + g[j].z + g[j].w;
         sgx += g[j].x * v[j].x + g[j].y * v[j].y + g[j].z * v[j].z + g[j].w * v[j].w;
@@ -114,6 +142,7 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const float* __restrict__
     }
     const float mg = RMS ? 0.f : wave_sum(sg) / (float)D;
     const float mgx = wave_sum(sgx) / (float)D;
+    MRB_ALL_LOADS_DONE();
 #pragma unroll
     for (int j = 0; j < NORM_MAXV; ++j) {
       const int i = lane + 64 * j;
@@ -122,13 +151,13 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const float* __restrict__
         o.x = rstd * (g[j].x - mg - v[j].x * mgx); o.y = rstd * (g[j].y - mg - v[j].y * mgx);
         o.z = rstd * (g[j].z - mg - v[j].z * mgx); o.w = rstd * (g[j].w - mg - v[j].w * mgx);
         if (dx_add) {
-          const float4 a = reinterpret_cast<const float4*>(dx_add + (long long)row * ldadd)[i];
+          const float4 a = aq[j];
           o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
         }
         if (dx) reinterpret_cast<float4*>(dx + (long long)row * lddx)[i] = o;
         if (out_b) {  // the consumer's bf16 GEMM operand = dropout-backward(dx) (what a separate mrblip_cast_dropout launch would write)
           if (drop.seed_ptr) {
-            const uint32_t seed = *drop.seed_ptr, base = (uint32_t)row * (uint32_t)D + (uint32_t)(4 * i);
+            const uint32_t base = (uint32_t)row * (uint32_t)D + (uint32_t)(4 * i);
             o.x = mrb_keep(base, seed, drop.site, drop.thresh24) ? o.x * drop.inv_keep : 0.f;
             o.y = mrb_keep(base + 1, seed, drop.site, drop.thresh24) ? o.y * drop.inv_keep : 0.f;
             o.z = mrb_keep(base + 2, seed, drop.site, drop.thresh24) ? o.z * drop.inv_keep : 0.f;
