@@ -744,18 +744,44 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
     const int c8 = (lane % LPR) * 8;                      // the lane's 8 columns inside the wave's WN
     const int n0 = bn_e * BN + wn * WN + c8;
     const bool n_ok = lane_on && n0 < p.N;
+    // Branch-free global side (round 3).  ISA reading of the first form (residual loads and stores inside `if (ok)`): the compiler put a
+    // wait in front of every conditional block, so each of the 4 row groups waited for its own residual loads AND for the previous
+    // group's stores to be acknowledged — the fp32-residual epilogue of fc2 / proj stamped 27 us per tile against 6 us for bias only.
+    // Now bias, residual and output go through bounds-checked buffer resources (rows >= M / columns >= N get an out-of-range offset:
+    // loads return 0, stores are dropped; every resource is < 2 GiB, the sentinel offset is 2^31), the residual rows of group mt + 1 are requested before group mt is finished, and nothing
+    // waits for a store.
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias), 0, p.bias ? p.N * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rres =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.residual), 0, RES ? (int)((((long long)p.M - 1) * p.ldr + p.N) * 4) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rout =
+        __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)((((long long)p.M - 1) * p.ldo + p.N) * (OUT_F32 ? 4 : 2)), 0x00020000);
     float bias8[8];
+    {
+      const uint32_t ob = n_ok ? (uint32_t)n0 * 4u : 0x80000000u;
+      const mrb_f32x4 b0 = __builtin_bit_cast(mrb_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, ob, 0, 0));
+      const mrb_f32x4 b1 = __builtin_bit_cast(mrb_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, ob + 16u, 0, 0));
 #pragma unroll
-    for (int i = 0; i < 8; ++i) bias8[i] = 0.f;
-    if (p.bias && n_ok) {
-      const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n0), b1 = *reinterpret_cast<const float4*>(p.bias + n0 + 4);
-      bias8[0] = b0.x; bias8[1] = b0.y; bias8[2] = b0.z; bias8[3] = b0.w; bias8[4] = b1.x; bias8[5] = b1.y; bias8[6] = b1.z; bias8[7] = b1.w;
+      for (int i = 0; i < 4; ++i) { bias8[i] = b0[i]; bias8[4 + i] = b1[i]; }
     }
+    mrb_f32x4 rq[2][PASSES][2];
+    auto res_fetch = [&](int mt, int buf) __attribute__((always_inline)) {
+      const int m_base = bm_e * BM + wm * 128 + mt * 32;
+#pragma unroll
+      for (int i = 0; i < PASSES; ++i) {
+        const int r = i * ROWS + lrow;
+        const bool ok = n_ok && r < 32 && m_base + r < p.M;
+        const uint32_t off = ok ? (uint32_t)(((long long)(m_base + r) * p.ldr + n0) * 4) : 0x80000000u;
+        rq[buf][i][0] = __builtin_bit_cast(mrb_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rres, off, 0, 0));
+        rq[buf][i][1] = __builtin_bit_cast(mrb_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rres, off + 16u, 0, 0));
+      }
+    };
+    if (RES) res_fetch(0, 0);
 #ifdef EXP_NOEPI
     if (p.M == -12345)
 #endif
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
+      if (RES && mt + 1 < 4) res_fetch(mt + 1, (mt + 1) & 1);
 #pragma unroll
       for (int nt = 0; nt < TN; ++nt)
 #pragma unroll
@@ -763,40 +789,28 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
           *reinterpret_cast<float4*>(slab + l31 * RS + (nt * 32 + 8 * g + 4 * hi) * 4) =
               make_float4(acc[mt][nt][4 * g], acc[mt][nt][4 * g + 1], acc[mt][nt][4 * g + 2], acc[mt][nt][4 * g + 3]);
       const int m_base = bm_e * BM + wm * 128 + mt * 32;
-      float4 x0[PASSES], x1[PASSES], r0[PASSES], r1[PASSES];
 #pragma unroll
       for (int i = 0; i < PASSES; ++i) {  // row ROWS i + lane / LPR of the slab
-        const int r = i * ROWS + lrow;
-        const bool ok = n_ok && r < 32 && m_base + r < p.M;
-        const char* sp = slab + (r < 32 ? r : 0) * RS + c8 * 4;
-        x0[i] = *reinterpret_cast<const float4*>(sp);
-        x1[i] = *reinterpret_cast<const float4*>(sp + 16);
-        if (RES && ok) {
-          const float* rp = p.residual + (long long)(m_base + r) * p.ldr + n0;
-          r0[i] = *reinterpret_cast<const float4*>(rp);
-          r1[i] = *reinterpret_cast<const float4*>(rp + 4);
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < PASSES; ++i) {
         const int r = i * ROWS + lrow, m = m_base + r;
-        float v[8] = {x0[i].x + bias8[0], x0[i].y + bias8[1], x0[i].z + bias8[2], x0[i].w + bias8[3],
-                      x1[i].x + bias8[4], x1[i].y + bias8[5], x1[i].z + bias8[6], x1[i].w + bias8[7]};
+        const bool ok = n_ok && r < 32 && m < p.M;
+        const char* sp = slab + (r < 32 ? r : 0) * RS + c8 * 4;
+        const float4 x0 = *reinterpret_cast<const float4*>(sp), x1 = *reinterpret_cast<const float4*>(sp + 16);
+        float v[8] = {x0.x + bias8[0], x0.y + bias8[1], x0.z + bias8[2], x0.w + bias8[3],
+                      x1.x + bias8[4], x1.y + bias8[5], x1.z + bias8[6], x1.w + bias8[7]};
         if (ACT == 1) {
           gelu_erf2(v[0], v[1]); gelu_erf2(v[2], v[3]); gelu_erf2(v[4], v[5]); gelu_erf2(v[6], v[7]);
         }
         if (RES) {
-          v[0] += r0[i].x; v[1] += r0[i].y; v[2] += r0[i].z; v[3] += r0[i].w; v[4] += r1[i].x; v[5] += r1[i].y; v[6] += r1[i].z; v[7] += r1[i].w;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { v[e] += rq[mt & 1][i][0][e]; v[4 + e] += rq[mt & 1][i][1][e]; }
         }
-        if (n_ok && r < 32 && m < p.M) {
-          if (OUT_F32) {
-            float4* o = reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + (long long)m * p.ldo + n0);
-            o[0] = make_float4(v[0], v[1], v[2], v[3]);
-            o[1] = make_float4(v[4], v[5], v[6], v[7]);
-          } else {
-            *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.out) + (long long)m * p.ldo + n0) =
-                make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
-          }
+        if (OUT_F32) {
+          const uint32_t off = ok ? (uint32_t)(((long long)m * p.ldo + n0) * 4) : 0x80000000u;
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(mrb_u32x4, mrb_f32x4{v[0], v[1], v[2], v[3]}), rout, off, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(mrb_u32x4, mrb_f32x4{v[4], v[5], v[6], v[7]}), rout, off + 16u, 0, 0);
+        } else {
+          const uint32_t off = ok ? (uint32_t)(((long long)m * p.ldo + n0) * 2) : 0x80000000u;
+          __builtin_amdgcn_raw_buffer_store_b128(mrb_u32x4{pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])}, rout, off, 0, 0);
         }
       }
     }
@@ -1640,6 +1654,8 @@ static int gemm_dispatch(const void* A, long long lda, const void* W, long long 
   if (cfg == 13 || cfg == 14) {  // four waves of 128 x 128 (cfg 13, 256x256 tile) / 128 x 96 (cfg 14, 256x192), hand-pipelined K loop
     MRB_REQUIRE(!gated && !Aext && !out2 && !(p_drop > 0.f), "gemm: cfg 13 / 14 take plain epilogues only");
     MRB_REQUIRE(act == 0 || act == 1, "gemm: cfg 13 / 14 know act 0 / 1");
+    MRB_REQUIRE((long long)M * ldo * (out_f32 ? 4 : 2) < (1ll << 31) && (!residual || (long long)M * ldr * 4 < (1ll << 31)),
+                "gemm: cfg 13 / 14 address output and residual through 2 GiB buffer resources");
     const int bn13 = cfg == 13 ? 256 : 192;
     a.tiles_m = (M + 255) / 256;
     a.tiles_n = (N + bn13 - 1) / bn13;
