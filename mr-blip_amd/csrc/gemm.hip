@@ -1508,9 +1508,10 @@ static int gemm_dispatch(const void* A, long long lda, const void* W, long long 
       if (!no8 && !gated && K >= 1024 && (eff256 >= 0.9 || (rounds == 1 && eff256 >= 0.7))) cfg = 8;
       // plain-epilogue GEMMs with many 256x256 tiles or a long K (the frozen ViT's qkv / fc1 / fc2): four waves of 128x128 with the
       // hand-pipelined K loop (cfg 13) - 10-20 % faster than every other form standalone, ~1 ms per step in the train step
+      // (round 3: also the ViT proj, 366 tiles of K = 1408 — it ran on the generic 128x128 tile until then: 71.95 -> 71.43 ms per step)
       static int no13 = -1;
       if (no13 < 0) no13 = getenv("MRB_NO_CFG13") ? 1 : 0;
-      if (!no13 && !gated && !Aext && !out2 && !(p_drop > 0.f) && (act == 0 || act == 1) && M >= 4096 && (t256 >= 2 * ncu || (t256 >= ncu && K >= 4096)))
+      if (!no13 && !gated && !Aext && !out2 && !(p_drop > 0.f) && (act == 0 || act == 1) && M >= 4096 && (t256 >= 2 * ncu || (t256 >= ncu && K >= 1024)))
         cfg = 13;
       // (256x128 with 16 waves, cfg 10, is 5-15 % faster than 128x128 at the ViT qkv shape standalone, but in the step it made things
       // worse: one more persistent 16-wave block per CU starves the small kernels of the clip that shares the GPU with the look-ahead)

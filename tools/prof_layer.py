@@ -1,19 +1,19 @@
 """rocprofv3 rocpd .db -> the ordered launches of ONE T5 encoder layer of the last profiled train step, forward and backward, on the main
 stream (the queue with most launches): start offset, duration, gap to the previous launch of that queue, grid, kernel name — and what ran
 on the other queues in the same window (summed per kernel).  Layer k forward = from the k-th encoder attention launch to the next one;
-backward = between consecutive attn_bwd_dkv_lds launches.   usage: prof_layer.py <db> [layer=12]"""
+backward = between consecutive attn_bwd_dkv_lds launches.   usage: prof_layer.py <db> [layer=12] [back=2: the step that starts at the back-th last seed_bump]"""
 import sqlite3
 import sys
 from collections import defaultdict
 
 
-def main(db, layer=12):
+def main(db, layer=12, back=2):
     cur = sqlite3.connect(db).cursor()
     cols = [r[1] for r in cur.execute("pragma table_info(kernels)").fetchall()]
     qcol = next((c for c in ("stream_id", "queue_id", "queue", "stream") if c in cols), None)
     rows = cur.execute(f"select name, start, end, {qcol or '0'}, grid_x from kernels order by start").fetchall()
     marks = [i for i, r in enumerate(rows) if "seed_bump" in r[0]]
-    seg = rows[marks[-2]:marks[-1]]
+    seg = rows[marks[-back]:marks[-back + 1]] if back > 1 else rows[marks[-1]:]
     byq = defaultdict(list)
     for r in seg:
         byq[r[3]].append(r)
@@ -52,4 +52,4 @@ def main(db, layer=12):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 12)
+    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 12, int(sys.argv[3]) if len(sys.argv) > 3 else 2)
