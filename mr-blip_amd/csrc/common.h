@@ -49,6 +49,11 @@ __device__ __forceinline__ uint32_t mrb_hash(uint32_t idx, uint32_t seed, uint32
 }
 // One 32-bit hash serves the element PAIR (idx & ~1, idx | 1): even index -> low 16 bits, odd index -> high 16 bits.
 // keep iff the 16-bit draw >= thresh16 = round(p * 65536)   (p = 0.1 -> 6554/65536 = 0.10001)
+// s_waitcnt vmcnt(0) as an INSTRUCTION the compiler's wait-count pass sees (gfx9 encoding: vmcnt 0, expcnt 7, lgkmcnt 15).  Placed between a
+// kernel's last load and a run of conditional stores it tells the pass that nothing is pending: without it every conditional block gets its
+// own conservative vmcnt(0), which also waits for the previous block's STORES to be acknowledged.
+#define MRB_ALL_LOADS_DONE() __builtin_amdgcn_s_waitcnt(0x0F70)
+
 // the step's dropout seed lives in device memory (written by the host-side engine before the step, never inside a kernel that reads it):
 // fetch it with ONE scalar load (constant address space -> s_load_dword through the scalar cache, which is invalidated at every kernel
 // start) instead of a per-use vector load

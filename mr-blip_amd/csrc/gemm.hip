@@ -146,6 +146,15 @@ __device__ __forceinline__ void epilogue_store8v(const GemmArgs& p, uint32_t see
   }
 }
 
+__device__ __forceinline__ void epilogue_store4v(const GemmArgs& p, uint32_t seed, bool out_f32, int m, int n0, float v0, float v1, float v2, float v3,
+                                                 int ncols, const float4 b, const float4 r) {
+  uint2 pre;
+  epilogue_apply4v(p, seed, m, n0, v0, v1, v2, v3, ncols, pre, b, r);
+  if (p.out2) *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out2) + (long long)m * p.ldo2 + n0) = pre;
+  if (out_f32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + (long long)m * p.ldo + n0) = make_float4(v0, v1, v2, v3);
+  else *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + (long long)m * p.ldo + n0) = make_uint2(pack2bf(v0, v1), pack2bf(v2, v3));
+}
+
 // gated: y = dropout(gelu(h0) * h1) for 8 consecutive columns; optional out2 = [h0 | h1] stacked ([M, 2*nh])
 __device__ __forceinline__ void epilogue_gated8(const GemmArgs& p, uint32_t seed, int m, int n0, const float h0[8], const float h1[8], int nh) {
   if (p.out2) {
@@ -1319,17 +1328,20 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const GemmArgs p) 
       for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[u][s], xf[u][s], acc, 0, 0, 0);
   }
   if (p.Aext && w == NW - 1 && zs == 0) {  // K-extension segment (one 64-wide block), taken by the last wave (of the first K split)
-    const bf16_t* wpe = p.Wext + (long long)n_row * p.ldwext + hi * 32;
-    const bf16_t* xpe = p.Aext + (long long)m_row * p.ldaext + hi * 32;
+    const bf16_t* wpe = p.Wext + (long long)(n_ok ? n_row : 0) * p.ldwext + hi * 32;
+    const bf16_t* xpe = p.Aext + (long long)(m_ok ? m_row : 0) * p.ldaext + hi * 32;
     f32x16 e;
 #pragma unroll
     for (int r = 0; r < 16; ++r) e[r] = 0.f;
+    // (all eight loads first, from clamped rows, then the selects: a conditional load per MFMA was four round trips in series)
+    bf16x8 wfe[4], xfe[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      const bf16x8 wf = n_ok ? *reinterpret_cast<const bf16x8*>(wpe + s * 8) : zero;
-      const bf16x8 xf = m_ok ? *reinterpret_cast<const bf16x8*>(xpe + s * 8) : zero;
-      e = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, e, 0, 0, 0);
+      wfe[s] = *reinterpret_cast<const bf16x8*>(wpe + s * 8);
+      xfe[s] = *reinterpret_cast<const bf16x8*>(xpe + s * 8);
     }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) e = __builtin_amdgcn_mfma_f32_32x32x16_bf16(n_ok ? wfe[s] : zero, m_ok ? xfe[s] : zero, e, 0, 0, 0);
     if (p.ext_first && p.ext_drop.seed_ptr) {  // LoRA backward form: mask the extension product (see GemmArgs)
       const uint32_t seed = mrb_seed_load(p.ext_drop.seed_ptr);
 #pragma unroll
@@ -1381,12 +1393,20 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const GemmArgs p) 
         }
       }
     } else if (m_ok) {
+      // bias / residual of the lane's four column groups first (clamped columns), seed by scalar load: every load in flight together
+      const uint32_t seed = p.drop.seed_ptr ? mrb_seed_load(p.drop.seed_ptr) : 0u;
+      float4 bq[4], rq[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n0 = blockIdx.x * 32 + 8 * g + 4 * hi, n0c = n0 < p.N ? n0 : 0;
+        bq[g] = p.bias ? *reinterpret_cast<const float4*>(p.bias + n0c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        rq[g] = p.residual ? *reinterpret_cast<const float4*>(p.residual + (long long)m_row * p.ldr + n0c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      MRB_ALL_LOADS_DONE();
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int n0 = blockIdx.x * 32 + 8 * g + 4 * hi;
-        if (n0 < p.N) {
-          epilogue_store4(p, OUT_F32, m_row, n0, acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3], p.N);
-        }
+        if (n0 < p.N) epilogue_store4v(p, seed, OUT_F32, m_row, n0, acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3], p.N, bq[g], rq[g]);
       }
     }
   }

@@ -7,8 +7,6 @@
 #include "common.h"
 
 #define NORM_MAXV 8  // float4 per lane -> D <= 64*4*8 = 2048
-// s_waitcnt vmcnt(0) as an instruction the compiler's wait-count pass sees (gfx9 encoding: vmcnt 0, expcnt 7, lgkmcnt 15)
-#define MRB_ALL_LOADS_DONE() __builtin_amdgcn_s_waitcnt(0x0F70)
 
 template <bool RMS>
 __global__ __launch_bounds__(256) void norm_fwd_kernel(const float* __restrict__ x, long long ldx, const float* __restrict__ gamma,

@@ -755,26 +755,29 @@ class MrBlipEngine:
     fuse_norm_lora = os.environ.get("MRB_FUSE_NORM_LORA", "1") == "1"
 
     def lg_bwd(self, g: LoraGroup, dy: torch.Tensor, x: torch.Tensor, u: torch.Tensor, gbuf: torch.Tensor, dx: Optional[torch.Tensor],
-               residual: Optional[torch.Tensor] = None, side: bool = False, tile_cfg: int = 0):
+               residual: Optional[torch.Tensor] = None, side: bool = False, tile_cfg: int = 0, flush: bool = True):
         """dy bf16 [M,N]; x the saved bf16 input; u the saved [M,64] LoRA activations.  Accumulates dA, dB of every adapter of the
         group (one launch) and (optionally) dx = dy W (+ residual) + mask * (g A) (one GEMM: the rank-8 term is its K-extension).
         side=True: the weight-gradient launch goes to the gradient side stream and runs beside the dX GEMM (the caller guarantees
-        that dy / gbuf are not overwritten before its next side_join_layer())."""
+        that dy / gbuf are not overwritten before its next side_join()).  flush=False only QUEUES that launch: it goes out with the
+        next flushing call (side_flush) — every hand-over to the side stream is an event record on the main stream, and a record
+        between two kernels costs ~7 us of dispatch bubble (round 3, tools/prof_layer.py: 5 records = 48 us per encoder layer)."""
         drop = self.drop(g.site, self.cfg.lora_dropout)
         seg = [v for a in g.adapters for v in (a.row0, a.row0 + a.out)] if len(g.adapters) > 1 else None
         if self.cfg.lora_mask_per_adapter and len(g.adapters) > 1 and drop is not None:
             # peft-faithful masks: the weight gradients and the rank-8 part of dX per adapter, each with ITS mask; the frozen-weight
             # part of dX is one plain GEMM
             self.lora_thin(dy, g.bblk, gbuf, g.N, seg=seg)
-            st = self._grad_stream() if (side and self.grad_side_stream_enabled) else None
-            if st is not None:
-                ev = torch.cuda.Event()
-                ev.record()
-            with torch.cuda.stream(st) if st is not None else contextlib.nullcontext():
-                if st is not None:
-                    st.wait_event(ev)
+
+            def grads_per_adapter():
                 for j, a in enumerate(g.adapters):
                     ops.lora_grads(dy, u[:, 8 * j:], x, gbuf[:, 8 * j:], [a.dBt], [a.row0], [a.out], [a.dA], g.K, drop=self.drop(a.site, self.cfg.lora_dropout))
+            if side and self.grad_side_stream_enabled:
+                self.side_defer(grads_per_adapter)
+                if flush:
+                    self.side_flush()
+            else:
+                grads_per_adapter()
             if dx is not None:
                 ops.gemm(dy, g.Wt, dx, residual=residual, K=pad64(g.N))
                 for j, a in enumerate(g.adapters):
@@ -786,15 +789,14 @@ class MrBlipEngine:
         else:
             self.lora_thin(dy, g.bblk, gbuf, g.N, seg=seg)                  # g' = scale * dy @ B      [M, 8*nad]
         ads = g.adapters
-        if side and self.grad_side_stream_enabled:
-            st = self._grad_stream()
-            ev = torch.cuda.Event()
-            ev.record()
-            with torch.cuda.stream(st):
-                st.wait_event(ev)
-                ops.lora_grads(dy, u, x, gbuf, [a.dBt for a in ads], [a.row0 for a in ads], [a.out for a in ads], [a.dA for a in ads], g.K, drop=drop)
-        else:
+        def grads():
             ops.lora_grads(dy, u, x, gbuf, [a.dBt for a in ads], [a.row0 for a in ads], [a.out for a in ads], [a.dA for a in ads], g.K, drop=drop)
+        if side and self.grad_side_stream_enabled:
+            self.side_defer(grads)
+            if flush:
+                self.side_flush()
+        else:
+            grads()
         if dx is not None:
             if ks > 1:
                 ops.lora_dx(dy, g.Wt, gbuf, g.acatt, dx, pad64(g.N), residual=None, drop=drop, k_splits=ks)
@@ -811,8 +813,33 @@ class MrBlipEngine:
             self._gstream = torch.cuda.Stream(device=self.dev)
         return self._gstream
 
+    _side_q: list = None
+
+    side_batch = os.environ.get("MRB_SIDE_BATCH", "1") == "1"   # 0: every queued job is handed over at once (one record each; for A/B)
+
+    def side_defer(self, fn: Callable[[], None]):
+        """queue launches for the gradient side stream (fn enqueues them on the then-current stream)"""
+        if self._side_q is None:
+            self._side_q = []
+        self._side_q.append(fn)
+        if not self.side_batch:
+            self.side_flush()
+
+    def side_flush(self):
+        """ONE event record on the main stream, then every queued job goes to the side stream behind it"""
+        if not self._side_q:
+            return
+        jobs, self._side_q = self._side_q, []
+        st, ev = self._grad_stream(), torch.cuda.Event()
+        ev.record()
+        with torch.cuda.stream(st):
+            st.wait_event(ev)
+            for fn in jobs:
+                fn()
+
     def side_join(self):
-        """the main stream waits for everything issued to the gradient side stream so far"""
+        """the main stream waits for everything issued (or still queued) for the gradient side stream so far"""
+        self.side_flush()
         if self._gstream is not None:
             ev = torch.cuda.Event()
             with torch.cuda.stream(self._gstream):
@@ -898,20 +925,21 @@ class MrBlipEngine:
             kq_ready = None
             if self.grad_side_stream_enabled:
                 qkv_i = self.ws[f"e{i}_qkv"]
-                st, ev = self._grad_stream(), torch.cuda.Event()
-                ev.record()  # (the previous layer's attention backward, the last reader of kt / qt, is ahead of this point)
-                with torch.cuda.stream(st):
-                    st.wait_event(ev)
+                kq_ready = torch.cuda.Event()
+
+                def kq_job(qkv_i=qkv_i, kq_ready=kq_ready):
                     ops.head_transpose(self.v4(qkv_i, B, S, H, dk, inner), out=kt)
                     ops.head_transpose(self.v4(qkv_i, B, S, H, dk, 0), out=qt)
-                    kq_ready = torch.cuda.Event()
                     kq_ready.record()
+                # queued: goes out with the wi group's record below (the previous layer's attention backward, the last reader of
+                # kt / qt, is ahead of that point; this layer's attention backward is ~400 us behind it)
+                self.side_defer(kq_job)
             # x_out = xm + drop(wo(y));  y = drop(gelu(wi_0 xn2) * wi_1 xn2)
             # (the bf16 operands dyb / dyb2 = dropout-backward(dx) are written by the RMSNorm backward that produced dx — one launch
             # and one 16 MB read fewer per sub-layer; only the top layer, whose dx comes from the decoder, casts on its own)
             if not dyb_ready:
                 ops.cast_dropout(dx, out_bf16=dyb, drop=self.drop(L["sites"][3], p))
-            self.lg_bwd(L["wo"], dyb, self.ws[f"e{i}_y"], self.ws[f"e{i}_u_wo"], gb, dyact, side=True, tile_cfg=_ENC_BWD_CFG[0])
+            self.lg_bwd(L["wo"], dyb, self.ws[f"e{i}_y"], self.ws[f"e{i}_u_wo"], gb, dyact, side=True, tile_cfg=_ENC_BWD_CFG[0], flush=False)
             ops.gated_gelu_bwd(dyact, self.ws[f"e{i}_h"], dh, drop=self.drop(L["sites"][2], p))
             self.lg_bwd(L["wi"], dh, self.ws[f"e{i}_xn2"], self.ws[f"e{i}_u_wi"], gb2, dxn, side=True, tile_cfg=_ENC_BWD_CFG[1])
             if self.fuse_bwd_cast:
@@ -921,7 +949,7 @@ class MrBlipEngine:
                 ops.cast_dropout(other, out_bf16=dyb2, drop=self.drop(L["sites"][1], p))
             dx, other = other, dx
             # xm = x_in + drop(o(attn(qkv(xn))))
-            self.lg_bwd(L["o"], dyb2, self.ws[f"e{i}_o"], self.ws[f"e{i}_u_o"], gb3, do, side=True, tile_cfg=_ENC_BWD_CFG[2])
+            self.lg_bwd(L["o"], dyb2, self.ws[f"e{i}_o"], self.ws[f"e{i}_u_o"], gb3, do, side=True, tile_cfg=_ENC_BWD_CFG[2], flush=False)
             qkv, o = self.ws[f"e{i}_qkv"], self.ws[f"e{i}_o"]
             q4, k4, v4 = self.v4(qkv, B, S, H, dk, 0), self.v4(qkv, B, S, H, dk, inner), self.v4(qkv, B, S, H, dk, 2 * inner)
             do4 = self.v4(do, B, S, H, dk)
@@ -1178,7 +1206,7 @@ class MrBlipEngine:
             self.side_join()
             dyb = dybs[0]
             ops.cast_dropout(dx, out_bf16=dyb, drop=self.drop(L["sites"][5], p))
-            self.lg_bwd(L["wo"], dyb, self.ws[f"d{i}_y"], self.ws[f"d{i}_u_wo"], gbs[0], dyact, side=dside)
+            self.lg_bwd(L["wo"], dyb, self.ws[f"d{i}_y"], self.ws[f"d{i}_u_wo"], gbs[0], dyact, side=dside, flush=False)
             ops.gated_gelu_bwd(dyact, self.ws[f"d{i}_h"], dh, drop=self.drop(L["sites"][4], p))
             self.lg_bwd(L["wi"], dh, self.ws[f"d{i}_xn2"], self.ws[f"d{i}_u_wi"], gbs[1], dxn, side=dside)
             ops.rmsnorm_bwd(dxn, self.ws[f"d{i}_x2"], L["ln2"], c.t5_eps, other, dx_add=dx)
@@ -1186,7 +1214,7 @@ class MrBlipEngine:
             # cross attention
             dyb = dybs[1]
             ops.cast_dropout(dx, out_bf16=dyb, drop=self.drop(L["sites"][3], p))
-            self.lg_bwd(L["co"], dyb, self.ws[f"d{i}_co"], self.ws[f"d{i}_u_co"], gbs[2], do, side=dside)
+            self.lg_bwd(L["co"], dyb, self.ws[f"d{i}_co"], self.ws[f"d{i}_u_co"], gbs[2], do, side=dside, flush=False)
             dckv = self.buf(f"db_dckv{i}", (Me, 2 * inner), bf16, zero=False)
             cq, ckv, co = self.ws[f"d{i}_cq"], self.ws[f"d{i}_ckv"], self.ws[f"d{i}_co"]
             q4, k4, v4 = self.v4(cq, B, Ld, H, dk), self.v4(ckv, B, S, H, dk, 0), self.v4(ckv, B, S, H, dk, inner)
@@ -1197,12 +1225,9 @@ class MrBlipEngine:
             ops.attention_bwd(q4, k4, v4, self.v4(co, B, Ld, H, dk), do4, kt_c, qt_s, dot_s, self.ws[f"d{i}_lsec"], delta,
                               self.v4(dcq, B, Ld, H, dk), self.v4(dckv, B, S, H, dk, 0), self.v4(dckv, B, S, H, dk, inner),
                               scale=1.0, kmask=kmask, drop=self.drop(L["sites"][2], p))
-            if dside:
-                st, ev = self._grad_stream(), torch.cuda.Event()
-                ev.record()
-                with torch.cuda.stream(st):
-                    st.wait_event(ev)
-                    self.lg_bwd(L["ckv"], dckv, enc, self.ws[f"d{i}_u_ckv"], self.buf(f"db_ge{i}", (Me, 64), bf16), denc, residual=denc)
+            if dside:   # queued: goes out with the cq group's record
+                ge_i, u_ckv_i = self.buf(f"db_ge{i}", (Me, 64), bf16), self.ws[f"d{i}_u_ckv"]
+                self.side_defer(lambda L=L, dckv=dckv, ge_i=ge_i, u_ckv_i=u_ckv_i: self.lg_bwd(L["ckv"], dckv, enc, u_ckv_i, ge_i, denc, residual=denc))
             else:
                 self.lg_bwd(L["ckv"], dckv, enc, self.ws[f"d{i}_u_ckv"], self.buf(f"db_ge{i}", (Me, 64), bf16), denc, residual=denc)
             self.lg_bwd(L["cq"], dcq, self.ws[f"d{i}_xn1"], self.ws[f"d{i}_u_cq"], gbs[3], dxn, side=dside)
@@ -1211,7 +1236,7 @@ class MrBlipEngine:
             # self attention
             dyb = dybs[2]
             ops.cast_dropout(dx, out_bf16=dyb, drop=self.drop(L["sites"][1], p))
-            self.lg_bwd(L["o"], dyb, self.ws[f"d{i}_o"], self.ws[f"d{i}_u_o"], gbs[4], do, side=dside)
+            self.lg_bwd(L["o"], dyb, self.ws[f"d{i}_o"], self.ws[f"d{i}_u_o"], gbs[4], do, side=dside, flush=False)
             qkv, o = self.ws[f"d{i}_qkv"], self.ws[f"d{i}_o"]
             q4, k4, v4 = self.v4(qkv, B, Ld, H, dk, 0), self.v4(qkv, B, Ld, H, dk, inner), self.v4(qkv, B, Ld, H, dk, 2 * inner)
             do4 = self.v4(do, B, Ld, H, dk)
