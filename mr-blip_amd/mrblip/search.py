@@ -10,17 +10,20 @@ best_running_sum / generated_len ** length_penalty; at the length limit the runn
 wins.  HF itself is third-party (not in the reference tree): tests/test_search_cpu.py pins this module against the HF implementation
 present in the image (transformers 5.x ``generate`` on a small random T5).
 """
-from typing import Callable, List
+from typing import Optional, Callable, List
 
 import torch
 
 
 def beam_search(step_fn: Callable[[torch.Tensor], torch.Tensor], batch: int, num_beams: int, max_new_tokens: int, min_length: int = 1,
-                length_penalty: float = 1.0, eos_id: int = 1, pad_id: int = 0, start_id: int = 0) -> List[torch.Tensor]:
+                length_penalty: float = 1.0, eos_id: int = 1, pad_id: int = 0, start_id: int = 0, trace: Optional[list] = None) -> List[torch.Tensor]:
     """step_fn(seqs [batch * K, L] int64) -> log-probabilities [batch * K, V] (float32, CPU) of the next token.
     A step function with a truthy ``takes_parents`` attribute is called as step_fn(seqs, parents): parents [batch * K] int64 names, for
     every row of ``seqs``, the row of the PREVIOUS call it extends (None on the first call) — what an incremental decoder needs to
     re-order its self-attention K/V cache (HF's ``_reorder_cache(beam_idx)``).
+    trace (diagnostics, optional list): receives one entry per step — for every batch item the 2K best candidate scores, best first
+    (entry[b][K-1] - entry[b][K] is the margin by which the K-th beam survived the pruning) — and a last entry with every item's final
+    pool scores, best first; tests use it to tell a genuine tie from a wrong result.
     Returns one 1-D tensor per batch item: start token, generated tokens, EOS if the hypothesis ended with one."""
     B, K = batch, max(1, int(num_beams))
     seqs = torch.full((B * K, 1), start_id, dtype=torch.long)
@@ -48,6 +51,8 @@ def beam_search(step_fn: Callable[[torch.Tensor], torch.Tensor], batch: int, num
             lp[:, eos_id] = -float("inf")
         cand = (lp + beam_scores.view(B * K, 1)).view(B, K * V)
         top, idx = cand.topk(min(2 * K, K * V), dim=-1)
+        if trace is not None:
+            trace.append([None if done[b] else top[b].tolist() for b in range(B)])
         new_seqs = torch.full((B * K, cur_len + 1), pad_id, dtype=torch.long)
         new_scores = torch.zeros(B, K)
         parents = torch.arange(B * K)
@@ -83,4 +88,6 @@ def beam_search(step_fn: Callable[[torch.Tensor], torch.Tensor], batch: int, num
             for k in range(K):
                 pool_add(b, seqs[b * K + k], beam_scores[b, k].item(), seqs.shape[1] - 1)
         out.append(max(pools[b], key=lambda t: t[0])[1])
+    if trace is not None:
+        trace.append([sorted((sc for sc, _ in pools[b]), reverse=True) for b in range(B)])
     return out
