@@ -20,6 +20,12 @@
 #ifndef TILE_PIPE
 #define TILE_PIPE 0
 #endif
+// TILE_REGSTAGE (experiment): operand tiles through registers (buffer_load_b128 -> VGPRs -> ds_write_b128, same LDS image as the LDS-DMA
+// pieces) instead of LDS-DMA: an LDS-DMA piece occupies a SIMD's issue for ~100-200 clocks, which caps a CU's fill rate at ~45 GB/s with
+// one block per CU (75 GB/s with two) — the per-K-tile time of the small tiles tracks their DMA bytes, not their MFMAs.
+#ifndef TILE_REGSTAGE
+#define TILE_REGSTAGE 0
+#endif
 #include <stdlib.h>
 
 struct GemmArgs {
@@ -309,6 +315,35 @@ __global__ __launch_bounds__(WGM* WGN * 64, gemm_min_blocks(NS * (BM + BN) * BK 
   };
   auto stage = [&](int kt, int buf) __attribute__((always_inline)) { stage_part(kt, buf, std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}); };
 
+  constexpr bool RSTG = TILE_REGSTAGE != 0 && NS == 2;
+  mrb_u32x4 rs_a[JA], rs_w[JW];
+  auto rs_issue = [&](int kt) __attribute__((always_inline)) {
+    const bool ext = kt >= nk_main;  // uniform
+    if (!ext) {
+      const uint32_t koff = (uint32_t)kt * (uint32_t)RB;
+      const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.A), 0, (int)(uint32_t)((long long)p.M * p.lda * 2), 0x00020000);
+      const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.W), 0, (int)(uint32_t)((long long)p.N * p.ldw * 2), 0x00020000);
+#pragma unroll
+      for (int j = 0; j < JA; ++j) rs_a[j] = __builtin_amdgcn_raw_buffer_load_b128(ra, vpa[j], koff, 0);
+#pragma unroll
+      for (int j = 0; j < JW; ++j) rs_w[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, vpw[j], koff, 0);
+    } else {
+      const uint32_t koff = (uint32_t)(kt - nk_main) * (uint32_t)RB;
+      const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.Aext), 0, (int)(uint32_t)((long long)p.M * p.ldaext * 2), 0x00020000);
+      const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.Wext), 0, (int)(uint32_t)((long long)p.N * p.ldwext * 2), 0x00020000);
+#pragma unroll
+      for (int j = 0; j < JA; ++j) rs_a[j] = __builtin_amdgcn_raw_buffer_load_b128(ra, vAe + (uint32_t)((long long)(bm * BM + (j * NW + w) * RPI) * p.ldaext * 2), koff, 0);
+#pragma unroll
+      for (int j = 0; j < JW; ++j) rs_w[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, vWe + (uint32_t)((long long)w_row_base(j) * p.ldwext * 2), koff, 0);
+    }
+  };
+  auto rs_commit = [&](int buf) __attribute__((always_inline)) {   // the LDS image of the LDS-DMA pieces: piece (j * NW + w), lane-linear
+    char* base = smem + buf * STAGE + lane * 16;
+#pragma unroll
+    for (int j = 0; j < JA; ++j) *reinterpret_cast<mrb_u32x4*>(base + (j * NW + w) * (RPI * RB)) = rs_a[j];
+#pragma unroll
+    for (int j = 0; j < JW; ++j) *reinterpret_cast<mrb_u32x4*>(base + A_BYTES + (j * NW + w) * (RPI * RB)) = rs_w[j];
+  };
   f32x16 acc[TM][TN];
 
   // fragment read offsets (bytes) inside a stage
@@ -350,21 +385,34 @@ __global__ __launch_bounds__(WGM* WGN * 64, gemm_min_blocks(NS * (BM + BN) * BK 
 
   const bool ext_first = p.ext_first != 0;  // uniform
   auto kmap = [&](int i) __attribute__((always_inline)) { return ext_first ? (i < NEXT ? nk_main + i : i - NEXT) : i; };
-  stage(kmap(0), 0);
+  if constexpr (RSTG) {
+    rs_issue(kmap(0));
+    rs_commit(0);
+    if (nk > 1) rs_issue(kmap(1));
+  } else {
+    stage(kmap(0), 0);
 #pragma unroll
-  for (int i = 1; i < NS - 1; ++i)
-    if (i < nk) stage(kmap(i), i);
+    for (int i = 1; i < NS - 1; ++i)
+      if (i < nk) stage(kmap(i), i);
+  }
   for (int kt = 0; kt < nk; ++kt) {
-    // stage kt must have landed; with a deeper ring the NS - 2 newest stages may still be in flight (LDS-DMA loads retire in order)
+    if constexpr (RSTG) {
+      // this wave's ds_writes of stage kt are done (NOT its global loads of K-tile kt + 1: no vmcnt wait here); behind the barrier
+      // every wave has written stage kt and finished reading stage kt - 1
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    } else {
+      // stage kt must have landed; with a deeper ring the NS - 2 newest stages may still be in flight (LDS-DMA loads retire in order)
 #ifndef EXP_NOSYNC
-    if (NS >= 4 && kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (JA + JW)) : "memory");
-    else if (NS >= 3 && kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(JA + JW) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+      if (NS >= 4 && kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (JA + JW)) : "memory");
+      else if (NS >= 3 && kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(JA + JW) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
 #endif
 #if !defined(EXP_NODMA) && TILE_PIPE != 1
-    if (kt + NS - 1 < nk) stage(kmap(kt + NS - 1), (kt + NS - 1) % NS);
+      if (kt + NS - 1 < nk) stage(kmap(kt + NS - 1), (kt + NS - 1) % NS);
 #endif
+    }
     const char* base = smem + (kt % NS) * STAGE;
 #if TILE_PIPE
     // Round 3: software-pipelined K-tile.  The compiler's own schedule of the plain loop below issues the whole next stage (6-8 LDS-DMA
@@ -430,6 +478,12 @@ __global__ __launch_bounds__(WGM* WGN * 64, gemm_min_blocks(NS * (BM + BN) * BK 
     }
 #endif
 #endif  // TILE_PIPE
+    if constexpr (RSTG) {
+      if (kt + 1 < nk) {             // K-tile kt + 1 (requested one K-tile ago) goes into the stage that K-tile kt - 1 used
+        rs_commit((kt + 1) & 1);
+        if (kt + 2 < nk) rs_issue(kmap(kt + 2));
+      }
+    }
     if (!GATED && ext_first && kt == NEXT - 1 && p.ext_drop.seed_ptr) {  // acc == Aext Wext^T: apply the LoRA input-dropout mask to it
       const uint32_t seed = mrb_seed_load(p.ext_drop.seed_ptr);
 #pragma unroll

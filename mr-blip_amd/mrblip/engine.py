@@ -1304,8 +1304,14 @@ class MrBlipEngine:
             F_ = next_video.shape[0] * next_video.shape[1]
             nb = c.vit_depth if self.vit_lookahead_blocks is None else max(1, min(c.vit_depth, int(self.vit_lookahead_blocks)))
             nb = max(1, nb - int(self.vit_tail_blocks))
-            with ops.gemm_cu_reserve(self.vit_lookahead_reserve):
-                xv = self.vit_forward(next_video.reshape(F_, 3, c.img, c.img), slot=slot, blocks=(0, nb))
+            frames = next_video.reshape(F_, 3, c.img, c.img)
+            b0 = 0
+            for upto, reserve in self.vit_reserve_schedule:   # (first-leg blocks < upto run with `reserve` CUs left to the other streams)
+                b1 = min(nb, upto)
+                if b1 > b0:
+                    with ops.gemm_cu_reserve(reserve):
+                        xv = self.vit_forward(frames, slot=slot, blocks=(b0, b1))
+                    b0 = b1
             done = torch.cuda.Event()
             done.record()
         self._vit_ready = (self._video_key(next_video), xv, done, slot, nb)
@@ -1315,6 +1321,10 @@ class MrBlipEngine:
     # launch; without a reserve the other stream's short, latency-bound kernels (the decoder chain above all) queue behind them
     # (QVH, B = 1: 85.0 ms per step with 0, 80.3 with 32, 78.3 with 64, 80.3 with 96, 84.1 with 128 reserved CUs).
     vit_lookahead_reserve = int(os.environ.get("MRB_VIT_RESERVE", "64"))
+    # optional per-block schedule "upto:reserve,upto:reserve" (experiments: the first blocks run beside the decoder's short kernels, the
+    # later ones beside the encoder backward's GEMMs); default: one segment with vit_lookahead_reserve
+    vit_reserve_schedule = ([(int(a), int(b)) for a, b in (seg.split(":") for seg in os.environ["MRB_VIT_RESERVE_SCHED"].split(","))]
+                            if os.environ.get("MRB_VIT_RESERVE_SCHED") else [(1 << 30, int(os.environ.get("MRB_VIT_RESERVE", "64")))])
     vit_lookahead_early = os.environ.get("MRB_VIT_EARLY", "0") == "1"  # start beside the encoder forward instead of after it
 
     vit_tail_blocks = int(os.environ.get("MRB_VIT_TAIL", "5"))  # look-ahead blocks held back for prefetch_vit_tail()
