@@ -273,6 +273,15 @@ static bool lora_thin_enabled() {
   return on == 1;
 }
 
+static int lora_thin_min_m() {   // rows from which the matrix-core thin kernel replaces the LDS-resident row kernel (MRB_LORA_THIN_MIN_M)
+  static int m = -1;
+  if (m < 0) {
+    const char* e = getenv("MRB_LORA_THIN_MIN_M");
+    m = e ? atoi(e) : LORA_THIN_MIN_M;
+  }
+  return m;
+}
+
 static int launch_thin(const LoraRowsArgs& a, hipStream_t st) {
   // 8-row blocks (MRB_LORA_THIN_ROWS=8; M = 2012: 252 blocks instead of 126) are FASTER stand-alone (enc g wi 17.8 vs 21.1 us, g qkv 14.4 vs
   // 16.3) and SLOWER in the train step (71.95 vs 71.36 ms; row kernel: 72.55): the 126-block form leaves half of the CUs to the
@@ -342,7 +351,7 @@ static int lora_rows_impl(const void* X, long long ldx, const void* A, long long
   a.drop.inv_keep = 1.0f / (1.0f - p_drop);
   MRB_REQUIRE(!init_dst || ((init_n % 4) == 0 && (ld_idst % 4) == 0 && (!init_src || (ld_isrc % 4) == 0)), "lora_rows: init job needs 16-B rows");
   a.init_dst = init_dst; a.init_src = init_src; a.ld_idst = ld_idst; a.ld_isrc = ld_isrc; a.init_n = init_dst ? init_n : 0;
-  if (M >= LORA_THIN_MIN_M && (K % 32) == 0 && (ldu % 4) == 0 && ((uintptr_t)U % 8) == 0 && (long long)M * ldx * 2 < (1ll << 31) && lora_thin_enabled())
+  if (M >= lora_thin_min_m() && (K % 32) == 0 && (ldu % 4) == 0 && ((uintptr_t)U % 8) == 0 && (long long)M * ldx * 2 < (1ll << 31) && lora_thin_enabled())
     return launch_thin(a, stream);
   switch (R / 8) {
     case 1: return launch_rows<1>(a, stream);
@@ -442,7 +451,7 @@ extern "C" int mrblip_rmsnorm_lora_fwd(const float* x, long long ldx, const floa
   MRB_REQUIRE(R > 0 && R <= 32 && (R % 8) == 0 && ldu >= R && (lda % 8) == 0 && (ldx % 4) == 0 && (ldob % 4) == 0, "rmsnorm_lora: bad shape (R=%d)", R);
   MRB_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)A % 16) == 0 && ((uintptr_t)out_bf16 % 8) == 0, "rmsnorm_lora: alignment");
   MRB_REQUIRE(!(p_drop > 0.f) || seed_ptr, "rmsnorm_lora: dropout needs a device seed pointer");
-  if (M >= LORA_THIN_MIN_M && (D % 32) == 0 && (ldob % 8) == 0 && ((uintptr_t)out_bf16 % 16) == 0 && lora_thin_enabled()) {
+  if (M >= lora_thin_min_m() && (D % 32) == 0 && (ldob % 8) == 0 && ((uintptr_t)out_bf16 % 16) == 0 && lora_thin_enabled()) {
     // tall inputs: the norm at HBM speed, then the matrix-core thin product on the rows it just wrote (they are still in the L2 / MALL)
     if (int e = mrblip_rmsnorm_fwd(x, ldx, weight, M, D, eps, out_bf16, ldob, nullptr, 0, stream)) return e;
     return lora_rows_impl(out_bf16, ldob, A, lda, M, R, D, U, ldu, nullptr, seed_ptr, site, p_drop, nullptr, 0, nullptr, 0, 0, stream);
