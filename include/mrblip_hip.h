@@ -162,6 +162,16 @@ int mrblip_lora_rows_init(const void* X, long long ldx, const void* A, long long
 int mrblip_rmsnorm_lora_fwd(const float* x, long long ldx, const float* weight, int M, int D, float eps, void* out_bf16, long long ldob,
                             const void* A, long long lda, int R, void* U, long long ldu, const uint32_t* seed_ptr, uint32_t site, float p_drop,
                             mrblip_stream_t stream);
+/* One launch for an adapted projection of the T5 DECODER rows (R <= 16; replaces mrblip_lora_rows / mrblip_rmsnorm_lora_fwd + mrblip_gemm_bf16
+ * of peft's lora.Linear.forward around modeling_t5.py:449-603 (q/k/v/o), :323-329 (wi_0/wi_1/wo), and mrblip_lora_rows + mrblip_gemm_lora_dx of
+ * its backward):  xin = x32 ? bf16(RMSNorm(x32) * gamma) (saved to xin) : xin;  U[R, 0:Rk] = bf16(dropout(xin; in_site, in_p) A[Rk,K]^T);
+ * acc = xin W[N,K]^T + (ext_p > 0 ? mask(ext_site, ext_p) (.) : ) U Bt[N,64]^T;
+ * mode 0: out bf16 = acc;  mode 1: out fp32 = residual + dropout(acc; out_site, out_p);  mode 2 (W, Bt hold 2 N rows: wi_0 then wi_1):
+ * out2 bf16 [R, 2 N] = [acc_0 | acc_1], out bf16 = dropout(gelu(acc_0) * acc_1).  N % 16 == 0, K % 32 == 0, Rk in {8, 16, 24, 32}. */
+int mrblip_dec_proj(const float* x32, long long ldx32, const float* gamma, float eps, void* xin, long long ldxin, const void* W, long long ldw,
+                    const void* A, long long lda, int Rk, const void* Bt, long long ldbt, void* U, long long ldu, int R, int N, int K, int mode,
+                    void* out, long long ldo, const float* residual, long long ldr, void* out2, long long ldo2, const uint32_t* seed_ptr,
+                    uint32_t in_site, float in_p, uint32_t out_site, float out_p, uint32_t ext_site, float ext_p, mrblip_stream_t stream);
 /* LoRA backward input gradient in one launch: dX[M,N] = dY[M,K] Wt[N,K]^T (+ residual) + mask(site,p) * (G[M,64] AcatT[N,64]^T);
  * N = in_features, K = out_features padded to 64, mask = the forward's lora_dropout keep mask scaled by 1/(1-p) */
 int mrblip_gemm_lora_dx(const void* dY, long long lddy, const void* Wt, long long ldwt, const void* G, long long ldg, const void* AcatT,

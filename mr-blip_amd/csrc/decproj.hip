@@ -1,0 +1,298 @@
+// Fused projection of the T5 DECODER rows (R <= 16 rows: 8-14 label tokens of one clip; modeling_t5.py:747-826 with peft LoRA Linear):
+//
+//     xin  = bf16(RMSNorm(x) * gamma)            (NORM inputs: q/k/v, EncDecAttention.q, wi_0/wi_1)   or the given bf16 rows (o, wo)
+//     u    = bf16( dropout_lora(xin) (sA)^T )                                          [R, Rk]    (saved for the backward)
+//     acc  = xin W^T + u B^T                                                           [R, N]
+//     out  = bf16(acc) | residual + dropout(acc) (fp32) | bf16(dropout(gelu(acc_0) * acc_1)) with out2 = bf16([acc_0 | acc_1])
+//
+// and the backward's input gradient of the same layers (the same arithmetic with other operands):
+//
+//     g    = bf16( dy (sB) )   (= "u", no dropout),   dx = dy W + mask_lora (.) (g (sA))  (+ residual)       (ext_masked)
+//
+// Until round 3 each of these was two launches — the LoRA row kernel (or the fused RMSNorm + row kernel) and the skinny GEMM — on a
+// chain of ~45 launches per decoder layer whose length, not whose work, sets the decoder's share of the train step (tools/prof_layer.py:
+// 283 + 325 us of kernels per layer for 113 MB of weights; skipping 3.2 ms of that chain shortens the step by 1.9 ms).  One launch now:
+// a block owns 16 * NT output columns, its 8 waves split K; every wave streams its share of the block's W rows, of the stacked LoRA "down"
+// rows (32-96 KB, L2 resident, re-read by every block) and of the input rows as 16-B loads straight into v_mfma_f32_16x16x32_bf16
+// fragments (lane (i = l & 15, kg = l >> 4) holds 8 consecutive k of row i), two batches of k-steps in flight; the partial accumulators
+// meet in LDS in fixed order; the rank-Rk "up" product is one more MFMA on u rounded to bf16 exactly as the two-launch path stores it.
+// NORM: the normalised rows are built once per block in LDS (padded rows: conflict-free fragment reads) and block 0 saves them.
+// Dropout masks: the element indices and hashes of the kernels this replaces (lora.hip: pair hash over row * K + k; gemm.hip epilogue:
+// single hash over row * N + n; the LoRA-backward mask: pair hash over row * N + n).
+#include "common.h"
+
+struct DecProjArgs {
+  const float* x32; long long ldx32; const float* gamma; float eps;   // NORM input (x32 != nullptr)
+  bf16_t* xin; long long ldxin;                                       // bf16 [R, >= K]: the input rows, or (NORM) where the normalised rows are saved
+  const bf16_t* W; long long ldw;                                     // [N (gated: 2 N), K]
+  const bf16_t* A; long long lda; int Rk;                             // [Rk, K] stacked scaled LoRA "down" rows (backward: s B^T block-diagonal)
+  const bf16_t* Bt; long long ldbt;                                   // [N (gated: 2 N), 64]: LoRA "up" rows (backward: (s A)^T)
+  bf16_t* U; long long ldu;                                           // [R, 64] out: u (forward) / g (backward)
+  int R, N, K;
+  void* out; long long ldo; const float* residual; long long ldr; bf16_t* out2; long long ldo2;
+  DropoutArg in_drop, out_drop, ext_drop;
+};
+
+typedef uint32_t dp_u32x4 __attribute__((ext_vector_type(4)));
+
+template <int NT, int MODE, int UB>   // NT tiles of 16 output columns (gated: NT of wi_0 and the same NT of wi_1); MODE 0 bf16, 1 fp32 (+ residual), 2 gated
+__global__ __launch_bounds__(512) void dec_proj_kernel(const DecProjArgs p) {
+  constexpr int NTW = MODE == 2 ? 2 * NT : NT, NA = 2, NACC = NTW + NA;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // LDS: [red: 8 waves x NACC x 64 lanes x 16 B][ubuf: 16 rows x 64 B][NORM: 16 rows x (2 K + 16) B]
+  f32x4* red = reinterpret_cast<f32x4*>(smem);
+  bf16_t* ubuf = reinterpret_cast<bf16_t*>(smem + 8 * NACC * 64 * 16);
+  char* xs = smem + 8 * NACC * 64 * 16 + 1024;
+  const bool NORM = p.x32 != nullptr;   // block-uniform
+  const int RS = p.K * 2 + 16;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, kg = lane >> 4;
+  const int n0 = blockIdx.x * 16 * NT;
+  const bool in_drop = p.in_drop.seed_ptr != nullptr, out_drop = p.out_drop.seed_ptr != nullptr, ext_masked = p.ext_drop.seed_ptr != nullptr;
+  const uint32_t* sp = in_drop ? p.in_drop.seed_ptr : out_drop ? p.out_drop.seed_ptr : p.ext_drop.seed_ptr;
+  const uint32_t seed = sp ? mrb_seed_load(sp) : 0u;
+
+  if (NORM) {   // rows 2 w, 2 w + 1: RMSNorm -> bf16 rows in LDS (the arithmetic of norm_fwd_kernel<true>: v * rstd * gamma, one rounding)
+    const int nv = p.K >> 2;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = 2 * w + i;
+      float4 v[8];
+      float q = 0.f;
+      const float4* xr = reinterpret_cast<const float4*>(p.x32 + (long long)(r < p.R ? r : 0) * p.ldx32);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int c = lane + 64 * j, cc = c < nv ? c : 0;
+        v[j] = xr[cc];
+        if (c >= nv || r >= p.R) v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        q += v[j].x * v[j].x + v[j].y * v[j].y + v[j].z * v[j].z + v[j].w * v[j].w;
+      }
+      const float rstd = rsqrtf(wave_sum(q) / (float)p.K + p.eps);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int c = lane + 64 * j;
+        if (c < nv) {
+          const float4 g = reinterpret_cast<const float4*>(p.gamma)[c];
+          const uint2 o = make_uint2(pack2bf(v[j].x * rstd * g.x, v[j].y * rstd * g.y), pack2bf(v[j].z * rstd * g.z, v[j].w * rstd * g.w));
+          *reinterpret_cast<uint2*>(xs + r * RS + c * 8) = o;
+          if (blockIdx.x == 0 && r < p.R) *reinterpret_cast<uint2*>(p.xin + (long long)r * p.ldxin + c * 4) = o;
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- main loop: this wave's k-steps of 32
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.W), 0, (int)((((long long)(MODE == 2 ? 2 : 1) * p.N - 1) * p.ldw + p.K) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.A), 0, (int)((((long long)p.Rk - 1) * p.lda + p.K) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(p.xin, 0, NORM ? 0 : (int)((((long long)p.R - 1) * p.ldxin + p.K) * 2), 0x00020000);
+  uint32_t woff[NTW], aoff[NA];
+#pragma unroll
+  for (int t = 0; t < NTW; ++t) {
+    const int col = n0 + (t % NT) * 16 + l15;                        // output column of this lane's W row
+    const long long row = (MODE == 2 && t >= NT) ? (long long)p.N + col : col;
+    woff[t] = col < p.N ? (uint32_t)((row * p.ldw + kg * 8) * 2) : 0x80000000u;
+  }
+#pragma unroll
+  for (int a = 0; a < NA; ++a) aoff[a] = (uint32_t)(((long long)(16 * a + l15) * p.lda + kg * 8) * 2);   // rows >= Rk: beyond the resource
+  const uint32_t xoff = (uint32_t)(((long long)l15 * p.ldxin + kg * 8) * 2);                              // rows >= R: beyond the resource
+  const int nks = p.K >> 5;
+  const int per = (nks + 7) >> 3;
+  const int ks0 = w * per, ks1 = min(nks, ks0 + per);
+  f32x4 acc[NTW], accu[NA];
+#pragma unroll
+  for (int t = 0; t < NTW; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int a = 0; a < NA; ++a) accu[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+  dp_u32x4 wf[2][UB][NTW], af[2][UB][NA], xf[2][UB];
+  auto fetch = [&](int buf, int ks) {   // unconditional (past the share: out-of-range offsets -> zeros, no traffic), see lora_thin_kernel
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const bool ok = ks + u < ks1;
+      const uint32_t kb = (uint32_t)(ks + u) * 64u;
+#pragma unroll
+      for (int t = 0; t < NTW; ++t) wf[buf][u][t] = __builtin_amdgcn_raw_buffer_load_b128(rw, ok ? woff[t] + kb : 0x80000000u, 0, 0);
+#pragma unroll
+      for (int a = 0; a < NA; ++a) af[buf][u][a] = __builtin_amdgcn_raw_buffer_load_b128(ra, ok ? aoff[a] + kb : 0x80000000u, 0, 0);
+      if (!NORM) xf[buf][u] = __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? xoff + kb : 0x80000000u, 0, 0);
+    }
+  };
+  auto consume = [&](int buf, int ks) {
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      dp_u32x4 x;
+      if (NORM) {
+        const int k = min(ks + u, nks - 1) * 32 + kg * 8;
+        x = *reinterpret_cast<const dp_u32x4*>(xs + l15 * RS + k * 2);
+        if (ks + u >= ks1) x = dp_u32x4{0u, 0u, 0u, 0u};
+      } else {
+        x = xf[buf][u];
+      }
+      dp_u32x4 xd = x;
+      if (in_drop) {   // block-uniform
+        const uint32_t e = (uint32_t)l15 * (uint32_t)p.K + (uint32_t)((ks + u) * 32 + kg * 8);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          bool k0, k1;
+          mrb_keep2(e + 2 * q, seed, p.in_drop.site, p.in_drop.thresh24, k0, k1);
+          xd[q] = (k0 ? x[q] & 0xffffu : 0u) | (k1 ? x[q] & 0xffff0000u : 0u);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < NTW; ++t)
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[buf][u][t]), __builtin_bit_cast(bf16x8, x), acc[t], 0, 0, 0);
+#pragma unroll
+      for (int a = 0; a < NA; ++a)
+        accu[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[buf][u][a]), __builtin_bit_cast(bf16x8, xd), accu[a], 0, 0, 0);
+    }
+  };
+  fetch(0, ks0);
+#pragma unroll 1
+  for (int ks = ks0; ks < ks1; ks += 2 * UB) {
+    fetch(1, ks + UB);
+    consume(0, ks);
+    fetch(0, ks + 2 * UB);
+    if (ks + UB < ks1) consume(1, ks + UB);
+  }
+
+  // ---- the 8 partial sums meet in LDS (fixed order)
+#pragma unroll
+  for (int t = 0; t < NTW; ++t) red[(w * NACC + t) * 64 + lane] = acc[t];
+#pragma unroll
+  for (int a = 0; a < NA; ++a) red[(w * NACC + NTW + a) * 64 + lane] = accu[a];
+  __syncthreads();
+  if (w < NA) {   // u tile w: lane (r = l15, kg) holds j = 16 w + 4 kg .. + 3
+    f32x4 v = red[(0 * NACC + NTW + w) * 64 + lane];
+#pragma unroll
+    for (int j = 1; j < 8; ++j) v += red[(j * NACC + NTW + w) * 64 + lane];
+    const float post = in_drop ? p.in_drop.inv_keep : 1.0f;
+    const uint2 ub = make_uint2(pack2bf(v[0] * post, v[1] * post), pack2bf(v[2] * post, v[3] * post));
+    const int j0 = 16 * w + 4 * kg;
+    *reinterpret_cast<uint2*>(ubuf + l15 * 32 + j0) = ub;
+    if (blockIdx.x == 0 && l15 < p.R && j0 < p.Rk) *reinterpret_cast<uint2*>(p.U + (long long)l15 * p.ldu + j0) = ub;
+  }
+  __syncthreads();
+  if (w < NT) {   // output tile w (gated: the pair w, w + NT)
+    const int col = n0 + w * 16;
+    constexpr int NH = MODE == 2 ? 2 : 1;
+    f32x4 h[NH];
+    const dp_u32x4 uf = *reinterpret_cast<const dp_u32x4*>(ubuf + l15 * 32 + kg * 8);    // u[r = l15][8 kg .. + 7]
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.Bt), 0, (int)((((long long)(MODE == 2 ? 2 : 1) * p.N - 1) * p.ldbt + 64) * 2), 0x00020000);
+#pragma unroll
+    for (int s = 0; s < NH; ++s) {
+      const int t = w + s * NT;
+      f32x4 v = red[(0 * NACC + t) * 64 + lane];
+#pragma unroll
+      for (int j = 1; j < 8; ++j) v += red[(j * NACC + t) * 64 + lane];
+      const long long brow = (long long)(s ? p.N : 0) + col + l15;
+      const dp_u32x4 bf = __builtin_amdgcn_raw_buffer_load_b128(rb, (col + l15 < p.N) ? (uint32_t)((brow * p.ldbt + kg * 8) * 2) : 0x80000000u, 0, 0);
+      const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+      if (ext_masked) {   // backward: dx = dy W + mask (.) (g A): the rank-Rk product on its own, masked per element (pair hash over row * N + n)
+        f32x4 e = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bf), __builtin_bit_cast(bf16x8, uf), zero, 0, 0, 0);
+        const uint32_t idx = (uint32_t)l15 * (uint32_t)p.N + (uint32_t)(col + 4 * kg);
+        bool k0, k1, k2, k3;
+        mrb_keep2(idx, seed, p.ext_drop.site, p.ext_drop.thresh24, k0, k1);
+        mrb_keep2(idx + 2, seed, p.ext_drop.site, p.ext_drop.thresh24, k2, k3);
+        v[0] += k0 ? e[0] * p.ext_drop.inv_keep : 0.f; v[1] += k1 ? e[1] * p.ext_drop.inv_keep : 0.f;
+        v[2] += k2 ? e[2] * p.ext_drop.inv_keep : 0.f; v[3] += k3 ? e[3] * p.ext_drop.inv_keep : 0.f;
+      } else {
+        v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bf), __builtin_bit_cast(bf16x8, uf), v, 0, 0, 0);
+      }
+      h[s] = v;
+    }
+    const int r = l15, n = col + 4 * kg;   // this lane: row r, columns n .. n + 3
+    if (r < p.R && n < p.N) {
+      if (MODE == 2) {
+        if (p.out2) {   // (generation keeps no pre-activations)
+          *reinterpret_cast<uint2*>(p.out2 + (long long)r * p.ldo2 + n) = make_uint2(pack2bf(h[0][0], h[0][1]), pack2bf(h[0][2], h[0][3]));
+          *reinterpret_cast<uint2*>(p.out2 + (long long)r * p.ldo2 + p.N + n) = make_uint2(pack2bf(h[NH - 1][0], h[NH - 1][1]), pack2bf(h[NH - 1][2], h[NH - 1][3]));
+        }
+        float y[4];
+#pragma unroll
+        for (int i = 0; i < 4; i += 2) {
+          float g0 = h[0][i], g1 = h[0][i + 1];
+          gelu_erf2(g0, g1);
+          y[i] = g0 * h[NH - 1][i];
+          y[i + 1] = g1 * h[NH - 1][i + 1];
+        }
+        if (out_drop) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            y[i] = mrb_keep((uint32_t)r * (uint32_t)p.N + (uint32_t)(n + i), seed, p.out_drop.site, p.out_drop.thresh24) ? y[i] * p.out_drop.inv_keep : 0.f;
+        }
+        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + (long long)r * p.ldo + n) = make_uint2(pack2bf(y[0], y[1]), pack2bf(y[2], y[3]));
+      } else {
+        float y[4] = {h[0][0], h[0][1], h[0][2], h[0][3]};
+        if (out_drop) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            y[i] = mrb_keep((uint32_t)r * (uint32_t)p.N + (uint32_t)(n + i), seed, p.out_drop.site, p.out_drop.thresh24) ? y[i] * p.out_drop.inv_keep : 0.f;
+        }
+        if (MODE == 1) {
+          if (p.residual) {
+            const float4 q = *reinterpret_cast<const float4*>(p.residual + (long long)r * p.ldr + n);
+            y[0] += q.x; y[1] += q.y; y[2] += q.z; y[3] += q.w;
+          }
+          *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + (long long)r * p.ldo + n) = make_float4(y[0], y[1], y[2], y[3]);
+        } else {
+          *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + (long long)r * p.ldo + n) = make_uint2(pack2bf(y[0], y[1]), pack2bf(y[2], y[3]));
+        }
+      }
+    }
+  }
+}
+
+static void dp_drop(DropoutArg& d, const uint32_t* seed_ptr, uint32_t site, float p) {
+  d.seed_ptr = (p > 0.f) ? seed_ptr : nullptr;
+  d.site = site;
+  d.thresh24 = (uint32_t)(p * 65536.0f + 0.5f);
+  d.inv_keep = 1.0f / (1.0f - p);
+}
+
+// mode: 0 = bf16 out, 1 = fp32 out (+ residual), 2 = gated (W / Bt hold 2 N rows: wi_0 then wi_1; out2 [R, 2 N], optional, receives the pre-activations).
+// x32 != NULL: RMSNorm(x32) * gamma is the input (K <= 2048) and is saved to xin; else xin is the bf16 input.  ext_p > 0: the LoRA-backward
+// form (the rank-Rk product masked per element before it is added).  R <= 16, N % 16 == 0, K % 32 == 0, Rk <= 32 and a multiple of 8.
+extern "C" int mrblip_dec_proj(const float* x32, long long ldx32, const float* gamma, float eps, void* xin, long long ldxin, const void* W,
+                               long long ldw, const void* A, long long lda, int Rk, const void* Bt, long long ldbt, void* U, long long ldu, int R,
+                               int N, int K, int mode, void* out, long long ldo, const float* residual, long long ldr, void* out2, long long ldo2,
+                               const uint32_t* seed_ptr, uint32_t in_site, float in_p, uint32_t out_site, float out_p, uint32_t ext_site, float ext_p,
+                               hipStream_t stream) {
+  MRB_REQUIRE(R > 0 && R <= 16 && N > 0 && (N % 16) == 0 && K > 0 && (K % 32) == 0, "dec_proj: need R <= 16, N %% 16 == 0, K %% 32 == 0 (R=%d N=%d K=%d)", R, N, K);
+  MRB_REQUIRE(Rk > 0 && Rk <= 32 && (Rk % 8) == 0 && ldu >= Rk && (ldu % 4) == 0, "dec_proj: bad LoRA rank rows (Rk=%d)", Rk);
+  MRB_REQUIRE(mode >= 0 && mode <= 2 && W && A && Bt && U && xin && out, "dec_proj: bad mode / missing operand");
+  MRB_REQUIRE(!x32 || (K <= 2048 && gamma && (ldx32 % 4) == 0), "dec_proj: the fused RMSNorm takes K <= 2048");
+  MRB_REQUIRE((ldw % 8) == 0 && (lda % 8) == 0 && (ldbt % 8) == 0 && (ldxin % 8) == 0 && (ldo % 4) == 0 && ((uintptr_t)W % 16) == 0 &&
+                  ((uintptr_t)A % 16) == 0 && ((uintptr_t)Bt % 16) == 0 && ((uintptr_t)xin % 16) == 0 && ((uintptr_t)out % 16) == 0,
+              "dec_proj: 16-B alignment");
+  MRB_REQUIRE((long long)(mode == 2 ? 2 : 1) * N * ldw * 2 < (1ll << 31), "dec_proj: W exceeds the 2 GiB buffer range");
+  MRB_REQUIRE(!((in_p > 0.f || out_p > 0.f || ext_p > 0.f) && !seed_ptr), "dec_proj: dropout needs a device seed pointer");
+  DecProjArgs a;
+  a.x32 = x32; a.ldx32 = ldx32; a.gamma = gamma; a.eps = eps; a.xin = (bf16_t*)xin; a.ldxin = ldxin; a.W = (const bf16_t*)W; a.ldw = ldw;
+  a.A = (const bf16_t*)A; a.lda = lda; a.Rk = Rk; a.Bt = (const bf16_t*)Bt; a.ldbt = ldbt; a.U = (bf16_t*)U; a.ldu = ldu; a.R = R; a.N = N; a.K = K;
+  a.out = out; a.ldo = ldo; a.residual = residual; a.ldr = ldr; a.out2 = (bf16_t*)out2; a.ldo2 = ldo2;
+  dp_drop(a.in_drop, seed_ptr, in_site, in_p);
+  dp_drop(a.out_drop, seed_ptr, out_site, out_p);
+  dp_drop(a.ext_drop, seed_ptr, ext_site, ext_p);
+  constexpr int NT = 2;
+  const int grid = (N + 16 * NT - 1) / (16 * NT);
+  const int ntw = mode == 2 ? 2 * NT : NT;
+  const int LDS = 8 * (ntw + 2) * 64 * 16 + 1024 + (x32 ? 16 * (K * 2 + 16) : 0);
+  static bool attr[3] = {};
+#define MRB_DP_LAUNCH(MODE_, UB_)                                                                                                  \
+  {                                                                                                                                \
+    auto k = dec_proj_kernel<NT, MODE_, UB_>;                                                                                      \
+    if (!attr[MODE_]) {                                                                                                            \
+      if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * (2 * NT + 2) * 64 * 16 + 1024 + 16 * (2048 * 2 + 16)) != hipSuccess) { \
+        mrblip_set_error("dec_proj: cannot raise dynamic LDS");                                                                    \
+        return MRBLIP_ELAUNCH;                                                                                                     \
+      }                                                                                                                            \
+      attr[MODE_] = true;                                                                                                          \
+    }                                                                                                                              \
+    hipLaunchKernelGGL(k, dim3(grid), dim3(512), LDS, stream, a);                                                                  \
+  }
+  if (mode == 0) MRB_DP_LAUNCH(0, 4)
+  else if (mode == 1) MRB_DP_LAUNCH(1, 4)
+  else MRB_DP_LAUNCH(2, 2)
+#undef MRB_DP_LAUNCH
+  return mrblip_check_launch("dec_proj");
+}

@@ -37,6 +37,8 @@ _ENC_FWD_CFG = (tuple(int(x) for x in os.environ.get("MRB_ENC_FWD_CFG", "0,0,0,0
 _ENC_BWD_CFG = (tuple(int(x) for x in os.environ.get("MRB_ENC_BWD_CFG", "0,0,0,0").split(",")) + (0, 0, 0, 0))[:4]
 
 # tile configs of the ViT qkv / proj / fc2 / fc1 GEMMs (0 = the library's own choice); MRB_VIT_CFG="q,p,f2,f1" overrides for experiments
+# timing probe only (WRONG results): the decoder's cross-attention launches are skipped — "how much does the step care about the decoder window?"
+_EXP_SKIP_DEC_CROSS = os.environ.get("MRB_EXP_SKIP_DEC_CROSS", "0") == "1"
 _VIT_CFG = (tuple(int(x) for x in os.environ.get("MRB_VIT_CFG", "0,0,0,0").split(",")) + (0, 0, 0, 0))[:4]
 
 
@@ -696,6 +698,11 @@ class MrBlipEngine:
                 self.lora_thin(x, g.acat[8 * j: 8 * j + 8], u[:, 8 * j:], g.K, drop=self.drop(a.site, self.cfg.lora_dropout))
             ops.gemm(x, g.W, out, aext=u, wext=g.wext, **kw)
             return
+        if not u_ready and self._dec_proj_ok(g, x.shape[0], kw):
+            # <= 16 decoder rows: LoRA "down", main product, "up" product and epilogue in ONE launch (csrc/decproj.hip)
+            ops.dec_proj(x, g.W, g.acat, g.wext, u, out, g.K, residual=kw.get("residual"), out2=kw.get("out2"), gated=bool(kw.get("gated")),
+                         in_drop=self.drop(g.site, self.cfg.lora_dropout), out_drop=kw.get("drop"))
+            return
         ks = self.k_splits_for(x.shape[0], g.N, g.K, out)
         if ks > 1 and not u_ready and kw.get("residual", None) is not None and not kw.get("gated") and kw.get("out2") is None:
             # 12-token decoder rows: a [M x 2048] output has 64 tiles of the skinny kernel; ks blocks per tile share K and add their
@@ -711,6 +718,19 @@ class MrBlipEngine:
     # Opt-in (MRB_KSPLIT=1).  Measured on the QVH step: 76.6 vs 77.0 ms — the decoder chain is not what bounds the step once the
     # frozen-ViT look-ahead runs beside it — and the fp32 atomics make the summation order, hence the last bits, run-dependent.
     ksplit_enabled = os.environ.get("MRB_KSPLIT", "0") == "1"
+    # Round 3: the adapted projections of the decoder's <= 16 rows as ONE launch each (forward: [RMSNorm +] LoRA down + GEMM + LoRA up +
+    # epilogue; backward: g = dy B + the dX GEMM with its masked rank-8 term) instead of two.  MRB_DEC_PROJ=0 restores the two-launch path.
+    dec_proj_enabled = os.environ.get("MRB_DEC_PROJ", "1") == "1"
+
+    def _dec_proj_ok(self, g: "LoraGroup", M: int, kw: dict) -> bool:
+        if not self.dec_proj_enabled or M > 16 or g.acat is None or g.acat.shape[0] > 32:
+            return False
+        if self.cfg.lora_mask_per_adapter and len(g.adapters) > 1 and self.training and self.cfg.lora_dropout > 0:
+            return False
+        if kw.get("bias") is not None or kw.get("act", 0) or kw.get("k_splits", 0):
+            return False
+        n_out = g.W.shape[0] // 2 if kw.get("gated") else g.W.shape[0]
+        return n_out % 16 == 0 and g.K % 32 == 0
 
     def k_splits_for(self, M: int, N: int, K: int, out: torch.Tensor) -> int:
         """K split of the skinny GEMM (csrc/gemm.hip): only for <= 32 rows, fp32 output, few output tiles and a long enough K"""
@@ -745,6 +765,10 @@ class MrBlipEngine:
     def norm_lg_fwd(self, x: torch.Tensor, ln: torch.Tensor, g: LoraGroup, xn: torch.Tensor, u: torch.Tensor, out: torch.Tensor, **kw):
         """T5 RMSNorm + the LoRA "down" product of its output in ONE launch, then the main GEMM (q/k/v, wi_0/wi_1, EncDecAttention.q)"""
         per_adapter = self.cfg.lora_mask_per_adapter and len(g.adapters) > 1 and self.training and self.cfg.lora_dropout > 0
+        if g.K <= 2048 and self._dec_proj_ok(g, x.shape[0], kw):   # <= 16 decoder rows: norm, LoRA and projection in one launch
+            ops.dec_proj(xn, g.W, g.acat, g.wext, u, out, g.K, x32=x, gamma=ln, eps=self.cfg.t5_eps, residual=kw.get("residual"),
+                         out2=kw.get("out2"), gated=bool(kw.get("gated")), in_drop=self.drop(g.site, self.cfg.lora_dropout), out_drop=kw.get("drop"))
+            return
         if self.fuse_norm_lora and x.shape[0] <= self.lora_rows_max_m and not per_adapter:
             ops.rmsnorm_lora_fwd(x, ln, self.cfg.t5_eps, xn, g.acat, u, drop=self.drop(g.site, self.cfg.lora_dropout))
             self.lg_fwd(g, xn, u, out, u_ready=True, **kw)
@@ -783,8 +807,11 @@ class MrBlipEngine:
                 for j, a in enumerate(g.adapters):
                     ops.lora_dx_add(dx, gbuf[:, 8 * j: 8 * j + 8], g.acat[8 * j: 8 * j + 8], drop=self.drop(a.site, self.cfg.lora_dropout))
             return
-        ks = self.k_splits_for(dy.shape[0], g.K, pad64(g.N), dx) if dx is not None else 1
-        if ks > 1:   # dX by the K-split skinny GEMM: this launch also pre-initialises dx (residual or zero)
+        fused = dx is not None and g.N % 32 == 0 and self._dec_proj_ok(g, dy.shape[0], {}) and g.Wt.shape[0] % 16 == 0
+        ks = self.k_splits_for(dy.shape[0], g.K, pad64(g.N), dx) if (dx is not None and not fused) else 1
+        if fused:    # <= 16 decoder rows: g = dy B and dX = dy W + mask (.) (g A) [+ residual] in one launch
+            ops.dec_proj(dy, g.Wt, g.bblk, g.acatt, gbuf, dx, g.N, residual=residual, ext_drop=drop)
+        elif ks > 1:   # dX by the K-split skinny GEMM: this launch also pre-initialises dx (residual or zero)
             self.lora_thin(dy, g.bblk, gbuf, g.N, seg=seg, init_dst=dx, init_src=residual)
         else:
             self.lora_thin(dy, g.bblk, gbuf, g.N, seg=seg)                  # g' = scale * dy @ B      [M, 8*nad]
@@ -797,7 +824,7 @@ class MrBlipEngine:
                 self.side_flush()
         else:
             grads()
-        if dx is not None:
+        if dx is not None and not fused:
             if ks > 1:
                 ops.lora_dx(dy, g.Wt, gbuf, g.acatt, dx, pad64(g.N), residual=None, drop=drop, k_splits=ks)
             else:
@@ -1065,7 +1092,8 @@ class MrBlipEngine:
                 if ready is not None:
                     torch.cuda.current_stream().wait_event(ready)
                 lsec = self.buf(f"d{i}_lsec", (B, H, ops.rup32(Ld)), f32)
-                ops.attention_fwd(self.v4(cq, B, Ld, H, dk), ck4, vt_i, self.v4(co, B, Ld, H, dk), lsec, scale=1.0, kmask=kmask, drop=self.drop(L["sites"][2], p))
+                if not _EXP_SKIP_DEC_CROSS:
+                    ops.attention_fwd(self.v4(cq, B, Ld, H, dk), ck4, vt_i, self.v4(co, B, Ld, H, dk), lsec, scale=1.0, kmask=kmask, drop=self.drop(L["sites"][2], p))
             else:
                 Bc = cross_batch
                 rows = (B // Bc) * Ld  # query rows per encoder sequence: beams x positions
@@ -1222,9 +1250,10 @@ class MrBlipEngine:
             kt_c = self.ws[f"d{i}_kt_c"]  # made beside the forward (t5_decoder_forward)
             ops.head_transpose(q4, out=qt_s)
             ops.head_transpose(do4, out=dot_s)
-            ops.attention_bwd(q4, k4, v4, self.v4(co, B, Ld, H, dk), do4, kt_c, qt_s, dot_s, self.ws[f"d{i}_lsec"], delta,
-                              self.v4(dcq, B, Ld, H, dk), self.v4(dckv, B, S, H, dk, 0), self.v4(dckv, B, S, H, dk, inner),
-                              scale=1.0, kmask=kmask, drop=self.drop(L["sites"][2], p))
+            if not _EXP_SKIP_DEC_CROSS:
+                ops.attention_bwd(q4, k4, v4, self.v4(co, B, Ld, H, dk), do4, kt_c, qt_s, dot_s, self.ws[f"d{i}_lsec"], delta,
+                                  self.v4(dcq, B, Ld, H, dk), self.v4(dckv, B, S, H, dk, 0), self.v4(dckv, B, S, H, dk, inner),
+                                  scale=1.0, kmask=kmask, drop=self.drop(L["sites"][2], p))
             if dside:   # queued: goes out with the cq group's record
                 ge_i, u_ckv_i = self.buf(f"db_ge{i}", (Me, 64), bf16), self.ws[f"d{i}_u_ckv"]
                 self.side_defer(lambda L=L, dckv=dckv, ge_i=ge_i, u_ckv_i=u_ckv_i: self.lg_bwd(L["ckv"], dckv, enc, u_ckv_i, ge_i, denc, residual=denc))

@@ -77,6 +77,7 @@ _lora_dx = _sig("mrblip_lora_dx_add", vp, ll, i32, vp, ll, vp, i32, i32, i32, vp
 _cu_reserve = _sig("mrblip_gemm_set_cu_reserve", i32)
 _lora_rows = _sig("mrblip_lora_rows", vp, ll, vp, ll, i32, i32, i32, vp, ll, vp, vp, u32, f32, vp)
 _lora_rows_init = _sig("mrblip_lora_rows_init", vp, ll, vp, ll, i32, i32, i32, vp, ll, vp, vp, u32, f32, vp, ll, vp, ll, i32, vp)
+_dec_proj = _sig("mrblip_dec_proj", vp, ll, vp, f32, vp, ll, vp, ll, vp, ll, i32, vp, ll, vp, ll, i32, i32, i32, i32, vp, ll, vp, ll, vp, ll, vp, u32, f32, u32, f32, u32, f32, vp)
 _rms_lora = _sig("mrblip_rmsnorm_lora_fwd", vp, ll, vp, i32, i32, f32, vp, ll, vp, ll, i32, vp, ll, vp, u32, f32, vp)
 
 EXPORTS = [
@@ -86,7 +87,7 @@ EXPORTS = [
     "mrblip_cast_dropout", "mrblip_gelu_bwd", "mrblip_gated_gelu_bwd", "mrblip_cross_entropy", "mrblip_adamw",
     "mrblip_seed_bump", "mrblip_lora_dx_add", "mrblip_dropout_bf16", "mrblip_colsum", "mrblip_lora_pack", "mrblip_lora_tn",
     "mrblip_lora_grads", "mrblip_gemm_lora_down", "mrblip_gemm_lora_dx", "mrblip_patchify_u8",
-    "mrblip_gemm_set_cu_reserve", "mrblip_lora_rows", "mrblip_rmsnorm_lora_fwd", "mrblip_lora_rows_init",
+    "mrblip_gemm_set_cu_reserve", "mrblip_lora_rows", "mrblip_rmsnorm_lora_fwd", "mrblip_lora_rows_init", "mrblip_dec_proj",
 ]
 
 
@@ -287,6 +288,24 @@ def rmsnorm_lora_fwd(x, weight, eps, out_bf16, a, u, drop: Optional[Dropout] = N
     M, D = x.shape
     sp, site, p = _d(drop)
     _chk(_rms_lora(_p(x), _ld(x), _p(weight), M, D, eps, _p(out_bf16), _ld(out_bf16), _p(a), _ld(a), a.shape[0], _p(u), _ld(u), sp, site, p, _stream()))
+
+
+def dec_proj(xin, w, a, bt, u, out, K, *, x32=None, gamma=None, eps=0.0, N=None, residual=None, out2=None, gated=False,
+             in_drop: Optional[Dropout] = None, out_drop: Optional[Dropout] = None, ext_drop: Optional[Dropout] = None):
+    """One launch for an adapted projection of <= 16 decoder rows (csrc/decproj.hip): u = dropout_in(xin) a^T (saved), out = xin w^T +
+    [mask_ext (.)] u bt^T with the epilogue the output asks for (bf16 | fp32 residual + dropout_out | gated with out2 = pre-activations).
+    x32 / gamma / eps: the input is RMSNorm(x32) * gamma, saved to ``xin``.  N: output columns (default w.shape[0], gated: half of it)."""
+    R = xin.shape[0] if x32 is None else x32.shape[0]
+    if N is None:
+        N = w.shape[0] // 2 if gated else w.shape[0]
+    mode = 2 if gated else (1 if out.dtype == torch.float32 else 0)
+    seeds = [d for d in (in_drop, out_drop, ext_drop) if d is not None and d.p > 0.0]
+    sp = seeds[0].seed.data_ptr() if seeds else None
+    s_in, p_in = (in_drop.site, in_drop.p) if in_drop is not None else (0, 0.0)
+    s_out, p_out = (out_drop.site, out_drop.p) if out_drop is not None else (0, 0.0)
+    s_ext, p_ext = (ext_drop.site, ext_drop.p) if ext_drop is not None else (0, 0.0)
+    _chk(_dec_proj(_p(x32), _ld(x32), _p(gamma), eps, _p(xin), _ld(xin), _p(w), _ld(w), _p(a), _ld(a), a.shape[0], _p(bt), _ld(bt), _p(u), _ld(u),
+                   R, N, K, mode, _p(out), _ld(out), _p(residual), _ld(residual), _p(out2), _ld(out2), sp, s_in, p_in, s_out, p_out, s_ext, p_ext, _stream()))
 
 
 def lora_dx(dy, wt, g, acatt, dx, K, residual=None, drop: Optional[Dropout] = None, tile_cfg=0, k_splits: int = 0):

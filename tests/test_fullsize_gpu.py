@@ -194,11 +194,14 @@ def test_c3_batch4_step_equals_four_accumulated_single_clip_steps(xl):
     # = four clips): u then differs in its last bf16 bit (1e-4 relative), which this ill-conditioned random-weight XL model (T5 attention is
     # unscaled: score std ~6.5 at d_model 2048 with N(0, 0.02) weights, see make_golden_c2.py) amplifies to 9e-3 in the loss through 48
     # layers.  Pin the choice for this test; test_lora_rows_kernel checks the two kernels against each other.
-    # The same holds for the attention forward: one clip (2016 query tiles) takes the key-split 8-wave form, four clips do not.
+    # The same holds for the attention forward (one clip, 2016 query tiles, takes the key-split 8-wave form, four clips do not) and for
+    # the decoder's projections (one clip's <= 16 label rows take the fused one-launch kernel of csrc/decproj.hip).
     import os
     rows_max = eng.lora_rows_max_m
     eng.lora_rows_max_m = 256
     os.environ["MRB_ATTN_KS2"] = "0"
+    dec_proj = eng.dec_proj_enabled
+    eng.dec_proj_enabled = False   # (the fused decoder projection serves <= 16 rows: one clip's labels, not four clips')
     samples, lay4 = _layout(xl, 4, 60, 150.0)
     # four different clips (same prompt, hence the same layout / label length per clip)
     video = samples["video"]
@@ -218,6 +221,7 @@ def test_c3_batch4_step_equals_four_accumulated_single_clip_steps(xl):
     check("c3.grad-norm B=4 vs accumulated (rel)", abs(g4.norm().item() - g1.norm().item()) / g1.norm().item(), 1e-5)
     assert len(set(round(x, 3) for x in ls)) > 1  # the clips really differ
     eng.lora_rows_max_m = rows_max
+    eng.dec_proj_enabled = dec_proj
     del os.environ["MRB_ATTN_KS2"]
 
 

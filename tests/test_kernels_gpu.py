@@ -815,3 +815,110 @@ def test_rmsnorm_bwd_with_fused_operand_cast(ops, D, p):
     assert torch.equal(dx, dx_ref) and torch.equal(got, want)
     if p > 0:
         assert 0.85 < (got != 0).float().mean().item() < 0.95
+
+
+# ---- fused decoder projection (csrc/decproj.hip) against the two-launch paths it replaces ------------------------------------------------
+def _dp_operands(R, N, K, Rk, gated=False, seed=41):
+    torch.manual_seed(seed)
+    rows = 2 * N if gated else N
+    w = bf(torch.randn(rows, K + 64, device=dev()) * 0.03)[:, :K]
+    acat = bf(torch.randn(Rk, K, device=dev()) * 0.05)
+    wext = torch.zeros(rows, 64, dtype=torch.bfloat16, device=dev())
+    wext[:, :Rk] = bf(torch.randn(rows, Rk, device=dev()) * 0.05)
+    return w, acat, wext
+
+
+@pytest.mark.parametrize("R,N,K,Rk", [(8, 2048, 2048, 8), (14, 2048, 5120, 8), (16, 2048, 2048, 16), (3, 96, 64, 24)])
+def test_dec_proj_plain_input_residual_out(ops, R, N, K, Rk):
+    """o / co / wo of a decoder layer: out = residual + dropout(x W^T + u B^T), u = dropout_lora(x) A^T — one launch vs lora_rows + gemm"""
+    from util import check
+    w, acat, wext = _dp_operands(R, N, K, Rk)
+    x = bf(torch.randn(R, K, device=dev()))
+    res = torch.randn(R, N, device=dev())
+    seed = torch.tensor([99], dtype=torch.int32, device=dev())
+    for ldrop, odrop in ((None, None), (ops.Dropout(seed, 4, 0.05), ops.Dropout(seed, 8, 0.1))):
+        u0 = torch.zeros(R, 64, dtype=torch.bfloat16, device=dev())
+        ref = torch.empty(R, N, device=dev())
+        ops.lora_rows(x, acat, u0, K, drop=ldrop)
+        ops.gemm(x, w, ref, aext=u0, wext=wext, residual=res, drop=odrop)
+        u1 = torch.zeros_like(u0)
+        out = torch.full((R, N), 7.0, device=dev())
+        ops.dec_proj(x, w, acat, wext, u1, out, K, residual=res, in_drop=ldrop, out_drop=odrop)
+        tag = "dec_proj R=%d N=%d K=%d Rk=%d %s: " % (R, N, K, Rk, "drop" if ldrop else "plain")
+        check(tag + "u vs lora_rows", rel(u1.float(), u0.float()), 4e-3)
+        assert u1[:, Rk:].abs().sum() == 0
+        check(tag + "out vs lora_rows + gemm", rel(out, ref), 2e-3)
+        if odrop is not None:   # the same output mask: dropped elements are exactly the residual
+            assert torch.equal((out == res), (ref == res))
+
+
+@pytest.mark.parametrize("R,N,Rk", [(8, 6144, 24), (14, 2048, 8), (16, 2048, 8)])
+def test_dec_proj_fused_rmsnorm_bf16_out(ops, R, N, Rk):
+    """q/k/v and the cross-attention q: RMSNorm -> (saved) bf16 rows -> projection, one launch vs rmsnorm_lora_fwd + gemm"""
+    from util import check
+    K = 2048
+    w, acat, wext = _dp_operands(R, N, K, Rk, seed=43)
+    x32 = torch.randn(R, K, device=dev()) * 1.7
+    gamma = torch.randn(K, device=dev()) * 0.1 + 1
+    seed = torch.tensor([5], dtype=torch.int32, device=dev())
+    for ldrop in (None, ops.Dropout(seed, 3, 0.05)):
+        xn0 = torch.zeros(R, K, dtype=torch.bfloat16, device=dev())
+        u0 = torch.zeros(R, 64, dtype=torch.bfloat16, device=dev())
+        ref = torch.empty(R, N, dtype=torch.bfloat16, device=dev())
+        ops.rmsnorm_lora_fwd(x32, gamma, 1e-6, xn0, acat, u0, drop=ldrop)
+        ops.gemm(xn0, w, ref, aext=u0, wext=wext)
+        xn1, u1, out = torch.zeros_like(xn0), torch.zeros_like(u0), torch.zeros_like(ref)
+        ops.dec_proj(xn1, w, acat, wext, u1, out, K, x32=x32, gamma=gamma, eps=1e-6, in_drop=ldrop)
+        tag = "dec_proj norm R=%d N=%d Rk=%d %s: " % (R, N, Rk, "drop" if ldrop else "plain")
+        check(tag + "xn vs rmsnorm_lora_fwd", rel(xn1.float(), xn0.float()), 1e-3)
+        check(tag + "u", rel(u1.float(), u0.float()), 6e-3)
+        check(tag + "out", rel(out.float(), ref.float()), 4e-3)
+
+
+@pytest.mark.parametrize("R", [8, 14])
+def test_dec_proj_fused_rmsnorm_gated(ops, R):
+    """wi_0 / wi_1: y = dropout(gelu(h0) * h1), out2 = [h0 | h1] — one launch vs rmsnorm_lora_fwd + the gated tile GEMM"""
+    from util import check
+    K, Nh, Rk = 2048, 5120, 16
+    w, acat, wext = _dp_operands(R, Nh, K, Rk, gated=True, seed=47)
+    x32 = torch.randn(R, K, device=dev())
+    gamma = torch.randn(K, device=dev()) * 0.1 + 1
+    seed = torch.tensor([17], dtype=torch.int32, device=dev())
+    for ldrop, odrop in ((None, None), (ops.Dropout(seed, 3, 0.05), ops.Dropout(seed, 6, 0.1))):
+        xn0 = torch.zeros(R, K, dtype=torch.bfloat16, device=dev())
+        u0 = torch.zeros(R, 64, dtype=torch.bfloat16, device=dev())
+        y0 = torch.zeros(R, Nh, dtype=torch.bfloat16, device=dev())
+        h0 = torch.zeros(R, 2 * Nh, dtype=torch.bfloat16, device=dev())
+        ops.rmsnorm_lora_fwd(x32, gamma, 1e-6, xn0, acat, u0, drop=ldrop)
+        ops.gemm(xn0, w, y0, aext=u0, wext=wext, out2=h0, gated=True, drop=odrop, tile_cfg=2)
+        xn1, u1, y1, h1 = torch.zeros_like(xn0), torch.zeros_like(u0), torch.zeros_like(y0), torch.zeros_like(h0)
+        ops.dec_proj(xn1, w, acat, wext, u1, y1, K, x32=x32, gamma=gamma, eps=1e-6, out2=h1, gated=True, in_drop=ldrop, out_drop=odrop)
+        tag = "dec_proj gated R=%d %s: " % (R, "drop" if ldrop else "plain")
+        check(tag + "pre-activations [h0 | h1]", rel(h1.float(), h0.float()), 4e-3)
+        check(tag + "y", rel(y1.float(), y0.float()), 6e-3)
+        if odrop is not None:
+            assert torch.equal(y1 == 0, y0 == 0) or ((y1 == 0) != (y0 == 0)).sum() <= 2   # same mask (up to a value that rounds to 0)
+
+
+@pytest.mark.parametrize("R,N,K,Rk,f32out", [(8, 2048, 6144, 24, True), (14, 2048, 10240, 16, True), (16, 5120, 2048, 8, False), (8, 2048, 2048, 8, False)])
+def test_dec_proj_backward_form(ops, R, N, K, Rk, f32out):
+    """the input gradient of an adapted decoder projection: g = dy (sB), dx = dy W + mask_lora (.) (g (sA)) [+ residual] vs lora_rows + lora_dx"""
+    from util import check
+    torch.manual_seed(53)
+    dy = bf(torch.randn(R, K, device=dev()))
+    wt = bf(torch.randn(N, K, device=dev()) * 0.03)
+    bblk = bf(torch.randn(Rk, K, device=dev()) * 0.05)
+    acatt = torch.zeros(N, 64, dtype=torch.bfloat16, device=dev())
+    acatt[:, :Rk] = bf(torch.randn(N, Rk, device=dev()) * 0.05)
+    res = torch.randn(R, N, device=dev()) if f32out else None
+    seed = torch.tensor([23], dtype=torch.int32, device=dev())
+    for ldrop in (None, ops.Dropout(seed, 4, 0.05)):
+        g0 = torch.zeros(R, 64, dtype=torch.bfloat16, device=dev())
+        dx0 = torch.empty(R, N, dtype=torch.float32 if f32out else torch.bfloat16, device=dev())
+        ops.lora_rows(dy, bblk, g0, K)
+        ops.lora_dx(dy, wt, g0, acatt, dx0, K, residual=res, drop=ldrop)
+        g1, dx1 = torch.zeros_like(g0), torch.zeros_like(dx0)
+        ops.dec_proj(dy, wt, bblk, acatt, g1, dx1, K, residual=res, ext_drop=ldrop)
+        tag = "dec_proj bwd R=%d N=%d K=%d Rk=%d %s: " % (R, N, K, Rk, "mask" if ldrop else "plain")
+        check(tag + "g vs lora_rows", rel(g1.float(), g0.float()), 4e-3)
+        check(tag + "dx vs lora_rows + lora_dx", rel(dx1.float(), dx0.float()), 4e-3 if not f32out else 2e-3)

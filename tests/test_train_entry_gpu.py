@@ -118,20 +118,27 @@ def test_incremental_decode_matches_prefix_rerun():
     enc = eng.t5_encoder_forward(inp, B, S, L["mask"])
     cross = eng.t5_cross_kv(enc, B, S)
     R, steps = B * K, 7
-    g = torch.Generator().manual_seed(5)
-    state = eng.t5_decode_begin(R, steps + 1)
-    seqs = torch.zeros(R, 1, dtype=torch.long)
-    parents, worst = None, 0.0
-    for t in range(steps):
-        inc = eng.t5_decode_step(state, seqs[:, -1], parents, cross, B, L["mask"]).float().clone()
-        _, full = eng.t5_decoder_forward(seqs, torch.ones(R, t + 1, dtype=torch.int32), enc, R, S, L["mask"], labels=None, cross_cache=cross, cross_batch=B)
-        ref = full.view(R, t + 1, -1)[:, -1].float()
-        worst = max(worst, ((inc - ref).norm() / ref.norm()).item())
-        assert (inc.argmax(-1) == ref.argmax(-1)).all()
-        # next step: every sequence extends a random beam of ITS clip with a random token (what the search does through `parents`)
-        parents = torch.cat([b * K + torch.randint(0, K, (K,), generator=g) for b in range(B)])
-        seqs = torch.cat([seqs[parents], torch.randint(2, eng.cfg.vocab, (R, 1), generator=g)], 1)
-    check("generate.incremental_vs_prefix_logits", worst, 1e-6)   # measured: bit-identical (same kernels, same operands)
+    # Two passes.  (i) both sides on the SAME kernels (the fused one-launch decoder projection serves <= 16 rows: the 6 rows of a decode
+    # step but not the 6 x (t + 1) rows of the prefix re-run — switched off here): bit-identical logits.  (ii) the product setting: the
+    # step takes the fused kernel, the re-run the two-launch path — equal up to the fp32 summation order of bf16 products.
+    for fused, name, tol in ((False, "generate.incremental_vs_prefix_logits", 1e-6), (True, "generate.incremental (fused projections) vs prefix re-run", 5e-3)):
+        eng.dec_proj_enabled = fused
+        g = torch.Generator().manual_seed(5)
+        state = eng.t5_decode_begin(R, steps + 1)
+        seqs = torch.zeros(R, 1, dtype=torch.long)
+        parents, worst = None, 0.0
+        for t in range(steps):
+            inc = eng.t5_decode_step(state, seqs[:, -1], parents, cross, B, L["mask"]).float().clone()
+            _, full = eng.t5_decoder_forward(seqs, torch.ones(R, t + 1, dtype=torch.int32), enc, R, S, L["mask"], labels=None, cross_cache=cross, cross_batch=B)
+            ref = full.view(R, t + 1, -1)[:, -1].float()
+            worst = max(worst, ((inc - ref).norm() / ref.norm()).item())
+            if not fused:
+                assert (inc.argmax(-1) == ref.argmax(-1)).all()
+            # next step: every sequence extends a random beam of ITS clip with a random token (what the search does through `parents`)
+            parents = torch.cat([b * K + torch.randint(0, K, (K,), generator=g) for b in range(B)])
+            seqs = torch.cat([seqs[parents], torch.randint(2, eng.cfg.vocab, (R, 1), generator=g)], 1)
+        check(name, worst, tol)   # (i) measured: bit-identical (same kernels, same operands)
+    eng.dec_proj_enabled = type(eng).dec_proj_enabled
 
 
 def test_bench_two_ranks_share_one_gpu():

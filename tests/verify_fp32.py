@@ -75,7 +75,9 @@ class Fp32Verify(contextlib.AbstractContextManager):
         eng.ws, eng._store = {}, {}
         S["buf"] = eng.buf
         S["fuse"], S["rows_max"] = eng.fuse_norm_lora, eng.lora_rows_max_m
+        S["dec_proj"] = eng.dec_proj_enabled
         eng.fuse_norm_lora = False
+        eng.dec_proj_enabled = False   # (the fused decoder projection is a bf16-operand kernel: the fp32-operand stand-ins below replace the two-launch ops)
 
         def buf(name, shape, dtype, zero=True):
             shape = tuple(int(s) for s in shape)
@@ -112,6 +114,7 @@ class Fp32Verify(contextlib.AbstractContextManager):
         eng.buf = S["buf"]
         eng.ws, eng._store = S["ws"], S["store"]
         eng.fuse_norm_lora, eng.lora_rows_max_m = S["fuse"], S["rows_max"]
+        eng.dec_proj_enabled = S["dec_proj"]
         for obj, key, val in self._weight_restore:
             obj[key] = val
         eng.proj_wb = self._proj_wb
