@@ -52,36 +52,6 @@ __global__ __launch_bounds__(512) void dec_proj_kernel(const DecProjArgs p) {
   const uint32_t* sp = in_drop ? p.in_drop.seed_ptr : out_drop ? p.out_drop.seed_ptr : p.ext_drop.seed_ptr;
   const uint32_t seed = sp ? mrb_seed_load(sp) : 0u;
 
-  if (NORM) {   // rows 2 w, 2 w + 1: RMSNorm -> bf16 rows in LDS (the arithmetic of norm_fwd_kernel<true>: v * rstd * gamma, one rounding)
-    const int nv = p.K >> 2;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int r = 2 * w + i;
-      float4 v[8];
-      float q = 0.f;
-      const float4* xr = reinterpret_cast<const float4*>(p.x32 + (long long)(r < p.R ? r : 0) * p.ldx32);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int c = lane + 64 * j, cc = c < nv ? c : 0;
-        v[j] = xr[cc];
-        if (c >= nv || r >= p.R) v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        q += v[j].x * v[j].x + v[j].y * v[j].y + v[j].z * v[j].z + v[j].w * v[j].w;
-      }
-      const float rstd = rsqrtf(wave_sum(q) / (float)p.K + p.eps);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int c = lane + 64 * j;
-        if (c < nv) {
-          const float4 g = reinterpret_cast<const float4*>(p.gamma)[c];
-          const uint2 o = make_uint2(pack2bf(v[j].x * rstd * g.x, v[j].y * rstd * g.y), pack2bf(v[j].z * rstd * g.z, v[j].w * rstd * g.w));
-          *reinterpret_cast<uint2*>(xs + r * RS + c * 8) = o;
-          if (blockIdx.x == 0 && r < p.R) *reinterpret_cast<uint2*>(p.xin + (long long)r * p.ldxin + c * 4) = o;
-        }
-      }
-    }
-    __syncthreads();
-  }
-
   // ---- main loop: this wave's k-steps of 32
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.W), 0, (int)((((long long)(MODE == 2 ? 2 : 1) * p.N - 1) * p.ldw + p.K) * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.A), 0, (int)((((long long)p.Rk - 1) * p.lda + p.K) * 2), 0x00020000);
@@ -147,6 +117,55 @@ __global__ __launch_bounds__(512) void dec_proj_kernel(const DecProjArgs p) {
     }
   };
   fetch(0, ks0);
+  if (NORM) {   // rows 2 w, 2 w + 1: RMSNorm -> bf16 rows in LDS (the arithmetic of norm_fwd_kernel<true>: v * rstd * gamma, one rounding);
+                // both rows' loads are in flight together, beside the first batch of weight fragments requested above
+    const int nv = p.K >> 2;
+    float4 v[2][8];
+    float q[2] = {0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = 2 * w + i;
+      const float4* xr = reinterpret_cast<const float4*>(p.x32 + (long long)(r < p.R ? r : 0) * p.ldx32);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int c = lane + 64 * j, cc = c < nv ? c : 0;
+        v[i][j] = xr[cc];
+      }
+    }
+    float4 gq[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = lane + 64 * j;
+      gq[j] = reinterpret_cast<const float4*>(p.gamma)[c < nv ? c : 0];
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = 2 * w + i;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int c = lane + 64 * j;
+        if (c >= nv || r >= p.R) v[i][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        q[i] += v[i][j].x * v[i][j].x + v[i][j].y * v[i][j].y + v[i][j].z * v[i][j].z + v[i][j].w * v[i][j].w;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = 2 * w + i;
+      const float rstd = rsqrtf(wave_sum(q[i]) / (float)p.K + p.eps);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int c = lane + 64 * j;
+        if (c < nv) {
+          const float4 g = gq[j];
+          const uint2 o = make_uint2(pack2bf(v[i][j].x * rstd * g.x, v[i][j].y * rstd * g.y), pack2bf(v[i][j].z * rstd * g.z, v[i][j].w * rstd * g.w));
+          *reinterpret_cast<uint2*>(xs + r * RS + c * 8) = o;
+          if (blockIdx.x == 0 && r < p.R) *reinterpret_cast<uint2*>(p.xin + (long long)r * p.ldxin + c * 4) = o;
+        }
+      }
+    }
+    __syncthreads();
+  }
+
 #pragma unroll 1
   for (int ks = ks0; ks < ks1; ks += 2 * UB) {
     fetch(1, ks + UB);

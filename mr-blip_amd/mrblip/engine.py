@@ -1226,22 +1226,30 @@ class MrBlipEngine:
         rl, rs = ops.rup32(Ld), ops.rup32(S)
         kt_s, qt_s, dot_s = (self.buf(n, (B, H, ops.rup32(dk), rl), bf16) for n in ("db_kt_s", "db_qt_s", "db_dot_s"))
         delta = self.buf("db_delta", (B, H, rl), f32)
+        dyb0_ready = False
+        dyb0_pair = (dybs[0], self.buf("db_dyb0b", (R, pad64(d)), bf16))
         for i in reversed(range(len(self.t5["dec"]))):
             L = self.t5["dec"][i]
             # side stream (see the encoder backward): the LoRA weight-gradient launches of this layer, and the WHOLE backward of the
             # cross-attention K/V projection (it only feeds denc, which nobody reads before the encoder backward; per-layer dckv / g
             # buffers, the accumulation into denc stays in order on that stream).  One join per layer for the buffers written once per layer.
             self.side_join()
-            dyb = dybs[0]
-            ops.cast_dropout(dx, out_bf16=dyb, drop=self.drop(L["sites"][5], p))
+            dyb = dyb0_pair[i & 1]
+            if not dyb0_ready:   # (top layer: dx comes from the final norm's backward; below, the previous layer's last RMSNorm backward wrote it)
+                ops.cast_dropout(dx, out_bf16=dyb, drop=self.drop(L["sites"][5], p))
             self.lg_bwd(L["wo"], dyb, self.ws[f"d{i}_y"], self.ws[f"d{i}_u_wo"], gbs[0], dyact, side=dside, flush=False)
             ops.gated_gelu_bwd(dyact, self.ws[f"d{i}_h"], dh, drop=self.drop(L["sites"][4], p))
             self.lg_bwd(L["wi"], dh, self.ws[f"d{i}_xn2"], self.ws[f"d{i}_u_wi"], gbs[1], dxn, side=dside)
-            ops.rmsnorm_bwd(dxn, self.ws[f"d{i}_x2"], L["ln2"], c.t5_eps, other, dx_add=dx)
+            # (the bf16 operand of the next sub-layer = dropout-backward(dx) is written by the RMSNorm backward that produces dx, as in the
+            # encoder backward: one launch fewer per sub-layer)
+            dyb = dybs[1]
+            if self.fuse_bwd_cast:
+                ops.rmsnorm_bwd(dxn, self.ws[f"d{i}_x2"], L["ln2"], c.t5_eps, other, dx_add=dx, out_bf16=dyb, out_drop=self.drop(L["sites"][3], p))
+            else:
+                ops.rmsnorm_bwd(dxn, self.ws[f"d{i}_x2"], L["ln2"], c.t5_eps, other, dx_add=dx)
+                ops.cast_dropout(other, out_bf16=dyb, drop=self.drop(L["sites"][3], p))
             dx, other = other, dx
             # cross attention
-            dyb = dybs[1]
-            ops.cast_dropout(dx, out_bf16=dyb, drop=self.drop(L["sites"][3], p))
             self.lg_bwd(L["co"], dyb, self.ws[f"d{i}_co"], self.ws[f"d{i}_u_co"], gbs[2], do, side=dside, flush=False)
             dckv = self.buf(f"db_dckv{i}", (Me, 2 * inner), bf16, zero=False)
             cq, ckv, co = self.ws[f"d{i}_cq"], self.ws[f"d{i}_ckv"], self.ws[f"d{i}_co"]
@@ -1260,11 +1268,14 @@ class MrBlipEngine:
             else:
                 self.lg_bwd(L["ckv"], dckv, enc, self.ws[f"d{i}_u_ckv"], self.buf(f"db_ge{i}", (Me, 64), bf16), denc, residual=denc)
             self.lg_bwd(L["cq"], dcq, self.ws[f"d{i}_xn1"], self.ws[f"d{i}_u_cq"], gbs[3], dxn, side=dside)
-            ops.rmsnorm_bwd(dxn, self.ws[f"d{i}_x1"], L["ln1"], c.t5_eps, other, dx_add=dx)
+            dyb = dybs[2]
+            if self.fuse_bwd_cast:
+                ops.rmsnorm_bwd(dxn, self.ws[f"d{i}_x1"], L["ln1"], c.t5_eps, other, dx_add=dx, out_bf16=dyb, out_drop=self.drop(L["sites"][1], p))
+            else:
+                ops.rmsnorm_bwd(dxn, self.ws[f"d{i}_x1"], L["ln1"], c.t5_eps, other, dx_add=dx)
+                ops.cast_dropout(other, out_bf16=dyb, drop=self.drop(L["sites"][1], p))
             dx, other = other, dx
             # self attention
-            dyb = dybs[2]
-            ops.cast_dropout(dx, out_bf16=dyb, drop=self.drop(L["sites"][1], p))
             self.lg_bwd(L["o"], dyb, self.ws[f"d{i}_o"], self.ws[f"d{i}_u_o"], gbs[4], do, side=dside, flush=False)
             qkv, o = self.ws[f"d{i}_qkv"], self.ws[f"d{i}_o"]
             q4, k4, v4 = self.v4(qkv, B, Ld, H, dk, 0), self.v4(qkv, B, Ld, H, dk, inner), self.v4(qkv, B, Ld, H, dk, 2 * inner)
@@ -1276,7 +1287,14 @@ class MrBlipEngine:
                               self.v4(dqkv, B, Ld, H, dk, 0), self.v4(dqkv, B, Ld, H, dk, inner), self.v4(dqkv, B, Ld, H, dk, 2 * inner),
                               scale=1.0, bias_lut=self.lut_dec, kmask=dmask, causal=True, drop=self.drop(L["sites"][0], p))
             self.lg_bwd(L["qkv"], dqkv, self.ws[f"d{i}_xn"], self.ws[f"d{i}_u_qkv"], gbs[5], dxn, side=dside)
-            ops.rmsnorm_bwd(dxn, self.ws[f"d{i}_xin"], L["ln0"], c.t5_eps, other, dx_add=dx)
+            if i > 0 and self.fuse_bwd_cast:   # ... and the layer below's first operand (its own buffer by layer parity: this layer's wo
+                # group may still be reading dyb0_pair[i & 1] on the side stream)
+                ops.rmsnorm_bwd(dxn, self.ws[f"d{i}_xin"], L["ln0"], c.t5_eps, other, dx_add=dx, out_bf16=dyb0_pair[(i - 1) & 1],
+                                out_drop=self.drop(self.t5["dec"][i - 1]["sites"][5], p))
+                dyb0_ready = True
+            else:
+                ops.rmsnorm_bwd(dxn, self.ws[f"d{i}_xin"], L["ln0"], c.t5_eps, other, dx_add=dx)
+                dyb0_ready = False
             dx, other = other, dx
         # the decoder embeddings are frozen: nothing flows below dx
         self.side_join()  # denc (and the decoder adapters' gradients) are complete

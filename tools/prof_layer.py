@@ -49,10 +49,10 @@ def main(db, layer=12, back=2):
 
     window(lambda n: "attn_fwd_lds_kernel<64" in n, "T5 encoder forward")
     window(lambda n: "attn_bwd_dkv_lds" in n, "T5 encoder backward")
-    # decoder layers: forward = between consecutive fused RMSNorm + LoRA-down launches of the q/k/v group (R = 24) on the few decoder
-    # rows (grid 512 = 2 blocks); backward = between consecutive g products of the q/k/v group (lora_rows<3, 1>, grid 512)
-    window(lambda n: "rmsnorm_lora_kernel<3>" in n, "T5 decoder forward", small_only=True)
-    window(lambda n: "lora_rows_kernel<3, 1>" in n, "T5 decoder backward", small_only=True)
+    # decoder layers: forward = between consecutive causal self-attention launches (attn_fwd_kernel<64, 13>: LUT | CAUSAL | DROP), backward
+    # = between consecutive causal self-attention dK/dV launches
+    window(lambda n: "attn_fwd_kernel<64, 13>" in n, "T5 decoder forward")
+    window(lambda n: "attn_bwd_dkv_kernel<64, 13>" in n, "T5 decoder backward")
 
 
 if __name__ == "__main__":
