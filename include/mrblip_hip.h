@@ -171,7 +171,11 @@ int mrblip_rmsnorm_lora_fwd(const float* x, long long ldx, const float* weight, 
 int mrblip_dec_proj(const float* x32, long long ldx32, const float* gamma, float eps, void* xin, long long ldxin, const void* W, long long ldw,
                     const void* A, long long lda, int Rk, const void* Bt, long long ldbt, void* U, long long ldu, int R, int N, int K, int mode,
                     void* out, long long ldo, const float* residual, long long ldr, void* out2, long long ldo2, const uint32_t* seed_ptr,
-                    uint32_t in_site, float in_p, uint32_t out_site, float out_p, uint32_t ext_site, float ext_p, mrblip_stream_t stream);
+                    uint32_t in_site, float in_p, uint32_t out_site, float out_p, uint32_t ext_site, float ext_p,
+                    /* mode 0, optional: head-transposed copies (mrblip_head_transpose layout [B, H, 64, t_spad]) of up to three consecutive column
+                     * ranges of width t_inner; rows are b * t_rows + s */
+                    void* tout0, void* tout1, void* tout2, int t_inner, int t_rows, int t_spad, long long t_bs, long long t_hs,
+                    mrblip_stream_t stream);
 /* LoRA backward input gradient in one launch: dX[M,N] = dY[M,K] Wt[N,K]^T (+ residual) + mask(site,p) * (G[M,64] AcatT[N,64]^T);
  * N = in_features, K = out_features padded to 64, mask = the forward's lora_dropout keep mask scaled by 1/(1-p) */
 int mrblip_gemm_lora_dx(const void* dY, long long lddy, const void* Wt, long long ldwt, const void* G, long long ldg, const void* AcatT,

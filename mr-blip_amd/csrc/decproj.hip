@@ -31,6 +31,10 @@ struct DecProjArgs {
   int R, N, K;
   void* out; long long ldo; const float* residual; long long ldr; bf16_t* out2; long long ldo2;
   DropoutArg in_drop, out_drop, ext_drop;
+  // mode 0 only: head-transposed copies of up to three consecutive column ranges of width t_inner (q | k | v of a fused projection, or one
+  // range = the whole output): tout[j][b][h][d][s] = out[b * t_rows + s][j * t_inner + h * 64 + d] — what mrblip_head_transpose would
+  // write (zero padding of the destination is the caller's: the buffers are zero-initialised once and only valid entries are written)
+  bf16_t* tout[3]; int t_inner, t_rows, t_spad; long long t_bs, t_hs;
 };
 
 typedef uint32_t dp_u32x4 __attribute__((ext_vector_type(4)));
@@ -254,7 +258,18 @@ __global__ __launch_bounds__(512) void dec_proj_kernel(const DecProjArgs p) {
           }
           *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + (long long)r * p.ldo + n) = make_float4(y[0], y[1], y[2], y[3]);
         } else {
-          *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + (long long)r * p.ldo + n) = make_uint2(pack2bf(y[0], y[1]), pack2bf(y[2], y[3]));
+          const uint2 ob = make_uint2(pack2bf(y[0], y[1]), pack2bf(y[2], y[3]));
+          *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + (long long)r * p.ldo + n) = ob;
+          if (p.t_inner > 0) {   // block-uniform
+            const int which = n / p.t_inner;
+            bf16_t* td = which < 3 ? p.tout[which] : nullptr;
+            if (td) {
+              const int c = n - which * p.t_inner, hh = c >> 6, d0 = c & 63, bb = r / p.t_rows, ss = r - bb * p.t_rows;
+              bf16_t* q = td + bb * p.t_bs + hh * p.t_hs + (long long)d0 * p.t_spad + ss;
+              q[0] = (bf16_t)(ob.x & 0xffffu); q[p.t_spad] = (bf16_t)(ob.x >> 16);
+              q[2 * p.t_spad] = (bf16_t)(ob.y & 0xffffu); q[3 * p.t_spad] = (bf16_t)(ob.y >> 16);
+            }
+          }
         }
       }
     }
@@ -275,6 +290,7 @@ extern "C" int mrblip_dec_proj(const float* x32, long long ldx32, const float* g
                                long long ldw, const void* A, long long lda, int Rk, const void* Bt, long long ldbt, void* U, long long ldu, int R,
                                int N, int K, int mode, void* out, long long ldo, const float* residual, long long ldr, void* out2, long long ldo2,
                                const uint32_t* seed_ptr, uint32_t in_site, float in_p, uint32_t out_site, float out_p, uint32_t ext_site, float ext_p,
+                               void* tout0, void* tout1, void* tout2, int t_inner, int t_rows, int t_spad, long long t_bs, long long t_hs,
                                hipStream_t stream) {
   MRB_REQUIRE(R > 0 && R <= 16 && N > 0 && (N % 16) == 0 && K > 0 && (K % 32) == 0, "dec_proj: need R <= 16, N %% 16 == 0, K %% 32 == 0 (R=%d N=%d K=%d)", R, N, K);
   MRB_REQUIRE(Rk > 0 && Rk <= 32 && (Rk % 8) == 0 && ldu >= Rk && (ldu % 4) == 0, "dec_proj: bad LoRA rank rows (Rk=%d)", Rk);
@@ -289,6 +305,10 @@ extern "C" int mrblip_dec_proj(const float* x32, long long ldx32, const float* g
   a.x32 = x32; a.ldx32 = ldx32; a.gamma = gamma; a.eps = eps; a.xin = (bf16_t*)xin; a.ldxin = ldxin; a.W = (const bf16_t*)W; a.ldw = ldw;
   a.A = (const bf16_t*)A; a.lda = lda; a.Rk = Rk; a.Bt = (const bf16_t*)Bt; a.ldbt = ldbt; a.U = (bf16_t*)U; a.ldu = ldu; a.R = R; a.N = N; a.K = K;
   a.out = out; a.ldo = ldo; a.residual = residual; a.ldr = ldr; a.out2 = (bf16_t*)out2; a.ldo2 = ldo2;
+  const bool any_t = tout0 || tout1 || tout2;
+  MRB_REQUIRE(!any_t || (mode == 0 && t_inner > 0 && (t_inner % 64) == 0 && t_rows > 0 && t_spad >= t_rows), "dec_proj: head-transposed copies need mode 0 and a head layout");
+  a.tout[0] = (bf16_t*)tout0; a.tout[1] = (bf16_t*)tout1; a.tout[2] = (bf16_t*)tout2;
+  a.t_inner = any_t ? t_inner : 0; a.t_rows = t_rows; a.t_spad = t_spad; a.t_bs = t_bs; a.t_hs = t_hs;
   dp_drop(a.in_drop, seed_ptr, in_site, in_p);
   dp_drop(a.out_drop, seed_ptr, out_site, out_p);
   dp_drop(a.ext_drop, seed_ptr, ext_site, ext_p);

@@ -177,6 +177,8 @@ class MrBlipEngine:
             seed = int(torch.initial_seed()) & 0x7FFFFFFF
         self.cfg, self.dev = cfg, device
         self.ws: Dict[str, torch.Tensor] = {}
+        self.dec_t_saved: Dict[int, bool] = {}    # decoder layer -> Q^T / K^T of its self-attention were written by the forward's fused projection
+        self.dec_tc_saved: Dict[int, bool] = {}   # ... and the cross-attention's Q^T
         self._store: Dict[str, torch.Tensor] = {}
         self.ws_allocation_log: List[tuple] = []
         self.training = True
@@ -691,6 +693,7 @@ class MrBlipEngine:
     def lg_fwd(self, g: LoraGroup, x: torch.Tensor, u: torch.Tensor, out: torch.Tensor, u_ready: bool = False, **kw):
         """out = x W^T + u B^T with u = dropout(x) (scale*A)^T:  the rank-8 "down" product is the row kernel of csrc/lora.hip (or was
         already produced by the fused RMSNorm launch: u_ready), the "up" product rides in the main GEMM as a 64-wide K extension."""
+        tout, t_rows = kw.pop("tout", None), kw.pop("t_rows", 0)   # head-transposed copies: only the fused decoder kernel writes them (-> True)
         per_adapter = self.cfg.lora_mask_per_adapter and len(g.adapters) > 1 and self.training and self.cfg.lora_dropout > 0
         if per_adapter:   # peft-faithful: u_j = dropout_j(x) (s A_j)^T with adapter j's own mask (its own call-site id)
             assert not u_ready
@@ -700,9 +703,10 @@ class MrBlipEngine:
             return
         if not u_ready and self._dec_proj_ok(g, x.shape[0], kw):
             # <= 16 decoder rows: LoRA "down", main product, "up" product and epilogue in ONE launch (csrc/decproj.hip)
+            t_ok = tout is not None and out.dtype == bf16 and not kw.get("gated")
             ops.dec_proj(x, g.W, g.acat, g.wext, u, out, g.K, residual=kw.get("residual"), out2=kw.get("out2"), gated=bool(kw.get("gated")),
-                         in_drop=self.drop(g.site, self.cfg.lora_dropout), out_drop=kw.get("drop"))
-            return
+                         in_drop=self.drop(g.site, self.cfg.lora_dropout), out_drop=kw.get("drop"), tout=tout if t_ok else None, t_rows=t_rows)
+            return t_ok
         ks = self.k_splits_for(x.shape[0], g.N, g.K, out)
         if ks > 1 and not u_ready and kw.get("residual", None) is not None and not kw.get("gated") and kw.get("out2") is None:
             # 12-token decoder rows: a [M x 2048] output has 64 tiles of the skinny kernel; ks blocks per tile share K and add their
@@ -721,6 +725,7 @@ class MrBlipEngine:
     # Round 3: the adapted projections of the decoder's <= 16 rows as ONE launch each (forward: [RMSNorm +] LoRA down + GEMM + LoRA up +
     # epilogue; backward: g = dy B + the dX GEMM with its masked rank-8 term) instead of two.  MRB_DEC_PROJ=0 restores the two-launch path.
     dec_proj_enabled = os.environ.get("MRB_DEC_PROJ", "1") == "1"
+    dec_tout_enabled = os.environ.get("MRB_DEC_TOUT", "1") == "1"   # ... which also write the head-transposed copies the attention kernels read (0: head_transpose launches)
 
     def _dec_proj_ok(self, g: "LoraGroup", M: int, kw: dict) -> bool:
         if not self.dec_proj_enabled or M > 16 or g.acat is None or g.acat.shape[0] > 32:
@@ -764,11 +769,14 @@ class MrBlipEngine:
 
     def norm_lg_fwd(self, x: torch.Tensor, ln: torch.Tensor, g: LoraGroup, xn: torch.Tensor, u: torch.Tensor, out: torch.Tensor, **kw):
         """T5 RMSNorm + the LoRA "down" product of its output in ONE launch, then the main GEMM (q/k/v, wi_0/wi_1, EncDecAttention.q)"""
+        tout, t_rows = kw.pop("tout", None), kw.pop("t_rows", 0)
         per_adapter = self.cfg.lora_mask_per_adapter and len(g.adapters) > 1 and self.training and self.cfg.lora_dropout > 0
         if g.K <= 2048 and self._dec_proj_ok(g, x.shape[0], kw):   # <= 16 decoder rows: norm, LoRA and projection in one launch
+            t_ok = tout is not None and out.dtype == bf16 and not kw.get("gated")
             ops.dec_proj(xn, g.W, g.acat, g.wext, u, out, g.K, x32=x, gamma=ln, eps=self.cfg.t5_eps, residual=kw.get("residual"),
-                         out2=kw.get("out2"), gated=bool(kw.get("gated")), in_drop=self.drop(g.site, self.cfg.lora_dropout), out_drop=kw.get("drop"))
-            return
+                         out2=kw.get("out2"), gated=bool(kw.get("gated")), in_drop=self.drop(g.site, self.cfg.lora_dropout), out_drop=kw.get("drop"),
+                         tout=tout if t_ok else None, t_rows=t_rows)
+            return t_ok
         if self.fuse_norm_lora and x.shape[0] <= self.lora_rows_max_m and not per_adapter:
             ops.rmsnorm_lora_fwd(x, ln, self.cfg.t5_eps, xn, g.acat, u, drop=self.drop(g.site, self.cfg.lora_dropout))
             self.lg_fwd(g, xn, u, out, u_ready=True, **kw)
@@ -779,7 +787,7 @@ class MrBlipEngine:
     fuse_norm_lora = os.environ.get("MRB_FUSE_NORM_LORA", "1") == "1"
 
     def lg_bwd(self, g: LoraGroup, dy: torch.Tensor, x: torch.Tensor, u: torch.Tensor, gbuf: torch.Tensor, dx: Optional[torch.Tensor],
-               residual: Optional[torch.Tensor] = None, side: bool = False, tile_cfg: int = 0, flush: bool = True):
+               residual: Optional[torch.Tensor] = None, side: bool = False, tile_cfg: int = 0, flush: bool = True, tout=None, t_rows: int = 0):
         """dy bf16 [M,N]; x the saved bf16 input; u the saved [M,64] LoRA activations.  Accumulates dA, dB of every adapter of the
         group (one launch) and (optionally) dx = dy W (+ residual) + mask * (g A) (one GEMM: the rank-8 term is its K-extension).
         side=True: the weight-gradient launch goes to the gradient side stream and runs beside the dX GEMM (the caller guarantees
@@ -810,7 +818,8 @@ class MrBlipEngine:
         fused = dx is not None and g.N % 32 == 0 and self._dec_proj_ok(g, dy.shape[0], {}) and g.Wt.shape[0] % 16 == 0
         ks = self.k_splits_for(dy.shape[0], g.K, pad64(g.N), dx) if (dx is not None and not fused) else 1
         if fused:    # <= 16 decoder rows: g = dy B and dX = dy W + mask (.) (g A) [+ residual] in one launch
-            ops.dec_proj(dy, g.Wt, g.bblk, g.acatt, gbuf, dx, g.N, residual=residual, ext_drop=drop)
+            t_ok = tout is not None and dx.dtype == bf16
+            ops.dec_proj(dy, g.Wt, g.bblk, g.acatt, gbuf, dx, g.N, residual=residual, ext_drop=drop, tout=tout if t_ok else None, t_rows=t_rows)
         elif ks > 1:   # dX by the K-split skinny GEMM: this launch also pre-initialises dx (residual or zero)
             self.lora_thin(dy, g.bblk, gbuf, g.N, seg=seg, init_dst=dx, init_src=residual)
         else:
@@ -829,6 +838,7 @@ class MrBlipEngine:
                 ops.lora_dx(dy, g.Wt, gbuf, g.acatt, dx, pad64(g.N), residual=None, drop=drop, k_splits=ks)
             else:
                 ops.lora_dx(dy, g.Wt, gbuf, g.acatt, dx, pad64(g.N), residual=residual, drop=drop, tile_cfg=tile_cfg)
+        return bool(fused and tout is not None and dx.dtype == bf16)   # True: the head-transposed copies of dx were written
 
     vit_rowv = os.environ.get("MRB_VIT_ROWV", "1") == "1"   # (0: the transposed-copy path, for A/B)
     fuse_bwd_cast = os.environ.get("MRB_FUSE_BWD_CAST", "1") == "1"
@@ -1072,9 +1082,17 @@ class MrBlipEngine:
             xn = self.buf(f"d{i}_xn", (R, pad64(d)), bf16)
             u = self.buf(f"d{i}_u_qkv", (R, 64), bf16)
             qkv = self.buf(f"d{i}_qkv", (R, 3 * inner), bf16, zero=False)
-            self.norm_lg_fwd(x, L["ln0"], L["qkv"], xn, u, qkv)
+            # (the fused decoder projection also writes V^T for this layer's attention and — training — Q^T / K^T / cross-Q^T for the backward:
+            # no head_transpose launches on the decoder chain)
+            keep_t = want_grad and labels is not None and dk == 64 and self.dec_tout_enabled
+            qt_i = self.buf(f"d{i}_qt_s", (B, H, 64, ops.rup32(Ld)), bf16) if keep_t else None
+            kt_i = self.buf(f"d{i}_kt_s", (B, H, 64, ops.rup32(Ld)), bf16) if keep_t else None
+            qtc_i = self.buf(f"d{i}_qt_c", (B, H, 64, ops.rup32(Ld)), bf16) if keep_t else None
+            t_done = self.norm_lg_fwd(x, L["ln0"], L["qkv"], xn, u, qkv, tout=(qt_i, kt_i, vt_s) if (dk == 64 and self.dec_tout_enabled) else None, t_rows=Ld)
             q4, k4, v4 = self.v4(qkv, B, Ld, H, dk, 0), self.v4(qkv, B, Ld, H, dk, inner), self.v4(qkv, B, Ld, H, dk, 2 * inner)
-            ops.head_transpose(v4, out=vt_s)
+            self.dec_t_saved[i] = bool(t_done and keep_t)
+            if not t_done:
+                ops.head_transpose(v4, out=vt_s)
             o = self.buf(f"d{i}_o", (R, pad64(inner)), bf16)
             lse = self.buf(f"d{i}_lse", (B, H, ops.rup32(Ld)), f32)
             ops.attention_fwd(q4, k4, vt_s, self.v4(o, B, Ld, H, dk), lse, scale=1.0, bias_lut=self.lut_dec, kmask=dmask, causal=True, drop=self.drop(L["sites"][0], p))
@@ -1085,7 +1103,8 @@ class MrBlipEngine:
             xn1 = self.buf(f"d{i}_xn1", (R, pad64(d)), bf16)
             ucq = self.buf(f"d{i}_u_cq", (R, 64), bf16)
             cq = self.buf(f"d{i}_cq", (R, inner), bf16, zero=False)
-            self.norm_lg_fwd(x1, L["ln1"], L["cq"], xn1, ucq, cq)
+            tc_done = self.norm_lg_fwd(x1, L["ln1"], L["cq"], xn1, ucq, cq, tout=(qtc_i,) if qtc_i is not None else None, t_rows=Ld)
+            self.dec_tc_saved[i] = bool(tc_done and keep_t)
             co = self.buf(f"d{i}_co", (R, pad64(inner)), bf16)
             if cross_cache is None:
                 ck4, vt_i, ready = ckv_side[i]
@@ -1250,16 +1269,22 @@ class MrBlipEngine:
                 ops.cast_dropout(other, out_bf16=dyb, drop=self.drop(L["sites"][3], p))
             dx, other = other, dx
             # cross attention
-            self.lg_bwd(L["co"], dyb, self.ws[f"d{i}_co"], self.ws[f"d{i}_u_co"], gbs[2], do, side=dside, flush=False)
+            dot_done = self.lg_bwd(L["co"], dyb, self.ws[f"d{i}_co"], self.ws[f"d{i}_u_co"], gbs[2], do, side=dside, flush=False,
+                                   tout=(dot_s,) if (dk == 64 and self.dec_tout_enabled) else None, t_rows=Ld)
             dckv = self.buf(f"db_dckv{i}", (Me, 2 * inner), bf16, zero=False)
             cq, ckv, co = self.ws[f"d{i}_cq"], self.ws[f"d{i}_ckv"], self.ws[f"d{i}_co"]
             q4, k4, v4 = self.v4(cq, B, Ld, H, dk), self.v4(ckv, B, S, H, dk, 0), self.v4(ckv, B, S, H, dk, inner)
             do4 = self.v4(do, B, Ld, H, dk)
             kt_c = self.ws[f"d{i}_kt_c"]  # made beside the forward (t5_decoder_forward)
-            ops.head_transpose(q4, out=qt_s)
-            ops.head_transpose(do4, out=dot_s)
+            qt_x = qt_s
+            if self.dec_tc_saved.get(i):
+                qt_x = self.ws[f"d{i}_qt_c"]     # written by the forward's fused projection
+            else:
+                ops.head_transpose(q4, out=qt_s)
+            if not dot_done:
+                ops.head_transpose(do4, out=dot_s)
             if not _EXP_SKIP_DEC_CROSS:
-                ops.attention_bwd(q4, k4, v4, self.v4(co, B, Ld, H, dk), do4, kt_c, qt_s, dot_s, self.ws[f"d{i}_lsec"], delta,
+                ops.attention_bwd(q4, k4, v4, self.v4(co, B, Ld, H, dk), do4, kt_c, qt_x, dot_s, self.ws[f"d{i}_lsec"], delta,
                                   self.v4(dcq, B, Ld, H, dk), self.v4(dckv, B, S, H, dk, 0), self.v4(dckv, B, S, H, dk, inner),
                                   scale=1.0, kmask=kmask, drop=self.drop(L["sites"][2], p))
             if dside:   # queued: goes out with the cq group's record
@@ -1276,14 +1301,20 @@ class MrBlipEngine:
                 ops.cast_dropout(other, out_bf16=dyb, drop=self.drop(L["sites"][1], p))
             dx, other = other, dx
             # self attention
-            self.lg_bwd(L["o"], dyb, self.ws[f"d{i}_o"], self.ws[f"d{i}_u_o"], gbs[4], do, side=dside, flush=False)
+            dot_done = self.lg_bwd(L["o"], dyb, self.ws[f"d{i}_o"], self.ws[f"d{i}_u_o"], gbs[4], do, side=dside, flush=False,
+                                   tout=(dot_s,) if (dk == 64 and self.dec_tout_enabled) else None, t_rows=Ld)
             qkv, o = self.ws[f"d{i}_qkv"], self.ws[f"d{i}_o"]
             q4, k4, v4 = self.v4(qkv, B, Ld, H, dk, 0), self.v4(qkv, B, Ld, H, dk, inner), self.v4(qkv, B, Ld, H, dk, 2 * inner)
             do4 = self.v4(do, B, Ld, H, dk)
-            ops.head_transpose(k4, out=kt_s)
-            ops.head_transpose(q4, out=qt_s)
-            ops.head_transpose(do4, out=dot_s)
-            ops.attention_bwd(q4, k4, v4, self.v4(o, B, Ld, H, dk), do4, kt_s, qt_s, dot_s, self.ws[f"d{i}_lse"], delta,
+            kt_x, qt_x = kt_s, qt_s
+            if self.dec_t_saved.get(i):
+                kt_x, qt_x = self.ws[f"d{i}_kt_s"], self.ws[f"d{i}_qt_s"]
+            else:
+                ops.head_transpose(k4, out=kt_s)
+                ops.head_transpose(q4, out=qt_s)
+            if not dot_done:
+                ops.head_transpose(do4, out=dot_s)
+            ops.attention_bwd(q4, k4, v4, self.v4(o, B, Ld, H, dk), do4, kt_x, qt_x, dot_s, self.ws[f"d{i}_lse"], delta,
                               self.v4(dqkv, B, Ld, H, dk, 0), self.v4(dqkv, B, Ld, H, dk, inner), self.v4(dqkv, B, Ld, H, dk, 2 * inner),
                               scale=1.0, bias_lut=self.lut_dec, kmask=dmask, causal=True, drop=self.drop(L["sites"][0], p))
             self.lg_bwd(L["qkv"], dqkv, self.ws[f"d{i}_xn"], self.ws[f"d{i}_u_qkv"], gbs[5], dxn, side=dside)

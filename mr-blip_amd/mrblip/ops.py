@@ -77,7 +77,8 @@ _lora_dx = _sig("mrblip_lora_dx_add", vp, ll, i32, vp, ll, vp, i32, i32, i32, vp
 _cu_reserve = _sig("mrblip_gemm_set_cu_reserve", i32)
 _lora_rows = _sig("mrblip_lora_rows", vp, ll, vp, ll, i32, i32, i32, vp, ll, vp, vp, u32, f32, vp)
 _lora_rows_init = _sig("mrblip_lora_rows_init", vp, ll, vp, ll, i32, i32, i32, vp, ll, vp, vp, u32, f32, vp, ll, vp, ll, i32, vp)
-_dec_proj = _sig("mrblip_dec_proj", vp, ll, vp, f32, vp, ll, vp, ll, vp, ll, i32, vp, ll, vp, ll, i32, i32, i32, i32, vp, ll, vp, ll, vp, ll, vp, u32, f32, u32, f32, u32, f32, vp)
+_dec_proj = _sig("mrblip_dec_proj", vp, ll, vp, f32, vp, ll, vp, ll, vp, ll, i32, vp, ll, vp, ll, i32, i32, i32, i32, vp, ll, vp, ll, vp, ll, vp, u32, f32, u32, f32, u32, f32,
+                 vp, vp, vp, i32, i32, i32, ll, ll, vp)
 _rms_lora = _sig("mrblip_rmsnorm_lora_fwd", vp, ll, vp, i32, i32, f32, vp, ll, vp, ll, i32, vp, ll, vp, u32, f32, vp)
 
 EXPORTS = [
@@ -291,10 +292,12 @@ def rmsnorm_lora_fwd(x, weight, eps, out_bf16, a, u, drop: Optional[Dropout] = N
 
 
 def dec_proj(xin, w, a, bt, u, out, K, *, x32=None, gamma=None, eps=0.0, N=None, residual=None, out2=None, gated=False,
-             in_drop: Optional[Dropout] = None, out_drop: Optional[Dropout] = None, ext_drop: Optional[Dropout] = None):
+             in_drop: Optional[Dropout] = None, out_drop: Optional[Dropout] = None, ext_drop: Optional[Dropout] = None, tout=None, t_rows: int = 0):
     """One launch for an adapted projection of <= 16 decoder rows (csrc/decproj.hip): u = dropout_in(xin) a^T (saved), out = xin w^T +
     [mask_ext (.)] u bt^T with the epilogue the output asks for (bf16 | fp32 residual + dropout_out | gated with out2 = pre-activations).
-    x32 / gamma / eps: the input is RMSNorm(x32) * gamma, saved to ``xin``.  N: output columns (default w.shape[0], gated: half of it)."""
+    x32 / gamma / eps: the input is RMSNorm(x32) * gamma, saved to ``xin``.  N: output columns (default w.shape[0], gated: half of it).
+    tout (bf16 output only): up to three [B, H, 64, Spad] tensors (None to skip one) receiving the head-transposed copies of the output's
+    consecutive column ranges of width H * 64 (what head_transpose would write), rows being b * t_rows + s."""
     R = xin.shape[0] if x32 is None else x32.shape[0]
     if N is None:
         N = w.shape[0] // 2 if gated else w.shape[0]
@@ -304,8 +307,17 @@ def dec_proj(xin, w, a, bt, u, out, K, *, x32=None, gamma=None, eps=0.0, N=None,
     s_in, p_in = (in_drop.site, in_drop.p) if in_drop is not None else (0, 0.0)
     s_out, p_out = (out_drop.site, out_drop.p) if out_drop is not None else (0, 0.0)
     s_ext, p_ext = (ext_drop.site, ext_drop.p) if ext_drop is not None else (0, 0.0)
+    t = [None, None, None]
+    t_inner = t_spad = 0
+    t_bs = t_hs = 0
+    if tout is not None and any(x is not None for x in tout):
+        ref = next(x for x in tout if x is not None)      # [B, H, 64, Spad]
+        assert ref.shape[2] == 64 and all(x is None or (x.shape == ref.shape and x.is_contiguous()) for x in tout)
+        t[:len(tout)] = list(tout)
+        t_inner, t_spad, t_bs, t_hs = ref.shape[1] * 64, ref.shape[3], ref.stride(0), ref.stride(1)
     _chk(_dec_proj(_p(x32), _ld(x32), _p(gamma), eps, _p(xin), _ld(xin), _p(w), _ld(w), _p(a), _ld(a), a.shape[0], _p(bt), _ld(bt), _p(u), _ld(u),
-                   R, N, K, mode, _p(out), _ld(out), _p(residual), _ld(residual), _p(out2), _ld(out2), sp, s_in, p_in, s_out, p_out, s_ext, p_ext, _stream()))
+                   R, N, K, mode, _p(out), _ld(out), _p(residual), _ld(residual), _p(out2), _ld(out2), sp, s_in, p_in, s_out, p_out, s_ext, p_ext,
+                   _p(t[0]), _p(t[1]), _p(t[2]), t_inner, int(t_rows), t_spad, t_bs, t_hs, _stream()))
 
 
 def lora_dx(dy, wt, g, acatt, dx, K, residual=None, drop: Optional[Dropout] = None, tile_cfg=0, k_splits: int = 0):

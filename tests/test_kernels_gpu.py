@@ -873,6 +873,15 @@ def test_dec_proj_fused_rmsnorm_bf16_out(ops, R, N, Rk):
         check(tag + "xn vs rmsnorm_lora_fwd", rel(xn1.float(), xn0.float()), 1e-3)
         check(tag + "u", rel(u1.float(), u0.float()), 6e-3)
         check(tag + "out", rel(out.float(), ref.float()), 4e-3)
+        if N % 2048 == 0:   # head-transposed copies of the 2048-wide column ranges (32 heads x 64): what head_transpose writes from the output
+            nj = N // 2048
+            touts = [torch.zeros(1, 32, 64, 32, dtype=torch.bfloat16, device=dev()) for _ in range(nj)]
+            out_t = torch.zeros_like(ref)
+            ops.dec_proj(xn1, w, acat, wext, u1, out_t, K, x32=x32, gamma=gamma, eps=1e-6, in_drop=ldrop, tout=touts, t_rows=R)
+            assert torch.equal(out_t, out)
+            for j in range(nj):
+                want = ops.head_transpose(out_t[:, j * 2048:(j + 1) * 2048].unflatten(1, (32, 64)).unsqueeze(0))
+                assert torch.equal(touts[j], want), j
 
 
 @pytest.mark.parametrize("R", [8, 14])
