@@ -20,6 +20,7 @@
 // Dropout masks: the element indices and hashes of the kernels this replaces (lora.hip: pair hash over row * K + k; gemm.hip epilogue:
 // single hash over row * N + n; the LoRA-backward mask: pair hash over row * N + n).
 #include "common.h"
+#include <stdlib.h>
 
 struct DecProjArgs {
   const float* x32; long long ldx32; const float* gamma; float eps;   // NORM input (x32 != nullptr)
@@ -312,26 +313,31 @@ extern "C" int mrblip_dec_proj(const float* x32, long long ldx32, const float* g
   dp_drop(a.in_drop, seed_ptr, in_site, in_p);
   dp_drop(a.out_drop, seed_ptr, out_site, out_p);
   dp_drop(a.ext_drop, seed_ptr, ext_site, ext_p);
-  constexpr int NT = 2;
-  const int grid = (N + 16 * NT - 1) / (16 * NT);
-  const int ntw = mode == 2 ? 2 * NT : NT;
+  // 32 output columns per block; 16 (twice the blocks, half the weight bytes each) for the long-K projections of a 2048-wide output, whose
+  // 64 blocks are otherwise a serial stream of 20-40 k-steps per wave (MRB_DEC_PROJ_NT1=0 keeps 32)
+  static int nt1 = -1;
+  if (nt1 < 0) { const char* e = getenv("MRB_DEC_PROJ_NT1"); nt1 = (e && e[0] == '0') ? 0 : 1; }
+  const bool narrow = nt1 && mode != 2 && K >= 4096 && N <= 4096;
+  const int nt = narrow ? 1 : 2;
+  const int grid = (N + 16 * nt - 1) / (16 * nt);
+  const int ntw = mode == 2 ? 2 * nt : nt;
   const int LDS = 8 * (ntw + 2) * 64 * 16 + 1024 + (x32 ? 16 * (K * 2 + 16) : 0);
-  static bool attr[3] = {};
-#define MRB_DP_LAUNCH(MODE_, UB_)                                                                                                  \
+  static bool attr[6] = {};
+#define MRB_DP_LAUNCH(NT_, MODE_, UB_)                                                                                             \
   {                                                                                                                                \
-    auto k = dec_proj_kernel<NT, MODE_, UB_>;                                                                                      \
-    if (!attr[MODE_]) {                                                                                                            \
-      if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * (2 * NT + 2) * 64 * 16 + 1024 + 16 * (2048 * 2 + 16)) != hipSuccess) { \
+    auto k = dec_proj_kernel<NT_, MODE_, UB_>;                                                                                     \
+    if (!attr[MODE_ + 3 * (NT_ - 1)]) {                                                                                            \
+      if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * (2 * NT_ + 2) * 64 * 16 + 1024 + 16 * (2048 * 2 + 16)) != hipSuccess) { \
         mrblip_set_error("dec_proj: cannot raise dynamic LDS");                                                                    \
         return MRBLIP_ELAUNCH;                                                                                                     \
       }                                                                                                                            \
-      attr[MODE_] = true;                                                                                                          \
+      attr[MODE_ + 3 * (NT_ - 1)] = true;                                                                                          \
     }                                                                                                                              \
     hipLaunchKernelGGL(k, dim3(grid), dim3(512), LDS, stream, a);                                                                  \
   }
-  if (mode == 0) MRB_DP_LAUNCH(0, 4)
-  else if (mode == 1) MRB_DP_LAUNCH(1, 4)
-  else MRB_DP_LAUNCH(2, 2)
+  if (mode == 0) { if (narrow) MRB_DP_LAUNCH(1, 0, 4) else MRB_DP_LAUNCH(2, 0, 4) }
+  else if (mode == 1) { if (narrow) MRB_DP_LAUNCH(1, 1, 4) else MRB_DP_LAUNCH(2, 1, 4) }
+  else MRB_DP_LAUNCH(2, 2, 2)
 #undef MRB_DP_LAUNCH
   return mrblip_check_launch("dec_proj");
 }
