@@ -187,16 +187,19 @@ __device__ __forceinline__ uint32_t mask_bits_lds(const uint32_t* mb, int t, int
   return (wd & 0xffu) | ((wd >> 8) & 0xff00u);
 }
 
-template <int DP, int FLAGS>
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs p) {
+// NSW: waves that split the key range of the block's one query tile in the SPLIT form (4, or 8 for long key ranges: the decoder's cross
+// attention has 8-14 queries against 2012 keys and ONE block per head — its waves walk 503 keys each, a chain of 16 dependent tiles)
+template <int DP, int FLAGS, int NSW = 4>
+__global__ __launch_bounds__(NSW * 64, NSW == 4 ? 2 : 1) void attn_fwd_kernel(const AttnArgs p) {
   constexpr int KS = DP / 16, MT = DP / 32;
   constexpr bool LUT = FLAGS & F_LUT, MASK = FLAGS & F_MASK, CAUSAL = FLAGS & F_CAUSAL, DROP = FLAGS & F_DROP, SPLIT = FLAGS & F_SPLIT;
+  static_assert(NSW == 4 || SPLIT, "more than four waves only in the key-split form");
   __shared__ float lut[LUT ? 257 : 1];
-  __shared__ float red[SPLIT ? 3 * (MT * 16 + 2) * 64 : 1];
+  __shared__ float red[SPLIT ? (NSW - 1) * (MT * 16 + 2) * 64 : 1];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, hi = lane >> 5, l31 = lane & 31;
   const int b = blockIdx.z, h = blockIdx.y;
   if (LUT) {
-    for (int i = threadIdx.x; i < 257; i += 256) lut[i] = p.lut[h * 257 + i] * MRB_LOG2E;
+    for (int i = threadIdx.x; i < 257; i += NSW * 64) lut[i] = p.lut[h * 257 + i] * MRB_LOG2E;
     __syncthreads();
   }
   const int q0 = SPLIT ? blockIdx.x * 32 : (blockIdx.x * 4 + w) * 32;
@@ -216,7 +219,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs p) {
   const uint32_t drop_seed = DROP ? *p.drop.seed_ptr : 0u;
   const uint32_t row_id = (uint32_t)(b * p.H + h) * (uint32_t)p.Sq + (uint32_t)q;
   const uint32_t t_lane = DROP ? (row_id * (uint32_t)((p.Sk + 3) >> 2) + 2u * (uint32_t)hi) * MRB_H1 + mrb_lin_base(drop_seed, p.drop.site) : 0u;
-  const int kstart = SPLIT ? w * 32 : 0, kstep = SPLIT ? 128 : 32;
+  const int kstart = SPLIT ? w * 32 : 0, kstep = SPLIT ? NSW * 32 : 32;
   const float scale2 = p.scale * MRB_LOG2E;
 
   // software pipeline: K fragments of the next tile and V^T fragments of this tile are in flight during the score math
@@ -292,7 +295,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs p) {
     else tile(BoolC<false>(), k0);
   }
   float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  if (SPLIT) {  // merge the four key-range partials: wave 0 collects (m, l, O) of waves 1..3
+  if (SPLIT) {  // merge the key-range partials: wave 0 collects (m, l, O) of waves 1 .. NSW - 1
     constexpr int STR = (MT * 16 + 2) * 64;
     if (w > 0) {
       float* r = red + (w - 1) * STR;
@@ -307,7 +310,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs p) {
     if (w > 0) return;
     float m_all = m_run;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) m_all = fmaxf(m_all, red[j * STR + lane]);
+    for (int j = 0; j < NSW - 1; ++j) m_all = fmaxf(m_all, red[j * STR + lane]);
     const float f0 = ex2(m_run - m_all);
     l_tot *= f0;
 #pragma unroll
@@ -315,7 +318,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs p) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) o[mt][i] *= f0;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
+    for (int j = 0; j < NSW - 1; ++j) {
       const float* r = red + j * STR;
       const float fj = ex2(r[lane] - m_all);
       l_tot += r[64 + lane] * fj;
@@ -606,16 +609,17 @@ __global__ __launch_bounds__((FLAGS & F_KS2) ? 512 : 256, (FLAGS & F_KS2) ? 1 : 
 }
 
 // ---- backward, part 1: dQ (and Delta = rowsum(dO * O), needed by part 2).  Same ownership as the forward.
-template <int DP, int FLAGS>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
+template <int DP, int FLAGS, int NSW = 4>
+__global__ __launch_bounds__(NSW * 64, NSW == 4 ? 2 : 1) void attn_bwd_dq_kernel(const AttnArgs p) {
   constexpr int KS = DP / 16, MT = DP / 32;
   constexpr bool LUT = FLAGS & F_LUT, MASK = FLAGS & F_MASK, CAUSAL = FLAGS & F_CAUSAL, DROP = FLAGS & F_DROP, SPLIT = FLAGS & F_SPLIT;
+  static_assert(NSW == 4 || SPLIT, "more than four waves only in the key-split form");
   __shared__ float lut[LUT ? 257 : 1];
-  __shared__ float red[SPLIT ? 3 * MT * 16 * 64 : 1];
+  __shared__ float red[SPLIT ? (NSW - 1) * MT * 16 * 64 : 1];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, hi = lane >> 5, l31 = lane & 31;
   const int b = blockIdx.z, h = blockIdx.y;
   if (LUT) {
-    for (int i = threadIdx.x; i < 257; i += 256) lut[i] = p.lut[h * 257 + i] * MRB_LOG2E;
+    for (int i = threadIdx.x; i < 257; i += NSW * 64) lut[i] = p.lut[h * 257 + i] * MRB_LOG2E;
     __syncthreads();
   }
   const int q0 = SPLIT ? blockIdx.x * 32 : (blockIdx.x * 4 + w) * 32;
@@ -652,7 +656,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
   const uint32_t drop_seed = DROP ? *p.drop.seed_ptr : 0u;
   const uint32_t row_id = (uint32_t)(b * p.H + h) * (uint32_t)p.Sq + (uint32_t)q;
   const uint32_t t_lane = DROP ? (row_id * (uint32_t)((p.Sk + 3) >> 2) + 2u * (uint32_t)hi) * MRB_H1 + mrb_lin_base(drop_seed, p.drop.site) : 0u;
-  const int kstart = SPLIT ? w * 32 : 0, kstep = SPLIT ? 128 : 32;
+  const int kstart = SPLIT ? w * 32 : 0, kstep = SPLIT ? NSW * 32 : 32;
 
   bf16x8 kcur[KS], vcur[KS];
   load_rows<KS>(kcur, kbase, p.K.rs, kstart + perm23(l31), p.Sk, p.D, hi);
@@ -724,7 +728,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
     __syncthreads();
     if (w > 0) return;
 #pragma unroll
-    for (int j = 0; j < 3; ++j)
+    for (int j = 0; j < NSW - 1; ++j)
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -1347,13 +1351,23 @@ static void fwd_lds96(const AttnArgs& a, dim3 grid, hipStream_t stream) {
   else hipLaunchKernelGGL((attn_fwd_lds_kernel<96, 0>), grid, dim3(256), 2 * (64 * 192 + 96 * 128) + 1040, stream, a);
 }
 
+// the key-split form on 8 waves instead of 4 (MRB_ATTN_SPLIT8=1; measured in round 3 on the decoder's cross attention, 8-14 queries x 2012
+// keys, one block per head: decoder phases 8.79 + 13.96 ms with 4 waves, 8.85 + 14.21 ms with 8, step 70.44 vs 70.52 ms — the block is
+// bound by what ONE CU streams, not by the length of a wave's tile chain; off by default)
+static bool attn_split8(const AttnArgs& a) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("MRB_ATTN_SPLIT8"); on = (e && e[0] == '1') ? 1 : 0; }
+  return on && a.Sk >= 1024;
+}
+
 template <int DP>
 static int launch_fwd(const AttnArgs& a, int flags, hipStream_t stream) {
   const bool split = a.Sq <= 32 && a.Sk >= 256 && !(flags & F_CAUSAL);
   dim3 grid(split ? 1 : (a.Sq + 127) / 128, a.H, a.B);
 #define X(DPV, FL)                                                                                             \
   if (flags == (FL)) {                                                                                         \
-    if (split && !((FL) & F_CAUSAL)) hipLaunchKernelGGL((attn_fwd_kernel<DPV, ((FL) & ~F_CAUSAL) | F_SPLIT>), grid, dim3(256), 0, stream, a); \
+    if (split && !((FL) & F_CAUSAL) && DPV == 64 && attn_split8(a)) hipLaunchKernelGGL((attn_fwd_kernel<DPV, ((FL) & ~F_CAUSAL) | F_SPLIT, DPV == 64 ? 8 : 4>), grid, dim3(DPV == 64 ? 512 : 256), 0, stream, a); \
+    else if (split && !((FL) & F_CAUSAL)) hipLaunchKernelGGL((attn_fwd_kernel<DPV, ((FL) & ~F_CAUSAL) | F_SPLIT>), grid, dim3(256), 0, stream, a); \
     else if (DPV == 64 && use_lds64(a, (FL))) fwd_lds64<((FL) & ~F_CAUSAL)>(a, grid, stream);                       \
     else hipLaunchKernelGGL((attn_fwd_kernel<DPV, (FL)>), grid, dim3(256), 0, stream, a);                       \
     return mrblip_check_launch("attention_fwd");                                                               \
@@ -1370,7 +1384,8 @@ static int launch_bwd(const AttnArgs& a, int flags, hipStream_t stream) {
   dim3 gq(split ? 1 : (a.Sq + 127) / 128, a.H, a.B), gk((a.Sk + 127) / 128, a.H, a.B);
 #define X(DPV, FL)                                                                                             \
   if (flags == (FL)) {                                                                                         \
-    if (split && !((FL) & F_CAUSAL)) hipLaunchKernelGGL((attn_bwd_dq_kernel<DPV, ((FL) & ~F_CAUSAL) | F_SPLIT>), gq, dim3(256), 0, stream, a); \
+    if (split && !((FL) & F_CAUSAL) && DPV == 64 && attn_split8(a)) hipLaunchKernelGGL((attn_bwd_dq_kernel<DPV, ((FL) & ~F_CAUSAL) | F_SPLIT, DPV == 64 ? 8 : 4>), gq, dim3(DPV == 64 ? 512 : 256), 0, stream, a); \
+    else if (split && !((FL) & F_CAUSAL)) hipLaunchKernelGGL((attn_bwd_dq_kernel<DPV, ((FL) & ~F_CAUSAL) | F_SPLIT>), gq, dim3(256), 0, stream, a); \
     else if (DPV == 64 && use_lds64(a, (FL))) dq_lds64<((FL) & ~F_CAUSAL)>(a, gq, stream);                          \
     else hipLaunchKernelGGL((attn_bwd_dq_kernel<DPV, (FL)>), gq, dim3(256), 0, stream, a);                      \
     if (DPV == 64 && a.D == 64 && a.Sq > 32) dkv_lds64<(FL)>(a, gk, stream);                                     \

@@ -259,7 +259,8 @@ def test_attention_fwd(ops, B, H, Sq, Sk, D):
 
 
 @pytest.mark.parametrize("causal", [False, True])
-@pytest.mark.parametrize("B,H,Sq,Sk,D", [(2, 4, 150, 150, 64), (1, 2, 40, 40, 16), (2, 3, 12, 200, 64), (3, 2, 32, 257, 64), (2, 4, 8, 700, 64)])
+@pytest.mark.parametrize("B,H,Sq,Sk,D", [(2, 4, 150, 150, 64), (1, 2, 40, 40, 16), (2, 3, 12, 200, 64), (3, 2, 32, 257, 64), (2, 4, 8, 700, 64),
+                                         (1, 4, 8, 2012, 64), (2, 2, 14, 1030, 64)])   # (the last two: long key ranges — 8 waves split them with MRB_ATTN_SPLIT8=1)
 def test_attention_bias_mask_dropout_fwd_bwd(ops, causal, B, H, Sq, Sk, D):
     if causal and Sq != Sk:
         pytest.skip("causal only for self-attention")
