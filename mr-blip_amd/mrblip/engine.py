@@ -1385,7 +1385,7 @@ class MrBlipEngine:
             nb = max(1, nb - int(self.vit_tail_blocks))
             frames = next_video.reshape(F_, 3, c.img, c.img)
             b0 = 0
-            for upto, reserve in self.vit_reserve_schedule:   # (first-leg blocks < upto run with `reserve` CUs left to the other streams)
+            for upto, reserve in self._reserve_schedule_for(F_):   # (first-leg blocks < upto run with `reserve` CUs left to the other streams)
                 b1 = min(nb, upto)
                 if b1 > b0:
                     with ops.gemm_cu_reserve(reserve):
@@ -1400,6 +1400,17 @@ class MrBlipEngine:
     # launch; without a reserve the other stream's short, latency-bound kernels (the decoder chain above all) queue behind them
     # (QVH, B = 1: 85.0 ms per step with 0, 80.3 with 32, 78.3 with 64, 80.3 with 96, 84.1 with 128 reserved CUs).
     vit_lookahead_reserve = int(os.environ.get("MRB_VIT_RESERVE", "64"))
+    _vit_reserve_fixed = "MRB_VIT_RESERVE" in os.environ or "MRB_VIT_RESERVE_SCHED" in os.environ
+
+    def _reserve_schedule_for(self, frames: int):
+        """The reserve follows the look-ahead's size unless MRB_VIT_RESERVE[_SCHED] pins it.  With 60+ frames the ViT is the larger half
+        of the step and 64 reserved CUs are the measured optimum (QVH 60 frames, QVH 4 x 60, ActivityNet 120: 48 / 64 / 80 -> +1.6 / 0 /
+        +1.8 ms).  With 20 frames (Charades-STA) the ViT is 14 ms of a 35 ms step made of launch chains whose kernels run twice as long
+        beside it: reserve 64 / 96 / 128 / 160 / 176 / 192 -> 35.05 / 33.49 / 32.97 / 32.42 / 32.51 / 35.18 ms.  Linear in between."""
+        if self._vit_reserve_fixed:
+            return self.vit_reserve_schedule
+        r = 64 + max(0, 60 - int(frames)) * 12 // 5      # 60 frames -> 64, 20 frames -> 160
+        return [(1 << 30, min(168, r // 8 * 8))]
     # optional per-block schedule "upto:reserve,upto:reserve" (experiments: the first blocks run beside the decoder's short kernels, the
     # later ones beside the encoder backward's GEMMs); default: one segment with vit_lookahead_reserve
     vit_reserve_schedule = ([(int(a), int(b)) for a, b in (seg.split(":") for seg in os.environ["MRB_VIT_RESERVE_SCHED"].split(","))]
@@ -1422,7 +1433,7 @@ class MrBlipEngine:
         with torch.cuda.stream(self._vit_stream):
             self._vit_stream.wait_event(start)
             F_ = v.shape[0] * v.shape[1]
-            with ops.gemm_cu_reserve(self.vit_lookahead_reserve):
+            with ops.gemm_cu_reserve(self._reserve_schedule_for(F_)[-1][1]):
                 self.vit_forward(v.reshape(F_, 3, c.img, c.img), slot=r[3], blocks=(r[4], c.vit_depth))
             done = torch.cuda.Event()
             done.record()
@@ -1478,6 +1489,12 @@ class MrBlipEngine:
             fr_all = self.buf("frames_gathered", (shard.T * n, d), f32, zero=False)
             shard.gather_rows(fr, n, fr_all)
             fr = fr_all
+        # (host-side, on the CPU index maps: a layout built for another tokens-per-frame count — n = 32 vs the mean-pooled 1 — would send
+        # the row gather past the frame-token matrix)
+        n_src = int(layout.frame_src.max()) + 1 if layout.frame_src.numel() else 0
+        if n_src > fr.shape[0] or int(layout.frame_dst.max() if layout.frame_dst.numel() else 0) >= Bv * S:
+            raise ValueError(f"encoder layout does not fit this engine: it gathers frame-token row {n_src - 1} of {fr.shape[0]} "
+                             f"(layout built with another n_per_frame / T than mean_pool={self.cfg.mean_pool}, num_query={self.cfg.num_query}?)")
         ops.row_copy(fr, L["frame_src"], inp, L["frame_dst"])
         ops.row_copy(self.emb, L["emb_src"], inp, L["emb_dst"])
         kmask = L["mask"]

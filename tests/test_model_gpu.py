@@ -93,6 +93,21 @@ def _samples(g):
                 relevant_windows=s["relevant_windows"])
 
 
+def test_layout_built_for_another_pooling_is_rejected():
+    """a layout with 8 tokens per frame handed to a mean-pooling engine (1 token per frame) must raise on the host, not fault on the GPU"""
+    from mrblip import prompt as P
+    from mrblip.tokenizer import FixtureTokenizer
+
+    g = load_golden("mr_tiny_mean")
+    tok = FixtureTokenizer()
+    repl = P.annoying_replacement_dict(P.find_annoying_numbers(tok, 200)[0])
+    samples = _samples(g)
+    eng = _engine(golden_state_dict(g), mean_pool=True)
+    with pytest.raises(ValueError, match="encoder layout does not fit"):
+        eng.forward_backward(samples["video"].cuda(), P.build_layout(tok, samples, repl, 8, T=3), backward=False)
+    eng.forward_backward(samples["video"].cuda(), P.build_layout(tok, samples, repl, 1, T=3), backward=False)   # the right one still runs
+
+
 @pytest.mark.parametrize("tag,mean", [("mr_tiny", False), ("mr_tiny_mean", True)])
 def test_train_step_forward_backward(tag, mean):
     from oracle import mrblip_oracle as O

@@ -14,14 +14,15 @@ from mrblip.tokenizer import FixtureTokenizer  # noqa: E402
 
 dev = torch.device("cuda:0")
 LOOKAHEAD = "--no-lookahead" not in sys.argv
-wl = bench.WORKLOADS["qvh"]
-cfg = EngineConfig.flan_t5_xl_qvh(mean_pool=False)
+WL = next((a.split("=")[1] for a in sys.argv if a.startswith("--workload=")), "qvh")   # qvh | charades | anet
+wl = bench.WORKLOADS[WL]
+cfg = EngineConfig.flan_t5_xl_qvh(mean_pool=bool(wl.get("mean_pool", False)))
 eng = MrBlipEngine(cfg, RandomSource(dev, seed=1234), dev, lora_init=bench.lora_init_nonzero, seed=42)
 eng.training = True
 tok = FixtureTokenizer()
 repl = P.annoying_replacement_dict(P.find_annoying_numbers(tok, 200)[0])
 samples = bench.synthetic_samples(1, wl["T"], wl["duration"], dev, 1234)
-layout = P.build_layout(tok, samples, repl, cfg.num_query, T=wl["T"])
+layout = P.build_layout(tok, samples, repl, 1 if cfg.mean_pool else cfg.num_query, T=wl["T"])
 video = samples["video"]
 st = torch.cuda.Stream(device=dev, priority=-1)
 per_step = []
