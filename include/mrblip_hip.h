@@ -162,7 +162,7 @@ int mrblip_lora_rows_init(const void* X, long long ldx, const void* A, long long
 int mrblip_rmsnorm_lora_fwd(const float* x, long long ldx, const float* weight, int M, int D, float eps, void* out_bf16, long long ldob,
                             const void* A, long long lda, int R, void* U, long long ldu, const uint32_t* seed_ptr, uint32_t site, float p_drop,
                             mrblip_stream_t stream);
-/* One launch for an adapted projection of the T5 DECODER rows (R <= 16; replaces mrblip_lora_rows / mrblip_rmsnorm_lora_fwd + mrblip_gemm_bf16
+/* One launch for an adapted projection of few rows — the T5 DECODER's, or a short encoder's (R <= 16; <= 80 without x32 / mode 2; replaces mrblip_lora_rows / mrblip_rmsnorm_lora_fwd + mrblip_gemm_bf16
  * of peft's lora.Linear.forward around modeling_t5.py:449-603 (q/k/v/o), :323-329 (wi_0/wi_1/wo), and mrblip_lora_rows + mrblip_gemm_lora_dx of
  * its backward):  xin = x32 ? bf16(RMSNorm(x32) * gamma) (saved to xin) : xin;  U[R, 0:Rk] = bf16(dropout(xin; in_site, in_p) A[Rk,K]^T);
  * acc = xin W[N,K]^T + (ext_p > 0 ? mask(ext_site, ext_p) (.) : ) U Bt[N,64]^T;

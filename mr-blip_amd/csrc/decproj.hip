@@ -40,9 +40,13 @@ struct DecProjArgs {
 
 typedef uint32_t dp_u32x4 __attribute__((ext_vector_type(4)));
 
-template <int NT, int MODE, int UB>   // NT tiles of 16 output columns (gated: NT of wi_0 and the same NT of wi_1); MODE 0 bf16, 1 fp32 (+ residual), 2 gated
+// RT: 16-row tiles of the input (R <= 16 RT).  RT > 1 — the S = 72 encoder of the 20-frame workload, the decoder rows of a 4-clip batch —
+// keeps a k-step's weight fragments in registers and multiplies them with every row tile; input rows come from global memory only
+// (no fused RMSNorm: 16 RT rows of 2048 bf16 do not fit the LDS), the partial sums go through the LDS buffer one row tile at a time.
+template <int NT, int MODE, int UB, int RT = 1>   // NT tiles of 16 output columns (gated: NT of wi_0 and the same NT of wi_1); MODE 0 bf16, 1 fp32 (+ residual), 2 gated
 __global__ __launch_bounds__(512) void dec_proj_kernel(const DecProjArgs p) {
   constexpr int NTW = MODE == 2 ? 2 * NT : NT, NA = 2, NACC = NTW + NA;
+  static_assert(RT == 1 || MODE != 2, "row tiles: plain and residual outputs only");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // LDS: [red: 8 waves x NACC x 64 lanes x 16 B][ubuf: 16 rows x 64 B][NORM: 16 rows x (2 K + 16) B]
   f32x4* red = reinterpret_cast<f32x4*>(smem);
@@ -70,16 +74,21 @@ __global__ __launch_bounds__(512) void dec_proj_kernel(const DecProjArgs p) {
   }
 #pragma unroll
   for (int a = 0; a < NA; ++a) aoff[a] = (uint32_t)(((long long)(16 * a + l15) * p.lda + kg * 8) * 2);   // rows >= Rk: beyond the resource
-  const uint32_t xoff = (uint32_t)(((long long)l15 * p.ldxin + kg * 8) * 2);                              // rows >= R: beyond the resource
+  uint32_t xoff[RT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) xoff[rt] = (uint32_t)(((long long)(16 * rt + l15) * p.ldxin + kg * 8) * 2);    // rows >= R: beyond the resource
   const int nks = p.K >> 5;
   const int per = (nks + 7) >> 3;
   const int ks0 = w * per, ks1 = min(nks, ks0 + per);
-  f32x4 acc[NTW], accu[NA];
+  f32x4 acc[RT][NTW], accu[RT][NA];
 #pragma unroll
-  for (int t = 0; t < NTW; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int rt = 0; rt < RT; ++rt) {
 #pragma unroll
-  for (int a = 0; a < NA; ++a) accu[a] = f32x4{0.f, 0.f, 0.f, 0.f};
-  dp_u32x4 wf[2][UB][NTW], af[2][UB][NA], xf[2][UB];
+    for (int t = 0; t < NTW; ++t) acc[rt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int a = 0; a < NA; ++a) accu[rt][a] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  dp_u32x4 wf[2][UB][NTW], af[2][UB][NA], xf[2][UB][RT];
   auto fetch = [&](int buf, int ks) {   // unconditional (past the share: out-of-range offsets -> zeros, no traffic), see lora_thin_kernel
 #pragma unroll
     for (int u = 0; u < UB; ++u) {
@@ -89,23 +98,28 @@ __global__ __launch_bounds__(512) void dec_proj_kernel(const DecProjArgs p) {
       for (int t = 0; t < NTW; ++t) wf[buf][u][t] = __builtin_amdgcn_raw_buffer_load_b128(rw, ok ? woff[t] + kb : 0x80000000u, 0, 0);
 #pragma unroll
       for (int a = 0; a < NA; ++a) af[buf][u][a] = __builtin_amdgcn_raw_buffer_load_b128(ra, ok ? aoff[a] + kb : 0x80000000u, 0, 0);
-      if (!NORM) xf[buf][u] = __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? xoff + kb : 0x80000000u, 0, 0);
+      if (!NORM) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) xf[buf][u][rt] = __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? xoff[rt] + kb : 0x80000000u, 0, 0);
+      }
     }
   };
   auto consume = [&](int buf, int ks) {
 #pragma unroll
-    for (int u = 0; u < UB; ++u) {
+    for (int u = 0; u < UB; ++u)
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
       dp_u32x4 x;
       if (NORM) {
         const int k = min(ks + u, nks - 1) * 32 + kg * 8;
         x = *reinterpret_cast<const dp_u32x4*>(xs + l15 * RS + k * 2);
         if (ks + u >= ks1) x = dp_u32x4{0u, 0u, 0u, 0u};
       } else {
-        x = xf[buf][u];
+        x = xf[buf][u][rt];
       }
       dp_u32x4 xd = x;
       if (in_drop) {   // block-uniform
-        const uint32_t e = (uint32_t)l15 * (uint32_t)p.K + (uint32_t)((ks + u) * 32 + kg * 8);
+        const uint32_t e = (uint32_t)(16 * rt + l15) * (uint32_t)p.K + (uint32_t)((ks + u) * 32 + kg * 8);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           bool k0, k1;
@@ -115,10 +129,10 @@ __global__ __launch_bounds__(512) void dec_proj_kernel(const DecProjArgs p) {
       }
 #pragma unroll
       for (int t = 0; t < NTW; ++t)
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[buf][u][t]), __builtin_bit_cast(bf16x8, x), acc[t], 0, 0, 0);
+        acc[rt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[buf][u][t]), __builtin_bit_cast(bf16x8, x), acc[rt][t], 0, 0, 0);
 #pragma unroll
       for (int a = 0; a < NA; ++a)
-        accu[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[buf][u][a]), __builtin_bit_cast(bf16x8, xd), accu[a], 0, 0, 0);
+        accu[rt][a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[buf][u][a]), __builtin_bit_cast(bf16x8, xd), accu[rt][a], 0, 0, 0);
     }
   };
   fetch(0, ks0);
@@ -179,11 +193,15 @@ __global__ __launch_bounds__(512) void dec_proj_kernel(const DecProjArgs p) {
     if (ks + UB < ks1) consume(1, ks + UB);
   }
 
-  // ---- the 8 partial sums meet in LDS (fixed order)
+  // ---- the 8 partial sums meet in LDS (fixed order), one 16-row tile at a time
 #pragma unroll
-  for (int t = 0; t < NTW; ++t) red[(w * NACC + t) * 64 + lane] = acc[t];
+  for (int rt = 0; rt < RT; ++rt) {
+  const int rbase = 16 * rt;
+  if (rt > 0) __syncthreads();   // the previous row tile's readers are done with red / ubuf
 #pragma unroll
-  for (int a = 0; a < NA; ++a) red[(w * NACC + NTW + a) * 64 + lane] = accu[a];
+  for (int t = 0; t < NTW; ++t) red[(w * NACC + t) * 64 + lane] = acc[rt][t];
+#pragma unroll
+  for (int a = 0; a < NA; ++a) red[(w * NACC + NTW + a) * 64 + lane] = accu[rt][a];
   __syncthreads();
   if (w < NA) {   // u tile w: lane (r = l15, kg) holds j = 16 w + 4 kg .. + 3
     f32x4 v = red[(0 * NACC + NTW + w) * 64 + lane];
@@ -193,7 +211,7 @@ __global__ __launch_bounds__(512) void dec_proj_kernel(const DecProjArgs p) {
     const uint2 ub = make_uint2(pack2bf(v[0] * post, v[1] * post), pack2bf(v[2] * post, v[3] * post));
     const int j0 = 16 * w + 4 * kg;
     *reinterpret_cast<uint2*>(ubuf + l15 * 32 + j0) = ub;
-    if (blockIdx.x == 0 && l15 < p.R && j0 < p.Rk) *reinterpret_cast<uint2*>(p.U + (long long)l15 * p.ldu + j0) = ub;
+    if (blockIdx.x == 0 && rbase + l15 < p.R && j0 < p.Rk) *reinterpret_cast<uint2*>(p.U + (long long)(rbase + l15) * p.ldu + j0) = ub;
   }
   __syncthreads();
   if (w < NT) {   // output tile w (gated: the pair w, w + NT)
@@ -213,7 +231,7 @@ __global__ __launch_bounds__(512) void dec_proj_kernel(const DecProjArgs p) {
       const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
       if (ext_masked) {   // backward: dx = dy W + mask (.) (g A): the rank-Rk product on its own, masked per element (pair hash over row * N + n)
         f32x4 e = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bf), __builtin_bit_cast(bf16x8, uf), zero, 0, 0, 0);
-        const uint32_t idx = (uint32_t)l15 * (uint32_t)p.N + (uint32_t)(col + 4 * kg);
+        const uint32_t idx = (uint32_t)(rbase + l15) * (uint32_t)p.N + (uint32_t)(col + 4 * kg);
         bool k0, k1, k2, k3;
         mrb_keep2(idx, seed, p.ext_drop.site, p.ext_drop.thresh24, k0, k1);
         mrb_keep2(idx + 2, seed, p.ext_drop.site, p.ext_drop.thresh24, k2, k3);
@@ -224,7 +242,7 @@ __global__ __launch_bounds__(512) void dec_proj_kernel(const DecProjArgs p) {
       }
       h[s] = v;
     }
-    const int r = l15, n = col + 4 * kg;   // this lane: row r, columns n .. n + 3
+    const int r = rbase + l15, n = col + 4 * kg;   // this lane: row r, columns n .. n + 3
     if (r < p.R && n < p.N) {
       if (MODE == 2) {
         if (p.out2) {   // (generation keeps no pre-activations)
@@ -275,6 +293,7 @@ __global__ __launch_bounds__(512) void dec_proj_kernel(const DecProjArgs p) {
       }
     }
   }
+  }
 }
 
 static void dp_drop(DropoutArg& d, const uint32_t* seed_ptr, uint32_t site, float p) {
@@ -286,14 +305,15 @@ static void dp_drop(DropoutArg& d, const uint32_t* seed_ptr, uint32_t site, floa
 
 // mode: 0 = bf16 out, 1 = fp32 out (+ residual), 2 = gated (W / Bt hold 2 N rows: wi_0 then wi_1; out2 [R, 2 N], optional, receives the pre-activations).
 // x32 != NULL: RMSNorm(x32) * gamma is the input (K <= 2048) and is saved to xin; else xin is the bf16 input.  ext_p > 0: the LoRA-backward
-// form (the rank-Rk product masked per element before it is added).  R <= 16, N % 16 == 0, K % 32 == 0, Rk <= 32 and a multiple of 8.
+// form (the rank-Rk product masked per element before it is added).  R <= 16 (<= 80 without the fused RMSNorm / gating), N % 16 == 0, K % 32 == 0, Rk <= 32 and a multiple of 8.
 extern "C" int mrblip_dec_proj(const float* x32, long long ldx32, const float* gamma, float eps, void* xin, long long ldxin, const void* W,
                                long long ldw, const void* A, long long lda, int Rk, const void* Bt, long long ldbt, void* U, long long ldu, int R,
                                int N, int K, int mode, void* out, long long ldo, const float* residual, long long ldr, void* out2, long long ldo2,
                                const uint32_t* seed_ptr, uint32_t in_site, float in_p, uint32_t out_site, float out_p, uint32_t ext_site, float ext_p,
                                void* tout0, void* tout1, void* tout2, int t_inner, int t_rows, int t_spad, long long t_bs, long long t_hs,
                                hipStream_t stream) {
-  MRB_REQUIRE(R > 0 && R <= 16 && N > 0 && (N % 16) == 0 && K > 0 && (K % 32) == 0, "dec_proj: need R <= 16, N %% 16 == 0, K %% 32 == 0 (R=%d N=%d K=%d)", R, N, K);
+  MRB_REQUIRE(R > 0 && R <= 80 && N > 0 && (N % 16) == 0 && K > 0 && (K % 32) == 0, "dec_proj: need R <= 80, N %% 16 == 0, K %% 32 == 0 (R=%d N=%d K=%d)", R, N, K);
+  MRB_REQUIRE(R <= 16 || (!x32 && mode != 2), "dec_proj: more than 16 rows only with bf16 input rows and a plain / residual output (R=%d)", R);
   MRB_REQUIRE(Rk > 0 && Rk <= 32 && (Rk % 8) == 0 && ldu >= Rk && (ldu % 4) == 0, "dec_proj: bad LoRA rank rows (Rk=%d)", Rk);
   MRB_REQUIRE(mode >= 0 && mode <= 2 && W && A && Bt && U && xin && out, "dec_proj: bad mode / missing operand");
   MRB_REQUIRE(!x32 || (K <= 2048 && gamma && (ldx32 % 4) == 0), "dec_proj: the fused RMSNorm takes K <= 2048");
@@ -317,27 +337,35 @@ extern "C" int mrblip_dec_proj(const float* x32, long long ldx32, const float* g
   // 64 blocks are otherwise a serial stream of 20-40 k-steps per wave (MRB_DEC_PROJ_NT1=0 keeps 32)
   static int nt1 = -1;
   if (nt1 < 0) { const char* e = getenv("MRB_DEC_PROJ_NT1"); nt1 = (e && e[0] == '0') ? 0 : 1; }
-  const bool narrow = nt1 && mode != 2 && K >= 4096 && N <= 4096;
+  const int rt = R <= 16 ? 1 : R <= 48 ? 3 : 5;
+  const bool narrow = nt1 && mode != 2 && K >= 4096 && N <= 4096 && rt == 1;
   const int nt = narrow ? 1 : 2;
   const int grid = (N + 16 * nt - 1) / (16 * nt);
   const int ntw = mode == 2 ? 2 * nt : nt;
   const int LDS = 8 * (ntw + 2) * 64 * 16 + 1024 + (x32 ? 16 * (K * 2 + 16) : 0);
-  static bool attr[6] = {};
-#define MRB_DP_LAUNCH(NT_, MODE_, UB_)                                                                                             \
+  static bool attr[16] = {};
+#define MRB_DP_LAUNCH(ID, NT_, MODE_, UB_, RT_)                                                                                    \
   {                                                                                                                                \
-    auto k = dec_proj_kernel<NT_, MODE_, UB_>;                                                                                     \
-    if (!attr[MODE_ + 3 * (NT_ - 1)]) {                                                                                            \
+    auto k = dec_proj_kernel<NT_, MODE_, UB_, RT_>;                                                                                \
+    if (!attr[ID]) {                                                                                                               \
       if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * (2 * NT_ + 2) * 64 * 16 + 1024 + 16 * (2048 * 2 + 16)) != hipSuccess) { \
         mrblip_set_error("dec_proj: cannot raise dynamic LDS");                                                                    \
         return MRBLIP_ELAUNCH;                                                                                                     \
       }                                                                                                                            \
-      attr[MODE_ + 3 * (NT_ - 1)] = true;                                                                                          \
+      attr[ID] = true;                                                                                                             \
     }                                                                                                                              \
     hipLaunchKernelGGL(k, dim3(grid), dim3(512), LDS, stream, a);                                                                  \
   }
-  if (mode == 0) { if (narrow) MRB_DP_LAUNCH(1, 0, 4) else MRB_DP_LAUNCH(2, 0, 4) }
-  else if (mode == 1) { if (narrow) MRB_DP_LAUNCH(1, 1, 4) else MRB_DP_LAUNCH(2, 1, 4) }
-  else MRB_DP_LAUNCH(2, 2, 2)
+  if (mode == 2) MRB_DP_LAUNCH(0, 2, 2, 2, 1)
+  else if (mode == 0) {
+    if (rt == 1) { if (narrow) MRB_DP_LAUNCH(1, 1, 0, 4, 1) else MRB_DP_LAUNCH(2, 2, 0, 4, 1) }
+    else if (rt == 3) MRB_DP_LAUNCH(3, 2, 0, 2, 3)
+    else MRB_DP_LAUNCH(4, 2, 0, 1, 5)
+  } else {
+    if (rt == 1) { if (narrow) MRB_DP_LAUNCH(5, 1, 1, 4, 1) else MRB_DP_LAUNCH(6, 2, 1, 4, 1) }
+    else if (rt == 3) MRB_DP_LAUNCH(7, 2, 1, 2, 3)
+    else MRB_DP_LAUNCH(8, 2, 1, 1, 5)
+  }
 #undef MRB_DP_LAUNCH
   return mrblip_check_launch("dec_proj");
 }

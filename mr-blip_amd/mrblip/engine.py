@@ -701,7 +701,7 @@ class MrBlipEngine:
                 self.lora_thin(x, g.acat[8 * j: 8 * j + 8], u[:, 8 * j:], g.K, drop=self.drop(a.site, self.cfg.lora_dropout))
             ops.gemm(x, g.W, out, aext=u, wext=g.wext, **kw)
             return
-        if not u_ready and self._dec_proj_ok(g, x.shape[0], kw):
+        if not u_ready and self._dec_proj_ok(g, x.shape[0], kw, 16 if kw.get("gated") else self.dec_proj_max_rows):
             # <= 16 decoder rows: LoRA "down", main product, "up" product and epilogue in ONE launch (csrc/decproj.hip)
             t_ok = tout is not None and out.dtype == bf16 and not kw.get("gated")
             ops.dec_proj(x, g.W, g.acat, g.wext, u, out, g.K, residual=kw.get("residual"), out2=kw.get("out2"), gated=bool(kw.get("gated")),
@@ -727,8 +727,11 @@ class MrBlipEngine:
     dec_proj_enabled = os.environ.get("MRB_DEC_PROJ", "1") == "1"
     dec_tout_enabled = os.environ.get("MRB_DEC_TOUT", "1") == "1"   # ... which also write the head-transposed copies the attention kernels read (0: head_transpose launches)
 
-    def _dec_proj_ok(self, g: "LoraGroup", M: int, kw: dict) -> bool:
-        if not self.dec_proj_enabled or M > 16 or g.acat is None or g.acat.shape[0] > 32:
+    dec_proj_norm_split = os.environ.get("MRB_DEC_PROJ_NORM_SPLIT", "1") == "1"
+    dec_proj_max_rows = int(os.environ.get("MRB_DEC_PROJ_ROWS", "80"))   # ... up to this many rows for the projections without a fused RMSNorm / gating
+
+    def _dec_proj_ok(self, g: "LoraGroup", M: int, kw: dict, max_rows: int = 16) -> bool:
+        if not self.dec_proj_enabled or M > max_rows or g.acat is None or g.acat.shape[0] > 32:
             return False
         if self.cfg.lora_mask_per_adapter and len(g.adapters) > 1 and self.training and self.cfg.lora_dropout > 0:
             return False
@@ -778,6 +781,13 @@ class MrBlipEngine:
                          out2=kw.get("out2"), gated=bool(kw.get("gated")), in_drop=self.drop(g.site, self.cfg.lora_dropout), out_drop=kw.get("drop"),
                          tout=tout if t_ok else None, t_rows=t_rows)
             return t_ok
+        if (16 < x.shape[0] <= self.dec_proj_max_rows and not kw.get("gated") and self.dec_proj_norm_split
+                and self._dec_proj_ok(g, x.shape[0], kw, self.dec_proj_max_rows)):
+            # 17..80 rows (a short encoder): the fused kernel cannot hold that many normalised rows in LDS — plain RMSNorm, then the
+            # one-launch projection on its output (instead of fused norm + LoRA-down and a tile GEMM with one or two 64-row tiles)
+            ops.rmsnorm_fwd(x, ln, self.cfg.t5_eps, out_bf16=xn)
+            kw["tout"], kw["t_rows"] = tout, t_rows
+            return self.lg_fwd(g, xn, u, out, **kw)
         if self.fuse_norm_lora and x.shape[0] <= self.lora_rows_max_m and not per_adapter:
             ops.rmsnorm_lora_fwd(x, ln, self.cfg.t5_eps, xn, g.acat, u, drop=self.drop(g.site, self.cfg.lora_dropout))
             self.lg_fwd(g, xn, u, out, u_ready=True, **kw)
@@ -816,7 +826,7 @@ class MrBlipEngine:
                 for j, a in enumerate(g.adapters):
                     ops.lora_dx_add(dx, gbuf[:, 8 * j: 8 * j + 8], g.acat[8 * j: 8 * j + 8], drop=self.drop(a.site, self.cfg.lora_dropout))
             return
-        fused = dx is not None and g.N % 32 == 0 and self._dec_proj_ok(g, dy.shape[0], {}) and g.Wt.shape[0] % 16 == 0
+        fused = dx is not None and g.N % 32 == 0 and self._dec_proj_ok(g, dy.shape[0], {}, self.dec_proj_max_rows) and g.Wt.shape[0] % 16 == 0
         ks = self.k_splits_for(dy.shape[0], g.K, pad64(g.N), dx) if (dx is not None and not fused) else 1
         if fused:    # <= 16 decoder rows: g = dy B and dX = dy W + mask (.) (g A) [+ residual] in one launch
             t_ok = tout is not None and dx.dtype == bf16

@@ -829,7 +829,8 @@ def _dp_operands(R, N, K, Rk, gated=False, seed=41):
     return w, acat, wext
 
 
-@pytest.mark.parametrize("R,N,K,Rk", [(8, 2048, 2048, 8), (14, 2048, 5120, 8), (16, 2048, 2048, 16), (3, 96, 64, 24)])
+@pytest.mark.parametrize("R,N,K,Rk", [(8, 2048, 2048, 8), (14, 2048, 5120, 8), (16, 2048, 2048, 16), (3, 96, 64, 24),
+                                      (32, 2048, 2048, 8), (40, 2048, 5120, 8), (72, 2048, 2048, 8), (80, 2048, 5120, 16)])   # (> 16 rows: 3 / 5 row tiles)
 def test_dec_proj_plain_input_residual_out(ops, R, N, K, Rk):
     """o / co / wo of a decoder layer: out = residual + dropout(x W^T + u B^T), u = dropout_lora(x) A^T — one launch vs lora_rows + gemm"""
     from util import check
@@ -910,7 +911,8 @@ def test_dec_proj_fused_rmsnorm_gated(ops, R):
             assert torch.equal(y1 == 0, y0 == 0) or ((y1 == 0) != (y0 == 0)).sum() <= 2   # same mask (up to a value that rounds to 0)
 
 
-@pytest.mark.parametrize("R,N,K,Rk,f32out", [(8, 2048, 6144, 24, True), (14, 2048, 10240, 16, True), (16, 5120, 2048, 8, False), (8, 2048, 2048, 8, False)])
+@pytest.mark.parametrize("R,N,K,Rk,f32out", [(8, 2048, 6144, 24, True), (14, 2048, 10240, 16, True), (16, 5120, 2048, 8, False), (8, 2048, 2048, 8, False),
+                                             (72, 2048, 6144, 24, True), (33, 2048, 10240, 16, True), (72, 5120, 2048, 8, False)])
 def test_dec_proj_backward_form(ops, R, N, K, Rk, f32out):
     """the input gradient of an adapted decoder projection: g = dy (sB), dx = dy W + mask_lora (.) (g (sA)) [+ residual] vs lora_rows + lora_dx"""
     from util import check
