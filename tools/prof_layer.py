@@ -47,6 +47,23 @@ def main(db, layer=12, back=2):
         for (q, n), (c, t) in sorted(other.items(), key=lambda kv: -kv[1][1])[:12]:
             print(f"  beside it, queue {q}: {c:3d} x {n}  {t / 1e3:.1f} us overlapping")
 
+    def phase(first_pred, title, until_pred=None):
+        """all main-stream launches from the first match to the end of the step (or the first until_pred match), summed per kernel"""
+        i0 = next((i for i, r in enumerate(mainq) if first_pred(r[0])), None)
+        if i0 is None:
+            return
+        i1 = next((i for i in range(i0 + 1, len(mainq)) if until_pred and until_pred(mainq[i][0])), len(mainq))
+        agg = defaultdict(lambda: [0, 0])
+        for n, s, e, q, g in mainq[i0:i1]:
+            agg[(n[:70], g)][0] += 1
+            agg[(n[:70], g)][1] += e - s
+        tot = sum(v[1] for v in agg.values())
+        print(f"## {title}: {i1 - i0} launches, {tot / 1e3:.0f} us of kernels, wall {(mainq[i1 - 1][2] - mainq[i0][1]) / 1e3:.0f} us")
+        for (n, g), (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:25]:
+            print(f"  {c:4d} x {t / c / 1e3:7.1f} us = {t / 1e3:8.1f} us  grid {g:8d}  {n}")
+
+    phase(lambda n: "colsum" in n, "t5_proj + Q-Former backward (from colsum to the end of the step)")
+    phase(lambda n: True, "step start: frames forward (up to the first encoder attention)", lambda n: "attn_fwd_lds_kernel<64" in n)
     window(lambda n: "attn_fwd_lds_kernel<64" in n, "T5 encoder forward")
     window(lambda n: "attn_bwd_dkv_lds" in n, "T5 encoder backward")
     # decoder layers: forward = between consecutive causal self-attention launches (attn_fwd_kernel<64, 13>: LUT | CAUSAL | DROP), backward
