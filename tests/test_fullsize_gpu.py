@@ -220,6 +220,16 @@ def test_c3_batch4_step_equals_four_accumulated_single_clip_steps(xl):
     check("c3.flat-grad B=4 vs 4 accumulated B=1 steps", relerr(g4, g1), 5e-6)
     check("c3.grad-norm B=4 vs accumulated (rel)", abs(g4.norm().item() - g1.norm().item()) / g1.norm().item(), 1e-5)
     assert len(set(round(x, 3) for x in ls)) > 1  # the clips really differ
+    # the product setting for four clips: the decoder's 4 x L_dec rows take the one-launch projections with 3 row tiles (and their
+    # head-transposed copies, rows = clip * L_dec + position).  Not bit-equal to the two-launch run above (other summation order, amplified
+    # by this ill-conditioned random model: tools/probes/c3_kernel_choice_probe.py — switching the thin-product kernel moves the loss by
+    # 7e-3 and the flat gradient by a relative 1.4, switching the decoder projections by 1e-3 / 0.26, for one clip as for four).  Only the
+    # loss is asserted here; the row -> (clip, position) mapping of the 3-row-tile form is checked exactly in
+    # test_dec_proj_head_transposed_copies_for_a_batch_of_clips, its arithmetic in test_dec_proj_* at 32..80 rows.
+    eng.dec_proj_enabled = True
+    eng.zero_grad()
+    l4f = eng.forward_backward(video, lay4, backward=True).item()
+    check("c3.loss B=4, fused decoder projections vs two-launch path (rel)", abs(l4f - l4) / abs(l4), 3e-2)
     eng.lora_rows_max_m = rows_max
     eng.dec_proj_enabled = dec_proj
     del os.environ["MRB_ATTN_KS2"]

@@ -886,6 +886,26 @@ def test_dec_proj_fused_rmsnorm_bf16_out(ops, R, N, Rk):
                 assert torch.equal(touts[j], want), j
 
 
+def test_dec_proj_head_transposed_copies_for_a_batch_of_clips(ops):
+    """4 clips x 8 label rows = 32 rows (3 row tiles): the q | k | v copies must land at [clip, head, d, position] exactly as head_transpose
+    of the [4, 8, 32, 64] views of the output would write them"""
+    B, Ld, N, K, Rk = 4, 8, 6144, 2048, 24
+    R = B * Ld
+    w, acat, wext = _dp_operands(R, N, K, Rk, seed=61)
+    x = bf(torch.randn(R, K, device=dev()))
+    u = torch.zeros(R, 64, dtype=torch.bfloat16, device=dev())
+    out = torch.zeros(R, N, dtype=torch.bfloat16, device=dev())
+    touts = [torch.zeros(B, 32, 64, 32, dtype=torch.bfloat16, device=dev()) for _ in range(3)]
+    ops.dec_proj(x, w, acat, wext, u, out, K, tout=touts, t_rows=Ld)
+    u0, ref = torch.zeros_like(u), torch.zeros_like(out)
+    ops.lora_rows(x, acat, u0, K)
+    ops.gemm(x, w, ref, aext=u0, wext=wext)
+    assert rel(out.float(), ref.float()) < 4e-3
+    for j in range(3):
+        want = ops.head_transpose(out[:, j * 2048:(j + 1) * 2048].unflatten(1, (32, 64)).unflatten(0, (B, Ld)))
+        assert torch.equal(touts[j], want), j
+
+
 @pytest.mark.parametrize("R", [8, 14])
 def test_dec_proj_fused_rmsnorm_gated(ops, R):
     """wi_0 / wi_1: y = dropout(gelu(h0) * h1), out2 = [h0 | h1] — one launch vs rmsnorm_lora_fwd + the gated tile GEMM"""
