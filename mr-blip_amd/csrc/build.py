@@ -1,11 +1,18 @@
-"""Builds libmrblip_hip.so (gfx950 only) in-tree:  python mr-blip_amd/csrc/build.py [--force]"""
+"""Builds libmrblip_hip.so (gfx950 only) in-tree:  python mr-blip_amd/csrc/build.py [--force]
+
+Staleness is decided by CONTENT, not by mtime: every object carries a stamp file (<name>.o.sha) holding the SHA-256 of its source, of the
+shared headers, of the compiler flags and of `hipcc --version`; an object is rebuilt when the stamp is missing or differs.  The stamps (like
+the objects) are git-ignored but travel with a gpurun snapshot, so a fresh box whose sources match reuses the prebuilt objects, and any box
+whose sources differ rebuilds — whatever the file times say.  MRB_REBUILD=1 forces a full rebuild (the driver's "does it build" check)."""
 import concurrent.futures as cf
+import hashlib
 import os
 import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRCS = ["errors.hip", "gemm.hip", "norm.hip", "attention.hip", "elementwise.hip", "lora.hip", "decproj.hip"]
+HDRS = ["common.h"]
 LIB = os.path.join(HERE, "libmrblip_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast"] + os.environ.get("MRB_EXTRA_HIPCC_FLAGS", "").split()
@@ -16,37 +23,83 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=f
 # MFMA shadow); measured: T5-encoder attention backward 227 -> 217 us per layer, forward equal (profiles/r03_attention_variants.txt)
 FILE_FLAGS = {"attention.hip": ["-fno-slp-vectorize"]}
 
+_compiler_id = None
 
-def _stale(out, deps):
-    if not os.path.exists(out):
-        return True
-    t = os.path.getmtime(out)
-    return any(os.path.getmtime(d) > t for d in deps)
+
+def _compiler():
+    global _compiler_id
+    if _compiler_id is None:
+        try:
+            _compiler_id = subprocess.run([HIPCC, "--version"], capture_output=True, text=True).stdout
+        except OSError:
+            _compiler_id = "no hipcc"
+    return _compiler_id
+
+
+def _digest(src, flags):
+    h = hashlib.sha256()
+    for f in [src] + [os.path.join(HERE, x) for x in HDRS]:
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+        h.update(b"\0")
+    h.update(" ".join(flags).encode())
+    h.update(_compiler().encode())
+    return h.hexdigest()
+
+
+def _stamp(path):
+    try:
+        with open(path) as fh:
+            return fh.read().strip()
+    except OSError:
+        return None
 
 
 def build(force=False, verbose=True):
+    """Returns the library path.  ``build.last_rebuilt`` lists the objects compiled by the last call (empty = everything was current)."""
+    force = force or os.environ.get("MRB_REBUILD", "0") == "1"
     objs, jobs = [], []
-    hdr = os.path.join(HERE, "common.h")
     for s in SRCS:
         src = os.path.join(HERE, s)
         obj = os.path.join(HERE, s.replace(".hip", ".o"))
-        objs.append(obj)
-        if force or _stale(obj, [src, hdr, os.path.abspath(__file__)]):
-            jobs.append([HIPCC, *FLAGS, *FILE_FLAGS.get(s, []), "-c", src, "-o", obj])
+        flags = FLAGS + FILE_FLAGS.get(s, [])
+        dig = _digest(src, flags)
+        objs.append((obj, dig))
+        if force or not os.path.exists(obj) or _stamp(obj + ".sha") != dig:
+            jobs.append((obj, dig, [HIPCC, *flags, "-c", src, "-o", obj]))
+
     def run(cmd):
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed: %s\n%s" % (" ".join(cmd), r.stderr))
         return r.stderr
+
+    def compile_one(job):
+        obj, dig, cmd = job
+        if os.path.exists(obj + ".sha"):
+            os.remove(obj + ".sha")
+        err = run(cmd)
+        with open(obj + ".sha", "w") as fh:
+            fh.write(dig + "\n")
+        return err
+
     if jobs:
         with cf.ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
-            for err in ex.map(run, jobs):
+            for err in ex.map(compile_one, jobs):
                 if verbose and err.strip():
                     print(err, file=sys.stderr)
-    if jobs or force or _stale(LIB, objs):
-        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB])
+    link_dig = hashlib.sha256(" ".join(d for _, d in objs).encode()).hexdigest()
+    if jobs or force or not os.path.exists(LIB) or _stamp(LIB + ".sha") != link_dig:
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *[o for o, _ in objs], "-o", LIB])
+        with open(LIB + ".sha", "w") as fh:
+            fh.write(link_dig + "\n")
+    build.last_rebuilt = [os.path.basename(j[0]) for j in jobs]
     return LIB
+
+
+build.last_rebuilt = []
 
 
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv))
+    print("rebuilt:", build.last_rebuilt or "nothing (all objects current by content hash)")

@@ -34,7 +34,7 @@ struct DecProjArgs {
   DropoutArg in_drop, out_drop, ext_drop;
   // mode 0 only: head-transposed copies of up to three consecutive column ranges of width t_inner (q | k | v of a fused projection, or one
   // range = the whole output): tout[j][b][h][d][s] = out[b * t_rows + s][j * t_inner + h * 64 + d] — what mrblip_head_transpose would
-  // write (zero padding of the destination is the caller's: the buffers are zero-initialised once and only valid entries are written)
+  // write, INCLUDING the zero pad columns [t_rows, t_spad) of every (clip, head, d) row, which the lane of the clip's last position clears on every call)
   bf16_t* tout[3]; int t_inner, t_rows, t_spad; long long t_bs, t_hs;
 };
 
@@ -287,6 +287,12 @@ __global__ __launch_bounds__(512) void dec_proj_kernel(const DecProjArgs p) {
               bf16_t* q = td + bb * p.t_bs + hh * p.t_hs + (long long)d0 * p.t_spad + ss;
               q[0] = (bf16_t)(ob.x & 0xffffu); q[p.t_spad] = (bf16_t)(ob.x >> 16);
               q[2 * p.t_spad] = (bf16_t)(ob.y & 0xffffu); q[3 * p.t_spad] = (bf16_t)(ob.y >> 16);
+              // the pad columns [t_rows, t_spad) of the (clip, head, d) rows this lane owns: zeroed on EVERY call by the lane of the
+              // clip's last position, like head_transpose does — the workspaces are capacity-based views (engine.buf), so when the label
+              // length or the batch changes between steps a tile may hold another layout's values there
+              if (ss == p.t_rows - 1) {
+                for (int z = 1; z < p.t_spad - ss; ++z) { q[z] = 0; q[p.t_spad + z] = 0; q[2 * p.t_spad + z] = 0; q[3 * p.t_spad + z] = 0; }
+              }
             }
           }
         }

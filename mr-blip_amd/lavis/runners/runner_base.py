@@ -149,6 +149,7 @@ class RunnerBase:
                                               accum_grad_iters=run.get("accum_grad_iters", 1), reduce_grads=self._reduce_grads,
                                               arm_exchange=self._arm_exchange)
                 self.log_stats(stats, "train")
+                self._check_loss_scale()
             for split in run.get("valid_splits", []):
                 m = self.eval_epoch(split, epoch)
                 if m is not None and is_main_process() and split == "val":
@@ -199,8 +200,23 @@ class RunnerBase:
         return self.task.after_evaluation(val_result=results, split_name=split_name, epoch=cur_epoch)
 
     # ---- checkpoints: trainable tensors only (runner_base.py:572-600)
-    @main_process
+    def _check_loss_scale(self):
+        """The fused-accumulation loss-scale check of the model is deferred (its verdict is read one step late so that the host never
+        drains the stream, blip2_mr.py: _check_fused_scale): a violation on the LAST micro-steps of an epoch would otherwise surface only
+        in the next epoch — or never, at the end of the run.  Blocking form at every epoch end and before every checkpoint: weights that a
+        wrongly scaled backward may have touched are never written out silently.  (On every rank: the error must not leave the others
+        waiting in a barrier.)"""
+        m = self.model.module if hasattr(self.model, "module") else self.model
+        chk = getattr(m, "check_fused_scale_now", None)
+        if chk is not None:
+            chk()
+
     def _save_checkpoint(self, cur_epoch, is_best=False):
+        self._check_loss_scale()
+        self._write_checkpoint(cur_epoch, is_best)
+
+    @main_process
+    def _write_checkpoint(self, cur_epoch, is_best=False):
         obj = {"model": self.model.state_dict(), "optimizer": self.optimizer.state_dict(), "config": self.config.to_dict(), "epoch": cur_epoch}
         path = os.path.join(self.output_dir, "checkpoint_{}.pth".format("best" if is_best else cur_epoch))
         logging.info("Saving checkpoint at epoch {} to {}.".format(cur_epoch, path))

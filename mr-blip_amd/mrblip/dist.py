@@ -158,6 +158,38 @@ class FrameShard:
         self.counts: List[int] = [base + (1 if r < rem else 0) for r in range(self.world)]
         self.starts: List[int] = [sum(self.counts[:r]) for r in range(self.world)]
         self.T = T
+        self._attached = None
+
+    def attach(self, engine, check: bool = True):
+        """Make ``engine`` a member of this shard group (called by forward_backward on the first sharded step; idempotent).  The slice-
+        instead-of-reduce-scatter of the frame-token gradient and the un-reduced LoRA gradients are valid ONLY if every rank runs a
+        bit-identical T5, i.e. the same dropout seed at the same position of its per-step sequence: rank 0's device seed is broadcast to
+        the group (train.py seeds every rank with run.seed + rank — those streams must not be used here), and later steps bump it
+        identically on every rank (ops.seed_bump).  The Q-Former, whose rows are this rank's LOCAL frames, gets rank-salted call-site
+        ids so that different frames do not draw the same masks on different ranks."""
+        if self._attached is engine:
+            return
+        self._attached = engine
+        if self.world == 1:
+            return
+        backend = dist.get_backend(self.group)
+        seed = engine.seed if backend == "nccl" else engine.seed.cpu()
+        dist.broadcast(seed, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+        engine.seed.copy_(seed)
+        engine.qf_site_salt = self.rank << 20      # call-site ids are small integers (engine.new_site): no collision with any other site
+        if check:
+            self.assert_same_seed(engine)
+
+    def assert_same_seed(self, engine):
+        """cheap guard (one 2-element all-reduce): every rank of the group holds the same device seed"""
+        if self.world == 1:
+            return
+        v = engine.seed.to(torch.int64).cpu()
+        mm = torch.stack([v[0], -v[0]])
+        dist.all_reduce(mm, op=dist.ReduceOp.MAX, group=self.group)
+        if int(mm[0]) != -int(mm[1]):
+            raise RuntimeError(f"frame-sharded mode: dropout seeds differ across the shard group (max {int(mm[0])}, min {-int(mm[1])}): "
+                               "the replicated T5 would draw different masks and the sliced frame-token gradient would be wrong")
 
     @property
     def t0(self) -> int:

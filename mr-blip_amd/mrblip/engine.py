@@ -37,8 +37,6 @@ _ENC_FWD_CFG = (tuple(int(x) for x in os.environ.get("MRB_ENC_FWD_CFG", "0,0,0,0
 _ENC_BWD_CFG = (tuple(int(x) for x in os.environ.get("MRB_ENC_BWD_CFG", "0,0,0,0").split(",")) + (0, 0, 0, 0))[:4]
 
 # tile configs of the ViT qkv / proj / fc2 / fc1 GEMMs (0 = the library's own choice); MRB_VIT_CFG="q,p,f2,f1" overrides for experiments
-# timing probe only (WRONG results): the decoder's cross-attention launches are skipped — "how much does the step care about the decoder window?"
-_EXP_SKIP_DEC_CROSS = os.environ.get("MRB_EXP_SKIP_DEC_CROSS", "0") == "1"
 _VIT_CFG = (tuple(int(x) for x in os.environ.get("MRB_VIT_CFG", "0,0,0,0").split(",")) + (0, 0, 0, 0))[:4]
 
 
@@ -207,7 +205,8 @@ class MrBlipEngine:
         Why views are safe for the zero-padded operands: padding is either COLUMN padding at fixed positions of a row (K padded to
         64, the 8 n_adapter columns of the [M, 64] LoRA activations: never written, so they stay at their initial zeros whatever the
         row count), or it is written by the producing kernel itself on every call (head_transpose writes the whole [DP, Spad] tile
-        with zeros outside the tensor; pad_mask builds a fresh mask), or it is never read (LSE / Delta / keep-bit rows past Sq)."""
+        with zeros outside the tensor, and so does the fused decoder projection for the head-transposed copies it emits: csrc/decproj.hip;
+        pad_mask builds a fresh mask), or it is never read (LSE / Delta / keep-bit rows past Sq)."""
         shape = tuple(int(s) for s in shape)
         n = 1
         for v in shape:
@@ -258,6 +257,14 @@ class MrBlipEngine:
 
     def drop(self, site: int, p: float):
         return ops.Dropout(self.seed, site, p) if (self.training and p > 0) else None
+
+    # Frame-sharded mode (dist.FrameShard.attach): the ranks of a shard group share ONE dropout seed (the T5 is replicated and must draw the
+    # same masks everywhere), but each rank's LOCAL frames start at row 0 of its Q-Former buffers — with the shared seed the ranks would
+    # draw identical Q-Former masks for different frames.  The Q-Former's call-site ids are therefore salted per rank (0 outside that mode).
+    qf_site_salt = 0
+
+    def qdrop(self, site: int, p: float):
+        return self.drop(site + self.qf_site_salt, p)
 
     def _w(self, w: torch.Tensor, n_pad: Optional[int] = None) -> torch.Tensor:
         """fp32 [N,K] -> bf16 [Np, pad64(K)] zero padded"""
@@ -423,7 +430,7 @@ class MrBlipEngine:
         x = self.buf("qf_x0", (Mq, D), f32, zero=False)
         ops.layernorm_fwd(q_exp, self.qf["emb_w"], self.qf["emb_b"], eps, out_f32=x)
         xb = self.buf("qf_xb0", (Mq, pad64(D)), bf16)
-        ops.cast_dropout(x, out_bf16=xb, out_f32=x, drop=self.drop(self.qf_emb_site, pdrop))
+        ops.cast_dropout(x, out_bf16=xb, out_f32=x, drop=self.qdrop(self.qf_emb_site, pdrop))
         vt_s = self.buf("qf_vt_s", (F_, H, ops.rup32(hd), ops.rup32(nq)), bf16)
         vt_c = self.buf("qf_vt_c", (F_, H, ops.rup32(hd), ops.rup32(Tv)), bf16)
         for i, L in enumerate(self.qf["layers"]):
@@ -434,9 +441,9 @@ class MrBlipEngine:
             ops.head_transpose(v4, out=vt_s)
             o = self.buf(f"qf{i}_o", (Mq, pad64(D)), bf16)
             lse = self.buf(f"qf{i}_lse", (F_, H, ops.rup32(nq)), f32)
-            ops.attention_fwd(q4, k4, vt_s, self.v4(o, F_, nq, H, hd), lse, scale=scale, drop=self.drop(S_["sites"][0], pdrop))
+            ops.attention_fwd(q4, k4, vt_s, self.v4(o, F_, nq, H, hd), lse, scale=scale, drop=self.qdrop(S_["sites"][0], pdrop))
             y = self.buf(f"qf{i}_y", (Mq, D), f32, zero=False)
-            ops.gemm(o, S_["ow"], y, bias=S_["ob"], residual=x, drop=self.drop(S_["sites"][1], pdrop))
+            ops.gemm(o, S_["ow"], y, bias=S_["ob"], residual=x, drop=self.qdrop(S_["sites"][1], pdrop))
             x = self.buf(f"qf{i}_x1", (Mq, D), f32, zero=False)
             xb = self.buf(f"qf{i}_x1b", (Mq, pad64(D)), bf16)
             ops.layernorm_fwd(y, S_["lnw"], S_["lnb"], eps, out_bf16=xb, out_f32=x)
@@ -450,9 +457,9 @@ class MrBlipEngine:
                 ops.head_transpose(v4, out=vt_c)
                 oc = self.buf(f"qf{i}_oc", (Mq, pad64(D)), bf16)
                 lsec = self.buf(f"qf{i}_lsec", (F_, H, ops.rup32(nq)), f32)
-                ops.attention_fwd(self.v4(qc, F_, nq, H, hd), k4, vt_c, self.v4(oc, F_, nq, H, hd), lsec, scale=scale, drop=self.drop(C_["sites"][0], pdrop))
+                ops.attention_fwd(self.v4(qc, F_, nq, H, hd), k4, vt_c, self.v4(oc, F_, nq, H, hd), lsec, scale=scale, drop=self.qdrop(C_["sites"][0], pdrop))
                 y2 = self.buf(f"qf{i}_y2", (Mq, D), f32, zero=False)
-                ops.gemm(oc, C_["ow"], y2, bias=C_["ob"], residual=x, drop=self.drop(C_["sites"][1], pdrop))
+                ops.gemm(oc, C_["ow"], y2, bias=C_["ob"], residual=x, drop=self.qdrop(C_["sites"][1], pdrop))
                 x = self.buf(f"qf{i}_x2", (Mq, D), f32, zero=False)
                 xb = self.buf(f"qf{i}_x2b", (Mq, pad64(D)), bf16)
                 ops.layernorm_fwd(y2, C_["lnw"], C_["lnb"], eps, out_bf16=xb, out_f32=x)
@@ -460,7 +467,7 @@ class MrBlipEngine:
             hpre = self.buf(f"qf{i}_hpre", (Mq, pad64(I)), bf16, zero=False)
             ops.gemm(xb, L["iw"], hact, bias=L["ib"], act=1, out2=hpre)
             y3 = self.buf(f"qf{i}_y3", (Mq, D), f32, zero=False)
-            ops.gemm(hact, L["ow"], y3, bias=L["ob"], residual=x, drop=self.drop(L["site"], pdrop))
+            ops.gemm(hact, L["ow"], y3, bias=L["ob"], residual=x, drop=self.qdrop(L["site"], pdrop))
             x = self.buf(f"qf{i}_x3", (Mq, D), f32, zero=False)
             xb = self.buf(f"qf{i}_x3b", (Mq, pad64(D)), bf16)
             ops.layernorm_fwd(y3, L["lnw"], L["lnb"], eps, out_bf16=xb, out_f32=x)
@@ -497,7 +504,7 @@ class MrBlipEngine:
             nxt = self.buf(f"qf_dx_{i % 2}", (Mq, D), f32, zero=False)
             # FFN: x3 = LN(y3), y3 = x2 + drop(dense(gelu(dense_i(x2b))))
             ops.layernorm_bwd(cur, self.ws[f"qf{i}_y3"], L["lnw"], eps, dy)
-            ops.cast_dropout(dy, out_bf16=dyb, drop=self.drop(L["site"], pdrop))
+            ops.cast_dropout(dy, out_bf16=dyb, drop=self.qdrop(L["site"], pdrop))
             ops.gemm(dyb, L["owt"], dh)
             ops.gelu_bwd(dh, self.ws[f"qf{i}_hpre"], dhp)
             ops.gemm(dhp, L["iwt"], nxt, residual=dy)
@@ -506,7 +513,7 @@ class MrBlipEngine:
                 C_ = L["cross"]
                 nxt = self.buf(f"qf_dxc_{i % 2}", (Mq, D), f32, zero=False)
                 ops.layernorm_bwd(cur, self.ws[f"qf{i}_y2"], C_["lnw"], eps, dy)
-                ops.cast_dropout(dy, out_bf16=dyb, drop=self.drop(C_["sites"][1], pdrop))
+                ops.cast_dropout(dy, out_bf16=dyb, drop=self.qdrop(C_["sites"][1], pdrop))
                 ops.gemm(dyb, C_["owt"], do)
                 qc, kv, oc = self.ws[f"qf{i}_qc"], self.ws[f"qf{i}_kvc"], self.ws[f"qf{i}_oc"]
                 q4, k4, v4 = self.v4(qc, F_, nq, H, hd), self.v4(kv, F_, Tv, H, hd, 0), self.v4(kv, F_, Tv, H, hd, D)
@@ -516,7 +523,7 @@ class MrBlipEngine:
                 ops.head_transpose(do4, out=dot_s)
                 ops.attention_bwd(q4, k4, v4, self.v4(oc, F_, nq, H, hd), do4, kt_c, qt_s, dot_s, self.ws[f"qf{i}_lsec"], delta,
                                   self.v4(dqc, F_, nq, H, hd), self.v4(dkv, F_, Tv, H, hd, 0), self.v4(dkv, F_, Tv, H, hd, D),
-                                  scale=scale, drop=self.drop(C_["sites"][0], pdrop))
+                                  scale=scale, drop=self.qdrop(C_["sites"][0], pdrop))
                 ops.gemm(dkv, C_["kv_wt"], dimg, residual=dimg)
                 if i > 0:
                     ops.gemm(dqc, C_["q_wt"], nxt, residual=dy)
@@ -526,7 +533,7 @@ class MrBlipEngine:
             S_ = L["self"]
             nxt = self.buf(f"qf_dxs_{i % 2}", (Mq, D), f32, zero=False)
             ops.layernorm_bwd(cur, self.ws[f"qf{i}_y"], S_["lnw"], eps, dy)
-            ops.cast_dropout(dy, out_bf16=dyb, drop=self.drop(S_["sites"][1], pdrop))
+            ops.cast_dropout(dy, out_bf16=dyb, drop=self.qdrop(S_["sites"][1], pdrop))
             ops.gemm(dyb, S_["owt"], do)
             qkv, o = self.ws[f"qf{i}_qkv"], self.ws[f"qf{i}_o"]
             q4, k4, v4 = self.v4(qkv, F_, nq, H, hd, 0), self.v4(qkv, F_, nq, H, hd, D), self.v4(qkv, F_, nq, H, hd, 2 * D)
@@ -536,7 +543,7 @@ class MrBlipEngine:
             ops.head_transpose(do4, out=dot_s)
             ops.attention_bwd(q4, k4, v4, self.v4(o, F_, nq, H, hd), do4, kt_s, qt_s, dot_s, self.ws[f"qf{i}_lse"], delta,
                               self.v4(dqkv, F_, nq, H, hd, 0), self.v4(dqkv, F_, nq, H, hd, D), self.v4(dqkv, F_, nq, H, hd, 2 * D),
-                              scale=scale, drop=self.drop(S_["sites"][0], pdrop))
+                              scale=scale, drop=self.qdrop(S_["sites"][0], pdrop))
             ops.gemm(dqkv, S_["qkv_wt"], nxt, residual=dy)
             cur = nxt
         return dimg
@@ -1122,8 +1129,7 @@ class MrBlipEngine:
                 if ready is not None:
                     torch.cuda.current_stream().wait_event(ready)
                 lsec = self.buf(f"d{i}_lsec", (B, H, ops.rup32(Ld)), f32)
-                if not _EXP_SKIP_DEC_CROSS:
-                    ops.attention_fwd(self.v4(cq, B, Ld, H, dk), ck4, vt_i, self.v4(co, B, Ld, H, dk), lsec, scale=1.0, kmask=kmask, drop=self.drop(L["sites"][2], p))
+                ops.attention_fwd(self.v4(cq, B, Ld, H, dk), ck4, vt_i, self.v4(co, B, Ld, H, dk), lsec, scale=1.0, kmask=kmask, drop=self.drop(L["sites"][2], p))
             else:
                 Bc = cross_batch
                 rows = (B // Bc) * Ld  # query rows per encoder sequence: beams x positions
@@ -1294,10 +1300,9 @@ class MrBlipEngine:
                 ops.head_transpose(q4, out=qt_s)
             if not dot_done:
                 ops.head_transpose(do4, out=dot_s)
-            if not _EXP_SKIP_DEC_CROSS:
-                ops.attention_bwd(q4, k4, v4, self.v4(co, B, Ld, H, dk), do4, kt_c, qt_x, dot_s, self.ws[f"d{i}_lsec"], delta,
-                                  self.v4(dcq, B, Ld, H, dk), self.v4(dckv, B, S, H, dk, 0), self.v4(dckv, B, S, H, dk, inner),
-                                  scale=1.0, kmask=kmask, drop=self.drop(L["sites"][2], p))
+            ops.attention_bwd(q4, k4, v4, self.v4(co, B, Ld, H, dk), do4, kt_c, qt_x, dot_s, self.ws[f"d{i}_lsec"], delta,
+                              self.v4(dcq, B, Ld, H, dk), self.v4(dckv, B, S, H, dk, 0), self.v4(dckv, B, S, H, dk, inner),
+                              scale=1.0, kmask=kmask, drop=self.drop(L["sites"][2], p))
             if dside:   # queued: goes out with the cq group's record
                 ge_i, u_ckv_i = self.buf(f"db_ge{i}", (Me, 64), bf16), self.ws[f"d{i}_u_ckv"]
                 self.side_defer(lambda L=L, dckv=dckv, ge_i=ge_i, u_ckv_i=u_ckv_i: self.lg_bwd(L["ckv"], dckv, enc, u_ckv_i, ge_i, denc, residual=denc))
@@ -1487,6 +1492,7 @@ class MrBlipEngine:
         sharded = shard is not None and shard.world > 1
         if sharded:
             assert Bv == 1 and T == shard.counts[shard.rank], "frame-sharded mode: one clip, this rank's frames only"
+            shard.attach(self)   # (first step only) one dropout stream for the group's replicated T5, per-rank Q-Former call sites
         if self.training:
             ops.seed_bump(self.seed)
         self._mark("start")
@@ -1593,14 +1599,15 @@ class MrBlipEngine:
         """logical dropout site (named after the reference's nn.Dropout modules) -> (call-site id, p, kind); used by the parity
         tests to rebuild the exact masks of a training step on the CPU oracle."""
         c = self.cfg
-        m = {"qf.emb": (self.qf_emb_site, c.qf_dropout, "2d")}
+        q = self.qf_site_salt
+        m = {"qf.emb": (self.qf_emb_site + q, c.qf_dropout, "2d")}
         for i, L in enumerate(self.qf["layers"]):
-            m[f"qf.{i}.self.attn"] = (L["self"]["sites"][0], c.qf_dropout, "attn")
-            m[f"qf.{i}.self.out"] = (L["self"]["sites"][1], c.qf_dropout, "2d")
+            m[f"qf.{i}.self.attn"] = (L["self"]["sites"][0] + q, c.qf_dropout, "attn")
+            m[f"qf.{i}.self.out"] = (L["self"]["sites"][1] + q, c.qf_dropout, "2d")
             if L["cross"] is not None:
-                m[f"qf.{i}.cross.attn"] = (L["cross"]["sites"][0], c.qf_dropout, "attn")
-                m[f"qf.{i}.cross.out"] = (L["cross"]["sites"][1], c.qf_dropout, "2d")
-            m[f"qf.{i}.ffn.out"] = (L["site"], c.qf_dropout, "2d")
+                m[f"qf.{i}.cross.attn"] = (L["cross"]["sites"][0] + q, c.qf_dropout, "attn")
+                m[f"qf.{i}.cross.out"] = (L["cross"]["sites"][1] + q, c.qf_dropout, "2d")
+            m[f"qf.{i}.ffn.out"] = (L["site"] + q, c.qf_dropout, "2d")
         p = c.t5_dropout
         for k, j in (("t5.enc.emb", 0), ("t5.enc.final", 1), ("t5.dec.emb", 2), ("t5.dec.final", 3)):
             m[k] = (self.t5["sites"][j], p, "2d")

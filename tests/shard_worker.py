@@ -13,7 +13,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 
-def main(out_path, mean_pool):
+def main(out_path, mean_pool, training="0"):
     from mrblip import prompt as P
     from mrblip.dist import FrameShard
     from mrblip.engine import EngineConfig, MrBlipEngine, StateDictSource
@@ -30,8 +30,12 @@ def main(out_path, mean_pool):
     repl = P.annoying_replacement_dict(P.find_annoying_numbers(tok, 200)[0])
     s = {k: v[:1] for k, v in _samples(g).items()}
     T = s["video"].shape[1]
-    eng = MrBlipEngine(EngineConfig.tiny(mean_pool=mean), StateDictSource(_peft_sd(golden_state_dict(g))), torch.device("cuda:0"), seed=42)
-    eng.training = False
+    train = bool(int(training))
+    # training mode: the ranks are DELIBERATELY built with different dropout seeds (what train.py's run.seed + rank gives every engine);
+    # FrameShard.attach must put the group on rank 0's stream, or the replicated T5 draws different masks per rank
+    eng = MrBlipEngine(EngineConfig.tiny(mean_pool=mean), StateDictSource(_peft_sd(golden_state_dict(g))), torch.device("cuda:0"),
+                       seed=42 + (rank if train else 0))
+    eng.training = train
     lay = P.build_layout(tok, s, repl, 1 if mean else 8, T=T)
     fs = FrameShard(T)
     local = s["video"][:, fs.t0: fs.t1].cuda().contiguous()
@@ -39,13 +43,23 @@ def main(out_path, mean_pool):
     loss = eng.forward_backward(local, lay, backward=True, shard=fs)
     fs.combine_grads(eng)
     torch.cuda.synchronize()
+    if train:   # a second step: the per-step seed bump must keep the ranks together
+        eng.zero_grad()
+        loss = eng.forward_backward(local, lay, backward=True, shard=fs)
+        fs.combine_grads(eng)
+        torch.cuda.synchronize()
     grads = [torch.zeros_like(eng.grad, device="cpu") for _ in range(fs.world)]
     dist.all_gather(grads, eng.grad.cpu())
+    losses = [torch.zeros(1) for _ in range(fs.world)]
+    dist.all_gather(losses, loss.detach().float().cpu().reshape(1))
+    seeds = [torch.zeros(1, dtype=torch.int32) for _ in range(fs.world)]
+    dist.all_gather(seeds, eng.seed.cpu())
     if rank == 0:
-        torch.save({"grad": grads[0], "grad_other": grads[1], "loss": loss.item(), "n_lora": eng.n_lora, "counts": fs.counts}, out_path)
+        torch.save({"grad": grads[0], "grad_other": grads[1], "loss": loss.item(), "n_lora": eng.n_lora, "counts": fs.counts,
+                    "losses": [float(x) for x in losses], "seeds": [int(x) for x in seeds], "qf_salt": eng.qf_site_salt}, out_path)
     dist.barrier()
     dist.destroy_process_group()
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    main(*sys.argv[1:4])

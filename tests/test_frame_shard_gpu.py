@@ -47,3 +47,24 @@ def test_frame_sharded_step_equals_unsharded(tmp_path, mean):
     check(tag + "t5_proj / ln_vision grads (summed over ranks) vs unsharded", relerr(sh["grad"][nl:], ref[nl:]), 2e-5)
     check(tag + "combined tail identical on both ranks", relerr(sh["grad_other"][nl:], sh["grad"][nl:]), 1e-7)
     assert ref[nl:].abs().sum() > 0
+
+
+def test_frame_sharded_training_step_keeps_the_replicated_t5_identical(tmp_path):
+    """the slice that replaces the reduce-scatter of the frame-token gradient, and the un-reduced LoRA gradients, are
+    valid only if every rank runs a bit-identical T5 — same dropout seed, same bump position.  The two ranks are built with DIFFERENT
+    seeds (run.seed + rank, as train.py seeds them) and run two TRAINING steps: FrameShard.attach must have put them on rank 0's stream
+    (equal device seeds after two bumps), the replicated T5's loss and every LoRA gradient must agree bit for bit across the ranks, and the
+    Q-Former call sites must be rank-salted (local frames start at row 0 on every rank: unsalted, different frames would share masks)."""
+    out = str(tmp_path / "shard_train.pt")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+           str(free_port()), os.path.join(ROOT, "tests", "shard_worker.py"), out, "0", "1"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-3000:])
+    sh = torch.load(out)
+    nl = sh["n_lora"]
+    assert sh["seeds"][0] == sh["seeds"][1], sh["seeds"]
+    assert sh["losses"][0] == sh["losses"][1], sh["losses"]
+    assert torch.equal(sh["grad"][:nl], sh["grad_other"][:nl])           # replicated T5: identical LoRA gradients, no reduction needed
+    assert torch.equal(sh["grad"][nl:], sh["grad_other"][nl:])           # t5_proj / ln_vision: summed over the ranks' local frames
+    assert sh["grad"][:nl].abs().sum() > 0 and sh["grad"][nl:].abs().sum() > 0 and torch.isfinite(sh["grad"]).all()
+    assert sh["qf_salt"] == 0   # rank 0's salt; rank r uses r << 20 (mrblip/dist.py: FrameShard.attach)

@@ -877,7 +877,8 @@ def test_dec_proj_fused_rmsnorm_bf16_out(ops, R, N, Rk):
         check(tag + "out", rel(out.float(), ref.float()), 4e-3)
         if N % 2048 == 0:   # head-transposed copies of the 2048-wide column ranges (32 heads x 64): what head_transpose writes from the output
             nj = N // 2048
-            touts = [torch.zeros(1, 32, 64, 32, dtype=torch.bfloat16, device=dev()) for _ in range(nj)]
+            # (stale contents of another layout in the tiles: the kernel must write the pad columns too — capacity-based workspaces)
+            touts = [torch.full((1, 32, 64, 32), 7.5, dtype=torch.bfloat16, device=dev()) for _ in range(nj)]
             out_t = torch.zeros_like(ref)
             ops.dec_proj(xn1, w, acat, wext, u1, out_t, K, x32=x32, gamma=gamma, eps=1e-6, in_drop=ldrop, tout=touts, t_rows=R)
             assert torch.equal(out_t, out)
@@ -895,7 +896,7 @@ def test_dec_proj_head_transposed_copies_for_a_batch_of_clips(ops):
     x = bf(torch.randn(R, K, device=dev()))
     u = torch.zeros(R, 64, dtype=torch.bfloat16, device=dev())
     out = torch.zeros(R, N, dtype=torch.bfloat16, device=dev())
-    touts = [torch.zeros(B, 32, 64, 32, dtype=torch.bfloat16, device=dev()) for _ in range(3)]
+    touts = [torch.full((B, 32, 64, 32), float("nan"), dtype=torch.bfloat16, device=dev()) for _ in range(3)]   # stale tiles of another layout
     ops.dec_proj(x, w, acat, wext, u, out, K, tout=touts, t_rows=Ld)
     u0, ref = torch.zeros_like(u), torch.zeros_like(out)
     ops.lora_rows(x, acat, u0, K)
@@ -904,6 +905,24 @@ def test_dec_proj_head_transposed_copies_for_a_batch_of_clips(ops):
     for j in range(3):
         want = ops.head_transpose(out[:, j * 2048:(j + 1) * 2048].unflatten(1, (32, 64)).unflatten(0, (B, Ld)))
         assert torch.equal(touts[j], want), j
+
+
+def test_dec_proj_head_transposed_copies_when_the_label_length_changes(ops):
+    """the head-transposed copies live in capacity-based workspaces (engine.buf hands out VIEWS of one backing store), so a step
+    with another label length finds the previous layout's values in the tile.  Ld 40 -> 12 -> 40 crosses a multiple of 32 in both
+    directions (t_spad 64 -> 32 -> 64) on the d_kv = 64 path: every call must equal head_transpose of its own output, pads included."""
+    N, K, Rk = 2048, 2048, 8
+    store = torch.zeros(32 * 64 * 64, dtype=torch.bfloat16, device=dev())      # one backing store, sized for the longest layout
+    for Ld in (40, 12, 40):
+        w, acat, wext = _dp_operands(Ld, N, K, Rk, seed=70 + Ld)
+        x = bf(torch.randn(Ld, K, device=dev()))
+        u = torch.zeros(Ld, 64, dtype=torch.bfloat16, device=dev())
+        out = torch.zeros(Ld, N, dtype=torch.bfloat16, device=dev())
+        spad = ops.rup32(Ld)
+        tile = store[: 32 * 64 * spad].view(1, 32, 64, spad)                     # what engine.buf returns for this shape
+        ops.dec_proj(x, w, acat, wext, u, out, K, tout=(tile,), t_rows=Ld)
+        want = ops.head_transpose(out.unflatten(1, (32, 64)).unsqueeze(0))
+        assert torch.equal(tile, want), Ld
 
 
 @pytest.mark.parametrize("R", [8, 14])
