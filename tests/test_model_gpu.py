@@ -24,7 +24,7 @@ def _engine(sd, **kw):
     return eng
 
 
-def _peft_sd(sd, with_lora=True, seed=0):
+def _peft_sd(sd, with_lora=True, seed=0, lora_std=None):
     """rename T5 Linear weights to peft's names and add seeded non-zero LoRA A/B (the reference wraps T5 with peft)."""
     from weights import seeded_array
 
@@ -40,8 +40,8 @@ def _peft_sd(sd, with_lora=True, seed=0):
             base = "t5_model.base_model.model." + rest[: -len(".weight")]
             out[base + ".base_layer.weight"] = v
             o, i = v.shape
-            out[base + ".lora_A.default.weight"] = torch.from_numpy(seeded_array(base + ".lora_A.default.weight", (8, i)))
-            out[base + ".lora_B.default.weight"] = torch.from_numpy(seeded_array(base + ".lora_B.default.weight", (o, 8)))
+            out[base + ".lora_A.default.weight"] = torch.from_numpy(seeded_array(base + ".lora_A.default.weight", (8, i), std=lora_std))
+            out[base + ".lora_B.default.weight"] = torch.from_numpy(seeded_array(base + ".lora_B.default.weight", (o, 8), std=lora_std))
         else:
             out["t5_model.base_model.model." + rest if with_lora else k] = v
     return out

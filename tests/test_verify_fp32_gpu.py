@@ -77,3 +77,23 @@ def test_fp32_operand_mode_c1_real_depth():
     check("c1.verify-fp32: inputs_embeds vs reference-fp32", relerr(emb.view(1, lay.S, 768)[..., ::4].cpu(), g["inputs_embs_sub"]), 2.5e-5)
     check("c1.verify-fp32: logits vs reference-fp32", relerr(lg[..., ::64], g["logits_sub"]), 5e-5)
     check("c1.verify-fp32: loss vs reference-fp32 (rel)", abs(loss - float(g["loss"])) / abs(float(g["loss"])), 2e-6)
+
+
+def test_fp32_operand_mode_c2_benched_size():
+    """VERDICT r3 missing 6 / next 3(b): the same verification AT THE BENCHED SIZE (BASELINE.json configs[1]: 60 frames, Flan-T5-XL dims, 24 + 24
+    layers, S_enc = 2012) against the reference's own fp32 run of that size (tests/golden/mr_c2.npz): the 9e-3 logits gap of the product
+    path at C2 is operand rounding, not logic."""
+    from test_fullsize_gpu import _c2_setup
+
+    eng, src, lay, video, g, T = _c2_setup()
+    eng._verify_src = src
+    loss, logits, emb, xv, qf = _run(eng, video.cuda(), lay)
+    lg = logits.cpu().view(1, -1, 32128)
+    S, d = lay.S, 2048
+    check("c2.verify-fp32: vit.out (60 frames) vs reference-fp32", relerr(xv.view(T, 257, 1408)[::6, ::16, ::16].cpu(), g["vit_sub"]), 3e-5)
+    check("c2.verify-fp32: qformer.out vs reference-fp32", relerr(qf.view(T, 32, 768)[::6, ::4, ::8].cpu(), g["qf_sub"]), 3e-5)
+    check("c2.verify-fp32: inputs_embeds vs reference-fp32", relerr(emb.view(1, S, d)[:, ::4, ::16].cpu(), g["inputs_embs_sub"]), 3e-5)
+    check("c2.verify-fp32: logits vs reference-fp32", relerr(lg[..., ::64], g["logits_sub"]), 1e-4)
+    check("c2.verify-fp32: loss vs reference-fp32 (rel)", abs(loss - float(g["loss"])) / abs(float(g["loss"])), 5e-6)
+    del eng
+    torch.cuda.empty_cache()
