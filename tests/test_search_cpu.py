@@ -59,3 +59,79 @@ def test_beam_search_equals_hf_generate(seed, eos_boost):
                     assert mine == r[:len(mine)] and all(t == 0 for t in r[len(mine):]), (seed, K, lp, max_new, b, mine, r)
                     n_eos_end += int(mine[-1] == 1)
     assert eos_boost == 1.0 or n_eos_end > 0      # the boosted runs really exercise finished hypotheses
+
+
+@pytest.mark.parametrize("seed,eos_boost", [(3, 1.0), (4, 2.5)])
+def test_repetition_penalty_and_num_return_sequences_equal_hf_generate(seed, eos_boost):
+    """generate(repetition_penalty != 1, num_captions > 1) as the reference passes them to HF (blip2_mr.py:883-899)"""
+    from mrblip.search import beam_search
+
+    m = _model(seed, eos_boost)
+    B, S = 2, 6
+    g = torch.Generator().manual_seed(200 + seed)
+    emb = torch.randn(B, S, 32, generator=g)
+    mask = torch.ones(B, S, dtype=torch.long)
+    with torch.no_grad():
+        enc = m.encoder(inputs_embeds=emb, attention_mask=mask).last_hidden_state
+
+    def step(seqs):
+        rep = seqs.shape[0] // B
+        with torch.no_grad():
+            out = m(encoder_outputs=(enc.repeat_interleave(rep, 0),), attention_mask=mask.repeat_interleave(rep, 0), decoder_input_ids=seqs)
+        return torch.log_softmax(out.logits[:, -1].float(), -1)
+
+    for K, n_ret, pen in ((3, 1, 1.3), (4, 3, 1.0), (5, 2, 2.0), (1, 1, 1.5)):
+        with torch.no_grad():
+            ref = m.generate(inputs_embeds=emb, attention_mask=mask, do_sample=False, num_beams=K, max_new_tokens=8, min_length=1, length_penalty=1.0,
+                             num_return_sequences=n_ret, repetition_penalty=pen, early_stopping=False)
+        if K == 1:   # one beam = HF's greedy decoding: the penalty acts on RAW logits (BLIP2_MR.generate routes it the same way)
+            from mrblip.search import sample_search
+
+            def step_raw(seqs):
+                with torch.no_grad():
+                    return m(encoder_outputs=(enc,), attention_mask=mask, decoder_input_ids=seqs).logits[:, -1].float()
+
+            got = sample_search(step_raw, B, 1, 8, min_length=1, repetition_penalty=pen, greedy=True)
+        else:
+            got = beam_search(step, B, K, 8, min_length=1, length_penalty=1.0, repetition_penalty=pen, num_return=n_ret)
+        assert len(got) == B * n_ret == ref.shape[0]
+        for i in range(B * n_ret):
+            r, mine = ref[i].tolist(), got[i].tolist()
+            if 1 in r[1:]:
+                r = r[: r.index(1, 1) + 1]
+            assert mine == r[:len(mine)] and all(t == 0 for t in r[len(mine):]), (K, n_ret, pen, i, mine, r)
+
+
+@pytest.mark.parametrize("seed", [5, 6])
+def test_nucleus_sampling_equals_hf_generate(seed):
+    """generate(use_nucleus_sampling=True, top_p, temperature, repetition_penalty, num_captions) -> HF multinomial sampling: the same
+    warps in the same order and ONE multinomial draw per step over all rows, so with the same torch RNG state the sampled ids agree"""
+    from mrblip.search import sample_search
+
+    m = _model(seed, 2.0)
+    B, S = 2, 6
+    g = torch.Generator().manual_seed(300 + seed)
+    emb = torch.randn(B, S, 32, generator=g)
+    mask = torch.ones(B, S, dtype=torch.long)
+    with torch.no_grad():
+        enc = m.encoder(inputs_embeds=emb, attention_mask=mask).last_hidden_state
+    for n_ret, top_p, temp, pen in ((1, 0.9, 1.0, 1.0), (3, 0.7, 0.8, 1.2), (2, 1.0, 1.5, 1.0)):
+        torch.manual_seed(1000 + seed)
+        with torch.no_grad():
+            ref = m.generate(inputs_embeds=emb, attention_mask=mask, do_sample=True, num_beams=1, top_p=top_p, top_k=0, temperature=temp, max_new_tokens=8,
+                             min_length=1, num_return_sequences=n_ret, repetition_penalty=pen)
+        R = B * n_ret
+
+        def step(seqs):
+            with torch.no_grad():
+                out = m(encoder_outputs=(enc.repeat_interleave(n_ret, 0),), attention_mask=mask.repeat_interleave(n_ret, 0), decoder_input_ids=seqs)
+            return out.logits[:, -1].float()
+
+        torch.manual_seed(1000 + seed)
+        got = sample_search(step, B, n_ret, 8, min_length=1, top_p=top_p, temperature=temp, repetition_penalty=pen)
+        assert len(got) == R == ref.shape[0]
+        for i in range(R):
+            r, mine = ref[i].tolist(), got[i].tolist()
+            if 1 in r[1:]:
+                r = r[: r.index(1, 1) + 1]
+            assert mine == r[:len(mine)] and all(t == 0 for t in r[len(mine):]), (n_ret, top_p, temp, pen, i, mine, r)
