@@ -258,6 +258,8 @@ def main():
     ap.add_argument("--c2-iters", type=int, default=3, help="timed QVH clip steps of --cpu-baseline-c2 (BASELINE.md §5: >= 3 after one warm-up)")
     ap.add_argument("--vit-chunk", type=int, default=0, help="frames per ViT pass (0 = engine default)")
     ap.add_argument("--no-dropout", action="store_true", help="debug only: the headline number keeps the reference's dropouts on")
+    ap.add_argument("--vit-operands", default="bf16", choices=["bf16", "fp16"], help="operand type of the frozen ViT's GEMMs / attention (fp16 = the "
+                    "reference's GPU arithmetic there; measured 2 %% slower per step than bf16 at a 5-8 %% smaller logits error: EngineConfig.vit_operands)")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: one blocking all-reduce after the backward instead of the overlapped exchange")
     ap.add_argument("--no-lookahead", action="store_true", help="do not overlap the next clip's frozen-ViT forward with this step's decoder")
     ap.add_argument("--lookahead-blocks", type=int, default=0, help="ViT blocks run ahead beside the decoder (0 = engine default)")
@@ -288,7 +290,7 @@ def main():
     from mrblip.tokenizer import FixtureTokenizer
 
     wl = WORKLOADS[args.workload]
-    cfg = EngineConfig.flan_t5_xl_qvh(mean_pool=wl["mean_pool"])
+    cfg = EngineConfig.flan_t5_xl_qvh(mean_pool=wl["mean_pool"], vit_operands=args.vit_operands)
     eng = MrBlipEngine(cfg, RandomSource(dev, seed=1234), dev, lora_init=lora_init_nonzero, seed=42 + rank)
     eng.training = not args.no_dropout
     if args.vit_chunk > 0:
@@ -430,7 +432,7 @@ def main():
             ach = 2.0 * m * n * k / avg / 1e12
             roof = dict(bound="mfma", achieved=round(ach, 1), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_BF16_TFLOPS, 4),
                         traffic=traffic, traffic_source=("committed PMC pass profiles/%s (tools/pmc_fc1.sh; not measured in this run)" % os.path.basename(pmc)) if traffic else None,
-                        kernel="gemm_w4_kernel<bf16 out, bias+GELU> (ViT fc1 %dx%dx%d)" % (m, n, k), launches=len(durs),
+                        kernel="gemm_w4_kernel<%s operands and out, bias+GELU> (ViT fc1 %dx%dx%d)" % ("fp16" if eng.vit_dtype == torch.float16 else "bf16", m, n, k), launches=len(durs),
                         avg_us=round(avg * 1e6, 1))
             if traffic_note:
                 roof["traffic_note"] = traffic_note
@@ -457,6 +459,9 @@ def main():
             "timing": "wall clock between barrier + synchronize pairs (value, ms_per_step); hipEvent intervals per step (median / min / max)",
             "higher_is_better": True, "scaling": "weak" if shard is None else "strong", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
+            # 16-bit MFMA operands, fp32 accumulate / residual streams everywhere; the frozen ViT on IEEE fp16 like the reference's GPU path
+            # (blip2_mr.py:446, eva_vit.py:439-441: same MFMA rate as bf16, 3 more mantissa bits), Q-Former / T5 on bf16
+            "operand_dtypes": {"vit": "fp16" if eng.vit_dtype == torch.float16 else "bf16", "qformer": "bf16", "t5": "bf16"},
             "config": {"workload": f"{args.workload}: ViT-g/14 + Q-Former(32) + Flan-T5-XL LoRA r=8 train step, {wl['T']} frames, S_enc={layout.S}, "
                                    f"L_dec={layout.labels.shape[1]}, random-init weights, dropout {'on' if eng.training else 'off'}",
                        "global_batch": global_batch, "batch_per_gpu": B, "frames": wl["T"], "parallelism": f"dp{world}" if shard is None else f"frame-shard{world} (ViT + Q-Former over T/{world} frames per rank, T5 replicated)",

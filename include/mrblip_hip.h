@@ -45,10 +45,22 @@ int mrblip_gemm_bf16(const void* A, long long lda, const void* W, long long ldw,
                      void* out2, long long ldo2, const float* bias, const float* residual, long long ldr, int act, int gated,
                      const uint32_t* seed_ptr, uint32_t site, float p_drop, int tile_cfg, mrblip_stream_t stream);
 
+/* The same entry on IEEE fp16 operands (A, W; a 16-bit `out` is fp16 too): v_mfma_f32_32x32x16_f16, fp32 accumulate.  The reference's GPU
+ * arithmetic for the frozen ViT is fp16 autocast over fp16 weights (blip2_mr.py:446; eva_vit.py:397-412, 439-441): 3 more mantissa bits
+ * than bf16 at the same MFMA rate.  Only the 4-wave 256x256 kernel (tile_cfg 0 / 13) has this form: plain epilogues — bias, bias + GELU
+ * (16-bit out), fp32 out with or without the fp32 residual.  Replaces F.linear under fp16 autocast: eva_vit.py:120-126, 146, 54-61, 196-203. */
+int mrblip_gemm_f16(const void* A, long long lda, const void* W, long long ldw, const void* Aext, long long ldaext,
+                    const void* Wext, long long ldwext, int M, int N, int K, void* out, long long ldo, int out_f32,
+                    void* out2, long long ldo2, const float* bias, const float* residual, long long ldr, int act, int gated,
+                    const uint32_t* seed_ptr, uint32_t site, float p_drop, int tile_cfg, mrblip_stream_t stream);
+
 /* LayerNorm / T5 RMSNorm over rows of fp32 x[M,D] (D <= 2048, D % 4 == 0); fp32 statistics.
  * eva_vit.py:157,163; blip2.py:113-119 (ln_vision); Qformer.py:104-107,285-289,372-375; modeling_t5.py:254-277. */
 int mrblip_layernorm_fwd(const float* x, long long ldx, const float* gamma, const float* beta, int M, int D, float eps,
                          void* out_bf16, long long ldob, float* out_f32, long long ldof, mrblip_stream_t stream);
+/* LayerNorm with an fp16 16-bit output: the fp16-operand ViT's norm1 / norm2 (eva_vit.py:157-163: fp32 LayerNorm, fp16 consumer) */
+int mrblip_layernorm_fwd_f16(const float* x, long long ldx, const float* gamma, const float* beta, int M, int D, float eps,
+                             void* out_f16, long long ldob, float* out_f32, long long ldof, mrblip_stream_t stream);
 int mrblip_rmsnorm_fwd(const float* x, long long ldx, const float* weight, int M, int D, float eps, void* out_bf16,
                        long long ldob, float* out_f32, long long ldof, mrblip_stream_t stream);
 /* dx = dx_add + dLN(dy); optional dgamma/dbeta += (fp32 atomics) */
@@ -81,6 +93,10 @@ int mrblip_attention_fwd(const void* Q, const long long* q_strides, const void* 
 int mrblip_attention_fwd_rowv(const void* Q, const long long* q_strides, const void* K, const long long* k_strides, const void* V,
                               const long long* v_strides, void* O, const long long* o_strides, float* LSE, int B, int H, int Sq, int Sk,
                               int D, float scale, mrblip_stream_t stream);
+/* ... on IEEE fp16 Q / K / V / O (fp16 matmuls, fp32 softmax: eva_vit.py:128-145 under the reference's fp16 autocast, blip2_mr.py:446) */
+int mrblip_attention_fwd_rowv_f16(const void* Q, const long long* q_strides, const void* K, const long long* k_strides, const void* V,
+                                  const long long* v_strides, void* O, const long long* o_strides, float* LSE, int B, int H, int Sq, int Sk,
+                                  int D, float scale, mrblip_stream_t stream);
 int mrblip_attention_bwd(const void* Q, const long long* q_strides, const void* K, const long long* k_strides, const void* V,
                          const long long* v_strides, const void* O, const long long* o_strides, const void* dO,
                          const long long* do_strides, const void* Kt, const void* Qt, const void* dOt, const float* LSE,
@@ -103,6 +119,10 @@ int mrblip_patchify(const float* video, void* out_bf16, int F, int IMG, int P, i
  * (blip_processors.py:63-66; mean3 / std3 are HOST arrays of 3 floats); bit-identical to normalising first */
 int mrblip_patchify_u8(const uint8_t* video, const float* mean3, const float* std3, void* out_bf16, int F, int IMG, int P, int Kpad,
                        mrblip_stream_t stream);
+/* both with fp16 patch rows (the fp16-operand ViT's patch-embedding GEMM, eva_vit.py:196-203 under fp16 autocast) */
+int mrblip_patchify_f16(const float* video, void* out_f16, int F, int IMG, int P, int Kpad, mrblip_stream_t stream);
+int mrblip_patchify_u8_f16(const uint8_t* video, const float* mean3, const float* std3, void* out_f16, int F, int IMG, int P, int Kpad,
+                           mrblip_stream_t stream);
 /* x = [cls ; patches] + pos  (eva_vit.py:328-331) */
 int mrblip_vit_assemble(const float* patch, const float* cls, const float* pos, float* x, int F, int NP, int D, mrblip_stream_t stream);
 /* dst[dst_idx[i],:] (=|+=) src[src_idx[i],:]; src_idx<0 -> zeros.  Embedding gathers and the frame/timestamp

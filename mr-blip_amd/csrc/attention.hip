@@ -41,7 +41,8 @@ struct AttnArgs {
                        // written by the LDS forward kernel and read back by the LDS backward kernels instead of re-hashing
 };
 
-enum { F_LUT = 1, F_MASK = 2, F_CAUSAL = 4, F_DROP = 8, F_SPLIT = 16, F_DBITS = 32, F_VROW = 64, F_KS2 = 128 };
+enum { F_LUT = 1, F_MASK = 2, F_CAUSAL = 4, F_DROP = 8, F_SPLIT = 16, F_DBITS = 32, F_VROW = 64, F_KS2 = 128,
+       F_F16 = 256 };   // F_F16 (round 4): Q / K / V / O and the probabilities fed to the second product are IEEE fp16 (the fp16-operand ViT)
 
 // Attention-probability dropout draws (v2, round 3).  ONE 32-bit hash serves a key QUAD: index = row * ceil(Sk / 4) + key / 4 with
 // row = (b * H + h) * Sq + q, hash = mrb_lin_fin(index * MRB_H1 + mrb_lin_base(seed, site)) (common.h), and key 4i + j takes the
@@ -81,6 +82,12 @@ __device__ __forceinline__ bf16x8 sel8(bool ok, bf16x8 v) {
 __device__ __forceinline__ bf16x8 pack8(const float* v) {
   union { bf16x8 v8; uint32_t u[4]; } r;
   r.u[0] = pack2bf(v[0], v[1]); r.u[1] = pack2bf(v[2], v[3]); r.u[2] = pack2bf(v[4], v[5]); r.u[3] = pack2bf(v[6], v[7]);
+  return r.v8;
+}
+template <bool F16>
+__device__ __forceinline__ bf16x8 pack8x(const float* v) {
+  union { bf16x8 v8; uint32_t u[4]; } r;
+  r.u[0] = pack2x<F16>(v[0], v[1]); r.u[1] = pack2x<F16>(v[2], v[3]); r.u[2] = pack2x<F16>(v[4], v[5]); r.u[3] = pack2x<F16>(v[6], v[7]);
   return r.v8;
 }
 // Scores live in the log2 domain: s2 = (q.k * scale + bias) * log2(e), so every softmax exponential is one v_exp_f32
@@ -380,6 +387,7 @@ __global__ __launch_bounds__((FLAGS & F_KS2) ? 512 : 256, (FLAGS & F_KS2) ? 1 : 
   // VROW: V is staged ROW-major straight from the projection output (like K) and the V^T fragments of the second product are
   // gathered with the LDS transpose read (ds_read_b64_tr_b16, two per 32 x 16 fragment): no transposed copy of V in HBM
   constexpr bool VROW = FLAGS & F_VROW;
+  constexpr bool F16 = FLAGS & F_F16;
   constexpr int KROW = DP * 2, KCPR = DP / 8;                 // K row bytes, 16-B chunks per K row
   constexpr int K_BYTES = 64 * KROW, V_BYTES = DP * 128, STAGE = K_BYTES + V_BYTES;
   constexpr int NJK = 64 * KCPR / NT, NJV = DP * 8 / NT;      // DMA instructions per thread per stage (VROW: 64 rows x KCPR chunks = the same count)
@@ -491,7 +499,7 @@ __global__ __launch_bounds__((FLAGS & F_KS2) ? 512 : 256, (FLAGS & F_KS2) ? 1 : 
     zero16(sacc);
 #pragma unroll
     for (int s = 0; s < KS; ++s)
-      sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(base + sub * (32 * KROW) + k_off[s]), qf[s], sacc, 0, 0, 0);
+      sacc = mfma32x16<F16>(*reinterpret_cast<const bf16x8*>(base + sub * (32 * KROW) + k_off[s]), qf[s], sacc);
     // lane (q, hi), register r  <->  key k0 + 16*(r>>3) + 8*hi + (r&7)
     float sv[16];
     tile_scores<LUT, 1>(sv, sacc, scale2, lut, k0 - (q0 + 31) >= 128 || (q0 - (k0 + 31)) >= 128, k0 > q0 ? 256 : 0, k0 + 8 * hi - q);
@@ -537,17 +545,17 @@ __global__ __launch_bounds__((FLAGS & F_KS2) ? 512 : 256, (FLAGS & F_KS2) ? 1 : 
       }
     }
     l_run += psum;
-    const bf16x8 pf0 = pack8(pv), pf1 = pack8(pv + 8);
+    const bf16x8 pf0 = pack8x<F16>(pv), pf1 = pack8x<F16>(pv + 8);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       if (VTR) {
         const v4s_t a0 = vtr_r[mt][0], a1 = vtr_r[mt][1], b0 = vtr_r[mt][2], b1 = vtr_r[mt][3];
         const bf16x8 vf0 = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]}, vf1 = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
-        o[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf0, pf0, o[mt], 0, 0, 0);
-        o[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf1, pf1, o[mt], 0, 0, 0);
+        o[mt] = mfma32x16<F16>(vf0, pf0, o[mt]);
+        o[mt] = mfma32x16<F16>(vf1, pf1, o[mt]);
       } else {
-        o[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(base + (v_off[mt][0] ^ (sub << 6))), pf0, o[mt], 0, 0, 0);
-        o[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(base + (v_off[mt][1] ^ (sub << 6))), pf1, o[mt], 0, 0, 0);
+        o[mt] = mfma32x16<F16>(*reinterpret_cast<const bf16x8*>(base + (v_off[mt][0] ^ (sub << 6))), pf0, o[mt]);
+        o[mt] = mfma32x16<F16>(*reinterpret_cast<const bf16x8*>(base + (v_off[mt][1] ^ (sub << 6))), pf1, o[mt]);
       }
     }
   };
@@ -601,8 +609,8 @@ __global__ __launch_bounds__((FLAGS & F_KS2) ? 512 : 256, (FLAGS & F_KS2) ? 1 : 
       for (int g = 0; g < 4; ++g) {
         const int d0 = mt * 32 + 8 * g + 4 * hi;
         if (d0 < p.D)
-          *reinterpret_cast<uint2*>(op + d0) = make_uint2(pack2bf(o[mt][4 * g] * inv, o[mt][4 * g + 1] * inv),
-                                                          pack2bf(o[mt][4 * g + 2] * inv, o[mt][4 * g + 3] * inv));
+          *reinterpret_cast<uint2*>(op + d0) = make_uint2(pack2x<F16>(o[mt][4 * g] * inv, o[mt][4 * g + 1] * inv),
+                                                          pack2x<F16>(o[mt][4 * g + 2] * inv, o[mt][4 * g + 3] * inv));
       }
     if (p.LSE && hi == 0) p.LSE[((long long)(b * p.H + h)) * p.Sqpad + q] = m_run * MRB_LN2 + __logf(fmaxf(l_tot, 1e-37f));
   }
@@ -1346,8 +1354,9 @@ static void dkv_lds64(const AttnArgs& a, dim3 grid, hipStream_t stream) {
     hipLaunchKernelGGL((attn_bwd_dkv_lds_kernel<((FL & F_DROP) && !(FL & F_CAUSAL)) ? (FL | F_DBITS) : FL>), grid, dim3(256), LDS, stream, a);
   else hipLaunchKernelGGL((attn_bwd_dkv_lds_kernel<FL>), grid, dim3(256), LDS, stream, a);
 }
-static void fwd_lds96(const AttnArgs& a, dim3 grid, hipStream_t stream) {
-  if (a.V.ptr) hipLaunchKernelGGL((attn_fwd_lds_kernel<96, F_VROW>), grid, dim3(256), 2 * (64 * 192 + 96 * 128) + 1040, stream, a);
+static void fwd_lds96(const AttnArgs& a, dim3 grid, hipStream_t stream, bool f16 = false) {
+  if (f16) hipLaunchKernelGGL((attn_fwd_lds_kernel<96, F_VROW | F_F16>), grid, dim3(256), 2 * (64 * 192 + 96 * 128) + 1040, stream, a);
+  else if (a.V.ptr) hipLaunchKernelGGL((attn_fwd_lds_kernel<96, F_VROW>), grid, dim3(256), 2 * (64 * 192 + 96 * 128) + 1040, stream, a);
   else hipLaunchKernelGGL((attn_fwd_lds_kernel<96, 0>), grid, dim3(256), 2 * (64 * 192 + 96 * 128) + 1040, stream, a);
 }
 
@@ -1435,6 +1444,20 @@ extern "C" int mrblip_attention_fwd_rowv(const void* Q, const long long* q_strid
   a.LSE = LSE; a.scale = scale;
   fwd_lds96(a, dim3((Sq + 127) / 128, H, B), stream);
   return mrblip_check_launch("attention_fwd_rowv");
+}
+
+// the same on IEEE fp16 Q / K / V / O (the fp16-operand ViT: eva_vit.py:128-145 under fp16 autocast — fp16 matmuls, fp32 softmax)
+extern "C" int mrblip_attention_fwd_rowv_f16(const void* Q, const long long* q_strides, const void* K, const long long* k_strides, const void* V,
+                                             const long long* v_strides, void* O, const long long* o_strides, float* LSE, int B, int H, int Sq,
+                                             int Sk, int D, float scale, hipStream_t stream) {
+  AttnArgs a = {};
+  if (int e = attn_fill(a, Q, q_strides, K, k_strides, V, v_strides, B, H, Sq, Sk, D)) return e;
+  MRB_REQUIRE(D > 64 && D <= 96 && Sq > 32, "attention_fwd_rowv_f16: the row-major-V form covers head_dim in (64, 96] with more than 32 queries (the ViT)");
+  MRB_REQUIRE(V != nullptr && (v_strides[2] % 8) == 0 && ((uintptr_t)V % 16) == 0, "attention_fwd_rowv_f16: V rows must be 16-B aligned");
+  a.O = T4{(const bf16_t*)O, o_strides[0], o_strides[1], o_strides[2]};
+  a.LSE = LSE; a.scale = scale;
+  fwd_lds96(a, dim3((Sq + 127) / 128, H, B), stream, true);
+  return mrblip_check_launch("attention_fwd_rowv_f16");
 }
 
 // Backward.  Needs the forward's O and LSE, the transposed copies Kt [B,H,DP,Skpad], Qt / dOt [B,H,DP,Sqpad];

@@ -35,6 +35,22 @@ __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, mrb_bf16v2));
 }
 __device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack2bf(f, 0.f) & 0xffffu); }
+// ---- IEEE fp16 operands (round 4): the reference's GPU arithmetic for the frozen ViT is fp16 autocast (blip2_mr.py:446, fp16 weights
+// eva_vit.py:397-412, 439-441) — 3 more mantissa bits than bf16 at the same MFMA rate.  Same 16-bit containers, other bit meaning.
+typedef _Float16 mrb_f16v2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ uint32_t pack2h(float lo, float hi) {   // round-to-nearest-even, like torch .half()
+  const mrb_f32v2 f = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, mrb_f16v2));
+}
+template <bool F16>
+__device__ __forceinline__ uint32_t pack2x(float lo, float hi) { return F16 ? pack2h(lo, hi) : pack2bf(lo, hi); }
+// 32x32x16 MFMA on 16-bit fragments held as 8 shorts: bf16 or fp16 by template flag (same rate)
+template <bool F16>
+__device__ __forceinline__ f32x16 mfma32x16(bf16x8 a, bf16x8 b, f32x16 c) {
+  if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
 
 // ---- counter-based dropout RNG.  One 32-bit hash per element; the oracle restates it in numpy
 // (oracle/mrblip_oracle.py: dropout_keep) so training-mode parity can be checked with p > 0.

@@ -6,49 +6,88 @@
 #define NEG_INF_F (-3.0e38f)
 
 // ---------------------------------------------------------------------------------------------------------
-// patchify: video fp32 [F,3,IMG,IMG] -> bf16 [F*G*G, Kpad], row = (f, gy, gx), col = c*P*P + py*P + px (the
-// Conv2d(k=s=P) weight order, eva_vit.py:196-203), cols >= 3*P*P zero.  One block per (f, gy): every image row
-// segment is read once, fully coalesced.
-__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ img, bf16_t* __restrict__ out, int IMG, int P, int G, int Kpad) {
+// patchify: video fp32 [F,3,IMG,IMG] (or uint8, normalised on the fly) -> 16-bit [F*G*G, Kpad], row = (f, gy, gx),
+// col = c*P*P + py*P + px (the Conv2d(k=s=P) weight order, eva_vit.py:196-203), cols >= 3*P*P zero.
+// One block per (f, gy) patch row.  Its 3 x P image rows are read once with 16-B (fp32) / 4-B (uint8) loads, fully coalesced; its
+// output — the G patch rows (f, gy, 0..G-1) — is ONE contiguous G x Kpad chunk, which is assembled in LDS in output order and then
+// written with 16-B coalesced stores.  (Round 4: the first form stored every element with its own 2-byte global store, 0.30 of the
+// HBM peak; P = 14 is not a multiple of the load width, so the scatter has to happen somewhere: in LDS it is free.)
+// F16: the output is IEEE fp16 (fp16-operand ViT) instead of bf16.
+template <bool U8, bool F16, int PC>   // PC: compile-time patch size (14 = ViT-g/14: the divisions by P become multiplies), 0 = run-time P
+__global__ __launch_bounds__(256) void patchify_kernel(const void* __restrict__ img_, bf16_t* __restrict__ out, int IMG, int P_, int G, int Kpad,
+                                                       float m0, float m1, float m2, float s0, float s1, float s2) {
+  extern __shared__ __attribute__((aligned(16))) char pf_sm[];
+  bf16_t* tile = reinterpret_cast<bf16_t*>(pf_sm);            // [G][Kpad]
+  const int P = PC ? PC : P_;
   const int f = blockIdx.y, gy = blockIdx.x;
-  const int K = 3 * P * P;
-  bf16_t* orow = out + ((long long)(f * G + gy) * G) * Kpad;
-  for (int c = 0; c < 3; ++c)
-    for (int py = 0; py < P; ++py) {
-      const float* src = img + (((long long)f * 3 + c) * IMG + gy * P + py) * IMG;
-      for (int x = threadIdx.x; x < G * P; x += 256) {
-        const int gx = x / P, px = x % P;
-        orow[(long long)gx * Kpad + c * P * P + py * P + px] = f2bf(src[x]);
-      }
-    }
-  for (int i = threadIdx.x; i < G * (Kpad - K); i += 256) {
-    const int gx = i / (Kpad - K), k = K + i % (Kpad - K);
-    orow[(long long)gx * Kpad + k] = 0;
-  }
-}
-
-// The same from uint8 frames: the processor's ToTensor + Normalize (blip_processors.py:63-66: x/255, then (x - mean)/std per
-// channel, all fp32, correctly rounded divisions) is applied on the fly -> bit-identical patches from a quarter of the bytes.
-__global__ __launch_bounds__(256) void patchify_u8_kernel(const uint8_t* __restrict__ img, bf16_t* __restrict__ out, int IMG, int P, int G, int Kpad,
-                                                          float m0, float m1, float m2, float s0, float s1, float s2) {
-  const int f = blockIdx.y, gy = blockIdx.x;
-  const int K = 3 * P * P;
-  bf16_t* orow = out + ((long long)(f * G + gy) * G) * Kpad;
-  for (int c = 0; c < 3; ++c) {
-    const float mean = c == 0 ? m0 : c == 1 ? m1 : m2, stdv = c == 0 ? s0 : c == 1 ? s1 : s2;
-    for (int py = 0; py < P; ++py) {
-      const uint8_t* src = img + (((long long)f * 3 + c) * IMG + gy * P + py) * IMG;
-      for (int x = threadIdx.x; x < G * P; x += 256) {
-        const int gx = x / P, px = x % P;
-        const float v = __fdiv_rn(__fsub_rn(__fdiv_rn((float)src[x], 255.0f), mean), stdv);
-        orow[(long long)gx * Kpad + c * P * P + py * P + px] = f2bf(v);
-      }
+  const int K = 3 * P * P, W4 = IMG >> 2;                      // 4-pixel groups per image row (IMG % 4 == 0 checked by the host)
+  const int n_out16 = G * Kpad / 8;                            // 16-B pieces of the output chunk
+  const int n_grp = 3 * P * W4;
+  // all of this thread's loads first (independent, in flight together), then the pad zero fill, then the scatter into the tile
+  constexpr int MAXG = 12;                                     // groups per thread the registers hold: 3 * 14 * 56 / 256 = 9.2 for ViT-g/14
+  float4 q[MAXG];
+  uint32_t wq[MAXG];
+#pragma unroll
+  for (int j = 0; j < MAXG; ++j) {
+    const int g = threadIdx.x + 256 * j;
+    if (g < n_grp) {
+      const int rowi = g / W4, x0 = (g - rowi * W4) * 4;
+      const int c = rowi / P, py = rowi - c * P;
+      const long long off = (((long long)f * 3 + c) * IMG + gy * P + py) * IMG + x0;
+      if (U8) wq[j] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(img_) + off);
+      else q[j] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(img_) + off);
     }
   }
-  for (int i = threadIdx.x; i < G * (Kpad - K); i += 256) {
-    const int gx = i / (Kpad - K), k = K + i % (Kpad - K);
-    orow[(long long)gx * Kpad + k] = 0;
+  for (int i = threadIdx.x; i < n_out16; i += 256) {           // zero the 16-B pieces that hold pad columns (K .. Kpad)
+    const int col = (i * 8) % Kpad;
+    if (col + 8 > K) reinterpret_cast<uint4*>(tile)[i] = make_uint4(0, 0, 0, 0);
   }
+  __syncthreads();
+  auto scatter = [&](int g, const float* v) {
+    const int rowi = g / W4, x0 = (g - rowi * W4) * 4;
+    const int c = rowi / P, py = rowi - c * P;
+    const int cbase = c * P * P + py * P;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int x = x0 + e, gx = x / P, px = x - gx * P;
+      tile[gx * Kpad + cbase + px] = (bf16_t)(pack2x<F16>(v[e], 0.f) & 0xffffu);
+    }
+  };
+#pragma unroll
+  for (int j = 0; j < MAXG; ++j) {
+    const int g = threadIdx.x + 256 * j;
+    if (g < n_grp) {
+      float v[4];
+      if (U8) {
+        const int c = (g / W4) / P;
+        const float mean = c == 0 ? m0 : c == 1 ? m1 : m2, stdv = c == 0 ? s0 : c == 1 ? s1 : s2;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = __fdiv_rn(__fsub_rn(__fdiv_rn((float)((wq[j] >> (8 * e)) & 0xffu), 255.0f), mean), stdv);
+      } else {
+        v[0] = q[j].x; v[1] = q[j].y; v[2] = q[j].z; v[3] = q[j].w;
+      }
+      scatter(g, v);
+    }
+  }
+  for (int g = threadIdx.x + 256 * MAXG; g < n_grp; g += 256) {   // (strips larger than the register batch: generic tail)
+    const int rowi = g / W4, x0 = (g - rowi * W4) * 4;
+    const int c = rowi / P, py = rowi - c * P;
+    const long long off = (((long long)f * 3 + c) * IMG + gy * P + py) * IMG + x0;
+    float v[4];
+    if (U8) {
+      const uint32_t w = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(img_) + off);
+      const float mean = c == 0 ? m0 : c == 1 ? m1 : m2, stdv = c == 0 ? s0 : c == 1 ? s1 : s2;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = __fdiv_rn(__fsub_rn(__fdiv_rn((float)((w >> (8 * e)) & 0xffu), 255.0f), mean), stdv);
+    } else {
+      const float4 t = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(img_) + off);
+      v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    }
+    scatter(g, v);
+  }
+  __syncthreads();
+  uint4* dst = reinterpret_cast<uint4*>(out + ((long long)(f * G + gy) * G) * Kpad);
+  for (int i = threadIdx.x; i < n_out16; i += 256) dst[i] = reinterpret_cast<const uint4*>(tile)[i];
 }
 
 // x[f,0,:] = cls + pos[0]; x[f,1+p,:] = patch[f*NP+p,:] + pos[1+p]   (eva_vit.py:328-331), fp32 residual stream
@@ -327,19 +366,32 @@ static DropoutArg mk_drop(const uint32_t* seed_ptr, uint32_t site, float p) {
 }
 static int grid_for(long long work_items) { return (int)((work_items + 255) / 256 > 4096 ? 4096 : (work_items + 255) / 256 < 1 ? 1 : (work_items + 255) / 256); }
 
-extern "C" int mrblip_patchify(const float* video, void* out_bf16, int F, int IMG, int P, int Kpad, hipStream_t stream) {
-  MRB_REQUIRE(F > 0 && P > 0 && IMG % P == 0 && Kpad >= 3 * P * P && Kpad % 64 == 0, "patchify: bad shape");
+template <bool U8, bool F16>
+static int patchify_launch(const void* video, const float* mean3, const float* std3, void* out16, int F, int IMG, int P, int Kpad, hipStream_t stream, const char* what) {
+  MRB_REQUIRE(F > 0 && P > 0 && IMG % P == 0 && IMG % 4 == 0 && Kpad >= 3 * P * P && Kpad % 64 == 0 && (!U8 || (mean3 && std3)), "%s: bad arguments", what);
+  MRB_REQUIRE(((uintptr_t)video % 16) == 0 && ((uintptr_t)out16 % 16) == 0, "%s: 16-B alignment", what);
   const int G = IMG / P;
-  hipLaunchKernelGGL(patchify_kernel, dim3(G, F), dim3(256), 0, stream, video, (bf16_t*)out_bf16, IMG, P, G, Kpad);
-  return mrblip_check_launch("patchify");
+  const int lds = G * Kpad * 2;
+  MRB_REQUIRE(lds <= 64 * 1024, "%s: a patch row of %d x %d 16-bit values does not fit the staging tile", what, G, Kpad);
+  const float m0 = U8 ? mean3[0] : 0.f, m1 = U8 ? mean3[1] : 0.f, m2 = U8 ? mean3[2] : 0.f, s0 = U8 ? std3[0] : 1.f, s1 = U8 ? std3[1] : 1.f, s2 = U8 ? std3[2] : 1.f;
+  if (P == 14) hipLaunchKernelGGL((patchify_kernel<U8, F16, 14>), dim3(G, F), dim3(256), lds, stream, video, (bf16_t*)out16, IMG, P, G, Kpad, m0, m1, m2, s0, s1, s2);
+  else hipLaunchKernelGGL((patchify_kernel<U8, F16, 0>), dim3(G, F), dim3(256), lds, stream, video, (bf16_t*)out16, IMG, P, G, Kpad, m0, m1, m2, s0, s1, s2);
+  return mrblip_check_launch(what);
+}
+extern "C" int mrblip_patchify(const float* video, void* out_bf16, int F, int IMG, int P, int Kpad, hipStream_t stream) {
+  return patchify_launch<false, false>(video, nullptr, nullptr, out_bf16, F, IMG, P, Kpad, stream, "patchify");
 }
 extern "C" int mrblip_patchify_u8(const uint8_t* video, const float* mean3, const float* std3, void* out_bf16, int F, int IMG, int P, int Kpad,
                                   hipStream_t stream) {
-  MRB_REQUIRE(F > 0 && P > 0 && IMG % P == 0 && Kpad >= 3 * P * P && Kpad % 64 == 0 && mean3 && std3, "patchify_u8: bad arguments");
-  const int G = IMG / P;
-  hipLaunchKernelGGL(patchify_u8_kernel, dim3(G, F), dim3(256), 0, stream, video, (bf16_t*)out_bf16, IMG, P, G, Kpad, mean3[0], mean3[1], mean3[2],
-                     std3[0], std3[1], std3[2]);
-  return mrblip_check_launch("patchify_u8");
+  return patchify_launch<true, false>(video, mean3, std3, out_bf16, F, IMG, P, Kpad, stream, "patchify_u8");
+}
+// fp16 patch rows (fp16-operand ViT, round 4)
+extern "C" int mrblip_patchify_f16(const float* video, void* out_f16, int F, int IMG, int P, int Kpad, hipStream_t stream) {
+  return patchify_launch<false, true>(video, nullptr, nullptr, out_f16, F, IMG, P, Kpad, stream, "patchify_f16");
+}
+extern "C" int mrblip_patchify_u8_f16(const uint8_t* video, const float* mean3, const float* std3, void* out_f16, int F, int IMG, int P, int Kpad,
+                                      hipStream_t stream) {
+  return patchify_launch<true, true>(video, mean3, std3, out_f16, F, IMG, P, Kpad, stream, "patchify_u8_f16");
 }
 extern "C" int mrblip_vit_assemble(const float* patch, const float* cls, const float* pos, float* x, int F, int NP, int D, hipStream_t stream) {
   MRB_REQUIRE(F > 0 && NP > 0 && D % 4 == 0, "vit_assemble: bad shape");

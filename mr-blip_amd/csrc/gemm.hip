@@ -641,7 +641,8 @@ __device__ constexpr int w4_piece_slot(int i, int total, int nslot) {
   const int off = (q != 0 && 2 * n <= nslot) ? 1 : 0;   // phases 0..2 start one slot late (slot 0 carries the first fragment read)
   return j * nslot / n + off;
 }
-template <bool OUT_F32, int ACT, bool RES, int TN>
+// F16 (round 4): the operands (and a 16-bit output) are IEEE fp16 instead of bf16 — v_mfma_f32_32x32x16_f16, same rate, same image.
+template <bool OUT_F32, int ACT, bool RES, int TN, bool F16 = false>
 __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
   constexpr int BM = 256, BN = 64 * TN, WN = BN / 2, RB = 128, NW = 4, RPI = 8;
   constexpr int A_BYTES = BM * RB, W_BYTES = BN * RB, STAGE = A_BYTES + W_BYTES;
@@ -704,7 +705,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
       _Pragma("unroll") for (int f_ = 0; f_ < NFRAG; ++f_)                                                               \
         if (j_ == f_ * NSLOT / NFRAG) W4_FRAG(GA, GB, NBASE, NKK, f_)                                                    \
     }                                                                                                                    \
-    acc[j_ / TN][j_ % TN] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FB[j_ % TN], FA[j_ / TN], acc[j_ / TN][j_ % TN], 0, 0, 0); \
+    acc[j_ / TN][j_ % TN] = mfma32x16<F16>(FB[j_ % TN], FA[j_ / TN], acc[j_ / TN][j_ % TN]);                             \
     __builtin_amdgcn_sched_barrier(0);                                                                                   \
   }
 #define W4_KTILE(DMA, NEXT)                                                                                              \
@@ -873,7 +874,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(mrb_u32x4, mrb_f32x4{v[4], v[5], v[6], v[7]}), rout, off + 16u, 0, 0);
         } else {
           const uint32_t off = ok ? (uint32_t)(((long long)m * p.ldo + n0) * 2) : 0x80000000u;
-          __builtin_amdgcn_raw_buffer_store_b128(mrb_u32x4{pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])}, rout, off, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(mrb_u32x4{pack2x<F16>(v[0], v[1]), pack2x<F16>(v[2], v[3]), pack2x<F16>(v[4], v[5]), pack2x<F16>(v[6], v[7])}, rout, off, 0, 0);
         }
       }
     }
@@ -1522,7 +1523,7 @@ static int gemm_dispatch(const void* A, long long lda, const void* W, long long 
                          const void* Wext, long long ldwext, int M, int N, int K, void* out, long long ldo, int out_f32,
                          void* out2, long long ldo2, const float* bias, const float* residual, long long ldr, int act,
                          int gated, const uint32_t* seed_ptr, uint32_t site, float p_drop, int tile_cfg, int ext_first,
-                         uint32_t ext_site, float ext_p, uint32_t a_site, float a_p, hipStream_t stream) {
+                         uint32_t ext_site, float ext_p, uint32_t a_site, float a_p, hipStream_t stream, bool f16 = false) {
   MRB_REQUIRE(M > 0 && N > 0 && K >= 0 && (K % 64) == 0, "gemm: need M,N>0 and K%%64==0 (M=%d N=%d K=%d)", M, N, K);
   MRB_REQUIRE(K > 0 || Aext, "gemm: empty contraction");
   MRB_REQUIRE((N % 8) == 0, "gemm: N %% 8 != 0 (N=%d)", N);
@@ -1556,6 +1557,10 @@ static int gemm_dispatch(const void* A, long long lda, const void* W, long long 
   const int reserve_arg = (tile_cfg >> 8) & 0x1ff;   // per-call CU reserve (see mrblip_gemm_set_cu_reserve)
   const int k_splits = (tile_cfg >> 17) & 0xf;        // skinny kernel: K split with atomic accumulation into a pre-initialised fp32 output
   int cfg = tile_cfg & 0xff;
+  if (f16) {   // IEEE fp16 operands: the frozen ViT's GEMMs, which all take the 4-wave 256x256 kernel with a plain epilogue
+    MRB_REQUIRE(cfg == 0 || cfg == 13, "gemm_f16: only the 4-wave 256x256 kernel (tile_cfg 0 / 13) has an fp16 form");
+    cfg = 13;
+  }
   if (cfg == 0) {
     if (M <= 64 && !gated) cfg = 3;
     else {
@@ -1752,11 +1757,11 @@ static int gemm_dispatch(const void* A, long long lda, const void* W, long long 
     // that keep the round count — ceil(tiles / rounds): ViT fc1 1464 tiles = 8 rounds on 184 CUs as on 192 — so that the other stream
     // gets the difference: +0.3 ms per step; the CUs of a partly filled last round are not idle, they go to the other stream EARLIER.)
     const int grid = nt13 < cus ? (nt13 + 7) / 8 * 8 : cus;
-    const int variant = (cfg == 14 ? 8 : 0) | (out_f32 ? 4 : 0) | (act == 1 ? 2 : 0) | (residual ? 1 : 0);
-    static bool attr_set13[16] = {};
-#define MRB_W4_LAUNCH(V, F32, ACT_, RES_, TN_)                                                                                     \
+    const int variant = (f16 ? 16 : 0) | (cfg == 14 ? 8 : 0) | (out_f32 ? 4 : 0) | (act == 1 ? 2 : 0) | (residual ? 1 : 0);
+    static bool attr_set13[24] = {};
+#define MRB_W4_LAUNCH(V, F32, ACT_, RES_, TN_, ...)                                                                                \
   case V: {                                                                                                                        \
-    auto k = gemm_w4_kernel<F32, ACT_, RES_, TN_>;                                                                                 \
+    auto k = gemm_w4_kernel<F32, ACT_, RES_, TN_, ##__VA_ARGS__>;                                                                                 \
     if (!attr_set13[V]) {                                                                                                          \
       if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {                    \
         mrblip_set_error("gemm: cannot raise dynamic LDS to %d", LDS);                                                             \
@@ -1784,6 +1789,14 @@ static int gemm_dispatch(const void* A, long long lda, const void* W, long long 
       MRB_W4_LAUNCH(13, true, 0, true, 3)
       MRB_W4_LAUNCH(14, true, 1, false, 3)
       MRB_W4_LAUNCH(15, true, 1, true, 3)
+      // fp16 operands (ViT): qkv (bf16-sized out + bias), fc1 (+ GELU), proj / fc2 (fp32 residual stream), patch embedding (fp32 out + bias)
+      MRB_W4_LAUNCH(16, false, 0, false, 4, true)
+      MRB_W4_LAUNCH(18, false, 1, false, 4, true)
+      MRB_W4_LAUNCH(20, true, 0, false, 4, true)
+      MRB_W4_LAUNCH(21, true, 0, true, 4, true)
+      default:
+        mrblip_set_error("gemm: no such 4-wave kernel variant (%d)%s", variant, f16 ? " - the fp16 form exists for bias / bias+GELU (16-bit out) and fp32 out with or without residual" : "");
+        return MRBLIP_EINVAL;
     }
 #undef MRB_W4_LAUNCH
     return mrblip_check_launch("gemm_w4");
@@ -1810,6 +1823,16 @@ extern "C" int mrblip_gemm_bf16(const void* A, long long lda, const void* W, lon
                                 hipStream_t stream) {
   return gemm_dispatch(A, lda, W, ldw, Aext, ldaext, Wext, ldwext, M, N, K, out, ldo, out_f32, out2, ldo2, bias, residual, ldr, act, gated,
                        seed_ptr, site, p_drop, tile_cfg, 0, 0, 0.f, 0, 0.f, stream);
+}
+
+// The same entry with IEEE fp16 operands (and fp16 for a 16-bit output): the frozen ViT's GEMMs (plain epilogues, 4-wave 256x256 kernel).
+extern "C" int mrblip_gemm_f16(const void* A, long long lda, const void* W, long long ldw, const void* Aext, long long ldaext,
+                               const void* Wext, long long ldwext, int M, int N, int K, void* out, long long ldo, int out_f32,
+                               void* out2, long long ldo2, const float* bias, const float* residual, long long ldr, int act,
+                               int gated, const uint32_t* seed_ptr, uint32_t site, float p_drop, int tile_cfg,
+                               hipStream_t stream) {
+  return gemm_dispatch(A, lda, W, ldw, Aext, ldaext, Wext, ldwext, M, N, K, out, ldo, out_f32, out2, ldo2, bias, residual, ldr, act, gated,
+                       seed_ptr, site, p_drop, tile_cfg, 0, 0, 0.f, 0, 0.f, stream, true);
 }
 
 // LoRA "down" product with the input dropout fused into the operand load:  U[M, N] = dropout(X)[M, K] Acat[N, K]^T, bf16 out.

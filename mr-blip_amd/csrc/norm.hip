@@ -8,7 +8,7 @@
 
 #define NORM_MAXV 8  // float4 per lane -> D <= 64*4*8 = 2048
 
-template <bool RMS>
+template <bool RMS, bool F16 = false>   // F16: the 16-bit output is IEEE fp16 (the frozen ViT's GEMM operands, round 4) instead of bf16
 __global__ __launch_bounds__(256) void norm_fwd_kernel(const float* __restrict__ x, long long ldx, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, int M, int D, float eps, bf16_t* out_b,
                                                        long long ldob, float* out_f, long long ldof) {
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void norm_fwd_kernel(const float* __restrict__
           o.x += b.x; o.y += b.y; o.z += b.z; o.w += b.w;
         }
         if (out_f) reinterpret_cast<float4*>(out_f + (long long)row * ldof)[i] = o;
-        if (out_b) reinterpret_cast<uint2*>(out_b + (long long)row * ldob)[i] = make_uint2(pack2bf(o.x, o.y), pack2bf(o.z, o.w));
+        if (out_b) reinterpret_cast<uint2*>(out_b + (long long)row * ldob)[i] = make_uint2(pack2x<F16>(o.x, o.y), pack2x<F16>(o.z, o.w));
       }
     }
   }
@@ -206,6 +206,16 @@ extern "C" int mrblip_layernorm_fwd(const float* x, long long ldx, const float* 
   const int grid = min((M + 3) / 4, 2048);
   hipLaunchKernelGGL(norm_fwd_kernel<false>, dim3(grid), dim3(256), 0, stream, x, ldx, gamma, beta, M, D, eps, (bf16_t*)out_bf16, ldob, out_f32, ldof);
   return mrblip_check_launch("layernorm_fwd");
+}
+
+// the same with an fp16 16-bit output (ViT norm1 / norm2 in fp16-operand mode; eva_vit.py:157-163 under fp16 autocast)
+extern "C" int mrblip_layernorm_fwd_f16(const float* x, long long ldx, const float* gamma, const float* beta, int M, int D, float eps,
+                                        void* out_f16, long long ldob, float* out_f32, long long ldof, hipStream_t stream) {
+  if (int e = norm_check(M, D, x, ldx)) return e;
+  MRB_REQUIRE(out_f16 || out_f32, "layernorm_fwd_f16: no output");
+  const int grid = min((M + 3) / 4, 2048);
+  hipLaunchKernelGGL((norm_fwd_kernel<false, true>), dim3(grid), dim3(256), 0, stream, x, ldx, gamma, beta, M, D, eps, (bf16_t*)out_f16, ldob, out_f32, ldof);
+  return mrblip_check_launch("layernorm_fwd_f16");
 }
 
 extern "C" int mrblip_rmsnorm_fwd(const float* x, long long ldx, const float* weight, int M, int D, float eps, void* out_bf16,

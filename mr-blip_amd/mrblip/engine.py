@@ -25,7 +25,7 @@ import torch
 from . import ops
 from .prompt import EncoderLayout, bias_lut
 
-bf16, f32 = torch.bfloat16, torch.float32
+bf16, f32, f16 = torch.bfloat16, torch.float32, torch.float16
 
 
 def pad64(n: int) -> int:
@@ -77,6 +77,17 @@ class EngineConfig:
     # per-adapter thin launches (measured: DESIGN.md §4).
     lora_mask_per_adapter: bool = False
     mean_pool: bool = False
+    # Operand type of the frozen ViT's GEMMs and attention (round 4).  The reference's GPU arithmetic there is fp16 autocast over fp16
+    # weights (blip2_mr.py:446; eva_vit.py:397-412, 439-441).  "fp16" runs the ViT on IEEE fp16 operands (v_mfma_f32_32x32x16_f16: 3 more
+    # mantissa bits than bf16); "bf16" (default) as rounds 1-3; "auto" = fp16 where the fp16 kernels apply (every ViT GEMM on the 4-wave
+    # 256x256 kernel, attention on the row-major-V form: head_dim in (64, 96], > 32 tokens — the real ViT-g/14), bf16 otherwise.
+    # MEASURED (round 4, one box, alternating runs; profiles/r04_vit_fp16_vs_bf16.txt): the ViT output's error against the reference's fp32
+    # run drops 8x (C1 6.1e-3 -> 7.7e-4, C2 5.2e-3 -> 6.9e-4) but the logits only 5-8 % (C2 9.4e-3 -> 8.9e-3: the Q-Former and T5 towers
+    # dominate), while the step gets SLOWER: 73.0 vs 71.6 ms, fc1 275 vs 261 us exclusive — at the same MFMA rate the fp16 multipliers
+    # draw more power and the chip, which runs every GEMM at its 1400 W cap, clocks lower.  Hence bf16 stays the default.
+    # The residual stream is fp32 either way; ln_vision's output, which feeds the Q-Former, stays bf16 (the Q-Former's BACKWARD needs
+    # bf16's exponent range for its gradient operands — the reference needs a GradScaler for the same reason: DESIGN.md §7).
+    vit_operands: str = "bf16"
 
     @staticmethod
     def flan_t5_xl_qvh(**kw):
@@ -266,11 +277,11 @@ class MrBlipEngine:
     def qdrop(self, site: int, p: float):
         return self.drop(site + self.qf_site_salt, p)
 
-    def _w(self, w: torch.Tensor, n_pad: Optional[int] = None) -> torch.Tensor:
-        """fp32 [N,K] -> bf16 [Np, pad64(K)] zero padded"""
+    def _w(self, w: torch.Tensor, n_pad: Optional[int] = None, dtype=bf16) -> torch.Tensor:
+        """fp32 [N,K] -> bf16 (or fp16) [Np, pad64(K)] zero padded"""
         N, K = w.shape
         Np = n_pad or N
-        out = torch.zeros(Np, pad64(K), dtype=bf16, device=self.dev)
+        out = torch.zeros(Np, pad64(K), dtype=dtype, device=self.dev)
         out[:N, :K] = w.to(self.dev)
         return out
 
@@ -292,6 +303,16 @@ class MrBlipEngine:
         p = "visual_encoder."
         self.vit_kpad = pad64(3 * P * P)
         self.vit_fp = pad64(c.vit_mlp)
+        hd, T = D // c.vit_heads, (c.img // P) ** 2 + 1
+        fp16_ok = 64 < hd <= 96 and T > 32 and self.vit_rowv
+        assert c.vit_operands in ("auto", "fp16", "bf16"), c.vit_operands
+        if c.vit_operands == "fp16" and not fp16_ok:
+            raise ValueError(f"vit_operands='fp16' needs the row-major-V attention form (head_dim in (64, 96], > 32 tokens): got head_dim {hd}, {T} tokens")
+        want16 = c.vit_operands != "bf16" or os.environ.get("MRB_VIT_FP16", "0") == "1"      # (MRB_VIT_FP16=1: A/B switch of the bench)
+        self.vit_dtype = f16 if (want16 and fp16_ok) else bf16
+        vt = self.vit_dtype
+        _w0 = self._w
+        self._w = lambda w, n_pad=None: _w0(w, n_pad, vt)     # (the ViT's packed GEMM operands only; restored below)
         self.vit = dict(
             pe_w=self._w(src.get(p + "patch_embed.proj.weight", (D, 3, P, P)).reshape(D, -1)),
             pe_b=self._v(src.get(p + "patch_embed.proj.bias", (D,))),
@@ -311,6 +332,7 @@ class MrBlipEngine:
                 fc1_w=self._w(src.get(q + "mlp.fc1.weight", (c.vit_mlp, D)), self.vit_fp), fc1_b=self._v(src.get(q + "mlp.fc1.bias", (c.vit_mlp,)), self.vit_fp),
                 fc2_w=self._w(src.get(q + "mlp.fc2.weight", (D, c.vit_mlp))), fc2_b=self._v(src.get(q + "mlp.fc2.bias", (D,))),
             ))
+        del self._w   # back to the class method (bf16)
 
     @torch.no_grad()
     def vit_forward(self, video: torch.Tensor, n_blocks: Optional[int] = None, slot: int = 0, blocks: Optional[tuple] = None) -> torch.Tensor:
@@ -339,17 +361,18 @@ class MrBlipEngine:
         M = F_ * T
         tag = f"_{F_}"
         b0, b1 = blocks if blocks is not None else (0, c.vit_depth if n_blocks is None else n_blocks)
+        vt_ = self.vit_dtype   # bf16, or IEEE fp16 (cfg.vit_operands)
         if b0 == 0:
-            patches = self.buf("vit_patches" + tag, (F_ * NP, self.vit_kpad), bf16, zero=False)
+            patches = self.buf("vit_patches" + tag, (F_ * NP, self.vit_kpad), vt_, zero=False)
             ops.patchify(video, patches, c.patch)
             pe = self.buf("vit_pe" + tag, (F_ * NP, D), f32, zero=False)
             ops.gemm(patches, v["pe_w"], pe, bias=v["pe_b"])
             ops.vit_assemble(pe, v["cls"], v["pos"], x.view(F_, T, D))
-        h = self.buf("vit_h" + tag, (M, pad64(D)), bf16)
-        qkv = self.buf("vit_qkv" + tag, (M, 3 * D), bf16, zero=False)
-        o = self.buf("vit_o" + tag, (M, pad64(D)), bf16)
-        f = self.buf("vit_f" + tag, (M, self.vit_fp), bf16, zero=False)
-        vt = self.buf("vit_vt" + tag, (F_, H, ops.rup32(hd), ops.rup32(T)), bf16)
+        h = self.buf("vit_h" + tag, (M, pad64(D)), vt_)
+        qkv = self.buf("vit_qkv" + tag, (M, 3 * D), vt_, zero=False)
+        o = self.buf("vit_o" + tag, (M, pad64(D)), vt_)
+        f = self.buf("vit_f" + tag, (M, self.vit_fp), vt_, zero=False)
+        vt = self.buf("vit_vt" + tag, (F_, H, ops.rup32(hd), ops.rup32(T)), bf16) if vt_ == bf16 else None
         q4, k4, v4 = self.v4(qkv, F_, T, H, hd, 0), self.v4(qkv, F_, T, H, hd, D), self.v4(qkv, F_, T, H, hd, 2 * D)
         o4 = self.v4(o, F_, T, H, hd)
         scale = hd ** -0.5

@@ -44,6 +44,11 @@ def _sig(name, *argtypes):
 
 
 _gemm = _sig("mrblip_gemm_bf16", vp, ll, vp, ll, vp, ll, vp, ll, i32, i32, i32, vp, ll, i32, vp, ll, vp, vp, ll, i32, i32, vp, u32, f32, i32, vp)
+_gemm_f16 = _sig("mrblip_gemm_f16", vp, ll, vp, ll, vp, ll, vp, ll, i32, i32, i32, vp, ll, i32, vp, ll, vp, vp, ll, i32, i32, vp, u32, f32, i32, vp)
+_ln_fwd_f16 = _sig("mrblip_layernorm_fwd_f16", vp, ll, vp, vp, i32, i32, f32, vp, ll, vp, ll, vp)
+_attn_fwd_rowv_f16 = _sig("mrblip_attention_fwd_rowv_f16", vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp)
+_patchify_f16 = _sig("mrblip_patchify_f16", vp, vp, i32, i32, i32, i32, vp)
+_patchify_u8_f16 = _sig("mrblip_patchify_u8_f16", vp, C.POINTER(C.c_float), C.POINTER(C.c_float), vp, i32, i32, i32, i32, vp)
 _ln_fwd = _sig("mrblip_layernorm_fwd", vp, ll, vp, vp, i32, i32, f32, vp, ll, vp, ll, vp)
 _rms_fwd = _sig("mrblip_rmsnorm_fwd", vp, ll, vp, i32, i32, f32, vp, ll, vp, ll, vp)
 _ln_bwd = _sig("mrblip_layernorm_bwd", vp, ll, vp, ll, vp, i32, i32, f32, vp, ll, vp, ll, vp, vp, vp)
@@ -89,6 +94,7 @@ EXPORTS = [
     "mrblip_seed_bump", "mrblip_lora_dx_add", "mrblip_dropout_bf16", "mrblip_colsum", "mrblip_lora_pack", "mrblip_lora_tn",
     "mrblip_lora_grads", "mrblip_gemm_lora_down", "mrblip_gemm_lora_dx", "mrblip_patchify_u8",
     "mrblip_gemm_set_cu_reserve", "mrblip_lora_rows", "mrblip_rmsnorm_lora_fwd", "mrblip_lora_rows_init", "mrblip_dec_proj",
+    "mrblip_gemm_f16", "mrblip_layernorm_fwd_f16", "mrblip_attention_fwd_rowv_f16", "mrblip_patchify_f16", "mrblip_patchify_u8_f16",
 ]
 
 
@@ -147,13 +153,16 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, aext=None, wext
     """out[M,N] = a[M,K] @ w[N,K]^T (+ aext @ wext^T) with the fused epilogue of mrblip_gemm_bf16.  cu_reserve: CUs a persistent
     tile kernel leaves to other streams (None = the calling thread's ``gemm_cu_reserve`` context, default 0).  k_splits > 1 (M <= 32,
     fp32 out, no residual): the skinny kernel's blocks split K and ADD into ``out``, which the caller pre-initialised."""
-    _req(a, torch.bfloat16, "gemm.a"); _req(w, torch.bfloat16, "gemm.w")
+    f16 = a.dtype == torch.float16   # IEEE fp16 operands (the fp16-operand ViT): both operands, and a 16-bit output, are fp16
+    _req(a, torch.float16 if f16 else torch.bfloat16, "gemm.a"); _req(w, a.dtype, "gemm.w")
+    if out.dtype != torch.float32 and out.dtype != a.dtype:
+        raise MrblipError(f"gemm: 16-bit output must have the operands' dtype ({a.dtype}), got {out.dtype}")
     M = a.shape[0]
     N = w.shape[0]
     K = a.shape[1] if K is None else K
     sp, site, p = _d(drop)
     reserve = getattr(_tls, "cu_reserve", 0) if cu_reserve is None else cu_reserve
-    _chk(_gemm(_p(a), _ld(a), _p(w), _ld(w), _p(aext), _ld(aext), _p(wext), _ld(wext), M, N, K, _p(out), _ld(out),
+    _chk((_gemm_f16 if f16 else _gemm)(_p(a), _ld(a), _p(w), _ld(w), _p(aext), _ld(aext), _p(wext), _ld(wext), M, N, K, _p(out), _ld(out),
                1 if out.dtype == torch.float32 else 0, _p(out2), _ld(out2), _p(bias), _p(residual), _ld(residual), act,
                1 if gated else 0, sp, site, p, (tile_cfg & 0xff) | ((int(reserve) & 0x1ff) << 8) | ((int(k_splits) & 0xf) << 17), _stream()))
     return out
@@ -181,9 +190,11 @@ class gemm_cu_reserve:
 
 # ------------------------------------------------------------------------------------------------ norms
 def layernorm_fwd(x, gamma, beta, eps, out_bf16=None, out_f32=None):
+    """out_bf16: the 16-bit output; a torch.float16 tensor gets IEEE fp16 values (fp16-operand ViT), a bfloat16 one bf16"""
     _req(x, torch.float32, "layernorm.x")
     M, D = x.shape
-    _chk(_ln_fwd(_p(x), _ld(x), _p(gamma), _p(beta), M, D, eps, _p(out_bf16), _ld(out_bf16), _p(out_f32), _ld(out_f32), _stream()))
+    fn = _ln_fwd_f16 if (out_bf16 is not None and out_bf16.dtype == torch.float16) else _ln_fwd
+    _chk(fn(_p(x), _ld(x), _p(gamma), _p(beta), M, D, eps, _p(out_bf16), _ld(out_bf16), _p(out_f32), _ld(out_f32), _stream()))
 
 
 def rmsnorm_fwd(x, weight, eps, out_bf16=None, out_f32=None):
@@ -355,7 +366,10 @@ def attention_fwd_rowv(q, k, v, o, lse=None, *, scale=1.0):
     """the plain ViT forward with v as a row-major [B,S,H,D] view (a column slice of the fused qkv buffer): no head_transpose of V"""
     B, Sq, H, D = q.shape
     Sk = k.shape[1]
-    _chk(_attn_fwd_rowv(_p(q), _strides3(q), _p(k), _strides3(k), _p(v), _strides3(v), _p(o), _strides3(o), _p(lse), B, H, Sq, Sk, D, scale,
+    if not (q.dtype == k.dtype == v.dtype == o.dtype):
+        raise MrblipError("attention_fwd_rowv: q, k, v, o must share one 16-bit dtype")
+    fn = _attn_fwd_rowv_f16 if q.dtype == torch.float16 else _attn_fwd_rowv
+    _chk(fn(_p(q), _strides3(q), _p(k), _strides3(k), _p(v), _strides3(v), _p(o), _strides3(o), _p(lse), B, H, Sq, Sk, D, scale,
                         _stream()))
 
 
@@ -376,10 +390,11 @@ CLIP_MEAN, CLIP_STD = (0.48145466, 0.4578275, 0.40821073), (0.26862954, 0.261302
 def patchify(video: torch.Tensor, out: torch.Tensor, patch: int, mean=CLIP_MEAN, std=CLIP_STD):
     """video: fp32 normalised frames, or uint8 frames (normalisation fused into the load)"""
     F_, _, IMG, _ = video.shape
+    f16 = out.dtype == torch.float16   # fp16 patch rows for the fp16-operand ViT
     if video.dtype == torch.uint8:
-        _chk(_patchify_u8(_p(video), (C.c_float * 3)(*mean), (C.c_float * 3)(*std), _p(out), F_, IMG, patch, out.shape[1], _stream()))
+        _chk((_patchify_u8_f16 if f16 else _patchify_u8)(_p(video), (C.c_float * 3)(*mean), (C.c_float * 3)(*std), _p(out), F_, IMG, patch, out.shape[1], _stream()))
     else:
-        _chk(_patchify(_p(video), _p(out), F_, IMG, patch, out.shape[1], _stream()))
+        _chk((_patchify_f16 if f16 else _patchify)(_p(video), _p(out), F_, IMG, patch, out.shape[1], _stream()))
 
 
 def vit_assemble(patch, cls, pos, x):

@@ -973,3 +973,94 @@ def test_dec_proj_backward_form(ops, R, N, K, Rk, f32out):
         tag = "dec_proj bwd R=%d N=%d K=%d Rk=%d %s: " % (R, N, K, Rk, "mask" if ldrop else "plain")
         check(tag + "g vs lora_rows", rel(g1.float(), g0.float()), 4e-3)
         check(tag + "dx vs lora_rows + lora_dx", rel(dx1.float(), dx0.float()), 4e-3 if not f32out else 2e-3)
+
+
+# ------------------------------------------------------------------------------------------------ IEEE fp16 operands (the fp16-operand ViT, round 4)
+def test_fp16_operand_gemm_four_wave_kernel(ops):
+    """mrblip_gemm_f16: the 4-wave 256x256 kernel on v_mfma_f32_32x32x16_f16 — every epilogue the frozen ViT uses (bias -> fp16, bias + GELU
+    -> fp16, fp32 out + bias, fp32 residual in place) against fp32 torch on the SAME fp16-rounded operands, and the precision argument:
+    on fp32 data the fp16-operand product is ~8x closer to the fp32 product than the bf16-operand one (3 more mantissa bits)."""
+    torch.manual_seed(5)
+    M, N, K = 700, 520, 320  # 3 x 3 tiles with ragged edges, 5 K-tiles
+    a32, w32 = torch.randn(M, K, device=dev()), torch.randn(N, K, device=dev()) * 0.1
+    a, w = a32.half(), w32.half()
+    bias = torch.randn(N, device=dev())
+    res = torch.randn(M, N, device=dev())
+    base = a.float() @ w.float().t() + bias
+    out = torch.full((M, N), float("nan"), dtype=torch.float16, device=dev())
+    ops.gemm(a, w, out, bias=bias)
+    assert rel(out.float(), base) < 4e-4            # fp16 output rounding only (2^-11 / sqrt(3))
+    ops.gemm(a, w, out, bias=bias, act=1)
+    assert rel(out.float(), torch.nn.functional.gelu(base)) < 6e-4
+    x = torch.empty(M, N, device=dev())
+    ops.gemm(a, w, x, bias=bias)
+    assert rel(x, base) < 2e-6
+    x = res.clone()
+    ops.gemm(a, w, x, bias=bias, residual=x)
+    assert rel(x, res + base) < 2e-6
+    # fp32 data: operand rounding error of the product, fp16 vs bf16
+    full = a32 @ w32.t()
+    y16, yb = torch.empty(M, N, device=dev()), torch.empty(M, N, device=dev())
+    ops.gemm(a, w, y16)
+    ops.gemm(bf(a32), bf(w32), yb, tile_cfg=13)
+    e16, eb = rel(y16, full), rel(yb, full)
+    from util import record
+    record("gemm 700x520x320: fp16-operand product vs fp32 product", e16, 6e-4)
+    record("gemm 700x520x320: bf16-operand product vs fp32 product", eb, 5e-3)
+    assert e16 < 6e-4 and eb > 5 * e16
+    for bad in (dict(gated=True), dict(tile_cfg=2), dict(out2=torch.empty(M, N, dtype=torch.bfloat16, device=dev()))):
+        with pytest.raises(ops.MrblipError):
+            ops.gemm(a, w, out, **bad)
+    with pytest.raises(ops.MrblipError):       # a 16-bit output takes the operands' format
+        ops.gemm(a, w, torch.empty(M, N, dtype=torch.bfloat16, device=dev()))
+
+
+def test_fp16_layernorm_patchify_and_vit_attention(ops):
+    """the other producers / consumers of the fp16-operand ViT: LayerNorm with an fp16 output, fp16 patch rows (fp32 and uint8 frames), and
+    the row-major-V attention (head_dim 88, 257 tokens) on fp16 q / k / v against fp32 torch"""
+    torch.manual_seed(9)
+    M, D = 77, 1408
+    x = torch.randn(M, D, device=dev()) * 2 + 0.5
+    g, b = torch.randn(D, device=dev()) * 0.1 + 1, torch.randn(D, device=dev()) * 0.1
+    want = torch.nn.functional.layer_norm(x, (D,), g, b, 1e-6)
+    o16 = torch.empty(M, D, dtype=torch.float16, device=dev())
+    ops.layernorm_fwd(x, g, b, 1e-6, out_bf16=o16)
+    assert rel(o16.float(), want) < 4e-4 and (o16.float() - want.half().float()).abs().max() <= 2e-3
+    F_, IMG, P = 3, 56, 14
+    G = IMG // P
+    video = torch.randn(F_, 3, IMG, IMG, device=dev())
+    out = torch.full((F_ * G * G, 640), 7.0, dtype=torch.float16, device=dev())
+    ops.patchify(video, out, P)
+    ref = video.reshape(F_, 3, G, P, G, P).permute(0, 2, 4, 1, 3, 5).reshape(F_ * G * G, 3 * P * P)
+    assert torch.equal(out[:, :588], ref.half()) and out[:, 588:].abs().max() == 0
+    u8 = torch.randint(0, 256, (F_, 3, IMG, IMG), device=dev(), dtype=torch.uint8)
+    # the processor's arithmetic (blip_processors.py:63-66) with correctly rounded fp32 divisions: on the CPU (the device's torch.div by a
+    # scalar multiplies by the reciprocal, 1 ulp off now and then — invisible in bf16, visible in a handful of fp16 roundings)
+    mean = torch.tensor(ops.CLIP_MEAN).view(1, 3, 1, 1)
+    std = torch.tensor(ops.CLIP_STD).view(1, 3, 1, 1)
+    norm = ((u8.cpu().float() / 255.0 - mean) / std).to(dev())
+    o_u8, o_f = torch.empty_like(out), torch.empty_like(out)
+    ops.patchify(u8, o_u8, P)
+    ops.patchify(norm.contiguous(), o_f, P)
+    assert torch.equal(o_u8, o_f)
+    B, H, S, Dh = 2, 3, 257, 88
+    qkv = (torch.randn(B * S, 3 * H * Dh, device=dev())).half()
+    view = lambda c0: torch.as_strided(qkv, (B, S, H, Dh), (S * 3 * H * Dh, 3 * H * Dh, Dh, 1), c0)  # noqa: E731
+    q, k, v = view(0), view(H * Dh), view(2 * H * Dh)
+    scale = Dh ** -0.5
+    o = torch.full((B, S, H, Dh), float("nan"), dtype=torch.float16, device=dev())
+    lse = torch.zeros(B, H, ops.rup32(S), device=dev())
+    ops.attention_fwd_rowv(q, k, v, o, lse, scale=scale)
+    want = torch.nn.functional.scaled_dot_product_attention(q.float().permute(0, 2, 1, 3), k.float().permute(0, 2, 1, 3),
+                                                            v.float().permute(0, 2, 1, 3), scale=scale).permute(0, 2, 1, 3)
+    e16 = rel(o.float(), want)
+    ob = torch.empty(B, S, H, Dh, dtype=torch.bfloat16, device=dev())
+    qb = qkv.bfloat16()
+    vb = lambda c0: torch.as_strided(qb, (B, S, H, Dh), (S * 3 * H * Dh, 3 * H * Dh, Dh, 1), c0)  # noqa: E731
+    ops.attention_fwd_rowv(vb(0), vb(H * Dh), vb(2 * H * Dh), ob, None, scale=scale)
+    from util import record
+    record("ViT attention 257 x 88: fp16 operands vs fp32 torch", e16, 8e-4)
+    record("ViT attention 257 x 88: bf16 operands vs fp32 torch (same data rounded to bf16)", rel(ob.float(), want), 8e-3)
+    assert e16 < 8e-4
+    s = (q.float().permute(0, 2, 1, 3) @ k.float().permute(0, 2, 3, 1)) * scale
+    assert rel(lse[:, :, :S], torch.logsumexp(s, -1)) < 1e-5

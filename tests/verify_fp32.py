@@ -76,6 +76,8 @@ class Fp32Verify(contextlib.AbstractContextManager):
         S["buf"] = eng.buf
         S["fuse"], S["rows_max"] = eng.fuse_norm_lora, eng.lora_rows_max_m
         S["dec_proj"] = eng.dec_proj_enabled
+        S["vit_dtype"] = eng.vit_dtype
+        eng.vit_dtype = bf16           # (this mode carries EVERY operand as split-bf16 hi + lo: the ViT's fp16 product mode is switched off inside)
         eng.fuse_norm_lora = False
         eng.dec_proj_enabled = False   # (the fused decoder projection is a bf16-operand kernel: the fp32-operand stand-ins below replace the two-launch ops)
 
@@ -115,6 +117,7 @@ class Fp32Verify(contextlib.AbstractContextManager):
         eng.ws, eng._store = S["ws"], S["store"]
         eng.fuse_norm_lora, eng.lora_rows_max_m = S["fuse"], S["rows_max"]
         eng.dec_proj_enabled = S["dec_proj"]
+        eng.vit_dtype = S["vit_dtype"]
         for obj, key, val in self._weight_restore:
             obj[key] = val
         eng.proj_wb = self._proj_wb
