@@ -196,6 +196,20 @@ int mrblip_dec_proj(const float* x32, long long ldx32, const float* gamma, float
                      * ranges of width t_inner; rows are b * t_rows + s */
                     void* tout0, void* tout1, void* tout2, int t_inner, int t_rows, int t_spad, long long t_bs, long long t_hs,
                     mrblip_stream_t stream);
+/* Cross-block key split of the few-query attention form (Sq <= 32, no bias LUT, head_dim 64: the T5 decoder's cross attention,
+ * modeling_t5.py:536-603 with 8-14 label rows against ~2000 encoder positions; round 4; host-side state of the calling thread, no torch
+ * counterpart).  With a workspace registered, mrblip_attention_fwd and the dQ pass of mrblip_attention_bwd cut the key range of such a
+ * problem into n_split chunks of whole 32-key tiles, one block each (0 = about one block per CU); partial (m, l, O) / partial dQ meet in
+ * the workspace (write-through stores + a ticket per (batch, head)) and the last arriver combines them in chunk order — deterministic,
+ * independent of dispatch order.  ws: >= 16 KB + B * H * n_split * 9216 bytes of 16-B aligned device memory whose first 16 KB are ZERO
+ * (the tickets; the kernels leave them zero); launches that use it must be stream-ordered.  ws = NULL: the one-block-per-head form. */
+int mrblip_attention_set_split_workspace(void* ws, long long bytes, int n_split);
+/* Launch shape of mrblip_dec_proj for R <= 16 (round 4; host-side state, no torch counterpart): n_blocks > 0 = blocks of the streaming kernel for
+ * the calling thread's later launches — each block owns a contiguous range of 16-column tiles and streams their weight rows back to back
+ * (0 = one block per CU, < 0 = unchanged); the engine asks for as many blocks as the frozen-ViT look-ahead leaves CUs.  version 0 = the
+ * one-tile-per-block kernel of round 3, 1 = the streaming kernel (default), any other value = unchanged.  Same results either way
+ * (bit-identical: same K split, same summation order).  Returns the previous n_blocks. */
+int mrblip_dec_proj_config(int n_blocks, int version);
 /* LoRA backward input gradient in one launch: dX[M,N] = dY[M,K] Wt[N,K]^T (+ residual) + mask(site,p) * (G[M,64] AcatT[N,64]^T);
  * N = in_features, K = out_features padded to 64, mask = the forward's lora_dropout keep mask scaled by 1/(1-p) */
 int mrblip_gemm_lora_dx(const void* dY, long long lddy, const void* Wt, long long ldwt, const void* G, long long ldg, const void* AcatT,

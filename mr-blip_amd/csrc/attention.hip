@@ -39,10 +39,13 @@ struct AttnArgs {
   DropoutArg drop;
   uint32_t* dbits;     // optional [B*H, Skpad/32, Sqpad]: keep bits of the probability dropout (bit i of word (kt, q) <-> key 32 kt + i),
                        // written by the LDS forward kernel and read back by the LDS backward kernels instead of re-hashing
+  // F_XS (round 4): the key range of a (batch, head) split over xs_n BLOCKS (gridDim.x); partial results meet in xs_ws, the last arriver
+  // (ticket xs_cnt[b * H + h], zero before the launch and reset by the merger) combines them in chunk order
+  float* xs_ws; uint32_t* xs_cnt; int xs_n;
 };
 
 enum { F_LUT = 1, F_MASK = 2, F_CAUSAL = 4, F_DROP = 8, F_SPLIT = 16, F_DBITS = 32, F_VROW = 64, F_KS2 = 128,
-       F_F16 = 256 };   // F_F16 (round 4): Q / K / V / O and the probabilities fed to the second product are IEEE fp16 (the fp16-operand ViT)
+       F_F16 = 256, F_XS = 512 };   // F_F16 (round 4): Q / K / V / O and the probabilities fed to the second product are IEEE fp16 (the fp16-operand ViT)
 
 // Attention-probability dropout draws (v2, round 3).  ONE 32-bit hash serves a key QUAD: index = row * ceil(Sk / 4) + key / 4 with
 // row = (b * H + h) * Sq + q, hash = mrb_lin_fin(index * MRB_H1 + mrb_lin_base(seed, site)) (common.h), and key 4i + j takes the
@@ -194,13 +197,49 @@ __device__ __forceinline__ uint32_t mask_bits_lds(const uint32_t* mb, int t, int
   return (wd & 0xffu) | ((wd >> 8) & 0xff00u);
 }
 
+
+// ---- F_XS: few queries (<= 32: the decoder's cross attention, 8-14 label rows against 2012 keys) leave ONE block per head in the key-split
+// form above — 32 blocks on a 256-CU chip, each streaming 515 KB of K / V through one CU as a chain of dependent tiles (25 us forward, 37 us
+// dQ per decoder layer).  With F_XS the key range is cut into gridDim.x chunks of whole 32-key tiles, one block each; a block's four waves
+// split ITS chunk as before and wave 0 publishes the block's partial — forward: (m, l, O), dQ: the partial sum — to a workspace with 16-B
+// WRITE-THROUGH (sc1) stores, drains them, and takes a ticket (relaxed agent-scope atomic).  The block that draws the last ticket resets it,
+// does ONE agent-scope acquire and combines the gridDim.x partials in CHUNK order, whichever block it is: deterministic, and independent
+// of dispatch order and XCD placement (cdna_hip_programming.md Guideline 16, form R1 with the ticket as the flag).
+typedef uint32_t attn_u32x4 __attribute__((ext_vector_type(4)));
+template <int NV4>
+__device__ __forceinline__ void xs_publish(float* slot, const f32x4 (&v)[NV4], int lane) {
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(slot, 0, NV4 * 64 * 16, 0x00020000);
+#pragma unroll
+  for (int g = 0; g < NV4; ++g)
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(attn_u32x4, v[g]), r, (uint32_t)((g * 64 + lane) * 16), 0, 16 /* sc1: write-through */);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the storing wave drains its stores before the ticket
+}
+template <int NV4>
+__device__ __forceinline__ void xs_fetch(const float* slot, f32x4 (&v)[NV4], int lane) {
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(slot), 0, NV4 * 64 * 16, 0x00020000);
+#pragma unroll
+  for (int g = 0; g < NV4; ++g) v[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (uint32_t)((g * 64 + lane) * 16), 0, 16 /* sc1 */));
+}
+// true for the one wave that merges (the caller is a single wave: the block's wave 0)
+__device__ __forceinline__ bool xs_last(uint32_t* cnt, int n, int lane) {
+  uint32_t old = 0;
+  if (lane == 0) old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  old = (uint32_t)__builtin_amdgcn_readfirstlane((int)old);
+  if (old != (uint32_t)(n - 1)) return false;
+  if (lane == 0) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch on this stream
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  return true;
+}
+
 // NSW: waves that split the key range of the block's one query tile in the SPLIT form (4, or 8 for long key ranges: the decoder's cross
 // attention has 8-14 queries against 2012 keys and ONE block per head — its waves walk 503 keys each, a chain of 16 dependent tiles)
 template <int DP, int FLAGS, int NSW = 4>
 __global__ __launch_bounds__(NSW * 64, NSW == 4 ? 2 : 1) void attn_fwd_kernel(const AttnArgs p) {
   constexpr int KS = DP / 16, MT = DP / 32;
   constexpr bool LUT = FLAGS & F_LUT, MASK = FLAGS & F_MASK, CAUSAL = FLAGS & F_CAUSAL, DROP = FLAGS & F_DROP, SPLIT = FLAGS & F_SPLIT;
+  constexpr bool XS = FLAGS & F_XS;
   static_assert(NSW == 4 || SPLIT, "more than four waves only in the key-split form");
+  static_assert(!XS || (SPLIT && !CAUSAL), "the cross-block key split extends the key-split form");
   __shared__ float lut[LUT ? 257 : 1];
   __shared__ float red[SPLIT ? (NSW - 1) * (MT * 16 + 2) * 64 : 1];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, hi = lane >> 5, l31 = lane & 31;
@@ -209,7 +248,7 @@ __global__ __launch_bounds__(NSW * 64, NSW == 4 ? 2 : 1) void attn_fwd_kernel(co
     for (int i = threadIdx.x; i < 257; i += NSW * 64) lut[i] = p.lut[h * 257 + i] * MRB_LOG2E;
     __syncthreads();
   }
-  const int q0 = SPLIT ? blockIdx.x * 32 : (blockIdx.x * 4 + w) * 32;
+  const int q0 = XS ? 0 : SPLIT ? blockIdx.x * 32 : (blockIdx.x * 4 + w) * 32;
   if (!SPLIT && q0 >= p.Sq) return;
   const int q = q0 + l31;
   const bool q_ok = q < p.Sq;
@@ -219,14 +258,16 @@ __global__ __launch_bounds__(NSW * 64, NSW == 4 ? 2 : 1) void attn_fwd_kernel(co
   f32x16 o[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) zero16(o[mt]);
-  const int kend = CAUSAL ? min(p.Sk, q0 + 32) : p.Sk;
+  // XS: this block's chunk of whole key tiles
+  const int xs_tiles = XS ? ((p.Sk + 31) / 32 + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+  const int kend = XS ? min(p.Sk, ((int)blockIdx.x + 1) * xs_tiles * 32) : CAUSAL ? min(p.Sk, q0 + 32) : p.Sk;
   const bf16_t* kbase = p.K.ptr + b * p.K.bs + h * p.K.hs;
   const bf16_t* vtbase = p.Vt.ptr + b * p.Vt.bs + h * p.Vt.hs;
   const int* km = MASK ? p.kmask + (long long)b * p.Skpad : nullptr;
   const uint32_t drop_seed = DROP ? *p.drop.seed_ptr : 0u;
   const uint32_t row_id = (uint32_t)(b * p.H + h) * (uint32_t)p.Sq + (uint32_t)q;
   const uint32_t t_lane = DROP ? (row_id * (uint32_t)((p.Sk + 3) >> 2) + 2u * (uint32_t)hi) * MRB_H1 + mrb_lin_base(drop_seed, p.drop.site) : 0u;
-  const int kstart = SPLIT ? w * 32 : 0, kstep = SPLIT ? NSW * 32 : 32;
+  const int kstart = (XS ? (int)blockIdx.x * xs_tiles * 32 : 0) + (SPLIT ? w * 32 : 0), kstep = SPLIT ? NSW * 32 : 32;
   const float scale2 = p.scale * MRB_LOG2E;
 
   // software pipeline: K fragments of the next tile and V^T fragments of this tile are in flight during the score math
@@ -333,6 +374,48 @@ __global__ __launch_bounds__(NSW * 64, NSW == 4 ? 2 : 1) void attn_fwd_kernel(co
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int i = 0; i < 16; ++i) o[mt][i] += r[(2 + mt * 16 + i) * 64 + lane] * fj;
+    }
+    m_run = m_all;
+  }
+  if constexpr (XS) {   // (wave 0 only from here) publish (m, l, O) of this chunk; the last arriver combines all chunks in chunk order
+    constexpr int NV4 = (2 + MT * 16 + 3) / 4;
+    const int nx = (int)gridDim.x;
+    float* base = p.xs_ws + (long long)(b * p.H + h) * nx * (NV4 * 64 * 4);
+    f32x4 v[NV4];
+    {
+      float flat[NV4 * 4];
+      flat[0] = m_run; flat[1] = l_tot;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) flat[2 + mt * 16 + i] = o[mt][i];
+#pragma unroll
+      for (int i = 2 + MT * 16; i < NV4 * 4; ++i) flat[i] = 0.f;
+#pragma unroll
+      for (int g = 0; g < NV4; ++g) v[g] = f32x4{flat[4 * g], flat[4 * g + 1], flat[4 * g + 2], flat[4 * g + 3]};
+    }
+    xs_publish<NV4>(base + (long long)blockIdx.x * (NV4 * 64 * 4), v, lane);
+    if (!xs_last(p.xs_cnt + b * p.H + h, nx, lane)) return;
+    float m_all = NEG_BIG;
+    for (int j = 0; j < nx; ++j) {   // pass 1: the overall maximum
+      const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(base + (long long)j * (NV4 * 64 * 4), 0, NV4 * 64 * 16, 0x00020000);
+      const f32x4 g0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (uint32_t)(lane * 16), 0, 16));
+      m_all = fmaxf(m_all, g0[0]);
+    }
+    l_tot = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) zero16(o[mt]);
+    for (int j = 0; j < nx; ++j) {   // pass 2: chunk order
+      xs_fetch<NV4>(base + (long long)j * (NV4 * 64 * 4), v, lane);
+      float flat[NV4 * 4];
+#pragma unroll
+      for (int g = 0; g < NV4; ++g) { flat[4 * g] = v[g][0]; flat[4 * g + 1] = v[g][1]; flat[4 * g + 2] = v[g][2]; flat[4 * g + 3] = v[g][3]; }
+      const float fj = ex2(flat[0] - m_all);
+      l_tot += flat[1] * fj;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[mt][i] += flat[2 + mt * 16 + i] * fj;
     }
     m_run = m_all;
   }
@@ -621,7 +704,9 @@ template <int DP, int FLAGS, int NSW = 4>
 __global__ __launch_bounds__(NSW * 64, NSW == 4 ? 2 : 1) void attn_bwd_dq_kernel(const AttnArgs p) {
   constexpr int KS = DP / 16, MT = DP / 32;
   constexpr bool LUT = FLAGS & F_LUT, MASK = FLAGS & F_MASK, CAUSAL = FLAGS & F_CAUSAL, DROP = FLAGS & F_DROP, SPLIT = FLAGS & F_SPLIT;
+  constexpr bool XS = FLAGS & F_XS;
   static_assert(NSW == 4 || SPLIT, "more than four waves only in the key-split form");
+  static_assert(!XS || (SPLIT && !CAUSAL), "the cross-block key split extends the key-split form");
   __shared__ float lut[LUT ? 257 : 1];
   __shared__ float red[SPLIT ? (NSW - 1) * MT * 16 * 64 : 1];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, hi = lane >> 5, l31 = lane & 31;
@@ -630,7 +715,7 @@ __global__ __launch_bounds__(NSW * 64, NSW == 4 ? 2 : 1) void attn_bwd_dq_kernel
     for (int i = threadIdx.x; i < 257; i += NSW * 64) lut[i] = p.lut[h * 257 + i] * MRB_LOG2E;
     __syncthreads();
   }
-  const int q0 = SPLIT ? blockIdx.x * 32 : (blockIdx.x * 4 + w) * 32;
+  const int q0 = XS ? 0 : SPLIT ? blockIdx.x * 32 : (blockIdx.x * 4 + w) * 32;
   if (!SPLIT && q0 >= p.Sq) return;
   const int q = q0 + l31;
   const bool q_ok = q < p.Sq;
@@ -649,14 +734,15 @@ __global__ __launch_bounds__(NSW * 64, NSW == 4 ? 2 : 1) void attn_bwd_dq_kernel
   delta += __shfl_xor(delta, 32, 64);
   const long long stat_off = ((long long)(b * p.H + h)) * p.Sqpad + min(q, p.Sqpad - 1);
   const float lse2 = q_ok ? p.LSE[stat_off] * MRB_LOG2E : 0.f;
-  if (q_ok && hi == 0 && (!SPLIT || w == 0)) p.Delta[stat_off] = delta;
+  if (q_ok && hi == 0 && (!SPLIT || w == 0) && (!XS || blockIdx.x == 0)) p.Delta[stat_off] = delta;
   const float scale2 = p.scale * MRB_LOG2E;
   const float keep_scale = DROP ? p.drop.inv_keep : 1.0f;
 
   f32x16 dq[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) zero16(dq[mt]);
-  const int kend = CAUSAL ? min(p.Sk, q0 + 32) : p.Sk;
+  const int xs_tiles = XS ? ((p.Sk + 31) / 32 + (int)gridDim.x - 1) / (int)gridDim.x : 0;   // XS: this block's chunk of whole key tiles
+  const int kend = XS ? min(p.Sk, ((int)blockIdx.x + 1) * xs_tiles * 32) : CAUSAL ? min(p.Sk, q0 + 32) : p.Sk;
   const bf16_t* kbase = p.K.ptr + b * p.K.bs + h * p.K.hs;
   const bf16_t* vbase = p.V.ptr + b * p.V.bs + h * p.V.hs;
   const bf16_t* ktbase = p.Kt.ptr + b * p.Kt.bs + h * p.Kt.hs;
@@ -664,7 +750,7 @@ __global__ __launch_bounds__(NSW * 64, NSW == 4 ? 2 : 1) void attn_bwd_dq_kernel
   const uint32_t drop_seed = DROP ? *p.drop.seed_ptr : 0u;
   const uint32_t row_id = (uint32_t)(b * p.H + h) * (uint32_t)p.Sq + (uint32_t)q;
   const uint32_t t_lane = DROP ? (row_id * (uint32_t)((p.Sk + 3) >> 2) + 2u * (uint32_t)hi) * MRB_H1 + mrb_lin_base(drop_seed, p.drop.site) : 0u;
-  const int kstart = SPLIT ? w * 32 : 0, kstep = SPLIT ? NSW * 32 : 32;
+  const int kstart = (XS ? (int)blockIdx.x * xs_tiles * 32 : 0) + (SPLIT ? w * 32 : 0), kstep = SPLIT ? NSW * 32 : 32;
 
   bf16x8 kcur[KS], vcur[KS];
   load_rows<KS>(kcur, kbase, p.K.rs, kstart + perm23(l31), p.Sk, p.D, hi);
@@ -741,6 +827,29 @@ __global__ __launch_bounds__(NSW * 64, NSW == 4 ? 2 : 1) void attn_bwd_dq_kernel
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int i = 0; i < 16; ++i) dq[mt][i] += red[(j * MT * 16 + mt * 16 + i) * 64 + lane];
+  }
+  if constexpr (XS) {   // (wave 0 only from here) publish this chunk's partial dQ; the last arriver adds all chunks in chunk order
+    constexpr int NV4 = MT * 4;
+    const int nx = (int)gridDim.x;
+    float* base = p.xs_ws + (long long)(b * p.H + h) * nx * (NV4 * 64 * 4);
+    f32x4 v[NV4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) v[mt * 4 + g] = f32x4{dq[mt][4 * g], dq[mt][4 * g + 1], dq[mt][4 * g + 2], dq[mt][4 * g + 3]};
+    xs_publish<NV4>(base + (long long)blockIdx.x * (NV4 * 64 * 4), v, lane);
+    if (!xs_last(p.xs_cnt + b * p.H + h, nx, lane)) return;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) zero16(dq[mt]);
+    for (int j = 0; j < nx; ++j) {
+      xs_fetch<NV4>(base + (long long)j * (NV4 * 64 * 4), v, lane);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          dq[mt][4 * g] += v[mt * 4 + g][0]; dq[mt][4 * g + 1] += v[mt * 4 + g][1]; dq[mt][4 * g + 2] += v[mt * 4 + g][2]; dq[mt][4 * g + 3] += v[mt * 4 + g][3];
+        }
+    }
   }
   if (q_ok) {
     bf16_t* op = const_cast<bf16_t*>(p.dQ.ptr) + b * p.dQ.bs + h * p.dQ.hs + (long long)q * p.dQ.rs;
@@ -1360,6 +1469,29 @@ static void fwd_lds96(const AttnArgs& a, dim3 grid, hipStream_t stream, bool f16
   else hipLaunchKernelGGL((attn_fwd_lds_kernel<96, 0>), grid, dim3(256), 2 * (64 * 192 + 96 * 128) + 1040, stream, a);
 }
 
+// ---- F_XS workspace (host-side, per calling thread; mrblip_attention_set_split_workspace): [tickets: 4096 uint32 (zero)][partials]
+static thread_local void* g_xs_ws = nullptr;
+static thread_local long long g_xs_bytes = 0;
+static thread_local int g_xs_n = 0;
+#define ATTN_XS_TICKETS 4096
+extern "C" int mrblip_attention_set_split_workspace(void* ws, long long bytes, int n_split) {
+  MRB_REQUIRE(!ws || (bytes >= ATTN_XS_TICKETS * 4 && ((uintptr_t)ws % 16) == 0 && n_split >= 0 && n_split <= 64), "attention split workspace: need >= 16 KB of 16-B aligned, ZEROED device memory and n_split <= 64");
+  g_xs_ws = ws; g_xs_bytes = ws ? bytes : 0; g_xs_n = ws ? n_split : 0;
+  return MRBLIP_OK;
+}
+// blocks per (batch, head) of the cross-block key split, 0 = not applicable: only the few-query form with a long key range and so few
+// (batch, head) pairs that the chip is mostly idle (the T5 decoder's cross attention: 32 heads x 2012 keys; NOT the Q-Former's 720 pairs)
+static int attn_xs_split(const AttnArgs& a, bool split) {
+  if (!split || !g_xs_ws || a.D != 64 || a.B * a.H > 128 || a.Sk < 1024 || a.B * a.H > ATTN_XS_TICKETS) return 0;
+  const int tiles = (a.Sk + 31) / 32;
+  int n = g_xs_n > 0 ? g_xs_n : 256 / (a.B * a.H);      // about one block per CU
+  if (n > tiles / 4) n = tiles / 4;                       // at least 4 key tiles (one per wave) per block
+  if (n > 64) n = 64;
+  const long long need = ATTN_XS_TICKETS * 4 + (long long)a.B * a.H * n * (9 * 64 * 16);
+  if (n < 2 || need > g_xs_bytes) return 0;
+  return n;
+}
+
 // the key-split form on 8 waves instead of 4 (MRB_ATTN_SPLIT8=1; measured in round 3 on the decoder's cross attention, 8-14 queries x 2012
 // keys, one block per head: decoder phases 8.79 + 13.96 ms with 4 waves, 8.85 + 14.21 ms with 8, step 70.44 vs 70.52 ms — the block is
 // bound by what ONE CU streams, not by the length of a wave's tile chain; off by default)
@@ -1373,9 +1505,13 @@ template <int DP>
 static int launch_fwd(const AttnArgs& a, int flags, hipStream_t stream) {
   const bool split = a.Sq <= 32 && a.Sk >= 256 && !(flags & F_CAUSAL);
   dim3 grid(split ? 1 : (a.Sq + 127) / 128, a.H, a.B);
+  const int xs = DP == 64 ? attn_xs_split(a, split) : 0;
+  AttnArgs ax = a;
+  if (xs) { ax.xs_cnt = (uint32_t*)g_xs_ws; ax.xs_ws = (float*)((char*)g_xs_ws + ATTN_XS_TICKETS * 4); ax.xs_n = xs; }
 #define X(DPV, FL)                                                                                             \
   if (flags == (FL)) {                                                                                         \
-    if (split && !((FL) & F_CAUSAL) && DPV == 64 && attn_split8(a)) hipLaunchKernelGGL((attn_fwd_kernel<DPV, ((FL) & ~F_CAUSAL) | F_SPLIT, DPV == 64 ? 8 : 4>), grid, dim3(DPV == 64 ? 512 : 256), 0, stream, a); \
+    if (xs && DPV == 64 && !((FL) & (F_CAUSAL | F_LUT))) hipLaunchKernelGGL((attn_fwd_kernel<64, ((FL) & ~(F_CAUSAL | F_LUT)) | F_SPLIT | F_XS>), dim3(xs, a.H, a.B), dim3(256), 0, stream, ax); \
+    else if (split && !((FL) & F_CAUSAL) && DPV == 64 && attn_split8(a)) hipLaunchKernelGGL((attn_fwd_kernel<DPV, ((FL) & ~F_CAUSAL) | F_SPLIT, DPV == 64 ? 8 : 4>), grid, dim3(DPV == 64 ? 512 : 256), 0, stream, a); \
     else if (split && !((FL) & F_CAUSAL)) hipLaunchKernelGGL((attn_fwd_kernel<DPV, ((FL) & ~F_CAUSAL) | F_SPLIT>), grid, dim3(256), 0, stream, a); \
     else if (DPV == 64 && use_lds64(a, (FL))) fwd_lds64<((FL) & ~F_CAUSAL)>(a, grid, stream);                       \
     else hipLaunchKernelGGL((attn_fwd_kernel<DPV, (FL)>), grid, dim3(256), 0, stream, a);                       \
@@ -1391,9 +1527,13 @@ template <int DP>
 static int launch_bwd(const AttnArgs& a, int flags, hipStream_t stream) {
   const bool split = a.Sq <= 32 && a.Sk >= 256 && !(flags & F_CAUSAL);
   dim3 gq(split ? 1 : (a.Sq + 127) / 128, a.H, a.B), gk((a.Sk + 127) / 128, a.H, a.B);
+  const int xs = DP == 64 ? attn_xs_split(a, split) : 0;
+  AttnArgs ax = a;
+  if (xs) { ax.xs_cnt = (uint32_t*)g_xs_ws; ax.xs_ws = (float*)((char*)g_xs_ws + ATTN_XS_TICKETS * 4); ax.xs_n = xs; }
 #define X(DPV, FL)                                                                                             \
   if (flags == (FL)) {                                                                                         \
-    if (split && !((FL) & F_CAUSAL) && DPV == 64 && attn_split8(a)) hipLaunchKernelGGL((attn_bwd_dq_kernel<DPV, ((FL) & ~F_CAUSAL) | F_SPLIT, DPV == 64 ? 8 : 4>), gq, dim3(DPV == 64 ? 512 : 256), 0, stream, a); \
+    if (xs && DPV == 64 && !((FL) & (F_CAUSAL | F_LUT))) hipLaunchKernelGGL((attn_bwd_dq_kernel<64, ((FL) & ~(F_CAUSAL | F_LUT)) | F_SPLIT | F_XS>), dim3(xs, a.H, a.B), dim3(256), 0, stream, ax); \
+    else if (split && !((FL) & F_CAUSAL) && DPV == 64 && attn_split8(a)) hipLaunchKernelGGL((attn_bwd_dq_kernel<DPV, ((FL) & ~F_CAUSAL) | F_SPLIT, DPV == 64 ? 8 : 4>), gq, dim3(DPV == 64 ? 512 : 256), 0, stream, a); \
     else if (split && !((FL) & F_CAUSAL)) hipLaunchKernelGGL((attn_bwd_dq_kernel<DPV, ((FL) & ~F_CAUSAL) | F_SPLIT>), gq, dim3(256), 0, stream, a); \
     else if (DPV == 64 && use_lds64(a, (FL))) dq_lds64<((FL) & ~F_CAUSAL)>(a, gq, stream);                          \
     else hipLaunchKernelGGL((attn_bwd_dq_kernel<DPV, (FL)>), gq, dim3(256), 0, stream, a);                      \

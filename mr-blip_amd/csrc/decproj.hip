@@ -21,6 +21,7 @@
 // single hash over row * N + n; the LoRA-backward mask: pair hash over row * N + n).
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 struct DecProjArgs {
   const float* x32; long long ldx32; const float* gamma; float eps;   // NORM input (x32 != nullptr)
@@ -302,6 +303,365 @@ __global__ __launch_bounds__(512) void dec_proj_kernel(const DecProjArgs p) {
   }
 }
 
+// ---- round 4: the same projection as a STREAMING kernel (R <= 16 rows).  What the round-3 kernel above costs is not its arithmetic but its
+// shape: one 32-column tile per block, so a block is launch + one memory round trip + reduction + a chain of dependent epilogue loads
+// (8-9 GB/s per CU; qkv: 192 blocks = THREE rounds on the 64 CUs the look-ahead ViT leaves to the decoder: 15 us alone, 49 us in the
+// step).  Here a block owns a CONTIGUOUS RANGE of 16-column tiles (grid = min(tiles, mrblip_dec_proj_set_grid) blocks) and streams their
+// weight rows back to back: the work that does not depend on the tile — the RMSNorm of the rows (or the copy of the bf16 rows) into
+// LDS and the LoRA "down" product u — is done ONCE per block, the next tile's weight fragments are requested before this tile's partial
+// sums meet (two batches of UB k-steps per wave always in flight, across tile boundaries), the rank-Rk "up" fragment and the residual of
+// a tile are requested a whole tile ahead, and the reduction buffer alternates so that a tile costs ONE barrier.  K split over the 8
+// waves and the summation order are those of the kernel above: bit-identical results (tests/test_kernels_gpu.py::test_dec_proj_*).
+//   XL: K <= 2048 — the input rows live in LDS (NORM: normalised there; else copied once); longer K streams the rows with the weights.
+static thread_local int g_dec_grid = 0;   // blocks of the streaming kernel (0: the CU count)
+static int g_dec_v2 = -1;                 // 1: streaming kernel for R <= 16 (default), 0: the one-tile-per-block kernel of round 3 (MRB_DEC_PROJ_V2=0)
+// n_blocks > 0: the streaming kernel's grid for the calling thread's later launches (0: one block per CU; < 0: unchanged) — the engine asks
+// for as many blocks as the look-ahead ViT leaves CUs, so that a projection is ONE round of resident blocks.  version 0 / 1 selects the
+// kernel (any other value: unchanged).  Returns the previous n_blocks.
+extern "C" int mrblip_dec_proj_config(int n_blocks, int version) {
+  const int prev = g_dec_grid;
+  if (n_blocks >= 0) g_dec_grid = n_blocks;
+  if (version == 0 || version == 1) g_dec_v2 = version;
+  return prev;
+}
+
+template <int MODE, int XM, int UB>   // XM: 0 = input rows streamed with the weights (K > 2048), 1 = bf16 rows copied into LDS, 2 = RMSNorm of fp32 rows into LDS
+__global__ __launch_bounds__(512) void dec_proj2_kernel(const DecProjArgs p, const int tpb) {
+  constexpr int NTW = MODE == 2 ? 2 : 1, NA = 2;
+  constexpr bool XL = XM != 0, NORM = XM == 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // LDS: [red: 2 x 8 waves x NTW x 64 lanes x 16 B][ured: 8 x NA x 64 x 16 B][ubuf: 16 rows x 64 B][XL: 16 rows x (2 K + 16) B]
+  f32x4* red = reinterpret_cast<f32x4*>(smem);
+  f32x4* ured = reinterpret_cast<f32x4*>(smem + 2 * 8 * NTW * 1024);
+  bf16_t* ubuf = reinterpret_cast<bf16_t*>(smem + 2 * 8 * NTW * 1024 + 8 * NA * 1024);
+  char* xs = smem + 2 * 8 * NTW * 1024 + 8 * NA * 1024 + 1024;
+  const int RS = p.K * 2 + 16;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, kg = lane >> 4;
+  const int ntiles = (p.N + 15) >> 4;
+  const int tile0 = blockIdx.x * tpb, tile1 = min(ntiles, tile0 + tpb);
+  const bool in_drop = p.in_drop.seed_ptr != nullptr, out_drop = p.out_drop.seed_ptr != nullptr, ext_masked = p.ext_drop.seed_ptr != nullptr;
+  const uint32_t* sp = in_drop ? p.in_drop.seed_ptr : out_drop ? p.out_drop.seed_ptr : p.ext_drop.seed_ptr;
+  const uint32_t seed = sp ? mrb_seed_load(sp) : 0u;
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.W), 0, (int)((((long long)(MODE == 2 ? 2 : 1) * p.N - 1) * p.ldw + p.K) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.A), 0, (int)((((long long)p.Rk - 1) * p.lda + p.K) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(p.xin, 0, NORM ? 0 : (int)((((long long)p.R - 1) * p.ldxin + p.K) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.Bt), 0, (int)((((long long)(MODE == 2 ? 2 : 1) * p.N - 1) * p.ldbt + 64) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.residual), 0, (MODE == 1 && p.residual) ? (int)((((long long)p.R - 1) * p.ldr + p.N) * 4) : 0, 0x00020000);
+  const int nks = p.K >> 5;
+  const int per = (nks + 7) >> 3;
+  const int ks0 = w * per, ks1 = min(nks, ks0 + per);
+  const int nb = (per + UB - 1) / UB;                 // batches per tile (the same for every wave)
+  const uint32_t lane_koff = (uint32_t)(kg * 16);
+  const uint32_t xoff = (uint32_t)(((long long)l15 * p.ldxin) * 2) + lane_koff;    // rows >= R: beyond the resource
+
+  // ---- the weight stream: item (tile, batch); fetches run two items ahead of the multiplications
+  dp_u32x4 wf[2][UB][NTW], xf[2][UB];
+  int ft = tile0, fb = 0;                              // next item to fetch
+  auto fetch = [&](auto bufc) {
+    constexpr int buf = decltype(bufc)::value;
+    const int col = ft * 16 + l15;
+    const bool tv = ft < tile1 && col < p.N;
+    uint32_t wrow[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) wrow[t] = (uint32_t)(((long long)(t ? p.N + col : col) * p.ldw) * 2) + lane_koff;
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int ks = ks0 + fb * UB + u;
+      const bool ok = tv && ks < ks1;
+      const uint32_t kb = (uint32_t)ks * 64u;
+#pragma unroll
+      for (int t = 0; t < NTW; ++t) wf[buf][u][t] = __builtin_amdgcn_raw_buffer_load_b128(rw, ok ? wrow[t] + kb : 0x80000000u, 0, 0);
+      if (!XL) xf[buf][u] = __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? xoff + kb : 0x80000000u, 0, 0);
+    }
+    if (++fb == nb) { fb = 0; ++ft; }
+  };
+  // ---- loads first, in the order their data is needed: the input rows (NORM: fp32 rows + gamma; else the bf16 rows), the first two batches of
+  // the thin operand, then two batches of weight fragments and the first tile's epilogue operands.  (vmcnt retires in issue order: a wait
+  // for the rows must not stand behind the weight stream.)
+  const int nv = p.K >> 2;     // NORM: float4 per row
+  const int nc = p.K >> 3;     // copy: 16-B chunks per row (<= 256)
+  float4 v[2][8], gq[8];
+  dp_u32x4 c4[2][4];
+  if (XL) {
+    if (NORM) {   // rows 2 w, 2 w + 1
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int r = 2 * w + i;
+        const float4* xr = reinterpret_cast<const float4*>(p.x32 + (long long)(r < p.R ? r : 0) * p.ldx32);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int c = lane + 64 * j, cc = c < nv ? c : 0;
+          v[i][j] = xr[cc];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int c = lane + 64 * j;
+        gq[j] = reinterpret_cast<const float4*>(p.gamma)[c < nv ? c : 0];
+      }
+    } else {      // the bf16 rows as they are (rows >= R: beyond the resource -> zeros; chunks past the row: the last chunk again)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int c = min(lane + 64 * j, nc - 1);
+          c4[i][j] = __builtin_amdgcn_raw_buffer_load_b128(rx, (uint32_t)(((long long)(2 * w + i) * p.ldxin) * 2) + (uint32_t)c * 16u, 0, 0);
+        }
+    }
+  }
+  constexpr int UA = 4;                               // k-steps per batch of the thin operand
+  const int nba = (per + UA - 1) / UA;
+  uint32_t aoff[NA];
+#pragma unroll
+  for (int a = 0; a < NA; ++a) aoff[a] = (uint32_t)(((long long)(16 * a + l15) * p.lda) * 2) + lane_koff;   // rows >= Rk: beyond the resource
+  dp_u32x4 af[2][UA][NA], ax[2][UA];
+  auto afetch = [&](auto bufc, int b) {
+    constexpr int buf = decltype(bufc)::value;
+#pragma unroll
+    for (int u = 0; u < UA; ++u) {
+      const int ks = ks0 + b * UA + u;
+      const bool ok = ks < ks1;
+      const uint32_t kb = (uint32_t)ks * 64u;
+#pragma unroll
+      for (int a = 0; a < NA; ++a) af[buf][u][a] = __builtin_amdgcn_raw_buffer_load_b128(ra, ok ? aoff[a] + kb : 0x80000000u, 0, 0);
+      if (!XL) ax[buf][u] = __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? xoff + kb : 0x80000000u, 0, 0);
+    }
+  };
+  afetch(std::integral_constant<int, 0>{}, 0);
+  afetch(std::integral_constant<int, 1>{}, 1);
+  fetch(std::integral_constant<int, 0>{});
+  if (!XL) fetch(std::integral_constant<int, 1>{});   // (XL: the second batch goes out once the row registers are free)
+  // wave 0: a tile's LoRA "up" fragment(s) and residual are requested when the tile BEFORE it starts (other waves, absent operands and
+  // tiles past the block's range: out-of-range offsets -> zeros, no traffic)
+  dp_u32x4 bfr[NTW], bfn[NTW];
+  dp_u32x4 resq = {0u, 0u, 0u, 0u}, resn = {0u, 0u, 0u, 0u};
+  auto epi_fetch = [&](int tile) {
+    const int col = tile * 16 + l15;
+    const bool v0 = w == 0 && tile < tile1 && col < p.N;
+#pragma unroll
+    for (int s = 0; s < NTW; ++s)
+      bfn[s] = __builtin_amdgcn_raw_buffer_load_b128(rb, v0 ? (uint32_t)(((long long)(s ? p.N + col : col) * p.ldbt + kg * 8) * 2) : 0x80000000u, 0, 0);
+    if (MODE == 1) {
+      const int n = tile * 16 + 4 * kg;
+      resn = __builtin_amdgcn_raw_buffer_load_b128(rr, (w == 0 && tile < tile1 && l15 < p.R && n < p.N) ? (uint32_t)(((long long)l15 * p.ldr + n) * 4) : 0x80000000u, 0, 0);
+    }
+  };
+  epi_fetch(tile0);
+
+  // ---- once per block: the input rows into LDS (XL), then u = bf16(dropout(x) (sA)^T)
+  if (XL) {
+    if (NORM) {   // the arithmetic of norm_fwd_kernel<true>: v * rstd * gamma, one rounding
+      float q[2] = {0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int r = 2 * w + i;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int c = lane + 64 * j;
+          if (c >= nv || r >= p.R) v[i][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+          q[i] += v[i][j].x * v[i][j].x + v[i][j].y * v[i][j].y + v[i][j].z * v[i][j].z + v[i][j].w * v[i][j].w;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int r = 2 * w + i;
+        const float rstd = rsqrtf(wave_sum(q[i]) / (float)p.K + p.eps);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int c = lane + 64 * j;
+          if (c < nv) {
+            const float4 g = gq[j];
+            const uint2 o = make_uint2(pack2bf(v[i][j].x * rstd * g.x, v[i][j].y * rstd * g.y), pack2bf(v[i][j].z * rstd * g.z, v[i][j].w * rstd * g.w));
+            *reinterpret_cast<uint2*>(xs + r * RS + c * 8) = o;
+            if (blockIdx.x == 0 && r < p.R) *reinterpret_cast<uint2*>(p.xin + (long long)r * p.ldxin + c * 4) = o;
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int c = min(lane + 64 * j, nc - 1);
+          *reinterpret_cast<dp_u32x4*>(xs + (2 * w + i) * RS + c * 16) = c4[i][j];
+        }
+    }
+    fetch(std::integral_constant<int, 1>{});
+    __syncthreads();
+  }
+  auto x_lds = [&](int ks) -> dp_u32x4 {   // XL: this lane's 8 k of row l15 at k-step ks (zero past the wave's share: the weights are zero there,
+                                           // but whatever lies behind the rows must not reach the MFMA as a NaN pattern)
+    const int k = min(ks, nks - 1) * 32 + kg * 8;
+    dp_u32x4 x = *reinterpret_cast<const dp_u32x4*>(xs + l15 * RS + k * 2);
+    if (ks >= ks1) x = dp_u32x4{0u, 0u, 0u, 0u};
+    return x;
+  };
+  {
+    f32x4 accu[NA];
+#pragma unroll
+    for (int a = 0; a < NA; ++a) accu[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto aconsume = [&](auto bufc, int b) {
+      constexpr int buf = decltype(bufc)::value;
+#pragma unroll
+      for (int u = 0; u < UA; ++u) {
+        const int ks = ks0 + b * UA + u;
+        dp_u32x4 x = XL ? x_lds(ks) : ax[buf][u];
+        if (in_drop) {   // block-uniform
+          const uint32_t e = (uint32_t)l15 * (uint32_t)p.K + (uint32_t)(ks * 32 + kg * 8);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            bool k0, k1;
+            mrb_keep2(e + 2 * q, seed, p.in_drop.site, p.in_drop.thresh24, k0, k1);
+            x[q] = (k0 ? x[q] & 0xffffu : 0u) | (k1 ? x[q] & 0xffff0000u : 0u);
+          }
+        }
+#pragma unroll
+        for (int a = 0; a < NA; ++a)
+          accu[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[buf][u][a]), __builtin_bit_cast(bf16x8, x), accu[a], 0, 0, 0);
+      }
+    };
+#pragma unroll 1
+    for (int b = 0; b < nba; b += 2) {
+      aconsume(std::integral_constant<int, 0>{}, b);
+      afetch(std::integral_constant<int, 0>{}, b + 2);
+      if (b + 1 < nba) aconsume(std::integral_constant<int, 1>{}, b + 1);
+      afetch(std::integral_constant<int, 1>{}, b + 3);
+    }
+#pragma unroll
+    for (int a = 0; a < NA; ++a) ured[(w * NA + a) * 64 + lane] = accu[a];
+    __syncthreads();
+    if (w < NA) {   // u tile w: lane (r = l15, kg) holds j = 16 w + 4 kg .. + 3
+      f32x4 v = ured[(0 * NA + w) * 64 + lane];
+#pragma unroll
+      for (int j = 1; j < 8; ++j) v += ured[(j * NA + w) * 64 + lane];
+      const float post = in_drop ? p.in_drop.inv_keep : 1.0f;
+      const uint2 ub = make_uint2(pack2bf(v[0] * post, v[1] * post), pack2bf(v[2] * post, v[3] * post));
+      const int j0 = 16 * w + 4 * kg;
+      *reinterpret_cast<uint2*>(ubuf + l15 * 32 + j0) = ub;
+      if (blockIdx.x == 0 && l15 < p.R && j0 < p.Rk) *reinterpret_cast<uint2*>(p.U + (long long)l15 * p.ldu + j0) = ub;
+    }
+    __syncthreads();
+  }
+  const dp_u32x4 uf = *reinterpret_cast<const dp_u32x4*>(ubuf + l15 * 32 + kg * 8);    // u[r = l15][8 kg .. + 7]
+
+  // ---- the tiles
+  f32x4 acc[NTW];
+#pragma unroll
+  for (int t = 0; t < NTW; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int ct = tile0, cb = 0, par = 0;                     // item being multiplied; reduction buffer of its tile
+  auto tile_done = [&]() {
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+      red[((par * 8 + w) * NTW + t) * 64 + lane] = acc[t];
+      acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    __syncthreads();
+    if (w == 0) {
+      const int col = ct * 16;
+      f32x4 h[NTW];
+#pragma unroll
+      for (int s = 0; s < NTW; ++s) {
+        f32x4 v = red[((par * 8 + 0) * NTW + s) * 64 + lane];
+#pragma unroll
+        for (int j = 1; j < 8; ++j) v += red[((par * 8 + j) * NTW + s) * 64 + lane];
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        if (ext_masked) {   // backward: dx = dy W + mask (.) (g A): the rank-Rk product on its own, masked per element (pair hash over row * N + n)
+          f32x4 e = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bfr[s]), __builtin_bit_cast(bf16x8, uf), zero, 0, 0, 0);
+          const uint32_t idx = (uint32_t)l15 * (uint32_t)p.N + (uint32_t)(col + 4 * kg);
+          bool k0, k1, k2, k3;
+          mrb_keep2(idx, seed, p.ext_drop.site, p.ext_drop.thresh24, k0, k1);
+          mrb_keep2(idx + 2, seed, p.ext_drop.site, p.ext_drop.thresh24, k2, k3);
+          v[0] += k0 ? e[0] * p.ext_drop.inv_keep : 0.f; v[1] += k1 ? e[1] * p.ext_drop.inv_keep : 0.f;
+          v[2] += k2 ? e[2] * p.ext_drop.inv_keep : 0.f; v[3] += k3 ? e[3] * p.ext_drop.inv_keep : 0.f;
+        } else {
+          v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bfr[s]), __builtin_bit_cast(bf16x8, uf), v, 0, 0, 0);
+        }
+        h[s] = v;
+      }
+      const int r = l15, n = col + 4 * kg;   // this lane: row r, columns n .. n + 3
+      if (r < p.R && n < p.N) {
+        if (MODE == 2) {
+          if (p.out2) {   // (generation keeps no pre-activations)
+            *reinterpret_cast<uint2*>(p.out2 + (long long)r * p.ldo2 + n) = make_uint2(pack2bf(h[0][0], h[0][1]), pack2bf(h[0][2], h[0][3]));
+            *reinterpret_cast<uint2*>(p.out2 + (long long)r * p.ldo2 + p.N + n) = make_uint2(pack2bf(h[NTW - 1][0], h[NTW - 1][1]), pack2bf(h[NTW - 1][2], h[NTW - 1][3]));
+          }
+          float y[4];
+#pragma unroll
+          for (int i = 0; i < 4; i += 2) {
+            float g0 = h[0][i], g1 = h[0][i + 1];
+            gelu_erf2(g0, g1);
+            y[i] = g0 * h[NTW - 1][i];
+            y[i + 1] = g1 * h[NTW - 1][i + 1];
+          }
+          if (out_drop) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              y[i] = mrb_keep((uint32_t)r * (uint32_t)p.N + (uint32_t)(n + i), seed, p.out_drop.site, p.out_drop.thresh24) ? y[i] * p.out_drop.inv_keep : 0.f;
+          }
+          *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + (long long)r * p.ldo + n) = make_uint2(pack2bf(y[0], y[1]), pack2bf(y[2], y[3]));
+        } else {
+          float y[4] = {h[0][0], h[0][1], h[0][2], h[0][3]};
+          if (out_drop) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              y[i] = mrb_keep((uint32_t)r * (uint32_t)p.N + (uint32_t)(n + i), seed, p.out_drop.site, p.out_drop.thresh24) ? y[i] * p.out_drop.inv_keep : 0.f;
+          }
+          if (MODE == 1) {
+            const f32x4 q = __builtin_bit_cast(f32x4, resq);   // zeros without a residual
+            y[0] += q[0]; y[1] += q[1]; y[2] += q[2]; y[3] += q[3];
+            *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + (long long)r * p.ldo + n) = make_float4(y[0], y[1], y[2], y[3]);
+          } else {
+            const uint2 ob = make_uint2(pack2bf(y[0], y[1]), pack2bf(y[2], y[3]));
+            *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + (long long)r * p.ldo + n) = ob;
+            if (p.t_inner > 0) {   // block-uniform: the head-transposed copies (see the kernel above)
+              const int which = n / p.t_inner;
+              bf16_t* td = which < 3 ? p.tout[which] : nullptr;
+              if (td) {
+                const int c = n - which * p.t_inner, hh = c >> 6, d0 = c & 63, bb = r / p.t_rows, ss = r - bb * p.t_rows;
+                bf16_t* q = td + bb * p.t_bs + hh * p.t_hs + (long long)d0 * p.t_spad + ss;
+                q[0] = (bf16_t)(ob.x & 0xffffu); q[p.t_spad] = (bf16_t)(ob.x >> 16);
+                q[2 * p.t_spad] = (bf16_t)(ob.y & 0xffffu); q[3 * p.t_spad] = (bf16_t)(ob.y >> 16);
+                if (ss == p.t_rows - 1) {
+                  for (int z = 1; z < p.t_spad - ss; ++z) { q[z] = 0; q[p.t_spad + z] = 0; q[2 * p.t_spad + z] = 0; q[3 * p.t_spad + z] = 0; }
+                }
+              }
+            }
+          }
+        }
+      }
+    }
+    par ^= 1;
+    ++ct;
+  };
+  auto consume = [&](auto bufc) {
+    constexpr int buf = decltype(bufc)::value;
+    if (cb == 0) {
+#pragma unroll
+      for (int s = 0; s < NTW; ++s) bfr[s] = bfn[s];
+      resq = resn;
+      epi_fetch(ct + 1);
+    }
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int ks = ks0 + cb * UB + u;
+      const dp_u32x4 x = XL ? x_lds(ks) : xf[buf][u];
+#pragma unroll
+      for (int t = 0; t < NTW; ++t)
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[buf][u][t]), __builtin_bit_cast(bf16x8, x), acc[t], 0, 0, 0);
+    }
+    if (++cb == nb) { cb = 0; tile_done(); }
+  };
+  const int items = (tile1 - tile0) * nb;
+#pragma unroll 1
+  for (int it = 0; it < items; it += 2) {
+    consume(std::integral_constant<int, 0>{});
+    fetch(std::integral_constant<int, 0>{});
+    if (it + 1 < items) consume(std::integral_constant<int, 1>{});
+    fetch(std::integral_constant<int, 1>{});
+  }
+}
+
 static void dp_drop(DropoutArg& d, const uint32_t* seed_ptr, uint32_t site, float p) {
   d.seed_ptr = (p > 0.f) ? seed_ptr : nullptr;
   d.site = site;
@@ -339,6 +699,43 @@ extern "C" int mrblip_dec_proj(const float* x32, long long ldx32, const float* g
   dp_drop(a.in_drop, seed_ptr, in_site, in_p);
   dp_drop(a.out_drop, seed_ptr, out_site, out_p);
   dp_drop(a.ext_drop, seed_ptr, ext_site, ext_p);
+  // round 4: R <= 16 rows take the streaming kernel (MRB_DEC_PROJ_V2=0: the one-tile-per-block kernel of round 3)
+  if (g_dec_v2 < 0) { const char* e = getenv("MRB_DEC_PROJ_V2"); g_dec_v2 = (e && e[0] == '0') ? 0 : 1; }
+  if (g_dec_v2 && R <= 16) {
+    static int ncu = 0, env_grid = -1;
+    if (ncu == 0) {
+      int dev = 0;
+      hipDeviceProp_t prop;
+      ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+    }
+    if (env_grid < 0) { const char* e = getenv("MRB_DEC_GRID"); env_grid = e ? atoi(e) : 0; }
+    const int G = env_grid > 0 ? env_grid : (g_dec_grid > 0 ? g_dec_grid : ncu);
+    const int tiles = (N + 15) / 16;
+    const int tpb = (tiles + G - 1) / G;
+    const int grid2 = (tiles + tpb - 1) / tpb;
+    const bool xl = K <= 2048;
+    const int ntw2 = mode == 2 ? 2 : 1;
+    const int LDS2 = 2 * 8 * ntw2 * 1024 + 8 * 2 * 1024 + 1024 + (xl ? 16 * (K * 2 + 16) : 0);
+    static bool attr2[9] = {};
+#define MRB_DP2_LAUNCH(ID, MODE_, XM_, UB_)                                                                                       \
+  {                                                                                                                                \
+    auto k = dec_proj2_kernel<MODE_, XM_, UB_>;                                                                                    \
+    if (!attr2[ID]) {                                                                                                              \
+      if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 8 * 2 * 1024 + 8 * 2 * 1024 + 1024 + 16 * (2048 * 2 + 16)) != hipSuccess) { \
+        mrblip_set_error("dec_proj: cannot raise dynamic LDS");                                                                    \
+        return MRBLIP_ELAUNCH;                                                                                                     \
+      }                                                                                                                            \
+      attr2[ID] = true;                                                                                                            \
+    }                                                                                                                              \
+    hipLaunchKernelGGL(k, dim3(grid2), dim3(512), LDS2, stream, a, tpb);                                                           \
+  }
+    const int xm = !xl ? 0 : (x32 ? 2 : 1);
+    if (mode == 2) { if (xm == 2) MRB_DP2_LAUNCH(0, 2, 2, 4) else if (xm == 1) MRB_DP2_LAUNCH(1, 2, 1, 4) else MRB_DP2_LAUNCH(2, 2, 0, 4) }
+    else if (mode == 0) { if (xm == 2) MRB_DP2_LAUNCH(3, 0, 2, 8) else if (xm == 1) MRB_DP2_LAUNCH(4, 0, 1, 8) else MRB_DP2_LAUNCH(5, 0, 0, 4) }
+    else { if (xm == 2) MRB_DP2_LAUNCH(6, 1, 2, 8) else if (xm == 1) MRB_DP2_LAUNCH(7, 1, 1, 8) else MRB_DP2_LAUNCH(8, 1, 0, 4) }
+#undef MRB_DP2_LAUNCH
+    return mrblip_check_launch("dec_proj");
+  }
   // 32 output columns per block; 16 (twice the blocks, half the weight bytes each) for the long-K projections of a 2048-wide output, whose
   // 64 blocks are otherwise a serial stream of 20-40 k-steps per wave (MRB_DEC_PROJ_NT1=0 keeps 32)
   static int nt1 = -1;

@@ -204,8 +204,16 @@ __global__ __launch_bounds__(256) void gated_bwd_kernel(const bf16_t* __restrict
 
 // cross entropy over fp32 logits [R,V], ignore_index = -100, mean over valid rows (modeling_t5.py:1873-1877).
 // loss += -(log softmax)[label] * inv_count ; dlogits (bf16) = (softmax - onehot) * inv_count * loss_scale.
+// Round 4: the row terms are added in ROW order by the block that finishes last (ticket), not by fp32 atomics in arrival order: the loss of a
+// step is the same bits on every run and on every rank of a replicated T5 (tests/test_frame_shard_gpu.py compares ranks bit for bit; with
+// atomicAdd the sum of the 8-14 row terms changed in the last bit from run to run).  The terms travel through a library-owned scratch
+// (write-through stores, one agent-scope acquire by the last arriver: cdna_hip_programming.md Guideline 16), so launches are expected to be
+// stream-ordered; R > CE_MAX_ROWS falls back to the atomic sum.
+#define CE_MAX_ROWS 4096
+__device__ float g_ce_terms[CE_MAX_ROWS];
+__device__ unsigned int g_ce_ticket;
 __global__ __launch_bounds__(1024) void ce_kernel(const float* __restrict__ logits, long long ldl, const int* __restrict__ labels, int V,
-                                                  float inv_count, float* loss, bf16_t* dlogits, long long ldd) {
+                                                  float inv_count, float* loss, bf16_t* dlogits, long long ldd, int ordered) {
   __shared__ float red[16];
   const int r = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const float* lr = logits + (long long)r * ldl;
@@ -229,7 +237,23 @@ __global__ __launch_bounds__(1024) void ce_kernel(const float* __restrict__ logi
   for (int i = 0; i < 16; ++i) s += red[i];
   const float lse = mx + __logf(s);
   const bool valid = label >= 0;
-  if (threadIdx.x == 0 && valid) atomicAdd(loss, (lse - lr[label]) * inv_count);
+  if (threadIdx.x == 0) {
+    const float term = valid ? (lse - lr[label]) * inv_count : 0.f;
+    if (!ordered) {
+      if (valid) atomicAdd(loss, term);
+    } else {
+      __hip_atomic_store(&g_ce_terms[r], term, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // write-through
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const unsigned int old = __hip_atomic_fetch_add(&g_ce_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (old == gridDim.x - 1) {
+        __hip_atomic_store(&g_ce_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        float acc = *loss;
+        for (int i = 0; i < (int)gridDim.x; ++i) acc += __hip_atomic_load(&g_ce_terms[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *loss = acc;
+      }
+    }
+  }
   if (dlogits) {
     bf16_t* dr = dlogits + (long long)r * ldd;
     for (int i = threadIdx.x; i < V; i += 1024) {
@@ -436,7 +460,7 @@ extern "C" int mrblip_gated_gelu_bwd(const void* dy, long long lddy, const void*
 extern "C" int mrblip_cross_entropy(const float* logits, long long ldl, const int* labels, int R, int V, float inv_count, float* loss,
                                     void* dlogits_bf16, long long ldd, hipStream_t stream) {
   MRB_REQUIRE(R > 0 && V > 0, "cross_entropy: bad shape");
-  hipLaunchKernelGGL(ce_kernel, dim3(R), dim3(1024), 0, stream, logits, ldl, labels, V, inv_count, loss, (bf16_t*)dlogits_bf16, ldd);
+  hipLaunchKernelGGL(ce_kernel, dim3(R), dim3(1024), 0, stream, logits, ldl, labels, V, inv_count, loss, (bf16_t*)dlogits_bf16, ldd, R <= CE_MAX_ROWS ? 1 : 0);
   return mrblip_check_launch("cross_entropy");
 }
 extern "C" int mrblip_adamw(float* p, const float* g, float* m, float* v, long long n, const float* hyper, float beta1, float beta2, float eps,

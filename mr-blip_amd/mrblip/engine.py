@@ -177,6 +177,23 @@ class LoraGroup:
     site: int = 0              # lora_dropout site (one mask per group input)
 
 
+def _with_attention_split(fn):
+    """Run a decoder entry point with the engine's cross-block key-split workspace registered for the cross attention (csrc/attention.hip F_XS;
+    thread-local on the C side), and unregister it afterwards: a direct ops.attention_* caller must never inherit a pointer into this engine."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(self, *a, **kw):
+        if self.xs_ws is None:
+            return fn(self, *a, **kw)
+        ops.attention_split_workspace(self.xs_ws, self.xs_split)
+        try:
+            return fn(self, *a, **kw)
+        finally:
+            ops.attention_split_workspace(None)
+    return wrapped
+
+
 class MrBlipEngine:
     @torch.no_grad()
     def __init__(self, cfg: EngineConfig, src, device, lora_init: Optional[Callable] = None, seed: Optional[int] = 42):
@@ -187,6 +204,9 @@ class MrBlipEngine:
         self.cfg, self.dev = cfg, device
         self.ws: Dict[str, torch.Tensor] = {}
         self.dec_t_saved: Dict[int, bool] = {}    # decoder layer -> Q^T / K^T of its self-attention were written by the forward's fused projection
+        # round 4: workspace of the cross-block key split of the decoder's cross attention (csrc/attention.hip F_XS): tickets (zero) + partials
+        self.xs_ws = torch.zeros(2 * 1024 * 1024, dtype=torch.int32, device=self.dev) if os.environ.get("MRB_ATTN_XS", "1") == "1" else None
+        self.xs_split = int(os.environ.get("MRB_ATTN_XS_N", "0"))
         self.dec_tc_saved: Dict[int, bool] = {}   # ... and the cross-attention's Q^T
         self._store: Dict[str, torch.Tensor] = {}
         self.ws_allocation_log: List[tuple] = []
@@ -1075,6 +1095,7 @@ class MrBlipEngine:
         return cache
 
     @torch.no_grad()
+    @_with_attention_split
     def t5_decoder_forward(self, dec_ids: torch.Tensor, dec_mask: torch.Tensor, enc: torch.Tensor, B: int, S: int, kmask: torch.Tensor,
                            labels: Optional[torch.Tensor] = None, want_grad: bool = True, cross_cache=None, cross_batch: Optional[int] = None):
         """cross_cache (inference only): the output of t5_cross_kv for ``cross_batch`` encoder sequences; the B decoder sequences are
@@ -1208,6 +1229,7 @@ class MrBlipEngine:
         return {"kv": kv, "t": 0, "R": R, "Lmax": Lmax}
 
     @torch.no_grad()
+    @_with_attention_split
     def t5_decode_step(self, state: dict, tokens: torch.Tensor, parents: Optional[torch.Tensor], cross_cache, cross_batch: int, kmask):
         """One decoder position for R sequences: tokens [R] (the newest token of each), parents [R] (row of the previous call each
         sequence extends; None = unchanged order) -> fp32 logits [R, vocab] of the next token.  modeling_t5.py:747-826 with
@@ -1256,6 +1278,7 @@ class MrBlipEngine:
         return logits
 
     @torch.no_grad()
+    @_with_attention_split
     def t5_decoder_backward(self, enc: torch.Tensor, B: int, S: int, Ld: int, kmask: torch.Tensor, dec_mask: torch.Tensor) -> torch.Tensor:
         """Backward from d_dlogits.  Returns fp32 grad of the encoder output [B*S, d]."""
         c = self.cfg

@@ -84,6 +84,8 @@ _lora_rows = _sig("mrblip_lora_rows", vp, ll, vp, ll, i32, i32, i32, vp, ll, vp,
 _lora_rows_init = _sig("mrblip_lora_rows_init", vp, ll, vp, ll, i32, i32, i32, vp, ll, vp, vp, u32, f32, vp, ll, vp, ll, i32, vp)
 _dec_proj = _sig("mrblip_dec_proj", vp, ll, vp, f32, vp, ll, vp, ll, vp, ll, i32, vp, ll, vp, ll, i32, i32, i32, i32, vp, ll, vp, ll, vp, ll, vp, u32, f32, u32, f32, u32, f32,
                  vp, vp, vp, i32, i32, i32, ll, ll, vp)
+_dec_proj_config = _sig("mrblip_dec_proj_config", i32, i32)
+_attn_split_ws = _sig("mrblip_attention_set_split_workspace", vp, ll, i32)
 _rms_lora = _sig("mrblip_rmsnorm_lora_fwd", vp, ll, vp, i32, i32, f32, vp, ll, vp, ll, i32, vp, ll, vp, u32, f32, vp)
 
 EXPORTS = [
@@ -93,7 +95,7 @@ EXPORTS = [
     "mrblip_cast_dropout", "mrblip_gelu_bwd", "mrblip_gated_gelu_bwd", "mrblip_cross_entropy", "mrblip_adamw",
     "mrblip_seed_bump", "mrblip_lora_dx_add", "mrblip_dropout_bf16", "mrblip_colsum", "mrblip_lora_pack", "mrblip_lora_tn",
     "mrblip_lora_grads", "mrblip_gemm_lora_down", "mrblip_gemm_lora_dx", "mrblip_patchify_u8",
-    "mrblip_gemm_set_cu_reserve", "mrblip_lora_rows", "mrblip_rmsnorm_lora_fwd", "mrblip_lora_rows_init", "mrblip_dec_proj",
+    "mrblip_gemm_set_cu_reserve", "mrblip_lora_rows", "mrblip_rmsnorm_lora_fwd", "mrblip_lora_rows_init", "mrblip_dec_proj", "mrblip_dec_proj_config", "mrblip_attention_set_split_workspace",
     "mrblip_gemm_f16", "mrblip_layernorm_fwd_f16", "mrblip_attention_fwd_rowv_f16", "mrblip_patchify_f16", "mrblip_patchify_u8_f16",
 ]
 
@@ -329,6 +331,37 @@ def dec_proj(xin, w, a, bt, u, out, K, *, x32=None, gamma=None, eps=0.0, N=None,
     _chk(_dec_proj(_p(x32), _ld(x32), _p(gamma), eps, _p(xin), _ld(xin), _p(w), _ld(w), _p(a), _ld(a), a.shape[0], _p(bt), _ld(bt), _p(u), _ld(u),
                    R, N, K, mode, _p(out), _ld(out), _p(residual), _ld(residual), _p(out2), _ld(out2), sp, s_in, p_in, s_out, p_out, s_ext, p_ext,
                    _p(t[0]), _p(t[1]), _p(t[2]), t_inner, int(t_rows), t_spad, t_bs, t_hs, _stream()))
+
+
+def attention_split_workspace(ws: Optional[torch.Tensor], n_split: int = 0):
+    """Register (or, with None, remove) the workspace of the cross-block key split of the few-query attention form for this thread's later
+    attention_fwd / attention_bwd launches (mrblip_attention_set_split_workspace): a ZEROED, 16-B aligned device tensor of at least
+    16 KB + B * H * n_split * 9216 bytes; n_split = 0 lets the library choose about one block per CU."""
+    rc = _attn_split_ws(None, 0, 0) if ws is None else _attn_split_ws(_p(ws), ws.numel() * ws.element_size(), int(n_split))
+    if rc != 0:
+        raise MrblipError(_lib.mrblip_last_error().decode())
+
+
+def dec_proj_config(n_blocks: int = -1, version: int = -1) -> int:
+    """Launch shape of ``dec_proj`` for <= 16 rows (mrblip_dec_proj_config): n_blocks > 0 = blocks of the streaming kernel (each owns a contiguous
+    range of 16-column tiles; 0 = one per CU; < 0 = unchanged), version 0 = the one-tile-per-block kernel of round 3, 1 = streaming.  Returns the
+    previous n_blocks.  Thread-local on the C side, like ``gemm_cu_reserve``."""
+    return int(_dec_proj_config(int(n_blocks), int(version)))
+
+
+class dec_proj_grid:
+    """``with dec_proj_grid(n):`` dec_proj launches of this thread use n blocks (0: one per CU) inside"""
+
+    def __init__(self, n: int):
+        self.n = int(n)
+
+    def __enter__(self):
+        self.prev = dec_proj_config(self.n)
+        return self
+
+    def __exit__(self, *exc):
+        dec_proj_config(self.prev)
+        return False
 
 
 def lora_dx(dy, wt, g, acatt, dx, K, residual=None, drop: Optional[Dropout] = None, tile_cfg=0, k_splits: int = 0):

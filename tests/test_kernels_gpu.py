@@ -301,6 +301,77 @@ def test_attention_bias_mask_dropout_fwd_bwd(ops, causal, B, H, Sq, Sk, D):
     assert rel(dv.float().permute(0, 2, 1, 3), vr.grad) < 1.5e-2
 
 
+@pytest.mark.parametrize("n_split", [0, 3, 8, 15])
+@pytest.mark.parametrize("B,H,Sq,Sk,masked,p", [(1, 32, 8, 2012, False, 0.1), (1, 32, 14, 2012, True, 0.1), (2, 32, 12, 1030, True, 0.0), (1, 8, 32, 4003, False, 0.0)])
+def test_attention_cross_block_key_split(ops, n_split, B, H, Sq, Sk, masked, p):
+    """Round 4: the decoder's cross attention (few queries, ~2000 keys, one block per head in the key-split form) with its key range cut over
+    several BLOCKS per head (mrblip_attention_set_split_workspace): partial (m, l, O) / partial dQ through a workspace, the last arriver
+    combines them in chunk order.  Forward (O, LSE) and backward (dQ; dK / dV do not change form) against the one-block form and against fp32
+    torch autograd; repeated launches are bit-identical (the combination order does not depend on which block arrives last) while a large
+    GEMM keeps every CU busy on another stream; the tickets are left at zero."""
+    torch.manual_seed(15)
+    D = 64
+    q = bf(torch.randn(B, Sq, H, D, device=dev()) * 0.5)
+    k = bf(torch.randn(B, Sk, H, D, device=dev()) * 0.5)
+    v = bf(torch.randn(B, Sk, H, D, device=dev()))
+    do = bf(torch.randn(B, Sq, H, D, device=dev()))
+    kmask = None
+    if masked:
+        kmask = torch.zeros(B, ops.rup32(Sk), dtype=torch.int32, device=dev())
+        kmask[:, :Sk] = 1
+        kmask[0, Sk - 40:] = 0
+        kmask[0, 100:170] = 0          # two whole key tiles of one chunk masked out
+    seed = torch.tensor([777], dtype=torch.int32, device=dev())
+    drop = ops.Dropout(seed, 9, p) if p > 0 else None
+    vt, kt, qt, dot = ops.head_transpose(v), ops.head_transpose(k), ops.head_transpose(q), ops.head_transpose(do)
+
+    def run():
+        o = torch.zeros_like(q)
+        lse = torch.zeros(B, H, ops.rup32(Sq), device=dev())
+        ops.attention_fwd(q, k, vt, o, lse, scale=1.0, kmask=kmask, drop=drop)
+        delta = torch.zeros_like(lse)
+        dq, dk, dv = torch.zeros_like(q), torch.zeros_like(k), torch.zeros_like(v)
+        ops.attention_bwd(q, k, v, o, do, kt, qt, dot, lse, delta, dq, dk, dv, scale=1.0, kmask=kmask, drop=drop)
+        return o, lse, dq, dk, dv, delta
+
+    ops.attention_split_workspace(None)
+    base = run()
+    ws = torch.zeros((16384 + B * H * 64 * 9216) // 4, dtype=torch.int32, device=dev())
+    ops.attention_split_workspace(ws, n_split)
+    try:
+        got = run()
+        # a busy chip on another stream: blocks of one head arrive in any order
+        a = bf(torch.randn(4096, 4096, device=dev()))
+        c = torch.empty(4096, 4096, device=dev())
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            for _ in range(12):
+                ops.gemm(a, a, c)
+        reps = [run() for _ in range(25)]
+        side.synchronize()
+    finally:
+        ops.attention_split_workspace(None)
+    torch.cuda.synchronize()
+    assert int(ws[:4096].abs().sum()) == 0                                   # the tickets are back at zero
+    for r in reps:
+        for x, y in zip(r, got):
+            assert torch.equal(x, y)
+    names = ("o", "lse", "dq", "dk", "dv", "delta")
+    for n, x, y in zip(names, got, base):
+        e = rel(x.float()[..., :Sq] if n in ("lse", "delta") else x.float(), y.float()[..., :Sq] if n in ("lse", "delta") else y.float())
+        assert e < (3e-3 if n in ("o", "dq", "dk", "dv") else 1e-5), (n, e)   # bf16 outputs: rounding flips under another fp32 summation order (dK / dV see it through LSE / Delta)
+    qr, kr, vr = (t.float().permute(0, 2, 1, 3).clone().requires_grad_(True) for t in (q, k, v))
+    mask = kmask[:, :Sk].bool()[:, None, None, :].expand(B, H, Sq, Sk) if masked else None
+    dmask = None
+    if p > 0:
+        from oracle.mrblip_oracle import dropout_keep_attn
+        dmask = dropout_keep_attn(B, H, Sq, Sk, 777, 9, p).to(dev())
+    ref, _ = _attn_ref(qr, kr, vr, 1.0, None, mask, dmask, p)
+    assert rel(got[0].float().permute(0, 2, 1, 3), ref) < 6e-3
+    ref.backward(do.float().permute(0, 2, 1, 3))
+    assert rel(got[2].float().permute(0, 2, 1, 3), qr.grad) < 1.5e-2
+
+
 @pytest.mark.parametrize("use_bits", [False, True])
 @pytest.mark.parametrize("use_lut", [False, True])
 @pytest.mark.parametrize("B,H,Sq,Sk,D", [(1, 3, 300, 300, 64), (2, 2, 257, 190, 64), (1, 2, 70, 333, 64)])
@@ -973,6 +1044,70 @@ def test_dec_proj_backward_form(ops, R, N, K, Rk, f32out):
         tag = "dec_proj bwd R=%d N=%d K=%d Rk=%d %s: " % (R, N, K, Rk, "mask" if ldrop else "plain")
         check(tag + "g vs lora_rows", rel(g1.float(), g0.float()), 4e-3)
         check(tag + "dx vs lora_rows + lora_dx", rel(dx1.float(), dx0.float()), 4e-3 if not f32out else 2e-3)
+
+
+@pytest.mark.parametrize("grid", [1, 5, 64, 0])
+def test_dec_proj_streaming_kernel_is_bit_identical_to_the_tile_kernel(ops, grid):
+    """Round 4: for <= 16 rows mrblip_dec_proj runs as a streaming kernel (a block owns a range of 16-column tiles; rows and LoRA "down"
+    product once per block).  Same K split over the waves and same summation order as the one-tile-per-block kernel of round 3: every
+    output must be bit-identical — forward forms (RMSNorm-fed bf16 with head-transposed copies, gated, plain-input residual, long K) and
+    the backward form, with and without dropout, for 1 / 5 / 64 blocks and one block per CU (ragged tile ranges included)."""
+    torch.manual_seed(71)
+    seed = torch.tensor([31], dtype=torch.int32, device=dev())
+
+    def both(fn):
+        outs = []
+        for ver in (0, 1):
+            ops.dec_proj_config(grid if ver else -1, ver)
+            outs.append(fn())
+        ops.dec_proj_config(0, 1)
+        for a, b in zip(*outs):
+            assert torch.equal(a, b)
+
+    for R, N, K, Rk in ((8, 6144, 2048, 24), (13, 2048, 2048, 8), (16, 48, 64, 8)):     # RMSNorm-fed, bf16 out (+ head-transposed copies)
+        w, acat, wext = _dp_operands(R, N, K, Rk, seed=43)
+        x32, gamma = torch.randn(R, K, device=dev()) * 1.7, torch.randn(K, device=dev()) * 0.1 + 1
+        for ldrop in (None, ops.Dropout(seed, 3, 0.05)):
+            def run():
+                xn, u, out = (torch.full((R, K), 3.0, dtype=torch.bfloat16, device=dev()), torch.zeros(R, 64, dtype=torch.bfloat16, device=dev()),
+                              torch.full((R, N), 5.0, dtype=torch.bfloat16, device=dev()))
+                touts = [torch.full((1, 32, 64, 32), 7.5, dtype=torch.bfloat16, device=dev()) for _ in range(N // 2048)] if N % 2048 == 0 else None
+                ops.dec_proj(xn, w, acat, wext, u, out, K, x32=x32, gamma=gamma, eps=1e-6, in_drop=ldrop, tout=touts, t_rows=R)
+                return [xn, u, out] + (touts or [])
+            both(run)
+    for R in (8, 14):                                                                      # gated (wi_0 / wi_1)
+        K, Nh, Rk = 2048, 5120, 16
+        w, acat, wext = _dp_operands(R, Nh, K, Rk, gated=True, seed=47)
+        x32, gamma = torch.randn(R, K, device=dev()), torch.randn(K, device=dev()) * 0.1 + 1
+        for ldrop, odrop in ((None, None), (ops.Dropout(seed, 3, 0.05), ops.Dropout(seed, 6, 0.1))):
+            def run():
+                xn, u = torch.zeros(R, K, dtype=torch.bfloat16, device=dev()), torch.zeros(R, 64, dtype=torch.bfloat16, device=dev())
+                y, h = torch.zeros(R, Nh, dtype=torch.bfloat16, device=dev()), torch.zeros(R, 2 * Nh, dtype=torch.bfloat16, device=dev())
+                ops.dec_proj(xn, w, acat, wext, u, y, K, x32=x32, gamma=gamma, eps=1e-6, out2=h, gated=True, in_drop=ldrop, out_drop=odrop)
+                return [xn, u, y, h]
+            both(run)
+    for R, N, K, Rk in ((8, 2048, 2048, 8), (12, 2048, 5120, 8), (16, 80, 96, 8)):        # plain bf16 input rows, fp32 residual out (o / co / wo)
+        w, acat, wext = _dp_operands(R, N, K, Rk)
+        x, res = bf(torch.randn(R, K, device=dev())), torch.randn(R, N, device=dev())
+        for ldrop, odrop in ((None, None), (ops.Dropout(seed, 4, 0.05), ops.Dropout(seed, 8, 0.1))):
+            def run():
+                u, out = torch.zeros(R, 64, dtype=torch.bfloat16, device=dev()), torch.full((R, N), 7.0, device=dev())
+                ops.dec_proj(x, w, acat, wext, u, out, K, residual=res, in_drop=ldrop, out_drop=odrop)
+                return [u, out]
+            both(run)
+    for R, N, K, Rk, f32out in ((8, 2048, 6144, 24, True), (14, 2048, 10240, 16, True), (16, 5120, 2048, 8, False), (8, 2048, 2048, 8, False)):   # backward form
+        dy, wt = bf(torch.randn(R, K, device=dev())), bf(torch.randn(N, K, device=dev()) * 0.03)
+        bblk = bf(torch.randn(Rk, K, device=dev()) * 0.05)
+        acatt = torch.zeros(N, 64, dtype=torch.bfloat16, device=dev())
+        acatt[:, :Rk] = bf(torch.randn(N, Rk, device=dev()) * 0.05)
+        res = torch.randn(R, N, device=dev()) if f32out else None
+        for ldrop in (None, ops.Dropout(seed, 4, 0.05)):
+            def run():
+                g, dx = torch.zeros(R, 64, dtype=torch.bfloat16, device=dev()), torch.zeros(R, N, dtype=torch.float32 if f32out else torch.bfloat16, device=dev())
+                touts = [torch.full((1, 32, 64, 32), 7.5, dtype=torch.bfloat16, device=dev())] if (not f32out and N == 2048) else None
+                ops.dec_proj(dy, wt, bblk, acatt, g, dx, K, residual=res, ext_drop=ldrop, tout=touts, t_rows=R)
+                return [g, dx] + (touts or [])
+            both(run)
 
 
 # ------------------------------------------------------------------------------------------------ IEEE fp16 operands (the fp16-operand ViT, round 4)
