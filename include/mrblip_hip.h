@@ -177,6 +177,18 @@ int mrblip_lora_rows(const void* X, long long ldx, const void* A, long long lda,
 int mrblip_lora_rows_init(const void* X, long long ldx, const void* A, long long lda, int M, int R, int K, void* U, long long ldu,
                           const int* seg, const uint32_t* seed_ptr, uint32_t site, float p_drop, float* init_dst, long long ld_idst,
                           const float* init_src, long long ld_isrc, int init_n, mrblip_stream_t stream);
+/* mrblip_lora_dx_add for `groups` LoRA groups that share one input, in ONE pass over dx (round 4): dx[m, k] += sum_g mask_g[m, k] *
+ * (G[m, g * g_gstride : + R] A_g[R, K])[k], A_g at A + g * a_gstride elements, mask_g = the forward's lora_dropout keep mask of group g
+ * (call-site id site0 + g * site_stride) scaled by 1 / (1 - p): the rank-R input-gradient terms of all decoder layers' cross K / V adapters. */
+int mrblip_lora_dx_add_batched(float* dx, long long lddx, const void* G, long long ldg, long long g_gstride, const void* A, long long a_gstride, int R,
+                               int M, int K, int groups, const uint32_t* seed_ptr, uint32_t site0, uint32_t site_stride, float p, mrblip_stream_t stream);
+/* mrblip_lora_rows for `groups` problems in ONE launch (round 4): group g reads X + g * x_gstride (0: the same rows for every group), A + g *
+ * a_gstride, writes U + g * u_gstride (strides in elements) and draws its mask with call-site id site0 + g * site_stride — the LoRA "down"
+ * products of all decoder layers' EncDecAttention.k / .v adapters on one encoder output, and their backward's g = dy B on the layers' dy
+ * column blocks (peft lora.Linear around modeling_t5.py:561-599).  K %% 32 == 0, R <= 32. */
+int mrblip_lora_rows_batched(const void* X, long long ldx, long long x_gstride, const void* A, long long lda, long long a_gstride, int M, int R, int K,
+                             void* U, long long ldu, long long u_gstride, int groups, const uint32_t* seed_ptr, uint32_t site0, uint32_t site_stride,
+                             float p_drop, mrblip_stream_t stream);
 /* T5LayerNorm (modeling_t5.py:254-277) fused with the LoRA "down" product of its output: out_bf16 = bf16(x * rsqrt(mean(x^2) + eps) * weight),
  * U[M, 0:R] = dropout(out_bf16) A[R,D]^T — one launch for the norm-fed adapted projections (q/k/v, wi_0/wi_1, EncDecAttention.q). */
 int mrblip_rmsnorm_lora_fwd(const float* x, long long ldx, const float* weight, int M, int D, float eps, void* out_bf16, long long ldob,
@@ -204,6 +216,17 @@ int mrblip_dec_proj(const float* x32, long long ldx32, const float* gamma, float
  * independent of dispatch order.  ws: >= 16 KB + B * H * n_split * 9216 bytes of 16-B aligned device memory whose first 16 KB are ZERO
  * (the tickets; the kernels leave them zero); launches that use it must be stream-ordered.  ws = NULL: the one-block-per-head form. */
 int mrblip_attention_set_split_workspace(void* ws, long long bytes, int n_split);
+/* One-shot extras of the calling thread's NEXT mrblip_gemm_bf16 / mrblip_gemm_lora_dx launch (round 4; generic tile kernels only, the call
+ * fails loudly for a kernel form that cannot honour them):
+ *  - tout0..2 (bf16 output, plain or bias epilogue, heads of 64): head-transposed copies of up to three consecutive column ranges of width
+ *    t_inner — exactly what mrblip_head_transpose would write from the output ([B, H, 64, t_spad], rows b * t_rows + s, pad columns zeroed;
+ *    one clip, or t_rows %% 32 == 0): q / k / v of a fused projection reach the attention kernels without a transpose launch
+ *    (modeling_t5.py:536-560, Qformer.py:141-147 feeding :195-262);
+ *  - ext_group_n > 0: output columns [g * ext_group_n, (g + 1) * ext_group_n) take columns [64 g, 64 g + 64) of Aext as their K extension:
+ *    the cross-attention K / V projections of ALL decoder layers (modeling_t5.py:561-599, peft LoRA on each) as one GEMM. */
+ *    (t_count > 0: range j < t_count goes to tout0 + j * t_stride elements instead of the three pointers);
+int mrblip_gemm_set_extra(void* tout0, void* tout1, void* tout2, int t_inner, int t_rows, int t_spad, long long t_bs, long long t_hs,
+                          long long t_stride, int t_count, int ext_group_n);
 /* Launch shape of mrblip_dec_proj for R <= 16 (round 4; host-side state, no torch counterpart): n_blocks > 0 = blocks of the streaming kernel for
  * the calling thread's later launches — each block owns a contiguous range of 16-column tiles and streams their weight rows back to back
  * (0 = one block per CU, < 0 = unchanged); the engine asks for as many blocks as the frozen-ViT look-ahead leaves CUs.  version 0 = the

@@ -480,6 +480,56 @@ extern "C" int mrblip_lora_dx_add(void* dx, long long lddx, int dx_f32, const vo
   else hipLaunchKernelGGL(lora_dx_add_kernel<false>, dim3(grid_for((long long)M * K / 4)), dim3(256), 0, stream, dx, lddx, (const bf16_t*)G, ldg, (const bf16_t*)Acat_bf16, R, M, K, mk_drop(seed_ptr, site, p));
   return mrblip_check_launch("lora_dx_add");
 }
+// the same for `groups` LoRA groups that share the input (round 4): dx[m, k] += sum_g mask_g[m, k] * (G[m, g * g_gstride : + R] . A[g * a_gstride ...][:, k]),
+// mask_g drawn with call-site id site0 + g * site_stride — the rank-R parts of the input gradient of ALL decoder layers' cross-attention
+// K / V adapters (each layer masked its own copy of the encoder output) in one pass over dx instead of one read-modify-write per layer.
+__global__ __launch_bounds__(256) void lora_dx_add_batched_kernel(float* __restrict__ dx, long long lddx, const bf16_t* __restrict__ G, long long ldg,
+                                                                  long long g_gstride, const bf16_t* __restrict__ A, long long a_gstride, int R, int M,
+                                                                  int K, int groups, uint32_t site_stride, DropoutArg drop) {
+  const long long total4 = (long long)M * (K / 4);
+  const uint32_t seed = drop.seed_ptr ? mrb_seed_load(drop.seed_ptr) : 0u;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
+    const int m = (int)(i / (K / 4)), k = (int)(i % (K / 4)) * 4;
+    float tot[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int g = 0; g < groups; ++g) {
+      float add[4] = {0.f, 0.f, 0.f, 0.f};
+      const bf16_t* Ag = A + g * a_gstride;
+      for (int r0 = 0; r0 < R; r0 += 8) {
+        const bf16x8 gv = *reinterpret_cast<const bf16x8*>(G + (long long)m * ldg + g * g_gstride + r0);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const float gr = bf2f((bf16_t)gv[r]);
+          const uint2 a = *reinterpret_cast<const uint2*>(Ag + (long long)(r0 + r) * K + k);
+          add[0] += gr * bf2f((bf16_t)(a.x & 0xffff)); add[1] += gr * bf2f((bf16_t)(a.x >> 16));
+          add[2] += gr * bf2f((bf16_t)(a.y & 0xffff)); add[3] += gr * bf2f((bf16_t)(a.y >> 16));
+        }
+      }
+      if (drop.seed_ptr) {
+        const uint32_t site = drop.site + (uint32_t)g * site_stride;
+        bool k0, k1, k2, k3;
+        mrb_keep2((uint32_t)m * (uint32_t)K + (uint32_t)k, seed, site, drop.thresh24, k0, k1);
+        mrb_keep2((uint32_t)m * (uint32_t)K + (uint32_t)k + 2u, seed, site, drop.thresh24, k2, k3);
+        tot[0] += k0 ? add[0] * drop.inv_keep : 0.f; tot[1] += k1 ? add[1] * drop.inv_keep : 0.f;
+        tot[2] += k2 ? add[2] * drop.inv_keep : 0.f; tot[3] += k3 ? add[3] * drop.inv_keep : 0.f;
+      } else {
+        tot[0] += add[0]; tot[1] += add[1]; tot[2] += add[2]; tot[3] += add[3];
+      }
+    }
+    float4* q = reinterpret_cast<float4*>(dx + (long long)m * lddx + k);
+    float4 v = *q;
+    v.x += tot[0]; v.y += tot[1]; v.z += tot[2]; v.w += tot[3];
+    *q = v;
+  }
+}
+extern "C" int mrblip_lora_dx_add_batched(float* dx, long long lddx, const void* G, long long ldg, long long g_gstride, const void* A, long long a_gstride,
+                                          int R, int M, int K, int groups, const uint32_t* seed_ptr, uint32_t site0, uint32_t site_stride, float p,
+                                          hipStream_t stream) {
+  MRB_REQUIRE(M > 0 && K > 0 && K % 4 == 0 && ldg % 8 == 0 && g_gstride % 8 == 0 && a_gstride % 4 == 0 && lddx % 4 == 0 && R > 0 && R <= 32 && R % 8 == 0 && groups > 0,
+              "lora_dx_add_batched: bad shape");
+  hipLaunchKernelGGL(lora_dx_add_batched_kernel, dim3(grid_for((long long)M * K / 4)), dim3(256), 0, stream, dx, lddx, (const bf16_t*)G, ldg, g_gstride,
+                     (const bf16_t*)A, a_gstride, R, M, K, groups, site_stride, mk_drop(seed_ptr, site0, p));
+  return mrblip_check_launch("lora_dx_add_batched");
+}
 extern "C" int mrblip_dropout_bf16(const void* x, long long ldx, void* out, long long ldo, int M, int N, const uint32_t* seed_ptr, uint32_t site,
                                    float p, hipStream_t stream) {
   MRB_REQUIRE(M > 0 && N > 0 && N % 8 == 0 && ldx % 8 == 0 && ldo % 8 == 0, "dropout_bf16: bad shape");

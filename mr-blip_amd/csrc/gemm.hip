@@ -53,6 +53,15 @@ struct GemmArgs {
   // (the caller pre-initialised it: residual or zero).  With M <= 32 rows a [32 x N] output has only N / 32 tiles — 64 for the T5
   // d_model — and one CU streams ~20 GB/s of weights: the K split puts every CU on the weight stream.
   int k_splits;
+  // round 4 (tile kernels, bf16 output, plain / bias epilogue only; set through mrblip_gemm_set_extra for the NEXT launch of the thread):
+  // head-transposed copies of up to three consecutive column ranges of width t_inner (heads of 64) — what mrblip_head_transpose would
+  // write from the output, pad columns [t_rows, t_spad) included: tout[j][b][h][d][s] = out[b * t_rows + s][j * t_inner + h * 64 + d];
+  // needs B == 1 or t_rows % 32 == 0 (a wave's 32-row slab then lies inside one clip, 32-aligned).
+  // t_count > 0: range j < t_count goes to tout[0] + j * t_stride (elements) instead — any number of ranges in one buffer.
+  bf16_t* tout[3]; int t_inner, t_rows, t_spad; long long t_bs, t_hs, t_stride; int t_count;
+  // the K extension of output-column group g = n / ext_group_n reads columns [64 g, 64 g + 64) of Aext (0: one group): one GEMM for the
+  // cross-attention K / V projections of ALL decoder layers, each layer with its own LoRA "down" activations
+  int ext_group_n;
 };
 
 // v0..v3: 4 consecutive columns n0..n0+3 of row m (raw accumulator). Applies bias -> (pre-activation copy) -> GELU -> dropout -> residual.
@@ -305,8 +314,9 @@ __global__ __launch_bounds__(WGM* WGN * 64, gemm_min_blocks(NS * (BM + BN) * BK 
                                                         (uint32_t)((long long)p.N * p.ldw * 2), vpa, vpw, w, koff);
     } else {
       uint32_t ea[JA], ew[JW];
+      const uint32_t egrp = p.ext_group_n ? (uint32_t)((bn * BNO) / p.ext_group_n) * 128u : 0u;   // this tile's 64-column slot of Aext
 #pragma unroll
-      for (int j = 0; j < JA; ++j) ea[j] = vAe + (uint32_t)((long long)(bm * BM + (j * NW + w) * RPI) * p.ldaext * 2);
+      for (int j = 0; j < JA; ++j) ea[j] = vAe + egrp + (uint32_t)((long long)(bm * BM + (j * NW + w) * RPI) * p.ldaext * 2);
 #pragma unroll
       for (int j = 0; j < JW; ++j) ew[j] = vWe + (uint32_t)((long long)w_row_base(j) * p.ldwext * 2);
       gemm_stage_dma_ext<JA, JW, NW, RPI * RB, PARTS, PART>(base, base + A_BYTES, p.Aext, (uint32_t)((long long)p.M * p.ldaext * 2), p.Wext,
@@ -332,7 +342,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, gemm_min_blocks(NS * (BM + BN) * BK 
       const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.Aext), 0, (int)(uint32_t)((long long)p.M * p.ldaext * 2), 0x00020000);
       const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.Wext), 0, (int)(uint32_t)((long long)p.N * p.ldwext * 2), 0x00020000);
 #pragma unroll
-      for (int j = 0; j < JA; ++j) rs_a[j] = __builtin_amdgcn_raw_buffer_load_b128(ra, vAe + (uint32_t)((long long)(bm * BM + (j * NW + w) * RPI) * p.ldaext * 2), koff, 0);
+      for (int j = 0; j < JA; ++j) rs_a[j] = __builtin_amdgcn_raw_buffer_load_b128(ra, vAe + (p.ext_group_n ? (uint32_t)((bn * BNO) / p.ext_group_n) * 128u : 0u) + (uint32_t)((long long)(bm * BM + (j * NW + w) * RPI) * p.ldaext * 2), koff, 0);
 #pragma unroll
       for (int j = 0; j < JW; ++j) rs_w[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, vWe + (uint32_t)((long long)w_row_base(j) * p.ldwext * 2), koff, 0);
     }
@@ -571,6 +581,38 @@ __global__ __launch_bounds__(WGM* WGN * 64, gemm_min_blocks(NS * (BM + BN) * BK 
           epilogue_store8v(p, drop_seed, OUT_F32, m, n0, a0, a1, ncols, make_float4(bq[i][0][0], bq[i][0][1], bq[i][0][2], bq[i][0][3]),
                            make_float4(bq[i][1][0], bq[i][1][1], bq[i][1][2], bq[i][1][3]), make_float4(rq[i][0][0], rq[i][0][1], rq[i][0][2], rq[i][0][3]),
                            make_float4(rq[i][1][0], rq[i][1][1], rq[i][1][2], rq[i][1][3]));
+      }
+      if constexpr (!OUT_F32 && SLAB_COLS == 64) {
+        if (p.t_inner > 0) {   // block-uniform: the head-transposed copies.  Lane = one output column: it reads the slab column-wise (row stride 68
+                               // words: 64 distinct banks), and writes its 32 positions as 64 contiguous bytes of the [.., d, s] row
+          const int n = bn * BN + wn * (BN / WGN) + lane;
+          const int bclip = m_base / p.t_rows, s0 = m_base - bclip * p.t_rows;
+          const int which = n / p.t_inner;
+          bf16_t* td = nullptr;
+          if (n < p.N && s0 < p.t_spad && m_base < p.M) {   // (a slab wholly past the last row belongs to no clip; the slab holding a clip's last
+                                                            // row reaches the end of its 32-padded tile: t_spad == roundup32(t_rows))
+            if (p.t_count > 0) td = which < p.t_count ? p.tout[0] + (long long)which * p.t_stride : nullptr;
+            else if (which < 3) td = p.tout[which];
+          }
+          if (td) {
+            const int cc = n - which * p.t_inner;
+            const float bv = p.bias ? p.bias[n] : 0.f;
+            uint32_t pk[16];
+#pragma unroll
+            for (int r2 = 0; r2 < 16; ++r2) {
+              float a = *reinterpret_cast<const float*>(slab + (2 * r2) * RS + lane * 4) + bv;
+              float b = *reinterpret_cast<const float*>(slab + (2 * r2 + 1) * RS + lane * 4) + bv;
+              a = (m_base + 2 * r2 < p.M) ? a : 0.f;          // rows past the problem = the pad columns of the transposed tile: zeros
+              b = (m_base + 2 * r2 + 1 < p.M) ? b : 0.f;
+              pk[r2] = pack2bf(a, b);
+            }
+            uint4* q = reinterpret_cast<uint4*>(td + bclip * p.t_bs + (long long)(cc >> 6) * p.t_hs + (long long)(cc & 63) * p.t_spad + s0);
+            q[0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+            q[1] = make_uint4(pk[4], pk[5], pk[6], pk[7]);
+            q[2] = make_uint4(pk[8], pk[9], pk[10], pk[11]);
+            q[3] = make_uint4(pk[12], pk[13], pk[14], pk[15]);
+          }
+        }
       }
     }
   }
@@ -1519,6 +1561,19 @@ extern "C" int mrblip_gemm_set_cu_reserve(int n_cus) {
 }
 
 // shared by the C entry points: validation, tile selection, launch.  ext_first / ext_* / a_* : see GemmArgs.
+// one-shot extras of the calling thread's NEXT mrblip_gemm_bf16 / mrblip_gemm_lora_dx launch (round 4): see GemmArgs.tout / ext_group_n
+struct GemmExtra { void* tout[3]; int t_inner, t_rows, t_spad; long long t_bs, t_hs, t_stride; int t_count, ext_group_n; bool set; };
+static thread_local GemmExtra g_gemm_extra = {};
+extern "C" int mrblip_gemm_set_extra(void* tout0, void* tout1, void* tout2, int t_inner, int t_rows, int t_spad, long long t_bs, long long t_hs,
+                                     long long t_stride, int t_count, int ext_group_n) {
+  const bool any_t = tout0 || tout1 || tout2;
+  MRB_REQUIRE(!any_t || (t_inner > 0 && (t_inner % 64) == 0 && t_rows > 0 && t_spad == (t_rows + 31) / 32 * 32), "gemm_set_extra: head-transposed copies need a head layout (t_inner %% 64 == 0, t_spad == roundup32(t_rows))");
+  MRB_REQUIRE(ext_group_n >= 0 && (ext_group_n % 256) == 0, "gemm_set_extra: ext_group_n must be a multiple of 256");
+  MRB_REQUIRE(t_count >= 0 && (t_count == 0 || (tout0 && t_stride > 0 && (t_stride % 8) == 0)), "gemm_set_extra: t_count ranges need tout0 and a 16-B aligned t_stride");
+  g_gemm_extra = GemmExtra{{tout0, tout1, tout2}, any_t ? t_inner : 0, t_rows, t_spad, t_bs, t_hs, t_stride, t_count, ext_group_n, true};
+  return MRBLIP_OK;
+}
+
 static int gemm_dispatch(const void* A, long long lda, const void* W, long long ldw, const void* Aext, long long ldaext,
                          const void* Wext, long long ldwext, int M, int N, int K, void* out, long long ldo, int out_f32,
                          void* out2, long long ldo2, const float* bias, const float* residual, long long ldr, int act,
@@ -1537,6 +1592,16 @@ static int gemm_dispatch(const void* A, long long lda, const void* W, long long 
   a.ext_first = ext_first;
   a.m_rows_per_block = 32;
   a.k_splits = 1;
+  const GemmExtra extra = g_gemm_extra;
+  g_gemm_extra = GemmExtra{};
+  a.tout[0] = (bf16_t*)extra.tout[0]; a.tout[1] = (bf16_t*)extra.tout[1]; a.tout[2] = (bf16_t*)extra.tout[2];
+  a.t_inner = extra.set ? extra.t_inner : 0; a.t_rows = extra.t_rows; a.t_spad = extra.t_spad; a.t_bs = extra.t_bs; a.t_hs = extra.t_hs;
+  a.t_stride = extra.t_stride; a.t_count = extra.set ? extra.t_count : 0;
+  a.ext_group_n = extra.set ? extra.ext_group_n : 0;
+  const bool has_extra = a.t_inner > 0 || a.ext_group_n > 0;
+  MRB_REQUIRE(a.t_inner == 0 || (!out_f32 && !gated && act == 0 && !(p_drop > 0.f) && !residual && !out2 && (M == a.t_rows || (a.t_rows % 32) == 0) && (M % a.t_rows) == 0),
+              "gemm: head-transposed copies need a bf16 output with a plain / bias epilogue and one clip or t_rows %% 32 == 0");
+  MRB_REQUIRE(a.ext_group_n == 0 || (Aext && !gated && (N % a.ext_group_n) == 0 && ldaext >= (long long)(N / a.ext_group_n) * 64), "gemm: ext_group_n needs a K extension with one 64-column slot per group");
   mk_drop_arg(a.ext_drop, seed_ptr, ext_site, ext_p);
   mk_drop_arg(a.a_drop, seed_ptr, a_site, a_p);
   MRB_REQUIRE(!(ext_p > 0.f || a_p > 0.f) || seed_ptr, "gemm: dropout needs a device seed pointer");
@@ -1599,6 +1664,12 @@ static int gemm_dispatch(const void* A, long long lda, const void* W, long long 
       else if (t64x128 >= 400 || gated) cfg = 4;
       else cfg = 5;
     }
+  }
+  if (has_extra) {   // the extras live in the generic tile kernel's staging / epilogue; the transposed copies need 64-column wave slabs
+    if (a.t_inner > 0 && cfg == 5) cfg = 4;
+    if (cfg == 13 || (cfg == 3 && (tile_cfg & 0xff) == 0)) cfg = (M >= 1024 && N >= 1024) ? 2 : 4;
+    MRB_REQUIRE(cfg == 1 || cfg == 2 || cfg == 4 || cfg == 7 || cfg == 8 || cfg == 9 || cfg == 11 || (a.t_inner == 0 && (cfg == 5 || cfg == 10 || cfg == 12)),
+                "gemm: head-transposed copies / grouped K extension are not available in tile config %d", cfg);
   }
   if (cfg == 3) {
     MRB_REQUIRE(!gated, "gemm: skinny kernel has no gated epilogue");

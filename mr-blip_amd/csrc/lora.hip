@@ -34,6 +34,10 @@ struct LoraRowsArgs {
   // optional side job for the K-split GEMM that follows on the stream (gemm.hip, k_splits): init_dst[m, 0:init_n] = init_src[m, :] (or 0)
   // for the same rows — the fp32 output its blocks then add their partial products to; costs no launch of its own
   float* init_dst; const float* init_src; long long ld_idst, ld_isrc; int init_n;
+  // batched form (thin kernel only, gridDim.y groups; round 4): group g reads X + g * x_gstride, A + g * a_gstride, writes U + g * u_gstride
+  // (elements) and draws its mask with call-site id drop.site + g * site_stride — the LoRA "down" products of ALL decoder layers'
+  // cross-attention K / V adapters on one encoder output (x_gstride = 0), or their backward's g = dy B on the layers' dy column blocks
+  long long x_gstride, a_gstride, u_gstride; uint32_t site_stride;
 };
 
 #define LORA_KC 2048  // K chunk held in LDS: R x (up to) 2048 bf16
@@ -185,9 +189,12 @@ __global__ __launch_bounds__(512) void lora_thin_kernel(const LoraRowsArgs p) {
   const bool row_ok = l15 < ROWS && row < p.M;
   const bool has_drop = p.drop.seed_ptr != nullptr;
   const uint32_t seed = has_drop ? mrb_seed_load(p.drop.seed_ptr) : 0u;
+  const int grp = blockIdx.y;                              // batched form: this block's group (0 otherwise)
+  const uint32_t site = p.drop.site + (uint32_t)grp * p.site_stride;
+  bf16_t* const Ug = p.U + grp * p.u_gstride;
   // bounds-checked operands: rows >= M of X and rows >= R of A lie beyond the last byte of their resource and read as zero
-  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.X), 0, (int)((((long long)p.M - 1) * p.ldx + p.K) * 2), 0x00020000);
-  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.A), 0, (int)((((long long)p.R - 1) * p.lda + p.K) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.X + grp * p.x_gstride), 0, (int)((((long long)p.M - 1) * p.ldx + p.K) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.A + grp * p.a_gstride), 0, (int)((((long long)p.R - 1) * p.lda + p.K) * 2), 0x00020000);
   const uint32_t xoff = (uint32_t)(((long long)row * p.ldx + kg * 8) * 2);
   uint32_t aoff[NT];
 #pragma unroll
@@ -218,7 +225,7 @@ __global__ __launch_bounds__(512) void lora_thin_kernel(const LoraRowsArgs p) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           bool k0, k1;
-          mrb_keep2(e + 2 * q, seed, p.drop.site, p.drop.thresh24, k0, k1);
+          mrb_keep2(e + 2 * q, seed, site, p.drop.thresh24, k0, k1);
           x[q] = (k0 ? x[q] & 0xffffu : 0u) | (k1 ? x[q] & 0xffff0000u : 0u);
         }
       }
@@ -260,7 +267,7 @@ __global__ __launch_bounds__(512) void lora_thin_kernel(const LoraRowsArgs p) {
     const float post = has_drop ? p.drop.inv_keep : 1.0f;
     const int r0 = w * 16 + 4 * kg;
     if (row_ok && r0 < p.R)
-      *reinterpret_cast<uint2*>(p.U + (long long)row * p.ldu + r0) = make_uint2(pack2bf(v[0] * post, v[1] * post), pack2bf(v[2] * post, v[3] * post));
+      *reinterpret_cast<uint2*>(Ug + (long long)row * p.ldu + r0) = make_uint2(pack2bf(v[0] * post, v[1] * post), pack2bf(v[2] * post, v[3] * post));
   }
 }
 
@@ -282,20 +289,20 @@ static int lora_thin_min_m() {   // rows from which the matrix-core thin kernel 
   return m;
 }
 
-static int launch_thin(const LoraRowsArgs& a, hipStream_t st) {
+static int launch_thin(const LoraRowsArgs& a, hipStream_t st, int groups = 1) {
   // 8-row blocks (MRB_LORA_THIN_ROWS=8; M = 2012: 252 blocks instead of 126) are FASTER stand-alone (enc g wi 17.8 vs 21.1 us, g qkv 14.4 vs
   // 16.3) and SLOWER in the train step (71.95 vs 71.36 ms; row kernel: 72.55): the 126-block form leaves half of the CUs to the
   // gradient side stream and the look-ahead ViT that run beside it.  16 rows is the default.
   static int rows8 = -1;
   if (rows8 < 0) { const char* e = getenv("MRB_LORA_THIN_ROWS"); rows8 = (e && atoi(e) == 8) ? 1 : 0; }
-  const bool half = rows8 && (a.M + 15) / 16 < lora_num_cu();
-  const int grid = half ? (a.M + 7) / 8 : (a.M + 15) / 16;
+  const bool half = rows8 && groups == 1 && (a.M + 15) / 16 < lora_num_cu();
+  const dim3 grid(half ? (a.M + 7) / 8 : (a.M + 15) / 16, groups);
   if (a.R <= 16) {
-    if (half) hipLaunchKernelGGL((lora_thin_kernel<1, 8, 8>), dim3(grid), dim3(512), 0, st, a);
-    else hipLaunchKernelGGL((lora_thin_kernel<1, 8, 16>), dim3(grid), dim3(512), 0, st, a);
+    if (half) hipLaunchKernelGGL((lora_thin_kernel<1, 8, 8>), grid, dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((lora_thin_kernel<1, 8, 16>), grid, dim3(512), 0, st, a);
   } else {
-    if (half) hipLaunchKernelGGL((lora_thin_kernel<2, 4, 8>), dim3(grid), dim3(512), 0, st, a);
-    else hipLaunchKernelGGL((lora_thin_kernel<2, 4, 16>), dim3(grid), dim3(512), 0, st, a);
+    if (half) hipLaunchKernelGGL((lora_thin_kernel<2, 4, 8>), grid, dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((lora_thin_kernel<2, 4, 16>), grid, dim3(512), 0, st, a);
   }
   return mrblip_check_launch("lora_thin");
 }
@@ -351,6 +358,7 @@ static int lora_rows_impl(const void* X, long long ldx, const void* A, long long
   a.drop.inv_keep = 1.0f / (1.0f - p_drop);
   MRB_REQUIRE(!init_dst || ((init_n % 4) == 0 && (ld_idst % 4) == 0 && (!init_src || (ld_isrc % 4) == 0)), "lora_rows: init job needs 16-B rows");
   a.init_dst = init_dst; a.init_src = init_src; a.ld_idst = ld_idst; a.ld_isrc = ld_isrc; a.init_n = init_dst ? init_n : 0;
+  a.x_gstride = a.a_gstride = a.u_gstride = 0; a.site_stride = 0;
   if (M >= lora_thin_min_m() && (K % 32) == 0 && (ldu % 4) == 0 && ((uintptr_t)U % 8) == 0 && (long long)M * ldx * 2 < (1ll << 31) && lora_thin_enabled())
     return launch_thin(a, stream);
   switch (R / 8) {
@@ -364,6 +372,29 @@ static int lora_rows_impl(const void* X, long long ldx, const void* A, long long
 extern "C" int mrblip_lora_rows(const void* X, long long ldx, const void* A, long long lda, int M, int R, int K, void* U, long long ldu,
                                 const int* seg, const uint32_t* seed_ptr, uint32_t site, float p_drop, hipStream_t stream) {
   return lora_rows_impl(X, ldx, A, lda, M, R, K, U, ldu, seg, seed_ptr, site, p_drop, nullptr, 0, nullptr, 0, 0, stream);
+}
+
+// The same product for `groups` problems in ONE launch (round 4): group g reads X + g * x_gstride (0: every group reads the same rows),
+// A + g * a_gstride, writes U + g * u_gstride (elements) and masks with call-site id site0 + g * site_stride.  Matrix-core thin kernel only:
+// K % 32 == 0, ldu % 4 == 0, R <= 32 (any M: short inputs just leave CUs idle).
+extern "C" int mrblip_lora_rows_batched(const void* X, long long ldx, long long x_gstride, const void* A, long long lda, long long a_gstride, int M, int R,
+                                        int K, void* U, long long ldu, long long u_gstride, int groups, const uint32_t* seed_ptr, uint32_t site0,
+                                        uint32_t site_stride, float p_drop, hipStream_t stream) {
+  MRB_REQUIRE(M > 0 && K > 0 && (K % 32) == 0 && R > 0 && R <= 32 && (R % 8) == 0 && groups > 0 && groups <= 65535, "lora_rows_batched: bad shape (M=%d R=%d K=%d groups=%d)", M, R, K, groups);
+  MRB_REQUIRE((ldx % 8) == 0 && (lda % 8) == 0 && (x_gstride % 8) == 0 && (a_gstride % 8) == 0 && (u_gstride % 4) == 0 && (ldu % 4) == 0 && ((uintptr_t)X % 16) == 0 &&
+                  ((uintptr_t)A % 16) == 0 && ((uintptr_t)U % 8) == 0 && ldu >= R, "lora_rows_batched: alignment");
+  MRB_REQUIRE((long long)M * ldx * 2 < (1ll << 31), "lora_rows_batched: X exceeds the 2 GiB buffer range");
+  MRB_REQUIRE(!(p_drop > 0.f) || seed_ptr, "lora_rows_batched: dropout needs a device seed pointer");
+  LoraRowsArgs a;
+  a.X = (const bf16_t*)X; a.ldx = ldx; a.A = (const bf16_t*)A; a.lda = lda; a.U = (bf16_t*)U; a.ldu = ldu; a.M = M; a.K = K; a.R = R;
+  for (int j = 0; j < 4; ++j) { a.seg_k0[j] = 0; a.seg_k1[j] = K; }
+  a.drop.seed_ptr = (p_drop > 0.f) ? seed_ptr : nullptr;
+  a.drop.site = site0;
+  a.drop.thresh24 = (uint32_t)(p_drop * 65536.0f + 0.5f);
+  a.drop.inv_keep = 1.0f / (1.0f - p_drop);
+  a.init_dst = nullptr; a.init_src = nullptr; a.ld_idst = a.ld_isrc = 0; a.init_n = 0;
+  a.x_gstride = x_gstride; a.a_gstride = a_gstride; a.u_gstride = u_gstride; a.site_stride = site_stride;
+  return launch_thin(a, stream, groups);
 }
 
 // mrblip_lora_rows + the side job  init_dst[m, 0:init_n] = init_src ? init_src[m, :] : 0  over the same M rows (fp32): prepares the

@@ -203,6 +203,7 @@ class MrBlipEngine:
             seed = int(torch.initial_seed()) & 0x7FFFFFFF
         self.cfg, self.dev = cfg, device
         self.ws: Dict[str, torch.Tensor] = {}
+        self.enc_t_saved: Dict[int, bool] = {}    # encoder layer -> Q^T / K^T were written by the forward's qkv GEMM
         self.dec_t_saved: Dict[int, bool] = {}    # decoder layer -> Q^T / K^T of its self-attention were written by the forward's fused projection
         # round 4: workspace of the cross-block key split of the decoder's cross attention (csrc/attention.hip F_XS): tickets (zero) + partials
         self.xs_ws = torch.zeros(2 * 1024 * 1024, dtype=torch.int32, device=self.dev) if os.environ.get("MRB_ATTN_XS", "1") == "1" else None
@@ -476,12 +477,21 @@ class MrBlipEngine:
         ops.cast_dropout(x, out_bf16=xb, out_f32=x, drop=self.qdrop(self.qf_emb_site, pdrop))
         vt_s = self.buf("qf_vt_s", (F_, H, ops.rup32(hd), ops.rup32(nq)), bf16)
         vt_c = self.buf("qf_vt_c", (F_, H, ops.rup32(hd), ops.rup32(Tv)), bf16)
+        t_ok = self.tout_ok(hd, F_, nq, 4)
+        want_t = bool(self.gemm_tout_sites & 8)   # the transposed Q / K copies of the forward are kept for the backward (eval / generate pay a few MB for them)
+        self.qf_t_saved = t_ok and want_t
         for i, L in enumerate(self.qf["layers"]):
             S_ = L["self"]
             qkv = self.buf(f"qf{i}_qkv", (Mq, 3 * D), bf16, zero=False)
-            ops.gemm(xb, S_["qkv_w"], qkv, bias=S_["qkv_b"])
             q4, k4, v4 = self.v4(qkv, F_, nq, H, hd, 0), self.v4(qkv, F_, nq, H, hd, D), self.v4(qkv, F_, nq, H, hd, 2 * D)
-            ops.head_transpose(v4, out=vt_s)
+            if t_ok:   # the projection writes V^T for this layer's attention and Q^T / K^T for its backward
+                keep = want_t and i > 0   # (layer 0's self-attention has no backward: it only feeds the frozen query tokens)
+                qt_i = self.buf(f"qf{i}_qt_s", (F_, H, 64, ops.rup32(nq)), bf16) if keep else None
+                kt_i = self.buf(f"qf{i}_kt_s", (F_, H, 64, ops.rup32(nq)), bf16) if keep else None
+                ops.gemm(xb, S_["qkv_w"], qkv, bias=S_["qkv_b"], tout=(qt_i, kt_i, vt_s), t_rows=nq)
+            else:
+                ops.gemm(xb, S_["qkv_w"], qkv, bias=S_["qkv_b"])
+                ops.head_transpose(v4, out=vt_s)
             o = self.buf(f"qf{i}_o", (Mq, pad64(D)), bf16)
             lse = self.buf(f"qf{i}_lse", (F_, H, ops.rup32(nq)), f32)
             ops.attention_fwd(q4, k4, vt_s, self.v4(o, F_, nq, H, hd), lse, scale=scale, drop=self.qdrop(S_["sites"][0], pdrop))
@@ -493,7 +503,10 @@ class MrBlipEngine:
             if L["cross"] is not None:
                 C_ = L["cross"]
                 qc = self.buf(f"qf{i}_qc", (Mq, D), bf16, zero=False)
-                ops.gemm(xb, C_["q_w"], qc, bias=C_["q_b"])
+                if t_ok and want_t:   # ... and the cross-attention's Q^T
+                    ops.gemm(xb, C_["q_w"], qc, bias=C_["q_b"], tout=(self.buf(f"qf{i}_qt_c", (F_, H, 64, ops.rup32(nq)), bf16),), t_rows=nq)
+                else:
+                    ops.gemm(xb, C_["q_w"], qc, bias=C_["q_b"])
                 kv = self.buf(f"qf{i}_kvc", (F_ * Tv, 2 * D), bf16, zero=False)
                 ops.gemm(img, C_["kv_w"], kv, bias=C_["kv_b"])
                 k4, v4 = self.v4(kv, F_, Tv, H, hd, 0), self.v4(kv, F_, Tv, H, hd, D)
@@ -557,14 +570,22 @@ class MrBlipEngine:
                 nxt = self.buf(f"qf_dxc_{i % 2}", (Mq, D), f32, zero=False)
                 ops.layernorm_bwd(cur, self.ws[f"qf{i}_y2"], C_["lnw"], eps, dy)
                 ops.cast_dropout(dy, out_bf16=dyb, drop=self.qdrop(C_["sites"][1], pdrop))
-                ops.gemm(dyb, C_["owt"], do)
+                t_saved = getattr(self, "qf_t_saved", False) and self.tout_ok(hd, F_, nq, 8)
+                if t_saved:
+                    ops.gemm(dyb, C_["owt"], do, tout=(dot_s,), t_rows=nq)
+                else:
+                    ops.gemm(dyb, C_["owt"], do)
                 qc, kv, oc = self.ws[f"qf{i}_qc"], self.ws[f"qf{i}_kvc"], self.ws[f"qf{i}_oc"]
                 q4, k4, v4 = self.v4(qc, F_, nq, H, hd), self.v4(kv, F_, Tv, H, hd, 0), self.v4(kv, F_, Tv, H, hd, D)
                 do4 = self.v4(do, F_, nq, H, hd)
                 ops.head_transpose(k4, out=kt_c)
-                ops.head_transpose(q4, out=qt_s)
-                ops.head_transpose(do4, out=dot_s)
-                ops.attention_bwd(q4, k4, v4, self.v4(oc, F_, nq, H, hd), do4, kt_c, qt_s, dot_s, self.ws[f"qf{i}_lsec"], delta,
+                qt_x = qt_s
+                if t_saved:
+                    qt_x = self.ws[f"qf{i}_qt_c"]
+                else:
+                    ops.head_transpose(q4, out=qt_s)
+                    ops.head_transpose(do4, out=dot_s)
+                ops.attention_bwd(q4, k4, v4, self.v4(oc, F_, nq, H, hd), do4, kt_c, qt_x, dot_s, self.ws[f"qf{i}_lsec"], delta,
                                   self.v4(dqc, F_, nq, H, hd), self.v4(dkv, F_, Tv, H, hd, 0), self.v4(dkv, F_, Tv, H, hd, D),
                                   scale=scale, drop=self.qdrop(C_["sites"][0], pdrop))
                 ops.gemm(dkv, C_["kv_wt"], dimg, residual=dimg)
@@ -577,14 +598,22 @@ class MrBlipEngine:
             nxt = self.buf(f"qf_dxs_{i % 2}", (Mq, D), f32, zero=False)
             ops.layernorm_bwd(cur, self.ws[f"qf{i}_y"], S_["lnw"], eps, dy)
             ops.cast_dropout(dy, out_bf16=dyb, drop=self.qdrop(S_["sites"][1], pdrop))
-            ops.gemm(dyb, S_["owt"], do)
+            t_saved = getattr(self, "qf_t_saved", False) and self.tout_ok(hd, F_, nq, 8)
+            if t_saved:
+                ops.gemm(dyb, S_["owt"], do, tout=(dot_s,), t_rows=nq)
+            else:
+                ops.gemm(dyb, S_["owt"], do)
             qkv, o = self.ws[f"qf{i}_qkv"], self.ws[f"qf{i}_o"]
             q4, k4, v4 = self.v4(qkv, F_, nq, H, hd, 0), self.v4(qkv, F_, nq, H, hd, D), self.v4(qkv, F_, nq, H, hd, 2 * D)
             do4 = self.v4(do, F_, nq, H, hd)
-            ops.head_transpose(k4, out=kt_s)
-            ops.head_transpose(q4, out=qt_s)
-            ops.head_transpose(do4, out=dot_s)
-            ops.attention_bwd(q4, k4, v4, self.v4(o, F_, nq, H, hd), do4, kt_s, qt_s, dot_s, self.ws[f"qf{i}_lse"], delta,
+            kt_x, qt_x = kt_s, qt_s
+            if t_saved:
+                kt_x, qt_x = self.ws[f"qf{i}_kt_s"], self.ws[f"qf{i}_qt_s"]
+            else:
+                ops.head_transpose(k4, out=kt_s)
+                ops.head_transpose(q4, out=qt_s)
+                ops.head_transpose(do4, out=dot_s)
+            ops.attention_bwd(q4, k4, v4, self.v4(o, F_, nq, H, hd), do4, kt_x, qt_x, dot_s, self.ws[f"qf{i}_lse"], delta,
                               self.v4(dqkv, F_, nq, H, hd, 0), self.v4(dqkv, F_, nq, H, hd, D), self.v4(dqkv, F_, nq, H, hd, 2 * D),
                               scale=scale, drop=self.qdrop(S_["sites"][0], pdrop))
             ops.gemm(dqkv, S_["qkv_wt"], nxt, residual=dy)
@@ -673,14 +702,8 @@ class MrBlipEngine:
         self.acat_all = torch.zeros(n_acat, dtype=bf16, device=self.dev)
         self.bblk_all = torch.zeros(n_bblk, dtype=bf16, device=self.dev)
         self.acatt_all = torch.zeros(sum(g.K for g in groups), 64, dtype=bf16, device=self.dev)
-        wrow = aoff = boff = trow = 0
         gen = torch.Generator(device="cpu").manual_seed(4321)
-        for g in groups:
-            nad = len(g.adapters)
-            g.wext = self.wext_all[wrow: wrow + g.N]
-            g.acat = self.acat_all[aoff: aoff + 8 * nad * g.K].view(8 * nad, g.K)
-            g.bblk = self.bblk_all[boff: boff + 8 * nad * g.N].view(8 * nad, g.N)
-            g.acatt = self.acatt_all[trow: trow + g.K]
+        for g in groups:      # the flat trainable buffer in creation order (the layout checkpoints and named_parameters see)
             for j, a in enumerate(g.adapters):
                 a.a_off, a.bt_off = off, off + r * a.in_dim
                 a.A = self.flat[a.a_off: a.a_off + r * a.in_dim].view(r, a.in_dim)
@@ -688,8 +711,6 @@ class MrBlipEngine:
                 a.dA = self.grad[a.a_off: a.a_off + r * a.in_dim].view(r, a.in_dim)
                 a.dBt = self.grad[a.bt_off: a.bt_off + r * a.out].view(r, a.out)
                 off += r * (a.in_dim + a.out)
-                desc.append([a.a_off, a.bt_off, a.in_dim, a.out, aoff + 8 * j * g.K, (wrow + a.row0) * 64 + a.col0,
-                             boff + 8 * j * g.N + a.row0, g.N, trow * 64 + 8 * j, 0])
                 ka, kb = t + "base_model.model." + a.name + ".lora_A.default.weight", t + "base_model.model." + a.name + ".lora_B.default.weight"
                 if isinstance(src, StateDictSource) and ka in src.sd:
                     a.A.copy_(src.sd[ka])
@@ -699,10 +720,26 @@ class MrBlipEngine:
                 else:  # peft default: A kaiming-uniform(a=sqrt(5)), B zeros
                     bound = 1.0 / math.sqrt(a.in_dim)
                     a.A.copy_((torch.rand(r, a.in_dim, generator=gen) * 2 - 1) * bound)
+        # the bf16 operand copies (acat / wext / bblk / acatt) in PACKING order: the decoder's cross-attention K / V groups last and next to
+        # each other, layer by layer — their operands then form ONE stacked operand each, which the batched projection of all layers' cross
+        # K / V (round 4: one thin product + one GEMM instead of 24 + 24) addresses with a per-layer stride
+        ckv_groups = [L["ckv"] for L in self.t5["dec"]]
+        pack = [g for g in groups if not any(g is x for x in ckv_groups)] + ckv_groups
+        wrow = aoff = boff = trow = 0
+        for g in pack:
+            nad = len(g.adapters)
+            g.wext = self.wext_all[wrow: wrow + g.N]
+            g.acat = self.acat_all[aoff: aoff + 8 * nad * g.K].view(8 * nad, g.K)
+            g.bblk = self.bblk_all[boff: boff + 8 * nad * g.N].view(8 * nad, g.N)
+            g.acatt = self.acatt_all[trow: trow + g.K]
+            for j, a in enumerate(g.adapters):
+                desc.append([a.a_off, a.bt_off, a.in_dim, a.out, aoff + 8 * j * g.K, (wrow + a.row0) * 64 + a.col0,
+                             boff + 8 * j * g.N + a.row0, g.N, trow * 64 + 8 * j, 0])
             wrow += g.N
             aoff += 8 * nad * g.K
             boff += 8 * nad * g.N
             trow += g.K
+        self._stack_cross_kv(ckv_groups)
         self.adapters, self.groups = adapters, groups
         self.lora_desc = torch.tensor(desc, dtype=torch.int64, device=self.dev)
         # t5_proj / ln_vision (trainable)
@@ -739,6 +776,36 @@ class MrBlipEngine:
         ops.cast_dropout(self.proj_w, out_bf16=self.proj_wb)
         self.transpose2d(self.proj_wb, c.qf_dim, self.proj_wtb)
 
+    def _stack_cross_kv(self, ckv_groups):
+        """The frozen weights of all decoder layers' EncDecAttention.k / .v as ONE operand [L * 2 * inner, Kp] (and one transposed operand
+        [d, L * 2 * inner] for the backward); the per-layer groups keep working as views.  modeling_t5.py:561-599 computes these projections
+        layer by layer inside the decoder; they depend only on the encoder output."""
+        self.ckv_all = None
+        if not ckv_groups:
+            return
+        g0 = ckv_groups[0]
+        Lc, N, Kp, K = len(ckv_groups), g0.N, g0.W.shape[1], g0.K
+        if any(g.N != N or g.K != K or g.W.shape[1] != Kp or len(g.adapters) != 2 for g in ckv_groups):
+            return
+        sites = [g.site for g in ckv_groups]
+        stride = sites[1] - sites[0] if Lc > 1 else 0
+        if any(sites[i] != sites[0] + i * stride for i in range(Lc)) or stride < 0:
+            return
+        W = torch.empty(Lc * N, Kp, dtype=bf16, device=self.dev)
+        Wt = torch.zeros(g0.Wt.shape[0], pad64(Lc * N), dtype=bf16, device=self.dev)
+        for i, g in enumerate(ckv_groups):
+            W[i * N:(i + 1) * N].copy_(g.W)
+            Wt[:, i * N:(i + 1) * N].copy_(g.Wt[:, :N])
+            g.W, g.Wt = W[i * N:(i + 1) * N], Wt[:, i * N:(i + 1) * N]
+        a0, w0, b0 = ckv_groups[0].acat, ckv_groups[0].wext, ckv_groups[0].bblk
+        R = a0.shape[0]
+        self.ckv_all = dict(W=W, Wt=Wt, L=Lc, N=N, K=K, R=R, site0=sites[0], site_stride=stride,
+                            acat=torch.as_strided(a0, (Lc * R, K), (K, 1), a0.storage_offset()),          # [L * 16, K]
+                            wext=torch.as_strided(w0, (Lc * N, 64), (64, 1), w0.storage_offset()),        # [L * N, 64]
+                            bblk=torch.as_strided(b0, (Lc * R, N), (N, 1), b0.storage_offset()))          # [L * 16, N]
+        for i, g in enumerate(ckv_groups):   # the views of the stacked operands ARE the groups' operands (contiguous packing)
+            assert g.acat.data_ptr() == self.ckv_all["acat"][i * R].data_ptr() and g.wext.data_ptr() == self.ckv_all["wext"][i * N].data_ptr()
+
     # ---- LoRA-group forward / backward -------------------------------------------------------------------------
     def lg_fwd(self, g: LoraGroup, x: torch.Tensor, u: torch.Tensor, out: torch.Tensor, u_ready: bool = False, **kw):
         """out = x W^T + u B^T with u = dropout(x) (scale*A)^T:  the rank-8 "down" product is the row kernel of csrc/lora.hip (or was
@@ -767,6 +834,9 @@ class MrBlipEngine:
             return
         if not u_ready:
             self.lora_thin(x, g.acat, u, g.K, drop=self.drop(g.site, self.cfg.lora_dropout))
+        if tout is not None and out.dtype == bf16 and not kw.get("gated") and x.shape[0] > 64 and self.gemm_tout_enabled:
+            ops.gemm(x, g.W, out, aext=u, wext=g.wext, tout=tout, t_rows=t_rows, **kw)   # tile GEMM: head-transposed copies from its epilogue
+            return True
         ops.gemm(x, g.W, out, aext=u, wext=g.wext, **kw)
 
     # Opt-in (MRB_KSPLIT=1).  Measured on the QVH step: 76.6 vs 77.0 ms — the decoder chain is not what bounds the step once the
@@ -774,6 +844,17 @@ class MrBlipEngine:
     ksplit_enabled = os.environ.get("MRB_KSPLIT", "0") == "1"
     # Round 3: the adapted projections of the decoder's <= 16 rows as ONE launch each (forward: [RMSNorm +] LoRA down + GEMM + LoRA up +
     # epilogue; backward: g = dy B + the dX GEMM with its masked rank-8 term) instead of two.  MRB_DEC_PROJ=0 restores the two-launch path.
+    # Round 4: the tile GEMMs that produce q / k / v (and the backward's dO) also write the head-transposed copies the attention kernels read
+    # (csrc/gemm.hip GemmArgs.tout): no head_transpose launches in the T5 encoder and the Q-Former's self / query paths.  MRB_GEMM_TOUT=0
+    # restores the transpose launches.
+    gemm_tout_enabled = os.environ.get("MRB_GEMM_TOUT", "1") == "1"
+
+    gemm_tout_sites = int(os.environ.get("MRB_TOUT_SITES", "15"))   # bit mask for A/B: 1 T5 encoder fwd (+ stacked cross K/V), 2 encoder bwd, 4 Q-Former fwd, 8 Q-Former bwd
+
+    def tout_ok(self, hd: int, B: int, rows: int, site: int = 1) -> bool:
+        """heads of 64, and one clip or clips of a multiple of 32 rows (a wave's 32-row slab then lies inside one clip)"""
+        return self.gemm_tout_enabled and bool(self.gemm_tout_sites & site) and hd == 64 and (B == 1 or rows % 32 == 0)
+
     dec_proj_enabled = os.environ.get("MRB_DEC_PROJ", "1") == "1"
     dec_tout_enabled = os.environ.get("MRB_DEC_TOUT", "1") == "1"   # ... which also write the head-transposed copies the attention kernels read (0: head_transpose launches)
 
@@ -838,12 +919,12 @@ class MrBlipEngine:
             ops.rmsnorm_fwd(x, ln, self.cfg.t5_eps, out_bf16=xn)
             kw["tout"], kw["t_rows"] = tout, t_rows
             return self.lg_fwd(g, xn, u, out, **kw)
+        kw["tout"], kw["t_rows"] = tout, t_rows
         if self.fuse_norm_lora and x.shape[0] <= self.lora_rows_max_m and not per_adapter:
             ops.rmsnorm_lora_fwd(x, ln, self.cfg.t5_eps, xn, g.acat, u, drop=self.drop(g.site, self.cfg.lora_dropout))
-            self.lg_fwd(g, xn, u, out, u_ready=True, **kw)
-        else:
-            ops.rmsnorm_fwd(x, ln, self.cfg.t5_eps, out_bf16=xn)
-            self.lg_fwd(g, xn, u, out, **kw)
+            return self.lg_fwd(g, xn, u, out, u_ready=True, **kw)
+        ops.rmsnorm_fwd(x, ln, self.cfg.t5_eps, out_bf16=xn)
+        return self.lg_fwd(g, xn, u, out, **kw)
 
     fuse_norm_lora = os.environ.get("MRB_FUSE_NORM_LORA", "1") == "1"
 
@@ -898,7 +979,10 @@ class MrBlipEngine:
             if ks > 1:
                 ops.lora_dx(dy, g.Wt, gbuf, g.acatt, dx, pad64(g.N), residual=None, drop=drop, k_splits=ks)
             else:
-                ops.lora_dx(dy, g.Wt, gbuf, g.acatt, dx, pad64(g.N), residual=residual, drop=drop, tile_cfg=tile_cfg)
+                t_tile = tout is not None and dx.dtype == bf16 and residual is None and dy.shape[0] > 64 and self.gemm_tout_enabled
+                ops.lora_dx(dy, g.Wt, gbuf, g.acatt, dx, pad64(g.N), residual=residual, drop=drop, tile_cfg=tile_cfg,
+                            tout=tout if t_tile else None, t_rows=t_rows)
+                return bool(t_tile)
         return bool(fused and tout is not None and dx.dtype == bf16)   # True: the head-transposed copies of dx were written
 
     vit_rowv = os.environ.get("MRB_VIT_ROWV", "1") == "1"   # (0: the transposed-copy path, for A/B)
@@ -959,9 +1043,15 @@ class MrBlipEngine:
             xn = self.buf(f"e{i}_xn", (M, pad64(d)), bf16)
             u = self.buf(f"e{i}_u_qkv", (M, 64), bf16)
             qkv = self.buf(f"e{i}_qkv", (M, 3 * inner), bf16, zero=False)
-            self.norm_lg_fwd(x, L["ln0"], L["qkv"], xn, u, qkv, tile_cfg=_ENC_FWD_CFG[0])
+            # (round 4: the projection's epilogue writes V^T for this layer's attention and Q^T / K^T for its backward)
+            t_ok = self.tout_ok(dk, B, S)
+            qt_i = self.buf(f"e{i}_qt", (B, H, 64, ops.rup32(S)), bf16) if t_ok else None
+            kt_i = self.buf(f"e{i}_kt", (B, H, 64, ops.rup32(S)), bf16) if t_ok else None
+            t_done = self.norm_lg_fwd(x, L["ln0"], L["qkv"], xn, u, qkv, tile_cfg=_ENC_FWD_CFG[0], tout=(qt_i, kt_i, vt) if t_ok else None, t_rows=S)
+            self.enc_t_saved[i] = bool(t_done)
             q4, k4, v4 = self.v4(qkv, B, S, H, dk, 0), self.v4(qkv, B, S, H, dk, inner), self.v4(qkv, B, S, H, dk, 2 * inner)
-            ops.head_transpose(v4, out=vt)
+            if not t_done:
+                ops.head_transpose(v4, out=vt)
             o = self.buf(f"e{i}_o", (M, pad64(inner)), bf16)
             lse = self.buf(f"e{i}_lse", (B, H, ops.rup32(S)), f32)
             adrop = self.drop(L["sites"][0], p)
@@ -1021,7 +1111,8 @@ class MrBlipEngine:
             self.side_join()
             # K^T / Q^T of this layer depend only on saved forward activations: transposed on the side stream while the FFN backward runs
             kq_ready = None
-            if self.grad_side_stream_enabled:
+            t_saved = bool(self.enc_t_saved.get(i))
+            if self.grad_side_stream_enabled and not t_saved:
                 qkv_i = self.ws[f"e{i}_qkv"]
                 kq_ready = torch.cuda.Event()
 
@@ -1047,17 +1138,22 @@ class MrBlipEngine:
                 ops.cast_dropout(other, out_bf16=dyb2, drop=self.drop(L["sites"][1], p))
             dx, other = other, dx
             # xm = x_in + drop(o(attn(qkv(xn))))
-            self.lg_bwd(L["o"], dyb2, self.ws[f"e{i}_o"], self.ws[f"e{i}_u_o"], gb3, do, side=True, tile_cfg=_ENC_BWD_CFG[2], flush=False)
+            dot_done = self.lg_bwd(L["o"], dyb2, self.ws[f"e{i}_o"], self.ws[f"e{i}_u_o"], gb3, do, side=True, tile_cfg=_ENC_BWD_CFG[2], flush=False,
+                                   tout=(dot,) if self.tout_ok(dk, B, S, 2) else None, t_rows=S)
             qkv, o = self.ws[f"e{i}_qkv"], self.ws[f"e{i}_o"]
             q4, k4, v4 = self.v4(qkv, B, S, H, dk, 0), self.v4(qkv, B, S, H, dk, inner), self.v4(qkv, B, S, H, dk, 2 * inner)
             do4 = self.v4(do, B, S, H, dk)
-            ops.head_transpose(do4, out=dot)
-            if kq_ready is not None:
+            if not dot_done:
+                ops.head_transpose(do4, out=dot)
+            kt_x, qt_x = kt, qt
+            if t_saved:
+                kt_x, qt_x = self.ws[f"e{i}_kt"], self.ws[f"e{i}_qt"]
+            elif kq_ready is not None:
                 torch.cuda.current_stream().wait_event(kq_ready)
             else:
                 ops.head_transpose(k4, out=kt)
                 ops.head_transpose(q4, out=qt)
-            ops.attention_bwd(q4, k4, v4, self.v4(o, B, S, H, dk), do4, kt, qt, dot, self.ws[f"e{i}_lse"], delta,
+            ops.attention_bwd(q4, k4, v4, self.v4(o, B, S, H, dk), do4, kt_x, qt_x, dot, self.ws[f"e{i}_lse"], delta,
                               self.v4(dqkv, B, S, H, dk, 0), self.v4(dqkv, B, S, H, dk, inner), self.v4(dqkv, B, S, H, dk, 2 * inner),
                               scale=1.0, bias_lut=self.lut_enc, kmask=kmask, drop=self.drop(L["sites"][0], p),
                               drop_bits=self.ws.get(f"e{i}_dbits") if self.drop(L["sites"][0], p) is not None else None)
@@ -1076,6 +1172,73 @@ class MrBlipEngine:
         return dinp
 
     # ---- decoder + LM head + loss (forward and backward) ---------------------------------------------------------
+    cross_kv_batched = os.environ.get("MRB_CKV_BATCH", "1") == "1"
+
+    dec_grid_follows_reserve = os.environ.get("MRB_DEC_GRID_AUTO", "1") == "1"
+    ckv_fwd_chunks = tuple(int(x) for x in os.environ.get("MRB_CKV_FWD_CHUNKS", "2,6,8,8").split(","))
+    ckv_min_rows = int(os.environ.get("MRB_CKV_MIN_ROWS", "512"))
+
+    def cross_kv_all(self, enc: torch.Tensor, B: int, S: int, prefix: str, events: bool = False):
+        """Cross-attention K / V of ALL decoder layers for one encoder output, in CHUNKS of layers (round 4; chunk sizes ckv_fwd_chunks: the
+        first chunk is small so that decoder layer 0 does not wait for everything): per chunk the LoRA "down" products of its adapters (one
+        batched thin launch, each layer with its own lora_dropout call site) and ONE GEMM [B S, d] x [d, layers * 2 * inner] whose
+        output-column group of a layer takes that layer's "down" activations as its K extension and whose epilogue writes K^T and V^T.
+        Until round 3: per layer a thin launch, a GEMM and two head_transpose launches (modeling_t5.py:561-599 does it layer by layer
+        inside the decoder).  events: record an event behind every chunk (the caller runs this on a side stream).  Returns per layer
+        (K rows view, V^T, K^T, u view, ckv view, event or None), or None when the stacked form does not apply (d_kv != 64, several clips
+        of a length that is not a multiple of 32, per-adapter masks, short inputs — below ckv_min_rows rows the decoder-style streaming
+        projection of each layer is the better kernel: Charades-STA's 72 rows)."""
+        ca = getattr(self, "ckv_all", None)
+        c = self.cfg
+        H, dk = c.t5_heads, c.d_kv
+        if (ca is None or not self.cross_kv_batched or not self.tout_ok(dk, B, S) or B * S < self.ckv_min_rows
+                or (c.lora_mask_per_adapter and self.training and c.lora_dropout > 0)):
+            return None
+        Lc, N, K, R = ca["L"], ca["N"], ca["K"], ca["R"]
+        Me = B * S
+        u_all = self.buf(prefix + "u_ckv_all", (Me, Lc * 64), bf16)
+        ckv_all = self.buf(prefix + "ckv_all", (Me, Lc * N), bf16, zero=False)
+        t_all = self.buf(prefix + "ckvT_all", (2 * Lc, B, H, 64, ops.rup32(S)), bf16)
+        out = []
+        i0 = 0
+        sizes = list(self.ckv_fwd_chunks)
+        while i0 < Lc:
+            i1 = min(Lc, i0 + (sizes.pop(0) if sizes else self.ckv_fwd_chunks[-1]))
+            G = i1 - i0
+            ops.lora_rows_batched(enc, ca["acat"][i0 * R:], u_all[:, i0 * 64:], K, G, a_gstride=R * K, u_gstride=64, R=R,
+                                  drop=self.drop(ca["site0"] + i0 * ca["site_stride"], c.lora_dropout), site_stride=ca["site_stride"])
+            ops.gemm(enc, ca["W"][i0 * N:i1 * N], ckv_all[:, i0 * N:i1 * N], aext=u_all[:, i0 * 64:], wext=ca["wext"][i0 * N:i1 * N], ext_group_n=N,
+                     tout=t_all[2 * i0:2 * i1], t_rows=S)
+            ev = None
+            if events:
+                ev = torch.cuda.Event()
+                ev.record()
+            for i in range(i0, i1):
+                out.append((self.v4(ckv_all, B, S, H, dk, i * N), t_all[2 * i + 1], t_all[2 * i], u_all[:, i * 64:(i + 1) * 64], ckv_all[:, i * N:(i + 1) * N],
+                            ev if i == i0 else None))   # (stream order: a chunk's later layers are behind its first layer's wait)
+            i0 = i1
+        return out
+
+    ckv_bwd_chunks = tuple(int(x) for x in os.environ.get("MRB_CKV_BWD_CHUNKS", "10,8,4,2").split(","))
+
+    def ckv_chunk_bwd(self, i0: int, i1: int, dckv_all: torch.Tensor, g_all: torch.Tensor, enc: torch.Tensor, denc: torch.Tensor):
+        """Backward of the cross-attention K / V projections of decoder layers [i0, i1) (peft lora.Linear backward around modeling_t5.py:
+        561-599), launched on whatever stream is current: g = dy (sB) of every layer (one batched thin launch), the adapters' weight
+        gradients (one launch per layer), the rank-8 input-gradient terms of all layers with their own lora_dropout masks (one pass over
+        denc), and denc += dy_chunk W_chunk as ONE GEMM over the chunk's (i1 - i0) * 2 * inner output features."""
+        ca, c = self.ckv_all, self.cfg
+        N, K, R = ca["N"], ca["K"], ca["R"]
+        G = i1 - i0
+        ops.lora_rows_batched(dckv_all[:, i0 * N:], ca["bblk"][i0 * R:], g_all[:, i0 * 64:], N, G, x_gstride=N, a_gstride=R * N, u_gstride=64, R=R)
+        for i in range(i0, i1):
+            g = self.t5["dec"][i]["ckv"]
+            ads = g.adapters
+            ops.lora_grads(dckv_all[:, i * N:(i + 1) * N], self.ws[f"d{i}_u_ckv"], enc, g_all[:, i * 64:(i + 1) * 64], [a.dBt for a in ads], [a.row0 for a in ads],
+                           [a.out for a in ads], [a.dA for a in ads], g.K, drop=self.drop(g.site, c.lora_dropout))
+        ops.lora_dx_add_batched(denc, g_all[:, i0 * 64:], ca["acat"][i0 * R:], K, G, g_gstride=64, a_gstride=R * K, R=R,
+                                drop=self.drop(ca["site0"] + i0 * ca["site_stride"], c.lora_dropout), site_stride=ca["site_stride"])
+        ops.gemm(dckv_all[:, i0 * N:i1 * N], ca["Wt"][:, i0 * N:i1 * N], denc, residual=denc)
+
     @torch.no_grad()
     def t5_cross_kv(self, enc: torch.Tensor, Be: int, S: int):
         """Cross-attention K / V^T of every decoder layer for a fixed encoder output (inference: computed once per clip and reused by
@@ -1084,6 +1247,9 @@ class MrBlipEngine:
         H, dk = c.t5_heads, c.d_kv
         inner = H * dk
         Me = Be * S
+        allkv = self.cross_kv_all(enc, Be, S, "g_")
+        if allkv is not None:
+            return [(k4, vt) for k4, vt, _, _, _, _ in allkv]
         cache = []
         for i, L in enumerate(self.t5["dec"]):
             ukv = self.buf(f"g{i}_u_ckv", (Me, 64), bf16)
@@ -1125,7 +1291,14 @@ class MrBlipEngine:
                 ev0 = torch.cuda.Event()
                 ev0.record()
                 st.wait_event(ev0)
-            for i, L in enumerate(self.t5["dec"]):
+            with torch.cuda.stream(st) if use_side else contextlib.nullcontext():
+                allkv = self.cross_kv_all(enc, B, S, "d_", events=use_side)
+                self.ckv_stacked = allkv is not None
+                if allkv is not None:
+                    for i, (k4, vt_i, kt_i, u_i, ckv_i, ready) in enumerate(allkv):
+                        self.ws[f"d{i}_ckv"], self.ws[f"d{i}_kt_c"], self.ws[f"d{i}_u_ckv"] = ckv_i, kt_i, u_i
+                        ckv_side.append((k4, vt_i, ready))
+            for i, L in (enumerate(self.t5["dec"]) if allkv is None else ()):
                 ukv = self.buf(f"d{i}_u_ckv", (Me, 64), bf16)
                 ckv = self.buf(f"d{i}_ckv", (Me, 2 * inner), bf16, zero=False)
                 vt_i = self.buf(f"d{i}_vt_c", (B, H, ops.rup32(dk), ops.rup32(S)), bf16)
@@ -1310,6 +1483,25 @@ class MrBlipEngine:
         delta = self.buf("db_delta", (B, H, rl), f32)
         dyb0_ready = False
         dyb0_pair = (dybs[0], self.buf("db_dyb0b", (R, pad64(d)), bf16))
+        # round 4: with the stacked cross K / V projection (cross_kv_all) its backward runs per CHUNK of layers: dK / dV of all layers land
+        # in one [Me, L * 2 * inner] buffer, and when the backward has passed the lowest layer of a chunk the chunk's three launches go to the
+        # side stream (see ckv_chunk_bwd).  Chunks get smaller towards layer 0: only the last one is not hidden behind the decoder chain.
+        stacked = bool(getattr(self, "ckv_stacked", False)) and getattr(self, "ckv_all", None) is not None
+        chunk_starts: Dict[int, int] = {}
+        if stacked:
+            Lc = len(self.t5["dec"])
+            dckv_all = self.buf("db_dckv_all", (Me, Lc * 2 * inner), bf16, zero=False)
+            g_all = self.buf("db_ge_all", (Me, Lc * 64), bf16)
+            hi = Lc
+            for size in self.ckv_bwd_chunks:
+                lo = max(0, hi - size)
+                if hi > lo:
+                    chunk_starts[lo] = hi
+                hi = lo
+            while hi > 0:     # (more layers than the schedule names: keep cutting chunks of the last size)
+                lo = max(0, hi - self.ckv_bwd_chunks[-1])
+                chunk_starts[lo] = hi
+                hi = lo
         for i in reversed(range(len(self.t5["dec"]))):
             L = self.t5["dec"][i]
             # side stream (see the encoder backward): the LoRA weight-gradient launches of this layer, and the WHOLE backward of the
@@ -1334,7 +1526,7 @@ class MrBlipEngine:
             # cross attention
             dot_done = self.lg_bwd(L["co"], dyb, self.ws[f"d{i}_co"], self.ws[f"d{i}_u_co"], gbs[2], do, side=dside, flush=False,
                                    tout=(dot_s,) if (dk == 64 and self.dec_tout_enabled) else None, t_rows=Ld)
-            dckv = self.buf(f"db_dckv{i}", (Me, 2 * inner), bf16, zero=False)
+            dckv = dckv_all[:, i * 2 * inner:(i + 1) * 2 * inner] if stacked else self.buf(f"db_dckv{i}", (Me, 2 * inner), bf16, zero=False)
             cq, ckv, co = self.ws[f"d{i}_cq"], self.ws[f"d{i}_ckv"], self.ws[f"d{i}_co"]
             q4, k4, v4 = self.v4(cq, B, Ld, H, dk), self.v4(ckv, B, S, H, dk, 0), self.v4(ckv, B, S, H, dk, inner)
             do4 = self.v4(do, B, Ld, H, dk)
@@ -1349,7 +1541,14 @@ class MrBlipEngine:
             ops.attention_bwd(q4, k4, v4, self.v4(co, B, Ld, H, dk), do4, kt_c, qt_x, dot_s, self.ws[f"d{i}_lsec"], delta,
                               self.v4(dcq, B, Ld, H, dk), self.v4(dckv, B, S, H, dk, 0), self.v4(dckv, B, S, H, dk, inner),
                               scale=1.0, kmask=kmask, drop=self.drop(L["sites"][2], p))
-            if dside:   # queued: goes out with the cq group's record
+            if stacked:   # the cross K / V projections' backward in chunks of layers (see ckv_chunk_bwd); queued like the per-layer form
+                if i in chunk_starts:
+                    i1 = chunk_starts[i]
+                    if dside:
+                        self.side_defer(lambda i0=i, i1=i1: self.ckv_chunk_bwd(i0, i1, dckv_all, g_all, enc, denc))
+                    else:
+                        self.ckv_chunk_bwd(i, i1, dckv_all, g_all, enc, denc)
+            elif dside:   # queued: goes out with the cq group's record
                 ge_i, u_ckv_i = self.buf(f"db_ge{i}", (Me, 64), bf16), self.ws[f"d{i}_u_ckv"]
                 self.side_defer(lambda L=L, dckv=dckv, ge_i=ge_i, u_ckv_i=u_ckv_i: self.lg_bwd(L["ckv"], dckv, enc, u_ckv_i, ge_i, denc, residual=denc))
             else:
@@ -1541,6 +1740,11 @@ class MrBlipEngine:
             shard.attach(self)   # (first step only) one dropout stream for the group's replicated T5, per-rank Q-Former call sites
         if self.training:
             ops.seed_bump(self.seed)
+        # round 4: the decoder's streaming projections run as many blocks as the look-ahead ViT leaves CUs (one round of resident blocks;
+        # measured: 256 blocks beside a ViT that holds 192 CUs cost +0.4 ms per step, 64 blocks -0.3 ms); 0 = one block per CU
+        if self.dec_grid_follows_reserve:
+            nf = next_video.shape[0] * next_video.shape[1] if next_video is not None else 0
+            ops.dec_proj_config(self._reserve_schedule_for(nf)[-1][1] if next_video is not None else 0)
         self._mark("start")
         fr, img, xv, qb = self.frames_forward(video)
         self._mark("frames_forward (ViT + ln_vision + Q-Former + t5_proj)")

@@ -85,6 +85,9 @@ _lora_rows_init = _sig("mrblip_lora_rows_init", vp, ll, vp, ll, i32, i32, i32, v
 _dec_proj = _sig("mrblip_dec_proj", vp, ll, vp, f32, vp, ll, vp, ll, vp, ll, i32, vp, ll, vp, ll, i32, i32, i32, i32, vp, ll, vp, ll, vp, ll, vp, u32, f32, u32, f32, u32, f32,
                  vp, vp, vp, i32, i32, i32, ll, ll, vp)
 _dec_proj_config = _sig("mrblip_dec_proj_config", i32, i32)
+_lora_dx_add_b = _sig("mrblip_lora_dx_add_batched", vp, ll, vp, ll, ll, vp, ll, i32, i32, i32, i32, vp, u32, u32, f32, vp)
+_lora_rows_b = _sig("mrblip_lora_rows_batched", vp, ll, ll, vp, ll, ll, i32, i32, i32, vp, ll, ll, i32, vp, u32, u32, f32, vp)
+_gemm_extra = _sig("mrblip_gemm_set_extra", vp, vp, vp, i32, i32, i32, ll, ll, ll, i32, i32)
 _attn_split_ws = _sig("mrblip_attention_set_split_workspace", vp, ll, i32)
 _rms_lora = _sig("mrblip_rmsnorm_lora_fwd", vp, ll, vp, i32, i32, f32, vp, ll, vp, ll, i32, vp, ll, vp, u32, f32, vp)
 
@@ -95,7 +98,7 @@ EXPORTS = [
     "mrblip_cast_dropout", "mrblip_gelu_bwd", "mrblip_gated_gelu_bwd", "mrblip_cross_entropy", "mrblip_adamw",
     "mrblip_seed_bump", "mrblip_lora_dx_add", "mrblip_dropout_bf16", "mrblip_colsum", "mrblip_lora_pack", "mrblip_lora_tn",
     "mrblip_lora_grads", "mrblip_gemm_lora_down", "mrblip_gemm_lora_dx", "mrblip_patchify_u8",
-    "mrblip_gemm_set_cu_reserve", "mrblip_lora_rows", "mrblip_rmsnorm_lora_fwd", "mrblip_lora_rows_init", "mrblip_dec_proj", "mrblip_dec_proj_config", "mrblip_attention_set_split_workspace",
+    "mrblip_gemm_set_cu_reserve", "mrblip_lora_rows", "mrblip_rmsnorm_lora_fwd", "mrblip_lora_rows_init", "mrblip_dec_proj", "mrblip_dec_proj_config", "mrblip_lora_dx_add_batched", "mrblip_lora_rows_batched", "mrblip_gemm_set_extra", "mrblip_attention_set_split_workspace",
     "mrblip_gemm_f16", "mrblip_layernorm_fwd_f16", "mrblip_attention_fwd_rowv_f16", "mrblip_patchify_f16", "mrblip_patchify_u8_f16",
 ]
 
@@ -151,10 +154,13 @@ def _d(d: Optional[Dropout]):
 # ------------------------------------------------------------------------------------------------ GEMM
 def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, aext=None, wext=None, out2=None, bias=None, residual=None,
          act: int = 0, gated: bool = False, drop: Optional[Dropout] = None, tile_cfg: int = 0, K: Optional[int] = None,
-         cu_reserve: Optional[int] = None, k_splits: int = 0):
+         cu_reserve: Optional[int] = None, k_splits: int = 0, tout=None, t_rows: int = 0, ext_group_n: int = 0):
     """out[M,N] = a[M,K] @ w[N,K]^T (+ aext @ wext^T) with the fused epilogue of mrblip_gemm_bf16.  cu_reserve: CUs a persistent
     tile kernel leaves to other streams (None = the calling thread's ``gemm_cu_reserve`` context, default 0).  k_splits > 1 (M <= 32,
-    fp32 out, no residual): the skinny kernel's blocks split K and ADD into ``out``, which the caller pre-initialised."""
+    fp32 out, no residual): the skinny kernel's blocks split K and ADD into ``out``, which the caller pre-initialised.
+    tout / t_rows (bf16 out, plain or bias epilogue): up to three [B, H, 64, Spad] tensors receiving the head-transposed copies of the
+    output's consecutive column ranges of width H * 64, rows being b * t_rows + s (see ``dec_proj``).  ext_group_n: output-column group
+    g = n // ext_group_n takes columns [64 g, 64 g + 64) of ``aext`` as its K extension (one GEMM for several LoRA groups)."""
     f16 = a.dtype == torch.float16   # IEEE fp16 operands (the fp16-operand ViT): both operands, and a 16-bit output, are fp16
     _req(a, torch.float16 if f16 else torch.bfloat16, "gemm.a"); _req(w, a.dtype, "gemm.w")
     if out.dtype != torch.float32 and out.dtype != a.dtype:
@@ -164,6 +170,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, aext=None, wext
     K = a.shape[1] if K is None else K
     sp, site, p = _d(drop)
     reserve = getattr(_tls, "cu_reserve", 0) if cu_reserve is None else cu_reserve
+    _set_gemm_extra(tout, t_rows, ext_group_n)
     _chk((_gemm_f16 if f16 else _gemm)(_p(a), _ld(a), _p(w), _ld(w), _p(aext), _ld(aext), _p(wext), _ld(wext), M, N, K, _p(out), _ld(out),
                1 if out.dtype == torch.float32 else 0, _p(out2), _ld(out2), _p(bias), _p(residual), _ld(residual), act,
                1 if gated else 0, sp, site, p, (tile_cfg & 0xff) | ((int(reserve) & 0x1ff) << 8) | ((int(k_splits) & 0xf) << 17), _stream()))
@@ -171,6 +178,29 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, aext=None, wext
 
 
 _tls = threading.local()
+
+
+def _set_gemm_extra(tout, t_rows: int, ext_group_n: int = 0):
+    """one-shot extras of this thread's next GEMM launch (mrblip_gemm_set_extra): head-transposed copies and / or the grouped K extension"""
+    if (tout is None or (not isinstance(tout, torch.Tensor) and all(x is None for x in tout))) and not ext_group_n:
+        return
+    t = [None, None, None]
+    t_inner = t_spad = 0
+    t_bs = t_hs = 0
+    t_stride = t_count = 0
+    if isinstance(tout, torch.Tensor):                     # ONE buffer [ranges, B, H, 64, Spad]: range j -> tout[j]
+        assert tout.dim() == 5 and tout.shape[3] == 64 and tout.is_contiguous()
+        t[0] = tout
+        t_count, t_stride = tout.shape[0], tout.stride(0)
+        t_inner, t_spad, t_bs, t_hs = tout.shape[2] * 64, tout.shape[4], tout.stride(1), tout.stride(2)
+    elif tout is not None and any(x is not None for x in tout):
+        ref = next(x for x in tout if x is not None)      # [B, H, 64, Spad]
+        assert ref.shape[2] == 64 and all(x is None or (x.shape == ref.shape and x.is_contiguous()) for x in tout)
+        t[:len(tout)] = list(tout)
+        t_inner, t_spad, t_bs, t_hs = ref.shape[1] * 64, ref.shape[3], ref.stride(0), ref.stride(1)
+    rc = _gemm_extra(_p(t[0]), _p(t[1]), _p(t[2]), t_inner, int(t_rows), t_spad, t_bs, t_hs, t_stride, t_count, int(ext_group_n))
+    if rc != 0:
+        raise MrblipError(_lib.mrblip_last_error().decode())
 
 
 class gemm_cu_reserve:
@@ -342,6 +372,23 @@ def attention_split_workspace(ws: Optional[torch.Tensor], n_split: int = 0):
         raise MrblipError(_lib.mrblip_last_error().decode())
 
 
+def lora_rows_batched(x, a, u, K, groups: int, *, x_gstride: int = 0, a_gstride: int, u_gstride: int, R: int, drop: Optional[Dropout] = None, site_stride: int = 0):
+    """``lora_rows`` for ``groups`` problems in one launch: group g reads x[:, g * x_gstride:] (0: the same rows), the R rows of ``a`` at
+    element offset g * a_gstride, writes u[:, g * u_gstride:] and masks with call-site id drop.site + g * site_stride."""
+    _req(x, torch.bfloat16, "lora_rows_batched.x")
+    sp, site, p = _d(drop)
+    _chk(_lora_rows_b(_p(x), _ld(x), int(x_gstride), _p(a), K if a.dim() == 1 else _ld(a), int(a_gstride), x.shape[0], int(R), int(K), _p(u), _ld(u), int(u_gstride),
+                      int(groups), sp, site, int(site_stride), p, _stream()))
+
+
+def lora_dx_add_batched(dx, g, a, K, groups: int, *, g_gstride: int, a_gstride: int, R: int, drop: Optional[Dropout] = None, site_stride: int = 0):
+    """dx (fp32 [M, >= K]) += sum over groups of mask_g (.) (g[:, j * g_gstride : + R] @ a_j[R, K]); a_j at element offset j * a_gstride of ``a``"""
+    _req(dx, torch.float32, "lora_dx_add_batched.dx")
+    sp, site, p = _d(drop)
+    _chk(_lora_dx_add_b(_p(dx), _ld(dx), _p(g), _ld(g), int(g_gstride), _p(a), int(a_gstride), int(R), dx.shape[0], int(K), int(groups), sp, site,
+                        int(site_stride), p, _stream()))
+
+
 def dec_proj_config(n_blocks: int = -1, version: int = -1) -> int:
     """Launch shape of ``dec_proj`` for <= 16 rows (mrblip_dec_proj_config): n_blocks > 0 = blocks of the streaming kernel (each owns a contiguous
     range of 16-column tiles; 0 = one per CU; < 0 = unchanged), version 0 = the one-tile-per-block kernel of round 3, 1 = streaming.  Returns the
@@ -364,11 +411,13 @@ class dec_proj_grid:
         return False
 
 
-def lora_dx(dy, wt, g, acatt, dx, K, residual=None, drop: Optional[Dropout] = None, tile_cfg=0, k_splits: int = 0):
-    """dx = dy[:, :K] @ wt^T (+ residual) + mask(drop) * (g @ acatt^T);  wt: bf16 [N_in, >=K], acatt: bf16 [N_in, 64]"""
+def lora_dx(dy, wt, g, acatt, dx, K, residual=None, drop: Optional[Dropout] = None, tile_cfg=0, k_splits: int = 0, tout=None, t_rows: int = 0):
+    """dx = dy[:, :K] @ wt^T (+ residual) + mask(drop) * (g @ acatt^T);  wt: bf16 [N_in, >=K], acatt: bf16 [N_in, 64].
+    tout / t_rows (bf16 dx, no residual): head-transposed copies of dx, as in ``gemm``."""
     M = dy.shape[0]
     N = wt.shape[0]
     sp, site, p = _d(drop)
+    _set_gemm_extra(tout, t_rows)
     _chk(_gemm_lora_dx(_p(dy), _ld(dy), _p(wt), _ld(wt), _p(g), _ld(g), _p(acatt), _ld(acatt), M, N, K, _p(dx), _ld(dx),
                   1 if dx.dtype == torch.float32 else 0, _p(residual), _ld(residual) if residual is not None else 0, sp, site, p,
                   (tile_cfg & 0xff) | ((int(k_splits) & 0xf) << 17), _stream()))

@@ -1,0 +1,51 @@
+"""data parallelism and the ragged frame shard TOGETHER on more than two ranks — four ranks share the test box's GPU
+over gloo (tests/dp_shard_worker.py): 2 clips x 2 frame shards (3 frames = 2 + 1).  The exchanged gradient must equal the mean of the two
+clips' unsharded single-process gradients; the losses of a pair must be equal and equal the clip's own loss."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+from util import check, free_port, load_golden, golden_state_dict, relerr  # noqa: E402
+
+
+def test_two_clips_times_two_frame_shards_on_four_ranks(tmp_path):
+    from mrblip import prompt as P
+    from mrblip.engine import EngineConfig, MrBlipEngine, StateDictSource
+    from mrblip.tokenizer import FixtureTokenizer
+    from test_model_gpu import _peft_sd, _samples
+    from dp_worker import equal_layout_clips
+
+    out = str(tmp_path / "dp_shard.pt")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1", "--master-port",
+           str(free_port()), os.path.join(ROOT, "tests", "dp_shard_worker.py"), out]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-3000:])
+    sh = torch.load(out)
+    assert sh["counts"] == [2, 1]
+    g = load_golden("mr_tiny")
+    tok = FixtureTokenizer()
+    repl = P.annoying_replacement_dict(P.find_annoying_numbers(tok, 200)[0])
+    s = equal_layout_clips(_samples(g))
+    eng = MrBlipEngine(EngineConfig.tiny(), StateDictSource(_peft_sd(golden_state_dict(g))), torch.device("cuda:0"), seed=42)
+    eng.training = False
+    ref = torch.zeros_like(eng.grad, device="cpu")
+    losses = []
+    for c in range(2):
+        mine = {k: v[c:c + 1] for k, v in s.items()}
+        lay = P.build_layout(tok, mine, repl, 8, T=3)
+        eng.zero_grad()
+        losses.append(eng.forward_backward(mine["video"].cuda(), lay, backward=True).item())
+        ref += eng.grad.cpu() / 2
+    nl = sh["n_lora"]
+    tag = "DP x frame shard (2 clips x 2 shards, 4 ranks): "
+    assert sh["losses"][0] == sh["losses"][1] and sh["losses"][2] == sh["losses"][3]         # a pair runs one replicated T5
+    check(tag + "pair losses vs the clips' own losses", max(abs(sh["losses"][2 * c] - losses[c]) / abs(losses[c]) for c in range(2)), 2e-6)
+    check(tag + "LoRA gradients vs mean of the unsharded clips", relerr(sh["grad"][:nl], ref[:nl]), 2e-5)
+    check(tag + "t5_proj / ln_vision gradients vs mean of the unsharded clips", relerr(sh["grad"][nl:], ref[nl:]), 2e-5)
+    assert ref[nl:].abs().sum() > 0 and ref[:nl].abs().sum() > 0

@@ -291,6 +291,11 @@ def test_c3_batch4_step_equals_four_accumulated_single_clip_steps(xl):
     os.environ["MRB_ATTN_KS2"] = "0"
     dec_proj = eng.dec_proj_enabled
     eng.dec_proj_enabled = False   # (the fused decoder projection serves <= 16 rows: one clip's labels, not four clips')
+    # round 4: two more shape-dependent choices — the stacked cross K / V projection of all decoder layers (one clip: its backward adds the
+    # layers' contributions to the encoder-output gradient chunk-wise; four ragged clips keep the per-layer launches) and the cross-block key
+    # split of the decoder's cross attention (other merge order of the softmax partials)
+    ckv_b, xs_ws = eng.cross_kv_batched, eng.xs_ws
+    eng.cross_kv_batched, eng.xs_ws = False, None
     samples, lay4 = _layout(xl, 4, 60, 150.0)
     # four different clips (same prompt, hence the same layout / label length per clip)
     video = samples["video"]
@@ -326,6 +331,12 @@ def test_c3_batch4_step_equals_four_accumulated_single_clip_steps(xl):
     l4t = eng.forward_backward(video, lay4, backward=True).item()
     check("c3.loss B=4, product thin-LoRA kernel choice vs pinned (rel)", abs(l4t - l4f) / abs(l4f), 1e-4)          # measured 9.4e-6
     check("c3.flat-grad B=4, product thin-LoRA kernel choice vs pinned", relerr(eng.grad, g4f), 1.3e-2)              # measured 6.1e-3
+    # ... and the round-4 choices for ONE clip (stacked cross K / V, key-split cross attention): the accumulated single-clip steps again
+    eng.cross_kv_batched, eng.xs_ws = ckv_b, xs_ws
+    eng.zero_grad()
+    ls4 = [eng.forward_backward(video[i:i + 1].contiguous(), lay1, backward=True).item() for i in range(4)]
+    check("c3.loss 4 x B=1, stacked cross K/V + key-split cross attention vs pinned per-layer forms (rel)", abs(sum(ls4) / 4 - l4t) / abs(l4t), 2e-4)
+    check("c3.flat-grad 4 x B=1, stacked cross K/V + key-split cross attention vs pinned per-layer forms", relerr(eng.grad / 4, g4f), 2e-2)
     eng.lora_rows_max_m = rows_max
     eng.dec_proj_enabled = dec_proj
     del os.environ["MRB_ATTN_KS2"]

@@ -359,7 +359,7 @@ def test_attention_cross_block_key_split(ops, n_split, B, H, Sq, Sk, masked, p):
     names = ("o", "lse", "dq", "dk", "dv", "delta")
     for n, x, y in zip(names, got, base):
         e = rel(x.float()[..., :Sq] if n in ("lse", "delta") else x.float(), y.float()[..., :Sq] if n in ("lse", "delta") else y.float())
-        assert e < (3e-3 if n in ("o", "dq", "dk", "dv") else 1e-5), (n, e)   # bf16 outputs: rounding flips under another fp32 summation order (dK / dV see it through LSE / Delta)
+        assert e < (3e-3 if n in ("o", "dq", "dk", "dv") else 5e-3 if n == "delta" else 1e-5), (n, e)   # bf16 outputs: rounding flips under another fp32 summation order (dK / dV see it through LSE / Delta = rowsum(dO * bf16 O))
     qr, kr, vr = (t.float().permute(0, 2, 1, 3).clone().requires_grad_(True) for t in (q, k, v))
     mask = kmask[:, :Sk].bool()[:, None, None, :].expand(B, H, Sq, Sk) if masked else None
     dmask = None
@@ -1044,6 +1044,82 @@ def test_dec_proj_backward_form(ops, R, N, K, Rk, f32out):
         tag = "dec_proj bwd R=%d N=%d K=%d Rk=%d %s: " % (R, N, K, Rk, "mask" if ldrop else "plain")
         check(tag + "g vs lora_rows", rel(g1.float(), g0.float()), 4e-3)
         check(tag + "dx vs lora_rows + lora_dx", rel(dx1.float(), dx0.float()), 4e-3 if not f32out else 2e-3)
+
+
+@pytest.mark.parametrize("B,S,N,K,ext,bias,cfg", [(1, 2012, 6144, 2048, True, False, 0), (1, 333, 2048, 512, False, False, 0), (60, 32, 2304, 768, False, True, 0),
+                                                  (1, 2012, 2048, 2048, True, False, 4), (1, 40, 2048, 256, False, False, 2), (3, 64, 4096, 128, True, False, 0)])
+def test_gemm_writes_head_transposed_copies(ops, B, S, N, K, ext, bias, cfg):
+    """Round 4: the tile GEMM's epilogue also writes the head-transposed copies of its bf16 output (q | k | v ranges of a fused projection)
+    that the attention kernels read — bit-identical to mrblip_head_transpose of the output, pad columns included (the tiles start out
+    holding another layout's values), for one clip of any length and for batches whose clips are multiples of 32 rows (the Q-Former's 32
+    query tokens per frame); the row-major output itself is unchanged."""
+    torch.manual_seed(33)
+    M = B * S
+    a = bf(torch.randn(M, K, device=dev()))
+    w = bf(torch.randn(N, K, device=dev()) * 0.05)
+    aext = bf(torch.randn(M, 64, device=dev())) if ext else None
+    wext = bf(torch.randn(N, 64, device=dev()) * 0.05) if ext else None
+    bvec = torch.randn(N, device=dev()) if bias else None
+    ref = torch.empty(M, N, dtype=torch.bfloat16, device=dev())
+    ops.gemm(a, w, ref, aext=aext, wext=wext, bias=bvec, tile_cfg=cfg)
+    H = 2048 // 64 if N % 2048 == 0 else 768 // 64
+    inner = H * 64
+    nj = min(3, N // inner)
+    spad = ops.rup32(S)
+    guard = torch.full((nj, B + 2, H, 64, spad), 7.5, dtype=torch.bfloat16, device=dev())     # a clip of guard space on either side of every tile
+    touts = [guard[j, 1:B + 1] for j in range(nj)]
+    out = torch.empty_like(ref)
+    ops.gemm(a, w, out, aext=aext, wext=wext, bias=bvec, tile_cfg=cfg, tout=touts, t_rows=S)
+    assert torch.equal(out, ref)
+    assert bool((guard[:, 0] == 7.5).all()) and bool((guard[:, B + 1] == 7.5).all())               # nothing written outside the tiles
+    for j in range(nj):
+        want = ops.head_transpose(out[:, j * inner:(j + 1) * inner].unflatten(1, (H, 64)).unflatten(0, (B, S)))
+        assert torch.equal(touts[j], want), j
+    # the LoRA-backward form (masked K extension first): dO^T of the o-projection's input gradient
+    if ext and N == 2048:
+        seed = torch.tensor([5], dtype=torch.int32, device=dev())
+        d0 = torch.empty(M, N, dtype=torch.bfloat16, device=dev())
+        ops.lora_dx(a, w, aext, wext, d0, K, drop=ops.Dropout(seed, 2, 0.05))
+        t = torch.full((B, H, 64, spad), -3.0, dtype=torch.bfloat16, device=dev())
+        d1 = torch.empty_like(d0)
+        ops.lora_dx(a, w, aext, wext, d1, K, drop=ops.Dropout(seed, 2, 0.05), tout=(t,), t_rows=S)
+        assert torch.equal(d1, d0)
+        assert torch.equal(t, ops.head_transpose(d1.unflatten(1, (H, 64)).unflatten(0, (B, S))))
+    with pytest.raises(ops.MrblipError):       # fp32 output: no transposed copies
+        ops.gemm(a, w, torch.empty(M, N, device=dev()), tout=touts, t_rows=S)
+    ops.gemm(a, w, out, aext=aext, wext=wext, bias=bvec, tile_cfg=cfg)     # the extras are one-shot: the failed call consumed them
+    assert torch.equal(out, ref)
+
+
+def test_gemm_grouped_k_extension(ops):
+    """Round 4: one GEMM for several LoRA groups that share the input — output-column group g takes ITS 64-column slot of Aext as the K
+    extension (the cross-attention K / V projections of all decoder layers on one encoder output): bit-identical to one GEMM per group."""
+    torch.manual_seed(35)
+    M, K, G, Ng = 2012, 2048, 5, 4096
+    a = bf(torch.randn(M, K, device=dev()))
+    w = bf(torch.randn(G * Ng, K, device=dev()) * 0.03)
+    u = bf(torch.randn(M, G * 64, device=dev()))
+    wext = bf(torch.randn(G * Ng, 64, device=dev()) * 0.05)
+    out = torch.empty(M, G * Ng, dtype=torch.bfloat16, device=dev())
+    H, spad = 32, ops.rup32(M)
+    ops.gemm(a, w, out, aext=u, wext=wext, ext_group_n=Ng)
+    for g in range(G):
+        ref = torch.empty(M, Ng, dtype=torch.bfloat16, device=dev())
+        ops.gemm(a, w[g * Ng:(g + 1) * Ng], ref, aext=u[:, g * 64:(g + 1) * 64], wext=wext[g * Ng:(g + 1) * Ng])
+        assert torch.equal(out[:, g * Ng:(g + 1) * Ng], ref), g
+    # with the transposed copies of the first three 2048-wide ranges (K, V of group 0, K of group 1)
+    touts = [torch.zeros(1, H, 64, spad, dtype=torch.bfloat16, device=dev()) for _ in range(3)]
+    out2 = torch.empty_like(out)
+    ops.gemm(a, w, out2, aext=u, wext=wext, ext_group_n=Ng, tout=touts, t_rows=M)
+    assert torch.equal(out2, out)
+    for j in range(3):
+        assert torch.equal(touts[j], ops.head_transpose(out[:, j * 2048:(j + 1) * 2048].unflatten(1, (H, 64)).unsqueeze(0)))
+    # ... and of ALL ranges into one buffer [ranges, B, H, 64, Spad]
+    tall = torch.full((2 * G, 1, H, 64, spad), 9.0, dtype=torch.bfloat16, device=dev())
+    ops.gemm(a, w, out2, aext=u, wext=wext, ext_group_n=Ng, tout=tall, t_rows=M)
+    assert torch.equal(out2, out)
+    for j in range(2 * G):
+        assert torch.equal(tall[j], ops.head_transpose(out[:, j * 2048:(j + 1) * 2048].unflatten(1, (H, 64)).unsqueeze(0))), j
 
 
 @pytest.mark.parametrize("grid", [1, 5, 64, 0])

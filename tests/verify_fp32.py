@@ -80,6 +80,11 @@ class Fp32Verify(contextlib.AbstractContextManager):
         eng.vit_dtype = bf16           # (this mode carries EVERY operand as split-bf16 hi + lo: the ViT's fp16 product mode is switched off inside)
         eng.fuse_norm_lora = False
         eng.dec_proj_enabled = False   # (the fused decoder projection is a bf16-operand kernel: the fp32-operand stand-ins below replace the two-launch ops)
+        # round 4: the transposed copies from the GEMM epilogue and the stacked cross K / V projection are bf16-operand forms too — this
+        # mode keeps the head_transpose stand-in and the per-layer projections (instance attributes; the engine is used for this mode only)
+        S["tout"], S["ckv"] = eng.gemm_tout_enabled, eng.cross_kv_batched
+        eng.gemm_tout_enabled = False
+        eng.cross_kv_batched = False
 
         def buf(name, shape, dtype, zero=True):
             shape = tuple(int(s) for s in shape)
@@ -117,6 +122,7 @@ class Fp32Verify(contextlib.AbstractContextManager):
         eng.ws, eng._store = S["ws"], S["store"]
         eng.fuse_norm_lora, eng.lora_rows_max_m = S["fuse"], S["rows_max"]
         eng.dec_proj_enabled = S["dec_proj"]
+        eng.gemm_tout_enabled, eng.cross_kv_batched = S["tout"], S["ckv"]
         eng.vit_dtype = S["vit_dtype"]
         for obj, key, val in self._weight_restore:
             obj[key] = val
