@@ -1482,9 +1482,11 @@ extern "C" int mrblip_attention_set_split_workspace(void* ws, long long bytes, i
 // blocks per (batch, head) of the cross-block key split, 0 = not applicable: only the few-query form with a long key range and so few
 // (batch, head) pairs that the chip is mostly idle (the T5 decoder's cross attention: 32 heads x 2012 keys; NOT the Q-Former's 720 pairs)
 static int attn_xs_split(const AttnArgs& a, bool split) {
-  if (!split || !g_xs_ws || a.D != 64 || a.B * a.H > 128 || a.Sk < 1024 || a.B * a.H > ATTN_XS_TICKETS) return 0;
+  if (!split || !g_xs_ws || a.D != 64 || a.B * a.H > 256 || a.Sk < 1024) return 0;
   const int tiles = (a.Sk + 31) / 32;
-  int n = g_xs_n > 0 ? g_xs_n : 256 / (a.B * a.H);      // about one block per CU
+  // chunks of ~8 key tiles (two per wave), whatever the batch: a clip's result must not depend on how many clips share the launch
+  // (B = 4 per GPU == four accumulated single-clip steps, tests/test_fullsize_gpu.py)
+  int n = g_xs_n > 0 ? g_xs_n : (tiles + 7) / 8;
   if (n > tiles / 4) n = tiles / 4;                       // at least 4 key tiles (one per wave) per block
   if (n > 64) n = 64;
   const long long need = ATTN_XS_TICKETS * 4 + (long long)a.B * a.H * n * (9 * 64 * 16);

@@ -206,7 +206,8 @@ class MrBlipEngine:
         self.enc_t_saved: Dict[int, bool] = {}    # encoder layer -> Q^T / K^T were written by the forward's qkv GEMM
         self.dec_t_saved: Dict[int, bool] = {}    # decoder layer -> Q^T / K^T of its self-attention were written by the forward's fused projection
         # round 4: workspace of the cross-block key split of the decoder's cross attention (csrc/attention.hip F_XS): tickets (zero) + partials
-        self.xs_ws = torch.zeros(2 * 1024 * 1024, dtype=torch.int32, device=self.dev) if os.environ.get("MRB_ATTN_XS", "1") == "1" else None
+        # (40 MB: up to 4 clips x 32 heads x 8 chunks of partials)
+        self.xs_ws = torch.zeros(10 * 1024 * 1024, dtype=torch.int32, device=self.dev) if os.environ.get("MRB_ATTN_XS", "1") == "1" else None
         self.xs_split = int(os.environ.get("MRB_ATTN_XS_N", "0"))
         self.dec_tc_saved: Dict[int, bool] = {}   # ... and the cross-attention's Q^T
         self._store: Dict[str, torch.Tensor] = {}
