@@ -1579,6 +1579,9 @@ static int gemm_dispatch(const void* A, long long lda, const void* W, long long 
                          void* out2, long long ldo2, const float* bias, const float* residual, long long ldr, int act,
                          int gated, const uint32_t* seed_ptr, uint32_t site, float p_drop, int tile_cfg, int ext_first,
                          uint32_t ext_site, float ext_p, uint32_t a_site, float a_p, hipStream_t stream, bool f16 = false) {
+  // the one-shot extras belong to THIS call whatever happens to it (a call that fails below must not leave them to the next GEMM)
+  const GemmExtra extra = g_gemm_extra;
+  g_gemm_extra = GemmExtra{};
   MRB_REQUIRE(M > 0 && N > 0 && K >= 0 && (K % 64) == 0, "gemm: need M,N>0 and K%%64==0 (M=%d N=%d K=%d)", M, N, K);
   MRB_REQUIRE(K > 0 || Aext, "gemm: empty contraction");
   MRB_REQUIRE((N % 8) == 0, "gemm: N %% 8 != 0 (N=%d)", N);
@@ -1592,8 +1595,6 @@ static int gemm_dispatch(const void* A, long long lda, const void* W, long long 
   a.ext_first = ext_first;
   a.m_rows_per_block = 32;
   a.k_splits = 1;
-  const GemmExtra extra = g_gemm_extra;
-  g_gemm_extra = GemmExtra{};
   a.tout[0] = (bf16_t*)extra.tout[0]; a.tout[1] = (bf16_t*)extra.tout[1]; a.tout[2] = (bf16_t*)extra.tout[2];
   a.t_inner = extra.set ? extra.t_inner : 0; a.t_rows = extra.t_rows; a.t_spad = extra.t_spad; a.t_bs = extra.t_bs; a.t_hs = extra.t_hs;
   a.t_stride = extra.t_stride; a.t_count = extra.set ? extra.t_count : 0;

@@ -1089,6 +1089,11 @@ def test_gemm_writes_head_transposed_copies(ops, B, S, N, K, ext, bias, cfg):
         ops.gemm(a, w, torch.empty(M, N, device=dev()), tout=touts, t_rows=S)
     ops.gemm(a, w, out, aext=aext, wext=wext, bias=bvec, tile_cfg=cfg)     # the extras are one-shot: the failed call consumed them
     assert torch.equal(out, ref)
+    with pytest.raises(ops.MrblipError):       # ... also when the call is rejected before a kernel form is chosen (K not a multiple of 64)
+        ops.gemm(a, w, out, K=K - 8, tout=touts, t_rows=S)
+    before = guard.clone()
+    ops.gemm(a, w, out, aext=aext, wext=wext, bias=bvec, tile_cfg=cfg)
+    assert torch.equal(out, ref) and torch.equal(guard, before)
 
 
 def test_gemm_grouped_k_extension(ops):
