@@ -684,12 +684,18 @@ __device__ constexpr int w4_piece_slot(int i, int total, int nslot) {
   return j * nslot / n + off;
 }
 // F16 (round 4): the operands (and a 16-bit output) are IEEE fp16 instead of bf16 — v_mfma_f32_32x32x16_f16, same rate, same image.
-template <bool OUT_F32, int ACT, bool RES, int TN, bool F16 = false>
+// W3 (round 4, experiment -> cfg 17): a THIRD stage buffer for the W operand (A0 W0 A1 W1 W2 = 160 KB, all of the CU's LDS).  With two
+// stages a stage's pieces can only be issued once the hand-over has freed its buffer — A one K-tile, W three k-slices (~1.1 us) before the
+// barrier that needs them; a piece that misses the L2 lands later than that and all four waves (one per SIMD: nothing else to run) wait.
+// With W2 the W pieces of K-tile kt + 2 go out in the first slice of K-tile kt (seven slices ahead); the hand-over waits with
+// vmcnt(JW): only those youngest pieces may still be in flight (LDS-DMA loads retire in order).
+template <bool OUT_F32, int ACT, bool RES, int TN, bool F16 = false, bool W3 = false>
 __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
   constexpr int BM = 256, BN = 64 * TN, WN = BN / 2, RB = 128, NW = 4, RPI = 8;
   constexpr int A_BYTES = BM * RB, W_BYTES = BN * RB, STAGE = A_BYTES + W_BYTES;
   constexpr int JA = BM / RPI / NW, JW = BN / RPI / NW;  // LDS-DMA pieces per wave: 8 of A, 8 / 6 of W
   constexpr int NSLOT = 4 * TN, NFRAG = 4 + TN;          // MFMAs and fragment reads per k-slice
+  static_assert(!W3 || (w4_piece_count(0, JA + JW) == JA && w4_piece_count(1, JA + JW) == JW), "W3: A pieces in the hand-over slice, W pieces in the slice behind it");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -711,6 +717,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
 #define W4_SYNC
 #else
 #define W4_SYNC asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier();
+#define W4_SYNC_KEEP(N) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory"); __builtin_amdgcn_s_barrier();
 #endif
 #ifdef EXP_W4_NODMA
 #define W4_DO_DMA false
@@ -718,47 +725,56 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
 #define W4_DO_DMA true
 #endif
   // fragment I of a k-slice, in the order the MFMAs below first need them: A0, W0 .. W(TN-1), A1, A2, A3
-#define W4_FRAG(FA, FB, BASE, KK, I)                                                                                     \
+#define W4_FRAG(FA, FB, BASE, BASEW, KK, I)                                                                              \
   {                                                                                                                      \
     const int coff_ = ((((KK) * 2 + hi) ^ swz) << 4);                                                                    \
     if ((I) == 0) FA[0] = *reinterpret_cast<const bf16x8*>((BASE) + a_off + coff_);                                      \
-    else if ((I) <= TN) FB[(I) - 1] = *reinterpret_cast<const bf16x8*>((BASE) + w_off + ((I) - 1) * 32 * RB + coff_);    \
+    else if ((I) <= TN) FB[(I) - 1] = *reinterpret_cast<const bf16x8*>((BASEW) + w_off + ((I) - 1) * 32 * RB + coff_);   \
     else FA[(I) - TN] = *reinterpret_cast<const bf16x8*>((BASE) + a_off + ((I) - TN) * 32 * RB + coff_);                 \
   }
+  // W3: byte offset of W stage buffer i (0, 1, 2) = behind A0, behind A1, behind everything
+#define W4_WOFS(I3) ((I3) == 0 ? A_BYTES : (I3) == 1 ? STAGE + A_BYTES : 2 * STAGE)
   // one k-slice: MFMA j = (mt, nt) = (j / TN, j % TN) on (FA, FB); the NFRAG fragment reads of the NEXT slice (into GA, GB) are spread
   // evenly over its slots.  The LDS-DMA of a stage is spread over two slices (all four waves pass the hand-over together: all pieces
   // at once would queue up in front of the address unit and stall the MFMA issue behind them): DMA_A = the A pieces of K-tile kt + 2
   // (hand-over slice, into the buffer the barrier just freed), DMA_W = the W pieces of K-tile kt + 1 (first slice of the following
   // K-tile).  sched_barrier pins the order.
-#define W4_SLICE(FA, FB, GA, GB, NBASE, NKK, NEXT, PHIDX, PACTIVE)                                                        \
+#define W4_SLICE(FA, FB, GA, GB, NBASE, NBASEW, NKK, NEXT, PHIDX, PACTIVE)                                                \
   _Pragma("unroll") for (int j_ = 0; j_ < NSLOT; ++j_) {                                                                 \
     if ((PACTIVE) && W4_DO_DMA) {                                                                                        \
       _Pragma("unroll") for (int i_ = 0; i_ < JA + JW; ++i_)                                                             \
         if (w4_piece_phidx(i_, JA + JW) == (PHIDX) && j_ == w4_piece_slot(i_, JA + JW, NSLOT)) {                         \
-          const int st_ = (PHIDX) == 0 ? kt + 2 : kt + 1;                                                                \
+          const int st_ = ((PHIDX) == 0 || W3) ? kt + 2 : kt + 1;                                                        \
           if (i_ < JA)                                                                                                   \
             gemm_dma_piece(smem + (st_ & 1) * STAGE + (i_ * NW + w) * (RPI * RB), p.A, bytes_a, vpa[i_ < JA ? i_ : 0], (uint32_t)st_ * (uint32_t)RB); \
           else                                                                                                           \
-            gemm_dma_piece(smem + (st_ & 1) * STAGE + A_BYTES + ((i_ - JA) * NW + w) * (RPI * RB), p.W, bytes_w,         \
+            gemm_dma_piece(smem + (W3 ? w3ofs2 : (st_ & 1) * STAGE + A_BYTES) + ((i_ - JA) * NW + w) * (RPI * RB), p.W, bytes_w, \
                            vpw[i_ >= JA ? i_ - JA : 0], (uint32_t)st_ * (uint32_t)RB);                                   \
         }                                                                                                                \
     }                                                                                                                    \
     if (NEXT) {                                                                                                          \
       _Pragma("unroll") for (int f_ = 0; f_ < NFRAG; ++f_)                                                               \
-        if (j_ == f_ * NSLOT / NFRAG) W4_FRAG(GA, GB, NBASE, NKK, f_)                                                    \
+        if (j_ == f_ * NSLOT / NFRAG) W4_FRAG(GA, GB, NBASE, NBASEW, NKK, f_)                                            \
     }                                                                                                                    \
     acc[j_ / TN][j_ % TN] = mfma32x16<F16>(FB[j_ % TN], FA[j_ / TN], acc[j_ / TN][j_ % TN]);                             \
     __builtin_amdgcn_sched_barrier(0);                                                                                   \
   }
+  // (w3 = kt % 3 under W3: the W stage of this K-tile; its fragment base is taken so that + w_off lands in the buffer)
 #define W4_KTILE(DMA, NEXT)                                                                                              \
   {                                                                                                                      \
     const char* base = smem + (kt & 1) * STAGE;                                                                          \
     const char* nbase = smem + ((kt + 1) & 1) * STAGE;                                                                   \
-    W4_SLICE(fa0, fb0, fa1, fb1, base, 1, true, 1, NEXT)                                                                 \
-    W4_SLICE(fa1, fb1, fa0, fb0, base, 2, true, 2, NEXT)                                                                 \
-    W4_SLICE(fa0, fb0, fa1, fb1, base, 3, true, 3, NEXT)                                                                 \
-    W4_SYNC                                                                                                              \
-    W4_SLICE(fa1, fb1, fa0, fb0, nbase, 0, NEXT, 0, DMA)                                                                 \
+    const int w3n = w3 == 2 ? 0 : w3 + 1, w3nn = w3n == 2 ? 0 : w3n + 1;                                                 \
+    const char* basew = W3 ? smem + W4_WOFS(w3) - A_BYTES : base;                                                        \
+    const char* nbasew = W3 ? smem + W4_WOFS(w3n) - A_BYTES : nbase;                                                     \
+    const int w3ofs2 = W4_WOFS(w3nn);                                                                                    \
+    (void)w3ofs2;                                                                                                        \
+    W4_SLICE(fa0, fb0, fa1, fb1, base, basew, 1, true, 1, (W3 ? (DMA) : (NEXT)))                                         \
+    W4_SLICE(fa1, fb1, fa0, fb0, base, basew, 2, true, 2, NEXT)                                                          \
+    W4_SLICE(fa0, fb0, fa1, fb1, base, basew, 3, true, 3, NEXT)                                                          \
+    if (W3 && (DMA)) { W4_SYNC_KEEP(JW) } else { W4_SYNC }                                                               \
+    W4_SLICE(fa1, fb1, fa0, fb0, nbase, nbasew, 0, NEXT, 0, DMA)                                                         \
+    w3 = w3n;                                                                                                            \
   }
 
   // Persistent walk: block b works on the tiles b, b + grid, ... ; tile ids congruent mod 8 stay on one XCD (blocks are dealt to the
@@ -807,11 +823,13 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    if (nk > 1) {  // the pieces of K-tile 1 a hand-over slice would have issued (the rest go out in the slices of K-tile 0)
-      constexpr int N3 = w4_piece_count(0, JA + JW);
+    int w3 = 0;    // (W3) kt % 3
+    (void)w3;
+    if (nk > 1) {  // the pieces of K-tile 1 a hand-over slice would have issued (the rest go out in the slices of K-tile 0; W3: all of K-tile 1)
+      constexpr int N3 = W3 ? JA + JW : w4_piece_count(0, JA + JW);
 #pragma unroll
       for (int i = 0; i < JA + JW; ++i)
-        if (w4_piece_phidx(i, JA + JW) == 0) {
+        if (W3 || w4_piece_phidx(i, JA + JW) == 0) {
           if (i < JA) gemm_dma_piece(smem + STAGE + (i * NW + w) * (RPI * RB), p.A, bytes_a, vpa[i < JA ? i : 0], (uint32_t)RB);
           else gemm_dma_piece(smem + STAGE + A_BYTES + ((i - JA) * NW + w) * (RPI * RB), p.W, bytes_w, vpw[i >= JA ? i - JA : 0], (uint32_t)RB);
         }
@@ -822,7 +840,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
     __builtin_amdgcn_s_barrier();
     bf16x8 fa0[4], fb0[TN], fa1[4], fb1[TN];
 #pragma unroll
-    for (int i = 0; i < NFRAG; ++i) W4_FRAG(fa0, fb0, smem, 0, i)
+    for (int i = 0; i < NFRAG; ++i) W4_FRAG(fa0, fb0, smem, smem, 0, i)
     W4_STAMP(1)
     int kt = 0;
     for (; kt < nk - 2; ++kt) W4_KTILE(true, true)
@@ -834,6 +852,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
 #undef W4_KTILE
 #undef W4_SLICE
 #undef W4_FRAG
+#undef W4_WOFS
 
     // ---- epilogue: 32-row x WN-column fp32 slabs per wave through LDS (the transposition of gemm_tile_kernel), then LPR lanes cover
     // one row and every lane owns the SAME 8 columns in all passes: its bias values are loaded once per tile.
@@ -1803,6 +1822,18 @@ static int gemm_dispatch(const void* A, long long lda, const void* W, long long 
 #undef MRB_W16_LAUNCH
     return mrblip_check_launch("gemm_w16");
   }
+  // cfg 17 (round 4): cfg 13 with a third stage buffer for the W operand (gemm_w4_kernel W3).  Measured (profiles/r04_w3_bench.txt):
+  // bit-identical; with the chip to itself equal within noise (8192^3 1426 vs 1426 TFLOP/s, fc1 252.5 vs 250.5 us, fc2 298 vs 303 us);
+  // on the 192 CUs the look-ahead runs on: 8192^3 1217 vs 1140 TFLOP/s, fc2 280 vs 285 us, fc1 in the step 340 vs 348 us; step 70.48 vs
+  // 70.45 ms.  So the late W pieces were NOT what the K loop waits for; the form is kept as the library's choice for an automatic cfg 13
+  // because it is never slower where it runs (MRB_W4_W3=0: two stages; an explicit tile_cfg 13 always means two stages)
+  bool w3 = cfg == 17;
+  if (cfg == 13 && !f16 && (tile_cfg & 0xff) == 0) {
+    static int w3env = -1;
+    if (w3env < 0) { const char* e = getenv("MRB_W4_W3"); w3env = (e && e[0] == '0') ? 0 : 1; }
+    w3 = w3env == 1;
+  }
+  if (cfg == 17) cfg = 13;
   if (cfg == 13 || cfg == 14) {  // four waves of 128 x 128 (cfg 13, 256x256 tile) / 128 x 96 (cfg 14, 256x192), hand-pipelined K loop
     MRB_REQUIRE(!gated && !Aext && !out2 && !(p_drop > 0.f), "gemm: cfg 13 / 14 take plain epilogues only");
     MRB_REQUIRE(act == 0 || act == 1, "gemm: cfg 13 / 14 know act 0 / 1");
@@ -1812,7 +1843,8 @@ static int gemm_dispatch(const void* A, long long lda, const void* W, long long 
     a.tiles_m = (M + 255) / 256;
     a.tiles_n = (N + bn13 - 1) / bn13;
     const int stage13 = (256 + bn13) * 128, slab13 = 4 * 32 * (bn13 / 2 * 4 + 16);
-    const int LDS = 2 * stage13 > stage13 + slab13 ? 2 * stage13 : stage13 + slab13;
+    MRB_REQUIRE(!w3 || (cfg == 13 && !f16), "gemm: the three-W-stage form (cfg 17) exists for the bf16 256x256 tile");
+    const int LDS = w3 ? 2 * stage13 + 256 * 128 : (2 * stage13 > stage13 + slab13 ? 2 * stage13 : stage13 + slab13);
     static int ncu13 = 0;
     if (ncu13 == 0) {
       int dev = 0;
@@ -1829,8 +1861,8 @@ static int gemm_dispatch(const void* A, long long lda, const void* W, long long 
     // that keep the round count — ceil(tiles / rounds): ViT fc1 1464 tiles = 8 rounds on 184 CUs as on 192 — so that the other stream
     // gets the difference: +0.3 ms per step; the CUs of a partly filled last round are not idle, they go to the other stream EARLIER.)
     const int grid = nt13 < cus ? (nt13 + 7) / 8 * 8 : cus;
-    const int variant = (f16 ? 16 : 0) | (cfg == 14 ? 8 : 0) | (out_f32 ? 4 : 0) | (act == 1 ? 2 : 0) | (residual ? 1 : 0);
-    static bool attr_set13[24] = {};
+    const int variant = (w3 ? 24 : 0) + ((f16 ? 16 : 0) | (cfg == 14 ? 8 : 0) | (out_f32 ? 4 : 0) | (act == 1 ? 2 : 0) | (residual ? 1 : 0));
+    static bool attr_set13[32] = {};
 #define MRB_W4_LAUNCH(V, F32, ACT_, RES_, TN_, ...)                                                                                \
   case V: {                                                                                                                        \
     auto k = gemm_w4_kernel<F32, ACT_, RES_, TN_, ##__VA_ARGS__>;                                                                                 \
@@ -1866,6 +1898,11 @@ static int gemm_dispatch(const void* A, long long lda, const void* W, long long 
       MRB_W4_LAUNCH(18, false, 1, false, 4, true)
       MRB_W4_LAUNCH(20, true, 0, false, 4, true)
       MRB_W4_LAUNCH(21, true, 0, true, 4, true)
+      // three W stages (cfg 17): the frozen ViT's four bf16 forms
+      MRB_W4_LAUNCH(24, false, 0, false, 4, false, true)
+      MRB_W4_LAUNCH(26, false, 1, false, 4, false, true)
+      MRB_W4_LAUNCH(28, true, 0, false, 4, false, true)
+      MRB_W4_LAUNCH(29, true, 0, true, 4, false, true)
       default:
         mrblip_set_error("gemm: no such 4-wave kernel variant (%d)%s", variant, f16 ? " - the fp16 form exists for bias / bias+GELU (16-bit out) and fp32 out with or without residual" : "");
         return MRBLIP_EINVAL;

@@ -100,6 +100,27 @@ def test_gemm_four_wave_tile_epilogues(ops):
             ops.gemm(a, w, out, gated=True, tile_cfg=cfg)
 
 
+@pytest.mark.parametrize("M,N,K", [(700, 520, 320), (1000, 768, 64), (515, 304, 128), (2100, 1408, 1408), (300, 264, 192)])
+def test_gemm_four_wave_tile_with_three_w_stages_is_bit_identical(ops, M, N, K):
+    """cfg 17 (round 4): the 4-wave 256x256 kernel with a THIRD stage buffer for the W operand (its pieces go out a K-tile earlier, the
+    hand-over waits with vmcnt(8)) — the same MFMA order as cfg 13, so the same bits, for every epilogue of the frozen ViT, with ragged
+    edges and 1 / 2 / 3 / 5 / 22 K-tiles (every prologue / tail form of the pipelined loop), and for a persistent block walking several tiles."""
+    torch.manual_seed(21)
+    a = bf(torch.randn(M, K, device=dev()))
+    w = bf(torch.randn(N, K, device=dev()) * 0.1)
+    bias = torch.randn(N, device=dev())
+    res = torch.randn(M, N, device=dev())
+    for kw in (dict(bias=bias), dict(bias=bias, act=1), dict(bias=bias, f32=True), dict(bias=bias, f32=True, res=True)):
+        outs = []
+        for cfg in (13, 17):
+            out = res.clone() if kw.get("res") else torch.full((M, N), 3.0, dtype=torch.float32 if kw.get("f32") else torch.bfloat16, device=dev())
+            with ops.gemm_cu_reserve(248 if M > 2000 else 0):       # 8 blocks: every block walks several tiles
+                ops.gemm(a, w, out, bias=kw.get("bias"), act=kw.get("act", 0), residual=out if kw.get("res") else None, tile_cfg=cfg)
+            outs.append(out)
+        assert torch.equal(outs[0], outs[1]), kw
+    assert rel(outs[1], res + a.float() @ w.float().t() + bias) < 2e-6
+
+
 def test_vit_gemms_full_size_against_fp32_reference(ops):
     """The frozen-ViT GEMMs at the QVH shapes (60 frames x 257 tokens = 15420 rows), as the library dispatches them itself (the
     persistent four-wave kernel), against fp32 torch: fc1 (bias + exact-erf GELU, bf16 out), fc2 (bias + fp32 residual, in place),
