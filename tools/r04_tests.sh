@@ -2,5 +2,4 @@
 ulimit -c 0
 cd "$(dirname "$0")/.."
 O=gpurun_out; mkdir -p $O
-timeout 2400 python -m pytest tests -m gpu -q --tb=short 2>&1 | grep -E "^E |passed|failed|^FAILED|^tests/.*(Error|assert)" | head -60 | tee $O/r04i_tests.log
-timeout 900 python tools/host_stress.py 4 charades 2>&1 | grep -v amdgpu.ids | tee $O/r04_host_stress.txt
+timeout 2400 python -m pytest tests -m gpu -q --tb=short 2>&1 | grep -E "^E |passed|failed|^FAILED|^tests/.*(Error|assert)" | head -60 | tee $O/r04j_tests.log
