@@ -341,14 +341,39 @@ __global__ __launch_bounds__(256) void dropout_bf16_kernel(const bf16_t* __restr
   }
 }
 
-// out[c] += sum_m x[m,c]  (bias gradients)
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, long long ldx, int M, int N, int rows_per_block, float* __restrict__ out) {
+// out[c] += sum_m x[m,c]  (bias gradients).  Round 4: the row blocks' partial sums are added in BLOCK order by the last-arriving block of a
+// column group (ticket; write-through partials in a library-owned scratch, as ce_kernel) instead of fp32 atomics in arrival order: the
+// t5_proj bias gradient is the same bits on every run.  Launches are expected to be stream-ordered.
+#define CS_MAXY 64
+#define CS_MAXN 8192
+__device__ float g_cs_part[CS_MAXY * CS_MAXN];
+__device__ unsigned int g_cs_ticket[CS_MAXN / 256];
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, long long ldx, int M, int N, int rows_per_block, float* __restrict__ out, int ordered) {
+  __shared__ int last_flag;
   const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= N) return;
   const int mbeg = blockIdx.y * rows_per_block, mend = min(M, mbeg + rows_per_block);
   float acc = 0.f;
-  for (int m = mbeg; m < mend; ++m) acc += x[(long long)m * ldx + c];
-  atomicAdd(out + c, acc);
+  if (c < N)
+    for (int m = mbeg; m < mend; ++m) acc += x[(long long)m * ldx + c];
+  if (!ordered) {
+    if (c < N) atomicAdd(out + c, acc);
+    return;
+  }
+  if (c < N) __hip_atomic_store(&g_cs_part[blockIdx.y * CS_MAXN + c], acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // write-through
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned int old = __hip_atomic_fetch_add(&g_cs_ticket[blockIdx.x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    last_flag = old == gridDim.y - 1;
+    if (last_flag) __hip_atomic_store(&g_cs_ticket[blockIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (last_flag && c < N) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    float tot = out[c];
+    for (int y = 0; y < (int)gridDim.y; ++y) tot += __hip_atomic_load(&g_cs_part[y * CS_MAXN + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    out[c] = tot;
+  }
 }
 
 // LoRA master weights (fp32 flat buffer: A [8,K], Bt [8,out] per adapter) -> bf16 GEMM operands, one launch for all
@@ -538,8 +563,10 @@ extern "C" int mrblip_dropout_bf16(const void* x, long long ldx, void* out, long
 }
 extern "C" int mrblip_colsum(const float* x, long long ldx, int M, int N, float* out, hipStream_t stream) {
   MRB_REQUIRE(M > 0 && N > 0, "colsum: bad shape");
-  const int rpb = 64;
-  hipLaunchKernelGGL(colsum_kernel, dim3((N + 255) / 256, (M + rpb - 1) / rpb), dim3(256), 0, stream, x, ldx, M, N, rpb, out);
+  int rpb = 64;
+  const int ordered = N <= CS_MAXN ? 1 : 0;
+  if (ordered && (M + rpb - 1) / rpb > CS_MAXY) rpb = (M + CS_MAXY - 1) / CS_MAXY;
+  hipLaunchKernelGGL(colsum_kernel, dim3((N + 255) / 256, (M + rpb - 1) / rpb), dim3(256), 0, stream, x, ldx, M, N, rpb, out, ordered);
   return mrblip_check_launch("colsum");
 }
 extern "C" int mrblip_lora_pack(const float* flat, void* acat_bf16, void* wext_bf16, void* bblk_bf16, void* acatt_bf16, const long long* desc,

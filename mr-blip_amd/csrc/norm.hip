@@ -68,6 +68,12 @@ __global__ __launch_bounds__(256) void norm_fwd_kernel(const float* __restrict__
   }
 }
 
+#define NORM_DW_MAXD 2048
+#define NORM_DW_MAXB 256
+typedef uint32_t norm_u32x4 __attribute__((ext_vector_type(4)));
+__device__ float g_dw_part[NORM_DW_MAXB * 2 * NORM_DW_MAXD];   // ordered weight gradients: [block][dgamma | dbeta][D] partial sums
+__device__ unsigned int g_dw_ticket;
+
 // dx = dx_add + rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma   (RMS: no mean(g) term, xhat = x*rstd)
 // dgamma += sum_rows dy * xhat, dbeta += sum_rows dy  (optional, fp32 atomics, one per column per block)
 template <bool RMS>
@@ -75,8 +81,9 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const float* __restrict__
                                                        long long ldx, const float* __restrict__ gamma, int M, int D, float eps,
                                                        const float* dx_add, long long ldadd, float* dx, long long lddx,
                                                        float* dgamma, float* dbeta, bf16_t* out_b = nullptr, long long ldob = 0,
-                                                       DropoutArg drop = DropoutArg{nullptr, 0u, 0u, 1.0f}) {
+                                                       DropoutArg drop = DropoutArg{nullptr, 0u, 0u, 1.0f}, int ordered_dw = 0) {
   __shared__ float red[2][4][64 * 4];
+  __shared__ int last_flag;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int nv = D >> 2;
   float4 ag[NORM_MAXV], ab[NORM_MAXV];
@@ -179,16 +186,67 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const float* __restrict__
       if (wv == 0) {
         const int i = lane + 64 * j;
         if (i < nv) {
+          float sgm[4], sbt[4];
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
-            const float sgm = red[0][0][lane * 4 + c] + red[0][1][lane * 4 + c] + red[0][2][lane * 4 + c] + red[0][3][lane * 4 + c];
-            const float sbt = red[1][0][lane * 4 + c] + red[1][1][lane * 4 + c] + red[1][2][lane * 4 + c] + red[1][3][lane * 4 + c];
-            atomicAdd(dgamma + i * 4 + c, sgm);
-            if (dbeta) atomicAdd(dbeta + i * 4 + c, sbt);
+            sgm[c] = red[0][0][lane * 4 + c] + red[0][1][lane * 4 + c] + red[0][2][lane * 4 + c] + red[0][3][lane * 4 + c];
+            sbt[c] = red[1][0][lane * 4 + c] + red[1][1][lane * 4 + c] + red[1][2][lane * 4 + c] + red[1][3][lane * 4 + c];
+          }
+          if (ordered_dw) {   // this block's partial sums, write-through (see below)
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(g_dw_part + (long long)blockIdx.x * 2 * NORM_DW_MAXD, 0, 2 * NORM_DW_MAXD * 4, 0x00020000);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(norm_u32x4, f32x4{sgm[0], sgm[1], sgm[2], sgm[3]}), rs, (uint32_t)(i * 16), 0, 16);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(norm_u32x4, f32x4{sbt[0], sbt[1], sbt[2], sbt[3]}), rs, (uint32_t)((NORM_DW_MAXD + i * 4) * 4), 0, 16);
+          } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              atomicAdd(dgamma + i * 4 + c, sgm[c]);
+              if (dbeta) atomicAdd(dbeta + i * 4 + c, sbt[c]);
+            }
           }
         }
       }
       __syncthreads();
+    }
+    // Round 4: ORDERED weight gradients.  fp32 atomics add the blocks' partial sums in arrival order, so dgamma / dbeta (ln_vision: the
+    // only trainable norm) changed in their last bits from run to run — the one thing left that made a train step irreproducible
+    // (tools/determinism_check.py).  Each block now publishes its partial row [2][D] to a library-owned scratch with write-through stores,
+    // drains them and takes a ticket; the block that draws the last ticket adds the partials in BLOCK order (cdna_hip_programming.md
+    // Guideline 16, form R1).  Launches are expected to be stream-ordered (one scratch).
+    if (ordered_dw) {
+      if (wv == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        const unsigned int old = __hip_atomic_fetch_add(&g_dw_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last_flag = old == gridDim.x - 1;
+        if (last_flag) __hip_atomic_store(&g_dw_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __syncthreads();
+      if (last_flag) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        const int nb = (int)gridDim.x;
+        for (int q = threadIdx.x; q < 2 * nv; q += 256) {          // float4 column group q of [dgamma | dbeta]
+          const int arr = q >= nv ? 1 : 0, i = q - arr * nv;
+          if (arr == 1 && !dbeta) continue;
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+          const uint32_t off = (uint32_t)((arr * NORM_DW_MAXD + i * 4) * 4);
+          for (int b0 = 0; b0 < nb; b0 += 8) {
+            f32x4 t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              const int b = min(b0 + u, nb - 1);
+              const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(g_dw_part + (long long)b * 2 * NORM_DW_MAXD, 0, 2 * NORM_DW_MAXD * 4, 0x00020000);
+              t[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16));
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+              if (b0 + u < nb) acc += t[u];
+          }
+          float* dst = (arr ? dbeta : dgamma) + i * 4;
+          float4 cur = *reinterpret_cast<float4*>(dst);
+          cur.x += acc[0]; cur.y += acc[1]; cur.z += acc[2]; cur.w += acc[3];
+          *reinterpret_cast<float4*>(dst) = cur;
+        }
+      }
     }
   }
 }
@@ -231,8 +289,13 @@ extern "C" int mrblip_layernorm_bwd(const float* dy, long long lddy, const float
                                     float eps, const float* dx_add, long long ldadd, float* dx, long long lddx, float* dgamma,
                                     float* dbeta, hipStream_t stream) {
   if (int e = norm_check(M, D, x, ldx)) return e;
-  const int grid = min((M + 3) / 4, dgamma ? 512 : 2048);
-  hipLaunchKernelGGL(norm_bwd_kernel<false>, dim3(grid), dim3(256), 0, stream, dy, lddy, x, ldx, gamma, M, D, eps, dx_add, ldadd, dx, lddx, dgamma, dbeta);
+  // (dgamma / dbeta: at most NORM_DW_MAXB blocks, whose partial sums the last one adds in block order; MRB_NORM_DW_ATOMIC=1: fp32 atomics)
+  static int dw_atomic = -1;
+  if (dw_atomic < 0) { const char* e = getenv("MRB_NORM_DW_ATOMIC"); dw_atomic = (e && e[0] == '1') ? 1 : 0; }
+  const int ordered = (dgamma && !dw_atomic && ((uintptr_t)dgamma % 16) == 0 && (!dbeta || ((uintptr_t)dbeta % 16) == 0)) ? 1 : 0;
+  const int grid = min((M + 3) / 4, dgamma ? (ordered ? NORM_DW_MAXB : 512) : 2048);
+  hipLaunchKernelGGL(norm_bwd_kernel<false>, dim3(grid), dim3(256), 0, stream, dy, lddy, x, ldx, gamma, M, D, eps, dx_add, ldadd, dx, lddx, dgamma, dbeta,
+                     (bf16_t*)nullptr, 0ll, DropoutArg{nullptr, 0u, 0u, 1.0f}, ordered);
   return mrblip_check_launch("layernorm_bwd");
 }
 

@@ -242,6 +242,43 @@ def test_norms(ops, D):
     assert rel(dx, xr.grad + add) < 1e-5
 
 
+def test_weight_gradient_reductions_are_ordered(ops):
+    """Round 4: the two reductions of the step that used fp32 atomics — LayerNorm's dgamma / dbeta (ln_vision, 15420 rows) and the
+    column sum behind the t5_proj bias gradient — add their blocks' partial sums in BLOCK order (last-arriver ticket): correct against
+    torch, accumulating (+=) semantics kept, and the same bits on every launch while another stream keeps the chip busy."""
+    torch.manual_seed(17)
+    M, D = 15420, 1408
+    x, dy = torch.randn(M, D, device=dev()), torch.randn(M, D, device=dev())
+    g = torch.randn(D, device=dev()) * 0.1 + 1
+    xr, gr, br = x.clone().requires_grad_(True), g.clone().requires_grad_(True), torch.zeros(D, device=dev(), requires_grad=True)
+    torch.nn.functional.layer_norm(xr, (D,), gr, br, 1e-6).backward(dy)
+    a = bf(torch.randn(4096, 4096, device=dev()))
+    c = torch.empty(4096, 4096, device=dev())
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        for _ in range(10):
+            ops.gemm(a, a, c)
+    outs = []
+    for rep in range(12):
+        dx = torch.empty_like(x)
+        dg, db = torch.full((D,), 0.5, device=dev()), torch.full((D,), -0.25, device=dev())
+        ops.layernorm_bwd(dy, x, g, 1e-6, dx, dgamma=dg, dbeta=db)
+        outs.append((dg.clone(), db.clone()))
+    side.synchronize()
+    assert rel(outs[0][0] - 0.5, gr.grad) < 2e-5 and rel(outs[0][1] + 0.25, br.grad) < 2e-5
+    for dg, db in outs[1:]:
+        assert torch.equal(dg, outs[0][0]) and torch.equal(db, outs[0][1])
+    for Mc, Nc in ((1920, 2048), (77, 300), (9000, 768)):
+        y = torch.randn(Mc, Nc, device=dev())
+        sums = []
+        for rep in range(8):
+            out = torch.full((Nc,), 2.0, device=dev())
+            ops.colsum(y, out)
+            sums.append(out.clone())
+        assert rel(sums[0] - 2.0, y.sum(0)) < 1e-5
+        assert all(torch.equal(s_, sums[0]) for s_ in sums[1:])
+
+
 def _attn_ref(q, k, v, scale, bias=None, mask=None, drop_mask=None, p=0.0):
     """q,k,v: [B,H,S,D] fp32 (already bf16-rounded values).  fp32 softmax, probabilities bf16-rounded before PV."""
     s = q @ k.transpose(-1, -2) * scale

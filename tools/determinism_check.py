@@ -1,6 +1,7 @@
 """Run-to-run determinism of the train step (training mode, dropout on): the SAME seed must give the SAME bits — loss and the flat gradient — on
 every repetition.  A difference means a race between the engine's streams (or a read of stale workspace contents), which no parity tolerance
-would show.  tiny config: many repetitions; QVH config: a few.   usage: determinism_check.py [tiny_reps=200] [qvh_reps=12]"""
+would show — or a reduction whose order follows arrival (round 4 removed the three the step had: the CE loss sum, LayerNorm's weight
+gradients, the bias column sum).  tiny config: many repetitions; QVH config: a few.   usage: determinism_check.py [tiny_reps=200] [qvh_reps=12]"""
 import os
 import sys
 
