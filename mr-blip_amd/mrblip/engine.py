@@ -481,6 +481,27 @@ class MrBlipEngine:
         t_ok = self.tout_ok(hd, F_, nq, 4)
         want_t = bool(self.gemm_tout_sites & 8)   # the transposed Q / K copies of the forward are kept for the backward (eval / generate pay a few MB for them)
         self.qf_t_saved = t_ok and want_t
+        # Round 4: the cross-attention K / V projections of the image tokens ([F * 257, 1408] x [1408, 1536] per cross layer: the only big
+        # GEMMs of the Q-Former, 70 us each) depend on nothing but ``img``: they (and their V^T copies) are issued on the side stream at
+        # entry and run beside the chain of small query-side kernels, each cross layer waits for its own event.  This phase runs with the
+        # chip to itself (the look-ahead ViT starts behind the encoder forward), so what is hidden here comes off the step 1:1.
+        kv_ready = {}
+        if self.qf_kv_side and self.grad_side_stream_enabled:
+            st, ev0 = self._grad_stream(), torch.cuda.Event()
+            ev0.record()
+            with torch.cuda.stream(st):
+                st.wait_event(ev0)
+                for i, L in enumerate(self.qf["layers"]):
+                    if L["cross"] is None:
+                        continue
+                    C_ = L["cross"]
+                    kv = self.buf(f"qf{i}_kvc", (F_ * Tv, 2 * D), bf16, zero=False)
+                    vt_i = self.buf(f"qf{i}_vt_c", (F_, H, ops.rup32(hd), ops.rup32(Tv)), bf16)
+                    ops.gemm(img, C_["kv_w"], kv, bias=C_["kv_b"])
+                    ops.head_transpose(self.v4(kv, F_, Tv, H, hd, D), out=vt_i)
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    kv_ready[i] = (kv, vt_i, ev)
         for i, L in enumerate(self.qf["layers"]):
             S_ = L["self"]
             qkv = self.buf(f"qf{i}_qkv", (Mq, 3 * D), bf16, zero=False)
@@ -508,10 +529,15 @@ class MrBlipEngine:
                     ops.gemm(xb, C_["q_w"], qc, bias=C_["q_b"], tout=(self.buf(f"qf{i}_qt_c", (F_, H, 64, ops.rup32(nq)), bf16),), t_rows=nq)
                 else:
                     ops.gemm(xb, C_["q_w"], qc, bias=C_["q_b"])
-                kv = self.buf(f"qf{i}_kvc", (F_ * Tv, 2 * D), bf16, zero=False)
-                ops.gemm(img, C_["kv_w"], kv, bias=C_["kv_b"])
-                k4, v4 = self.v4(kv, F_, Tv, H, hd, 0), self.v4(kv, F_, Tv, H, hd, D)
-                ops.head_transpose(v4, out=vt_c)
+                if i in kv_ready:
+                    kv, vt_c, ev = kv_ready[i]
+                    torch.cuda.current_stream().wait_event(ev)
+                    k4 = self.v4(kv, F_, Tv, H, hd, 0)
+                else:
+                    kv = self.buf(f"qf{i}_kvc", (F_ * Tv, 2 * D), bf16, zero=False)
+                    ops.gemm(img, C_["kv_w"], kv, bias=C_["kv_b"])
+                    k4, v4 = self.v4(kv, F_, Tv, H, hd, 0), self.v4(kv, F_, Tv, H, hd, D)
+                    ops.head_transpose(v4, out=vt_c)
                 oc = self.buf(f"qf{i}_oc", (Mq, pad64(D)), bf16)
                 lsec = self.buf(f"qf{i}_lsec", (F_, H, ops.rup32(nq)), f32)
                 ops.attention_fwd(self.v4(qc, F_, nq, H, hd), k4, vt_c, self.v4(oc, F_, nq, H, hd), lsec, scale=scale, drop=self.qdrop(C_["sites"][0], pdrop))
@@ -848,6 +874,7 @@ class MrBlipEngine:
     # Round 4: the tile GEMMs that produce q / k / v (and the backward's dO) also write the head-transposed copies the attention kernels read
     # (csrc/gemm.hip GemmArgs.tout): no head_transpose launches in the T5 encoder and the Q-Former's self / query paths.  MRB_GEMM_TOUT=0
     # restores the transpose launches.
+    qf_kv_side = os.environ.get("MRB_QF_KV_SIDE", "1") == "1"   # Q-Former cross K / V projections on the side stream beside the query chain
     gemm_tout_enabled = os.environ.get("MRB_GEMM_TOUT", "1") == "1"
 
     gemm_tout_sites = int(os.environ.get("MRB_TOUT_SITES", "15"))   # bit mask for A/B: 1 T5 encoder fwd (+ stacked cross K/V), 2 encoder bwd, 4 Q-Former fwd, 8 Q-Former bwd
