@@ -494,6 +494,29 @@ extern "C" int mrblip_adamw(float* p, const float* g, float* m, float* v, long l
   hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n)), dim3(256), 0, stream, p, g, m, v, n, hyper, beta1, beta2, eps, weight_decay);
   return mrblip_check_launch("adamw");
 }
+// Pull a byte range through the memory-side cache ahead of its consumer (round 4): the weights of a T5 layer are touched once per pass,
+// so every GEMM finds them in HBM — stand-alone loops over one weight set (which the 256 MB Infinity Cache holds) are 10-25 % faster
+// than the same launches in the step.  A few blocks on a side stream read the NEXT launch's operands while the current one computes;
+// the loads are dropped (the xor below can never match), nothing is written.
+__global__ __launch_bounds__(256) void prefetch_kernel(const uint4* __restrict__ p, long long n16, uint32_t* sink) {
+  uint32_t acc = 0;
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long step = (long long)gridDim.x * 256;
+  for (; i + 3 * step < n16; i += 4 * step) {
+    const uint4 a = p[i], b = p[i + step], c = p[i + 2 * step], d = p[i + 3 * step];
+    acc |= (a.x ^ b.x ^ c.x ^ d.x) & (a.y ^ b.y ^ c.y ^ d.y) & (a.z ^ b.z ^ c.z ^ d.z) & (a.w ^ b.w ^ c.w ^ d.w);
+  }
+  for (; i < n16; i += step) { const uint4 a = p[i]; acc |= a.x & a.y & a.z & a.w; }
+  if (acc == 0x9e3779b9u && sink) *sink = acc;   // keeps the loads alive; never true for bf16 weight data in practice, harmless if it is
+}
+extern "C" int mrblip_prefetch(const void* ptr, long long bytes, int n_blocks, hipStream_t stream) {
+  MRB_REQUIRE(ptr && bytes >= 0 && ((uintptr_t)ptr % 16) == 0 && n_blocks > 0 && n_blocks <= 1024, "prefetch: 16-byte aligned range, 1..1024 blocks");
+  if (bytes < 16) return MRBLIP_OK;
+  static uint32_t* sink = nullptr;
+  if (!sink && hipMalloc((void**)&sink, 64) != hipSuccess) { mrblip_set_error("prefetch: cannot allocate the sink word"); return MRBLIP_ELAUNCH; }
+  hipLaunchKernelGGL(prefetch_kernel, dim3(n_blocks), dim3(256), 0, stream, (const uint4*)ptr, bytes / 16, sink);
+  return mrblip_check_launch("prefetch");
+}
 extern "C" int mrblip_seed_bump(uint32_t* seed, hipStream_t stream) {
   hipLaunchKernelGGL(seed_bump_kernel, dim3(1), dim3(64), 0, stream, seed);
   return mrblip_check_launch("seed_bump");

@@ -62,6 +62,11 @@ struct GemmArgs {
   // the K extension of output-column group g = n / ext_group_n reads columns [64 g, 64 g + 64) of Aext (0: one group): one GEMM for the
   // cross-attention K / V projections of ALL decoder layers, each layer with its own LoRA "down" activations
   int ext_group_n;
+  int group_m;      // generic tile kernel: row tiles per group of the tile walk (launch_tile)
+  // round 4, generic tile kernel: the FIRST pf_blocks workgroups of the grid (a multiple of 8: the tiles keep their XCD) do not compute;
+  // they read [pf_ptr, pf_ptr + 16 pf_n16) and drop it — the weights of a LATER launch, pulled into the memory-side cache while this
+  // one computes (mrblip_gemm_set_prefetch)
+  const void* pf_ptr; long long pf_n16; int pf_blocks;
 };
 
 // v0..v3: 4 consecutive columns n0..n0+3 of row m (raw accumulator). Applies bias -> (pre-activation copy) -> GELU -> dropout -> residual.
@@ -253,6 +258,22 @@ __global__ __launch_bounds__(WGM* WGN * 64, gemm_min_blocks(NS * (BM + BN) * BK 
   static_assert(!GATED || TN == 2, "gated epilogue pairs the wave's two n-tiles");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
+  const int pfb = p.pf_blocks;   // uniform
+  if (pfb > 0 && (int)blockIdx.x < pfb) {   // prefetch role: stream a later launch's weights through the memory-side cache, keep nothing
+    const mrb_u32x4* __restrict__ q = reinterpret_cast<const mrb_u32x4*>(p.pf_ptr);
+    const long long step = (long long)pfb * (NW * 64);
+    long long i = (long long)blockIdx.x * (NW * 64) + threadIdx.x;
+    uint32_t keep = 0;
+    // (plain loads: with the non-temporal hint the lines are not kept by the memory-side cache — measured, the consumer ran at its cold speed)
+    for (; i + 3 * step < p.pf_n16; i += 4 * step) {
+      const mrb_u32x4 a = q[i], b = q[i + step], c = q[i + 2 * step], d = q[i + 3 * step];
+      keep |= a[0] ^ b[1] ^ c[2] ^ d[3];
+    }
+    for (; i < p.pf_n16; i += step) keep |= q[i][0];
+    asm volatile("" ::"v"(keep));   // the loads stay, no store
+    return;
+  }
+
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = w / WGN, wn = w % WGN;
@@ -372,12 +393,12 @@ __global__ __launch_bounds__(WGM* WGN * 64, gemm_min_blocks(NS * (BM + BN) * BK 
 #endif
   // ---- persistent tile loop: grid = resident blocks; a block's epilogue stores drain while it already stages the next tile
   const int ntiles = p.tiles_m * p.tiles_n;
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  for (int tile = (int)blockIdx.x - pfb; tile < ntiles; tile += (int)gridDim.x - pfb) {
   {  // tile id -> (bm, bn): XCD-contiguous remap (bijective), then grouped ordering for L2 reuse of the W panel
     int bid = tile;
     const int q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    constexpr int GROUP_M = 8;
+    const int GROUP_M = p.group_m;
     const int per_group = GROUP_M * p.tiles_n;
     const int gid = bid / per_group;
     const int first_m = gid * GROUP_M;
@@ -1534,6 +1555,11 @@ static int launch_tile(GemmArgs& a, hipStream_t st) {
   const int ncols = GATED ? a.N / 2 : a.N;
   a.tiles_m = (a.M + BM - 1) / BM;
   a.tiles_n = (ncols + BNO - 1) / BNO;
+  {
+    static int env_gm = -1;
+    if (env_gm < 0) { const char* e = getenv("MRB_GROUP_M"); env_gm = e ? atoi(e) : 0; }
+    a.group_m = env_gm > 0 ? env_gm : 8;
+  }
   constexpr int TN_ = BN / WGN / 32, SLAB = 32 * (TN_ * 32 * 4 + 16) * WGM * WGN;   // epilogue staging (see the kernel)
   constexpr int LDS = NS * (BM + BN) * BK * 2 > SLAB ? NS * (BM + BN) * BK * 2 : SLAB;
   auto kern = gemm_tile_kernel<BM, BN, WGM, WGN, OUT_F32, GATED, BK, NS>;
@@ -1556,7 +1582,8 @@ static int launch_tile(GemmArgs& a, hipStream_t st) {
   // dispatch of 2 blocks/CU measured slightly faster than a static persistent walk).
   const int ntiles = a.tiles_m * a.tiles_n;
   const int grid = (NS == 2 && LDS > 80 * 1024 && ntiles > num_cu) ? num_cu : ntiles;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(WGM * WGN * 64), LDS, st, a);
+  a.pf_blocks = (a.pf_ptr && a.pf_n16 > 0) ? (a.pf_blocks + 7) / 8 * 8 : 0;
+  hipLaunchKernelGGL(kern, dim3(grid + a.pf_blocks), dim3(WGM * WGN * 64), LDS, st, a);
   return mrblip_check_launch("gemm_tile");
 }
 
@@ -1593,6 +1620,16 @@ extern "C" int mrblip_gemm_set_extra(void* tout0, void* tout1, void* tout2, int 
   return MRBLIP_OK;
 }
 
+// one-shot, like the extras: the calling thread's NEXT GEMM launch also streams [ptr, ptr + bytes) through the memory-side cache with
+// n_blocks extra workgroups (generic tile kernels; the other forms ignore it — it is a hint and changes no result)
+struct GemmPrefetch { const void* ptr; long long bytes; int n_blocks; };
+static thread_local GemmPrefetch g_gemm_prefetch = {};
+extern "C" int mrblip_gemm_set_prefetch(const void* ptr, long long bytes, int n_blocks) {
+  MRB_REQUIRE(bytes >= 0 && ((uintptr_t)ptr % 16) == 0 && n_blocks >= 0 && n_blocks <= 1024, "gemm_set_prefetch: 16-byte aligned range, at most 1024 blocks");
+  g_gemm_prefetch = GemmPrefetch{ptr, bytes, n_blocks};
+  return MRBLIP_OK;
+}
+
 static int gemm_dispatch(const void* A, long long lda, const void* W, long long ldw, const void* Aext, long long ldaext,
                          const void* Wext, long long ldwext, int M, int N, int K, void* out, long long ldo, int out_f32,
                          void* out2, long long ldo2, const float* bias, const float* residual, long long ldr, int act,
@@ -1601,6 +1638,8 @@ static int gemm_dispatch(const void* A, long long lda, const void* W, long long 
   // the one-shot extras belong to THIS call whatever happens to it (a call that fails below must not leave them to the next GEMM)
   const GemmExtra extra = g_gemm_extra;
   g_gemm_extra = GemmExtra{};
+  const GemmPrefetch pf = g_gemm_prefetch;
+  g_gemm_prefetch = GemmPrefetch{};
   MRB_REQUIRE(M > 0 && N > 0 && K >= 0 && (K % 64) == 0, "gemm: need M,N>0 and K%%64==0 (M=%d N=%d K=%d)", M, N, K);
   MRB_REQUIRE(K > 0 || Aext, "gemm: empty contraction");
   MRB_REQUIRE((N % 8) == 0, "gemm: N %% 8 != 0 (N=%d)", N);
@@ -1618,6 +1657,7 @@ static int gemm_dispatch(const void* A, long long lda, const void* W, long long 
   a.t_inner = extra.set ? extra.t_inner : 0; a.t_rows = extra.t_rows; a.t_spad = extra.t_spad; a.t_bs = extra.t_bs; a.t_hs = extra.t_hs;
   a.t_stride = extra.t_stride; a.t_count = extra.set ? extra.t_count : 0;
   a.ext_group_n = extra.set ? extra.ext_group_n : 0;
+  a.pf_ptr = pf.n_blocks > 0 ? pf.ptr : nullptr; a.pf_n16 = pf.bytes / 16; a.pf_blocks = pf.n_blocks;
   const bool has_extra = a.t_inner > 0 || a.ext_group_n > 0;
   MRB_REQUIRE(a.t_inner == 0 || (!out_f32 && !gated && act == 0 && !(p_drop > 0.f) && !residual && !out2 && (M == a.t_rows || (a.t_rows % 32) == 0) && (M % a.t_rows) == 0),
               "gemm: head-transposed copies need a bf16 output with a plain / bias epilogue and one clip or t_rows %% 32 == 0");
@@ -1688,7 +1728,7 @@ static int gemm_dispatch(const void* A, long long lda, const void* W, long long 
   if (has_extra) {   // the extras live in the generic tile kernel's staging / epilogue; the transposed copies need 64-column wave slabs
     if (a.t_inner > 0 && cfg == 5) cfg = 4;
     if (cfg == 13 || (cfg == 3 && (tile_cfg & 0xff) == 0)) cfg = (M >= 1024 && N >= 1024) ? 2 : 4;
-    MRB_REQUIRE(cfg == 1 || cfg == 2 || cfg == 4 || cfg == 7 || cfg == 8 || cfg == 9 || cfg == 11 || (a.t_inner == 0 && (cfg == 5 || cfg == 10 || cfg == 12)),
+    MRB_REQUIRE(cfg == 1 || cfg == 2 || cfg == 4 || cfg == 7 || cfg == 8 || cfg == 9 || cfg == 11 || (cfg >= 18 && cfg <= 21) || (a.t_inner == 0 && (cfg == 5 || cfg == 10 || cfg == 12)),
                 "gemm: head-transposed copies / grouped K extension are not available in tile config %d", cfg);
   }
   if (cfg == 3) {
@@ -1913,6 +1953,24 @@ static int gemm_dispatch(const void* A, long long lda, const void* W, long long 
   // (round 3, measured at the T5 [2012 x 2048] outputs and removed again: 128x128 tiles — one per CU, 2/3 of the L2->LDS traffic of
   // 64x128 — with a 3- or 4-stage ring, or with 8 waves of 64x32: K = 10240: 115.9 / 114.6 / 112.5 us against 120.6 us for the plain
   // 128x128 and 105.1 us for 64x128 at two blocks per CU; profiles/r03_gemm_t5_tiles.txt)
+  // deeper rings of the small tiles: with weights that come from HBM (every layer's own, not the re-used panel of a stand-alone loop) one
+  // K-tile of prefetch distance (0.5 us) is shorter than the memory latency
+  if (cfg == 18) {  // 64x128, 3 stages (72 KB: still two blocks per CU)
+    if (gated) return launch_tile<64, 128, 2, 2, false, true, 64, 3>(a, stream);
+    return out_f32 ? launch_tile<64, 128, 2, 2, true, false, 64, 3>(a, stream) : launch_tile<64, 128, 2, 2, false, false, 64, 3>(a, stream);
+  }
+  if (cfg == 19) {  // 64x128, 4 stages (96 KB: one block per CU)
+    if (gated) return launch_tile<64, 128, 2, 2, false, true, 64, 4>(a, stream);
+    return out_f32 ? launch_tile<64, 128, 2, 2, true, false, 64, 4>(a, stream) : launch_tile<64, 128, 2, 2, false, false, 64, 4>(a, stream);
+  }
+  if (cfg == 20) {  // 128x128, 3 stages (96 KB)
+    if (gated) return launch_tile<128, 128, 2, 2, false, true, 64, 3>(a, stream);
+    return out_f32 ? launch_tile<128, 128, 2, 2, true, false, 64, 3>(a, stream) : launch_tile<128, 128, 2, 2, false, false, 64, 3>(a, stream);
+  }
+  if (cfg == 21) {  // 128x128, 4 stages (128 KB)
+    if (gated) return launch_tile<128, 128, 2, 2, false, true, 64, 4>(a, stream);
+    return out_f32 ? launch_tile<128, 128, 2, 2, true, false, 64, 4>(a, stream) : launch_tile<128, 128, 2, 2, false, false, 64, 4>(a, stream);
+  }
   if (cfg == 4) {
     if (gated) return launch_tile<64, 128, 2, 2, false, true>(a, stream);
     return out_f32 ? launch_tile<64, 128, 2, 2, true, false>(a, stream) : launch_tile<64, 128, 2, 2, false, false>(a, stream);

@@ -175,6 +175,8 @@ class LoraGroup:
     bblk: torch.Tensor = None  # bf16 [8*nad, N]: scale * B^T block-diagonal (operand of g = dy @ B)
     acatt: torch.Tensor = None  # bf16 [K, 64]: (scale * A)^T, K-extension operand of the dX GEMM
     site: int = 0              # lora_dropout site (one mask per group input)
+    w_off: int = -1            # encoder groups: element offset of W in the engine's enc_w_arena
+    wt_off: int = -1           # ... and of Wt in enc_wt_arena
 
 
 def _with_attention_split(fn):
@@ -702,6 +704,25 @@ class MrBlipEngine:
                 sites=[self.new_site() for _ in range(6)],
             ))
         self.t5["enc_final"] = self._v(src.get(t + "encoder.final_layer_norm.weight", (d,)))
+        # the encoder's forward weights in one arena, in the order the forward reads them: a GEMM's prefetch workgroups (enc_prefetch)
+        # pull a contiguous range — the weights of the next launches — through the memory-side cache
+        eorder = [L[k] for L in self.t5["enc"] for k in ("qkv", "o", "wi", "wo")]
+        self.enc_w_arena = torch.empty(sum(g.W.numel() for g in eorder), dtype=bf16, device=self.dev)
+        off = 0
+        for g in eorder:
+            v = self.enc_w_arena[off: off + g.W.numel()].view_as(g.W)
+            v.copy_(g.W)
+            g.W, g.w_off = v, off
+            off += v.numel()
+        # ... and the transposed copies the backward's dX GEMMs read, in the backward's order
+        border = [L[k] for L in reversed(self.t5["enc"]) for k in ("wo", "wi", "o", "qkv")]
+        self.enc_wt_arena = torch.empty(sum(g.Wt.numel() for g in border), dtype=bf16, device=self.dev)
+        off = 0
+        for g in border:
+            v = self.enc_wt_arena[off: off + g.Wt.numel()].view_as(g.Wt)
+            v.copy_(g.Wt)
+            g.Wt, g.wt_off = v, off
+            off += v.numel()
         self.t5["dec_final"] = self._v(src.get(t + "decoder.final_layer_norm.weight", (d,)))
         self.t5["lm"] = group(["lm_head"], d, [V])
         self.t5["sites"] = [self.new_site() for _ in range(4)]
@@ -834,10 +855,34 @@ class MrBlipEngine:
             assert g.acat.data_ptr() == self.ckv_all["acat"][i * R].data_ptr() and g.wext.data_ptr() == self.ckv_all["wext"][i * N].data_ptr()
 
     # ---- LoRA-group forward / backward -------------------------------------------------------------------------
+    # Round 4: each T5 layer's weights are read once per pass, so every GEMM finds them in HBM; the [2012 x N] tile GEMMs run 10-25 % slower
+    # on cold weights than on a re-used set (tools/prefetch_bench.py).  The qkv GEMM of an encoder layer starts extra workgroups that read
+    # the o and wi weights, the wi GEMM the wo weights and the next layer's qkv weights (csrc/gemm.hip pf_blocks).  MRB_ENC_PREFETCH=0: off.
+    enc_prefetch = tuple(int(x) for x in (os.environ.get("MRB_ENC_PREFETCH", "32,128,32") + ",,").split(",")[:3] if x)   # workgroups per host launch (qkv, o, wi; 0: none)
+    enc_pf_plan = int(os.environ.get("MRB_ENC_PF_PLAN", "1"))   # which launch carries which range (see t5_encoder_forward)
+    enc_prefetch_min_rows = int(os.environ.get("MRB_ENC_PREFETCH_MIN_ROWS", "1024"))   # a shorter host launch ends before its prefetch does
+
+    def enc_pf(self, groups, M: int, host: int = 0):
+        """(tensor, bytes, workgroups) covering the arena range of `groups` (adjacent in the arena), or None"""
+        nb = self.enc_prefetch[min(host, len(self.enc_prefetch) - 1)] if self.enc_prefetch else 0
+        if not nb or M < self.enc_prefetch_min_rows or not groups:
+            return None
+        a, b = groups[0].w_off, groups[-1].w_off + groups[-1].W.numel()
+        return (self.enc_w_arena[a:b], (b - a) * 2, nb)
+
+    enc_bwd_prefetch = int(os.environ.get("MRB_ENC_BWD_PREFETCH", "0"))   # the same for the backward's dX GEMMs (transposed weights)
+
+    def enc_pf_bwd(self, groups, M: int):
+        if not self.enc_bwd_prefetch or M < self.enc_prefetch_min_rows or not groups:
+            return None
+        a, b = groups[0].wt_off, groups[-1].wt_off + groups[-1].Wt.numel()
+        return (self.enc_wt_arena[a:b], (b - a) * 2, self.enc_bwd_prefetch)
+
     def lg_fwd(self, g: LoraGroup, x: torch.Tensor, u: torch.Tensor, out: torch.Tensor, u_ready: bool = False, **kw):
         """out = x W^T + u B^T with u = dropout(x) (scale*A)^T:  the rank-8 "down" product is the row kernel of csrc/lora.hip (or was
         already produced by the fused RMSNorm launch: u_ready), the "up" product rides in the main GEMM as a 64-wide K extension."""
         tout, t_rows = kw.pop("tout", None), kw.pop("t_rows", 0)   # head-transposed copies: only the fused decoder kernel writes them (-> True)
+        pf = kw.pop("prefetch", None)       # (tensor, bytes, workgroups): rides in the tile GEMM below (a hint: the other paths drop it)
         per_adapter = self.cfg.lora_mask_per_adapter and len(g.adapters) > 1 and self.training and self.cfg.lora_dropout > 0
         if per_adapter:   # peft-faithful: u_j = dropout_j(x) (s A_j)^T with adapter j's own mask (its own call-site id)
             assert not u_ready
@@ -861,6 +906,8 @@ class MrBlipEngine:
             return
         if not u_ready:
             self.lora_thin(x, g.acat, u, g.K, drop=self.drop(g.site, self.cfg.lora_dropout))
+        if pf is not None:
+            ops.gemm_prefetch(pf[0], n_blocks=pf[2], nbytes=pf[1])
         if tout is not None and out.dtype == bf16 and not kw.get("gated") and x.shape[0] > 64 and self.gemm_tout_enabled:
             ops.gemm(x, g.W, out, aext=u, wext=g.wext, tout=tout, t_rows=t_rows, **kw)   # tile GEMM: head-transposed copies from its epilogue
             return True
@@ -957,7 +1004,8 @@ class MrBlipEngine:
     fuse_norm_lora = os.environ.get("MRB_FUSE_NORM_LORA", "1") == "1"
 
     def lg_bwd(self, g: LoraGroup, dy: torch.Tensor, x: torch.Tensor, u: torch.Tensor, gbuf: torch.Tensor, dx: Optional[torch.Tensor],
-               residual: Optional[torch.Tensor] = None, side: bool = False, tile_cfg: int = 0, flush: bool = True, tout=None, t_rows: int = 0):
+               residual: Optional[torch.Tensor] = None, side: bool = False, tile_cfg: int = 0, flush: bool = True, tout=None, t_rows: int = 0,
+               prefetch=None):
         """dy bf16 [M,N]; x the saved bf16 input; u the saved [M,64] LoRA activations.  Accumulates dA, dB of every adapter of the
         group (one launch) and (optionally) dx = dy W (+ residual) + mask * (g A) (one GEMM: the rank-8 term is its K-extension).
         side=True: the weight-gradient launch goes to the gradient side stream and runs beside the dX GEMM (the caller guarantees
@@ -1008,6 +1056,8 @@ class MrBlipEngine:
                 ops.lora_dx(dy, g.Wt, gbuf, g.acatt, dx, pad64(g.N), residual=None, drop=drop, k_splits=ks)
             else:
                 t_tile = tout is not None and dx.dtype == bf16 and residual is None and dy.shape[0] > 64 and self.gemm_tout_enabled
+                if prefetch is not None:
+                    ops.gemm_prefetch(prefetch[0], n_blocks=prefetch[2], nbytes=prefetch[1])
                 ops.lora_dx(dy, g.Wt, gbuf, g.acatt, dx, pad64(g.N), residual=residual, drop=drop, tile_cfg=tile_cfg,
                             tout=tout if t_tile else None, t_rows=t_rows)
                 return bool(t_tile)
@@ -1075,7 +1125,8 @@ class MrBlipEngine:
             t_ok = self.tout_ok(dk, B, S)
             qt_i = self.buf(f"e{i}_qt", (B, H, 64, ops.rup32(S)), bf16) if t_ok else None
             kt_i = self.buf(f"e{i}_kt", (B, H, 64, ops.rup32(S)), bf16) if t_ok else None
-            t_done = self.norm_lg_fwd(x, L["ln0"], L["qkv"], xn, u, qkv, tile_cfg=_ENC_FWD_CFG[0], tout=(qt_i, kt_i, vt) if t_ok else None, t_rows=S)
+            t_done = self.norm_lg_fwd(x, L["ln0"], L["qkv"], xn, u, qkv, tile_cfg=_ENC_FWD_CFG[0], tout=(qt_i, kt_i, vt) if t_ok else None, t_rows=S,
+                                      prefetch=self.enc_pf([L["o"], L["wi"]] if self.enc_pf_plan == 0 else [L["o"]], M))
             self.enc_t_saved[i] = bool(t_done)
             q4, k4, v4 = self.v4(qkv, B, S, H, dk, 0), self.v4(qkv, B, S, H, dk, inner), self.v4(qkv, B, S, H, dk, 2 * inner)
             if not t_done:
@@ -1087,15 +1138,19 @@ class MrBlipEngine:
             ops.attention_fwd(q4, k4, vt, self.v4(o, B, S, H, dk), lse, scale=1.0, bias_lut=self.lut_enc, kmask=kmask, drop=adrop, drop_bits=dbits)
             uo = self.buf(f"e{i}_u_o", (M, 64), bf16)
             xm = self.buf(f"e{i}_xm", (M, d), f32, zero=False)
-            self.lg_fwd(L["o"], o, uo, xm, residual=x, drop=self.drop(L["sites"][1], p), tile_cfg=_ENC_FWD_CFG[1])
+            self.lg_fwd(L["o"], o, uo, xm, residual=x, drop=self.drop(L["sites"][1], p), tile_cfg=_ENC_FWD_CFG[1],
+                        prefetch=self.enc_pf([L["wi"]], M, 1) if self.enc_pf_plan else None)
             xn2 = self.buf(f"e{i}_xn2", (M, pad64(d)), bf16)
             uw = self.buf(f"e{i}_u_wi", (M, 64), bf16)
             y = self.buf(f"e{i}_y", (M, pad64(ff)), bf16)
             h = self.buf(f"e{i}_h", (M, 2 * ff), bf16, zero=False)
-            self.norm_lg_fwd(xm, L["ln1"], L["wi"], xn2, uw, y, out2=h, gated=True, drop=self.drop(L["sites"][2], p), tile_cfg=_ENC_FWD_CFG[2])
+            nxt = [self.t5["enc"][i + 1]["qkv"]] if i + 1 < len(self.t5["enc"]) else []
+            self.norm_lg_fwd(xm, L["ln1"], L["wi"], xn2, uw, y, out2=h, gated=True, drop=self.drop(L["sites"][2], p), tile_cfg=_ENC_FWD_CFG[2],
+                             prefetch=self.enc_pf([L["wo"]] + (nxt if self.enc_pf_plan < 2 else []), M, 2))
             uwo = self.buf(f"e{i}_u_wo", (M, 64), bf16)
             xo = self.buf(f"e{i + 1}_x" if i + 1 < len(self.t5["enc"]) else "e_xlast", (M, d), f32, zero=False)
-            self.lg_fwd(L["wo"], y, uwo, xo, residual=xm, drop=self.drop(L["sites"][3], p), tile_cfg=_ENC_FWD_CFG[3])
+            self.lg_fwd(L["wo"], y, uwo, xo, residual=xm, drop=self.drop(L["sites"][3], p), tile_cfg=_ENC_FWD_CFG[3],
+                        prefetch=self.enc_pf(nxt, M, 2) if self.enc_pf_plan == 2 else None)
             self.ws[f"e{i}_xin"] = x
             x = xo
         nf = self.buf("e_nf", (M, d), f32, zero=False)
@@ -1156,9 +1211,11 @@ class MrBlipEngine:
             # and one 16 MB read fewer per sub-layer; only the top layer, whose dx comes from the decoder, casts on its own)
             if not dyb_ready:
                 ops.cast_dropout(dx, out_bf16=dyb, drop=self.drop(L["sites"][3], p))
-            self.lg_bwd(L["wo"], dyb, self.ws[f"e{i}_y"], self.ws[f"e{i}_u_wo"], gb, dyact, side=True, tile_cfg=_ENC_BWD_CFG[0], flush=False)
+            self.lg_bwd(L["wo"], dyb, self.ws[f"e{i}_y"], self.ws[f"e{i}_u_wo"], gb, dyact, side=True, tile_cfg=_ENC_BWD_CFG[0], flush=False,
+                        prefetch=self.enc_pf_bwd([L["wi"]], M))
             ops.gated_gelu_bwd(dyact, self.ws[f"e{i}_h"], dh, drop=self.drop(L["sites"][2], p))
-            self.lg_bwd(L["wi"], dh, self.ws[f"e{i}_xn2"], self.ws[f"e{i}_u_wi"], gb2, dxn, side=True, tile_cfg=_ENC_BWD_CFG[1])
+            self.lg_bwd(L["wi"], dh, self.ws[f"e{i}_xn2"], self.ws[f"e{i}_u_wi"], gb2, dxn, side=True, tile_cfg=_ENC_BWD_CFG[1],
+                        prefetch=self.enc_pf_bwd([L["o"]], M))
             if self.fuse_bwd_cast:
                 ops.rmsnorm_bwd(dxn, self.ws[f"e{i}_xm"], L["ln1"], c.t5_eps, other, dx_add=dx, out_bf16=dyb2, out_drop=self.drop(L["sites"][1], p))
             else:
@@ -1185,7 +1242,8 @@ class MrBlipEngine:
                               self.v4(dqkv, B, S, H, dk, 0), self.v4(dqkv, B, S, H, dk, inner), self.v4(dqkv, B, S, H, dk, 2 * inner),
                               scale=1.0, bias_lut=self.lut_enc, kmask=kmask, drop=self.drop(L["sites"][0], p),
                               drop_bits=self.ws.get(f"e{i}_dbits") if self.drop(L["sites"][0], p) is not None else None)
-            self.lg_bwd(L["qkv"], dqkv, self.ws[f"e{i}_xn"], self.ws[f"e{i}_u_qkv"], gb4, dxn, side=True, tile_cfg=_ENC_BWD_CFG[3])
+            self.lg_bwd(L["qkv"], dqkv, self.ws[f"e{i}_xn"], self.ws[f"e{i}_u_qkv"], gb4, dxn, side=True, tile_cfg=_ENC_BWD_CFG[3],
+                        prefetch=self.enc_pf_bwd([self.t5["enc"][i - 1]["wo"]], M) if i > 0 else None)
             if i > 0 and self.fuse_bwd_cast:   # ... and the layer below's first operand
                 ops.rmsnorm_bwd(dxn, self.ws[f"e{i}_xin"], L["ln0"], c.t5_eps, other, dx_add=dx, out_bf16=dyb_pair[(i - 1) & 1],
                                 out_drop=self.drop(self.t5["enc"][i - 1]["sites"][3], p))

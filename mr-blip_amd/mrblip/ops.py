@@ -78,6 +78,8 @@ _gated_bwd = _sig("mrblip_gated_gelu_bwd", vp, ll, vp, ll, vp, ll, i32, i32, vp,
 _ce = _sig("mrblip_cross_entropy", vp, ll, vp, i32, i32, f32, vp, vp, ll, vp)
 _adamw = _sig("mrblip_adamw", vp, vp, vp, vp, ll, vp, f32, f32, f32, f32, vp)
 _seed_bump = _sig("mrblip_seed_bump", vp, vp)
+_prefetch = _sig("mrblip_prefetch", vp, ll, i32, vp)
+_gemm_set_prefetch = _sig("mrblip_gemm_set_prefetch", vp, ll, i32)
 _lora_dx = _sig("mrblip_lora_dx_add", vp, ll, i32, vp, ll, vp, i32, i32, i32, vp, u32, f32, vp)
 _cu_reserve = _sig("mrblip_gemm_set_cu_reserve", i32)
 _lora_rows = _sig("mrblip_lora_rows", vp, ll, vp, ll, i32, i32, i32, vp, ll, vp, vp, u32, f32, vp)
@@ -96,7 +98,7 @@ EXPORTS = [
     "mrblip_layernorm_bwd", "mrblip_rmsnorm_bwd", "mrblip_rmsnorm_bwd_cast", "mrblip_attention_fwd", "mrblip_attention_fwd_rowv", "mrblip_attention_bwd", "mrblip_head_transpose",
     "mrblip_patchify", "mrblip_vit_assemble", "mrblip_row_copy", "mrblip_mean_pool", "mrblip_mean_pool_bwd",
     "mrblip_cast_dropout", "mrblip_gelu_bwd", "mrblip_gated_gelu_bwd", "mrblip_cross_entropy", "mrblip_adamw",
-    "mrblip_seed_bump", "mrblip_lora_dx_add", "mrblip_dropout_bf16", "mrblip_colsum", "mrblip_lora_pack", "mrblip_lora_tn",
+    "mrblip_seed_bump", "mrblip_prefetch", "mrblip_gemm_set_prefetch", "mrblip_lora_dx_add", "mrblip_dropout_bf16", "mrblip_colsum", "mrblip_lora_pack", "mrblip_lora_tn",
     "mrblip_lora_grads", "mrblip_gemm_lora_down", "mrblip_gemm_lora_dx", "mrblip_patchify_u8",
     "mrblip_gemm_set_cu_reserve", "mrblip_lora_rows", "mrblip_rmsnorm_lora_fwd", "mrblip_lora_rows_init", "mrblip_dec_proj", "mrblip_dec_proj_config", "mrblip_lora_dx_add_batched", "mrblip_lora_rows_batched", "mrblip_gemm_set_extra", "mrblip_attention_set_split_workspace",
     "mrblip_gemm_f16", "mrblip_layernorm_fwd_f16", "mrblip_attention_fwd_rowv_f16", "mrblip_patchify_f16", "mrblip_patchify_u8_f16",
@@ -526,6 +528,20 @@ def adamw(p, g, m, v, hyper, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0)
 
 def seed_bump(seed):
     _chk(_seed_bump(_p(seed), _stream()))
+
+
+def gemm_prefetch(t, n_blocks: int = 64, nbytes: int = None):
+    """The NEXT gemm() / lora_dx() launch of this thread also reads tensor t's bytes (contiguous; or its first nbytes) with n_blocks
+    extra workgroups and drops them: a later launch finds them in the memory-side cache.  Not a launch (no _chk count)."""
+    rc = _gemm_set_prefetch(_p(t), t.numel() * t.element_size() if nbytes is None else nbytes, n_blocks)
+    if rc != 0:
+        raise MrblipError(_lib.mrblip_last_error().decode())
+
+
+def prefetch(t, n_blocks: int = 32):
+    """Read tensor t's bytes (contiguous) on the current stream and drop them: the next launch finds them in the memory-side cache."""
+    assert t.is_contiguous()
+    _chk(_prefetch(_p(t), t.numel() * t.element_size(), n_blocks, _stream()))
 
 
 def lora_dx_add(dx, G, acat, drop: Optional[Dropout] = None):

@@ -1185,6 +1185,42 @@ def test_gemm_grouped_k_extension(ops):
         assert torch.equal(tall[j], ops.head_transpose(out[:, j * 2048:(j + 1) * 2048].unflatten(1, (H, 64)).unsqueeze(0))), j
 
 
+@pytest.mark.parametrize("cfg,gated,f32", [(4, False, True), (2, True, False), (8, False, False), (5, False, False), (1, False, True)])
+def test_gemm_prefetch_workgroups_change_no_result(ops, cfg, gated, f32):
+    """Round 4: a tile GEMM may start extra workgroups that stream a later launch's weights through the memory-side cache
+    (mrblip_gemm_set_prefetch).  They take the first block ids of the grid; the tiles behind them must produce the same bits, for
+    one-tile-per-block and persistent forms, any number of prefetch blocks (rounded up to 8), odd byte counts, and the hint must be
+    one-shot.  The stand-alone prefetch launch only reads."""
+    torch.manual_seed(36)
+    M, K, N = 1000, 512, 1536
+    rows = 2 * N if gated else N
+    a = bf(torch.randn(M, K, device=dev())); w = bf(torch.randn(rows, K, device=dev()) * 0.05)
+    u = bf(torch.randn(M, 64, device=dev())); wext = bf(torch.randn(rows, 64, device=dev()) * 0.05)
+    res = torch.randn(M, N, device=dev()) if f32 else None
+    far = bf(torch.randn(3 * 2**20 + 24, device=dev()))      # the "later launch's weights"
+    far0 = far.clone()
+
+    def run(pf=None):
+        out = torch.full((M, N), 7.0, dtype=torch.float32 if f32 else torch.bfloat16, device=dev())
+        h = torch.zeros(M, 2 * N, dtype=torch.bfloat16, device=dev()) if gated else None
+        if pf is not None:
+            ops.gemm_prefetch(far, n_blocks=pf[0], nbytes=pf[1])
+        ops.gemm(a, w, out, aext=u, wext=wext, residual=res, out2=h, gated=gated, tile_cfg=cfg)
+        return out, h
+    ref, href = run()
+    for pf in ((8, None), (3, None), (64, 2**20 + 16), (1024, None), (16, 32), (16, 0)):
+        out, h = run(pf)
+        assert torch.equal(out, ref), pf
+        assert href is None or torch.equal(h, href), pf
+    out, _ = run()                      # the hint above was consumed by its launch
+    assert torch.equal(out, ref)
+    ops.prefetch(far, 16)
+    torch.cuda.synchronize()
+    assert torch.equal(far, far0)
+    with pytest.raises(ops.MrblipError):
+        ops.gemm_prefetch(far, n_blocks=2000)
+
+
 @pytest.mark.parametrize("grid", [1, 5, 64, 0])
 def test_dec_proj_streaming_kernel_is_bit_identical_to_the_tile_kernel(ops, grid):
     """Round 4: for <= 16 rows mrblip_dec_proj runs as a streaming kernel (a block owns a range of 16-column tiles; rows and LoRA "down"

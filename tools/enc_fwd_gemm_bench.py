@@ -20,10 +20,18 @@ def timeit(fn, n=20):
     return s.elapsed_time(e) / n * 1e3
 
 
+CF = [int(c) for c in os.environ.get("CFGS", "").split(",") if c]
+COLD = int(os.environ.get("COLD", "0"))     # > 0: rotate through COLD weight sets (> the 256 MB Infinity Cache), as the step's 24 layers do
+
+
 def case(name, N, K, cfgs, gated=False, f32=False, tout=False):
     rows = 2 * N if gated else N
     a = bf(torch.randn(M, K, device=dev)); w = bf(torch.randn(rows, K, device=dev) * 0.03)
     u = bf(torch.randn(M, 64, device=dev)); wext = bf(torch.randn(rows, 64, device=dev) * 0.05)
+    if COLD:
+        nset = max(COLD, -(-640 * 2**20 // (rows * K * 2)))      # more than the Infinity Cache holds
+        ws = [w] + [w.clone() for _ in range(nset - 1)]; wes = [wext] + [wext.clone() for _ in range(nset - 1)]
+        state = [0]
     out = torch.empty(M, N, dtype=torch.float32 if f32 else torch.bfloat16, device=dev)
     res = torch.randn(M, N, device=dev) if f32 else None
     h = torch.empty(M, 2 * N, dtype=torch.bfloat16, device=dev) if gated else None
@@ -32,15 +40,22 @@ def case(name, N, K, cfgs, gated=False, f32=False, tout=False):
     line = f"{name:24s} N={N:5d} K={K:5d}:"
     for c in cfgs:
         try:
-            t = timeit(lambda: ops.gemm(a, w, out, aext=u, wext=wext, residual=res, out2=h, gated=gated, drop=drop, tile_cfg=c, tout=touts, t_rows=M))
+            def run():
+                if COLD:
+                    state[0] = (state[0] + 1) % nset
+                    ww, we = ws[state[0]], wes[state[0]]
+                else:
+                    ww, we = w, wext
+                ops.gemm(a, ww, out, aext=u, wext=we, residual=res, out2=h, gated=gated, drop=drop, tile_cfg=c, tout=touts, t_rows=M)
+            t = timeit(run, n=48 if COLD else 20)
             line += f"  cfg{c} {t:6.1f}us {2 * M * rows * K / t / 1e6:5.0f}TF"
         except Exception as e:
             line += f"  cfg{c} ERR({str(e)[:30]})"
     print(line, flush=True)
 
 
-case("qkv (bf16 + q/k/v^T)", 6144, 2048, [0, 8, 2, 4, 1, 11], tout=True)
-case("qkv (bf16, no copies)", 6144, 2048, [0, 8, 12, 2, 4, 1, 10, 11])
-case("o (fp32 residual)", 2048, 2048, [0, 4, 5, 2], f32=True)
-case("wi (gated)", 5120, 2048, [0, 2, 4, 8, 1, 7, 9], gated=True)
-case("wo (fp32 residual)", 2048, 5120, [0, 4, 5, 2], f32=True)
+case("qkv (bf16 + q/k/v^T)", 6144, 2048, CF or [0, 8, 2, 4, 1], tout=True)
+case("qkv (bf16, no copies)", 6144, 2048, CF or [0, 8, 12, 2, 4, 1])
+case("o (fp32 residual)", 2048, 2048, CF or [0, 4, 5, 2], f32=True)
+case("wi (gated)", 5120, 2048, CF or [0, 2, 4, 8, 1, 9], gated=True)
+case("wo (fp32 residual)", 2048, 5120, CF or [0, 4, 5, 2], f32=True)
