@@ -504,6 +504,17 @@ class MrBlipEngine:
                     ev = torch.cuda.Event()
                     ev.record()
                     kv_ready[i] = (kv, vt_i, ev)
+        # the query chain's GEMMs are 10-40 us each and every weight is touched once: each launch carries prefetch workgroups for the NEXT
+        # launch's weights (see enc_prefetch; stand-alone o 13.3 -> 11.2, fc2 37.9 -> 28.8 us on cold weights)
+        chain = []
+        for L in self.qf["layers"]:
+            chain += [L["self"]["qkv_w"], L["self"]["ow"]] + ([L["cross"]["q_w"], L["cross"]["ow"]] if L["cross"] is not None else []) + [L["iw"], L["ow"]]
+        nxt_w = {id(a): b for a, b in zip(chain, chain[1:])}
+
+        def pf(w):
+            n = nxt_w.get(id(w)) if self.qf_prefetch else None
+            if n is not None:
+                ops.gemm_prefetch(n, n_blocks=16 if n.numel() < 2**20 else 32)
         for i, L in enumerate(self.qf["layers"]):
             S_ = L["self"]
             qkv = self.buf(f"qf{i}_qkv", (Mq, 3 * D), bf16, zero=False)
@@ -512,14 +523,17 @@ class MrBlipEngine:
                 keep = want_t and i > 0   # (layer 0's self-attention has no backward: it only feeds the frozen query tokens)
                 qt_i = self.buf(f"qf{i}_qt_s", (F_, H, 64, ops.rup32(nq)), bf16) if keep else None
                 kt_i = self.buf(f"qf{i}_kt_s", (F_, H, 64, ops.rup32(nq)), bf16) if keep else None
+                pf(S_["qkv_w"])
                 ops.gemm(xb, S_["qkv_w"], qkv, bias=S_["qkv_b"], tout=(qt_i, kt_i, vt_s), t_rows=nq)
             else:
+                pf(S_["qkv_w"])
                 ops.gemm(xb, S_["qkv_w"], qkv, bias=S_["qkv_b"])
                 ops.head_transpose(v4, out=vt_s)
             o = self.buf(f"qf{i}_o", (Mq, pad64(D)), bf16)
             lse = self.buf(f"qf{i}_lse", (F_, H, ops.rup32(nq)), f32)
             ops.attention_fwd(q4, k4, vt_s, self.v4(o, F_, nq, H, hd), lse, scale=scale, drop=self.qdrop(S_["sites"][0], pdrop))
             y = self.buf(f"qf{i}_y", (Mq, D), f32, zero=False)
+            pf(S_["ow"])
             ops.gemm(o, S_["ow"], y, bias=S_["ob"], residual=x, drop=self.qdrop(S_["sites"][1], pdrop))
             x = self.buf(f"qf{i}_x1", (Mq, D), f32, zero=False)
             xb = self.buf(f"qf{i}_x1b", (Mq, pad64(D)), bf16)
@@ -527,6 +541,7 @@ class MrBlipEngine:
             if L["cross"] is not None:
                 C_ = L["cross"]
                 qc = self.buf(f"qf{i}_qc", (Mq, D), bf16, zero=False)
+                pf(C_["q_w"])
                 if t_ok and want_t:   # ... and the cross-attention's Q^T
                     ops.gemm(xb, C_["q_w"], qc, bias=C_["q_b"], tout=(self.buf(f"qf{i}_qt_c", (F_, H, 64, ops.rup32(nq)), bf16),), t_rows=nq)
                 else:
@@ -544,14 +559,17 @@ class MrBlipEngine:
                 lsec = self.buf(f"qf{i}_lsec", (F_, H, ops.rup32(nq)), f32)
                 ops.attention_fwd(self.v4(qc, F_, nq, H, hd), k4, vt_c, self.v4(oc, F_, nq, H, hd), lsec, scale=scale, drop=self.qdrop(C_["sites"][0], pdrop))
                 y2 = self.buf(f"qf{i}_y2", (Mq, D), f32, zero=False)
+                pf(C_["ow"])
                 ops.gemm(oc, C_["ow"], y2, bias=C_["ob"], residual=x, drop=self.qdrop(C_["sites"][1], pdrop))
                 x = self.buf(f"qf{i}_x2", (Mq, D), f32, zero=False)
                 xb = self.buf(f"qf{i}_x2b", (Mq, pad64(D)), bf16)
                 ops.layernorm_fwd(y2, C_["lnw"], C_["lnb"], eps, out_bf16=xb, out_f32=x)
             hact = self.buf(f"qf{i}_hact", (Mq, pad64(I)), bf16, zero=False)
             hpre = self.buf(f"qf{i}_hpre", (Mq, pad64(I)), bf16, zero=False)
+            pf(L["iw"])
             ops.gemm(xb, L["iw"], hact, bias=L["ib"], act=1, out2=hpre)
             y3 = self.buf(f"qf{i}_y3", (Mq, D), f32, zero=False)
+            pf(L["ow"])
             ops.gemm(hact, L["ow"], y3, bias=L["ob"], residual=x, drop=self.qdrop(L["site"], pdrop))
             x = self.buf(f"qf{i}_x3", (Mq, D), f32, zero=False)
             xb = self.buf(f"qf{i}_x3b", (Mq, pad64(D)), bf16)
@@ -921,6 +939,7 @@ class MrBlipEngine:
     # Round 4: the tile GEMMs that produce q / k / v (and the backward's dO) also write the head-transposed copies the attention kernels read
     # (csrc/gemm.hip GemmArgs.tout): no head_transpose launches in the T5 encoder and the Q-Former's self / query paths.  MRB_GEMM_TOUT=0
     # restores the transpose launches.
+    qf_prefetch = os.environ.get("MRB_QF_PREFETCH", "1") == "1"   # Q-Former forward: every GEMM carries the next one's weight prefetch
     qf_kv_side = os.environ.get("MRB_QF_KV_SIDE", "1") == "1"   # Q-Former cross K / V projections on the side stream beside the query chain
     gemm_tout_enabled = os.environ.get("MRB_GEMM_TOUT", "1") == "1"
 
@@ -1693,6 +1712,8 @@ class MrBlipEngine:
         ops.layernorm_fwd(xv, self.lnv_w, self.lnv_b, self.ln_vision_eps, out_bf16=img)
         qb = self.qformer_forward(img, F_)
         fr = self.buf("frames", (F_ * c.num_query, c.d_model), f32, zero=False)
+        if self.qf_prefetch and self.enc_prefetch and self.enc_prefetch[0] and fr.shape[0] >= 256:   # ... and t5_proj the first encoder layer's qkv weights
+            ops.gemm_prefetch(self.t5["enc"][0]["qkv"].W, n_blocks=32)
         ops.gemm(qb, self.proj_wb, fr, bias=self.proj_b)
         if c.mean_pool:
             pooled = self.buf("frames_pooled", (F_, c.d_model), f32, zero=False)

@@ -60,6 +60,40 @@ def case(name, N, K, gated=False, f32=False):
     print(line + " us", flush=True)
 
 
+def qcase(name, N, K, f32=False, act=0):
+    """Q-Former shapes (M = 60 x 32 query rows, d = 768): bias epilogues, no LoRA"""
+    Mq = 1920
+    nset = -(-640 * 2**20 // (N * K * 2))
+    a = bf(torch.randn(Mq, K, device=dev)); w0 = bf(torch.randn(N, K, device=dev) * 0.03)
+    ws = [w0] + [w0.clone() for _ in range(nset - 1)]
+    bias = torch.randn(N, device=dev)
+    out = torch.empty(Mq, N, dtype=torch.float32 if f32 else torch.bfloat16, device=dev)
+    res = torch.randn(Mq, N, device=dev) if f32 else None
+    pre = torch.empty(Mq, N, dtype=torch.bfloat16, device=dev) if act else None
+    drop = ops.Dropout(seed, 7, 0.1) if f32 else None
+
+    def loop(mode, nb=0, n=240):
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for rep in range(2):
+            if rep == 1: s.record()
+            for i in range(n):
+                w = ws[0] if mode == "warm" else ws[i % nset]
+                if mode == "grid": ops.gemm_prefetch(ws[(i + 1) % nset], nb)
+                ops.gemm(a, w, out, bias=bias, residual=res, drop=drop, act=act, out2=pre)
+        e.record(); torch.cuda.synchronize()
+        return s.elapsed_time(e) / n * 1e3
+    line = f"{name:20s} N={N:5d} K={K:5d} ({N * K * 2 / 2**20:5.1f} MB x {nset}):  warm {loop('warm'):6.1f}  cold {loop('cold'):6.1f}"
+    for nb in (8, 16, 32): line += f"  in-grid/{nb} {loop('grid', nb):6.1f}"
+    print(line + " us", flush=True)
+
+
+if os.environ.get("QF"):
+    qcase("qf qkv", 2304, 768)
+    qcase("qf o (res)", 768, 768, f32=True)
+    qcase("qf fc1 (gelu)", 3072, 768, act=1)
+    qcase("qf fc2 (res)", 768, 3072, f32=True)
+    sys.exit(0)
 ONLY = os.environ.get("ONLY", "")
 if not ONLY or ONLY == "qkv": case("qkv", 6144, 2048)
 if not ONLY or ONLY == "o": case("o (fp32 residual)", 2048, 2048, f32=True)
