@@ -148,9 +148,9 @@ int mrblip_seed_bump(uint32_t* seed, mrblip_stream_t stream);
 /* Reads [ptr, ptr + bytes) with n_blocks small workgroups and drops the data: pulls the next launch's weights into the memory-side cache
  * from a side stream.  No torch counterpart (the reference leaves weight residency to the caches); it changes no result. */
 /* The same from inside a GEMM launch: the calling thread's NEXT mrblip_gemm_bf16 / mrblip_gemm_lora_dx launch starts n_blocks extra
- * workgroups that read the range while the tiles compute (no side stream, no event).  One-shot; ignored by the tile forms that have
+ * workgroups that read the range (and a second one, ptr2 / bytes2, may be NULL / 0) while the tiles compute (no side stream, no event).  One-shot; ignored by the tile forms that have
  * no such role. */
-int mrblip_gemm_set_prefetch(const void* ptr, long long bytes, int n_blocks);
+int mrblip_gemm_set_prefetch(const void* ptr, long long bytes, const void* ptr2, long long bytes2, int n_blocks);
 int mrblip_prefetch(const void* ptr, long long bytes, int n_blocks, mrblip_stream_t stream);
 /* LoRA r=8 (peft 0.13.0 Linear; blip2_mr.py:182-200,236).  The rank-8 products themselves run on mrblip_gemm_bf16
  * (u = drop(x) Acat^T, g = dy Bblk^T, dBt += u^T dy, dA += g^T drop(x) on transposed copies); these are the side pieces:

@@ -66,7 +66,7 @@ struct GemmArgs {
   // round 4, generic tile kernel: the FIRST pf_blocks workgroups of the grid (a multiple of 8: the tiles keep their XCD) do not compute;
   // they read [pf_ptr, pf_ptr + 16 pf_n16) and drop it — the weights of a LATER launch, pulled into the memory-side cache while this
   // one computes (mrblip_gemm_set_prefetch)
-  const void* pf_ptr; long long pf_n16; int pf_blocks;
+  const void* pf_ptr; long long pf_n16; const void* pf_ptr2; long long pf_n16_2; int pf_blocks;   // (a second, usually small range: the LoRA K-extension operand)
 };
 
 // v0..v3: 4 consecutive columns n0..n0+3 of row m (raw accumulator). Applies bias -> (pre-activation copy) -> GELU -> dropout -> residual.
@@ -270,6 +270,8 @@ __global__ __launch_bounds__(WGM* WGN * 64, gemm_min_blocks(NS * (BM + BN) * BK 
       keep |= a[0] ^ b[1] ^ c[2] ^ d[3];
     }
     for (; i < p.pf_n16; i += step) keep |= q[i][0];
+    const mrb_u32x4* __restrict__ q2 = reinterpret_cast<const mrb_u32x4*>(p.pf_ptr2);
+    for (i = (long long)blockIdx.x * (NW * 64) + threadIdx.x; i < p.pf_n16_2; i += step) keep |= q2[i][1];
     asm volatile("" ::"v"(keep));   // the loads stay, no store
     return;
   }
@@ -1582,7 +1584,7 @@ static int launch_tile(GemmArgs& a, hipStream_t st) {
   // dispatch of 2 blocks/CU measured slightly faster than a static persistent walk).
   const int ntiles = a.tiles_m * a.tiles_n;
   const int grid = (NS == 2 && LDS > 80 * 1024 && ntiles > num_cu) ? num_cu : ntiles;
-  a.pf_blocks = (a.pf_ptr && a.pf_n16 > 0) ? (a.pf_blocks + 7) / 8 * 8 : 0;
+  a.pf_blocks = (a.pf_n16 > 0 || a.pf_n16_2 > 0) ? (a.pf_blocks + 7) / 8 * 8 : 0;
   hipLaunchKernelGGL(kern, dim3(grid + a.pf_blocks), dim3(WGM * WGN * 64), LDS, st, a);
   return mrblip_check_launch("gemm_tile");
 }
@@ -1622,11 +1624,12 @@ extern "C" int mrblip_gemm_set_extra(void* tout0, void* tout1, void* tout2, int 
 
 // one-shot, like the extras: the calling thread's NEXT GEMM launch also streams [ptr, ptr + bytes) through the memory-side cache with
 // n_blocks extra workgroups (generic tile kernels; the other forms ignore it — it is a hint and changes no result)
-struct GemmPrefetch { const void* ptr; long long bytes; int n_blocks; };
+struct GemmPrefetch { const void* ptr; long long bytes; const void* ptr2; long long bytes2; int n_blocks; };
 static thread_local GemmPrefetch g_gemm_prefetch = {};
-extern "C" int mrblip_gemm_set_prefetch(const void* ptr, long long bytes, int n_blocks) {
-  MRB_REQUIRE(bytes >= 0 && ((uintptr_t)ptr % 16) == 0 && n_blocks >= 0 && n_blocks <= 1024, "gemm_set_prefetch: 16-byte aligned range, at most 1024 blocks");
-  g_gemm_prefetch = GemmPrefetch{ptr, bytes, n_blocks};
+extern "C" int mrblip_gemm_set_prefetch(const void* ptr, long long bytes, const void* ptr2, long long bytes2, int n_blocks) {
+  MRB_REQUIRE(bytes >= 0 && bytes2 >= 0 && ((uintptr_t)ptr % 16) == 0 && ((uintptr_t)ptr2 % 16) == 0 && n_blocks >= 0 && n_blocks <= 1024,
+              "gemm_set_prefetch: 16-byte aligned ranges, at most 1024 blocks");
+  g_gemm_prefetch = GemmPrefetch{ptr, ptr ? bytes : 0, ptr2, ptr2 ? bytes2 : 0, n_blocks};
   return MRBLIP_OK;
 }
 
@@ -1657,7 +1660,7 @@ static int gemm_dispatch(const void* A, long long lda, const void* W, long long 
   a.t_inner = extra.set ? extra.t_inner : 0; a.t_rows = extra.t_rows; a.t_spad = extra.t_spad; a.t_bs = extra.t_bs; a.t_hs = extra.t_hs;
   a.t_stride = extra.t_stride; a.t_count = extra.set ? extra.t_count : 0;
   a.ext_group_n = extra.set ? extra.ext_group_n : 0;
-  a.pf_ptr = pf.n_blocks > 0 ? pf.ptr : nullptr; a.pf_n16 = pf.bytes / 16; a.pf_blocks = pf.n_blocks;
+  a.pf_ptr = pf.ptr; a.pf_n16 = pf.bytes / 16; a.pf_ptr2 = pf.ptr2; a.pf_n16_2 = pf.bytes2 / 16; a.pf_blocks = pf.n_blocks;
   const bool has_extra = a.t_inner > 0 || a.ext_group_n > 0;
   MRB_REQUIRE(a.t_inner == 0 || (!out_f32 && !gated && act == 0 && !(p_drop > 0.f) && !residual && !out2 && (M == a.t_rows || (a.t_rows % 32) == 0) && (M % a.t_rows) == 0),
               "gemm: head-transposed copies need a bf16 output with a plain / bias epilogue and one clip or t_rows %% 32 == 0");

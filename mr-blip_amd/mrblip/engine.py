@@ -877,6 +877,7 @@ class MrBlipEngine:
     # on cold weights than on a re-used set (tools/prefetch_bench.py).  The qkv GEMM of an encoder layer starts extra workgroups that read
     # the o and wi weights, the wi GEMM the wo weights and the next layer's qkv weights (csrc/gemm.hip pf_blocks).  MRB_ENC_PREFETCH=0: off.
     enc_prefetch = tuple(int(x) for x in (os.environ.get("MRB_ENC_PREFETCH", "32,128,32") + ",,").split(",")[:3] if x)   # workgroups per host launch (qkv, o, wi; 0: none)
+    enc_prefetch_ext = os.environ.get("MRB_ENC_PREFETCH_EXT", "0") == "1"   # (measured: no difference)
     enc_pf_plan = int(os.environ.get("MRB_ENC_PF_PLAN", "1"))   # which launch carries which range (see t5_encoder_forward)
     enc_prefetch_min_rows = int(os.environ.get("MRB_ENC_PREFETCH_MIN_ROWS", "1024"))   # a shorter host launch ends before its prefetch does
 
@@ -886,7 +887,9 @@ class MrBlipEngine:
         if not nb or M < self.enc_prefetch_min_rows or not groups:
             return None
         a, b = groups[0].w_off, groups[-1].w_off + groups[-1].W.numel()
-        return (self.enc_w_arena[a:b], (b - a) * 2, nb)
+        # (second range: the groups' LoRA "up" operands — the K extension's W side, adjacent rows of wext_all)
+        e0, e1 = groups[0].wext.storage_offset(), groups[-1].wext.storage_offset() + groups[-1].wext.numel()
+        return (self.enc_w_arena[a:b], (b - a) * 2, nb, self.wext_all.view(-1)[e0:e1] if self.enc_prefetch_ext else None)
 
     enc_bwd_prefetch = int(os.environ.get("MRB_ENC_BWD_PREFETCH", "0"))   # the same for the backward's dX GEMMs (transposed weights)
 
@@ -925,7 +928,7 @@ class MrBlipEngine:
         if not u_ready:
             self.lora_thin(x, g.acat, u, g.K, drop=self.drop(g.site, self.cfg.lora_dropout))
         if pf is not None:
-            ops.gemm_prefetch(pf[0], n_blocks=pf[2], nbytes=pf[1])
+            ops.gemm_prefetch(pf[0], n_blocks=pf[2], nbytes=pf[1], t2=pf[3] if len(pf) > 3 else None)
         if tout is not None and out.dtype == bf16 and not kw.get("gated") and x.shape[0] > 64 and self.gemm_tout_enabled:
             ops.gemm(x, g.W, out, aext=u, wext=g.wext, tout=tout, t_rows=t_rows, **kw)   # tile GEMM: head-transposed copies from its epilogue
             return True

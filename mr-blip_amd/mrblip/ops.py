@@ -79,7 +79,7 @@ _ce = _sig("mrblip_cross_entropy", vp, ll, vp, i32, i32, f32, vp, vp, ll, vp)
 _adamw = _sig("mrblip_adamw", vp, vp, vp, vp, ll, vp, f32, f32, f32, f32, vp)
 _seed_bump = _sig("mrblip_seed_bump", vp, vp)
 _prefetch = _sig("mrblip_prefetch", vp, ll, i32, vp)
-_gemm_set_prefetch = _sig("mrblip_gemm_set_prefetch", vp, ll, i32)
+_gemm_set_prefetch = _sig("mrblip_gemm_set_prefetch", vp, ll, vp, ll, i32)
 _lora_dx = _sig("mrblip_lora_dx_add", vp, ll, i32, vp, ll, vp, i32, i32, i32, vp, u32, f32, vp)
 _cu_reserve = _sig("mrblip_gemm_set_cu_reserve", i32)
 _lora_rows = _sig("mrblip_lora_rows", vp, ll, vp, ll, i32, i32, i32, vp, ll, vp, vp, u32, f32, vp)
@@ -530,10 +530,11 @@ def seed_bump(seed):
     _chk(_seed_bump(_p(seed), _stream()))
 
 
-def gemm_prefetch(t, n_blocks: int = 64, nbytes: int = None):
+def gemm_prefetch(t, n_blocks: int = 64, nbytes: int = None, t2=None):
     """The NEXT gemm() / lora_dx() launch of this thread also reads tensor t's bytes (contiguous; or its first nbytes) with n_blocks
     extra workgroups and drops them: a later launch finds them in the memory-side cache.  Not a launch (no _chk count)."""
-    rc = _gemm_set_prefetch(_p(t), t.numel() * t.element_size() if nbytes is None else nbytes, n_blocks)
+    rc = _gemm_set_prefetch(_p(t), t.numel() * t.element_size() if nbytes is None else nbytes,
+                            _p(t2) if t2 is not None else None, t2.numel() * t2.element_size() if t2 is not None else 0, n_blocks)
     if rc != 0:
         raise MrblipError(_lib.mrblip_last_error().decode())
 

@@ -1204,7 +1204,7 @@ def test_gemm_prefetch_workgroups_change_no_result(ops, cfg, gated, f32):
         out = torch.full((M, N), 7.0, dtype=torch.float32 if f32 else torch.bfloat16, device=dev())
         h = torch.zeros(M, 2 * N, dtype=torch.bfloat16, device=dev()) if gated else None
         if pf is not None:
-            ops.gemm_prefetch(far, n_blocks=pf[0], nbytes=pf[1])
+            ops.gemm_prefetch(far, n_blocks=pf[0], nbytes=pf[1], t2=far[4096:4096 + 100 * 1024] if pf[0] == 64 else None)   # (a second range once)
         ops.gemm(a, w, out, aext=u, wext=wext, residual=res, out2=h, gated=gated, tile_cfg=cfg)
         return out, h
     ref, href = run()
