@@ -151,6 +151,13 @@ int mrblip_seed_bump(uint32_t* seed, mrblip_stream_t stream);
  * workgroups that read the range (and a second one, ptr2 / bytes2, may be NULL / 0) while the tiles compute (no side stream, no event).  One-shot; ignored by the tile forms that have
  * no such role. */
 int mrblip_gemm_set_prefetch(const void* ptr, long long bytes, const void* ptr2, long long bytes2, int n_blocks);
+/* One-shot: the calling thread's NEXT mrblip_gemm_bf16 launch (generic tile kernel, M > 64, K extension read last) computes its own
+ * K-extension operand Aext[m, 0:R] = dropout(A)[m, 0:K] acat^T — what mrblip_lora_rows would have written in a launch of its own (peft
+ * lora_A(lora_dropout(x)), same bits) — in its first workgroups while the tiles already run; the tiles wait for flags[m / 16] == epoch before
+ * they read those rows.  flags: >= ceil(M / 16) words shared by the launches of ONE stream; epoch: a value no earlier launch left there.
+ * The mask uses the GEMM call's seed pointer with call-site id `site`. */
+int mrblip_gemm_set_thin(const void* acat, long long lda, int R, int K, uint32_t site, float p_drop, uint32_t* flags, long long n_flags,
+                         uint32_t epoch);
 int mrblip_prefetch(const void* ptr, long long bytes, int n_blocks, mrblip_stream_t stream);
 /* LoRA r=8 (peft 0.13.0 Linear; blip2_mr.py:182-200,236).  The rank-8 products themselves run on mrblip_gemm_bf16
  * (u = drop(x) Acat^T, g = dy Bblk^T, dBt += u^T dy, dA += g^T drop(x) on transposed copies); these are the side pieces:

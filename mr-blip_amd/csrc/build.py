@@ -12,7 +12,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRCS = ["errors.hip", "gemm.hip", "norm.hip", "attention.hip", "elementwise.hip", "lora.hip", "decproj.hip"]
-HDRS = ["common.h"]
+HDRS = ["common.h", "lora_thin.h"]
 LIB = os.path.join(HERE, "libmrblip_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast"] + os.environ.get("MRB_EXTRA_HIPCC_FLAGS", "").split()

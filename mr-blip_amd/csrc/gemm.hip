@@ -13,6 +13,7 @@
 // (A-operand = W tile, B-operand = X tile) so each lane owns one output row and 4 consecutive columns per
 // accumulator group -> 16-B (fp32) / 8-B (bf16) row-major stores.
 #include "common.h"
+#include "lora_thin.h"
 #include <type_traits>
 // TILE_PIPE (experiment, off): 1 = fragments of k-step kk+1 requested before the MFMAs of kk AND the next stage's LDS-DMA pieces spread over
 // the k-steps (64x128 tile, K = 10240: 129.7 us against 107.3 us — pieces issued later land later, the 2-stage ring waits for them);
@@ -66,6 +67,11 @@ struct GemmArgs {
   // round 4, generic tile kernel: the FIRST pf_blocks workgroups of the grid (a multiple of 8: the tiles keep their XCD) do not compute;
   // they read [pf_ptr, pf_ptr + 16 pf_n16) and drop it — the weights of a LATER launch, pulled into the memory-side cache while this
   // one computes (mrblip_gemm_set_prefetch)
+  // thin role (round 4, generic tile kernel; mrblip_gemm_set_thin): the th_blocks workgroups behind the prefetch ones compute the K
+  // extension's A operand themselves — Aext[m, 0:th_R] = dropout(A)[m, 0:th_K] th_A^T, the LoRA "down" product (body: lora_thin.h), 16
+  // rows each — write it with write-through stores and set th_flags[row block] = th_epoch; a tile waits for the flags of its rows before
+  // it stages the K extension (its LAST K-tile) and reads Aext past its XCD's L2
+  const bf16_t* th_A; long long th_lda; int th_R, th_K; DropoutArg th_drop; uint32_t* th_flags; uint32_t th_epoch; int th_blocks;
   const void* pf_ptr; long long pf_n16; const void* pf_ptr2; long long pf_n16_2; int pf_blocks;   // (a second, usually small range: the LoRA K-extension operand)
 };
 
@@ -222,14 +228,15 @@ __device__ __forceinline__ void gemm_stage_dma(char* dstA, char* dstW, const voi
 }
 // (same body under a second name: two call sites of ONE function get merged into a call with selected array pointers, which sends
 // the offset arrays through scratch memory)
-template <int CA, int CW, int NW_, int PIECE_BYTES, int PARTS = 1, int PART = 0>
+// AUX_A: cache-policy bits of the A pieces (16 = sc1: agent-scope read past the XCD's L2 — the thin role of another XCD wrote them)
+template <int CA, int CW, int NW_, int PIECE_BYTES, int PARTS = 1, int PART = 0, int AUX_A = 0>
 __device__ __forceinline__ void gemm_stage_dma_ext(char* dstA, char* dstW, const void* pa, uint32_t bytes_a, const void* pw, uint32_t bytes_w,
                                                const uint32_t* va, const uint32_t* vw, int w, uint32_t koff) {
   const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(pa), 0, (int)bytes_a, 0x00020000);
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(pw), 0, (int)bytes_w, 0x00020000);
 #pragma unroll
   for (int j = 0; j < CA; ++j)
-    if (j % PARTS == PART) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr_t)(dstA + (j * NW_ + w) * PIECE_BYTES), 16, va[j], koff, 0, 0);
+    if (j % PARTS == PART) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr_t)(dstA + (j * NW_ + w) * PIECE_BYTES), 16, va[j], koff, 0, AUX_A);
 #pragma unroll
   for (int j = 0; j < CW; ++j)
     if ((CA + j) % PARTS == PART) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(dstW + (j * NW_ + w) * PIECE_BYTES), 16, vw[j], koff, 0, 0);
@@ -278,6 +285,21 @@ __global__ __launch_bounds__(WGM* WGN * 64, gemm_min_blocks(NS * (BM + BN) * BK 
 
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int thb = p.th_blocks;   // uniform
+  if (thb > 0 && (int)blockIdx.x - pfb < thb) {   // thin role: 16 rows of the K extension's A operand (see GemmArgs)
+    const int rb = (int)blockIdx.x - pfb;
+    if (rb * 16 < p.M) {
+      ThinArgs t;
+      t.X = p.A; t.ldx = p.lda; t.A = p.th_A; t.lda = p.th_lda; t.U = const_cast<bf16_t*>(p.Aext); t.ldu = p.ldaext;
+      t.M = p.M; t.K = p.th_K; t.R = p.th_R;
+      t.seed_ptr = p.th_drop.seed_ptr; t.site = p.th_drop.site; t.thresh16 = p.th_drop.thresh24; t.inv_keep = p.th_drop.inv_keep;
+      if (p.th_R <= 16) lora_thin_body<1, 8, 16, NW, true>(t, rb * 16, reinterpret_cast<f32x4(*)[1][64]>(smem), w, lane, []() {});
+      else lora_thin_body<2, 4, 16, NW, true>(t, rb * 16, reinterpret_cast<f32x4(*)[2][64]>(smem), w, lane, []() {});
+      __syncthreads();   // the storing waves have drained their write-through stores
+      if (threadIdx.x == 0) __hip_atomic_store(p.th_flags + rb, p.th_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return;
+  }
   const int wm = w / WGN, wn = w % WGN;
   const int hi = lane >> 5, l31 = lane & 31;
 
@@ -336,14 +358,26 @@ __global__ __launch_bounds__(WGM* WGN * 64, gemm_min_blocks(NS * (BM + BN) * BK 
       gemm_stage_dma<JA, JW, NW, RPI * RB, PARTS, PART>(base, base + A_BYTES, p.A, (uint32_t)((long long)p.M * p.lda * 2), p.W,
                                                         (uint32_t)((long long)p.N * p.ldw * 2), vpa, vpw, w, koff);
     } else {
+      if (p.th_flags && kt == nk_main) {   // uniform: the tile's rows of Aext come from this launch's thin role — wait for their flags
+        const int rbk = ((bm * BM) >> 4) + lane;
+        if (lane < BM / 16 && rbk * 16 < p.M) {
+          uint32_t tries = 0;   // (bounded: a protocol error must show as a wrong result in the tests, not as a hung GPU)
+          while (__hip_atomic_load(p.th_flags + rbk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.th_epoch && ++tries < (1u << 17)) __builtin_amdgcn_s_sleep(4);
+        }
+        asm volatile("" ::: "memory");
+      }
       uint32_t ea[JA], ew[JW];
       const uint32_t egrp = p.ext_group_n ? (uint32_t)((bn * BNO) / p.ext_group_n) * 128u : 0u;   // this tile's 64-column slot of Aext
 #pragma unroll
       for (int j = 0; j < JA; ++j) ea[j] = vAe + egrp + (uint32_t)((long long)(bm * BM + (j * NW + w) * RPI) * p.ldaext * 2);
 #pragma unroll
       for (int j = 0; j < JW; ++j) ew[j] = vWe + (uint32_t)((long long)w_row_base(j) * p.ldwext * 2);
-      gemm_stage_dma_ext<JA, JW, NW, RPI * RB, PARTS, PART>(base, base + A_BYTES, p.Aext, (uint32_t)((long long)p.M * p.ldaext * 2), p.Wext,
-                                                            (uint32_t)((long long)p.N * p.ldwext * 2), ea, ew, w, (uint32_t)(kt - nk_main) * (uint32_t)RB);
+      if (p.th_flags)
+        gemm_stage_dma_ext<JA, JW, NW, RPI * RB, PARTS, PART, 16>(base, base + A_BYTES, p.Aext, (uint32_t)((long long)p.M * p.ldaext * 2), p.Wext,
+                                                                  (uint32_t)((long long)p.N * p.ldwext * 2), ea, ew, w, (uint32_t)(kt - nk_main) * (uint32_t)RB);
+      else
+        gemm_stage_dma_ext<JA, JW, NW, RPI * RB, PARTS, PART>(base, base + A_BYTES, p.Aext, (uint32_t)((long long)p.M * p.ldaext * 2), p.Wext,
+                                                              (uint32_t)((long long)p.N * p.ldwext * 2), ea, ew, w, (uint32_t)(kt - nk_main) * (uint32_t)RB);
     }
   };
   auto stage = [&](int kt, int buf) __attribute__((always_inline)) { stage_part(kt, buf, std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}); };
@@ -395,7 +429,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, gemm_min_blocks(NS * (BM + BN) * BK 
 #endif
   // ---- persistent tile loop: grid = resident blocks; a block's epilogue stores drain while it already stages the next tile
   const int ntiles = p.tiles_m * p.tiles_n;
-  for (int tile = (int)blockIdx.x - pfb; tile < ntiles; tile += (int)gridDim.x - pfb) {
+  for (int tile = (int)blockIdx.x - pfb - thb; tile < ntiles; tile += (int)gridDim.x - pfb - thb) {
   {  // tile id -> (bm, bn): XCD-contiguous remap (bijective), then grouped ordering for L2 reuse of the W panel
     int bid = tile;
     const int q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, idx = bid >> 3;
@@ -1585,7 +1619,9 @@ static int launch_tile(GemmArgs& a, hipStream_t st) {
   const int ntiles = a.tiles_m * a.tiles_n;
   const int grid = (NS == 2 && LDS > 80 * 1024 && ntiles > num_cu) ? num_cu : ntiles;
   a.pf_blocks = (a.pf_n16 > 0 || a.pf_n16_2 > 0) ? (a.pf_blocks + 7) / 8 * 8 : 0;
-  hipLaunchKernelGGL(kern, dim3(grid + a.pf_blocks), dim3(WGM * WGN * 64), LDS, st, a);
+  a.th_blocks = a.th_flags ? ((a.M + 15) / 16 + 7) / 8 * 8 : 0;
+  static_assert(LDS >= THIN_RED_BYTES(2), "the thin role's partial sums live in the tile's LDS");
+  hipLaunchKernelGGL(kern, dim3(grid + a.pf_blocks + a.th_blocks), dim3(WGM * WGN * 64), LDS, st, a);
   return mrblip_check_launch("gemm_tile");
 }
 
@@ -1633,6 +1669,18 @@ extern "C" int mrblip_gemm_set_prefetch(const void* ptr, long long bytes, const 
   return MRBLIP_OK;
 }
 
+// one-shot: the calling thread's NEXT GEMM launch computes its own K-extension operand Aext = dropout(A) acat^T (see GemmArgs.th_*).
+// flags: >= ceil(M / 16) words the launches of ONE stream may share; epoch: a value no earlier launch on that stream left in them.
+struct GemmThin { const void* acat; long long lda; int R, K; uint32_t site; float p; uint32_t* flags; long long n_flags; uint32_t epoch; bool set; };
+static thread_local GemmThin g_gemm_thin = {};
+extern "C" int mrblip_gemm_set_thin(const void* acat, long long lda, int R, int K, uint32_t site, float p_drop, uint32_t* flags, long long n_flags,
+                                    uint32_t epoch) {
+  MRB_REQUIRE(acat && flags && ((uintptr_t)acat % 16) == 0 && R > 0 && R <= 32 && (R % 8) == 0 && K > 0 && (K % 32) == 0 && (lda % 8) == 0 && lda >= K,
+              "gemm_set_thin: acat [R <= 32, K %% 32 == 0] with 16-B rows and a flag buffer");
+  g_gemm_thin = GemmThin{acat, lda, R, K, site, p_drop, flags, n_flags, epoch, true};
+  return MRBLIP_OK;
+}
+
 static int gemm_dispatch(const void* A, long long lda, const void* W, long long ldw, const void* Aext, long long ldaext,
                          const void* Wext, long long ldwext, int M, int N, int K, void* out, long long ldo, int out_f32,
                          void* out2, long long ldo2, const float* bias, const float* residual, long long ldr, int act,
@@ -1643,6 +1691,8 @@ static int gemm_dispatch(const void* A, long long lda, const void* W, long long 
   g_gemm_extra = GemmExtra{};
   const GemmPrefetch pf = g_gemm_prefetch;
   g_gemm_prefetch = GemmPrefetch{};
+  const GemmThin th = g_gemm_thin;
+  g_gemm_thin = GemmThin{};
   MRB_REQUIRE(M > 0 && N > 0 && K >= 0 && (K % 64) == 0, "gemm: need M,N>0 and K%%64==0 (M=%d N=%d K=%d)", M, N, K);
   MRB_REQUIRE(K > 0 || Aext, "gemm: empty contraction");
   MRB_REQUIRE((N % 8) == 0, "gemm: N %% 8 != 0 (N=%d)", N);
@@ -1660,6 +1710,15 @@ static int gemm_dispatch(const void* A, long long lda, const void* W, long long 
   a.t_inner = extra.set ? extra.t_inner : 0; a.t_rows = extra.t_rows; a.t_spad = extra.t_spad; a.t_bs = extra.t_bs; a.t_hs = extra.t_hs;
   a.t_stride = extra.t_stride; a.t_count = extra.set ? extra.t_count : 0;
   a.ext_group_n = extra.set ? extra.ext_group_n : 0;
+  a.th_flags = nullptr; a.th_blocks = 0; a.th_A = nullptr; a.th_lda = 0; a.th_R = a.th_K = 0; a.th_epoch = 0;
+  mk_drop_arg(a.th_drop, seed_ptr, 0, 0.f);
+  if (th.set) {
+    MRB_REQUIRE(Aext && !ext_first && !f16 && M > 64 && th.K <= K && ldaext >= th.R && (ldaext % 4) == 0 && ((uintptr_t)Aext % 8) == 0 && th.n_flags >= (M + 15) / 16 &&
+                    (long long)M * lda * 2 < (1ll << 31) && !(th.p > 0.f && !seed_ptr),
+                "gemm: the thin role needs a K extension read last, more than 64 rows and one flag per 16 rows");
+    a.th_A = (const bf16_t*)th.acat; a.th_lda = th.lda; a.th_R = th.R; a.th_K = th.K; a.th_flags = th.flags; a.th_epoch = th.epoch;
+    mk_drop_arg(a.th_drop, seed_ptr, th.site, th.p);
+  }
   a.pf_ptr = pf.ptr; a.pf_n16 = pf.bytes / 16; a.pf_ptr2 = pf.ptr2; a.pf_n16_2 = pf.bytes2 / 16; a.pf_blocks = pf.n_blocks;
   const bool has_extra = a.t_inner > 0 || a.ext_group_n > 0;
   MRB_REQUIRE(a.t_inner == 0 || (!out_f32 && !gated && act == 0 && !(p_drop > 0.f) && !residual && !out2 && (M == a.t_rows || (a.t_rows % 32) == 0) && (M % a.t_rows) == 0),
@@ -1734,6 +1793,7 @@ static int gemm_dispatch(const void* A, long long lda, const void* W, long long 
     MRB_REQUIRE(cfg == 1 || cfg == 2 || cfg == 4 || cfg == 7 || cfg == 8 || cfg == 9 || cfg == 11 || (cfg >= 18 && cfg <= 21) || (a.t_inner == 0 && (cfg == 5 || cfg == 10 || cfg == 12)),
                 "gemm: head-transposed copies / grouped K extension are not available in tile config %d", cfg);
   }
+  MRB_REQUIRE(!a.th_flags || !(cfg == 3 || (cfg >= 13 && cfg <= 17)), "gemm: the thin role lives in the generic tile kernel (tile config %d has none)", cfg);
   if (cfg == 3) {
     MRB_REQUIRE(!gated, "gemm: skinny kernel has no gated epilogue");
     // rows of the tall operand per block: 32, fewer when the grid would leave most CUs idle (LoRA down / g products at M = 2012)

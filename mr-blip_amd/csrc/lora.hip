@@ -12,6 +12,7 @@
 // rmsnorm_lora_fwd additionally fuses T5LayerNorm (modeling_t5.py:254-277): the normalised row is still in registers when its LoRA
 // projection is taken, so `xn` and `u` of the norm-fed projections (q/k/v, wi_0/wi_1, EncDecAttention.q) cost one launch.
 #include "common.h"
+#include "lora_thin.h"
 #include <stdlib.h>
 
 extern "C" int mrblip_rmsnorm_fwd(const float* x, long long ldx, const float* weight, int M, int D, float eps, void* out_bf16,
@@ -176,99 +177,33 @@ static int lora_num_cu() {
 // contiguous bytes per instruction; A: the same lane map over r — A is 32..96 KB and L2 resident) — nothing is staged in LDS, every x
 // byte is fetched once, the structural zeros of a block-diagonal A cost nothing extra, and 8 x 8 KB are in flight per CU.  The 8
 // partial accumulators meet in LDS at the end (fixed order: deterministic).  Same dropout mask, same result up to fp32 summation order.
-typedef uint32_t lora_u32x4 __attribute__((ext_vector_type(4)));
 #define LORA_THIN_MIN_M 512
 
 template <int NT, int UB, int ROWS>  // NT = 16-wide r tiles (R <= 16 * NT), UB = k-steps per batch, ROWS = rows per block: 16, or 8 (the MFMA's
                                      // other 8 rows idle, their lanes load nothing) when 16-row blocks would leave half of the CUs without one
-__global__ __launch_bounds__(512) void lora_thin_kernel(const LoraRowsArgs p) {
+__global__ __launch_bounds__(512) void lora_thin_kernel(const LoraRowsArgs p) {   // body: lora_thin.h (shared with the tile GEMM's thin role)
   __shared__ f32x4 red[8][NT][64];
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int l15 = lane & 15, kg = lane >> 4;
-  const int m0 = blockIdx.x * ROWS, row = m0 + l15;
-  const bool row_ok = l15 < ROWS && row < p.M;
-  const bool has_drop = p.drop.seed_ptr != nullptr;
-  const uint32_t seed = has_drop ? mrb_seed_load(p.drop.seed_ptr) : 0u;
+  const int m0 = blockIdx.x * ROWS;
   const int grp = blockIdx.y;                              // batched form: this block's group (0 otherwise)
-  const uint32_t site = p.drop.site + (uint32_t)grp * p.site_stride;
-  bf16_t* const Ug = p.U + grp * p.u_gstride;
-  // bounds-checked operands: rows >= M of X and rows >= R of A lie beyond the last byte of their resource and read as zero
-  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.X + grp * p.x_gstride), 0, (int)((((long long)p.M - 1) * p.ldx + p.K) * 2), 0x00020000);
-  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.A + grp * p.a_gstride), 0, (int)((((long long)p.R - 1) * p.lda + p.K) * 2), 0x00020000);
-  const uint32_t xoff = (uint32_t)(((long long)row * p.ldx + kg * 8) * 2);
-  uint32_t aoff[NT];
+  ThinArgs t;
+  t.X = p.X + grp * p.x_gstride; t.ldx = p.ldx; t.A = p.A + grp * p.a_gstride; t.lda = p.lda; t.U = p.U + grp * p.u_gstride; t.ldu = p.ldu;
+  t.M = p.M; t.K = p.K; t.R = p.R;
+  t.seed_ptr = p.drop.seed_ptr; t.site = p.drop.site + (uint32_t)grp * p.site_stride; t.thresh16 = p.drop.thresh24; t.inv_keep = p.drop.inv_keep;
+  lora_thin_body<NT, UB, ROWS, 8, false>(t, m0, red, w, lane, [&]() __attribute__((always_inline)) {
+    // side job (see LoraRowsArgs): the block's fp32 init rows, ROWS / 8 rows per wave
+    if (p.init_dst) {
 #pragma unroll
-  for (int t = 0; t < NT; ++t) aoff[t] = (uint32_t)(((long long)(t * 16 + l15) * p.lda + kg * 8) * 2);
-  const int nks = p.K >> 5;                       // k-steps of 32 (the launcher guarantees K % 32 == 0)
-  const int per = (nks + 7) >> 3;
-  const int ks0 = w * per, ks1 = min(nks, ks0 + per);
-  f32x4 acc[NT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  lora_u32x4 xf[2][UB], af[2][UB][NT];
-  auto fetch = [&](int buf, int ks) {
-#pragma unroll
-    for (int u = 0; u < UB; ++u) {
-      const bool k_ok = ks + u < ks1;               // past the wave's share: an out-of-range offset -> zeros, no memory traffic
-      const uint32_t kb = (uint32_t)(ks + u) * 64u;
-      xf[buf][u] = __builtin_amdgcn_raw_buffer_load_b128(rx, (k_ok && row_ok) ? xoff + kb : 0xfffffff0u, 0, 0);
-#pragma unroll
-      for (int t = 0; t < NT; ++t) af[buf][u][t] = __builtin_amdgcn_raw_buffer_load_b128(ra, k_ok ? aoff[t] + kb : 0xfffffff0u, 0, 0);
-    }
-  };
-  auto consume = [&](int buf, int ks) {
-#pragma unroll
-    for (int u = 0; u < UB; ++u) {
-      lora_u32x4 x = xf[buf][u];
-      if (has_drop) {  // wave-uniform
-        const uint32_t e = (uint32_t)row * (uint32_t)p.K + (uint32_t)((ks + u) * 32 + kg * 8);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          bool k0, k1;
-          mrb_keep2(e + 2 * q, seed, site, p.drop.thresh24, k0, k1);
-          x[q] = (k0 ? x[q] & 0xffffu : 0u) | (k1 ? x[q] & 0xffff0000u : 0u);
-        }
+      for (int i = 0; i < ROWS / 8; ++i) {
+        const int r = m0 + (ROWS / 8) * w + i;
+        if (r < p.M)
+          for (int c = lane * 4; c < p.init_n; c += 256) {
+            const float4 v = p.init_src ? *reinterpret_cast<const float4*>(p.init_src + (long long)r * p.ld_isrc + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(p.init_dst + (long long)r * p.ld_idst + c) = v;
+          }
       }
-#pragma unroll
-      for (int t = 0; t < NT; ++t)
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[buf][u][t]), __builtin_bit_cast(bf16x8, x), acc[t], 0, 0, 0);
     }
-  };
-  // two batches of operands in flight: batch b+1 is requested before batch b is multiplied
-  // (the fetches are UNCONDITIONAL — past the wave's share they read out of range, which costs no memory traffic: a conditional fetch
-  // makes the compiler merge "loaded" and "not loaded" register sets with copies, i.e. wait for every load right after issuing it)
-  fetch(0, ks0);
-#pragma unroll 1
-  for (int ks = ks0; ks < ks1; ks += 2 * UB) {
-    fetch(1, ks + UB);
-    consume(0, ks);
-    fetch(0, ks + 2 * UB);
-    if (ks + UB < ks1) consume(1, ks + UB);
-  }
-  // side job (see LoraRowsArgs): the block's fp32 init rows, ROWS / 8 rows per wave
-  if (p.init_dst) {
-#pragma unroll
-    for (int i = 0; i < ROWS / 8; ++i) {
-      const int r = m0 + (ROWS / 8) * w + i;
-      if (r < p.M)
-        for (int c = lane * 4; c < p.init_n; c += 256) {
-          const float4 v = p.init_src ? *reinterpret_cast<const float4*>(p.init_src + (long long)r * p.ld_isrc + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-          *reinterpret_cast<float4*>(p.init_dst + (long long)r * p.ld_idst + c) = v;
-        }
-    }
-  }
-#pragma unroll
-  for (int t = 0; t < NT; ++t) red[w][t][lane] = acc[t];
-  __syncthreads();
-  if (w < NT) {  // wave t finishes r tile t: lane (m = l15, kg) holds r = 16 t + 4 kg .. + 3 of row m
-    f32x4 v = red[0][w][lane];
-#pragma unroll
-    for (int j = 1; j < 8; ++j) v += red[j][w][lane];
-    const float post = has_drop ? p.drop.inv_keep : 1.0f;
-    const int r0 = w * 16 + 4 * kg;
-    if (row_ok && r0 < p.R)
-      *reinterpret_cast<uint2*>(Ug + (long long)row * p.ldu + r0) = make_uint2(pack2bf(v[0] * post, v[1] * post), pack2bf(v[2] * post, v[3] * post));
-  }
+  });
 }
 
 static bool lora_thin_enabled() {

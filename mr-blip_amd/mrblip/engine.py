@@ -891,6 +891,10 @@ class MrBlipEngine:
         e0, e1 = groups[0].wext.storage_offset(), groups[-1].wext.storage_offset() + groups[-1].wext.numel()
         return (self.enc_w_arena[a:b], (b - a) * 2, nb, self.wext_all.view(-1)[e0:e1] if self.enc_prefetch_ext else None)
 
+    # Round 4: the LoRA "down" product of a tall input (the T5 encoder's 2012 rows) rides in the GEMM that consumes it.  MRB_GEMM_THIN=0: a launch
+    # of its own (lora_thin_kernel), as before; same bits either way.
+    gemm_thin_enabled = os.environ.get("MRB_GEMM_THIN", "1") == "1"
+    gemm_thin_min_rows = 512      # (= LORA_THIN_MIN_M: below it lora_rows takes the row kernel, whose summation order differs)
     enc_bwd_prefetch = int(os.environ.get("MRB_ENC_BWD_PREFETCH", "0"))   # the same for the backward's dX GEMMs (transposed weights)
 
     def enc_pf_bwd(self, groups, M: int):
@@ -925,8 +929,15 @@ class MrBlipEngine:
             ops.lora_rows(x, g.acat, u, g.K, drop=self.drop(g.site, self.cfg.lora_dropout), init_dst=out, init_src=res)
             ops.gemm(x, g.W, out, aext=u, wext=g.wext, k_splits=ks, **kw)
             return
+        thin = None
         if not u_ready:
-            self.lora_thin(x, g.acat, u, g.K, drop=self.drop(g.site, self.cfg.lora_dropout))
+            if self.gemm_thin_enabled and self.gemm_thin_min_rows <= x.shape[0] <= self.lora_rows_max_m and g.K % 32 == 0 and g.acat.shape[0] <= 32:
+                # the GEMM's first workgroups compute u while its tiles run (csrc/gemm.hip thin role): no launch for the "down" product
+                thin = (g.acat, g.K, self.drop(g.site, self.cfg.lora_dropout))
+            else:
+                self.lora_thin(x, g.acat, u, g.K, drop=self.drop(g.site, self.cfg.lora_dropout))
+        if thin is not None:
+            kw["thin"] = thin
         if pf is not None:
             ops.gemm_prefetch(pf[0], n_blocks=pf[2], nbytes=pf[1], t2=pf[3] if len(pf) > 3 else None)
         if tout is not None and out.dtype == bf16 and not kw.get("gated") and x.shape[0] > 64 and self.gemm_tout_enabled:
@@ -1017,7 +1028,8 @@ class MrBlipEngine:
             kw["tout"], kw["t_rows"] = tout, t_rows
             return self.lg_fwd(g, xn, u, out, **kw)
         kw["tout"], kw["t_rows"] = tout, t_rows
-        if self.fuse_norm_lora and x.shape[0] <= self.lora_rows_max_m and not per_adapter:
+        thin_in_gemm = self.gemm_thin_enabled and self.gemm_thin_min_rows <= x.shape[0] <= self.lora_rows_max_m and g.K % 32 == 0 and not per_adapter
+        if self.fuse_norm_lora and x.shape[0] <= self.lora_rows_max_m and not per_adapter and not thin_in_gemm:
             ops.rmsnorm_lora_fwd(x, ln, self.cfg.t5_eps, xn, g.acat, u, drop=self.drop(g.site, self.cfg.lora_dropout))
             return self.lg_fwd(g, xn, u, out, u_ready=True, **kw)
         ops.rmsnorm_fwd(x, ln, self.cfg.t5_eps, out_bf16=xn)

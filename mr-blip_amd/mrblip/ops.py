@@ -79,6 +79,7 @@ _ce = _sig("mrblip_cross_entropy", vp, ll, vp, i32, i32, f32, vp, vp, ll, vp)
 _adamw = _sig("mrblip_adamw", vp, vp, vp, vp, ll, vp, f32, f32, f32, f32, vp)
 _seed_bump = _sig("mrblip_seed_bump", vp, vp)
 _prefetch = _sig("mrblip_prefetch", vp, ll, i32, vp)
+_gemm_set_thin = _sig("mrblip_gemm_set_thin", vp, ll, i32, i32, u32, f32, vp, ll, u32)
 _gemm_set_prefetch = _sig("mrblip_gemm_set_prefetch", vp, ll, vp, ll, i32)
 _lora_dx = _sig("mrblip_lora_dx_add", vp, ll, i32, vp, ll, vp, i32, i32, i32, vp, u32, f32, vp)
 _cu_reserve = _sig("mrblip_gemm_set_cu_reserve", i32)
@@ -98,7 +99,7 @@ EXPORTS = [
     "mrblip_layernorm_bwd", "mrblip_rmsnorm_bwd", "mrblip_rmsnorm_bwd_cast", "mrblip_attention_fwd", "mrblip_attention_fwd_rowv", "mrblip_attention_bwd", "mrblip_head_transpose",
     "mrblip_patchify", "mrblip_vit_assemble", "mrblip_row_copy", "mrblip_mean_pool", "mrblip_mean_pool_bwd",
     "mrblip_cast_dropout", "mrblip_gelu_bwd", "mrblip_gated_gelu_bwd", "mrblip_cross_entropy", "mrblip_adamw",
-    "mrblip_seed_bump", "mrblip_prefetch", "mrblip_gemm_set_prefetch", "mrblip_lora_dx_add", "mrblip_dropout_bf16", "mrblip_colsum", "mrblip_lora_pack", "mrblip_lora_tn",
+    "mrblip_seed_bump", "mrblip_prefetch", "mrblip_gemm_set_prefetch", "mrblip_gemm_set_thin", "mrblip_lora_dx_add", "mrblip_dropout_bf16", "mrblip_colsum", "mrblip_lora_pack", "mrblip_lora_tn",
     "mrblip_lora_grads", "mrblip_gemm_lora_down", "mrblip_gemm_lora_dx", "mrblip_patchify_u8",
     "mrblip_gemm_set_cu_reserve", "mrblip_lora_rows", "mrblip_rmsnorm_lora_fwd", "mrblip_lora_rows_init", "mrblip_dec_proj", "mrblip_dec_proj_config", "mrblip_lora_dx_add_batched", "mrblip_lora_rows_batched", "mrblip_gemm_set_extra", "mrblip_attention_set_split_workspace",
     "mrblip_gemm_f16", "mrblip_layernorm_fwd_f16", "mrblip_attention_fwd_rowv_f16", "mrblip_patchify_f16", "mrblip_patchify_u8_f16",
@@ -156,13 +157,15 @@ def _d(d: Optional[Dropout]):
 # ------------------------------------------------------------------------------------------------ GEMM
 def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, aext=None, wext=None, out2=None, bias=None, residual=None,
          act: int = 0, gated: bool = False, drop: Optional[Dropout] = None, tile_cfg: int = 0, K: Optional[int] = None,
-         cu_reserve: Optional[int] = None, k_splits: int = 0, tout=None, t_rows: int = 0, ext_group_n: int = 0):
+         cu_reserve: Optional[int] = None, k_splits: int = 0, tout=None, t_rows: int = 0, ext_group_n: int = 0, thin=None):
     """out[M,N] = a[M,K] @ w[N,K]^T (+ aext @ wext^T) with the fused epilogue of mrblip_gemm_bf16.  cu_reserve: CUs a persistent
     tile kernel leaves to other streams (None = the calling thread's ``gemm_cu_reserve`` context, default 0).  k_splits > 1 (M <= 32,
     fp32 out, no residual): the skinny kernel's blocks split K and ADD into ``out``, which the caller pre-initialised.
     tout / t_rows (bf16 out, plain or bias epilogue): up to three [B, H, 64, Spad] tensors receiving the head-transposed copies of the
     output's consecutive column ranges of width H * 64, rows being b * t_rows + s (see ``dec_proj``).  ext_group_n: output-column group
-    g = n // ext_group_n takes columns [64 g, 64 g + 64) of ``aext`` as its K extension (one GEMM for several LoRA groups)."""
+    g = n // ext_group_n takes columns [64 g, 64 g + 64) of ``aext`` as its K extension (one GEMM for several LoRA groups).
+    thin = (acat [R, K'], K', Dropout or None): the launch computes aext[:, :R] = dropout(a)[:, :K'] @ acat^T itself (``lora_rows`` without a
+    launch of its own: the first workgroups of the GEMM do it while the tiles run; M > 64)."""
     f16 = a.dtype == torch.float16   # IEEE fp16 operands (the fp16-operand ViT): both operands, and a 16-bit output, are fp16
     _req(a, torch.float16 if f16 else torch.bfloat16, "gemm.a"); _req(w, a.dtype, "gemm.w")
     if out.dtype != torch.float32 and out.dtype != a.dtype:
@@ -173,6 +176,15 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, aext=None, wext
     sp, site, p = _d(drop)
     reserve = getattr(_tls, "cu_reserve", 0) if cu_reserve is None else cu_reserve
     _set_gemm_extra(tout, t_rows, ext_group_n)
+    if thin is not None:
+        acat, tk, tdrop = thin
+        tsp, tsite, tp = _d(tdrop)
+        if sp is None:
+            sp = tsp          # the launch's one seed pointer (the epilogue's own dropout stays off: p = 0)
+        flags, epoch = _thin_flags(a.device, (M + 15) // 16)
+        rc = _gemm_set_thin(_p(acat), _ld(acat), acat.shape[0], int(tk), tsite, tp, _p(flags), flags.numel(), epoch)
+        if rc != 0:
+            raise MrblipError(_lib.mrblip_last_error().decode())
     _chk((_gemm_f16 if f16 else _gemm)(_p(a), _ld(a), _p(w), _ld(w), _p(aext), _ld(aext), _p(wext), _ld(wext), M, N, K, _p(out), _ld(out),
                1 if out.dtype == torch.float32 else 0, _p(out2), _ld(out2), _p(bias), _p(residual), _ld(residual), act,
                1 if gated else 0, sp, site, p, (tile_cfg & 0xff) | ((int(reserve) & 0x1ff) << 8) | ((int(k_splits) & 0xf) << 17), _stream()))
@@ -180,6 +192,19 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, aext=None, wext
 
 
 _tls = threading.local()
+_thin_state = {}
+
+
+def _thin_flags(device, n: int):
+    """(flag words, fresh epoch) for a GEMM with the thin role on the CURRENT stream: launches of one stream are ordered, so they share a
+    buffer and tell their flags apart by the epoch; another stream gets its own buffer"""
+    key = (device.index, _stream())
+    st = _thin_state.get(key)
+    if st is None or st[0].numel() < n:
+        st = [torch.zeros(max(n, 1024), dtype=torch.int32, device=device), 0]
+        _thin_state[key] = st
+    st[1] = st[1] % 0x7fffffff + 1
+    return st[0], st[1]
 
 
 def _set_gemm_extra(tout, t_rows: int, ext_group_n: int = 0):

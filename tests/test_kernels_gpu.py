@@ -1221,6 +1221,57 @@ def test_gemm_prefetch_workgroups_change_no_result(ops, cfg, gated, f32):
         ops.gemm_prefetch(far, n_blocks=2000)
 
 
+@pytest.mark.parametrize("M,N,K,nad,cfg,gated,f32", [(2012, 2048, 2048, 1, 0, False, True), (2012, 5120, 2048, 2, 0, True, False),
+                                                   (2012, 6144, 2048, 3, 8, False, False), (2012, 2048, 5120, 1, 0, False, True),
+                                                   (1000, 1536, 512, 3, 1, False, False), (600, 512, 256, 1, 5, False, False)])
+def test_gemm_thin_role_equals_the_lora_rows_launch(ops, M, N, K, nad, cfg, gated, f32):
+    """Round 4: the GEMM that consumes the LoRA "down" product u = dropout(x) (sA)^T as its K extension computes it in its own first
+    workgroups (mrblip_gemm_set_thin; body shared with lora_thin_kernel: csrc/lora_thin.h) and hands it to the tiles through
+    write-through stores and per-row-block flags.  u and the output must have the bits of lora_rows + gemm — for 4-, 8- and 16-wave
+    tiles, one and two r tiles (8 / 16 / 24 adapters' rows), persistent and one-tile-per-block grids, with the head-transposed copies and
+    with prefetch workgroups in the same launch; repeated, because a broken hand-over would show as a race."""
+    torch.manual_seed(37)
+    seed = torch.tensor([41], dtype=torch.int32, device=dev())
+    rows = 2 * N if gated else N
+    R = 8 * nad
+    x = bf(torch.randn(M, K, device=dev())); w = bf(torch.randn(rows, K, device=dev()) * 0.03)
+    acat = bf(torch.randn(R, K, device=dev()) * 0.05); wext = bf(torch.randn(rows, 64, device=dev()) * 0.05)
+    wext[:, R:] = 0
+    res = torch.randn(M, N, device=dev()) if f32 else None
+    far = bf(torch.randn(2**20, device=dev()))
+    in_drop = ops.Dropout(seed, 11, 0.05)
+    out_drop = ops.Dropout(seed, 12, 0.1) if (f32 or gated) else None
+    H = N // 64
+    t_ok = not f32 and not gated and cfg != 5
+    spad = ops.rup32(M)
+
+    def run(fused, pf=False):
+        u = torch.zeros(M, 64, dtype=torch.bfloat16, device=dev())
+        out = torch.full((M, N), 3.0, dtype=torch.float32 if f32 else torch.bfloat16, device=dev())
+        h = torch.zeros(M, 2 * N, dtype=torch.bfloat16, device=dev()) if gated else None
+        tt = torch.zeros(1, H, 64, spad, dtype=torch.bfloat16, device=dev()) if t_ok else None
+        if not fused:
+            ops.lora_rows(x, acat, u, K, drop=in_drop)
+        if pf:
+            ops.gemm_prefetch(far, n_blocks=24)
+        ops.gemm(x, w, out, aext=u, wext=wext, residual=res, out2=h, gated=gated, drop=out_drop, tile_cfg=cfg, tout=(tt,) if t_ok else None, t_rows=M,
+                 thin=(acat, K, in_drop) if fused else None)
+        return u, out, h, tt
+    ref = run(False)
+    for rep in range(6):
+        got = run(True, pf=bool(rep & 1))
+        for name, a, b in zip(("u", "out", "h", "tout"), got, ref):
+            assert (a is None and b is None) or torch.equal(a, b), (name, rep)
+    # no mask (eval): same
+    in_drop = None
+    ref = run(False)
+    got = run(True)
+    assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
+    with pytest.raises(ops.MrblipError):     # <= 64 rows take the skinny kernel, which has no such role
+        ops.gemm(x[:32], w, torch.empty(32, N, dtype=torch.bfloat16, device=dev()), aext=torch.zeros(32, 64, dtype=torch.bfloat16, device=dev()), wext=wext,
+                 thin=(acat, K, None)) if not gated else (_ for _ in ()).throw(ops.MrblipError("n/a"))
+
+
 @pytest.mark.parametrize("grid", [1, 5, 64, 0])
 def test_dec_proj_streaming_kernel_is_bit_identical_to_the_tile_kernel(ops, grid):
     """Round 4: for <= 16 rows mrblip_dec_proj runs as a streaming kernel (a block owns a range of 16-column tiles; rows and LoRA "down"
