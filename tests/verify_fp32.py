@@ -82,9 +82,12 @@ class Fp32Verify(contextlib.AbstractContextManager):
         eng.dec_proj_enabled = False   # (the fused decoder projection is a bf16-operand kernel: the fp32-operand stand-ins below replace the two-launch ops)
         # round 4: the transposed copies from the GEMM epilogue and the stacked cross K / V projection are bf16-operand forms too — this
         # mode keeps the head_transpose stand-in and the per-layer projections (instance attributes; the engine is used for this mode only)
-        S["tout"], S["ckv"] = eng.gemm_tout_enabled, eng.cross_kv_batched
+        S["tout"], S["ckv"], S["thin"] = eng.gemm_tout_enabled, eng.cross_kv_batched, eng.gemm_thin_enabled
         eng.gemm_tout_enabled = False
         eng.cross_kv_batched = False
+        eng.gemm_thin_enabled = False      # (the patched gemm has no thin role: the "down" product stays a launch of its own)
+        S["pf"] = (eng.enc_prefetch, eng.qf_prefetch)
+        eng.enc_prefetch, eng.qf_prefetch = (0,), False   # (... and would leave the prefetch hints unconsumed)
 
         def buf(name, shape, dtype, zero=True):
             shape = tuple(int(s) for s in shape)
@@ -122,7 +125,8 @@ class Fp32Verify(contextlib.AbstractContextManager):
         eng.ws, eng._store = S["ws"], S["store"]
         eng.fuse_norm_lora, eng.lora_rows_max_m = S["fuse"], S["rows_max"]
         eng.dec_proj_enabled = S["dec_proj"]
-        eng.gemm_tout_enabled, eng.cross_kv_batched = S["tout"], S["ckv"]
+        eng.gemm_tout_enabled, eng.cross_kv_batched, eng.gemm_thin_enabled = S["tout"], S["ckv"], S["thin"]
+        eng.enc_prefetch, eng.qf_prefetch = S["pf"]
         eng.vit_dtype = S["vit_dtype"]
         for obj, key, val in self._weight_restore:
             obj[key] = val
