@@ -72,6 +72,7 @@ struct GemmArgs {
   // rows each — write it with write-through stores and set th_flags[row block] = th_epoch; a tile waits for the flags of its rows before
   // it stages the K extension (its LAST K-tile) and reads Aext past its XCD's L2
   const bf16_t* th_A; long long th_lda; int th_R, th_K; DropoutArg th_drop; uint32_t* th_flags; uint32_t th_epoch; int th_blocks;
+  int role_base;    // block id of the first role workgroup: 0 (roles first) or the number of tile workgroups (roles last)
   const void* pf_ptr; long long pf_n16; const void* pf_ptr2; long long pf_n16_2; int pf_blocks;   // (a second, usually small range: the LoRA K-extension operand)
 };
 
@@ -265,11 +266,15 @@ __global__ __launch_bounds__(WGM* WGN * 64, gemm_min_blocks(NS * (BM + BN) * BK 
   static_assert(!GATED || TN == 2, "gated epilogue pairs the wave's two n-tiles");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
+  // role workgroups (prefetch, then thin) sit either in FRONT of the tiles (role_base = 0: they are resident before any tile that waits for
+  // them) or BEHIND them (role_base = number of tile workgroups — only when the tiles leave CUs idle, e.g. 192 persistent tiles of the T5
+  // qkv projection: the roles then run on the idle CUs instead of delaying half of the tiles)
   const int pfb = p.pf_blocks;   // uniform
-  if (pfb > 0 && (int)blockIdx.x < pfb) {   // prefetch role: stream a later launch's weights through the memory-side cache, keep nothing
+  const int rid = (int)blockIdx.x - p.role_base;   // role index if in [0, pfb + th_blocks)
+  if (rid >= 0 && rid < pfb) {   // prefetch role: stream a later launch's weights through the memory-side cache, keep nothing
     const mrb_u32x4* __restrict__ q = reinterpret_cast<const mrb_u32x4*>(p.pf_ptr);
     const long long step = (long long)pfb * (NW * 64);
-    long long i = (long long)blockIdx.x * (NW * 64) + threadIdx.x;
+    long long i = (long long)rid * (NW * 64) + threadIdx.x;
     uint32_t keep = 0;
     // (plain loads: with the non-temporal hint the lines are not kept by the memory-side cache — measured, the consumer ran at its cold speed)
     for (; i + 3 * step < p.pf_n16; i += 4 * step) {
@@ -278,7 +283,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, gemm_min_blocks(NS * (BM + BN) * BK 
     }
     for (; i < p.pf_n16; i += step) keep |= q[i][0];
     const mrb_u32x4* __restrict__ q2 = reinterpret_cast<const mrb_u32x4*>(p.pf_ptr2);
-    for (i = (long long)blockIdx.x * (NW * 64) + threadIdx.x; i < p.pf_n16_2; i += step) keep |= q2[i][1];
+    for (i = (long long)rid * (NW * 64) + threadIdx.x; i < p.pf_n16_2; i += step) keep |= q2[i][1];
     asm volatile("" ::"v"(keep));   // the loads stay, no store
     return;
   }
@@ -286,15 +291,17 @@ __global__ __launch_bounds__(WGM* WGN * 64, gemm_min_blocks(NS * (BM + BN) * BK 
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int thb = p.th_blocks;   // uniform
-  if (thb > 0 && (int)blockIdx.x - pfb < thb) {   // thin role: 16 rows of the K extension's A operand (see GemmArgs)
-    const int rb = (int)blockIdx.x - pfb;
+  if (rid >= pfb && rid < pfb + thb) {   // thin role: 16 rows of the K extension's A operand (see GemmArgs)
+    const int rb = rid - pfb;
     if (rb * 16 < p.M) {
       ThinArgs t;
       t.X = p.A; t.ldx = p.lda; t.A = p.th_A; t.lda = p.th_lda; t.U = const_cast<bf16_t*>(p.Aext); t.ldu = p.ldaext;
       t.M = p.M; t.K = p.th_K; t.R = p.th_R;
       t.seed_ptr = p.th_drop.seed_ptr; t.site = p.th_drop.site; t.thresh16 = p.th_drop.thresh24; t.inv_keep = p.th_drop.inv_keep;
-      if (p.th_R <= 16) lora_thin_body<1, 8, 16, NW, true>(t, rb * 16, reinterpret_cast<f32x4(*)[1][64]>(smem), w, lane, []() {});
-      else lora_thin_body<2, 4, 16, NW, true>(t, rb * 16, reinterpret_cast<f32x4(*)[2][64]>(smem), w, lane, []() {});
+      // (operand batches sized to the kernel's register budget — 128 VGPRs with 16 waves: the batch depth does not change the summation order)
+      constexpr int UB1 = NW >= 16 ? 4 : 8, UB2 = NW >= 16 ? 2 : 4;
+      if (p.th_R <= 16) lora_thin_body<1, UB1, 16, NW, true>(t, rb * 16, reinterpret_cast<f32x4(*)[1][64]>(smem), w, lane, []() {});
+      else lora_thin_body<2, UB2, 16, NW, true>(t, rb * 16, reinterpret_cast<f32x4(*)[2][64]>(smem), w, lane, []() {});
       __syncthreads();   // the storing waves have drained their write-through stores
       if (threadIdx.x == 0) __hip_atomic_store(p.th_flags + rb, p.th_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -429,7 +436,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, gemm_min_blocks(NS * (BM + BN) * BK 
 #endif
   // ---- persistent tile loop: grid = resident blocks; a block's epilogue stores drain while it already stages the next tile
   const int ntiles = p.tiles_m * p.tiles_n;
-  for (int tile = (int)blockIdx.x - pfb - thb; tile < ntiles; tile += (int)gridDim.x - pfb - thb) {
+  for (int tile = (int)blockIdx.x - (p.role_base ? 0 : pfb + thb); tile < ntiles; tile += (int)gridDim.x - pfb - thb) {
   {  // tile id -> (bm, bn): XCD-contiguous remap (bijective), then grouped ordering for L2 reuse of the W panel
     int bid = tile;
     const int q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, idx = bid >> 3;
@@ -1585,6 +1592,12 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const GemmArgs p) 
   }
 }
 
+static bool roles_last_enabled() {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("MRB_GEMM_ROLES_LAST"); on = (e && e[0] == '0') ? 0 : 1; }
+  return on == 1;
+}
+
 template <int BM, int BN, int WGM, int WGN, bool OUT_F32, bool GATED, int BK = 64, int NS = 2>
 static int launch_tile(GemmArgs& a, hipStream_t st) {
   constexpr int BNO = GATED ? BN / 2 : BN;
@@ -1620,6 +1633,10 @@ static int launch_tile(GemmArgs& a, hipStream_t st) {
   const int grid = (NS == 2 && LDS > 80 * 1024 && ntiles > num_cu) ? num_cu : ntiles;
   a.pf_blocks = (a.pf_n16 > 0 || a.pf_n16_2 > 0) ? (a.pf_blocks + 7) / 8 * 8 : 0;
   a.th_blocks = a.th_flags ? ((a.M + 15) / 16 + 7) / 8 * 8 : 0;
+  // roles behind the tiles when the tiles leave at least 32 workgroup slots of the chip empty (the producers then start at once on the idle
+  // CUs; a tile that reaches its K extension first polls until they are through)
+  constexpr int per_cu = gemm_min_blocks(LDS, WGM * WGN);
+  a.role_base = (a.pf_blocks + a.th_blocks > 0 && grid + 32 <= num_cu * per_cu && roles_last_enabled()) ? grid : 0;
   static_assert(LDS >= THIN_RED_BYTES(2), "the thin role's partial sums live in the tile's LDS");
   hipLaunchKernelGGL(kern, dim3(grid + a.pf_blocks + a.th_blocks), dim3(WGM * WGN * 64), LDS, st, a);
   return mrblip_check_launch("gemm_tile");
