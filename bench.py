@@ -473,6 +473,8 @@ def main():
             "step_tflop_per_clip": round(step_tf, 3),
             "step_mfu": round(clips_s * step_tf / (world * PEAK_BF16_TFLOPS), 4),   # (frame-shard mode: algorithmic FLOPs of ONE clip; the replicated T5 work is not counted twice)
             "loss": round(loss_v, 4),
+            # tiles of a GEMM whose bounded wait for the launch's own thin-role workgroups ran out (csrc/gemm.hip th_err): must be 0
+            "thin_role_timeouts": ops.gemm_thin_timeouts(),
             "roofline": roof,
         }
         if selftest is not None:

@@ -154,7 +154,8 @@ int mrblip_gemm_set_prefetch(const void* ptr, long long bytes, const void* ptr2,
 /* One-shot: the calling thread's NEXT mrblip_gemm_bf16 launch (generic tile kernel, M > 64, K extension read last) computes its own
  * K-extension operand Aext[m, 0:R] = dropout(A)[m, 0:K] acat^T — what mrblip_lora_rows would have written in a launch of its own (peft
  * lora_A(lora_dropout(x)), same bits) — in its first workgroups while the tiles already run; the tiles wait for flags[m / 16] == epoch before
- * they read those rows.  flags: >= ceil(M / 16) words shared by the launches of ONE stream; epoch: a value no earlier launch left there.
+ * they read those rows.  flags: >= ceil(M / 16) + 1 words shared by the launches of ONE stream (the last one is an error word: 0xffffffff
+ * after a tile's bounded wait ran out — check it; it never happens in a correct run); epoch: a value no earlier launch left there.
  * The mask uses the GEMM call's seed pointer with call-site id `site`. */
 int mrblip_gemm_set_thin(const void* acat, long long lda, int R, int K, uint32_t site, float p_drop, uint32_t* flags, long long n_flags,
                          uint32_t epoch);

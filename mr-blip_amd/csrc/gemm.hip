@@ -71,7 +71,7 @@ struct GemmArgs {
   // extension's A operand themselves — Aext[m, 0:th_R] = dropout(A)[m, 0:th_K] th_A^T, the LoRA "down" product (body: lora_thin.h), 16
   // rows each — write it with write-through stores and set th_flags[row block] = th_epoch; a tile waits for the flags of its rows before
   // it stages the K extension (its LAST K-tile) and reads Aext past its XCD's L2
-  const bf16_t* th_A; long long th_lda; int th_R, th_K; DropoutArg th_drop; uint32_t* th_flags; uint32_t th_epoch; int th_blocks;
+  const bf16_t* th_A; long long th_lda; int th_R, th_K; DropoutArg th_drop; uint32_t* th_flags; uint32_t* th_err; uint32_t th_epoch; int th_blocks;
   int role_base;    // block id of the first role workgroup: 0 (roles first) or the number of tile workgroups (roles last)
   const void* pf_ptr; long long pf_n16; const void* pf_ptr2; long long pf_n16_2; int pf_blocks;   // (a second, usually small range: the LoRA K-extension operand)
 };
@@ -370,6 +370,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, gemm_min_blocks(NS * (BM + BN) * BK 
         if (lane < BM / 16 && rbk * 16 < p.M) {
           uint32_t tries = 0;   // (bounded: a protocol error must show as a wrong result in the tests, not as a hung GPU)
           while (__hip_atomic_load(p.th_flags + rbk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.th_epoch && ++tries < (1u << 17)) __builtin_amdgcn_s_sleep(4);
+          if (tries >= (1u << 17)) __hip_atomic_store(p.th_err, 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // loud: the host checks this word
         }
         asm volatile("" ::: "memory");
       }
@@ -1687,7 +1688,9 @@ extern "C" int mrblip_gemm_set_prefetch(const void* ptr, long long bytes, const 
 }
 
 // one-shot: the calling thread's NEXT GEMM launch computes its own K-extension operand Aext = dropout(A) acat^T (see GemmArgs.th_*).
-// flags: >= ceil(M / 16) words the launches of ONE stream may share; epoch: a value no earlier launch on that stream left in them.
+// flags: >= ceil(M / 16) + 1 words the launches of ONE stream may share (the LAST word is an error word: a tile whose bounded wait ran out
+// stores 0xffffffff there — a protocol failure is a wrong result the caller can detect, never a hung GPU); epoch: a value no earlier launch
+// on that stream left in them.
 struct GemmThin { const void* acat; long long lda; int R, K; uint32_t site; float p; uint32_t* flags; long long n_flags; uint32_t epoch; bool set; };
 static thread_local GemmThin g_gemm_thin = {};
 extern "C" int mrblip_gemm_set_thin(const void* acat, long long lda, int R, int K, uint32_t site, float p_drop, uint32_t* flags, long long n_flags,
@@ -1727,13 +1730,13 @@ static int gemm_dispatch(const void* A, long long lda, const void* W, long long 
   a.t_inner = extra.set ? extra.t_inner : 0; a.t_rows = extra.t_rows; a.t_spad = extra.t_spad; a.t_bs = extra.t_bs; a.t_hs = extra.t_hs;
   a.t_stride = extra.t_stride; a.t_count = extra.set ? extra.t_count : 0;
   a.ext_group_n = extra.set ? extra.ext_group_n : 0;
-  a.th_flags = nullptr; a.th_blocks = 0; a.th_A = nullptr; a.th_lda = 0; a.th_R = a.th_K = 0; a.th_epoch = 0;
+  a.th_flags = nullptr; a.th_err = nullptr; a.th_blocks = 0; a.th_A = nullptr; a.th_lda = 0; a.th_R = a.th_K = 0; a.th_epoch = 0;
   mk_drop_arg(a.th_drop, seed_ptr, 0, 0.f);
   if (th.set) {
-    MRB_REQUIRE(Aext && !ext_first && !f16 && M > 64 && th.K <= K && ldaext >= th.R && (ldaext % 4) == 0 && ((uintptr_t)Aext % 8) == 0 && th.n_flags >= (M + 15) / 16 &&
+    MRB_REQUIRE(Aext && !ext_first && !f16 && M > 64 && th.K <= K && ldaext >= th.R && (ldaext % 4) == 0 && ((uintptr_t)Aext % 8) == 0 && th.n_flags >= (M + 15) / 16 + 1 &&
                     (long long)M * lda * 2 < (1ll << 31) && !(th.p > 0.f && !seed_ptr),
                 "gemm: the thin role needs a K extension read last, more than 64 rows and one flag per 16 rows");
-    a.th_A = (const bf16_t*)th.acat; a.th_lda = th.lda; a.th_R = th.R; a.th_K = th.K; a.th_flags = th.flags; a.th_epoch = th.epoch;
+    a.th_A = (const bf16_t*)th.acat; a.th_lda = th.lda; a.th_R = th.R; a.th_K = th.K; a.th_flags = th.flags; a.th_err = th.flags + (th.n_flags - 1); a.th_epoch = th.epoch;
     mk_drop_arg(a.th_drop, seed_ptr, th.site, th.p);
   }
   a.pf_ptr = pf.ptr; a.pf_n16 = pf.bytes / 16; a.pf_ptr2 = pf.ptr2; a.pf_n16_2 = pf.bytes2 / 16; a.pf_blocks = pf.n_blocks;

@@ -200,11 +200,16 @@ def _thin_flags(device, n: int):
     buffer and tell their flags apart by the epoch; another stream gets its own buffer"""
     key = (device.index, _stream())
     st = _thin_state.get(key)
-    if st is None or st[0].numel() < n:
-        st = [torch.zeros(max(n, 1024), dtype=torch.int32, device=device), 0]
+    if st is None or st[0].numel() < n + 1:
+        st = [torch.zeros(max(n + 1, 1024), dtype=torch.int32, device=device), 0]
         _thin_state[key] = st
     st[1] = st[1] % 0x7fffffff + 1
     return st[0], st[1]
+
+
+def gemm_thin_timeouts() -> int:
+    """flag buffers whose error word is set: a tile's bounded wait for the thin role ran out (synchronises; 0 in every correct run)"""
+    return sum(int(st[0][-1].item() != 0) for st in _thin_state.values())
 
 
 def _set_gemm_extra(tout, t_rows: int, ext_group_n: int = 0):

@@ -1267,6 +1267,7 @@ def test_gemm_thin_role_equals_the_lora_rows_launch(ops, M, N, K, nad, cfg, gate
     ref = run(False)
     got = run(True)
     assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
+    assert ops.gemm_thin_timeouts() == 0
     with pytest.raises(ops.MrblipError):     # <= 64 rows take the skinny kernel, which has no such role
         ops.gemm(x[:32], w, torch.empty(32, N, dtype=torch.bfloat16, device=dev()), aext=torch.zeros(32, 64, dtype=torch.bfloat16, device=dev()), wext=wext,
                  thin=(acat, K, None)) if not gated else (_ for _ in ()).throw(ops.MrblipError("n/a"))
