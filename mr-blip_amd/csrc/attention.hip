@@ -646,6 +646,7 @@ __global__ __launch_bounds__((FLAGS & F_KS2) ? 512 : 256, (FLAGS & F_KS2) ? 1 : 
   const int nst = (p.Sk + 63) >> 6, ntile = (p.Sk + 31) >> 5;
   stage(0, 0);
   uint32_t vm0 = 0xffffu, vm1 = 0xffffu;
+  bool part0 = false, part1 = false;   // wave-uniform: the tile holds masked keys (a tile of valid keys only skips the per-score selects)
 #pragma unroll 1
   for (int t = KS2 ? wsub : 0; t < (KS2 ? 2 * nst : ntile); t += KS2 ? 2 : 1) {  // one 32-key tile per trip (KS2: this wave's half of the stage)
     const int st = t >> 1, sub = t & 1;
@@ -655,10 +656,12 @@ __global__ __launch_bounds__((FLAGS & F_KS2) ? 512 : 256, (FLAGS & F_KS2) ? 1 : 
       if (MASK) {  // Skpad is a multiple of 32: the second half of the last stage may lie past the row
         vm0 = mask_bits_lds(mbits, 2 * st, hi);
         vm1 = st * 64 + 32 < p.Skpad ? mask_bits_lds(mbits, 2 * st + 1, hi) : 0u;
+        part0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)mbits[2 * st]) != 0xffffffffu;
+        part1 = st * 64 + 32 < p.Skpad ? (uint32_t)__builtin_amdgcn_readfirstlane((int)mbits[2 * st + 1]) != 0xffffffffu : true;
       }
       if (st + 1 < nst) stage(st + 1, (st + 1) & 1);
     }
-    if (active && 32 * t < p.Sk) tile(MASK || 32 * t + 32 > p.Sk, 32 * t, sm + (st & 1) * STAGE, sub, sub ? vm1 : vm0);
+    if (active && 32 * t < p.Sk) tile((MASK && (sub ? part1 : part0)) || 32 * t + 32 > p.Sk, 32 * t, sm + (st & 1) * STAGE, sub, sub ? vm1 : vm0);
   }
   if (KS2) {  // merge the two key halves of every query tile: wave w + 4 hands (m, l, O) to wave w through the (now idle) stage buffers
     float* mg = reinterpret_cast<float*>(sm) + (w & 3) * ((MT * 16 + 2) * 64);
@@ -1004,9 +1007,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_lds_kernel(const AttnArgs 
     uint32_t vm0 = 0xffffu, vm1 = 0xffffu;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    bool part0 = false, part1 = false;   // wave-uniform: the tile holds masked keys (see the forward)
     if (MASK) {
       vm0 = mask_bits_lds(mbits, 2 * st, hi);
       vm1 = st * 64 + 32 < p.Skpad ? mask_bits_lds(mbits, 2 * st + 1, hi) : 0u;
+      part0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)mbits[2 * st]) != 0xffffffffu;
+      part1 = st * 64 + 32 < p.Skpad ? (uint32_t)__builtin_amdgcn_readfirstlane((int)mbits[2 * st + 1]) != 0xffffffffu : true;
     }
     const uint32_t cw0 = dw0, cw1 = dw1;
     if (st + 1 < nst) {
@@ -1021,7 +1027,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_lds_kernel(const AttnArgs 
 #pragma unroll
       for (int sub = 0; sub < 2; ++sub) {   // (sub is a compile-time constant here: two instances, the edge test stays a run-time branch)
         const int k0 = st * 64 + 32 * sub;
-        if (k0 < p.Sk) tile(MASK || k0 + 32 > p.Sk, k0, base, sub, sub ? vm1 : vm0, sub ? cw1 : cw0);
+        if (k0 < p.Sk) tile((MASK && (sub ? part1 : part0)) || k0 + 32 > p.Sk, k0, base, sub, sub ? vm1 : vm0, sub ? cw1 : cw0);
       }
     }
   }
