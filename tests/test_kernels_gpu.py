@@ -1223,9 +1223,11 @@ def test_gemm_prefetch_workgroups_change_no_result(ops, cfg, gated, f32):
 
 @pytest.mark.parametrize("M,N,K,nad,cfg,gated,f32", [(2012, 2048, 2048, 1, 0, False, True), (2012, 5120, 2048, 2, 0, True, False),
                                                    (2012, 6144, 2048, 3, 8, False, False), (2012, 2048, 5120, 1, 0, False, True),
-                                                   (1000, 1536, 512, 3, 1, False, False), (600, 512, 256, 1, 5, False, False)])
+                                                   (1000, 1536, 512, 3, 1, False, False), (600, 512, 256, 1, 5, False, False),
+                                                   (4100, 6144, 512, 3, 8, False, False), (8048, 2048, 512, 1, 0, False, True)])
 def test_gemm_thin_role_equals_the_lora_rows_launch(ops, M, N, K, nad, cfg, gated, f32):
-    """Round 4: the GEMM that consumes the LoRA "down" product u = dropout(x) (sA)^T as its K extension computes it in its own first
+    """(the last two shapes: more tiles than workgroup slots — a persistent 16-wave grid and a 64x128 grid of several rounds: roles in FRONT)
+    Round 4: the GEMM that consumes the LoRA "down" product u = dropout(x) (sA)^T as its K extension computes it in its own first
     workgroups (mrblip_gemm_set_thin; body shared with lora_thin_kernel: csrc/lora_thin.h) and hands it to the tiles through
     write-through stores and per-row-block flags.  u and the output must have the bits of lora_rows + gemm — for 4-, 8- and 16-wave
     tiles, one and two r tiles (8 / 16 / 24 adapters' rows), persistent and one-tile-per-block grids, with the head-transposed copies and
