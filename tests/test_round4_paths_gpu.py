@@ -73,3 +73,25 @@ def test_several_clips_whose_length_is_not_a_multiple_of_32_fall_back():
     assert lay.S % 32 != 0
     assert l == base_l          # same forward kernels -> the same loss bits; the gradient has fp32 atomics (LayerNorm weight gradients): 1e-6
     check("round-4 paths, 2 ragged clips: flat gradient of the fall-back vs forced-off run", relerr(g, base_g), 1e-6)
+
+
+def test_role_workgroups_of_the_encoder_gemms_change_no_bit():
+    """The LoRA "down" products computed by the consuming GEMMs' thin-role workgroups and the weight prefetch that rides in the encoder's /
+    Q-Former's GEMMs (S > 1024 rows here, so both are active by default) against launches of their own and no prefetch: the loss of both
+    steps and the whole flat gradient must be the SAME BITS (the thin body is shared, the prefetch only reads), and no tile may have run
+    out of its bounded wait for the thin role."""
+    from mrblip import ops
+    base_l, base_g, eng0, lay = _step(dict(gemm_thin_enabled=False, enc_prefetch=(0,), qf_prefetch=False))
+    assert lay.S >= eng0.gemm_thin_min_rows and lay.S >= eng0.enc_prefetch_min_rows
+    n0 = ops.launch_count
+    _step(dict(gemm_thin_enabled=False, enc_prefetch=(0,), qf_prefetch=False), steps=1)
+    launches_old = ops.launch_count - n0
+    n0 = ops.launch_count
+    l, g, eng, _ = _step(dict(), steps=2)
+    assert eng.gemm_thin_enabled and eng.enc_prefetch[0] > 0 and eng.qf_prefetch
+    assert l == base_l, (l, base_l)
+    assert torch.equal(g, base_g)
+    assert ops.gemm_thin_timeouts() == 0
+    n0 = ops.launch_count
+    _step(dict(), steps=1)
+    assert ops.launch_count - n0 <= launches_old - 2 * 3, (launches_old, ops.launch_count - n0)   # o and wo of 3 encoder layers lost their thin launch
