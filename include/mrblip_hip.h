@@ -156,7 +156,8 @@ int mrblip_gemm_set_prefetch(const void* ptr, long long bytes, const void* ptr2,
  * lora_A(lora_dropout(x)), same bits) — in its first workgroups while the tiles already run; the tiles wait for flags[m / 16] == epoch before
  * they read those rows.  flags: >= ceil(M / 16) + 1 words shared by the launches of ONE stream (the last one is an error word: 0xffffffff
  * after a tile's bounded wait ran out — check it; it never happens in a correct run); epoch: a value no earlier launch left there.
- * The mask uses the GEMM call's seed pointer with call-site id `site`. */
+ * The mask uses the GEMM call's seed pointer with call-site id `site`.  The epoch is a launch argument: a captured graph that replays such a
+ * launch must clear the flag words between replays (one memset node), or every replay would find the previous replay's flags set. */
 int mrblip_gemm_set_thin(const void* acat, long long lda, int R, int K, uint32_t site, float p_drop, uint32_t* flags, long long n_flags,
                          uint32_t epoch);
 int mrblip_prefetch(const void* ptr, long long bytes, int n_blocks, mrblip_stream_t stream);
