@@ -2164,6 +2164,7 @@ __global__ __launch_bounds__(512) void lora_tn_kernel(const TnArgs2 q) {
   const int per = (steps + 7) / 8;
   const int s_beg = w * per, s_end = min(steps, s_beg + per);
   const int srow = lane >> 2, schunk = lane & 3;     // staging role: row of the 16-row slice, 8-column chunk
+  const int tr_off = (8 * hi + ((lane & 15) >> 2)) * 64 + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;   // transpose-read address inside a [16][32] slice image
   const bool ychunk_ok = c0 + 8 * schunk < C, uchunk_ok = 8 * schunk < R;
   const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
   const bf16_t* const ysrc = Y + c0 + 8 * schunk;
@@ -2192,12 +2193,17 @@ __global__ __launch_bounds__(512) void lora_tn_kernel(const TnArgs2 q) {
     if (s0 + UNROLL < s_end) fetch(s0 + UNROLL);   // wave-uniform
 #pragma unroll
     for (int v = 0; v < UNROLL; ++v) {
-      bf16x8 yf, uf;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        yf[j] = (short)slot[w][v][0][(8 * hi + j) * 32 + l31];
-        uf[j] = (short)slot[w][v][1][(8 * hi + j) * 32 + l31];
-      }
+      // k-major MFMA fragments out of the row-major slices: lane (column l31, hi) needs rows 8 hi .. 8 hi + 7 of its column.  gfx950's
+      // LDS transpose read hands a 16-lane group the columns of a [4 rows][16 columns] block (lane i supplies the address of 4
+      // contiguous columns of row i / 4, lane c receives the 4 rows of column c): two reads per operand instead of eight 2-byte reads
+      // (the same gather as the ViT attention's row-major V, attention.hip; lane map probed in tools/probes/tr_probe.hip)
+      typedef short tn_v4s __attribute__((ext_vector_type(4)));
+      typedef __attribute__((address_space(3))) tn_v4s* tn_tr_ptr;
+      const char* sy = reinterpret_cast<const char*>(&slot[w][v][0][0]) + tr_off;
+      const char* su = reinterpret_cast<const char*>(&slot[w][v][1][0]) + tr_off;
+      const tn_v4s y0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tn_tr_ptr)(sy)), y1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tn_tr_ptr)(sy + 4 * 64));
+      const tn_v4s u0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tn_tr_ptr)(su)), u1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tn_tr_ptr)(su + 4 * 64));
+      bf16x8 yf = {y0[0], y0[1], y0[2], y0[3], y1[0], y1[1], y1[2], y1[3]}, uf = {u0[0], u0[1], u0[2], u0[3], u1[0], u1[1], u1[2], u1[3]};
       if (has_drop) {  // wave-uniform
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
