@@ -2205,10 +2205,22 @@ __global__ __launch_bounds__(512) void lora_tn_kernel(const TnArgs2 q) {
       const tn_v4s u0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tn_tr_ptr)(su)), u1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tn_tr_ptr)(su + 4 * 64));
       bf16x8 yf = {y0[0], y0[1], y0[2], y0[3], y1[0], y1[1], y1[2], y1[3]}, uf = {u0[0], u0[1], u0[2], u0[3], u1[0], u1[1], u1[2], u1[3]};
       if (has_drop) {  // wave-uniform
+        // One 32-bit hash serves the element pair (c even, c + 1) of a row (mrb_keep) and the pair sits in neighbouring lanes: each lane
+        // hashes FOUR of its eight rows and takes the other four from its partner (DPP quad_perm [1,0,3,2]) — the hashes were ~1/3 of
+        // this kernel's time (o group 14.7 us with the mask, 9.6 us without).  (C % 8 == 0 and c0 % 32 == 0: the pair never straddles rows.)
+        const int q = lane & 1;
+        uint32_t mine[4], theirs[4];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const int m = (s0 + v) * 16 + 8 * hi + 4 * q + jj;
+          mine[jj] = mrb_hash(((uint32_t)m * (uint32_t)C + (uint32_t)c) >> 1, seed, site);
+        }
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) theirs[jj] = (uint32_t)__builtin_amdgcn_mov_dpp((int)mine[jj], 0xB1, 0xf, 0xf, true);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const int m = (s0 + v) * 16 + 8 * hi + j;
-          const bool keep = mrb_keep((uint32_t)m * (uint32_t)C + (uint32_t)c, seed, site, thresh24);
+          const uint32_t h = ((j >> 2) == q) ? mine[j & 3] : theirs[j & 3];
+          const bool keep = (q ? (h >> 16) : (h & 0xffffu)) >= thresh24;
           yf[j] = keep ? (short)f2bf(bf2f((bf16_t)yf[j]) * inv_keep) : (short)0;
         }
       }
