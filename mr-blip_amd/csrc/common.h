@@ -88,6 +88,13 @@ __device__ __forceinline__ void mrb_keep2(uint32_t idx_even, uint32_t seed, uint
   k1 = (h >> 16) >= thresh16;
 }
 
+// the draws of FOUR consecutive elements starting at an EVEN index e: two pair hashes.  (Four mrb_keep(e + i) calls cost four: the compiler
+// cannot know that e is even, so it cannot merge the hashes of e and e + 1.)  Every caller's e is row * (even row length) + (column % 4 == 0).
+__device__ __forceinline__ void mrb_keep4(uint32_t e, uint32_t seed, uint32_t site, uint32_t thresh16, bool& k0, bool& k1, bool& k2, bool& k3) {
+  mrb_keep2(e, seed, site, thresh16, k0, k1);
+  mrb_keep2(e + 2u, seed, site, thresh16, k2, k3);
+}
+
 // LINEAR form of the counter hash for kernels that walk consecutive indices (attention-probability dropout): hash(idx) =
 // fin(idx * MRB_H1 + base), base = mrb_lin_base(seed, site).  idx * MRB_H1 is a Weyl sequence in idx, so a kernel evaluates it with
 // adds (a lane constant + a wave-uniform term computed on the scalar unit + a compile-time constant) and pays ONE quarter-rate

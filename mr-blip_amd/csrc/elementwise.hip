@@ -156,10 +156,12 @@ __global__ __launch_bounds__(256) void cast_drop_kernel(const float* __restrict_
     float4 v = *reinterpret_cast<const float4*>(x + (long long)m * ldx + c);
     if (drop.seed_ptr) {
       const uint32_t base = (uint32_t)m * (uint32_t)N + (uint32_t)c;
-      v.x = mrb_keep(base, seed, drop.site, drop.thresh24) ? v.x * drop.inv_keep : 0.f;
-      v.y = mrb_keep(base + 1, seed, drop.site, drop.thresh24) ? v.y * drop.inv_keep : 0.f;
-      v.z = mrb_keep(base + 2, seed, drop.site, drop.thresh24) ? v.z * drop.inv_keep : 0.f;
-      v.w = mrb_keep(base + 3, seed, drop.site, drop.thresh24) ? v.w * drop.inv_keep : 0.f;
+      bool k0, k1, k2, k3;   // (N % 4 == 0: base is even)
+      mrb_keep4(base, seed, drop.site, drop.thresh24, k0, k1, k2, k3);
+      v.x = k0 ? v.x * drop.inv_keep : 0.f;
+      v.y = k1 ? v.y * drop.inv_keep : 0.f;
+      v.z = k2 ? v.z * drop.inv_keep : 0.f;
+      v.w = k3 ? v.w * drop.inv_keep : 0.f;
     }
     if (out_f) *reinterpret_cast<float4*>(out_f + (long long)m * ldof + c) = v;
     if (out_b) *reinterpret_cast<uint2*>(out_b + (long long)m * ldob + c) = make_uint2(pack2bf(v.x, v.y), pack2bf(v.z, v.w));
@@ -189,10 +191,15 @@ __global__ __launch_bounds__(256) void gated_bwd_kernel(const bf16_t* __restrict
     const bf16x8 a = *reinterpret_cast<const bf16x8*>(h + (long long)m * ldh + c);
     const bf16x8 b = *reinterpret_cast<const bf16x8*>(h + (long long)m * ldh + Nh + c);
     float d0[8], d1[8];
+    bool kp[8] = {true, true, true, true, true, true, true, true};
+    if (drop.seed_ptr) {   // (c % 8 == 0, Nh % 8 == 0: element pairs share a hash)
+#pragma unroll
+      for (int j = 0; j < 8; j += 2) mrb_keep2((uint32_t)m * (uint32_t)Nh + (uint32_t)(c + j), seed, drop.site, drop.thresh24, kp[j], kp[j + 1]);
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       float gy = bf2f((bf16_t)g[j]);
-      if (drop.seed_ptr) gy = mrb_keep((uint32_t)m * (uint32_t)Nh + (uint32_t)(c + j), seed, drop.site, drop.thresh24) ? gy * drop.inv_keep : 0.f;
+      if (drop.seed_ptr) gy = kp[j] ? gy * drop.inv_keep : 0.f;
       const float h0 = bf2f((bf16_t)a[j]), h1 = bf2f((bf16_t)b[j]);
       d0[j] = gy * h1 * gelu_erf_grad(h0);
       d1[j] = gy * gelu_erf(h0);

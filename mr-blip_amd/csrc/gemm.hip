@@ -92,10 +92,12 @@ __device__ __forceinline__ void epilogue_apply4(const GemmArgs& p, int m, int n0
   if (p.drop.seed_ptr) {
     const uint32_t seed = mrb_seed_load(p.drop.seed_ptr);
     const uint32_t e = (uint32_t)m * (uint32_t)ncols + (uint32_t)n0;
-    v0 = mrb_keep(e, seed, p.drop.site, p.drop.thresh24) ? v0 * p.drop.inv_keep : 0.f;
-    v1 = mrb_keep(e + 1, seed, p.drop.site, p.drop.thresh24) ? v1 * p.drop.inv_keep : 0.f;
-    v2 = mrb_keep(e + 2, seed, p.drop.site, p.drop.thresh24) ? v2 * p.drop.inv_keep : 0.f;
-    v3 = mrb_keep(e + 3, seed, p.drop.site, p.drop.thresh24) ? v3 * p.drop.inv_keep : 0.f;
+    bool k0, k1, k2, k3;   // (n0 % 4 == 0 and an even row length: e is even)
+    mrb_keep4(e, seed, p.drop.site, p.drop.thresh24, k0, k1, k2, k3);
+    v0 = k0 ? v0 * p.drop.inv_keep : 0.f;
+    v1 = k1 ? v1 * p.drop.inv_keep : 0.f;
+    v2 = k2 ? v2 * p.drop.inv_keep : 0.f;
+    v3 = k3 ? v3 * p.drop.inv_keep : 0.f;
   }
   if (p.residual) {
     const float4 r = *reinterpret_cast<const float4*>(p.residual + (long long)m * p.ldr + n0);
@@ -149,10 +151,12 @@ __device__ __forceinline__ void epilogue_apply4v(const GemmArgs& p, uint32_t see
   }
   if (p.drop.seed_ptr) {
     const uint32_t e = (uint32_t)m * (uint32_t)ncols + (uint32_t)n0;
-    v0 = mrb_keep(e, seed, p.drop.site, p.drop.thresh24) ? v0 * p.drop.inv_keep : 0.f;
-    v1 = mrb_keep(e + 1, seed, p.drop.site, p.drop.thresh24) ? v1 * p.drop.inv_keep : 0.f;
-    v2 = mrb_keep(e + 2, seed, p.drop.site, p.drop.thresh24) ? v2 * p.drop.inv_keep : 0.f;
-    v3 = mrb_keep(e + 3, seed, p.drop.site, p.drop.thresh24) ? v3 * p.drop.inv_keep : 0.f;
+    bool k0, k1, k2, k3;   // (n0 % 4 == 0 and an even row length: e is even)
+    mrb_keep4(e, seed, p.drop.site, p.drop.thresh24, k0, k1, k2, k3);
+    v0 = k0 ? v0 * p.drop.inv_keep : 0.f;
+    v1 = k1 ? v1 * p.drop.inv_keep : 0.f;
+    v2 = k2 ? v2 * p.drop.inv_keep : 0.f;
+    v3 = k3 ? v3 * p.drop.inv_keep : 0.f;
   }
   if (p.residual) { v0 += r.x; v1 += r.y; v2 += r.z; v3 += r.w; }
 }
@@ -199,8 +203,12 @@ __device__ __forceinline__ void epilogue_gated8(const GemmArgs& p, uint32_t seed
   }
   if (p.drop.seed_ptr) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
-      v[i] = mrb_keep((uint32_t)m * (uint32_t)nh + (uint32_t)(n0 + i), seed, p.drop.site, p.drop.thresh24) ? v[i] * p.drop.inv_keep : 0.f;
+    for (int i = 0; i < 8; i += 2) {   // (n0 % 8 == 0, nh even: pairs share a hash)
+      bool k0, k1;
+      mrb_keep2((uint32_t)m * (uint32_t)nh + (uint32_t)(n0 + i), seed, p.drop.site, p.drop.thresh24, k0, k1);
+      v[i] = k0 ? v[i] * p.drop.inv_keep : 0.f;
+      v[i + 1] = k1 ? v[i + 1] * p.drop.inv_keep : 0.f;
+    }
   }
   *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.out) + (long long)m * p.ldo + n0) =
       make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));

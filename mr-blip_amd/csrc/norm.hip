@@ -163,10 +163,12 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const float* __restrict__
         if (out_b) {  // the consumer's bf16 GEMM operand = dropout-backward(dx) (what a separate mrblip_cast_dropout launch would write)
           if (drop.seed_ptr) {
             const uint32_t base = (uint32_t)row * (uint32_t)D + (uint32_t)(4 * i);
-            o.x = mrb_keep(base, seed, drop.site, drop.thresh24) ? o.x * drop.inv_keep : 0.f;
-            o.y = mrb_keep(base + 1, seed, drop.site, drop.thresh24) ? o.y * drop.inv_keep : 0.f;
-            o.z = mrb_keep(base + 2, seed, drop.site, drop.thresh24) ? o.z * drop.inv_keep : 0.f;
-            o.w = mrb_keep(base + 3, seed, drop.site, drop.thresh24) ? o.w * drop.inv_keep : 0.f;
+            bool k0, k1, k2, k3;   // (D % 4 == 0: base is even)
+            mrb_keep4(base, seed, drop.site, drop.thresh24, k0, k1, k2, k3);
+            o.x = k0 ? o.x * drop.inv_keep : 0.f;
+            o.y = k1 ? o.y * drop.inv_keep : 0.f;
+            o.z = k2 ? o.z * drop.inv_keep : 0.f;
+            o.w = k3 ? o.w * drop.inv_keep : 0.f;
           }
           reinterpret_cast<uint2*>(out_b + (long long)row * ldob)[i] = make_uint2(pack2bf(o.x, o.y), pack2bf(o.z, o.w));
         }
