@@ -1764,7 +1764,7 @@ class MrBlipEngine:
             self._vit_stream.wait_event(start)
             F_ = next_video.shape[0] * next_video.shape[1]
             nb = c.vit_depth if self.vit_lookahead_blocks is None else max(1, min(c.vit_depth, int(self.vit_lookahead_blocks)))
-            nb = max(1, nb - int(self.vit_tail_blocks))
+            nb = max(1, nb - self._tail_blocks_for(F_))
             frames = next_video.reshape(F_, 3, c.img, c.img)
             b0 = 0
             for upto, reserve in self._reserve_schedule_for(F_):   # (first-leg blocks < upto run with `reserve` CUs left to the other streams)
@@ -1800,6 +1800,15 @@ class MrBlipEngine:
     vit_lookahead_early = os.environ.get("MRB_VIT_EARLY", "0") == "1"  # start beside the encoder forward instead of after it
 
     vit_tail_blocks = int(os.environ.get("MRB_VIT_TAIL", "5"))  # look-ahead blocks held back for prefetch_vit_tail()
+    _vit_tail_fixed = "MRB_VIT_TAIL" in os.environ
+
+    def _tail_blocks_for(self, frames: int) -> int:
+        """Blocks of the look-ahead held back for the Q-Former backward.  Measured at the end of round 4 (profiles/r04_vit_tail.txt, three
+        alternating sets): QVH 60 frames 5 / 6 / 7 / 8 blocks -> 67.40 / 67.26 / 67.09 / 67.30 ms; Charades-STA (20 frames) 5 / 7 -> 29.0 /
+        29.5 ms; ActivityNet (120) equal; QVH x 4 clips (240 frames) 237.9 / 238.9 ms.  7 around 60 frames, 5 elsewhere; MRB_VIT_TAIL pins it."""
+        if self._vit_tail_fixed:
+            return int(self.vit_tail_blocks)
+        return 7 if 40 <= int(frames) <= 80 else int(self.vit_tail_blocks)
 
     @torch.no_grad()
     def prefetch_vit_tail(self):
