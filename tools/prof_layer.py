@@ -54,6 +54,12 @@ def main(db, layer=12, back=2):
             return
         i1 = next((i for i in range(i0 + 1, len(mainq)) if until_pred and until_pred(mainq[i][0])), len(mainq))
         agg = defaultdict(lambda: [0, 0])
+        import os
+        if os.environ.get("PROF_ORDERED"):   # every launch of the phase in order (offset, duration, gap)
+            t0, prev = mainq[i0][1], mainq[i0][1]
+            for n, s, e, q, g in mainq[i0:i1]:
+                print(f"  +{(s - t0) / 1e3:8.1f} us  dur {(e - s) / 1e3:7.1f}  gap {max(0, s - prev) / 1e3:5.1f}  grid {g:8d}  {n[:90]}")
+                prev = e
         for n, s, e, q, g in mainq[i0:i1]:
             agg[(n[:70], g)][0] += 1
             agg[(n[:70], g)][1] += e - s
