@@ -707,6 +707,9 @@ __device__ __forceinline__ mrb_u32x4 gemm_load_piece(const void* ptr, uint32_t b
   return __builtin_amdgcn_raw_buffer_load_b128(r, voff, koff, 0);
 }
 
+#ifndef W4_STORE_AUX
+#define W4_STORE_AUX 0   // cache-policy bits of the 4-wave kernel's output stores (experiment: 2 = nt; measured)
+#endif
 #ifndef W4_GROUP_M
 #define W4_GROUP_M 8
 #endif
@@ -1004,11 +1007,11 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
         }
         if (OUT_F32) {
           const uint32_t off = ok ? (uint32_t)(((long long)m * p.ldo + n0) * 4) : 0x80000000u;
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(mrb_u32x4, mrb_f32x4{v[0], v[1], v[2], v[3]}), rout, off, 0, 0);
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(mrb_u32x4, mrb_f32x4{v[4], v[5], v[6], v[7]}), rout, off + 16u, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(mrb_u32x4, mrb_f32x4{v[0], v[1], v[2], v[3]}), rout, off, 0, W4_STORE_AUX);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(mrb_u32x4, mrb_f32x4{v[4], v[5], v[6], v[7]}), rout, off + 16u, 0, W4_STORE_AUX);
         } else {
           const uint32_t off = ok ? (uint32_t)(((long long)m * p.ldo + n0) * 2) : 0x80000000u;
-          __builtin_amdgcn_raw_buffer_store_b128(mrb_u32x4{pack2x<F16>(v[0], v[1]), pack2x<F16>(v[2], v[3]), pack2x<F16>(v[4], v[5]), pack2x<F16>(v[6], v[7])}, rout, off, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(mrb_u32x4{pack2x<F16>(v[0], v[1]), pack2x<F16>(v[2], v[3]), pack2x<F16>(v[4], v[5]), pack2x<F16>(v[6], v[7])}, rout, off, 0, W4_STORE_AUX);
         }
       }
     }
