@@ -259,17 +259,23 @@ __global__ __launch_bounds__(512) void dec_proj_kernel(const DecProjArgs p) {
           y[i + 1] = g1 * h[NH - 1][i + 1];
         }
         if (out_drop) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-            y[i] = mrb_keep((uint32_t)r * (uint32_t)p.N + (uint32_t)(n + i), seed, p.out_drop.site, p.out_drop.thresh24) ? y[i] * p.out_drop.inv_keep : 0.f;
+          bool kq0, kq1, kq2, kq3;   // (n % 4 == 0, N even: two pair hashes)
+          mrb_keep4((uint32_t)r * (uint32_t)p.N + (uint32_t)n, seed, p.out_drop.site, p.out_drop.thresh24, kq0, kq1, kq2, kq3);
+          y[0] = kq0 ? y[0] * p.out_drop.inv_keep : 0.f;
+          y[1] = kq1 ? y[1] * p.out_drop.inv_keep : 0.f;
+          y[2] = kq2 ? y[2] * p.out_drop.inv_keep : 0.f;
+          y[3] = kq3 ? y[3] * p.out_drop.inv_keep : 0.f;
         }
         *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + (long long)r * p.ldo + n) = make_uint2(pack2bf(y[0], y[1]), pack2bf(y[2], y[3]));
       } else {
         float y[4] = {h[0][0], h[0][1], h[0][2], h[0][3]};
         if (out_drop) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-            y[i] = mrb_keep((uint32_t)r * (uint32_t)p.N + (uint32_t)(n + i), seed, p.out_drop.site, p.out_drop.thresh24) ? y[i] * p.out_drop.inv_keep : 0.f;
+          bool kq0, kq1, kq2, kq3;   // (n % 4 == 0, N even: two pair hashes)
+          mrb_keep4((uint32_t)r * (uint32_t)p.N + (uint32_t)n, seed, p.out_drop.site, p.out_drop.thresh24, kq0, kq1, kq2, kq3);
+          y[0] = kq0 ? y[0] * p.out_drop.inv_keep : 0.f;
+          y[1] = kq1 ? y[1] * p.out_drop.inv_keep : 0.f;
+          y[2] = kq2 ? y[2] * p.out_drop.inv_keep : 0.f;
+          y[3] = kq3 ? y[3] * p.out_drop.inv_keep : 0.f;
         }
         if (MODE == 1) {
           if (p.residual) {
@@ -595,17 +601,23 @@ __global__ __launch_bounds__(512) void dec_proj2_kernel(const DecProjArgs p, con
             y[i + 1] = g1 * h[NTW - 1][i + 1];
           }
           if (out_drop) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-              y[i] = mrb_keep((uint32_t)r * (uint32_t)p.N + (uint32_t)(n + i), seed, p.out_drop.site, p.out_drop.thresh24) ? y[i] * p.out_drop.inv_keep : 0.f;
+            bool kq0, kq1, kq2, kq3;   // (n % 4 == 0, N even: two pair hashes)
+            mrb_keep4((uint32_t)r * (uint32_t)p.N + (uint32_t)n, seed, p.out_drop.site, p.out_drop.thresh24, kq0, kq1, kq2, kq3);
+            y[0] = kq0 ? y[0] * p.out_drop.inv_keep : 0.f;
+            y[1] = kq1 ? y[1] * p.out_drop.inv_keep : 0.f;
+            y[2] = kq2 ? y[2] * p.out_drop.inv_keep : 0.f;
+            y[3] = kq3 ? y[3] * p.out_drop.inv_keep : 0.f;
           }
           *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + (long long)r * p.ldo + n) = make_uint2(pack2bf(y[0], y[1]), pack2bf(y[2], y[3]));
         } else {
           float y[4] = {h[0][0], h[0][1], h[0][2], h[0][3]};
           if (out_drop) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-              y[i] = mrb_keep((uint32_t)r * (uint32_t)p.N + (uint32_t)(n + i), seed, p.out_drop.site, p.out_drop.thresh24) ? y[i] * p.out_drop.inv_keep : 0.f;
+            bool kq0, kq1, kq2, kq3;   // (n % 4 == 0, N even: two pair hashes)
+            mrb_keep4((uint32_t)r * (uint32_t)p.N + (uint32_t)n, seed, p.out_drop.site, p.out_drop.thresh24, kq0, kq1, kq2, kq3);
+            y[0] = kq0 ? y[0] * p.out_drop.inv_keep : 0.f;
+            y[1] = kq1 ? y[1] * p.out_drop.inv_keep : 0.f;
+            y[2] = kq2 ? y[2] * p.out_drop.inv_keep : 0.f;
+            y[3] = kq3 ? y[3] * p.out_drop.inv_keep : 0.f;
           }
           if (MODE == 1) {
             const f32x4 q = __builtin_bit_cast(f32x4, resq);   // zeros without a residual

@@ -312,9 +312,10 @@ __global__ __launch_bounds__(256) void lora_dx_add_kernel(void* __restrict__ dx_
       }
     }
     if (drop.seed_ptr) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        add[j] = mrb_keep((uint32_t)m * (uint32_t)K + (uint32_t)(k + j), seed, drop.site, drop.thresh24) ? add[j] * drop.inv_keep : 0.f;
+      bool kq0, kq1, kq2, kq3;   // (k % 4 == 0, K % 4 == 0: two pair hashes)
+      mrb_keep4((uint32_t)m * (uint32_t)K + (uint32_t)k, seed, drop.site, drop.thresh24, kq0, kq1, kq2, kq3);
+      add[0] = kq0 ? add[0] * drop.inv_keep : 0.f; add[1] = kq1 ? add[1] * drop.inv_keep : 0.f;
+      add[2] = kq2 ? add[2] * drop.inv_keep : 0.f; add[3] = kq3 ? add[3] * drop.inv_keep : 0.f;
     }
     if (DX_F32) {
       float4* p = reinterpret_cast<float4*>(reinterpret_cast<float*>(dx_) + (long long)m * lddx + k);
@@ -339,10 +340,15 @@ __global__ __launch_bounds__(256) void dropout_bf16_kernel(const bf16_t* __restr
     const int m = (int)(i / (N / 8)), c = (int)(i % (N / 8)) * 8;
     const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + (long long)m * ldx + c);
     float o[8];
+    bool kq[8] = {true, true, true, true, true, true, true, true};
+    if (drop.seed_ptr) {   // (c % 8 == 0, N % 8 == 0: element pairs share a hash)
+#pragma unroll
+      for (int j = 0; j < 8; j += 2) mrb_keep2((uint32_t)m * (uint32_t)N + (uint32_t)(c + j), seed, drop.site, drop.thresh24, kq[j], kq[j + 1]);
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       o[j] = bf2f((bf16_t)v[j]);
-      if (drop.seed_ptr) o[j] = mrb_keep((uint32_t)m * (uint32_t)N + (uint32_t)(c + j), seed, drop.site, drop.thresh24) ? o[j] * drop.inv_keep : 0.f;
+      if (drop.seed_ptr) o[j] = kq[j] ? o[j] * drop.inv_keep : 0.f;
     }
     *reinterpret_cast<uint4*>(out + (long long)m * ldo + c) = make_uint4(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7]));
   }
