@@ -72,7 +72,7 @@ struct GemmArgs {
   // rows each — write it with write-through stores and set th_flags[row block] = th_epoch; a tile waits for the flags of its rows before
   // it stages the K extension (its LAST K-tile) and reads Aext past its XCD's L2
   const bf16_t* th_A; long long th_lda; int th_R, th_K; DropoutArg th_drop; uint32_t* th_flags; uint32_t* th_err; uint32_t th_epoch; int th_blocks;
-  int role_base;    // block id of the first role workgroup: 0 (roles first) or the number of tile workgroups (roles last)
+  int pf_base, th_base, tile_base;   // first block id of the prefetch / thin / tile workgroups (launch_tile lays the three groups out)
   const void* pf_ptr; long long pf_n16; const void* pf_ptr2; long long pf_n16_2; int pf_blocks;   // (a second, usually small range: the LoRA K-extension operand)
 };
 
@@ -274,11 +274,12 @@ __global__ __launch_bounds__(WGM* WGN * 64, gemm_min_blocks(NS * (BM + BN) * BK 
   static_assert(!GATED || TN == 2, "gated epilogue pairs the wave's two n-tiles");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
-  // role workgroups (prefetch, then thin) sit either in FRONT of the tiles (role_base = 0: they are resident before any tile that waits for
-  // them) or BEHIND them (role_base = number of tile workgroups — only when the tiles leave CUs idle, e.g. 192 persistent tiles of the T5
-  // qkv projection: the roles then run on the idle CUs instead of delaying half of the tiles)
+  // role workgroups sit in FRONT of the tiles (resident before any tile that waits for them) or BEHIND them (only where the tiles leave
+  // workgroup slots idle, e.g. 192 persistent tiles of the T5 qkv projection: the roles then run on the idle CUs instead of delaying half
+  // of the tiles); the prefetch ones, which nothing waits for, may also sit behind a grid of several rounds and run in its last,
+  // partly empty round (launch_tile decides: pf_base / th_base / tile_base)
   const int pfb = p.pf_blocks;   // uniform
-  const int rid = (int)blockIdx.x - p.role_base;   // role index if in [0, pfb + th_blocks)
+  const int rid = (int)blockIdx.x - p.pf_base;   // prefetch index if in [0, pfb)
   if (rid >= 0 && rid < pfb) {   // prefetch role: stream a later launch's weights through the memory-side cache, keep nothing
     const mrb_u32x4* __restrict__ q = reinterpret_cast<const mrb_u32x4*>(p.pf_ptr);
     const long long step = (long long)pfb * (NW * 64);
@@ -299,8 +300,8 @@ __global__ __launch_bounds__(WGM* WGN * 64, gemm_min_blocks(NS * (BM + BN) * BK 
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int thb = p.th_blocks;   // uniform
-  if (rid >= pfb && rid < pfb + thb) {   // thin role: 16 rows of the K extension's A operand (see GemmArgs)
-    const int rb = rid - pfb;
+  const int rb = (int)blockIdx.x - p.th_base;
+  if (rb >= 0 && rb < thb) {   // thin role: 16 rows of the K extension's A operand (see GemmArgs)
     if (rb * 16 < p.M) {
       ThinArgs t;
       t.X = p.A; t.ldx = p.lda; t.A = p.th_A; t.lda = p.th_lda; t.U = const_cast<bf16_t*>(p.Aext); t.ldu = p.ldaext;
@@ -445,7 +446,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, gemm_min_blocks(NS * (BM + BN) * BK 
 #endif
   // ---- persistent tile loop: grid = resident blocks; a block's epilogue stores drain while it already stages the next tile
   const int ntiles = p.tiles_m * p.tiles_n;
-  for (int tile = (int)blockIdx.x - (p.role_base ? 0 : pfb + thb); tile < ntiles; tile += (int)gridDim.x - pfb - thb) {
+  for (int tile = (int)blockIdx.x - p.tile_base; tile < ntiles; tile += (int)gridDim.x - pfb - thb) {
   {  // tile id -> (bm, bn): XCD-contiguous remap (bijective), then grouped ordering for L2 reuse of the W panel
     int bid = tile;
     const int q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, idx = bid >> 3;
@@ -1604,6 +1605,11 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const GemmArgs p) 
   }
 }
 
+static bool pf_tail_enabled() {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("MRB_GEMM_PF_TAIL"); on = (e && e[0] == '1') ? 1 : 0; }
+  return on == 1;
+}
 static bool roles_last_enabled() {
   static int on = -1;
   if (on < 0) { const char* e = getenv("MRB_GEMM_ROLES_LAST"); on = (e && e[0] == '0') ? 0 : 1; }
@@ -1648,7 +1654,16 @@ static int launch_tile(GemmArgs& a, hipStream_t st) {
   // roles behind the tiles when the tiles leave at least 32 workgroup slots of the chip empty (the producers then start at once on the idle
   // CUs; a tile that reaches its K extension first polls until they are through)
   constexpr int per_cu = gemm_min_blocks(LDS, WGM * WGN);
-  a.role_base = (a.pf_blocks + a.th_blocks > 0 && grid + 32 <= num_cu * per_cu && roles_last_enabled()) ? grid : 0;
+  const int slots = num_cu * per_cu;
+  if (a.pf_blocks + a.th_blocks > 0 && grid + 32 <= slots && roles_last_enabled()) {   // tiles | prefetch | thin
+    a.tile_base = 0; a.pf_base = grid; a.th_base = grid + a.pf_blocks;
+  } else if (a.pf_blocks > 0 && grid == ntiles && grid > slots && pf_tail_enabled() && slots - (grid + a.th_blocks) % slots >= a.pf_blocks) {
+    // several rounds of one-tile workgroups with a partly empty last round: thin | tiles | prefetch — the prefetch workgroups start when
+    // the last round leaves slots free and end inside it (nothing waits for them)
+    a.th_base = 0; a.tile_base = a.th_blocks; a.pf_base = a.th_blocks + grid;
+  } else {                                                                               // prefetch | thin | tiles
+    a.pf_base = 0; a.th_base = a.pf_blocks; a.tile_base = a.pf_blocks + a.th_blocks;
+  }
   static_assert(LDS >= THIN_RED_BYTES(2), "the thin role's partial sums live in the tile's LDS");
   hipLaunchKernelGGL(kern, dim3(grid + a.pf_blocks + a.th_blocks), dim3(WGM * WGN * 64), LDS, st, a);
   return mrblip_check_launch("gemm_tile");
