@@ -54,8 +54,9 @@ def case(name, N, K, cfgs, gated=False, f32=False, tout=False):
     print(line, flush=True)
 
 
-case("qkv (bf16 + q/k/v^T)", 6144, 2048, CF or [0, 8, 2, 4, 1], tout=True)
-case("qkv (bf16, no copies)", 6144, 2048, CF or [0, 8, 12, 2, 4, 1])
-case("o (fp32 residual)", 2048, 2048, CF or [0, 4, 5, 2], f32=True)
-case("wi (gated)", 5120, 2048, CF or [0, 2, 4, 8, 1, 9], gated=True)
+if not os.environ.get("ONLY_WO"):
+  case("qkv (bf16 + q/k/v^T)", 6144, 2048, CF or [0, 8, 2, 4, 1], tout=True)
+  case("qkv (bf16, no copies)", 6144, 2048, CF or [0, 8, 12, 2, 4, 1])
+  case("o (fp32 residual)", 2048, 2048, CF or [0, 4, 5, 2], f32=True)
+  case("wi (gated)", 5120, 2048, CF or [0, 2, 4, 8, 1, 9], gated=True)
 case("wo (fp32 residual)", 2048, 5120, CF or [0, 4, 5, 2], f32=True)
