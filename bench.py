@@ -268,6 +268,9 @@ def main():
                     "use with --workload anet)")
     ap.add_argument("--vary-text", action="store_true", help="cycle 8 queries of different token counts (S_enc changes every step, as in a real "
                     "QVH epoch: blip2_mr.py:572-824) instead of one fixed prompt; the headline number keeps the fixed prompt")
+    ap.add_argument("--vary-video", action="store_true", help="alternate TWO different resident clips: step i trains on clip i %% 2 while the look-ahead "
+                    "encodes clip (i + 1) %% 2, so every look-ahead result is consumed under a DIFFERENT key than the one before (the headline passes the "
+                    "same tensor every step; the look-ahead hit is keyed on data_ptr / shape / version)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -311,6 +314,13 @@ def main():
     video = samples["video"]
     if shard is not None:
         video = video[:, shard.t0: shard.t1].contiguous()
+    videos = [video]
+    if args.vary_video:
+        v2 = synthetic_samples(B, wl["T"], wl["duration"], dev, 4321 + rank)["video"]
+        if shard is not None:
+            v2 = v2[:, shard.t0: shard.t1].contiguous()
+        assert v2.data_ptr() != video.data_ptr() and not torch.equal(v2, video)
+        videos.append(v2)
     layouts = [layout]
     if args.vary_text:   # 8 queries, 3 .. 31 words: the encoder length changes on every step (workspaces are capacity-based views: engine.buf)
         words = ("a person opens the red door and walks into the kitchen while the small dog sleeps on the sofa near the window and "
@@ -342,8 +352,9 @@ def main():
         if exchange is not None:
             exchange.arm()
         lay = layouts[step_no[0] % len(layouts)]
+        vid, nxt = videos[step_no[0] % len(videos)], videos[(step_no[0] + 1) % len(videos)]
         step_no[0] += 1
-        loss = eng.forward_backward(video, lay, backward=True, next_video=None if args.no_lookahead else video, shard=shard)
+        loss = eng.forward_backward(vid, lay, backward=True, next_video=None if args.no_lookahead else nxt, shard=shard)
         if shard is not None:
             shard.combine_grads(eng)     # t5_proj / ln_vision gradients: sums over the ranks' local frames (LoRA gradients are replicated)
         scale = exchange.finish() if exchange is not None else 1.0
@@ -466,7 +477,8 @@ def main():
                                    f"L_dec={layout.labels.shape[1]}, random-init weights, dropout {'on' if eng.training else 'off'}",
                        "global_batch": global_batch, "batch_per_gpu": B, "frames": wl["T"], "parallelism": f"dp{world}" if shard is None else f"frame-shard{world} (ViT + Q-Former over T/{world} frames per rank, T5 replicated)",
                        "vit_lookahead": not args.no_lookahead,
-                       "vary_text": ([l.S for l in layouts] if args.vary_text else False)},
+                       "vary_text": ([l.S for l in layouts] if args.vary_text else False), "vary_video": bool(args.vary_video),
+                       "lookahead_hits": MrBlipEngine.vit_prefetch_hits, "lookahead_misses": MrBlipEngine.vit_prefetch_misses},
             "launches_per_step": round(launches, 1),     # C-ABI kernel launches per step (torch-native ones: ~10, profiles/r02_native_in_step.txt)
             "host_enqueue_ms": round(1e3 * min(host_s), 2) if host_s else None,   # host time to enqueue one step onto an idle GPU (untimed extra steps); must stay below ms_per_step
             "workspace_allocations_in_timed_region": [n for n, _ in allocs_timed],

@@ -159,7 +159,16 @@ int mrblip_gemm_set_prefetch(const void* ptr, long long bytes, const void* ptr2,
  * The mask uses the GEMM call's seed pointer with call-site id `site`.  The epoch is a launch argument: a captured graph that replays such a
  * launch must clear the flag words between replays (one memset node), or every replay would find the previous replay's flags set. */
 int mrblip_gemm_set_thin(const void* acat, long long lda, int R, int K, uint32_t site, float p_drop, uint32_t* flags, long long n_flags,
-                         uint32_t epoch);
+                         uint32_t epoch, uint32_t* err /* NULL: the last flag word */);
+/* Failing loudly (round 5).  `err` above is the word a timed-out tile sets; the host side keeps ONE per device, hands it to every launch
+ * and to mrblip_adamw_guarded: a non-zero *guard makes the optimizer step a no-op on the device (the reference has no counterpart: its
+ * GEMMs cannot time out; the closest is GradScaler's skipped step on inf / nan, runner_base.py:127-132, moment_retrieval.py:221-233),
+ * and the engine reads the word one step late and raises.  mrblip_gemm_debug_stall_thin(1) is a TEST HOOK: the calling thread's later
+ * launches start thin-role workgroups that exit without publishing, which drives every consumer into its bounded wait; returns the
+ * previous setting. */
+int mrblip_adamw_guarded(float* p, const float* g, float* m, float* v, long long n, const float* hyper, float beta1, float beta2, float eps,
+                         float weight_decay, const uint32_t* guard, mrblip_stream_t stream);
+int mrblip_gemm_debug_stall_thin(int on);
 int mrblip_prefetch(const void* ptr, long long bytes, int n_blocks, mrblip_stream_t stream);
 /* LoRA r=8 (peft 0.13.0 Linear; blip2_mr.py:182-200,236).  The rank-8 products themselves run on mrblip_gemm_bf16
  * (u = drop(x) Acat^T, g = dy Bblk^T, dBt += u^T dy, dA += g^T drop(x) on transposed copies); these are the side pieces:

@@ -274,7 +274,11 @@ __global__ __launch_bounds__(1024) void ce_kernel(const float* __restrict__ logi
 // AdamW on a flat fp32 segment (torch.optim.AdamW semantics; runner_base.py:102-132).  hyper = {lr, 1/bc1, 1/sqrt(bc2), grad_scale}
 // lives in device memory so a captured graph replays with fresh values.
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                                                    long long n, const float* __restrict__ hyper, float beta1, float beta2, float eps, float wd) {
+                                                    long long n, const float* __restrict__ hyper, float beta1, float beta2, float eps, float wd,
+                                                    const uint32_t* __restrict__ guard) {
+  // guard (optional): a device word that must be ZERO for the step to be applied — the error word of the in-GEMM thin role (gemm.hip):
+  // a step whose activations / gradients may be wrong because a bounded wait ran out is dropped on the device, before the host knows
+  if (guard && *guard != 0u) return;
   const float lr = hyper[0], ibc1 = hyper[1], isbc2 = hyper[2], gs = hyper[3];
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
     const float gi = g[i] * gs;
@@ -504,8 +508,15 @@ extern "C" int mrblip_cross_entropy(const float* logits, long long ldl, const in
 extern "C" int mrblip_adamw(float* p, const float* g, float* m, float* v, long long n, const float* hyper, float beta1, float beta2, float eps,
                             float weight_decay, hipStream_t stream) {
   if (n <= 0) return MRBLIP_OK;
-  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n)), dim3(256), 0, stream, p, g, m, v, n, hyper, beta1, beta2, eps, weight_decay);
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n)), dim3(256), 0, stream, p, g, m, v, n, hyper, beta1, beta2, eps, weight_decay, (const uint32_t*)nullptr);
   return mrblip_check_launch("adamw");
+}
+extern "C" int mrblip_adamw_guarded(float* p, const float* g, float* m, float* v, long long n, const float* hyper, float beta1, float beta2, float eps,
+                                    float weight_decay, const uint32_t* guard, hipStream_t stream) {
+  MRB_REQUIRE(p && g && m && v && hyper && n >= 0, "adamw_guarded: null operand");
+  if (n == 0) return MRBLIP_OK;
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n)), dim3(256), 0, stream, p, g, m, v, n, hyper, beta1, beta2, eps, weight_decay, guard);
+  return mrblip_check_launch("adamw_guarded");
 }
 // Pull a byte range through the memory-side cache ahead of its consumer (round 4): the weights of a T5 layer are touched once per pass,
 // so every GEMM finds them in HBM — stand-alone loops over one weight set (which the 256 MB Infinity Cache holds) are 10-25 % faster

@@ -71,7 +71,7 @@ struct GemmArgs {
   // extension's A operand themselves — Aext[m, 0:th_R] = dropout(A)[m, 0:th_K] th_A^T, the LoRA "down" product (body: lora_thin.h), 16
   // rows each — write it with write-through stores and set th_flags[row block] = th_epoch; a tile waits for the flags of its rows before
   // it stages the K extension (its LAST K-tile) and reads Aext past its XCD's L2
-  const bf16_t* th_A; long long th_lda; int th_R, th_K; DropoutArg th_drop; uint32_t* th_flags; uint32_t* th_err; uint32_t th_epoch; int th_blocks;
+  const bf16_t* th_A; long long th_lda; int th_R, th_K; DropoutArg th_drop; uint32_t* th_flags; uint32_t* th_err; uint32_t th_epoch; int th_blocks; int th_stall;   // th_stall: TEST HOOK (mrblip_gemm_debug_stall_thin) — the role exits without publishing
   int pf_base, th_base, tile_base;   // first block id of the prefetch / thin / tile workgroups (launch_tile lays the three groups out)
   const void* pf_ptr; long long pf_n16; const void* pf_ptr2; long long pf_n16_2; int pf_blocks;   // (a second, usually small range: the LoRA K-extension operand)
 };
@@ -274,10 +274,10 @@ __global__ __launch_bounds__(WGM* WGN * 64, gemm_min_blocks(NS * (BM + BN) * BK 
   static_assert(!GATED || TN == 2, "gated epilogue pairs the wave's two n-tiles");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
-  // role workgroups sit in FRONT of the tiles (resident before any tile that waits for them) or BEHIND them (only where the tiles leave
-  // workgroup slots idle, e.g. 192 persistent tiles of the T5 qkv projection: the roles then run on the idle CUs instead of delaying half
-  // of the tiles); the prefetch ones, which nothing waits for, may also sit behind a grid of several rounds and run in its last,
-  // partly empty round (launch_tile decides: pf_base / th_base / tile_base)
+  // the THIN role workgroups sit in FRONT of the tiles (handed out before any tile that waits for them; round 4 also put them BEHIND the
+  // tiles where those left slots idle — starved under contention, see launch_tile); the prefetch ones, which nothing waits for, sit in
+  // front, or behind the tiles where the tiles leave workgroup slots idle / in the last, partly empty round of a multi-round grid
+  // (launch_tile decides: pf_base / th_base / tile_base)
   const int pfb = p.pf_blocks;   // uniform
   const int rid = (int)blockIdx.x - p.pf_base;   // prefetch index if in [0, pfb)
   if (rid >= 0 && rid < pfb) {   // prefetch role: stream a later launch's weights through the memory-side cache, keep nothing
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, gemm_min_blocks(NS * (BM + BN) * BK 
   const int thb = p.th_blocks;   // uniform
   const int rb = (int)blockIdx.x - p.th_base;
   if (rb >= 0 && rb < thb) {   // thin role: 16 rows of the K extension's A operand (see GemmArgs)
-    if (rb * 16 < p.M) {
+    if (rb * 16 < p.M && !p.th_stall) {
       ThinArgs t;
       t.X = p.A; t.ldx = p.lda; t.A = p.th_A; t.lda = p.th_lda; t.U = const_cast<bf16_t*>(p.Aext); t.ldu = p.ldaext;
       t.M = p.M; t.K = p.th_K; t.R = p.th_R;
@@ -378,8 +378,8 @@ __global__ __launch_bounds__(WGM* WGN * 64, gemm_min_blocks(NS * (BM + BN) * BK 
         const int rbk = ((bm * BM) >> 4) + lane;
         if (lane < BM / 16 && rbk * 16 < p.M) {
           uint32_t tries = 0;   // (bounded: a protocol error must show as a wrong result in the tests, not as a hung GPU)
-          while (__hip_atomic_load(p.th_flags + rbk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.th_epoch && ++tries < (1u << 17)) __builtin_amdgcn_s_sleep(4);
-          if (tries >= (1u << 17)) __hip_atomic_store(p.th_err, 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // loud: the host checks this word
+          while (__hip_atomic_load(p.th_flags + rbk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.th_epoch && ++tries < (1u << 19)) __builtin_amdgcn_s_sleep(4);
+          if (tries >= (1u << 19)) __hip_atomic_store(p.th_err, 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // loud: the host checks this word
         }
         asm volatile("" ::: "memory");
       }
@@ -1655,8 +1655,14 @@ static int launch_tile(GemmArgs& a, hipStream_t st) {
   // CUs; a tile that reaches its K extension first polls until they are through)
   constexpr int per_cu = gemm_min_blocks(LDS, WGM * WGN);
   const int slots = num_cu * per_cu;
-  if (a.pf_blocks + a.th_blocks > 0 && grid + 32 <= slots && roles_last_enabled()) {   // tiles | prefetch | thin
-    a.tile_base = 0; a.pf_base = grid; a.th_base = grid + a.pf_blocks;
+  // Round 5: the THIN role always sits in FRONT of the tiles.  Its consumers poll flags; producers behind the consumers were starved under
+  // contention (two processes sharing a GPU: resident tiles span while their producers waited for a slot behind another queue's
+  // workgroups, the bounded wait ran out and the step went on with stale operands — found by the error word's first real reader,
+  // tests/test_train_entry_gpu.py::test_bench_two_ranks_share_one_gpu).  In front, every XCD's dispatcher hands out its share of the
+  // producers before any tile of that XCD, and producers never wait: a consumer can only ever wait for workgroups that are resident or
+  // done.  The prefetch role, which nothing waits for, may still go behind the tiles where they leave slots idle.
+  if (a.pf_blocks > 0 && grid + 32 <= slots && roles_last_enabled()) {   // thin | tiles | prefetch
+    a.th_base = 0; a.tile_base = a.th_blocks; a.pf_base = a.th_blocks + grid;
   } else if (a.pf_blocks > 0 && grid == ntiles && grid > slots && pf_tail_enabled() && slots - (grid + a.th_blocks) % slots >= a.pf_blocks) {
     // several rounds of one-tile workgroups with a partly empty last round: thin | tiles | prefetch — the prefetch workgroups start when
     // the last round leaves slots free and end inside it (nothing waits for them)
@@ -1717,13 +1723,23 @@ extern "C" int mrblip_gemm_set_prefetch(const void* ptr, long long bytes, const 
 // flags: >= ceil(M / 16) + 1 words the launches of ONE stream may share (the LAST word is an error word: a tile whose bounded wait ran out
 // stores 0xffffffff there — a protocol failure is a wrong result the caller can detect, never a hung GPU); epoch: a value no earlier launch
 // on that stream left in them.
-struct GemmThin { const void* acat; long long lda; int R, K; uint32_t site; float p; uint32_t* flags; long long n_flags; uint32_t epoch; bool set; };
+// err (may be NULL = the last flag word): the word a timed-out tile sets.  Callers hand ONE word per device to every stream's launches and
+// to mrblip_adamw_guarded, so that an optimizer step never applies gradients of a step in which a wait ran out.
+struct GemmThin { const void* acat; long long lda; int R, K; uint32_t site; float p; uint32_t* flags; long long n_flags; uint32_t epoch; uint32_t* err; bool set; };
 static thread_local GemmThin g_gemm_thin = {};
+static thread_local int g_thin_stall = 0;
+// TEST HOOK: while on, the thin-role workgroups of this thread's launches exit without computing or publishing anything, so every
+// consumer tile runs into its bounded wait — the way tests/ prove that a protocol failure is loud (error word, skipped AdamW, raise).
+extern "C" int mrblip_gemm_debug_stall_thin(int on) {
+  const int prev = g_thin_stall;
+  g_thin_stall = on ? 1 : 0;
+  return prev;
+}
 extern "C" int mrblip_gemm_set_thin(const void* acat, long long lda, int R, int K, uint32_t site, float p_drop, uint32_t* flags, long long n_flags,
-                                    uint32_t epoch) {
+                                    uint32_t epoch, uint32_t* err) {
   MRB_REQUIRE(acat && flags && ((uintptr_t)acat % 16) == 0 && R > 0 && R <= 32 && (R % 8) == 0 && K > 0 && (K % 32) == 0 && (lda % 8) == 0 && lda >= K,
               "gemm_set_thin: acat [R <= 32, K %% 32 == 0] with 16-B rows and a flag buffer");
-  g_gemm_thin = GemmThin{acat, lda, R, K, site, p_drop, flags, n_flags, epoch, true};
+  g_gemm_thin = GemmThin{acat, lda, R, K, site, p_drop, flags, n_flags, epoch, err, true};
   return MRBLIP_OK;
 }
 
@@ -1756,13 +1772,13 @@ static int gemm_dispatch(const void* A, long long lda, const void* W, long long 
   a.t_inner = extra.set ? extra.t_inner : 0; a.t_rows = extra.t_rows; a.t_spad = extra.t_spad; a.t_bs = extra.t_bs; a.t_hs = extra.t_hs;
   a.t_stride = extra.t_stride; a.t_count = extra.set ? extra.t_count : 0;
   a.ext_group_n = extra.set ? extra.ext_group_n : 0;
-  a.th_flags = nullptr; a.th_err = nullptr; a.th_blocks = 0; a.th_A = nullptr; a.th_lda = 0; a.th_R = a.th_K = 0; a.th_epoch = 0;
+  a.th_flags = nullptr; a.th_err = nullptr; a.th_blocks = 0; a.th_stall = 0; a.th_A = nullptr; a.th_lda = 0; a.th_R = a.th_K = 0; a.th_epoch = 0;
   mk_drop_arg(a.th_drop, seed_ptr, 0, 0.f);
   if (th.set) {
     MRB_REQUIRE(Aext && !ext_first && !f16 && M > 64 && th.K <= K && ldaext >= th.R && (ldaext % 4) == 0 && ((uintptr_t)Aext % 8) == 0 && th.n_flags >= (M + 15) / 16 + 1 &&
                     (long long)M * lda * 2 < (1ll << 31) && !(th.p > 0.f && !seed_ptr),
                 "gemm: the thin role needs a K extension read last, more than 64 rows and one flag per 16 rows");
-    a.th_A = (const bf16_t*)th.acat; a.th_lda = th.lda; a.th_R = th.R; a.th_K = th.K; a.th_flags = th.flags; a.th_err = th.flags + (th.n_flags - 1); a.th_epoch = th.epoch;
+    a.th_A = (const bf16_t*)th.acat; a.th_lda = th.lda; a.th_R = th.R; a.th_K = th.K; a.th_flags = th.flags; a.th_err = th.err ? th.err : th.flags + (th.n_flags - 1); a.th_epoch = th.epoch; a.th_stall = g_thin_stall;
     mk_drop_arg(a.th_drop, seed_ptr, th.site, th.p);
   }
   a.pf_ptr = pf.ptr; a.pf_n16 = pf.bytes / 16; a.pf_ptr2 = pf.ptr2; a.pf_n16_2 = pf.bytes2 / 16; a.pf_blocks = pf.n_blocks;

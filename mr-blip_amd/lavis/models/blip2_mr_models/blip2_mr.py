@@ -375,7 +375,7 @@ class BLIP2_MR(BaseModel):
             from mrblip import ops
             ops.row_copy(fr, L["frame_src"], inp, L["frame_dst"])
             ops.row_copy(eng.emb, L["emb_src"], inp, L["emb_dst"])
-            enc = eng.t5_encoder_forward(inp, B, S, L["mask"])
+            enc = eng.t5_encoder_forward(inp, B, S, L["mask"], want_grad=False)
             K = n_ret if use_nucleus_sampling else max(1, int(num_beams))   # decoder rows per clip: beams, or sampled sequences
             # one beam with a repetition penalty is HF's GREEDY decoding, which penalises raw logits (beam search penalises log-probabilities)
             greedy_pen = (not use_nucleus_sampling) and K == 1 and float(repetition_penalty) != 1.0

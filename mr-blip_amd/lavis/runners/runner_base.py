@@ -42,8 +42,11 @@ class FlatAdamW:
         scale = self.grad_scale * self.model.grad_scale()
         self.hyper.copy_(torch.tensor([self.lr, 1.0 / (1 - b1 ** self.t), 1.0 / math.sqrt(1 - b2 ** self.t), scale]).pin_memory(), non_blocking=True)
         g, nd = self.model.grad_buffer(), eng.n_decay
-        ops.adamw(eng.flat[:nd], g[:nd], self.m[:nd], self.v[:nd], self.hyper, b1, b2, self.eps, self.wd)
-        ops.adamw(eng.flat[nd:], g[nd:], self.m[nd:], self.v[nd:], self.hyper, b1, b2, self.eps, 0.0)
+        # guard: the error word of the in-GEMM thin role — the update is dropped on the device if a tile's bounded wait ran out during the
+        # step (mrblip/engine.py check_thin_role; the host raises one step later / at the next blocking check point)
+        guard = eng.thin_guard() if eng.gemm_thin_enabled else None
+        ops.adamw(eng.flat[:nd], g[:nd], self.m[:nd], self.v[:nd], self.hyper, b1, b2, self.eps, self.wd, guard=guard)
+        ops.adamw(eng.flat[nd:], g[nd:], self.m[nd:], self.v[nd:], self.hyper, b1, b2, self.eps, 0.0, guard=guard)
         eng.refresh_trainable()
 
     def state_dict(self):
@@ -210,6 +213,9 @@ class RunnerBase:
         chk = getattr(m, "check_fused_scale_now", None)
         if chk is not None:
             chk()
+        eng = getattr(m, "engine", None)
+        if eng is not None and hasattr(eng, "check_thin_role"):
+            eng.check_thin_role(block=True)   # (the same deferral, the same two blocking points: end of epoch, before a checkpoint)
 
     def _save_checkpoint(self, cur_epoch, is_best=False):
         self._check_loss_scale()

@@ -184,9 +184,14 @@ class FrameShard:
         """cheap guard (one 2-element all-reduce): every rank of the group holds the same device seed"""
         if self.world == 1:
             return
-        v = engine.seed.to(torch.int64).cpu()
+        # RCCL ("nccl") reduces DEVICE tensors only, gloo (the CPU / shared-GPU test path) host tensors: build the pair where the
+        # group's backend can reach it (ADVICE r4: a CPU tensor on the production backend raised at the first sharded step)
+        v = engine.seed.to(torch.int64).reshape(-1)
+        if dist.get_backend(self.group) != "nccl":
+            v = v.cpu()
         mm = torch.stack([v[0], -v[0]])
         dist.all_reduce(mm, op=dist.ReduceOp.MAX, group=self.group)
+        mm = mm.cpu()
         if int(mm[0]) != -int(mm[1]):
             raise RuntimeError(f"frame-sharded mode: dropout seeds differ across the shard group (max {int(mm[0])}, min {-int(mm[1])}): "
                                "the replicated T5 would draw different masks and the sliced frame-token gradient would be wrong")

@@ -1142,8 +1142,9 @@ class MrBlipEngine:
 
     # ---- encoder ---------------------------------------------------------------------------------------------
     @torch.no_grad()
-    def t5_encoder_forward(self, x0: torch.Tensor, B: int, S: int, kmask: torch.Tensor) -> torch.Tensor:
-        """x0 fp32 [B*S, d] (inputs_embeds).  Returns bf16 encoder output [B*S, d]."""
+    def t5_encoder_forward(self, x0: torch.Tensor, B: int, S: int, kmask: torch.Tensor, want_grad: bool = True) -> torch.Tensor:
+        """x0 fp32 [B*S, d] (inputs_embeds).  Returns bf16 encoder output [B*S, d].  want_grad=False (eval / generate): the per-layer
+        Q^T / K^T copies that only the backward reads (~400 MB at S = 2012, XL) are neither allocated nor written."""
         c = self.cfg
         d, H, dk, ff, p = c.d_model, c.t5_heads, c.d_kv, c.d_ff, c.t5_dropout
         inner = H * dk
@@ -1151,17 +1152,18 @@ class MrBlipEngine:
         x = self.buf("e_x0", (M, d), f32, zero=False)
         ops.cast_dropout(x0, out_f32=x, drop=self.drop(self.t5["sites"][0], p))
         vt = self.buf("e_vt", (B, H, ops.rup32(dk), ops.rup32(S)), bf16)
+        self.enc_t_saved.clear()     # (sticky flags a later backward trusts: reset by every forward)
         for i, L in enumerate(self.t5["enc"]):
             xn = self.buf(f"e{i}_xn", (M, pad64(d)), bf16)
             u = self.buf(f"e{i}_u_qkv", (M, 64), bf16)
             qkv = self.buf(f"e{i}_qkv", (M, 3 * inner), bf16, zero=False)
             # (round 4: the projection's epilogue writes V^T for this layer's attention and Q^T / K^T for its backward)
             t_ok = self.tout_ok(dk, B, S)
-            qt_i = self.buf(f"e{i}_qt", (B, H, 64, ops.rup32(S)), bf16) if t_ok else None
-            kt_i = self.buf(f"e{i}_kt", (B, H, 64, ops.rup32(S)), bf16) if t_ok else None
+            qt_i = self.buf(f"e{i}_qt", (B, H, 64, ops.rup32(S)), bf16) if (t_ok and want_grad) else None
+            kt_i = self.buf(f"e{i}_kt", (B, H, 64, ops.rup32(S)), bf16) if (t_ok and want_grad) else None
             t_done = self.norm_lg_fwd(x, L["ln0"], L["qkv"], xn, u, qkv, tile_cfg=_ENC_FWD_CFG[0], tout=(qt_i, kt_i, vt) if t_ok else None, t_rows=S,
                                       prefetch=self.enc_pf([L["o"], L["wi"]] if self.enc_pf_plan == 0 else [L["o"]], M))
-            self.enc_t_saved[i] = bool(t_done)
+            self.enc_t_saved[i] = bool(t_done) and want_grad
             q4, k4, v4 = self.v4(qkv, B, S, H, dk, 0), self.v4(qkv, B, S, H, dk, inner), self.v4(qkv, B, S, H, dk, 2 * inner)
             if not t_done:
                 ops.head_transpose(v4, out=vt)
@@ -1869,6 +1871,7 @@ class MrBlipEngine:
         if sharded:
             assert Bv == 1 and T == shard.counts[shard.rank], "frame-sharded mode: one clip, this rank's frames only"
             shard.attach(self)   # (first step only) one dropout stream for the group's replicated T5, per-rank Q-Former call sites
+        self.check_thin_role(block=False)   # verdict of an EARLIER step, if it has arrived (raises; see check_thin_role)
         if self.training:
             ops.seed_bump(self.seed)
         # round 4: the decoder's streaming projections run as many blocks as the look-ahead ViT leaves CUs (one round of resident blocks;
@@ -1897,13 +1900,15 @@ class MrBlipEngine:
         kmask = L["mask"]
         if next_video is not None and self.vit_lookahead_early:
             self.prefetch_vit(next_video)
-        enc = self.t5_encoder_forward(inp, Bv, S, kmask)
+        enc = self.t5_encoder_forward(inp, Bv, S, kmask, want_grad=backward)
         self._mark("t5_encoder_forward")
         if next_video is not None and not self.vit_lookahead_early:
             self.prefetch_vit(next_video)
         loss, logits = self.t5_decoder_forward(layout.decoder_input_ids, layout.decoder_mask, enc, Bv, S, kmask, layout.labels, want_grad=backward)
         self._mark("t5_decoder_forward + loss")
         if not backward:
+            if self.gemm_thin_enabled:
+                self._post_thin_check()
             return loss
         Ld = layout.labels.shape[1]
         denc = self.t5_decoder_backward(enc, Bv, S, Ld, kmask, layout.decoder_mask)
@@ -1944,6 +1949,8 @@ class MrBlipEngine:
         self._mark("t5_proj + Q-Former backward")
         if self.grad_ready_hook is not None:
             self.grad_ready_hook("all")
+        if self.gemm_thin_enabled:
+            self._post_thin_check()   # (at the END of the step: an event record between two kernels costs a dispatch bubble)
         return loss
 
     def _mark(self, name: str):
@@ -2010,14 +2017,55 @@ class MrBlipEngine:
     def zero_grad(self):
         self.grad.zero_()
 
+    # ---- the in-GEMM thin role must fail LOUDLY (VERDICT r4 weak 3 / ADVICE r4).  A consumer tile of csrc/gemm.hip whose bounded wait
+    # for its producer workgroups runs out continues with whatever the K-extension operand holds and sets the device's error word
+    # (ops.thin_error_word).  Three things follow from that word: (i) the fused AdamW takes it as its guard — a step whose activations may be
+    # wrong is never applied, decided on the device; (ii) its value travels to pinned host memory behind every step and is read ONE STEP
+    # LATE (no stream drain: the same trick as the deferred loss-scale check, blip2_mr.py _check_fused_scale) — a set word raises; (iii) the
+    # runner's blocking check points (end of epoch, before every checkpoint) call check_thin_role(block=True).
+    _thin_host = None
+    _thin_event = None
+
+    def thin_guard(self) -> torch.Tensor:
+        return ops.thin_error_word(self.dev)
+
+    def _post_thin_check(self):
+        """enqueue the error word's copy to the host behind everything this step launched"""
+        if self._thin_host is None:
+            self._thin_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self._thin_host.copy_(self.thin_guard(), non_blocking=True)
+        self._thin_event = torch.cuda.Event()
+        self._thin_event.record()
+
+    def check_thin_role(self, block: bool = False):
+        ev = self._thin_event
+        if ev is None:
+            if block and self.gemm_thin_enabled:
+                self._post_thin_check()
+                ev = self._thin_event
+            else:
+                return
+        if block:
+            ev.synchronize()
+        elif not ev.query():
+            return
+        self._thin_event = None
+        if int(self._thin_host[0]) != 0:
+            raise ops.MrblipError(
+                "a tile GEMM's bounded wait for its in-launch thin-role workgroups (the LoRA 'down' product, csrc/gemm.hip) ran out: the "
+                "step's encoder activations and LoRA gradients may be wrong.  The guarded AdamW has skipped every optimizer step since; "
+                "set MRB_GEMM_THIN=0 (the thin product as a launch of its own) to run without the role, and report the configuration")
+
     @torch.no_grad()
     def optimizer_step(self, lr: float, weight_decay: float = 0.05, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8,
                        grad_scale: float = 1.0):
-        """AdamW(beta=(0.9,0.999), wd on >=2-D non-bias/ln params) as in runner_base.py:102-132."""
+        """AdamW(beta=(0.9,0.999), wd on >=2-D non-bias/ln params) as in runner_base.py:102-132.  Guarded by the thin role's error word: see
+        check_thin_role."""
         self.opt_step += 1
         t = self.opt_step
         self.hyper.copy_(torch.tensor([lr, 1.0 / (1 - beta1 ** t), 1.0 / math.sqrt(1 - beta2 ** t), grad_scale], dtype=f32).pin_memory(), non_blocking=True)
         nd = self.n_decay
-        ops.adamw(self.flat[:nd], self.grad[:nd], self.adam_m[:nd], self.adam_v[:nd], self.hyper, beta1, beta2, eps, weight_decay)
-        ops.adamw(self.flat[nd:], self.grad[nd:], self.adam_m[nd:], self.adam_v[nd:], self.hyper, beta1, beta2, eps, 0.0)
+        guard = self.thin_guard() if self.gemm_thin_enabled else None
+        ops.adamw(self.flat[:nd], self.grad[:nd], self.adam_m[:nd], self.adam_v[:nd], self.hyper, beta1, beta2, eps, weight_decay, guard=guard)
+        ops.adamw(self.flat[nd:], self.grad[nd:], self.adam_m[nd:], self.adam_v[nd:], self.hyper, beta1, beta2, eps, 0.0, guard=guard)
         self.refresh_trainable()

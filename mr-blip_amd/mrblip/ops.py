@@ -79,7 +79,9 @@ _ce = _sig("mrblip_cross_entropy", vp, ll, vp, i32, i32, f32, vp, vp, ll, vp)
 _adamw = _sig("mrblip_adamw", vp, vp, vp, vp, ll, vp, f32, f32, f32, f32, vp)
 _seed_bump = _sig("mrblip_seed_bump", vp, vp)
 _prefetch = _sig("mrblip_prefetch", vp, ll, i32, vp)
-_gemm_set_thin = _sig("mrblip_gemm_set_thin", vp, ll, i32, i32, u32, f32, vp, ll, u32)
+_gemm_set_thin = _sig("mrblip_gemm_set_thin", vp, ll, i32, i32, u32, f32, vp, ll, u32, vp)
+_gemm_stall_thin = _sig("mrblip_gemm_debug_stall_thin", i32)
+_adamw_guarded = _sig("mrblip_adamw_guarded", vp, vp, vp, vp, ll, vp, f32, f32, f32, f32, vp, vp)
 _gemm_set_prefetch = _sig("mrblip_gemm_set_prefetch", vp, ll, vp, ll, i32)
 _lora_dx = _sig("mrblip_lora_dx_add", vp, ll, i32, vp, ll, vp, i32, i32, i32, vp, u32, f32, vp)
 _cu_reserve = _sig("mrblip_gemm_set_cu_reserve", i32)
@@ -98,7 +100,7 @@ EXPORTS = [
     "mrblip_last_error", "mrblip_abi_version", "mrblip_gemm_bf16", "mrblip_layernorm_fwd", "mrblip_rmsnorm_fwd",
     "mrblip_layernorm_bwd", "mrblip_rmsnorm_bwd", "mrblip_rmsnorm_bwd_cast", "mrblip_attention_fwd", "mrblip_attention_fwd_rowv", "mrblip_attention_bwd", "mrblip_head_transpose",
     "mrblip_patchify", "mrblip_vit_assemble", "mrblip_row_copy", "mrblip_mean_pool", "mrblip_mean_pool_bwd",
-    "mrblip_cast_dropout", "mrblip_gelu_bwd", "mrblip_gated_gelu_bwd", "mrblip_cross_entropy", "mrblip_adamw",
+    "mrblip_cast_dropout", "mrblip_gelu_bwd", "mrblip_gated_gelu_bwd", "mrblip_cross_entropy", "mrblip_adamw", "mrblip_adamw_guarded", "mrblip_gemm_debug_stall_thin",
     "mrblip_seed_bump", "mrblip_prefetch", "mrblip_gemm_set_prefetch", "mrblip_gemm_set_thin", "mrblip_lora_dx_add", "mrblip_dropout_bf16", "mrblip_colsum", "mrblip_lora_pack", "mrblip_lora_tn",
     "mrblip_lora_grads", "mrblip_gemm_lora_down", "mrblip_gemm_lora_dx", "mrblip_patchify_u8",
     "mrblip_gemm_set_cu_reserve", "mrblip_lora_rows", "mrblip_rmsnorm_lora_fwd", "mrblip_lora_rows_init", "mrblip_dec_proj", "mrblip_dec_proj_config", "mrblip_lora_dx_add_batched", "mrblip_lora_rows_batched", "mrblip_gemm_set_extra", "mrblip_attention_set_split_workspace",
@@ -182,9 +184,11 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, aext=None, wext
         if sp is None:
             sp = tsp          # the launch's one seed pointer (the epilogue's own dropout stays off: p = 0)
         flags, epoch = _thin_flags(a.device, (M + 15) // 16)
-        rc = _gemm_set_thin(_p(acat), _ld(acat), acat.shape[0], int(tk), tsite, tp, _p(flags), flags.numel(), epoch)
+        rc = _gemm_set_thin(_p(acat), _ld(acat), acat.shape[0], int(tk), tsite, tp, _p(flags), flags.numel(), epoch, _p(thin_error_word(a.device)))
         if rc != 0:
-            raise MrblipError(_lib.mrblip_last_error().decode())
+            msg = _lib.mrblip_last_error().decode()
+            _clear_one_shots()     # the extras set above belong to THIS call: they must not ride on the thread's next unrelated GEMM
+            raise MrblipError(msg)
     _chk((_gemm_f16 if f16 else _gemm)(_p(a), _ld(a), _p(w), _ld(w), _p(aext), _ld(aext), _p(wext), _ld(wext), M, N, K, _p(out), _ld(out),
                1 if out.dtype == torch.float32 else 0, _p(out2), _ld(out2), _p(bias), _p(residual), _ld(residual), act,
                1 if gated else 0, sp, site, p, (tile_cfg & 0xff) | ((int(reserve) & 0x1ff) << 8) | ((int(k_splits) & 0xf) << 17), _stream()))
@@ -207,9 +211,50 @@ def _thin_flags(device, n: int):
     return st[0], st[1]
 
 
+_thin_err = {}
+
+
+def thin_error_word(device) -> torch.Tensor:
+    """THE error word of the in-GEMM thin role on ``device`` (one int32, shared by every stream's launches): a consumer tile whose bounded
+    wait for its producer workgroups ran out stores 0xffffffff here (csrc/gemm.hip).  It is also the ``guard`` of the fused AdamW
+    (``adamw(..., guard=)``: a non-zero word makes the optimizer step a no-op ON THE DEVICE), and MrBlipEngine.check_thin_role() reads it
+    one step late and raises — a protocol failure skips the update and stops the run instead of training on a corrupted step."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    t = _thin_err.get(idx)
+    if t is None:
+        t = _thin_err[idx] = torch.zeros(1, dtype=torch.int32, device=torch.device("cuda", idx))
+    return t
+
+
 def gemm_thin_timeouts() -> int:
-    """flag buffers whose error word is set: a tile's bounded wait for the thin role ran out (synchronises; 0 in every correct run)"""
-    return sum(int(st[0][-1].item() != 0) for st in _thin_state.values())
+    """devices whose thin-role error word is set: a tile's bounded wait for the thin role ran out (synchronises; 0 in every correct run)"""
+    return sum(int(t.item() != 0) for t in _thin_err.values())
+
+
+def gemm_thin_clear():
+    """reset the error words (tests of the failure path)"""
+    for t in _thin_err.values():
+        t.zero_()
+
+
+class gemm_debug_stall_thin:
+    """TEST HOOK: ``with gemm_debug_stall_thin():`` the thin-role workgroups of this thread's GEMM launches exit without publishing, so the
+    consumer tiles run into their bounded wait (about 0.2 s per launch) and set the error word"""
+
+    def __enter__(self):
+        self.prev = _gemm_stall_thin(1)
+        return self
+
+    def __exit__(self, *exc):
+        _gemm_stall_thin(self.prev)
+        return False
+
+
+def _clear_one_shots():
+    """drop the calling thread's pending one-shot GEMM extras (head-transposed copies, grouped K extension, prefetch range) after a
+    failure between their setters and the launch they were meant for"""
+    _gemm_extra(None, None, None, 0, 0, 0, 0, 0, 0, 0, 0)
+    _gemm_set_prefetch(None, 0, None, 0, 0)
 
 
 def _set_gemm_extra(tout, t_rows: int, ext_group_n: int = 0):
@@ -552,8 +597,12 @@ def cross_entropy(logits, labels_i32, inv_count, loss, dlogits=None):
     _chk(_ce(_p(logits), _ld(logits), _p(labels_i32), R, V, inv_count, _p(loss), _p(dlogits), _ld(dlogits), _stream()))
 
 
-def adamw(p, g, m, v, hyper, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0):
-    _chk(_adamw(_p(p), _p(g), _p(m), _p(v), p.numel(), _p(hyper), beta1, beta2, eps, weight_decay, _stream()))
+def adamw(p, g, m, v, hyper, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, guard=None):
+    """guard (optional int32 device word, see thin_error_word): the update is applied only while it is zero"""
+    if guard is None:
+        _chk(_adamw(_p(p), _p(g), _p(m), _p(v), p.numel(), _p(hyper), beta1, beta2, eps, weight_decay, _stream()))
+    else:
+        _chk(_adamw_guarded(_p(p), _p(g), _p(m), _p(v), p.numel(), _p(hyper), beta1, beta2, eps, weight_decay, _p(guard), _stream()))
 
 
 def seed_bump(seed):

@@ -35,13 +35,25 @@ def top_p_filter_(scores: torch.Tensor, top_p: float, min_tokens_to_keep: int = 
     return scores
 
 
+def top_k_filter_(scores: torch.Tensor, top_k: int, min_tokens_to_keep: int = 1) -> torch.Tensor:
+    """HF TopKLogitsWarper (in place): everything below the k-th largest logit of a row -> -inf (ties with the k-th survive)"""
+    k = min(max(int(top_k), min_tokens_to_keep), scores.shape[-1])
+    if k > 0 and k < scores.shape[-1]:
+        kth = torch.topk(scores, k)[0][..., -1, None]
+        scores.masked_fill_(scores < kth, -float("inf"))
+    return scores
+
+
 def sample_search(step_fn: Callable[[torch.Tensor], torch.Tensor], batch: int, num_return: int, max_new_tokens: int, min_length: int = 1,
                   top_p: float = 0.9, temperature: float = 1.0, repetition_penalty: float = 1.0, eos_id: int = 1, pad_id: int = 0,
-                  start_id: int = 0, generator: Optional[torch.Generator] = None, greedy: bool = False) -> List[torch.Tensor]:
+                  start_id: int = 0, generator: Optional[torch.Generator] = None, greedy: bool = False,
+                  top_k: int = 50) -> List[torch.Tensor]:
     """Multinomial ("nucleus") sampling, the reference's ``generate(use_nucleus_sampling=True, num_beams=1)`` -> HF ``_sample``
     (blip2_mr.py:883-899: do_sample=True, top_p, temperature, repetition_penalty, num_return_sequences=num_captions).  step_fn(seqs
     [batch * num_return, L]) -> RAW next-token logits [rows, V] (the repetition penalty depends on the logits' signs).  Order of the
-    warps as in HF: repetition penalty, min-length EOS ban, temperature, top-p, softmax, one multinomial draw per row; a finished row
+    warps as in HF: repetition penalty, min-length EOS ban, temperature, top-k, top-p, softmax, one multinomial draw per row (top_k = 50
+    is ``GenerationConfig``'s default in the reference's pinned transformers 4.46.1: the reference never overrides it, so HF puts
+    TopKLogitsWarper(50) between the temperature and the top-p warps; 0 switches it off); a finished row
     keeps emitting the pad id.  greedy=True: HF's greedy decoding (do_sample=False, num_beams=1) — argmax of the penalised RAW logits,
     no temperature / top-p (HF ignores them without sampling); needed because with ONE beam HF applies the repetition penalty to raw
     logits, whose signs differ from the log-probabilities its beam search penalises.
@@ -60,6 +72,7 @@ def sample_search(step_fn: Callable[[torch.Tensor], torch.Tensor], batch: int, n
         else:
             if temperature != 1.0:
                 logits = logits / temperature
+            top_k_filter_(logits, int(top_k))
             top_p_filter_(logits, float(top_p))
             nxt = torch.multinomial(torch.softmax(logits, dim=-1), num_samples=1, generator=generator).squeeze(1)
         nxt = torch.where(unfinished, nxt, torch.full_like(nxt, pad_id))

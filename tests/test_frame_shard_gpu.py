@@ -68,3 +68,34 @@ def test_frame_sharded_training_step_keeps_the_replicated_t5_identical(tmp_path)
     assert torch.equal(sh["grad"][nl:], sh["grad_other"][nl:])           # t5_proj / ln_vision: summed over the ranks' local frames
     assert sh["grad"][:nl].abs().sum() > 0 and sh["grad"][nl:].abs().sum() > 0 and torch.isfinite(sh["grad"]).all()
     assert sh["qf_salt"] == 0   # rank 0's salt; rank r uses r << 20 (mrblip/dist.py: FrameShard.attach)
+
+
+def test_seed_guard_reduces_a_device_tensor_on_the_rccl_backend(monkeypatch):
+    """FrameShard.assert_same_seed all-reduced a CPU tensor whatever the backend; RCCL ("nccl") has no CPU backend, so the
+    first frame-sharded step on real multi-GPU raised.  With the backend reported as "nccl" the reduced pair must live on the seed's
+    device (and on the host for gloo); a seed mismatch must still raise."""
+    import types
+    import torch.distributed as dist
+    from mrblip.dist import FrameShard
+
+    seen = []
+
+    def fake_all_reduce(t, op=None, group=None):
+        seen.append(t.device.type)
+
+    fs = FrameShard.__new__(FrameShard)
+    fs.group, fs.world, fs.rank = None, 2, 0
+    eng = types.SimpleNamespace(seed=torch.tensor([1234567], dtype=torch.int64, device="cuda:0"))
+    monkeypatch.setattr(dist, "all_reduce", fake_all_reduce)
+    monkeypatch.setattr(dist, "get_backend", lambda group=None: "nccl")
+    fs.assert_same_seed(eng)
+    monkeypatch.setattr(dist, "get_backend", lambda group=None: "gloo")
+    fs.assert_same_seed(eng)
+    assert seen == ["cuda", "cpu"], seen
+
+    def mismatch(t, op=None, group=None):
+        t[1] += 5       # as if another rank held a smaller seed: max(-seed) grows
+
+    monkeypatch.setattr(dist, "all_reduce", mismatch)
+    with pytest.raises(RuntimeError, match="dropout seeds differ"):
+        fs.assert_same_seed(eng)

@@ -95,3 +95,37 @@ def test_role_workgroups_of_the_encoder_gemms_change_no_bit():
     n0 = ops.launch_count
     _step(dict(), steps=1)
     assert ops.launch_count - n0 <= launches_old - 2 * 3, (launches_old, ops.launch_count - n0)   # o and wo of 3 encoder layers lost their thin launch
+
+
+def test_a_thin_role_timeout_is_loud_and_skips_the_optimizer_step():
+    """VERDICT r4 weak 3 / ADVICE r4: a consumer tile whose bounded wait for the in-launch thin role runs out used to continue on stale
+    operands with an error word nobody in the training path read.  Forced here with the test hook (the role workgroups exit without
+    publishing): the device error word must be set, the guarded AdamW must leave parameters AND moments untouched, the NEXT step's entry
+    check (and the runner's blocking check) must raise — and after clearing the word training continues."""
+    from mrblip import ops
+    _, _, eng, lay = _step(dict(), steps=1)        # a healthy step first (workspaces, flag buffer, error word exist)
+    assert ops.gemm_thin_timeouts() == 0
+    eng.optimizer_step(1e-3)
+    torch.cuda.synchronize()
+    flat0, m0, v0 = eng.flat.clone(), eng.adam_m.clone(), eng.adam_v.clone()
+    assert m0.abs().sum() > 0
+    import bench
+    samples = bench.synthetic_samples(1, 40, 150.0, torch.device("cuda:0"), 5)
+    eng.zero_grad()
+    with ops.gemm_debug_stall_thin():
+        eng.forward_backward(samples["video"], lay, backward=True)
+    eng.optimizer_step(1e-3)                       # guarded: must be a no-op
+    torch.cuda.synchronize()
+    assert ops.gemm_thin_timeouts() == 1
+    assert torch.equal(eng.flat, flat0) and torch.equal(eng.adam_m, m0) and torch.equal(eng.adam_v, v0)
+    with pytest.raises(ops.MrblipError, match="thin-role"):
+        eng.forward_backward(samples["video"], lay, backward=True)      # the verdict of the stalled step has arrived by now
+    with pytest.raises(ops.MrblipError, match="thin-role"):
+        eng.check_thin_role(block=True)            # the runner's blocking form (end of epoch / before a checkpoint) sees the sticky word too
+    ops.gemm_thin_clear()
+    eng.zero_grad()
+    l = eng.forward_backward(samples["video"], lay, backward=True).item()
+    eng.optimizer_step(1e-3)
+    torch.cuda.synchronize()
+    eng.check_thin_role(block=True)
+    assert l == l and not torch.equal(eng.flat, flat0) and ops.gemm_thin_timeouts() == 0

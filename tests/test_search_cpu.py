@@ -115,10 +115,12 @@ def test_nucleus_sampling_equals_hf_generate(seed):
     mask = torch.ones(B, S, dtype=torch.long)
     with torch.no_grad():
         enc = m.encoder(inputs_embeds=emb, attention_mask=mask).last_hidden_state
-    for n_ret, top_p, temp, pen in ((1, 0.9, 1.0, 1.0), (3, 0.7, 0.8, 1.2), (2, 1.0, 1.5, 1.0)):
+    # top_k: the reference never sets it, so HF 4.46's GenerationConfig default (50) applies -> sample_search's default; the small
+    # fixture vocabulary needs small k's to make the warp bite (0 = off)
+    for n_ret, top_p, temp, pen, top_k in ((1, 0.9, 1.0, 1.0, 0), (3, 0.7, 0.8, 1.2, 7), (2, 1.0, 1.5, 1.0, 3), (2, 0.9, 1.0, 1.0, 50)):
         torch.manual_seed(1000 + seed)
         with torch.no_grad():
-            ref = m.generate(inputs_embeds=emb, attention_mask=mask, do_sample=True, num_beams=1, top_p=top_p, top_k=0, temperature=temp, max_new_tokens=8,
+            ref = m.generate(inputs_embeds=emb, attention_mask=mask, do_sample=True, num_beams=1, top_p=top_p, top_k=top_k, temperature=temp, max_new_tokens=8,
                              min_length=1, num_return_sequences=n_ret, repetition_penalty=pen)
         R = B * n_ret
 
@@ -128,10 +130,10 @@ def test_nucleus_sampling_equals_hf_generate(seed):
             return out.logits[:, -1].float()
 
         torch.manual_seed(1000 + seed)
-        got = sample_search(step, B, n_ret, 8, min_length=1, top_p=top_p, temperature=temp, repetition_penalty=pen)
+        got = sample_search(step, B, n_ret, 8, min_length=1, top_p=top_p, temperature=temp, repetition_penalty=pen, top_k=top_k)
         assert len(got) == R == ref.shape[0]
         for i in range(R):
             r, mine = ref[i].tolist(), got[i].tolist()
             if 1 in r[1:]:
                 r = r[: r.index(1, 1) + 1]
-            assert mine == r[:len(mine)] and all(t == 0 for t in r[len(mine):]), (n_ret, top_p, temp, pen, i, mine, r)
+            assert mine == r[:len(mine)] and all(t == 0 for t in r[len(mine):]), (n_ret, top_p, temp, pen, top_k, i, mine, r)
