@@ -188,6 +188,17 @@ int mrblip_lora_grads(const void* dY, long long lddy, const void* U, long long l
                       long long ldg, int M, int N, int K, int R, float* const* dBt, const int* b_col0, const int* b_ncols,
                       const long long* b_lds, float* const* dA, const long long* a_lds, const uint32_t* seed_ptr, uint32_t site,
                       float p_drop, mrblip_stream_t stream);
+/* The same for SEVERAL fused groups in ONE launch (round 5: every group of a T5 layer — peft computes these one Linear at a time in
+ * autograd, blip2_mr.py:182-200): jobs[i] holds the arguments of one mrblip_lora_grads call (arrays of 4: unused slots NULL / 0), all
+ * with the same device seed; 1..8 jobs; same block -> output ownership as the one-group launch, i.e. the same bits. */
+typedef struct MrblipLoraGradsJob {
+  const void* dY; long long lddy; const void* U; long long ldu; const void* X; long long ldx; const void* G; long long ldg;
+  int M, N, K, R;
+  float* dBt[4]; int b_col0[4]; int b_ncols[4]; long long b_lds[4];
+  float* dA[4]; long long a_lds[4];
+  uint32_t site; float p_drop;
+} MrblipLoraGradsJob;
+int mrblip_lora_grads_batched(int n_jobs, const MrblipLoraGradsJob* jobs, const uint32_t* seed_ptr, mrblip_stream_t stream);
 /* LoRA "down" product with the lora_dropout fused into the operand load: U[M,N] = dropout(X)[M,K] Acat[N,K]^T (bf16; peft lora_A(lora_dropout(x))) */
 int mrblip_gemm_lora_down(const void* X, long long ldx, const void* Acat, long long lda, int M, int N, int K, void* U, long long ldu,
                           const uint32_t* seed_ptr, uint32_t site, float p_drop, mrblip_stream_t stream);

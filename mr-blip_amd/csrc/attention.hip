@@ -47,30 +47,80 @@ struct AttnArgs {
 enum { F_LUT = 1, F_MASK = 2, F_CAUSAL = 4, F_DROP = 8, F_SPLIT = 16, F_DBITS = 32, F_VROW = 64, F_KS2 = 128,
        F_F16 = 256, F_XS = 512 };   // F_F16 (round 4): Q / K / V / O and the probabilities fed to the second product are IEEE fp16 (the fp16-operand ViT)
 
-// Attention-probability dropout draws (v2, round 3).  ONE 32-bit hash serves a key QUAD: index = row * ceil(Sk / 4) + key / 4 with
-// row = (b * H + h) * Sq + q, hash = mrb_lin_fin(index * MRB_H1 + mrb_lin_base(seed, site)) (common.h), and key 4i + j takes the
-// 11-bit window of the hash at bit 7j (bits 0-10, 7-17, 14-24, 21-31): keep iff window >= round(p * 2048) (p = 0.1 -> 205 / 2048 =
-// 0.1001).  Windows of neighbouring keys share 4 bits — the LOW bits of one are the HIGH bits of the previous — which moves the
-// conditional drop probability of a neighbour from 0.1001 to 0.1016 (measured on the restatement: tests/test_host_cpu.py); independent
-// across quads and rows.  A lane of the query-owner kernels owns two runs of 8 consecutive keys per 32-key tile = 4
-// hashes (round 2: one hash per key PAIR with mrb_hash's two quarter-rate multiplies = 8 hashes, 38 % of the forward tile's VALU time).
+// Attention-probability dropout draws (v3, round 5).  ONE 32-bit hash serves a key QUAD: index = row * ceil(Sk / 4) + key / 4 with
+// row = (b * H + h) * Sq + q, hash h = mrb_lin_fin24(index * MRB_H1 + mrb_lin_base(seed, site)) (common.h: the finaliser runs on the
+// full-rate 24-bit multiplier), g = rotr(h, 8); key 4i + j takes the 16-bit draw  j = 0: h & 0xffff,  1: h >> 16,  2: g & 0xffff,
+// 3: g >> 16  — every byte of h is the TOP byte of exactly one draw; keep iff draw >= round(p * 65536) (p = 0.1 -> 0.10001, the element
+// dropout's resolution; v2 had 11-bit windows: 0.1001).  A draw's low byte is another draw's top byte, which matters only when the
+// top byte equals the threshold's: neighbour conditionals 0.100-0.103 (v2: 0.1016), measured on the restatement
+// (tests/test_host_cpu.py).  WHY this shape: the words h and g hold the draws of the element pairs (0, 1) and (2, 3) in their 16-bit
+// halves, exactly where a packed bf16 pair holds the two probabilities — the LDS forward applies the mask to the PACKED pair with
+// three packed-16-bit instructions (saturating subtract, min, multiply) and collects the keep bits with one shift-or per pair, instead
+// of extract + compare + select + select per ELEMENT (v2: ~110 VALU per 32 x 32 score tile for the dropout alone).
 #define NEG_BIG (-1.0e30f)
-__device__ __forceinline__ uint32_t attn_draw(uint32_t hash, int j) { return (hash >> (7 * j)) & 0x7ffu; }
+__device__ __forceinline__ uint32_t attn_rot8(uint32_t h) { return __builtin_amdgcn_alignbit(h, h, 8); }
+__device__ __forceinline__ uint32_t attn_draw(uint32_t hash, int j) {   // scalar form (per-wave kernels, key-owner backward)
+  const uint32_t w = (j & 2) ? attn_rot8(hash) : hash;
+  return (j & 1) ? (w >> 16) : (w & 0xffffu);
+}
+// packed form: halves of w = two draws; returns 1 / 0 in each 16-bit half (keep / drop).  tm1x2 = (thresh - 1) in both halves, thresh >= 1.
+// (inline asm: written with vector builtins, LLVM canonicalises min(sub_sat(x, t), 1) to zext(x > t) and emits compare + select + byte
+// permute per element again)
+__device__ __forceinline__ uint32_t attn_keep01(uint32_t w, uint32_t tm1x2) {
+  uint32_t s;
+  asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(s) : "v"(w), "s"(tm1x2));
+  asm("v_pk_min_u16 %0, %1, %2" : "=v"(s) : "v"(s), "s"(0x00010001u));
+  return s;
+}
+__device__ __forceinline__ uint32_t attn_pkmul(uint32_t pair, uint32_t k01) {   // a packed 16-bit pair times its 0 / 1 keep factors
+  uint32_t r;
+  asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(r) : "v"(pair), "v"(k01));
+  return r;
+}
+// lane <-> lane ^ 32 exchange without the LDS crossbar: v_permlane32_swap (gfx950) on two copies; {r[0], r[1]} = {own or partner, partner
+// or own} depending on the half, so any SYMMETRIC combination of the two is what __shfl_xor(x, 32) + combine gave
+__device__ __forceinline__ float attn_max_x32(float x) {
+  const uint32_t u = __builtin_bit_cast(uint32_t, x);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return fmaxf(__builtin_bit_cast(float, (uint32_t)r[0]), __builtin_bit_cast(float, (uint32_t)r[1]));
+}
+__device__ __forceinline__ uint32_t attn_or_x32(uint32_t x) {
+  const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+  return (uint32_t)r[0] | (uint32_t)r[1];
+}
+__device__ __forceinline__ float attn_sum_x32(float x) {
+  const uint32_t u = __builtin_bit_cast(uint32_t, x);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return __builtin_bit_cast(float, (uint32_t)r[0]) + __builtin_bit_cast(float, (uint32_t)r[1]);
+}
+// a wave-uniform float the compiler must keep as ONE finished scalar: the value passes through a VGPR it cannot see into, so the
+// arithmetic that produced it (a scalar load times a constant: the scalar unit has no float multiply) is not re-done at every use
+__device__ __forceinline__ float attn_uniform(float x) {
+  asm volatile("" : "+v"(x));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x)));
+}
+// keep-bit word of a (32-key tile, query): the forward collects the bit of register pair i (registers 2i, 2i + 1 of lane half hi) at
+// positions 8 hi + i and 16 + 8 hi + i, i.e. key 16 c + 8 hi + j (register r = 8 c + j) sits at bit 16 (j & 1) + 8 hi + 4 c + (j >> 1).
+// Any fixed permutation serves the backward kernels equally (one v_bfe_i32 per element either way).
+__device__ __forceinline__ int attn_bitpos_reg(int r) { return 16 * (r & 1) + (r >> 1); }   // of register r, in the word shifted right by 8 hi
+__device__ __forceinline__ int attn_bitpos_key(int kk) {                                      // of key kk = 0..31 of the tile
+  return 16 * (kk & 1) + 8 * ((kk >> 3) & 1) + 4 * (kk >> 4) + ((kk & 7) >> 1);
+}
 // key-owner (dK/dV) kernels: lane owns one key, register j a query row; no sharing (these forms only run where the forward's keep bits
 // are not stored: the 32-query Q-Former and the 12-token decoder)
 __device__ __forceinline__ void drop_draws8_keyowner(uint32_t (&draw)[8], uint32_t rowbase, int key, int skq, uint32_t dbase) {
 #pragma unroll
   for (int j = 0; j < 8; ++j)
-    draw[j] = attn_draw(mrb_lin_fin(((rowbase + (uint32_t)j) * (uint32_t)skq + (uint32_t)(key >> 2)) * MRB_H1 + dbase), key & 3);
+    draw[j] = attn_draw(mrb_lin_fin24(((rowbase + (uint32_t)j) * (uint32_t)skq + (uint32_t)(key >> 2)) * MRB_H1 + dbase), key & 3);
 }
 // query-owner kernels (forward, dQ): lane (q, hi) owns keys k0 + 16c + 8hi + j (c < 2, j < 8) of a 32-key tile.  t_lane =
 // (row * skq + 2 * hi) * MRB_H1 + dbase is a lane constant; the tile term ((k0 >> 2) + 4c + qd) * MRB_H1 is wave-uniform.
-// keep bit of register r = 8c + 4qd + j  ->  bit r of the result.
+// keep bit of register r = 8c + 4qd + j  ->  apply(r, keep).
 template <typename F>
 __device__ __forceinline__ void attn_keep16(uint32_t t_lane, int k0, uint32_t thresh, F&& apply) {  // apply(r, keep) for r = 0..15
 #pragma unroll
   for (int cq = 0; cq < 4; ++cq) {  // cq = 2c + qd
-    const uint32_t hsh = mrb_lin_fin(t_lane + (uint32_t)((k0 >> 2) + 4 * (cq >> 1) + (cq & 1)) * MRB_H1);
+    const uint32_t hsh = mrb_lin_fin24(t_lane + (uint32_t)((k0 >> 2) + 4 * (cq >> 1) + (cq & 1)) * MRB_H1);
 #pragma unroll
     for (int j = 0; j < 4; ++j) apply(4 * cq + j, attn_draw(hsh, j) >= thresh);
   }
@@ -306,7 +356,7 @@ __global__ __launch_bounds__(NSW * 64, NSW == 4 ? 2 : 1) void attn_fwd_kernel(co
     float mx = fmaxf(sv[0], sv[1]);
 #pragma unroll
     for (int r = 2; r < 16; r += 2) mx = fmaxf(fmaxf(mx, sv[r]), sv[r + 1]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = attn_max_x32(mx);
     if (__builtin_amdgcn_ballot_w64(mx > m_run) != 0) {  // lazy rescale: once the running max has settled nothing is multiplied
       const float m_new = fmaxf(m_run, mx);
       const float alpha = ex2(m_run - m_new);
@@ -508,6 +558,10 @@ __global__ __launch_bounds__((FLAGS & F_KS2) ? 512 : 256, (FLAGS & F_KS2) ? 1 : 
   const uint32_t t_lane = DROP ? (row_id * (uint32_t)((p.Sk + 3) >> 2) + 2u * (uint32_t)hi) * MRB_H1 + mrb_lin_base(drop_seed, p.drop.site) : 0u;
   const float scale2 = p.scale * MRB_LOG2E;
   uint32_t* dbits_row = DBITS ? p.dbits + (long long)(b * p.H + h) * (p.Skpad >> 5) * p.Sqpad + q : nullptr;
+  const uint32_t drop_tm1 = DROP ? (p.drop.thresh24 - 1u) * 0x10001u : 0u;   // (thresh - 1) in both 16-bit halves (attn_keep01)
+  // the two far buckets of the relative-position bias (every key >= 128 positions before / after the query), as scalars
+  const float bfar_lo = LUT ? attn_uniform(p.lut[h * 257] * MRB_LOG2E) : 0.f;
+  const float bfar_hi = LUT ? attn_uniform(p.lut[h * 257 + 256] * MRB_LOG2E) : 0.f;
 
   // ---- staging: buffer resources span from this head's first element to the end of the tensor (reads past the head's rows stay
   // inside the tensor or return 0; whatever they return is finite and meets P == 0 / zero-padded Q)
@@ -584,20 +638,47 @@ __global__ __launch_bounds__((FLAGS & F_KS2) ? 512 : 256, (FLAGS & F_KS2) ? 1 : 
     for (int s = 0; s < KS; ++s)
       sacc = mfma32x16<F16>(*reinterpret_cast<const bf16x8*>(base + sub * (32 * KROW) + k_off[s]), qf[s], sacc);
     // lane (q, hi), register r  <->  key k0 + 16*(r>>3) + 8*hi + (r&7)
-    float sv[16];
-    tile_scores<LUT, 1>(sv, sacc, scale2, lut, k0 - (q0 + 31) >= 128 || (q0 - (k0 + 31)) >= 128, k0 > q0 ? 256 : 0, k0 + 8 * hi - q);
-    if (EDGE) {
+    // Round 5.  The common tile (every ViT / Q-Former tile; ~85 % of the T5 encoder's at S = 2012) has ONE bias bucket: the bias is a
+    // per-head SCALAR held in an SGPR since before the loop (no LDS read + wait + readfirstlane per tile), the running maximum is taken on
+    // the RAW accumulators (scale2 > 0: s -> s * scale2 + b is monotonic, so max and fma commute bit for bit) and every probability is ONE
+    // fma + ONE exp: exp2(s * scale2 + (b - m)).  The general tile (per-element bias, masked keys) prepares finished scores and runs the
+    // same exponent line with multiplier 1 (fma(s, 1, -m) == s - m exactly): one rescale site, one exponent site for both.
+    float mx, emul, ebase;   // emul / ebase: wave-uniform
+    const bool far_tile = !LUT || k0 - (q0 + 31) >= 128 || (q0 - (k0 + 31)) >= 128;   // wave-uniform: one bias bucket for the whole tile
+    if (!EDGE && far_tile) {
+      emul = scale2;
+      ebase = LUT ? (k0 > q0 ? bfar_hi : bfar_lo) : 0.f;
+      float mraw = fmaxf(sacc[0], sacc[1]);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = k0 + 16 * (r >> 3) + 8 * hi + (r & 7);
-        const bool ok = key < p.Sk && ((vmask >> r) & 1u);
-        sv[r] = ok ? sv[r] : NEG_INF;
+      for (int r = 2; r < 16; r += 2) mraw = fmaxf(fmaxf(mraw, sacc[r]), sacc[r + 1]);
+      mx = __builtin_fmaf(mraw, scale2, ebase);
+    } else {   // (the finished scores replace the accumulators IN PLACE: both arms hand the same registers to the exponent line)
+      emul = 1.0f;
+      ebase = 0.f;
+      if (LUT) {
+        float bias[16];
+        const int relbase = k0 + 8 * hi - q;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bias[r] = lut[max(-128, min(128, relbase + 16 * (r >> 3) + (r & 7))) + 128];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[r] = __builtin_fmaf(sacc[r], scale2, bias[r]);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[r] *= scale2;
       }
-    }
-    float mx = fmaxf(sv[0], sv[1]);
+      if (EDGE) {
 #pragma unroll
-    for (int r = 2; r < 16; r += 2) mx = fmaxf(fmaxf(mx, sv[r]), sv[r + 1]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        for (int r = 0; r < 16; ++r) {
+          const int key = k0 + 16 * (r >> 3) + 8 * hi + (r & 7);
+          const bool ok = key < p.Sk && ((vmask >> r) & 1u);
+          sacc[r] = ok ? sacc[r] : NEG_INF;
+        }
+      }
+      mx = fmaxf(sacc[0], sacc[1]);
+#pragma unroll
+      for (int r = 2; r < 16; r += 2) mx = fmaxf(fmaxf(mx, sacc[r]), sacc[r + 1]);
+    }
+    mx = attn_max_x32(mx);
     if (__builtin_amdgcn_ballot_w64(mx > m_run) != 0) {  // lazy rescale
       const float m_new = fmaxf(m_run, mx);
       const float alpha = ex2(m_run - m_new);
@@ -608,27 +689,35 @@ __global__ __launch_bounds__((FLAGS & F_KS2) ? 512 : 256, (FLAGS & F_KS2) ? 1 : 
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[mt][r] *= alpha;
     }
+    const float cadd = ebase - m_run;
     float psum = 0.f;
     float pv[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      pv[r] = ex2(sv[r] - m_run);
+      pv[r] = ex2(__builtin_fmaf(sacc[r], emul, cadd));
       psum += pv[r];
     }
+    l_run += psum;
+    // the probabilities are packed FIRST; the dropout mask is applied to the packed pairs (draws v3, see attn_keep01)
+    union { bf16x8 v8[2]; uint32_t u[8]; } pk;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) pk.u[i] = pack2x<F16>(pv[2 * i], pv[2 * i + 1]);
     if (DROP) {
-      uint32_t bits = 0;  // keep bit of register r at position 16*(r>>3) + (r&7); shifted by 8*hi it is the key's bit in the tile word
-      attn_keep16(t_lane, k0, p.drop.thresh24, [&](int r, bool kp) {
-        pv[r] = kp ? pv[r] : 0.f;
-        if (DBITS) bits |= kp ? 1u << (16 * (r >> 3) + (r & 7)) : 0u;
-      });
+      uint32_t bits = 0;  // keep bit of register pair i at positions i and 16 + i; shifted by 8 * hi it is the lane half's share of the tile word
+#pragma unroll
+      for (int cq = 0; cq < 4; ++cq) {  // cq = 2c + qd: registers 4 cq .. 4 cq + 3 = pairs 2 cq, 2 cq + 1
+        const uint32_t hsh = mrb_lin_fin24(t_lane + (uint32_t)((k0 >> 2) + 4 * (cq >> 1) + (cq & 1)) * MRB_H1);
+        const uint32_t ka = attn_keep01(hsh, drop_tm1), kb = attn_keep01(attn_rot8(hsh), drop_tm1);
+        pk.u[2 * cq] = attn_pkmul(pk.u[2 * cq], ka);
+        pk.u[2 * cq + 1] = attn_pkmul(pk.u[2 * cq + 1], kb);
+        if (DBITS) bits |= (ka << (2 * cq)) | (kb << (2 * cq + 1));
+      }
       if (DBITS) {
-        uint32_t wbits = bits << (8 * hi);
-        wbits |= (uint32_t)__shfl_xor((int)wbits, 32, 64);
+        const uint32_t wbits = attn_or_x32(bits << (8 * hi));
         if (hi == 0) dbits_row[(long long)(k0 >> 5) * p.Sqpad] = wbits;
       }
     }
-    l_run += psum;
-    const bf16x8 pf0 = pack8x<F16>(pv), pf1 = pack8x<F16>(pv + 8);
+    const bf16x8 pf0 = pk.v8[0], pf1 = pk.v8[1];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       if (VTR) {
@@ -907,6 +996,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_lds_kernel(const AttnArgs 
   if (q_ok && hi == 0) p.Delta[stat_off] = delta;
   const float scale2 = p.scale * MRB_LOG2E;
   const float keep_scale = DROP ? p.drop.inv_keep : 1.0f;
+  const float bfar_lo = LUT ? attn_uniform(p.lut[h * 257] * MRB_LOG2E) : 0.f;        // the two far buckets of the bias, as scalars
+  const float bfar_hi = LUT ? attn_uniform(p.lut[h * 257 + 256] * MRB_LOG2E) : 0.f;
 
   f32x16 dq[MT];
 #pragma unroll
@@ -953,7 +1044,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_lds_kernel(const AttnArgs 
       t_off[mt][hf] = 2 * T_BYTES + d * 128 + (((2 * hf + hi) ^ ((d >> 1) & 7)) << 4);
     }
 
-  auto tile = [&](const bool EDGE, int k0, const char* base, int sub, uint32_t vmask, uint32_t dword) {
+  // EDGE is a COMPILE-TIME flag of the tile body (round 5): as a run-time argument of the inlined lambda the compiler if-converted the
+  // edge handling — every interior tile computed 16 x (key index, range compare, mask-bit test, two selects) and threw them away
+  // (~100 of ~280 VALU instructions per tile, found in the ISA); the call site now branches (wave-uniform) between two instances.
+  auto tile = [&](auto edge_c, int k0, const char* base, int sub, uint32_t vmask, uint32_t dword) {
+    constexpr bool EDGE = decltype(edge_c)::value;
     f32x16 sacc, dpacc;
     zero16(sacc);
     zero16(dpacc);
@@ -962,28 +1057,51 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_lds_kernel(const AttnArgs 
       sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(base + sub * 4096 + k_off[s]), qf[s], sacc, 0, 0, 0);
       dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(base + T_BYTES + sub * 4096 + k_off[s]), dof[s], dpacc, 0, 0, 0);
     }
-    float sv[16];
-    tile_scores<LUT, 1>(sv, sacc, scale2, lut, k0 - (q0 + 31) >= 128 || (q0 - (k0 + 31)) >= 128, k0 > q0 ? 256 : 0, k0 + 8 * hi - q);
+    // P = exp2(s * emul + cadd): the one-bucket tile folds scale, bias and -LSE into ONE fma per score (see attn_fwd_lds_kernel); the
+    // general tile finishes its scores in place first
+    float emul, cadd;
+    const bool far_tile = !LUT || k0 - (q0 + 31) >= 128 || (q0 - (k0 + 31)) >= 128;   // wave-uniform
+    if (!EDGE && far_tile) {
+      emul = scale2;
+      cadd = (LUT ? (k0 > q0 ? bfar_hi : bfar_lo) : 0.f) - lse2;
+    } else {
+      emul = 1.0f;
+      cadd = -lse2;
+      if (LUT) {
+        float bias[16];
+        const int relbase = k0 + 8 * hi - q;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bias[r] = lut[max(-128, min(128, relbase + 16 * (r >> 3) + (r & 7))) + 128];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[r] = __builtin_fmaf(sacc[r], scale2, bias[r]);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[r] *= scale2;
+      }
+      if (EDGE) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = k0 + 16 * (r >> 3) + 8 * hi + (r & 7);
+          const bool ok = key < p.Sk && ((vmask >> r) & 1u);
+          sacc[r] = ok ? sacc[r] : NEG_INF;     // exp2(-inf + finite) = 0
+        }
+      }
+    }
     float kf[16];  // dropout factor of dP: keep ? 1/(1-p) : 0
 #pragma unroll
     for (int r = 0; r < 16; ++r) kf[r] = keep_scale;
-    if (DROP && DBITS) {  // keep bits stored by the forward
+    if (DROP && DBITS) {  // keep bits stored by the forward (layout: attn_bitpos_reg)
       const int wsh = (int)(dword >> (8 * hi));
 #pragma unroll
       for (int r = 0; r < 16; ++r)   // v_bfe_i32: the key's bit as 0 / -1, then one AND (instead of and + compare + select)
-        kf[r] = __builtin_bit_cast(float, __builtin_amdgcn_sbfe(wsh, 16 * (r >> 3) + (r & 7), 1) & __builtin_bit_cast(int, keep_scale));
+        kf[r] = __builtin_bit_cast(float, __builtin_amdgcn_sbfe(wsh, attn_bitpos_reg(r), 1) & __builtin_bit_cast(int, keep_scale));
     } else if (DROP) {
       attn_keep16(t_lane, k0, p.drop.thresh24, [&](int r, bool kp) { kf[r] = kp ? keep_scale : 0.f; });
     }
     float ds[16];  // dS / scale (the scale is applied once to dQ at the end)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      float pr = ex2(sv[r] - lse2);
-      if (EDGE) {
-        const int key = k0 + 16 * (r >> 3) + 8 * hi + (r & 7);
-        const bool ok = key < p.Sk && ((vmask >> r) & 1u);
-        pr = ok ? pr : 0.f;
-      }
+      const float pr = ex2(__builtin_fmaf(sacc[r], emul, cadd));
       ds[r] = pr * (kf[r] * dpacc[r] - delta);
     }
     const bf16x8 f0 = pack8(ds), f1 = pack8(ds + 8);
@@ -1027,7 +1145,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_lds_kernel(const AttnArgs 
 #pragma unroll
       for (int sub = 0; sub < 2; ++sub) {   // (sub is a compile-time constant here: two instances, the edge test stays a run-time branch)
         const int k0 = st * 64 + 32 * sub;
-        if (k0 < p.Sk) tile((MASK && (sub ? part1 : part0)) || k0 + 32 > p.Sk, k0, base, sub, sub ? vm1 : vm0, sub ? cw1 : cw0);
+        if (k0 < p.Sk) {
+          if ((MASK && (sub ? part1 : part0)) || k0 + 32 > p.Sk) tile(BoolC<true>{}, k0, base, sub, sub ? vm1 : vm0, sub ? cw1 : cw0);
+          else tile(BoolC<false>{}, k0, base, sub, sub ? vm1 : vm0, sub ? cw1 : cw0);
+        }
       }
     }
   }
@@ -1225,6 +1346,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_lds_kernel(const AttnArgs
   const int st0 = CAUSAL ? bx_ * 2 : 0;  // first 64-query stage (block-uniform); the per-wave causal limit is applied below
   const float scale2 = p.scale * MRB_LOG2E;
   const float keep_scale = DROP ? p.drop.inv_keep : 1.0f;
+  const float bfar_lo = LUT ? attn_uniform(p.lut[h * 257] * MRB_LOG2E) : 0.f;        // the two far buckets of the bias, as scalars
+  const float bfar_hi = LUT ? attn_uniform(p.lut[h * 257 + 256] * MRB_LOG2E) : 0.f;
 
   const bf16_t* qbase = p.Q.ptr + b * p.Q.bs + h * p.Q.hs;
   const bf16_t* dobase = p.dO.ptr + b * p.dO.bs + h * p.dO.hs;
@@ -1259,6 +1382,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_lds_kernel(const AttnArgs
   };
 
   const int frow = perm23(l31);  // fragment row of the row tiles (the MFMA row permutation)
+  const int kbitpos = attn_bitpos_key(l31);   // where the forward put this lane's key in a keep-bit word (attn_bitpos_key)
   int r_off[KS], t_off[MT][2];  // rows of sub-tile 1 sit 32 * 128 B further (the swizzle (row >> 1) & 7 ignores bit 5); its Q^T / dO^T
   // chunks have index ^ 4 (^ 64 B).  ONE instance of the tile body for both sub-tiles and the edge tiles (see attn_fwd_lds_kernel).
 #pragma unroll
@@ -1271,6 +1395,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_lds_kernel(const AttnArgs
       t_off[mt][hf] = 2 * T_BYTES + d * 128 + (((2 * hf + hi) ^ ((d >> 1) & 7)) << 4);
     }
 
+  // EDGE is a run-time, wave-uniform flag; its block holds an `asm volatile` so that it stays a BRANCH (round 5): left to itself the
+  // compiler if-converted the edge handling and every interior tile computed 16 x (query index, range compare, two selects) for nothing
+  // (64 VALU instructions per tile, found in the ISA).  (Two compile-time instances, as in the dQ kernel, cost 256 VGPRs + scratch here.)
   auto tile = [&](const bool EDGE, int q0, const char* base, int sub) {
     f32x16 sacc, dpacc;
     zero16(sacc);
@@ -1282,7 +1409,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_lds_kernel(const AttnArgs
     }
     // lane (key, hi), register r  <->  query q0 + 16*(r>>3) + 8*hi + (r&7)
     float sv[16];
-    tile_scores<LUT, -1>(sv, sacc, scale2, lut, kb0 - (q0 + 31) >= 128 || (q0 - (kb0 + 31)) >= 128, kb0 > q0 ? 256 : 0, key - q0 - 8 * hi);
+    if (LUT && (kb0 - (q0 + 31) >= 128 || (q0 - (kb0 + 31)) >= 128)) {   // wave-uniform: one bias bucket, a scalar held since before the loop
+      const float bconst = kb0 > q0 ? bfar_hi : bfar_lo;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sv[r] = __builtin_fmaf(sacc[r], scale2, bconst);
+    } else {
+      tile_scores<LUT, -1>(sv, sacc, scale2, lut, false, 0, key - q0 - 8 * hi);
+    }
 #pragma unroll
     for (int c = 0; c < 2; ++c) {  // two independent halves (8 query rows each): short live ranges
       const float* sp = reinterpret_cast<const float*>(base + 4 * T_BYTES) + 32 * sub + 16 * c + 8 * hi;
@@ -1290,12 +1423,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_lds_kernel(const AttnArgs
       const float4 b0 = *reinterpret_cast<const float4*>(sp + 64), b1 = *reinterpret_cast<const float4*>(sp + 68);
       const float lse[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w}, del[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
       int keepm[8];   // 0 / -1 per query row: the dropped values are cleared with one AND each
-      if (DROP && DBITS) {  // stored keep bits: word j = query row q0 + 16c + 8hi + j, bit l31 = this lane's key
+      if (DROP && DBITS) {  // stored keep bits: word j = query row q0 + 16c + 8hi + j, bit kbitpos = this lane's key
         const uint32_t* bp = reinterpret_cast<const uint32_t*>(base + 4 * T_BYTES + 512 + w * 256) + 32 * sub + 16 * c + 8 * hi;
         const uint4 w0 = *reinterpret_cast<const uint4*>(bp), w1 = *reinterpret_cast<const uint4*>(bp + 4);
         const uint32_t ws[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
 #pragma unroll
-        for (int j = 0; j < 8; ++j) keepm[j] = __builtin_amdgcn_sbfe((int)ws[j], l31, 1);
+        for (int j = 0; j < 8; ++j) keepm[j] = __builtin_amdgcn_sbfe((int)ws[j], kbitpos, 1);
       } else if (DROP) {
         uint32_t draw[8];
         drop_draws8_keyowner(draw, bh_idx + (uint32_t)(q0 + 16 * c + 8 * hi), key, (p.Sk + 3) >> 2, mrb_lin_base(drop_seed, p.drop.site));
@@ -1303,16 +1436,23 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_lds_kernel(const AttnArgs
         for (int j = 0; j < 8; ++j) keepm[j] = draw[j] >= p.drop.thresh24 ? -1 : 0;
       }
       float pd[8], ds[8];  // pd: dropped P (without 1/(1-p));  ds: dS / scale  — both factors are applied once at the end
+      float prs[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int r = 8 * c + j;
-        float pr = ex2(fmaf(lse[j], -MRB_LOG2E, sv[r]));
-        if (EDGE) {
+      for (int j = 0; j < 8; ++j) prs[j] = ex2(fmaf(lse[j], -MRB_LOG2E, sv[8 * c + j]));
+      if (EDGE) {
+        asm volatile("; edge tile" ::: "memory");   // (keeps this block behind a real branch)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
           const int qq = q0 + 16 * c + 8 * hi + j;
           bool ok = qq < p.Sq;
           if (CAUSAL) ok = ok && (key <= qq);
-          pr = ok ? pr : 0.f;
+          prs[j] = ok ? prs[j] : 0.f;
         }
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int r = 8 * c + j;
+        const float pr = prs[j];
         float kfr = keep_scale, prd = pr;
         if (DROP) {
           kfr = __builtin_bit_cast(float, keepm[j] & __builtin_bit_cast(int, keep_scale));
@@ -1339,7 +1479,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_lds_kernel(const AttnArgs
     const char* base = sm + (it & 1) * STAGE;
     if (active) {
 #pragma unroll
-      for (int sub = 0; sub < 2; ++sub) {   // (sub is a compile-time constant here: two instances, the edge test stays a run-time branch)
+      for (int sub = 0; sub < 2; ++sub) {   // (sub is a compile-time constant here: two instances)
         const int q0 = st * 64 + 32 * sub;
         if (q0 < p.Sq && !(CAUSAL && q0 + 31 < kb0)) tile(q0 + 32 > p.Sq || (CAUSAL && q0 < kb0 + 31), q0, base, sub);
       }
@@ -1412,7 +1552,8 @@ static int attn_fill(AttnArgs& a, const void* Q, const long long* qs, const void
 static void attn_drop(AttnArgs& a, const uint32_t* seed_ptr, uint32_t site, float p_drop) {
   a.drop.seed_ptr = (p_drop > 0.f) ? seed_ptr : nullptr;
   a.drop.site = site;
-  a.drop.thresh24 = (uint32_t)(p_drop * 2048.0f + 0.5f);   // 11-bit draws (attn_draw)
+  a.drop.thresh24 = (uint32_t)(p_drop * 65536.0f + 0.5f);   // 16-bit draws (attn_draw, v3)
+  if (a.drop.seed_ptr && a.drop.thresh24 < 1u) a.drop.thresh24 = 1u;   // (the packed compare subtracts thresh - 1)
   a.drop.inv_keep = 1.0f / (1.0f - p_drop);
 }
 

@@ -108,11 +108,21 @@ __device__ __forceinline__ uint32_t mrb_lin_fin(uint32_t t) {
   return t;
 }
 
+// Round 5: the finaliser of the attention-probability draws on the FULL-RATE 24-bit multiplier (v_mul_u32_u24: low 32 bits of the product
+// of the operands' low 24 bits; v_mul_lo_u32 is quarter rate).  The xor-shift in front folds bits 15..31 into the 24 bits the multiplier
+// sees; statistics of the resulting draws (marginals, neighbour conditionals, quad patterns): tests/test_host_cpu.py.
+__device__ __forceinline__ uint32_t mrb_lin_fin24(uint32_t t) {
+  t ^= t >> 15;
+  t = (t & 0xffffffu) * 0x9E3779u;
+  t ^= t >> 13;
+  return t;
+}
+
 struct DropoutArg {
   const uint32_t* seed_ptr;  // nullptr or p == 0 -> disabled
   uint32_t site;
-  uint32_t thresh24;  // draw threshold (historic field name): round(p * 65536) for the 16-bit element draws, round(p * 2048) for the
-                      // 11-bit attention-probability draws (attention.hip: attn_drop)
+  uint32_t thresh24;  // draw threshold (historic field name): round(p * 65536) — 16-bit draws everywhere (element dropout: mrb_keep;
+                      // attention probabilities: attention.hip "draws v3")
   float inv_keep;  // 1 / (1 - p)
 };
 

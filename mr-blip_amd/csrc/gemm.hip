@@ -2160,22 +2160,18 @@ struct TnArgs {
 };
 
 struct TnArgs2 { TnArgs a, b; int blocks_a; };  // two independent problems in one launch (blocks [0, blocks_a) -> a, the rest -> b)
+// Round 5: up to TN_MAX_PROBLEMS independent problems in one launch — the weight-gradient pairs of ALL LoRA groups of a T5 layer (round
+// 4: one launch per group, ~305 launches and ~5 ms of side-stream kernel time per step for ~20 GFLOP).  blk_end[i] = first block id
+// behind problem i.
+#define TN_MAX_PROBLEMS 16
+struct TnMulti { TnArgs p[TN_MAX_PROBLEMS]; int blk_end[TN_MAX_PROBLEMS]; int n; };
 
-__global__ __launch_bounds__(512) void lora_tn_kernel(const TnArgs2 q) {
-  const bool second = (int)blockIdx.x >= q.blocks_a;  // block-uniform
-  const int bx = second ? blockIdx.x - q.blocks_a : blockIdx.x;
-  // The problem's scalars are copied out of the kernel arguments ONCE.  (Round 3, ISA reading: with `const TnArgs& p = second ? q.b : q.a`
-  // the compiler kept a run-time pointer into the kernarg segment and re-fetched p.Y / p.ldy / p.drop.* with s_load + s_waitcnt lgkmcnt(0)
-  // at every use — 40 scalar round trips per loop iteration, ~1 us per pair of slices.)
-#define TN_SEL(f) (second ? q.b.f : q.a.f)
-  const bf16_t* __restrict__ const Y = TN_SEL(Y);
-  const bf16_t* __restrict__ const U = TN_SEL(U);
-  const long long ldy = TN_SEL(ldy), ldu = TN_SEL(ldu);
-  const int M = TN_SEL(M), C = TN_SEL(C), R = TN_SEL(R);
-  const uint32_t* const seed_ptr = TN_SEL(drop.seed_ptr);
-  const uint32_t site = TN_SEL(drop.site), thresh24 = TN_SEL(drop.thresh24);
-  const float inv_keep = TN_SEL(drop.inv_keep);
-#undef TN_SEL
+// the block body shared by both kernels: the problem's scalars arrive in registers (see the note on kernarg re-fetches below), its four
+// output segments through a pointer into the kernel arguments (read once, in the epilogue)
+__device__ __forceinline__ void lora_tn_body(const bf16_t* __restrict__ const Y, const bf16_t* __restrict__ const U, const long long ldy,
+                                             const long long ldu, const int M, const int C, const int R, const uint32_t* const seed_ptr,
+                                             const uint32_t site, const uint32_t thresh24, const float inv_keep, const TnSeg* const segs,
+                                             const int bx) {
   const bool has_drop = seed_ptr != nullptr;
   // Each wave stages its own 16-row slices of Y (16 x 32 columns) and U (16 x 32) with ONE 16-B global load per lane each,
   // parks them in a wave-private LDS slot and gathers the k-major MFMA fragments from there with 2-byte LDS reads.
@@ -2278,7 +2274,7 @@ __global__ __launch_bounds__(512) void lora_tn_kernel(const TnArgs2 q) {
   // all 16 as a chain of load -> wait -> store round trips.)
   {
     const int sgi = w >> 1;
-    const TnSeg sg = second ? q.b.seg[sgi] : q.a.seg[sgi];
+    const TnSeg sg = segs[sgi];
     float v[2], old[2];
     float* ptr[2];
     bool ok[2];
@@ -2297,6 +2293,34 @@ __global__ __launch_bounds__(512) void lora_tn_kernel(const TnArgs2 q) {
     for (int t = 0; t < 2; ++t)
       if (ok[t]) *ptr[t] = old[t] + v[t];
   }
+}
+
+__global__ __launch_bounds__(512) void lora_tn_kernel(const TnArgs2 q) {
+  const bool second = (int)blockIdx.x >= q.blocks_a;  // block-uniform
+  const int bx = second ? blockIdx.x - q.blocks_a : blockIdx.x;
+  // The problem's scalars are copied out of the kernel arguments ONCE.  (Round 3, ISA reading: with `const TnArgs& p = second ? q.b : q.a`
+  // the compiler kept a run-time pointer into the kernarg segment and re-fetched p.Y / p.ldy / p.drop.* with s_load + s_waitcnt lgkmcnt(0)
+  // at every use — 40 scalar round trips per loop iteration, ~1 us per pair of slices.)
+#define TN_SEL(f) (second ? q.b.f : q.a.f)
+  lora_tn_body(TN_SEL(Y), TN_SEL(U), TN_SEL(ldy), TN_SEL(ldu), TN_SEL(M), TN_SEL(C), TN_SEL(R), TN_SEL(drop.seed_ptr), TN_SEL(drop.site),
+               TN_SEL(drop.thresh24), TN_SEL(drop.inv_keep), second ? q.b.seg : q.a.seg, bx);
+#undef TN_SEL
+}
+
+__global__ __launch_bounds__(512) void lora_tn_multi_kernel(const TnMulti q) {
+  int pi = 0, b0 = 0;   // block-uniform: the problem this block belongs to (scalar compares over <= 16 cumulative counts)
+#pragma unroll 1
+  for (int i = 0; i + 1 < q.n; ++i)
+    if ((int)blockIdx.x >= q.blk_end[i]) { pi = i + 1; b0 = q.blk_end[i]; }
+  const TnArgs& a = q.p[pi];
+  // (copied into registers once, as above — the references below are each evaluated exactly here)
+  const bf16_t* const Y = a.Y; const bf16_t* const U = a.U;
+  const long long ldy = a.ldy, ldu = a.ldu;
+  const int M = a.M, C = a.C, R = a.R;
+  const uint32_t* const seed_ptr = a.drop.seed_ptr;
+  const uint32_t site = a.drop.site, thresh24 = a.drop.thresh24;
+  const float inv_keep = a.drop.inv_keep;
+  lora_tn_body(Y, U, ldy, ldu, M, C, R, seed_ptr, site, thresh24, inv_keep, a.seg, (int)blockIdx.x - b0);
 }
 
 // (A VALU form of these products - one lane per Y column, the row's U values as wave-uniform scalar loads, M split over 8 waves and
@@ -2328,6 +2352,31 @@ extern "C" int mrblip_lora_tn(const void* Y, long long ldy, const void* U, long 
   q.b = q.a;
   q.blocks_a = (C + 31) / 32;
   return launch_tn(q, q.blocks_a, stream);
+}
+
+// The weight-gradient pairs of SEVERAL fused groups in ONE launch (round 5): jobs[i] is what one mrblip_lora_grads call took (same
+// arithmetic, same block -> output ownership, so the same bits); at most 8 jobs (16 problems).
+struct MrblipLoraGradsJob {   // (= the typedef of include/mrblip_hip.h)
+  const void* dY; long long lddy; const void* U; long long ldu; const void* X; long long ldx; const void* G; long long ldg;
+  int M, N, K, R;
+  float* dBt[4]; int b_col0[4]; int b_ncols[4]; long long b_lds[4];
+  float* dA[4]; long long a_lds[4];
+  uint32_t site; float p_drop;
+};
+extern "C" int mrblip_lora_grads_batched(int n_jobs, const MrblipLoraGradsJob* jobs, const uint32_t* seed_ptr, hipStream_t stream) {
+  MRB_REQUIRE(n_jobs > 0 && 2 * n_jobs <= TN_MAX_PROBLEMS && jobs, "lora_grads_batched: 1..%d jobs", TN_MAX_PROBLEMS / 2);
+  TnMulti q = {};
+  int blocks = 0;
+  for (int i = 0; i < n_jobs; ++i) {
+    const MrblipLoraGradsJob& j = jobs[i];
+    if (int e = tn_fill(q.p[2 * i], j.dY, j.lddy, j.U, j.ldu, j.M, j.N, j.R, j.dBt, j.b_col0, j.b_ncols, j.b_lds, nullptr, 0, 0.f)) return e;
+    if (int e = tn_fill(q.p[2 * i + 1], j.X, j.ldx, j.G, j.ldg, j.M, j.K, j.R, j.dA, nullptr, nullptr, j.a_lds, seed_ptr, j.site, j.p_drop)) return e;
+    blocks += (j.N + 31) / 32; q.blk_end[2 * i] = blocks;
+    blocks += (j.K + 31) / 32; q.blk_end[2 * i + 1] = blocks;
+  }
+  q.n = 2 * n_jobs;
+  hipLaunchKernelGGL(lora_tn_multi_kernel, dim3(blocks), dim3(512), 0, stream, q);
+  return mrblip_check_launch("lora_tn_multi");
 }
 
 // Both LoRA weight gradients of a fused group in ONE launch:

@@ -1037,9 +1037,14 @@ class MrBlipEngine:
 
     fuse_norm_lora = os.environ.get("MRB_FUSE_NORM_LORA", "1") == "1"
 
+    # Round 5: the weight-gradient launches of several LoRA groups go out as ONE launch (ops.lora_grads_batched: the same blocks, the same
+    # bits).  Jobs queued for the side stream are merged per hand-over (side_flush); the encoder backward collects a whole layer's four
+    # groups itself (t5_encoder_backward).  MRB_LORA_GRADS_BATCH=0: one launch per group, as in round 4.
+    lora_grads_batch = os.environ.get("MRB_LORA_GRADS_BATCH", "1") == "1"
+
     def lg_bwd(self, g: LoraGroup, dy: torch.Tensor, x: torch.Tensor, u: torch.Tensor, gbuf: torch.Tensor, dx: Optional[torch.Tensor],
                residual: Optional[torch.Tensor] = None, side: bool = False, tile_cfg: int = 0, flush: bool = True, tout=None, t_rows: int = 0,
-               prefetch=None):
+               prefetch=None, collect: Optional[list] = None):
         """dy bf16 [M,N]; x the saved bf16 input; u the saved [M,64] LoRA activations.  Accumulates dA, dB of every adapter of the
         group (one launch) and (optionally) dx = dy W (+ residual) + mask * (g A) (one GEMM: the rank-8 term is its K-extension).
         side=True: the weight-gradient launch goes to the gradient side stream and runs beside the dX GEMM (the caller guarantees
@@ -1077,14 +1082,23 @@ class MrBlipEngine:
         else:
             self.lora_thin(dy, g.bblk, gbuf, g.N, seg=seg)                  # g' = scale * dy @ B      [M, 8*nad]
         ads = g.adapters
-        def grads():
-            ops.lora_grads(dy, u, x, gbuf, [a.dBt for a in ads], [a.row0 for a in ads], [a.out for a in ads], [a.dA for a in ads], g.K, drop=drop)
-        if side and self.grad_side_stream_enabled:
-            self.side_defer(grads)
-            if flush:
-                self.side_flush()
+        if self.lora_grads_batch and (collect is not None or (side and self.grad_side_stream_enabled)):
+            job = ops.lora_grads_job(dy, u, x, gbuf, [a.dBt for a in ads], [a.row0 for a in ads], [a.out for a in ads], [a.dA for a in ads], g.K, drop=drop)
+            if collect is not None:
+                collect.append(job)          # the caller launches the layer's jobs together
+            else:
+                self.side_defer(("grads", job))
+                if flush:
+                    self.side_flush()
         else:
-            grads()
+            def grads():
+                ops.lora_grads(dy, u, x, gbuf, [a.dBt for a in ads], [a.row0 for a in ads], [a.out for a in ads], [a.dA for a in ads], g.K, drop=drop)
+            if side and self.grad_side_stream_enabled:
+                self.side_defer(grads)
+                if flush:
+                    self.side_flush()
+            else:
+                grads()
         if dx is not None and not fused:
             if ks > 1:
                 ops.lora_dx(dy, g.Wt, gbuf, g.acatt, dx, pad64(g.N), residual=None, drop=drop, k_splits=ks)
@@ -1128,8 +1142,14 @@ class MrBlipEngine:
         ev.record()
         with torch.cuda.stream(st):
             st.wait_event(ev)
-            for fn in jobs:
-                fn()
+            grads = []     # ("grads", job) entries: independent launches (disjoint outputs, read-only inputs) — merged, up to 8 per launch,
+            for fn in jobs:  # and issued behind the hand-over's other jobs
+                if isinstance(fn, tuple):
+                    grads.append(fn[1])
+                else:
+                    fn()
+            for k in range(0, len(grads), 8):
+                ops.lora_grads_batched(grads[k: k + 8])
 
     def side_join(self):
         """the main stream waits for everything issued (or still queued) for the gradient side stream so far"""
@@ -1209,14 +1229,21 @@ class MrBlipEngine:
         ops.rmsnorm_bwd(t, self.ws["e_xfinal_in"], self.t5["enc_final"], c.t5_eps, dx)
         # (dyb alternates between two buffers: the fused write of layer i - 1's operand happens at the END of layer i, when layer i's
         # weight-gradient launch on the side stream may still be reading its own; the other buffer's readers were joined at the top of i)
-        dyb_pair = (self.buf("eb_dyb", (M, pad64(d)), bf16), self.buf("eb_dyb_alt", (M, pad64(d)), bf16))
-        dyb2 = self.buf("eb_dyb2", (M, pad64(d)), bf16)
-        gb, gb2, gb3, gb4 = (self.buf(n, (M, 64), bf16) for n in ("eb_g", "eb_g2", "eb_g3", "eb_g4"))
+        # Round 5: ONE weight-gradient launch per layer (the four groups' jobs together, on the side stream at the end of the layer) and its
+        # completion is awaited TWO layers later: the buffers it reads exist twice (layer parity; dyb, which the layer ABOVE writes for the
+        # layer below, three times), so the main stream never waits for a side-stream launch that was issued a moment ago (round 4: four
+        # launches, two hand-overs and one join per layer — the join at the top of a layer waited for the qkv group's launch).
+        batch = self.lora_grads_batch and self.grad_side_stream_enabled and not c.lora_mask_per_adapter
+        dyb_pair = (self.buf("eb_dyb", (M, pad64(d)), bf16), self.buf("eb_dyb_alt", (M, pad64(d)), bf16)) + ((self.buf("eb_dyb_alt2", (M, pad64(d)), bf16),) if batch else ())
+        nb = 2 if batch else 1
+        dyb2_s = [self.buf("eb_dyb2" + "_alt" * k, (M, pad64(d)), bf16) for k in range(nb)]
+        g_s = [tuple(self.buf(n + "_alt" * k, (M, 64), bf16) for n in ("eb_g", "eb_g2", "eb_g3", "eb_g4")) for k in range(nb)]
         dyact = self.buf("eb_dyact", (M, ff), bf16, zero=False)
-        dh = self.buf("eb_dh", (M, 2 * ff), bf16, zero=False)
+        dh_s = [self.buf("eb_dh" + "_alt" * k, (M, 2 * ff), bf16, zero=False) for k in range(nb)]
         dxn = self.buf("eb_dxn", (M, d), f32, zero=False)
         do = self.buf("eb_do", (M, inner), bf16, zero=False)
-        dqkv = self.buf("eb_dqkv", (M, 3 * inner), bf16, zero=False)
+        dqkv_s = [self.buf("eb_dqkv" + "_alt" * k, (M, 3 * inner), bf16, zero=False) for k in range(nb)]
+        grads_done: Dict[int, torch.cuda.Event] = {}
         rs = ops.rup32(S)
         kt, qt, dot = (self.buf(n, (B, H, ops.rup32(dk), rs), bf16) for n in ("eb_kt", "eb_qt", "eb_dot"))
         delta = self.buf("eb_delta", (B, H, rs), f32)
@@ -1224,10 +1251,20 @@ class MrBlipEngine:
         dyb_ready = False
         for i in reversed(range(len(self.t5["enc"]))):
             L = self.t5["enc"][i]
-            dyb = dyb_pair[i & 1]
-            # the LoRA weight-gradient launches of this layer run on the side stream beside the dX GEMMs; their inputs (dyb/dyb2/dh/
-            # dqkv and the four g buffers) are written once per layer, so one join per layer keeps every reader ahead of its next writer
-            self.side_join()
+            nd = len(dyb_pair)
+            dyb = dyb_pair[i % nd]
+            par = i & 1 if batch else 0
+            dyb2, dh, dqkv = dyb2_s[par], dh_s[par], dqkv_s[par]
+            gb, gb2, gb3, gb4 = g_s[par]
+            layer_jobs: Optional[list] = [] if batch else None
+            if batch:
+                ev_old = grads_done.pop(i + 2, None)     # the launch that read this parity's buffers two layers ago
+                if ev_old is not None:
+                    torch.cuda.current_stream().wait_event(ev_old)
+            else:
+                # the LoRA weight-gradient launches of this layer run on the side stream beside the dX GEMMs; their inputs (dyb/dyb2/dh/
+                # dqkv and the four g buffers) are written once per layer, so one join per layer keeps every reader ahead of its next writer
+                self.side_join()
             # K^T / Q^T of this layer depend only on saved forward activations: transposed on the side stream while the FFN backward runs
             kq_ready = None
             t_saved = bool(self.enc_t_saved.get(i))
@@ -1248,10 +1285,12 @@ class MrBlipEngine:
             if not dyb_ready:
                 ops.cast_dropout(dx, out_bf16=dyb, drop=self.drop(L["sites"][3], p))
             self.lg_bwd(L["wo"], dyb, self.ws[f"e{i}_y"], self.ws[f"e{i}_u_wo"], gb, dyact, side=True, tile_cfg=_ENC_BWD_CFG[0], flush=False,
-                        prefetch=self.enc_pf_bwd([L["wi"]], M))
+                        prefetch=self.enc_pf_bwd([L["wi"]], M), collect=layer_jobs)
             ops.gated_gelu_bwd(dyact, self.ws[f"e{i}_h"], dh, drop=self.drop(L["sites"][2], p))
             self.lg_bwd(L["wi"], dh, self.ws[f"e{i}_xn2"], self.ws[f"e{i}_u_wi"], gb2, dxn, side=True, tile_cfg=_ENC_BWD_CFG[1],
-                        prefetch=self.enc_pf_bwd([L["o"]], M))
+                        prefetch=self.enc_pf_bwd([L["o"]], M), collect=layer_jobs)
+            if batch and kq_ready is not None:
+                self.side_flush()      # (the K^T / Q^T job queued above must go out here: this layer's attention backward waits for it)
             if self.fuse_bwd_cast:
                 ops.rmsnorm_bwd(dxn, self.ws[f"e{i}_xm"], L["ln1"], c.t5_eps, other, dx_add=dx, out_bf16=dyb2, out_drop=self.drop(L["sites"][1], p))
             else:
@@ -1260,7 +1299,7 @@ class MrBlipEngine:
             dx, other = other, dx
             # xm = x_in + drop(o(attn(qkv(xn))))
             dot_done = self.lg_bwd(L["o"], dyb2, self.ws[f"e{i}_o"], self.ws[f"e{i}_u_o"], gb3, do, side=True, tile_cfg=_ENC_BWD_CFG[2], flush=False,
-                                   tout=(dot,) if self.tout_ok(dk, B, S, 2) else None, t_rows=S)
+                                   tout=(dot,) if self.tout_ok(dk, B, S, 2) else None, t_rows=S, collect=layer_jobs)
             qkv, o = self.ws[f"e{i}_qkv"], self.ws[f"e{i}_o"]
             q4, k4, v4 = self.v4(qkv, B, S, H, dk, 0), self.v4(qkv, B, S, H, dk, inner), self.v4(qkv, B, S, H, dk, 2 * inner)
             do4 = self.v4(do, B, S, H, dk)
@@ -1279,9 +1318,18 @@ class MrBlipEngine:
                               scale=1.0, bias_lut=self.lut_enc, kmask=kmask, drop=self.drop(L["sites"][0], p),
                               drop_bits=self.ws.get(f"e{i}_dbits") if self.drop(L["sites"][0], p) is not None else None)
             self.lg_bwd(L["qkv"], dqkv, self.ws[f"e{i}_xn"], self.ws[f"e{i}_u_qkv"], gb4, dxn, side=True, tile_cfg=_ENC_BWD_CFG[3],
-                        prefetch=self.enc_pf_bwd([self.t5["enc"][i - 1]["wo"]], M) if i > 0 else None)
+                        prefetch=self.enc_pf_bwd([self.t5["enc"][i - 1]["wo"]], M) if i > 0 else None, collect=layer_jobs)
+            if batch and layer_jobs:   # the layer's four weight-gradient pairs: one launch, one hand-over
+                ev_done = torch.cuda.Event()
+
+                def grads_job(jobs=layer_jobs, ev_done=ev_done):
+                    ops.lora_grads_batched(jobs)
+                    ev_done.record()
+                self.side_defer(grads_job)
+                self.side_flush()
+                grads_done[i] = ev_done
             if i > 0 and self.fuse_bwd_cast:   # ... and the layer below's first operand
-                ops.rmsnorm_bwd(dxn, self.ws[f"e{i}_xin"], L["ln0"], c.t5_eps, other, dx_add=dx, out_bf16=dyb_pair[(i - 1) & 1],
+                ops.rmsnorm_bwd(dxn, self.ws[f"e{i}_xin"], L["ln0"], c.t5_eps, other, dx_add=dx, out_bf16=dyb_pair[(i - 1) % nd],
                                 out_drop=self.drop(self.t5["enc"][i - 1]["sites"][3], p))
                 dyb_ready = True
             else:

@@ -63,6 +63,8 @@ _colsum = _sig("mrblip_colsum", vp, ll, i32, i32, vp, vp)
 _lora_tn = _sig("mrblip_lora_tn", vp, ll, vp, ll, i32, i32, i32, vp, vp, vp, vp, vp, u32, f32, vp)
 _lora_pack = _sig("mrblip_lora_pack", vp, vp, vp, vp, vp, vp, i32, f32, vp)
 _lora_grads = _sig("mrblip_lora_grads", vp, ll, vp, ll, vp, ll, vp, ll, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, u32, f32, vp)
+_lora_grads_b_raw = _sig("mrblip_lora_grads_batched", i32, vp, vp, vp)
+_lora_grads_b = lambda arr, n, sp, st: _lora_grads_b_raw(n, C.cast(arr, vp), sp, st)   # noqa: E731
 _lora_down = _sig("mrblip_gemm_lora_down", vp, ll, vp, ll, i32, i32, i32, vp, ll, vp, u32, f32, vp)
 _gemm_lora_dx = _sig("mrblip_gemm_lora_dx", vp, ll, vp, ll, vp, ll, vp, ll, i32, i32, i32, vp, ll, i32, vp, ll, vp, u32, f32, i32, vp)
 _drop_b16 = _sig("mrblip_dropout_bf16", vp, ll, vp, ll, i32, i32, vp, u32, f32, vp)
@@ -102,7 +104,7 @@ EXPORTS = [
     "mrblip_patchify", "mrblip_vit_assemble", "mrblip_row_copy", "mrblip_mean_pool", "mrblip_mean_pool_bwd",
     "mrblip_cast_dropout", "mrblip_gelu_bwd", "mrblip_gated_gelu_bwd", "mrblip_cross_entropy", "mrblip_adamw", "mrblip_adamw_guarded", "mrblip_gemm_debug_stall_thin",
     "mrblip_seed_bump", "mrblip_prefetch", "mrblip_gemm_set_prefetch", "mrblip_gemm_set_thin", "mrblip_lora_dx_add", "mrblip_dropout_bf16", "mrblip_colsum", "mrblip_lora_pack", "mrblip_lora_tn",
-    "mrblip_lora_grads", "mrblip_gemm_lora_down", "mrblip_gemm_lora_dx", "mrblip_patchify_u8",
+    "mrblip_lora_grads", "mrblip_lora_grads_batched", "mrblip_gemm_lora_down", "mrblip_gemm_lora_dx", "mrblip_patchify_u8",
     "mrblip_gemm_set_cu_reserve", "mrblip_lora_rows", "mrblip_rmsnorm_lora_fwd", "mrblip_lora_rows_init", "mrblip_dec_proj", "mrblip_dec_proj_config", "mrblip_lora_dx_add_batched", "mrblip_lora_rows_batched", "mrblip_gemm_set_extra", "mrblip_attention_set_split_workspace",
     "mrblip_gemm_f16", "mrblip_layernorm_fwd_f16", "mrblip_attention_fwd_rowv_f16", "mrblip_patchify_f16", "mrblip_patchify_u8_f16",
 ]
@@ -377,6 +379,39 @@ def lora_grads(dy, u, x, g, dBt, b_col0, b_ncols, dA, K, drop: Optional[Dropout]
     _chk(_lora_grads(_p(dy), _ld(dy), _p(u), _ld(u), _p(x), _ld(x), _p(g), _ld(g), M, N, K, 8 * n,
                      (vp * n)(*[o.data_ptr() for o in dBt]), (i32 * n)(*b_col0), (i32 * n)(*b_ncols), (ll * n)(*b_ncols),
                      (vp * n)(*[o.data_ptr() for o in dA]), (ll * n)(*([K] * n)), sp, site, p, _stream()))
+
+
+class LoraGradsJob(C.Structure):
+    """mirror of MrblipLoraGradsJob (include/mrblip_hip.h)"""
+    _fields_ = [("dY", vp), ("lddy", ll), ("U", vp), ("ldu", ll), ("X", vp), ("ldx", ll), ("G", vp), ("ldg", ll),
+                ("M", i32), ("N", i32), ("K", i32), ("R", i32),
+                ("dBt", vp * 4), ("b_col0", i32 * 4), ("b_ncols", i32 * 4), ("b_lds", ll * 4),
+                ("dA", vp * 4), ("a_lds", ll * 4), ("site", u32), ("p_drop", f32)]
+
+
+def lora_grads_job(dy, u, x, g, dBt, b_col0, b_ncols, dA, K, drop: Optional[Dropout] = None):
+    """the arguments of one ``lora_grads`` call as a job of ``lora_grads_batched`` (a tuple: (seed tensor or None, filled struct))"""
+    j = LoraGradsJob()
+    j.dY, j.lddy, j.U, j.ldu, j.X, j.ldx, j.G, j.ldg = dy.data_ptr(), _ld(dy), u.data_ptr(), _ld(u), x.data_ptr(), _ld(x), g.data_ptr(), _ld(g)
+    j.M, j.N, j.K, j.R = dy.shape[0], dy.shape[1], K, 8 * len(dBt)
+    for i in range(len(dBt)):
+        j.dBt[i], j.b_col0[i], j.b_ncols[i], j.b_lds[i] = dBt[i].data_ptr(), b_col0[i], b_ncols[i], b_ncols[i]
+        j.dA[i], j.a_lds[i] = dA[i].data_ptr(), K
+    seed = None
+    if drop is not None and drop.p > 0.0:
+        j.site, j.p_drop, seed = drop.site, drop.p, drop.seed
+    return seed, j
+
+
+def lora_grads_batched(jobs):
+    """both weight gradients of up to 8 fused LoRA groups in ONE launch (same bits as one ``lora_grads`` call per group)"""
+    n = len(jobs)
+    assert 1 <= n <= 8
+    seeds = {s.data_ptr(): s for s, _ in jobs if s is not None}
+    assert len(seeds) <= 1, "one device seed per launch"
+    arr = (LoraGradsJob * n)(*[j for _, j in jobs])
+    sp = next(iter(seeds)) if seeds else None
+    _chk(_lora_grads_b(arr, n, sp, _stream()))
 
 
 def lora_down(x, acat, u, K, drop: Optional[Dropout] = None):

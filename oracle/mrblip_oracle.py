@@ -522,13 +522,28 @@ def dropout_hash_lin(idx: Tensor, seed: int, site: int) -> Tensor:
     return t
 
 
+def dropout_hash_lin24(idx: Tensor, seed: int, site: int) -> Tensor:
+    """Restates csrc/common.h mrb_lin_fin24(idx * MRB_H1 + mrb_lin_base(seed, site)): the linear-index counter hash whose finaliser runs
+    on the 24-bit multiplier (uint32 arithmetic emulated in int64)."""
+    idx = idx.to(torch.int64)
+    base = _u32(_u32((seed & 0xFFFFFFFF) * 0x9E3779B1) + _u32((site & 0xFFFFFFFF) * 0x85EBCA77))
+    t = _u32(_u32(idx * 0x9E3779B1) + base)
+    t = t ^ (t >> 15)
+    t = _u32((t & 0xFFFFFF) * 0x9E3779)
+    t = t ^ (t >> 13)
+    return t
+
+
 def dropout_keep_attn(B: int, H: int, Sq: int, Sk: int, seed: int, site: int, p: float) -> Tensor:
-    """keep mask [B,H,Sq,Sk] of the attention-probability dropout (csrc/attention.hip, "draws v2"): one hash per
-    (row = (b*H+h)*Sq+q, key QUAD): index = row * ceil(Sk/4) + key/4; key 4i + j reads the 11-bit window of the hash at bit 7j;
-    keep iff window >= round(p * 2048)."""
+    """keep mask [B,H,Sq,Sk] of the attention-probability dropout (csrc/attention.hip, "draws v3"): one hash h per
+    (row = (b*H+h)*Sq+q, key QUAD): index = row * ceil(Sk/4) + key/4; g = rotr(h, 8); key 4i + j reads the 16-bit draw
+    j = 0: h & 0xffff, 1: h >> 16, 2: g & 0xffff, 3: g >> 16; keep iff draw >= max(1, round(p * 65536))."""
     skq = (Sk + 3) // 4
     row = torch.arange(B * H * Sq, dtype=torch.int64)[:, None]
     key = torch.arange(Sk, dtype=torch.int64)[None, :]
-    h = dropout_hash_lin((row * skq + (key >> 2)) & 0xFFFFFFFF, seed, site)
-    draw = (h >> (7 * (key & 3))) & 0x7FF
-    return (draw >= int(p * 2048.0 + 0.5)).reshape(B, H, Sq, Sk).float()
+    h = dropout_hash_lin24((row * skq + (key >> 2)) & 0xFFFFFFFF, seed, site)
+    g = _u32((h >> 8) | (h << 24))
+    j = key & 3
+    w = torch.where(j >= 2, g, h)
+    draw = torch.where((j & 1) == 1, w >> 16, w & 0xFFFF)
+    return (draw >= max(1, int(p * 65536.0 + 0.5))).reshape(B, H, Sq, Sk).float()

@@ -456,9 +456,12 @@ def test_attention_lds_path_dropout_bits(ops, use_bits, use_lut, B, H, Sq, Sk, D
     dmask = dropout_keep_attn(B, H, Sq, Sk, 977, 5, p).to(dev())
     ref, _ = _attn_ref(qr, kr, vr, 1.0, bias, None, dmask, p)
     assert rel(o.float().permute(0, 2, 1, 3), ref) < 6e-3
-    if use_bits:  # the stored words are exactly the oracle's keep mask
+    if use_bits:  # the stored words are exactly the oracle's keep mask, key kk of a tile at bit attn_bitpos_key(kk) (csrc/attention.hip:
+        # the forward collects the bits of PACKED probability pairs, so a word holds even keys in its low and odd keys in its high half)
         w = bits.view(B, H, ops.rup32(Sk) // 32, ops.rup32(Sq))
-        got = ((w[:, :, :, :Sq, None] >> torch.arange(32, device=dev())) & 1).permute(0, 1, 3, 2, 4).reshape(B, H, Sq, -1)[..., :Sk]
+        kk = torch.arange(32, device=dev())
+        pos = 16 * (kk & 1) + 8 * ((kk >> 3) & 1) + 4 * (kk >> 4) + ((kk & 7) >> 1)
+        got = ((w[:, :, :, :Sq, None] >> pos) & 1).permute(0, 1, 3, 2, 4).reshape(B, H, Sq, -1)[..., :Sk]
         assert torch.equal(got.bool(), dmask.bool())
     ref.backward(do.float().permute(0, 2, 1, 3))
     kt, qt, dot = ops.head_transpose(k), ops.head_transpose(q), ops.head_transpose(do)
