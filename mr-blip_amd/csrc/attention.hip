@@ -1167,8 +1167,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_lds_kernel(const AttnArgs 
 }
 
 // ---- backward, part 2: dK, dV.  One wave owns 32 keys and walks the query tiles.
+// Round 5: the kernel is compiled for TWO resident blocks per CU.  Left to itself the compiler took 398 registers (256 + 142 accumulation
+// registers: two instances of the tile body and the next tile's prefetched fragments) — ONE wave per SIMD, so the Q-Former's cross-attention
+// backward (32 queries x 257 keys: one tile per wave, a chain of dependent loads) ran 2160 blocks as 8.4 rounds of exposed latency:
+// 142 us per launch, six launches per step.
+#ifndef ATTN_DKV_BLOCKS
+#define ATTN_DKV_BLOCKS 2
+#endif
 template <int DP, int FLAGS>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
+__global__ __launch_bounds__(256, ATTN_DKV_BLOCKS) void attn_bwd_dkv_kernel(const AttnArgs p) {
   constexpr int KS = DP / 16, MT = DP / 32;
   constexpr bool LUT = FLAGS & F_LUT, MASK = FLAGS & F_MASK, CAUSAL = FLAGS & F_CAUSAL, DROP = FLAGS & F_DROP;
   __shared__ float lut[LUT ? 257 : 1];
@@ -1201,33 +1208,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
   const float scale2 = p.scale * MRB_LOG2E;
   const float keep_scale = DROP ? p.drop.inv_keep : 1.0f;
 
-  bf16x8 qcur[KS], docur[KS];
-  load_rows<KS>(qcur, qbase, p.Q.rs, qstart + perm23(l31), p.Sq, p.D, hi);
-  load_rows<KS>(docur, dobase, p.dO.rs, qstart + perm23(l31), p.Sq, p.D, hi);
-  auto tile = [&](auto edge_c, int q0) {
-    constexpr bool EDGE = decltype(edge_c)::value;
-    bf16x8 dotf[MT][2], qtf[MT][2];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      const bf16_t* dot = dotbase + (long long)(mt * 32 + l31) * p.dOt.ds + q0 + 8 * hi;
-      const bf16_t* qt = qtbase + (long long)(mt * 32 + l31) * p.Qt.ds + q0 + 8 * hi;
-      dotf[mt][0] = ld8(dot); dotf[mt][1] = ld8(dot + 16);
-      qtf[mt][0] = ld8(qt); qtf[mt][1] = ld8(qt + 16);
-    }
-    float lse[16], del[16];
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      const int qq = q0 + 16 * c + 8 * hi;  // Sqpad is a multiple of 32 -> in-bounds
-      const float4 a0 = *reinterpret_cast<const float4*>(lsebase + qq), a1 = *reinterpret_cast<const float4*>(lsebase + qq + 4);
-      const float4 b0 = *reinterpret_cast<const float4*>(delbase + qq), b1 = *reinterpret_cast<const float4*>(delbase + qq + 4);
-      lse[8 * c + 0] = a0.x; lse[8 * c + 1] = a0.y; lse[8 * c + 2] = a0.z; lse[8 * c + 3] = a0.w;
-      lse[8 * c + 4] = a1.x; lse[8 * c + 5] = a1.y; lse[8 * c + 6] = a1.z; lse[8 * c + 7] = a1.w;
-      del[8 * c + 0] = b0.x; del[8 * c + 1] = b0.y; del[8 * c + 2] = b0.z; del[8 * c + 3] = b0.w;
-      del[8 * c + 4] = b1.x; del[8 * c + 5] = b1.y; del[8 * c + 6] = b1.z; del[8 * c + 7] = b1.w;
-    }
-    bf16x8 qnext[KS], donext[KS];
-    load_rows<KS>(qnext, qbase, p.Q.rs, q0 + 32 + perm23(l31), p.Sq, p.D, hi);
-    load_rows<KS>(donext, dobase, p.dO.rs, q0 + 32 + perm23(l31), p.Sq, p.D, hi);
+  // ONE instance of the tile body, EDGE a run-time wave-uniform flag behind a real branch, operands fetched where they are used (round 5:
+  // two compile-time instances + the next tile's prefetched fragments cost 398 registers, see above; every caller of this form has at most
+  // 32 queries, i.e. ONE tile per wave — nothing to prefetch for)
+  auto tile = [&](const bool EDGE, int q0) {
+    bf16x8 qcur[KS], docur[KS];
+    load_rows<KS>(qcur, qbase, p.Q.rs, q0 + perm23(l31), p.Sq, p.D, hi);
+    load_rows<KS>(docur, dobase, p.dO.rs, q0 + perm23(l31), p.Sq, p.D, hi);
     f32x16 sacc, dpacc;
     zero16(sacc);
     zero16(dpacc);
@@ -1242,19 +1229,36 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
     // two independent halves (8 query rows each): short live ranges for the per-element temporaries
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
+      bf16x8 dotf[MT], qtf[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        dotf[mt] = ld8(dotbase + (long long)(mt * 32 + l31) * p.dOt.ds + q0 + 8 * hi + 16 * c);
+        qtf[mt] = ld8(qtbase + (long long)(mt * 32 + l31) * p.Qt.ds + q0 + 8 * hi + 16 * c);
+      }
+      const int qq0 = q0 + 16 * c + 8 * hi;  // Sqpad is a multiple of 32 -> in-bounds
+      const float4 a0 = *reinterpret_cast<const float4*>(lsebase + qq0), a1 = *reinterpret_cast<const float4*>(lsebase + qq0 + 4);
+      const float4 b0 = *reinterpret_cast<const float4*>(delbase + qq0), b1 = *reinterpret_cast<const float4*>(delbase + qq0 + 4);
+      const float lse[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w}, del[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
       uint32_t draw[8];
-      if (DROP) drop_draws8_keyowner(draw, bh_idx + (uint32_t)(q0 + 16 * c + 8 * hi), key, (p.Sk + 3) >> 2, mrb_lin_base(drop_seed, p.drop.site));
+      if (DROP) drop_draws8_keyowner(draw, bh_idx + (uint32_t)qq0, key, (p.Sk + 3) >> 2, mrb_lin_base(drop_seed, p.drop.site));
+      float prs[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) prs[j] = ex2(fmaf(lse[j], -MRB_LOG2E, sv[8 * c + j]));
+      if (EDGE) {
+        asm volatile("; edge tile" ::: "memory");   // (keeps this block behind a real branch: see attn_bwd_dkv_lds_kernel)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int qq = qq0 + j;
+          bool ok = qq < p.Sq;
+          if (CAUSAL) ok = ok && (key <= qq);
+          prs[j] = ok ? prs[j] : 0.f;
+        }
+      }
       float pd[8], ds[8];  // pd: dropped P (without 1/(1-p));  ds: dS / scale  — both factors are applied once at the end
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int r = 8 * c + j;
-        float pr = ex2(fmaf(lse[r], -MRB_LOG2E, sv[r]));
-        if (EDGE) {
-          const int qq = q0 + 16 * c + 8 * hi + j;
-          bool ok = qq < p.Sq;
-          if (CAUSAL) ok = ok && (key <= qq);
-          pr = ok ? pr : 0.f;
-        }
+        const float pr = prs[j];
         float kfr = keep_scale, prd = pr;
         if (DROP) {
           const bool keep = draw[j] >= p.drop.thresh24;
@@ -1262,23 +1266,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
           prd = keep ? pr : 0.f;
         }
         pd[j] = prd;
-        ds[j] = pr * (kfr * dpacc[r] - del[r]);
+        ds[j] = pr * (kfr * dpacc[r] - del[j]);
       }
       const bf16x8 pc = pack8(pd), sc = pack8(ds);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
-        dv[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dotf[mt][c], pc, dv[mt], 0, 0, 0);
-        dk[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf[mt][c], sc, dk[mt], 0, 0, 0);
+        dv[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dotf[mt], pc, dv[mt], 0, 0, 0);
+        dk[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf[mt], sc, dk[mt], 0, 0, 0);
       }
     }
-#pragma unroll
-    for (int s = 0; s < KS; ++s) { qcur[s] = qnext[s]; docur[s] = donext[s]; }
   };
-  for (int q0 = qstart; q0 < p.Sq; q0 += 32) {
-    const bool edge = q0 + 32 > p.Sq || (CAUSAL && q0 < kb0 + 31);
-    if (edge) tile(BoolC<true>(), q0);
-    else tile(BoolC<false>(), q0);
-  }
+  for (int q0 = qstart; q0 < p.Sq; q0 += 32) tile(q0 + 32 > p.Sq || (CAUSAL && q0 < kb0 + 31), q0);
   const float fk = key_ok ? p.scale : 0.f, fv = key_ok ? keep_scale : 0.f;  // masked keys: exact zeros
   if (key < p.Sk) {
     bf16_t* kp = const_cast<bf16_t*>(p.dK.ptr) + b * p.dK.bs + h * p.dK.hs + (long long)key * p.dK.rs;

@@ -166,6 +166,19 @@ def lr_at(cur_epoch: int, cur_step: int, state: dict, *, max_epoch, min_lr, init
 
 
 # ====================================================================================== floating-point path
+class _GradRound(torch.autograd.Function):
+    """identity whose backward rounds the incoming gradient (see Oracle.emu_grad)"""
+
+    @staticmethod
+    def forward(ctx, x, fn):
+        ctx.fn = fn
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ctx.fn(g), None
+
+
 class Oracle:
     """Functional forward over a flat state dict with the reference's parameter names."""
 
@@ -195,15 +208,24 @@ class Oracle:
     emu_towers = None
     _tower = None
 
+    # Rounding experiments (tools/grad_noise_budget.py, round 5): ``round_fn`` replaces round-to-nearest-even (e.g. by a stochastic rounding
+    # to one of the two bf16 neighbours: another, equally legitimate realisation of the same rounding points); ``emu_grad`` also rounds the
+    # GRADIENT arriving at every linear layer's output in the backward pass — the HIP backward feeds its dX / dW GEMMs bf16 copies of dy
+    # (mrblip/engine.py: cast_dropout / rmsnorm_bwd_cast), a rounding point the forward-only emulation does not have.
+    round_fn = None
+    emu_grad = False
+
     def rb(self, x: Tensor) -> Tensor:
         if not self.emu:
             return x
         if self.emu_towers is not None and self._tower not in self.emu_towers and (self._tower or "").split(":")[0] not in self.emu_towers:
             return x
-        return x.bfloat16().float()
+        return x.bfloat16().float() if self.round_fn is None else self.round_fn(x)
 
     def lin(self, x: Tensor, w: Tensor, b: Optional[Tensor] = None) -> Tensor:
         y = self.rb(x) @ self.rb(w).t()
+        if self.emu and self.emu_grad and y.requires_grad:
+            y = _GradRound.apply(y, self.round_fn or (lambda g: g.bfloat16().float()))
         return y if b is None else y + b
 
     def P(self, key: str) -> Tensor:

@@ -174,7 +174,7 @@ def test_c1_real_depth_nonzero_lora_gradients_against_oracle_autograd():
     compare("oracle-fp32", False, 5e-4, 2.4e-2, 5e-2, 9e-2)
 
 
-def _c2_setup():
+def _c2_setup(lora_init=None):
     """the engine, layout, clip and golden of the BENCHED size (BASELINE.json configs[1]); weights regenerated from their reference keys"""
     import os
 
@@ -201,7 +201,7 @@ def _c2_setup():
 
     dev = torch.device("cuda:0")
     src = NameKeyed()
-    eng = MrBlipEngine(EngineConfig.flan_t5_xl_qvh(), src, dev)   # LoRA: peft default init (B = 0) = the reference's LoRA-free run
+    eng = MrBlipEngine(EngineConfig.flan_t5_xl_qvh(), src, dev, lora_init=lora_init)   # lora_init None: peft default init (B = 0) = the reference's LoRA-free run
     eng.training = False
     tok = FixtureTokenizer()
     repl = P.annoying_replacement_dict(P.find_annoying_numbers(tok, 200)[0])
@@ -243,6 +243,89 @@ def test_c2_benched_size_against_reference():
     check("c2.grad t5_proj.bias vs reference-fp32 autograd", relerr(eng.dproj_b.cpu(), g["grad__t5_proj__bias"]), 5e-2)
     check("c2.grad ln_vision.weight vs reference-fp32 autograd", relerr(eng.dlnv_w.cpu(), g["grad__ln_vision__weight"]), 5e-2)
     check("c2.grad ln_vision.bias vs reference-fp32 autograd", relerr(eng.dlnv_b.cpu(), g["grad__ln_vision__bias"]), 5e-2)
+    del eng
+    torch.cuda.empty_cache()
+
+
+def _bias_report(tag, got, want):
+    """A rounding-limited gradient is an UNBIASED noisy copy of the true one: its norm ratio is 1 +- err and its cosine 1 - err^2 / 2.  A
+    logic error (a missing term, a wrong scale or mask) shows as a norm ratio off 1 or a cosine far below that.  Recorded per adapter class."""
+    got, want = torch.as_tensor(got, dtype=torch.float64).reshape(-1), torch.as_tensor(want, dtype=torch.float64).reshape(-1)
+    ratio = (got.norm() / want.norm().clamp_min(1e-30)).item()
+    cos = (torch.dot(got, want) / (got.norm() * want.norm()).clamp_min(1e-30)).item()
+    record(tag + ": |g_hip| / |g_ref| - 1 (abs)", abs(ratio - 1.0), 1e-2)
+    record(tag + ": 1 - cosine", 1.0 - cos, 1e-3)
+    return ratio, cos
+
+
+def test_c2_benched_size_nonzero_lora_gradients():
+    """VERDICT r4 missing 2 / next 2(b): the BENCHED model's LoRA path — XL width (d 2048, d_ff 5120, the K = 10240 dX, 24 + 24 layers), S = 2012,
+    where the stacked cross K / V projection, the in-GEMM thin role and the tall-input thin kernels engage — with NON-ZERO A and B in every one
+    of the 433 adapters, against the fp32 ORACLE's autograd (tests/golden/mr_c2_lora.npz from make_golden_c2_lora.py: sub-sampled dA / dB of
+    every adapter + their full norms; the reference cannot provide this, peft is absent: "parity unpinned" for the LoRA numerics, DESIGN.md
+    section 2).  Eval mode.  Besides the relative errors, every adapter class reports norm ratio and cosine (_bias_report): rounding noise is
+    unbiased, a logic error is not."""
+    import os
+
+    from util import GOLDEN
+    if not os.path.exists(os.path.join(GOLDEN, "mr_c2_lora.npz")):
+        pytest.skip("tests/golden/mr_c2_lora.npz not generated")
+    from weights import seeded_array
+    gl = load_golden("mr_c2_lora")
+    names, stride, std = gl["strings"]["names"], int(gl["strings"]["stride"]), float(gl["strings"]["lora_std"])
+
+    def lora_init(a, gen):
+        base = "t5_model.base_model.model." + a.name
+        a.A.copy_(torch.from_numpy(seeded_array(base + ".lora_A.default.weight", (8, a.in_dim), std=std)))
+        a.Bt.copy_(torch.from_numpy(seeded_array(base + ".lora_B.default.weight", (a.out, 8), std=std)).t())
+
+    eng, _, lay, video, g, T = _c2_setup(lora_init=lora_init)
+    dev = eng.dev
+    eng.zero_grad()
+    loss = eng.forward_backward(video.to(dev), lay, backward=True)
+    torch.cuda.synchronize()
+    d, S = 2048, lay.S
+    tag = "c2.lora!=0: "
+    # tolerances = ~1.6x the values measured in round 5 (loss 1.8e-4, encoder output 1.05e-2, logits 9.2e-3, t5_proj / ln_vision 2.2e-2 /
+    # 1.9e-2, all 433 adapters flat 1.7e-2, the worst single adapter 6.0e-2 (a decoder cross-attention q), norm ratios within 4.3e-3 of 1,
+    # cosine deficits <= 4.4e-4 = err^2 / 2 of an unbiased 3e-2 error)
+    check(tag + "loss vs oracle-fp32 (rel)", abs(loss.item() - float(gl["loss"])) / abs(float(gl["loss"])), 4e-4)
+    logits = eng.ws["d_logits"].view(1, -1, 32128).cpu()
+    check(tag + "t5.enc_out vs oracle-fp32", relerr(eng.ws["e_out"][:, :d].float().view(1, S, d)[:, ::4, ::16].cpu(), gl["enc_sub"]), 1.7e-2)
+    check(tag + "logits vs oracle-fp32", relerr(logits[..., ::64], gl["logits_sub"]), 1.5e-2)
+    check(tag + "grad t5_proj.weight vs oracle-fp32 autograd", relerr(eng.dproj_w.cpu()[::16, ::4], gl["grad__t5_proj__weight"]), 3.6e-2)
+    check(tag + "grad ln_vision.weight vs oracle-fp32 autograd", relerr(eng.dlnv_w.cpu(), gl["grad__ln_vision__weight"]), 3.2e-2)
+    by_name = {a.name: a for a in eng.adapters}
+    assert sorted(by_name) == sorted(names) and len(names) == 24 * 7 + 24 * 11 + 1
+    oa = ob = 0
+    num = den = 0.0
+    worst, worst_name = 0.0, ""
+    kinds = {}
+    for nm in names:
+        a = by_name[nm]
+        na, nb = 8 * len(range(0, a.in_dim, stride)), len(range(0, a.out, stride)) * 8
+        ga = torch.from_numpy(gl["lora_dA_sub"][oa: oa + na]).view(8, -1)
+        gb = torch.from_numpy(gl["lora_dB_sub"][ob: ob + nb]).view(-1, 8)
+        oa, ob = oa + na, ob + nb
+        ha, hb = a.dA.cpu()[:, ::stride], a.dBt.cpu().t()[::stride]
+        ea, eb = relerr(ha, ga), relerr(hb, gb)
+        num += float((ha - ga).pow(2).sum() + (hb - gb).pow(2).sum())
+        den += float(ga.pow(2).sum() + gb.pow(2).sum())
+        parts = nm.split(".")
+        kind = (parts[0][:3] + "." + ".".join(parts[-2:])) if len(parts) > 2 else nm
+        k = kinds.setdefault(kind, dict(worst=0.0, h=[], r=[]))
+        k["worst"] = max(k["worst"], ea, eb)
+        k["h"] += [ha.reshape(-1), hb.reshape(-1)]
+        k["r"] += [ga.reshape(-1), gb.reshape(-1)]
+        if max(ea, eb) > worst:
+            worst, worst_name = max(ea, eb), nm
+    assert oa == gl["lora_dA_sub"].size and ob == gl["lora_dB_sub"].size
+    for kind, k in sorted(kinds.items()):
+        record(tag + f"worst dA/dB (sub-sampled) of {kind} adapters vs oracle-fp32", k["worst"], 1e-1)
+        ratio, cos = _bias_report(tag + f"{kind} adapters, dA and dB together", torch.cat(k["h"]), torch.cat(k["r"]))
+        assert abs(ratio - 1.0) < 1e-2 and 1.0 - cos < 1e-3, (kind, ratio, cos)
+    check(tag + f"ALL LoRA gradients (flat over the sub-samples of {len(names)} adapters) vs oracle-fp32 autograd", math.sqrt(num / den), 2.8e-2)
+    check(tag + f"worst single adapter dA/dB vs oracle-fp32 autograd ({worst_name})", worst, 1e-1)
     del eng
     torch.cuda.empty_cache()
 
