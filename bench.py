@@ -268,6 +268,8 @@ def main():
                     "use with --workload anet)")
     ap.add_argument("--vary-text", action="store_true", help="cycle 8 queries of different token counts (S_enc changes every step, as in a real "
                     "QVH epoch: blip2_mr.py:572-824) instead of one fixed prompt; the headline number keeps the fixed prompt")
+    ap.add_argument("--graph", choices=["0", "1", "auto"], default=None, help="captured T5 part of the step (hipGraph replay per shape bucket, "
+                    "mrblip/engine.py): 0 off, 1 on, auto (the engine's default) = on for encoders of at most 512 rows (Charades-STA)")
     ap.add_argument("--vary-video", action="store_true", help="alternate TWO different resident clips: step i trains on clip i %% 2 while the look-ahead "
                     "encodes clip (i + 1) %% 2, so every look-ahead result is consumed under a DIFFERENT key than the one before (the headline passes the "
                     "same tensor every step; the look-ahead hit is keyed on data_ptr / shape / version)")
@@ -279,6 +281,9 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     if os.environ.get("MRB_BENCH_SHARE_GPU"):  # test hook: several ranks on ONE GPU (gloo) to exercise the N > 1 code path on a 1-GPU box
         local = 0
+        # two processes time-slice the CUs: the in-GEMM thin role hands out its roles by ticket (csrc/gemm.hip: by block id, tiles of one
+        # process span on producers whose CUs the other process's spinning tiles held — every run timed out, loudly since round 5)
+        os.environ.setdefault("MRB_GEMM_THIN_TICKET", "1")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
@@ -296,6 +301,8 @@ def main():
     cfg = EngineConfig.flan_t5_xl_qvh(mean_pool=wl["mean_pool"], vit_operands=args.vit_operands)
     eng = MrBlipEngine(cfg, RandomSource(dev, seed=1234), dev, lora_init=lora_init_nonzero, seed=42 + rank)
     eng.training = not args.no_dropout
+    if args.graph is not None:
+        eng.graph_mode = args.graph
     if args.vit_chunk > 0:
         eng.vit_chunk = args.vit_chunk
     if args.lookahead_blocks > 0:
@@ -477,7 +484,7 @@ def main():
                                    f"L_dec={layout.labels.shape[1]}, random-init weights, dropout {'on' if eng.training else 'off'}",
                        "global_batch": global_batch, "batch_per_gpu": B, "frames": wl["T"], "parallelism": f"dp{world}" if shard is None else f"frame-shard{world} (ViT + Q-Former over T/{world} frames per rank, T5 replicated)",
                        "vit_lookahead": not args.no_lookahead,
-                       "vary_text": ([l.S for l in layouts] if args.vary_text else False), "vary_video": bool(args.vary_video),
+                       "vary_text": ([l.S for l in layouts] if args.vary_text else False), "vary_video": bool(args.vary_video), "graph_mode": eng.graph_mode, "graph_replays": MrBlipEngine.graph_replays,
                        "lookahead_hits": MrBlipEngine.vit_prefetch_hits, "lookahead_misses": MrBlipEngine.vit_prefetch_misses},
             "launches_per_step": round(launches, 1),     # C-ABI kernel launches per step (torch-native ones: ~10, profiles/r02_native_in_step.txt)
             "host_enqueue_ms": round(1e3 * min(host_s), 2) if host_s else None,   # host time to enqueue one step onto an idle GPU (untimed extra steps); must stay below ms_per_step

@@ -154,8 +154,11 @@ int mrblip_gemm_set_prefetch(const void* ptr, long long bytes, const void* ptr2,
 /* One-shot: the calling thread's NEXT mrblip_gemm_bf16 launch (generic tile kernel, M > 64, K extension read last) computes its own
  * K-extension operand Aext[m, 0:R] = dropout(A)[m, 0:K] acat^T — what mrblip_lora_rows would have written in a launch of its own (peft
  * lora_A(lora_dropout(x)), same bits) — in its first workgroups while the tiles already run; the tiles wait for flags[m / 16] == epoch before
- * they read those rows.  flags: >= ceil(M / 16) + 1 words shared by the launches of ONE stream (the last one is an error word: 0xffffffff
- * after a tile's bounded wait ran out — check it; it never happens in a correct run); epoch: a value no earlier launch left there.
+ * they read those rows.  flags: >= ceil(M / 16) + 4 ZERO-initialised words shared by the launches of ONE stream: one flag per 16 rows, then
+ * (words n_flags - 3, n_flags - 2) the ticket and finished-workgroup counters by which the launch hands out its roles in the order its
+ * workgroups START (round 5: producers are then running before any consumer can wait for them, whatever the dispatch order; the kernel
+ * returns both to zero), then the fallback error word (non-zero after a tile's bounded wait ran out — it never happens in a correct
+ * run; `err` below overrides where it lives); epoch: a value no earlier launch left in the flags.
  * The mask uses the GEMM call's seed pointer with call-site id `site`.  The epoch is a launch argument: a captured graph that replays such a
  * launch must clear the flag words between replays (one memset node), or every replay would find the previous replay's flags set. */
 int mrblip_gemm_set_thin(const void* acat, long long lda, int R, int K, uint32_t site, float p_drop, uint32_t* flags, long long n_flags,

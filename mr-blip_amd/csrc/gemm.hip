@@ -71,7 +71,7 @@ struct GemmArgs {
   // extension's A operand themselves — Aext[m, 0:th_R] = dropout(A)[m, 0:th_K] th_A^T, the LoRA "down" product (body: lora_thin.h), 16
   // rows each — write it with write-through stores and set th_flags[row block] = th_epoch; a tile waits for the flags of its rows before
   // it stages the K extension (its LAST K-tile) and reads Aext past its XCD's L2
-  const bf16_t* th_A; long long th_lda; int th_R, th_K; DropoutArg th_drop; uint32_t* th_flags; uint32_t* th_err; uint32_t th_epoch; int th_blocks; int th_stall;   // th_stall: TEST HOOK (mrblip_gemm_debug_stall_thin) — the role exits without publishing
+  const bf16_t* th_A; long long th_lda; int th_R, th_K; DropoutArg th_drop; uint32_t* th_flags; uint32_t* th_err; uint32_t* th_tick; uint32_t th_epoch; int th_blocks; int th_stall;   // th_stall: TEST HOOK (mrblip_gemm_debug_stall_thin) — the role exits without publishing
   int pf_base, th_base, tile_base;   // first block id of the prefetch / thin / tile workgroups (launch_tile lays the three groups out)
   const void* pf_ptr; long long pf_n16; const void* pf_ptr2; long long pf_n16_2; int pf_blocks;   // (a second, usually small range: the LoRA K-extension operand)
 };
@@ -278,8 +278,34 @@ __global__ __launch_bounds__(WGM* WGN * 64, gemm_min_blocks(NS * (BM + BN) * BK 
   // tiles where those left slots idle — starved under contention, see launch_tile); the prefetch ones, which nothing waits for, sit in
   // front, or behind the tiles where the tiles leave workgroup slots idle / in the last, partly empty round of a multi-round grid
   // (launch_tile decides: pf_base / th_base / tile_base)
+  // Round 5: a launch with a THIN role hands out its roles by TICKET, not by block id.  Every workgroup draws a ticket when it starts to
+  // run (one relaxed agent-scope atomic on th_tick[0]); tickets [0, thb) compute the thin product, the next pfb prefetch, the rest walk
+  // the tiles.  A consumer tile therefore only ever waits for producers that STARTED BEFORE IT — resident and running, whatever order the
+  // eight XCD dispatchers hand the grid out in.  By block id the producers merely sat at the front of the grid: XCDs advance through
+  // their shares independently, and with two processes on one GPU a tile on one XCD span on a producer that another XCD — its CUs held by
+  // the OTHER process's spinning tiles — had not started: a cross-process deadlock until the bounded waits ran out (found by the error
+  // word's first reader, tests/test_train_entry_gpu.py::test_bench_two_ranks_share_one_gpu; every run, both ranks).  The last workgroup to
+  // finish (second counter, th_tick[1]) clears both counters: the next launch of the stream, and every replay of a captured graph, starts
+  // from zero without any host-side state.
+  int vbid = (int)blockIdx.x;
+  const bool ticketed = p.th_tick != nullptr;   // uniform
+  if (ticketed) {
+    if (threadIdx.x == 0) *reinterpret_cast<volatile uint32_t*>(smem) = __hip_atomic_fetch_add(p.th_tick, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    vbid = (int)*reinterpret_cast<volatile uint32_t*>(smem);
+    __syncthreads();
+  }
+  auto wg_done = [&]() __attribute__((always_inline)) {   // every exit of a ticketed launch counts; the last one resets the counters
+    if (ticketed && threadIdx.x == 0) {
+      const uint32_t old = __hip_atomic_fetch_add(p.th_tick + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (old == gridDim.x - 1) {
+        __hip_atomic_store(p.th_tick + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(p.th_tick, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  };
   const int pfb = p.pf_blocks;   // uniform
-  const int rid = (int)blockIdx.x - p.pf_base;   // prefetch index if in [0, pfb)
+  const int rid = vbid - p.pf_base;   // prefetch index if in [0, pfb)
   if (rid >= 0 && rid < pfb) {   // prefetch role: stream a later launch's weights through the memory-side cache, keep nothing
     const mrb_u32x4* __restrict__ q = reinterpret_cast<const mrb_u32x4*>(p.pf_ptr);
     const long long step = (long long)pfb * (NW * 64);
@@ -294,13 +320,14 @@ __global__ __launch_bounds__(WGM* WGN * 64, gemm_min_blocks(NS * (BM + BN) * BK 
     const mrb_u32x4* __restrict__ q2 = reinterpret_cast<const mrb_u32x4*>(p.pf_ptr2);
     for (i = (long long)rid * (NW * 64) + threadIdx.x; i < p.pf_n16_2; i += step) keep |= q2[i][1];
     asm volatile("" ::"v"(keep));   // the loads stay, no store
+    wg_done();
     return;
   }
 
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int thb = p.th_blocks;   // uniform
-  const int rb = (int)blockIdx.x - p.th_base;
+  const int rb = vbid - p.th_base;
   if (rb >= 0 && rb < thb) {   // thin role: 16 rows of the K extension's A operand (see GemmArgs)
     if (rb * 16 < p.M && !p.th_stall) {
       ThinArgs t;
@@ -314,6 +341,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, gemm_min_blocks(NS * (BM + BN) * BK 
       __syncthreads();   // the storing waves have drained their write-through stores
       if (threadIdx.x == 0) __hip_atomic_store(p.th_flags + rb, p.th_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    wg_done();
     return;
   }
   const int wm = w / WGN, wn = w % WGN;
@@ -379,7 +407,8 @@ __global__ __launch_bounds__(WGM* WGN * 64, gemm_min_blocks(NS * (BM + BN) * BK 
         if (lane < BM / 16 && rbk * 16 < p.M) {
           uint32_t tries = 0;   // (bounded: a protocol error must show as a wrong result in the tests, not as a hung GPU)
           while (__hip_atomic_load(p.th_flags + rbk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.th_epoch && ++tries < (1u << 19)) __builtin_amdgcn_s_sleep(4);
-          if (tries >= (1u << 19)) __hip_atomic_store(p.th_err, 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // loud: the host checks this word
+          // loud: the host checks this word (non-zero = failure; it carries the first-come diagnostics 0x80000000 | row block << 16 | block id)
+          if (tries >= (1u << 19)) __hip_atomic_store(p.th_err, 0x80000000u | ((uint32_t)(rbk & 0x7fff) << 16) | ((uint32_t)blockIdx.x & 0xffffu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         asm volatile("" ::: "memory");
       }
@@ -446,7 +475,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, gemm_min_blocks(NS * (BM + BN) * BK 
 #endif
   // ---- persistent tile loop: grid = resident blocks; a block's epilogue stores drain while it already stages the next tile
   const int ntiles = p.tiles_m * p.tiles_n;
-  for (int tile = (int)blockIdx.x - p.tile_base; tile < ntiles; tile += (int)gridDim.x - pfb - thb) {
+  for (int tile = vbid - p.tile_base; tile < ntiles; tile += (int)gridDim.x - pfb - thb) {
   {  // tile id -> (bm, bn): XCD-contiguous remap (bijective), then grouped ordering for L2 reuse of the W panel
     int bid = tile;
     const int q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, idx = bid >> 3;
@@ -694,6 +723,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, gemm_min_blocks(NS * (BM + BN) * BK 
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   }  // persistent tile loop
+  wg_done();
 }
 
 // one LDS-DMA piece (1 KiB, lane-linear in LDS) of an operand tile
@@ -1610,6 +1640,11 @@ static bool pf_tail_enabled() {
   if (on < 0) { const char* e = getenv("MRB_GEMM_PF_TAIL"); on = (e && e[0] == '1') ? 1 : 0; }
   return on == 1;
 }
+static bool thin_ticket_enabled() {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("MRB_GEMM_THIN_TICKET"); on = (e && e[0] == '1') ? 1 : 0; }
+  return on == 1;
+}
 static bool roles_last_enabled() {
   static int on = -1;
   if (on < 0) { const char* e = getenv("MRB_GEMM_ROLES_LAST"); on = (e && e[0] == '0') ? 0 : 1; }
@@ -1651,24 +1686,35 @@ static int launch_tile(GemmArgs& a, hipStream_t st) {
   const int grid = (NS == 2 && LDS > 80 * 1024 && ntiles > num_cu) ? num_cu : ntiles;
   a.pf_blocks = (a.pf_n16 > 0 || a.pf_n16_2 > 0) ? (a.pf_blocks + 7) / 8 * 8 : 0;
   a.th_blocks = a.th_flags ? ((a.M + 15) / 16 + 7) / 8 * 8 : 0;
-  // roles behind the tiles when the tiles leave at least 32 workgroup slots of the chip empty (the producers then start at once on the idle
-  // CUs; a tile that reaches its K extension first polls until they are through)
+  // Role layout.  With a thin role the roles go by TICKET (see the kernel): thin | prefetch | tiles in ticket order, i.e. in the order
+  // the workgroups start to run.  Without one (prefetch only: nothing waits for it) by block id: behind the tiles where those leave
+  // workgroup slots idle, in a partly empty last round, or in front.
   constexpr int per_cu = gemm_min_blocks(LDS, WGM * WGN);
   const int slots = num_cu * per_cu;
-  // Round 5: the THIN role always sits in FRONT of the tiles.  Its consumers poll flags; producers behind the consumers were starved under
-  // contention (two processes sharing a GPU: resident tiles span while their producers waited for a slot behind another queue's
-  // workgroups, the bounded wait ran out and the step went on with stale operands — found by the error word's first real reader,
-  // tests/test_train_entry_gpu.py::test_bench_two_ranks_share_one_gpu).  In front, every XCD's dispatcher hands out its share of the
-  // producers before any tile of that XCD, and producers never wait: a consumer can only ever wait for workgroups that are resident or
-  // done.  The prefetch role, which nothing waits for, may still go behind the tiles where they leave slots idle.
-  if (a.pf_blocks > 0 && grid + 32 <= slots && roles_last_enabled()) {   // thin | tiles | prefetch
-    a.th_base = 0; a.tile_base = a.th_blocks; a.pf_base = a.th_blocks + grid;
-  } else if (a.pf_blocks > 0 && grid == ntiles && grid > slots && pf_tail_enabled() && slots - (grid + a.th_blocks) % slots >= a.pf_blocks) {
-    // several rounds of one-tile workgroups with a partly empty last round: thin | tiles | prefetch — the prefetch workgroups start when
-    // the last round leaves slots free and end inside it (nothing waits for them)
-    a.th_base = 0; a.tile_base = a.th_blocks; a.pf_base = a.th_blocks + grid;
-  } else {                                                                               // prefetch | thin | tiles
-    a.pf_base = 0; a.th_base = a.pf_blocks; a.tile_base = a.pf_blocks + a.th_blocks;
+  if (a.th_blocks > 0 && thin_ticket_enabled()) {
+    a.th_base = 0; a.pf_base = a.th_blocks; a.tile_base = a.th_blocks + a.pf_blocks;
+  } else if (a.th_blocks > 0) {
+    // Default: roles by BLOCK ID with the thin role in FRONT of the tiles.  Every XCD's dispatcher hands out its share of the grid in
+    // order and producers never wait, so on a GPU that this process has to itself a tile can only wait for producers that other,
+    // FINITE kernels delay.  That is not a guarantee — see the ticket mode above, which is one — but it costs no atomics: the ticket
+    // mode's 500-1400 same-address atomics per launch cost 2.3 ms per QVH step (72.0 vs 69.7 ms), more than the role saves.  A
+    // starved hand-over fails loudly either way (error word -> skipped AdamW -> raise).  MRB_GEMM_THIN_TICKET=1 selects the ticket
+    // mode (GPU shared between processes: bench.py's MRB_BENCH_SHARE_GPU test hook sets it).
+    a.th_tick = nullptr;
+    if (a.pf_blocks > 0 && grid + 32 <= slots && roles_last_enabled()) {   // thin | tiles | prefetch
+      a.th_base = 0; a.tile_base = a.th_blocks; a.pf_base = a.th_blocks + grid;
+    } else {                                                               // prefetch | thin | tiles
+      a.pf_base = 0; a.th_base = a.pf_blocks; a.tile_base = a.pf_blocks + a.th_blocks;
+    }
+  } else {
+    a.th_tick = nullptr;
+    if (a.pf_blocks > 0 && grid + 32 <= slots && roles_last_enabled()) {   // tiles | prefetch
+      a.th_base = 0; a.tile_base = 0; a.pf_base = grid;
+    } else if (a.pf_blocks > 0 && grid == ntiles && grid > slots && pf_tail_enabled() && slots - grid % slots >= a.pf_blocks) {
+      a.th_base = 0; a.tile_base = 0; a.pf_base = grid;
+    } else {                                                               // prefetch | tiles
+      a.pf_base = 0; a.th_base = a.pf_blocks; a.tile_base = a.pf_blocks;
+    }
   }
   static_assert(LDS >= THIN_RED_BYTES(2), "the thin role's partial sums live in the tile's LDS");
   hipLaunchKernelGGL(kern, dim3(grid + a.pf_blocks + a.th_blocks), dim3(WGM * WGN * 64), LDS, st, a);
@@ -1772,13 +1818,15 @@ static int gemm_dispatch(const void* A, long long lda, const void* W, long long 
   a.t_inner = extra.set ? extra.t_inner : 0; a.t_rows = extra.t_rows; a.t_spad = extra.t_spad; a.t_bs = extra.t_bs; a.t_hs = extra.t_hs;
   a.t_stride = extra.t_stride; a.t_count = extra.set ? extra.t_count : 0;
   a.ext_group_n = extra.set ? extra.ext_group_n : 0;
-  a.th_flags = nullptr; a.th_err = nullptr; a.th_blocks = 0; a.th_stall = 0; a.th_A = nullptr; a.th_lda = 0; a.th_R = a.th_K = 0; a.th_epoch = 0;
+  a.th_flags = nullptr; a.th_err = nullptr; a.th_tick = nullptr; a.th_blocks = 0; a.th_stall = 0; a.th_A = nullptr; a.th_lda = 0; a.th_R = a.th_K = 0; a.th_epoch = 0;
   mk_drop_arg(a.th_drop, seed_ptr, 0, 0.f);
   if (th.set) {
-    MRB_REQUIRE(Aext && !ext_first && !f16 && M > 64 && th.K <= K && ldaext >= th.R && (ldaext % 4) == 0 && ((uintptr_t)Aext % 8) == 0 && th.n_flags >= (M + 15) / 16 + 1 &&
+    MRB_REQUIRE(Aext && !ext_first && !f16 && M > 64 && th.K <= K && ldaext >= th.R && (ldaext % 4) == 0 && ((uintptr_t)Aext % 8) == 0 && th.n_flags >= (M + 15) / 16 + 2 &&
                     (long long)M * lda * 2 < (1ll << 31) && !(th.p > 0.f && !seed_ptr),
                 "gemm: the thin role needs a K extension read last, more than 64 rows and one flag per 16 rows");
     a.th_A = (const bf16_t*)th.acat; a.th_lda = th.lda; a.th_R = th.R; a.th_K = th.K; a.th_flags = th.flags; a.th_err = th.err ? th.err : th.flags + (th.n_flags - 1); a.th_epoch = th.epoch; a.th_stall = g_thin_stall;
+    a.th_tick = th.flags + (th.n_flags - 3);   // two words: ticket, finished-workgroup count (zero between launches: the kernel resets them)
+    MRB_REQUIRE(th.n_flags >= (M + 15) / 16 + 4, "gemm: the thin role's flag buffer needs ceil(M / 16) + 4 words (flags, ticket, count, error)");
     mk_drop_arg(a.th_drop, seed_ptr, th.site, th.p);
   }
   a.pf_ptr = pf.ptr; a.pf_n16 = pf.bytes / 16; a.pf_ptr2 = pf.ptr2; a.pf_n16_2 = pf.bytes2 / 16; a.pf_blocks = pf.n_blocks;

@@ -206,8 +206,8 @@ def _thin_flags(device, n: int):
     buffer and tell their flags apart by the epoch; another stream gets its own buffer"""
     key = (device.index, _stream())
     st = _thin_state.get(key)
-    if st is None or st[0].numel() < n + 1:
-        st = [torch.zeros(max(n + 1, 1024), dtype=torch.int32, device=device), 0]
+    if st is None or st[0].numel() < n + 4:      # flags | ticket, finished count (the kernel keeps them at zero between launches) | spare
+        st = [torch.zeros(max(n + 4, 1024), dtype=torch.int32, device=device), 0]
         _thin_state[key] = st
     st[1] = st[1] % 0x7fffffff + 1
     return st[0], st[1]
@@ -226,6 +226,18 @@ def thin_error_word(device) -> torch.Tensor:
     if t is None:
         t = _thin_err[idx] = torch.zeros(1, dtype=torch.int32, device=torch.device("cuda", idx))
     return t
+
+
+def thin_flags_reset(device):
+    """clear the thin role's flag words of the CURRENT stream (creating them if needed).  Called at the head of a stream capture: the
+    launches' epochs are kernel arguments, so a replayed graph would find the previous replay's flags already set — the captured fill
+    clears them on every replay (include/mrblip_hip.h: mrblip_gemm_set_thin)."""
+    key = (device.index, _stream())
+    st = _thin_state.get(key)
+    if st is None:
+        _thin_state[key] = [torch.zeros(4096, dtype=torch.int32, device=device), 0]
+    else:
+        st[0].zero_()
 
 
 def gemm_thin_timeouts() -> int:

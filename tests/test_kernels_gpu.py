@@ -1278,6 +1278,20 @@ def test_gemm_thin_role_equals_the_lora_rows_launch(ops, M, N, K, nad, cfg, gate
                  thin=(acat, K, None)) if not gated else (_ for _ in ()).throw(ops.MrblipError("n/a"))
 
 
+def test_gemm_thin_role_ticket_mode_in_a_fresh_process():
+    """Round 5: MRB_GEMM_THIN_TICKET=1 hands the roles of a thin-role launch out by TICKET (the order in which the workgroups start to
+    run) instead of by block id — the provably live form for a GPU that several processes share (csrc/gemm.hip).  The switch is read once
+    per process: the equality test above runs again in a fresh interpreter with it set (same bits as the lora_rows launch, counters back
+    at zero after every launch or the repetitions would hang)."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, MRB_GEMM_THIN_TICKET="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", "test_gemm_thin_role_equals_the_lora_rows_launch"],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0 and "8 passed" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])
+
+
 @pytest.mark.parametrize("grid", [1, 5, 64, 0])
 def test_dec_proj_streaming_kernel_is_bit_identical_to_the_tile_kernel(ops, grid):
     """Round 4: for <= 16 rows mrblip_dec_proj runs as a streaming kernel (a block owns a range of 16-column tiles; rows and LoRA "down"

@@ -12,15 +12,16 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 WL = sys.argv[2] if len(sys.argv) > 2 else "charades"
+GRAPH = sys.argv[3] if len(sys.argv) > 3 else "auto"      # bench.py --graph: 0 eager, 1 / auto: the captured T5 part (round 5)
 ncpu = os.cpu_count()
 share = max(1, ncpu // 8)
 procs = []
 for i in range(N):
     cores = f"{i * share}-{(i + 1) * share - 1}"
     cmd = ["taskset", "-c", cores, sys.executable, os.path.join(ROOT, "bench.py"), "--workload", WL, "--steps", "12", "--warmup", "4", "--no-cpu-baseline",
-           "--no-hbm-kernels"]
+           "--no-hbm-kernels", "--graph", GRAPH]
     procs.append((cores, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)))
-print(f"# {N} concurrent bench.py --workload {WL} processes on one GPU, each pinned to {share} of {ncpu} cores (1/8 of the box)")
+print(f"# {N} concurrent bench.py --workload {WL} --graph {GRAPH} processes on one GPU, each pinned to {share} of {ncpu} cores (1/8 of the box)")
 worst = 0.0
 for cores, p in procs:
     out, _ = p.communicate(timeout=1500)
