@@ -101,6 +101,11 @@ class EngineConfig:
         return EngineConfig(**base)
 
 
+# tile configuration of the Q-Former's cross K / V input-gradient GEMM [F * 257, 1408] x [1408, 1536]^T (0 = auto = the 4-wave 256x256 form;
+# 14 = its 256x192 form: N = 1408 is 5.5 tiles of 256 but 7.3 of 192)
+_QF_KV_BWD_CFG = int(os.environ.get("MRB_QF_KV_BWD_CFG", "0"))
+
+
 class StateDictSource:
     """Weights by reference state-dict key (plain HF names or peft names for T5)."""
 
@@ -635,7 +640,7 @@ class MrBlipEngine:
                 ops.attention_bwd(q4, k4, v4, self.v4(oc, F_, nq, H, hd), do4, kt_c, qt_x, dot_s, self.ws[f"qf{i}_lsec"], delta,
                                   self.v4(dqc, F_, nq, H, hd), self.v4(dkv, F_, Tv, H, hd, 0), self.v4(dkv, F_, Tv, H, hd, D),
                                   scale=scale, drop=self.qdrop(C_["sites"][0], pdrop))
-                ops.gemm(dkv, C_["kv_wt"], dimg, residual=dimg)
+                ops.gemm(dkv, C_["kv_wt"], dimg, residual=dimg, tile_cfg=_QF_KV_BWD_CFG)
                 if i > 0:
                     ops.gemm(dqc, C_["q_wt"], nxt, residual=dy)
                     cur = nxt
