@@ -281,9 +281,8 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     if os.environ.get("MRB_BENCH_SHARE_GPU"):  # test hook: several ranks on ONE GPU (gloo) to exercise the N > 1 code path on a 1-GPU box
         local = 0
-        # two processes time-slice the CUs: the in-GEMM thin role hands out its roles by ticket (csrc/gemm.hip: by block id, tiles of one
-        # process span on producers whose CUs the other process's spinning tiles held — every run timed out, loudly since round 5)
-        os.environ.setdefault("MRB_GEMM_THIN_TICKET", "1")
+        # (two processes share the CUs here: the configuration in which the in-GEMM thin role's hand-over by block id deadlocked across the
+        # processes in every run — loudly since round 5; its units are claimed in start order now, csrc/gemm.hip)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
@@ -434,7 +433,7 @@ def main():
         m, n, k = F_ * 257, cfg.vit_mlp, cfg.vit_dim
         traffic_note = None
         traffic = None  # HBM-side bytes per launch of the same kernel from the committed PMC pass (tools/pmc_fc1.sh), QVH B=1 shape only
-        pmc = next((q for q in (os.path.join(ROOT, "profiles", n) for n in ("r04_pmc_fc1.json", "r03_pmc_fc1.json", "r02_pmc_fc1.json")) if os.path.exists(q)), None)
+        pmc = next((q for q in (os.path.join(ROOT, "profiles", n) for n in ("r05_pmc_fc1.json", "r04_pmc_fc1.json", "r03_pmc_fc1.json", "r02_pmc_fc1.json")) if os.path.exists(q)), None)
         if pmc and args.workload == "qvh" and B == 1 and F_ == 60:
             pj = json.load(open(pmc))
             traffic = pj.get("traffic_bytes_per_launch")
