@@ -281,8 +281,9 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     if os.environ.get("MRB_BENCH_SHARE_GPU"):  # test hook: several ranks on ONE GPU (gloo) to exercise the N > 1 code path on a 1-GPU box
         local = 0
-        # (two processes share the CUs here: the configuration in which the in-GEMM thin role's hand-over by block id deadlocked across the
-        # processes in every run — loudly since round 5; its units are claimed in start order now, csrc/gemm.hip)
+        # two processes time-slice the CUs: the in-GEMM thin role hands out its roles by ticket (csrc/gemm.hip: by block id, tiles of one
+        # process span on producers whose CUs the other process's spinning tiles held — every run timed out, loudly since round 5)
+        os.environ.setdefault("MRB_GEMM_THIN_TICKET", "1")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:

@@ -155,10 +155,9 @@ int mrblip_gemm_set_prefetch(const void* ptr, long long bytes, const void* ptr2,
  * K-extension operand Aext[m, 0:R] = dropout(A)[m, 0:K] acat^T — what mrblip_lora_rows would have written in a launch of its own (peft
  * lora_A(lora_dropout(x)), same bits) — in its first workgroups while the tiles already run; the tiles wait for flags[m / 16] == epoch before
  * they read those rows.  flags: >= ceil(M / 16) + 4 ZERO-initialised words shared by the launches of ONE stream: one flag per 16 rows, then
- * (words n_flags - 3, n_flags - 2) a ping-pong pair of claim counters, indexed by the epoch's parity: the launch's role units are
- * CLAIMED by its workgroups in the order they START (round 5: every unit is then in the hands of a running workgroup before any consumer
- * can wait for it, whatever the dispatch order; a launch clears the pair's other word for the next one — epochs must advance by one per
- * launch), then the fallback error word (non-zero after a tile's bounded wait ran out — it never happens in a correct
+ * (words n_flags - 3, n_flags - 2) the ticket and finished-workgroup counters by which the launch hands out its roles in the order its
+ * workgroups START (round 5: producers are then running before any consumer can wait for them, whatever the dispatch order; the kernel
+ * returns both to zero), then the fallback error word (non-zero after a tile's bounded wait ran out — it never happens in a correct
  * run; `err` below overrides where it lives); epoch: a value no earlier launch left in the flags.
  * The mask uses the GEMM call's seed pointer with call-site id `site`.  The epoch is a launch argument: a captured graph that replays such a
  * launch must clear the flag words between replays (one memset node), or every replay would find the previous replay's flags set. */

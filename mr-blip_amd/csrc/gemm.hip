@@ -274,28 +274,39 @@ __global__ __launch_bounds__(WGM* WGN * 64, gemm_min_blocks(NS * (BM + BN) * BK 
   static_assert(!GATED || TN == 2, "gated epilogue pairs the wave's two n-tiles");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
-  // ---- role workgroups.  A launch may carry PREFETCH units (stream a later launch's weights through the memory-side cache; nothing waits
-  // for them) and THIN units (16 rows each of this launch's own K-extension operand u = dropout(x)(sA)^T, published with write-through
-  // stores + a flag per unit that the tiles poll before their last K-tile).
-  //
-  // Round 5: in a launch with a thin role the units are CLAIMED, not assigned by block id.  The grid is [helpers | tiles]; every workgroup,
-  // when it STARTS TO RUN and before anything else, looks at the launch's claim counter (one load) and, while units are left, claims one
-  // (one atomic) and executes it; helpers then exit, tile workgroups go on to their tiles (tiles stay assigned by block id: the XCD-aware
-  // tile order is untouched).  So when any workgroup gets as far as waiting for a flag, every unit has been claimed by a workgroup that
-  // was already running — the hand-over is live under ANY dispatch order and next to ANY co-tenant.  By block id the producers merely
-  // sat at the front of the grid: the eight XCD dispatchers walk their shares independently, and with two processes on one GPU a tile on
-  // one XCD span on a producer that another XCD — its CUs held by the OTHER process's spinning tiles — had not started: a cross-process
-  // deadlock until the bounded waits ran out (every run, both ranks; found by the error word's first reader,
-  // tests/test_train_entry_gpu.py::test_bench_two_ranks_share_one_gpu).  With in-order dispatch the helpers (lowest block ids) claim
-  // everything and the behaviour is that of "roles in front"; cost: one atomic per unit (~160 per launch) and one counter load per tile
-  // workgroup.  (A first version drew a ticket for EVERY workgroup and counted every exit: 1400 x 2 same-address atomics per launch,
-  // 2.3 ms per QVH step.)  The counters come in a ping-pong pair indexed by the launch's epoch parity: the workgroup that claims unit 0
-  // clears the OTHER one for the stream's next thin launch — no finished-count, no host state, replayable (a captured graph clears the
-  // pair at its head: ops.thin_flags_reset).
-  const int lane = threadIdx.x & 63;
-  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int pfb = p.pf_blocks, thb = p.th_blocks;   // uniform
-  auto prefetch_unit = [&](int rid) __attribute__((always_inline)) {
+  // the THIN role workgroups sit in FRONT of the tiles (handed out before any tile that waits for them; round 4 also put them BEHIND the
+  // tiles where those left slots idle — starved under contention, see launch_tile); the prefetch ones, which nothing waits for, sit in
+  // front, or behind the tiles where the tiles leave workgroup slots idle / in the last, partly empty round of a multi-round grid
+  // (launch_tile decides: pf_base / th_base / tile_base)
+  // Round 5: a launch with a THIN role hands out its roles by TICKET, not by block id.  Every workgroup draws a ticket when it starts to
+  // run (one relaxed agent-scope atomic on th_tick[0]); tickets [0, thb) compute the thin product, the next pfb prefetch, the rest walk
+  // the tiles.  A consumer tile therefore only ever waits for producers that STARTED BEFORE IT — resident and running, whatever order the
+  // eight XCD dispatchers hand the grid out in.  By block id the producers merely sat at the front of the grid: XCDs advance through
+  // their shares independently, and with two processes on one GPU a tile on one XCD span on a producer that another XCD — its CUs held by
+  // the OTHER process's spinning tiles — had not started: a cross-process deadlock until the bounded waits ran out (found by the error
+  // word's first reader, tests/test_train_entry_gpu.py::test_bench_two_ranks_share_one_gpu; every run, both ranks).  The last workgroup to
+  // finish (second counter, th_tick[1]) clears both counters: the next launch of the stream, and every replay of a captured graph, starts
+  // from zero without any host-side state.
+  int vbid = (int)blockIdx.x;
+  const bool ticketed = p.th_tick != nullptr;   // uniform
+  if (ticketed) {
+    if (threadIdx.x == 0) *reinterpret_cast<volatile uint32_t*>(smem) = __hip_atomic_fetch_add(p.th_tick, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    vbid = (int)*reinterpret_cast<volatile uint32_t*>(smem);
+    __syncthreads();
+  }
+  auto wg_done = [&]() __attribute__((always_inline)) {   // every exit of a ticketed launch counts; the last one resets the counters
+    if (ticketed && threadIdx.x == 0) {
+      const uint32_t old = __hip_atomic_fetch_add(p.th_tick + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (old == gridDim.x - 1) {
+        __hip_atomic_store(p.th_tick + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(p.th_tick, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  };
+  const int pfb = p.pf_blocks;   // uniform
+  const int rid = vbid - p.pf_base;   // prefetch index if in [0, pfb)
+  if (rid >= 0 && rid < pfb) {   // prefetch role: stream a later launch's weights through the memory-side cache, keep nothing
     const mrb_u32x4* __restrict__ q = reinterpret_cast<const mrb_u32x4*>(p.pf_ptr);
     const long long step = (long long)pfb * (NW * 64);
     long long i = (long long)rid * (NW * 64) + threadIdx.x;
@@ -309,8 +320,15 @@ __global__ __launch_bounds__(WGM* WGN * 64, gemm_min_blocks(NS * (BM + BN) * BK 
     const mrb_u32x4* __restrict__ q2 = reinterpret_cast<const mrb_u32x4*>(p.pf_ptr2);
     for (i = (long long)rid * (NW * 64) + threadIdx.x; i < p.pf_n16_2; i += step) keep |= q2[i][1];
     asm volatile("" ::"v"(keep));   // the loads stay, no store
-  };
-  auto thin_unit = [&](int rb) __attribute__((always_inline)) {   // 16 rows of the K extension's A operand (see GemmArgs)
+    wg_done();
+    return;
+  }
+
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int thb = p.th_blocks;   // uniform
+  const int rb = vbid - p.th_base;
+  if (rb >= 0 && rb < thb) {   // thin role: 16 rows of the K extension's A operand (see GemmArgs)
     if (rb * 16 < p.M && !p.th_stall) {
       ThinArgs t;
       t.X = p.A; t.ldx = p.lda; t.A = p.th_A; t.lda = p.th_lda; t.U = const_cast<bf16_t*>(p.Aext); t.ldu = p.ldaext;
@@ -323,31 +341,8 @@ __global__ __launch_bounds__(WGM* WGN * 64, gemm_min_blocks(NS * (BM + BN) * BK 
       __syncthreads();   // the storing waves have drained their write-through stores
       if (threadIdx.x == 0) __hip_atomic_store(p.th_flags + rb, p.th_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-  };
-  if (p.th_tick != nullptr) {   // uniform: claimed units (thin [0, thb), prefetch [thb, thb + pfb))
-    uint32_t* const cnt = p.th_tick + (p.th_epoch & 1u);
-    const uint32_t nunits = (uint32_t)(thb + pfb);
-    for (;;) {
-      if (threadIdx.x == 0) {
-        uint32_t t = 0xffffffffu;
-        if (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nunits) t = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *reinterpret_cast<volatile uint32_t*>(smem) = t;
-      }
-      __syncthreads();
-      const uint32_t t = *reinterpret_cast<volatile uint32_t*>(smem);
-      __syncthreads();
-      if (t >= nunits) break;
-      if (t == 0 && threadIdx.x == 0) __hip_atomic_store(p.th_tick + ((p.th_epoch & 1u) ^ 1u), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (t < (uint32_t)thb) thin_unit((int)t);
-      else prefetch_unit((int)t - thb);
-      __syncthreads();   // the unit's LDS reads are over before the next claim word lands in smem
-    }
-    if ((int)blockIdx.x < p.tile_base) return;   // a helper
-  } else {                      // by block id (prefetch-only launches; MRB_GEMM_THIN_CLAIM=0: the round-4 thin role, for A/B)
-    const int rid = (int)blockIdx.x - p.pf_base;
-    if (rid >= 0 && rid < pfb) { prefetch_unit(rid); return; }
-    const int rb = (int)blockIdx.x - p.th_base;
-    if (rb >= 0 && rb < thb) { thin_unit(rb); return; }
+    wg_done();
+    return;
   }
   const int wm = w / WGN, wn = w % WGN;
   const int hi = lane >> 5, l31 = lane & 31;
@@ -480,7 +475,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, gemm_min_blocks(NS * (BM + BN) * BK 
 #endif
   // ---- persistent tile loop: grid = resident blocks; a block's epilogue stores drain while it already stages the next tile
   const int ntiles = p.tiles_m * p.tiles_n;
-  for (int tile = (int)blockIdx.x - p.tile_base; tile < ntiles; tile += (int)gridDim.x - pfb - thb) {
+  for (int tile = vbid - p.tile_base; tile < ntiles; tile += (int)gridDim.x - pfb - thb) {
   {  // tile id -> (bm, bn): XCD-contiguous remap (bijective), then grouped ordering for L2 reuse of the W panel
     int bid = tile;
     const int q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, idx = bid >> 3;
@@ -728,6 +723,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, gemm_min_blocks(NS * (BM + BN) * BK 
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   }  // persistent tile loop
+  wg_done();
 }
 
 // one LDS-DMA piece (1 KiB, lane-linear in LDS) of an operand tile
@@ -1644,9 +1640,9 @@ static bool pf_tail_enabled() {
   if (on < 0) { const char* e = getenv("MRB_GEMM_PF_TAIL"); on = (e && e[0] == '1') ? 1 : 0; }
   return on == 1;
 }
-static bool thin_claim_enabled() {
+static bool thin_ticket_enabled() {
   static int on = -1;
-  if (on < 0) { const char* e = getenv("MRB_GEMM_THIN_CLAIM"); on = (e && e[0] == '0') ? 0 : 1; }
+  if (on < 0) { const char* e = getenv("MRB_GEMM_THIN_TICKET"); on = (e && e[0] == '1') ? 1 : 0; }
   return on == 1;
 }
 static bool roles_last_enabled() {
@@ -1695,9 +1691,15 @@ static int launch_tile(GemmArgs& a, hipStream_t st) {
   // workgroup slots idle, in a partly empty last round, or in front.
   constexpr int per_cu = gemm_min_blocks(LDS, WGM * WGN);
   const int slots = num_cu * per_cu;
-  if (a.th_blocks > 0 && thin_claim_enabled()) {   // [helpers | tiles]: units are claimed (see the kernel); the bases only size the grid
+  if (a.th_blocks > 0 && thin_ticket_enabled()) {
     a.th_base = 0; a.pf_base = a.th_blocks; a.tile_base = a.th_blocks + a.pf_blocks;
-  } else if (a.th_blocks > 0) {                    // MRB_GEMM_THIN_CLAIM=0: roles by block id, thin in front (round 4 / A-B)
+  } else if (a.th_blocks > 0) {
+    // Default: roles by BLOCK ID with the thin role in FRONT of the tiles.  Every XCD's dispatcher hands out its share of the grid in
+    // order and producers never wait, so on a GPU that this process has to itself a tile can only wait for producers that other,
+    // FINITE kernels delay.  That is not a guarantee — see the ticket mode above, which is one — but it costs no atomics: the ticket
+    // mode's 500-1400 same-address atomics per launch cost 2.3 ms per QVH step (72.0 vs 69.7 ms), more than the role saves.  A
+    // starved hand-over fails loudly either way (error word -> skipped AdamW -> raise).  MRB_GEMM_THIN_TICKET=1 selects the ticket
+    // mode (GPU shared between processes: bench.py's MRB_BENCH_SHARE_GPU test hook sets it).
     a.th_tick = nullptr;
     if (a.pf_blocks > 0 && grid + 32 <= slots && roles_last_enabled()) {   // thin | tiles | prefetch
       a.th_base = 0; a.tile_base = a.th_blocks; a.pf_base = a.th_blocks + grid;
@@ -1823,7 +1825,7 @@ static int gemm_dispatch(const void* A, long long lda, const void* W, long long 
                     (long long)M * lda * 2 < (1ll << 31) && !(th.p > 0.f && !seed_ptr),
                 "gemm: the thin role needs a K extension read last, more than 64 rows and one flag per 16 rows");
     a.th_A = (const bf16_t*)th.acat; a.th_lda = th.lda; a.th_R = th.R; a.th_K = th.K; a.th_flags = th.flags; a.th_err = th.err ? th.err : th.flags + (th.n_flags - 1); a.th_epoch = th.epoch; a.th_stall = g_thin_stall;
-    a.th_tick = th.flags + (th.n_flags - 3);   // the ping-pong pair of claim counters (indexed by the epoch's parity; see the kernel)
+    a.th_tick = th.flags + (th.n_flags - 3);   // two words: ticket, finished-workgroup count (zero between launches: the kernel resets them)
     MRB_REQUIRE(th.n_flags >= (M + 15) / 16 + 4, "gemm: the thin role's flag buffer needs ceil(M / 16) + 4 words (flags, ticket, count, error)");
     mk_drop_arg(a.th_drop, seed_ptr, th.site, th.p);
   }

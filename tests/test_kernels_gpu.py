@@ -1278,14 +1278,15 @@ def test_gemm_thin_role_equals_the_lora_rows_launch(ops, M, N, K, nad, cfg, gate
                  thin=(acat, K, None)) if not gated else (_ for _ in ()).throw(ops.MrblipError("n/a"))
 
 
-def test_gemm_thin_role_by_block_id_in_a_fresh_process():
-    """Round 5: the thin role's units are CLAIMED by the workgroups in the order they start to run (csrc/gemm.hip; the default, exercised by
-    every other thin-role test).  MRB_GEMM_THIN_CLAIM=0 restores round 4's roles by block id for A/B runs; the switch is read once per
-    process, so the equality test above runs again in a fresh interpreter with it set."""
+def test_gemm_thin_role_ticket_mode_in_a_fresh_process():
+    """Round 5: MRB_GEMM_THIN_TICKET=1 hands the roles of a thin-role launch out by TICKET (the order in which the workgroups start to
+    run) instead of by block id — the provably live form for a GPU that several processes share (csrc/gemm.hip).  The switch is read once
+    per process: the equality test above runs again in a fresh interpreter with it set (same bits as the lora_rows launch, counters back
+    at zero after every launch or the repetitions would hang)."""
     import os
     import subprocess
     import sys
-    env = dict(os.environ, MRB_GEMM_THIN_CLAIM="0")
+    env = dict(os.environ, MRB_GEMM_THIN_TICKET="1")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", "test_gemm_thin_role_equals_the_lora_rows_launch"],
                        capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0 and "8 passed" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])
