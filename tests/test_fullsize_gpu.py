@@ -174,6 +174,82 @@ def test_c1_real_depth_nonzero_lora_gradients_against_oracle_autograd():
     compare("oracle-fp32", False, 5e-4, 2.4e-2, 5e-2, 9e-2)
 
 
+def test_c1_real_depth_training_mode_dropout_parity():
+    """VERDICT r4 next 2(b), second half: training-mode parity at REAL depth (39-block ViT-g, 12-layer Q-Former, 12 + 12 T5 layers), non-zero
+    LoRA in every adapter, every dropout of the reference ON — the HIP step against the emu-bf16 oracle fed with the SAME masks, rebuilt
+    on the CPU through ``dropout_site_map()`` and the oracle's restatement of the counter hashes (hidden states: one hash per element pair;
+    attention probabilities: draws v3).  Until round 5 this existed at tiny dimensions only (tests/test_model_gpu.py).  A wrong call-site
+    id, a backward that regenerates another mask than its forward used, or keep bits read in the wrong layout would leave the loss right
+    and the gradients wrong."""
+    from weights import seeded_state_dict
+    from mrblip import prompt as P
+    from mrblip.engine import EngineConfig, MrBlipEngine, StateDictSource
+    from mrblip.tokenizer import FixtureTokenizer
+    from oracle import mrblip_oracle as O
+    from test_model_gpu import _peft_sd
+
+    g = load_golden("mr_c1")
+    sd = seeded_state_dict(g["manifest"], wscale=g["strings"]["wscale"], fast=True)
+    sdl = _peft_sd(sd, lora_std=0.02)
+    train_keys = [k for k in sdl if ("lora_" in k) or k.startswith("t5_proj") or k.startswith("ln_vision")]
+    for k in train_keys:
+        sdl[k].requires_grad_(True)
+    tok = FixtureTokenizer()
+    repl = P.annoying_replacement_dict(P.find_annoying_numbers(tok, 200)[0])
+    samples = _c1_samples(g)
+    cfg = EngineConfig(d_model=768, d_kv=64, t5_heads=12, d_ff=2048, t5_layers=12, t5_dec_layers=12)
+    dev = torch.device("cuda:0")
+    eng = MrBlipEngine(cfg, StateDictSource(sdl), dev, seed=20240)
+    eng.training = True
+    eng.graph_mode = "0"
+    lay = P.build_layout(tok, samples, repl, 32, T=4)
+    eng.zero_grad()
+    loss = eng.forward_backward(samples["video"].to(dev), lay, backward=True)
+    torch.cuda.synchronize()
+    seed = int(eng.seed.item()) & 0xFFFFFFFF
+    sites = eng.dropout_site_map()
+    used = set()
+
+    def provider(name, shape):
+        site, p, kind = sites[name]
+        used.add(name)
+        if p <= 0:
+            return None
+        if kind == "attn":
+            return O.dropout_keep_attn(*shape, seed, site, p) / (1.0 - p)
+        return O.dropout_keep(shape, seed, site, p) / (1.0 - p)
+
+    orc = O.Oracle(sdl, C1_CFG, emu_bf16=True, lora=dict(r=8, alpha=8), dropout=provider)
+    ref = orc.forward_mr(tok, samples, repl)
+    assert len(used) > 200 and "t5.dec.11.cross.attn" in used and any(k.startswith("lora:") for k in used)
+    tag = "c1.train-mode (real depth, LoRA != 0, all dropouts on): "
+    check(tag + "loss vs emu-oracle, same masks (rel)", abs(loss.item() - ref["loss"].item()) / abs(ref["loss"].item()), 5e-4)   # (measured 2.2e-4; gradients 3.0-3.3e-2, worst adapter 5.8e-2, norm ratio 1 + 2.6e-4, cosine deficit 4.6e-4)
+    eng.training = False
+    l_eval = eng.forward_backward(samples["video"].to(dev), lay, backward=False).item()
+    assert abs(l_eval - ref["loss"].item()) > 1e-3          # dropout really happened
+    ref["loss"].backward()
+    check(tag + "grad t5_proj.weight vs emu-oracle autograd", relerr(eng.dproj_w.cpu(), sdl["t5_proj.weight"].grad), 5e-2)
+    check(tag + "grad ln_vision.weight vs emu-oracle autograd", relerr(eng.dlnv_w.cpu(), sdl["ln_vision.weight"].grad), 5e-2)
+    num = den = 0.0
+    worst, worst_name = 0.0, ""
+    hs, rs = [], []
+    for a in eng.adapters:
+        base = "t5_model.base_model.model." + a.name
+        ga, gb = sdl[base + ".lora_A.default.weight"].grad, sdl[base + ".lora_B.default.weight"].grad
+        ha, hb = a.dA.cpu(), a.dBt.cpu().t()
+        ea, eb = relerr(ha, ga), relerr(hb, gb)
+        num += float((ha - ga).pow(2).sum() + (hb - gb).pow(2).sum())
+        den += float(ga.pow(2).sum() + gb.pow(2).sum())
+        hs += [ha.reshape(-1), hb.reshape(-1)]
+        rs += [ga.reshape(-1), gb.reshape(-1)]
+        if max(ea, eb) > worst:
+            worst, worst_name = max(ea, eb), a.name
+    check(tag + f"ALL LoRA gradients (flat, {len(eng.adapters)} adapters) vs emu-oracle autograd, same masks", math.sqrt(num / den), 5e-2)
+    check(tag + f"worst single adapter dA/dB ({worst_name})", worst, 1e-1)
+    ratio, cos = _bias_report(tag + "all adapters", torch.cat(hs), torch.cat(rs))
+    assert abs(ratio - 1.0) < 1e-2 and 1.0 - cos < 1e-3, (ratio, cos)
+
+
 def _c2_setup(lora_init=None):
     """the engine, layout, clip and golden of the BENCHED size (BASELINE.json configs[1]); weights regenerated from their reference keys"""
     import os
