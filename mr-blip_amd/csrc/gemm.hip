@@ -292,7 +292,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, gemm_min_blocks(NS * (BM + BN) * BK 
   if (ticketed) {
     if (threadIdx.x == 0) *reinterpret_cast<volatile uint32_t*>(smem) = __hip_atomic_fetch_add(p.th_tick, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
-    vbid = (int)*reinterpret_cast<volatile uint32_t*>(smem);
+    vbid = __builtin_amdgcn_readfirstlane((int)*reinterpret_cast<volatile uint32_t*>(smem));   // (block-uniform: a VECTOR register here turned every tile index of the kernel into vector arithmetic)
     __syncthreads();
   }
   auto wg_done = [&]() __attribute__((always_inline)) {   // every exit of a ticketed launch counts; the last one resets the counters
