@@ -844,6 +844,9 @@ class MrBlipEngine:
         """Re-derive the bf16 operand copies of the trainable tensors (after init / optimizer step / checkpoint load)."""
         c = self.cfg
         ops.lora_pack(self.flat, self.acat_all, self.wext_all, self.bblk_all, self.acatt_all, self.lora_desc, len(self.adapters), self.lora_scale)
+        if getattr(self, "enc_qkv_wc", None) is not None:   # [W | B] of the encoder's qkv groups (enc_qkv_w4): refresh the B columns
+            K = self.enc_qkv_wc.shape[2] - 64
+            self.enc_qkv_wc[:, :, K:].copy_(self.wext_all.index_select(0, self._enc_qkv_rows).view(self.enc_qkv_wc.shape[0], -1, 64))
         ops.cast_dropout(self.proj_w, out_bf16=self.proj_wb)
         self.transpose2d(self.proj_wb, c.qf_dim, self.proj_wtb)
 
@@ -1186,8 +1189,21 @@ class MrBlipEngine:
             t_ok = self.tout_ok(dk, B, S)
             qt_i = self.buf(f"e{i}_qt", (B, H, 64, ops.rup32(S)), bf16) if (t_ok and want_grad) else None
             kt_i = self.buf(f"e{i}_kt", (B, H, 64, ops.rup32(S)), bf16) if (t_ok and want_grad) else None
-            t_done = self.norm_lg_fwd(x, L["ln0"], L["qkv"], xn, u, qkv, tile_cfg=_ENC_FWD_CFG[0], tout=(qt_i, kt_i, vt) if t_ok else None, t_rows=S,
-                                      prefetch=self.enc_pf([L["o"], L["wi"]] if self.enc_pf_plan == 0 else [L["o"]], M))
+            if self._enc_qkv_w4_ok(M):
+                # Round 5 (opt-in, MRB_ENC_QKV_W4): the projection through the hand-pipelined 4-wave kernel, which has no K extension —
+                # [xn | u] x [W | B]^T is ONE plain product over K + 64 (csrc/gemm.hip gemm_w4_kernel; tools/qkv_tile_probe.py: 50-54 us
+                # against 80 us for the 16-wave tile).  u by its own thin launch, V^T by a transpose launch, Q^T / K^T in the backward.
+                g = L["qkv"]
+                xnu = self.buf(f"e{i}_xnu", (M, g.K + 64), bf16)
+                xn, u = xnu[:, :g.K], xnu[:, g.K:]
+                self.ws[f"e{i}_xn"], self.ws[f"e{i}_u_qkv"] = xn, u
+                ops.rmsnorm_fwd(x, L["ln0"], c.t5_eps, out_bf16=xn)
+                self.lora_thin(xn, g.acat, u, g.K, drop=self.drop(g.site, c.lora_dropout))
+                ops.gemm(xnu, self.enc_qkv_wc[i], qkv, tile_cfg=self.enc_qkv_w4, K=g.K + 64)
+                t_done = False
+            else:
+                t_done = self.norm_lg_fwd(x, L["ln0"], L["qkv"], xn, u, qkv, tile_cfg=_ENC_FWD_CFG[0], tout=(qt_i, kt_i, vt) if t_ok else None, t_rows=S,
+                                          prefetch=self.enc_pf([L["o"], L["wi"]] if self.enc_pf_plan == 0 else [L["o"]], M))
             self.enc_t_saved[i] = bool(t_done) and want_grad
             q4, k4, v4 = self.v4(qkv, B, S, H, dk, 0), self.v4(qkv, B, S, H, dk, inner), self.v4(qkv, B, S, H, dk, 2 * inner)
             if not t_done:
@@ -1220,6 +1236,35 @@ class MrBlipEngine:
         ops.cast_dropout(nf, out_bf16=enc, drop=self.drop(self.t5["sites"][1], p))
         self.ws["e_xfinal_in"] = x
         return enc
+
+    # Round 5: the T5 encoder's qkv projection ([2012 x 6144 x 2048] at QVH) through the hand-pipelined 4-wave kernel of the ViT: 14 = its
+    # 256x192 form (256 tiles = one full round of the chip), 13 = 256x256, 0 = the 16-wave generic tile with K extension, thin role and
+    # head-transposed copies (round 4).  Stand-alone on cold weights 49.8 / 54.3 / 79.7 us (tools/qkv_tile_probe.py); in the step
+    # norm + thin + GEMM + V^T transpose = 70 us against 96 (profiles/r05_layer_timeline_w4qkv.txt), 67.90 vs 68.18 ms per step.
+    enc_qkv_w4 = int(os.environ.get("MRB_ENC_QKV_W4", "14"))
+    enc_qkv_wc = None
+
+    def _enc_qkv_w4_ok(self, M: int) -> bool:
+        if not self.enc_qkv_w4 or M < 1024 or (self.cfg.lora_mask_per_adapter and self.training and self.cfg.lora_dropout > 0):
+            return False
+        if self.enc_qkv_wc is None:       # [layers, N, K + 64] = [W | B] per layer; B columns refreshed by refresh_trainable
+            gs = [L["qkv"] for L in self.t5["enc"]]
+            g0 = gs[0]
+            if g0.K % 64 or any(g.K != g0.K or g.W.shape[0] != g0.W.shape[0] for g in gs):
+                self.enc_qkv_w4 = 0
+                return False
+            N = g0.W.shape[0]
+            wc = torch.zeros(len(gs), N, g0.K + 64, dtype=bf16, device=self.dev)
+            rows = []
+            base = self.wext_all.data_ptr()
+            for i, g in enumerate(gs):
+                wc[i, :, :g.K].copy_(g.W[:, :g.K])
+                r0 = (g.wext.data_ptr() - base) // (64 * 2)
+                rows.append(torch.arange(r0, r0 + N, dtype=torch.int64))
+            self._enc_qkv_rows = torch.cat(rows).to(self.dev)
+            self.enc_qkv_wc = wc
+            self.enc_qkv_wc[:, :, g0.K:].copy_(self.wext_all.index_select(0, self._enc_qkv_rows).view(len(gs), N, 64))
+        return True
 
     @torch.no_grad()
     def t5_encoder_backward(self, denc: torch.Tensor, B: int, S: int, kmask: torch.Tensor) -> torch.Tensor:

@@ -22,6 +22,7 @@ def _step(flags, B=1, steps=2):
     cfg = EngineConfig(vit_dim=320, vit_depth=2, vit_heads=5, vit_mlp=512, qf_dim=256, qf_heads=4, qf_inter=512, qf_layers=4, num_query=32,
                        d_model=256, d_kv=64, t5_heads=4, d_ff=512, t5_layers=3, t5_dec_layers=3)
     eng = MrBlipEngine(cfg, RandomSource(dev, seed=77), dev, lora_init=bench.lora_init_nonzero, seed=11)
+    flags = dict(dict(enc_qkv_w4=0), **flags)     # the round-4 paths under test live in the generic tile's qkv projection; the 4-wave form has its own test below
     for k, v in flags.items():
         setattr(eng, k, v)
     if flags.get("xs_off"):
@@ -129,3 +130,23 @@ def test_a_thin_role_timeout_is_loud_and_skips_the_optimizer_step():
     torch.cuda.synchronize()
     eng.check_thin_role(block=True)
     assert l == l and not torch.equal(eng.flat, flat0) and ops.gemm_thin_timeouts() == 0
+
+
+def test_encoder_qkv_through_the_four_wave_kernel_equals_the_generic_tile_path():
+    """Round 5: above 1024 rows the T5 encoder's qkv projection runs as ONE plain product [xn | u] x [W | B]^T over K + 64 on the
+    hand-pipelined 4-wave kernel (no K extension, no thin role, no epilogue transposes there: a thin launch, a V^T transpose and the
+    backward's Q^T / K^T transposes replace them).  Same arithmetic, other summation order: loss and flat gradient against the generic
+    tile path (enc_qkv_w4 = 0), dropout on; and the concatenated weights must follow the optimizer (B changes every step)."""
+    base_l, base_g, eng0, lay = _step(dict(enc_qkv_w4=0))
+    assert lay.S >= 1024
+    for cfg in (14, 13):
+        l, g, eng, _ = _step(dict(enc_qkv_w4=cfg))
+        assert eng.enc_qkv_wc is not None and eng.enc_qkv_wc.shape[2] == eng.cfg.d_model + 64
+        tag = "encoder qkv via the 4-wave kernel (cfg %d) vs the generic tile path: " % cfg
+        check(tag + "loss (rel)", max(abs(a - b) / abs(b) for a, b in zip(l, base_l)), 2e-4)
+        check(tag + "flat gradient", relerr(g, base_g), 1e-2)
+        # the B columns of [W | B] are refreshed with the trainable tensors
+        eng.optimizer_step(1e-2)
+        torch.cuda.synchronize()
+        g0 = eng.t5["enc"][0]["qkv"]
+        assert torch.equal(eng.enc_qkv_wc[0, :, eng.cfg.d_model:], g0.wext) and torch.equal(eng.enc_qkv_wc[0, :, :g0.K], g0.W[:, :g0.K])
