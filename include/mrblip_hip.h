@@ -277,6 +277,24 @@ int mrblip_dec_proj_config(int n_blocks, int version);
 int mrblip_gemm_lora_dx(const void* dY, long long lddy, const void* Wt, long long ldwt, const void* G, long long ldg, const void* AcatT,
                         long long ldat, int M, int N, int K, void* dX, long long lddx, int out_f32, const float* residual, long long ldr,
                         const uint32_t* seed_ptr, uint32_t site, float p_drop, int tile_cfg, mrblip_stream_t stream);
+/* Round 5: the same input gradient for outputs with too few 256x256 tiles to fill 256 CUs (T5 encoder at ~2000 rows: 64 tiles), as PARTIAL
+ * products of a K-split on the hand-pipelined 4-wave kernel: out + s * part_stride = A[:, K range s] W[:, K range s]^T for s < k_splits and,
+ * with a K extension (Aext = G [M,64], Wext = AcatT [N,64]), out + k_splits * part_stride = Aext Wext^T — the LoRA term, still UNMASKED.
+ * fp32 or bf16 parts, no bias / residual / activation; tile_cfg 13 (256x256 tiles) or 14 (256x192); K %% (64 k_splits) == 0.  The consumer adds
+ * the parts in part order and applies the lora_dropout keep mask to the last one:
+ *   mrblip_rmsnorm_bwd_parts   = mrblip_rmsnorm_bwd / _bwd_cast with dy = sum of nparts fp32 parts (ext_part: last part masked by (ext_site, ext_p) over [M, D])
+ *   mrblip_gated_gelu_bwd_parts = mrblip_gated_gelu_bwd with dy + mask(ext_site, ext_p) (.) dy_ext (two bf16 parts, same leading dimension)
+ * Reference: the autograd of peft lora.Linear.forward (blip2_mr.py:182-200) feeding T5LayerNorm / T5DenseGatedActDense backward
+ * (modeling_t5.py:254-277, 323-329); same sum in a fixed order, so the step stays bit-reproducible. */
+int mrblip_gemm_ksplit(const void* A, long long lda, const void* W, long long ldw, const void* Aext, long long ldaext, const void* Wext,
+                       long long ldwext, int M, int N, int K, void* out, long long ldo, long long part_stride, int out_f32, int k_splits,
+                       int tile_cfg, mrblip_stream_t stream);
+int mrblip_rmsnorm_bwd_parts(const float* dy, long long lddy, int nparts, long long pstride, int ext_part, uint32_t ext_site, float ext_p,
+                             const float* x, long long ldx, const float* weight, int M, int D, float eps, const float* dx_add, long long ldadd,
+                             float* dx, long long lddx, void* out_bf16, long long ldob, const uint32_t* seed_ptr, uint32_t site, float p_drop,
+                             mrblip_stream_t stream);
+int mrblip_gated_gelu_bwd_parts(const void* dy, const void* dy_ext, long long lddy, const void* h, long long ldh, void* dh, long long lddh, int M, int Nh,
+                                const uint32_t* seed_ptr, uint32_t site, float p, uint32_t ext_site, float ext_p, mrblip_stream_t stream);
 /* fp32 LoRA master weights -> bf16 GEMM operands for every adapter of a device descriptor table (10 int64 per adapter:
  * a_off, bt_off, K, out, acat_off, wext_off, bblk_off, Ntot, acatt_off, 0); acatt = [K,64] transposed copy of scale*A */
 int mrblip_lora_pack(const float* flat, void* acat_bf16, void* wext_bf16, void* bblk_bf16, void* acatt_bf16, const long long* desc,

@@ -181,24 +181,37 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const bf16_t* __restrict_
 }
 
 // gated-GELU backward (modeling_t5.py:323-329): y = drop(gelu(h0) * h1);  h = [h0 | h1] ([M, 2*Nh]), dh same layout
+// dy_ext (round 5, mrblip_gated_gelu_bwd_parts): a second bf16 part of dy that is added under the mask of ext_drop over [M, Nh] — the LoRA
+// term g A of the wo projection's input gradient, written as its own part by mrblip_gemm_ksplit (mask = wo's lora_dropout keep mask of y)
 __global__ __launch_bounds__(256) void gated_bwd_kernel(const bf16_t* __restrict__ dy, long long lddy, const bf16_t* __restrict__ h, long long ldh,
-                                                        bf16_t* __restrict__ dh, long long lddh, int M, int Nh, DropoutArg drop) {
+                                                        bf16_t* __restrict__ dh, long long lddh, int M, int Nh, DropoutArg drop,
+                                                        const bf16_t* __restrict__ dy_ext = nullptr, DropoutArg ext_drop = DropoutArg{nullptr, 0u, 0u, 1.0f}) {
   const long long total8 = (long long)M * (Nh / 8);
-  const uint32_t seed = drop.seed_ptr ? *drop.seed_ptr : 0u;
+  const uint32_t seed = drop.seed_ptr ? *drop.seed_ptr : ext_drop.seed_ptr ? *ext_drop.seed_ptr : 0u;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total8; i += (long long)gridDim.x * 256) {
     const int m = (int)(i / (Nh / 8)), c = (int)(i % (Nh / 8)) * 8;
     const bf16x8 g = *reinterpret_cast<const bf16x8*>(dy + (long long)m * lddy + c);
     const bf16x8 a = *reinterpret_cast<const bf16x8*>(h + (long long)m * ldh + c);
     const bf16x8 b = *reinterpret_cast<const bf16x8*>(h + (long long)m * ldh + Nh + c);
-    float d0[8], d1[8];
+    float d0[8], d1[8], ge[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     bool kp[8] = {true, true, true, true, true, true, true, true};
     if (drop.seed_ptr) {   // (c % 8 == 0, Nh % 8 == 0: element pairs share a hash)
 #pragma unroll
       for (int j = 0; j < 8; j += 2) mrb_keep2((uint32_t)m * (uint32_t)Nh + (uint32_t)(c + j), seed, drop.site, drop.thresh24, kp[j], kp[j + 1]);
     }
+    if (dy_ext) {
+      const bf16x8 e = *reinterpret_cast<const bf16x8*>(dy_ext + (long long)m * lddy + c);
+#pragma unroll
+      for (int j = 0; j < 8; j += 2) {
+        bool k0 = true, k1 = true;
+        if (ext_drop.seed_ptr) mrb_keep2((uint32_t)m * (uint32_t)Nh + (uint32_t)(c + j), seed, ext_drop.site, ext_drop.thresh24, k0, k1);
+        ge[j] = k0 ? bf2f((bf16_t)e[j]) * ext_drop.inv_keep : 0.f;
+        ge[j + 1] = k1 ? bf2f((bf16_t)e[j + 1]) * ext_drop.inv_keep : 0.f;
+      }
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      float gy = bf2f((bf16_t)g[j]);
+      float gy = bf2f((bf16_t)g[j]) + ge[j];
       if (drop.seed_ptr) gy = kp[j] ? gy * drop.inv_keep : 0.f;
       const float h0 = bf2f((bf16_t)a[j]), h1 = bf2f((bf16_t)b[j]);
       d0[j] = gy * h1 * gelu_erf_grad(h0);
@@ -498,6 +511,15 @@ extern "C" int mrblip_gated_gelu_bwd(const void* dy, long long lddy, const void*
   MRB_REQUIRE(M > 0 && Nh > 0 && Nh % 8 == 0, "gated_gelu_bwd: bad shape");
   hipLaunchKernelGGL(gated_bwd_kernel, dim3(grid_for((long long)M * Nh / 8)), dim3(256), 0, stream, (const bf16_t*)dy, lddy, (const bf16_t*)h, ldh, (bf16_t*)dh, lddh, M, Nh, mk_drop(seed_ptr, site, p));
   return mrblip_check_launch("gated_gelu_bwd");
+}
+// ... with dy in two bf16 parts: dy + mask(ext_site, ext_p) (.) dy_ext (same leading dimension; dy_ext == nullptr: plain)
+extern "C" int mrblip_gated_gelu_bwd_parts(const void* dy, const void* dy_ext, long long lddy, const void* h, long long ldh, void* dh, long long lddh, int M, int Nh,
+                                           const uint32_t* seed_ptr, uint32_t site, float p, uint32_t ext_site, float ext_p, hipStream_t stream) {
+  MRB_REQUIRE(M > 0 && Nh > 0 && Nh % 8 == 0 && (lddy % 8) == 0 && ((uintptr_t)dy_ext % 16) == 0, "gated_gelu_bwd_parts: bad shape");
+  MRB_REQUIRE(!(p > 0.f || ext_p > 0.f) || seed_ptr, "gated_gelu_bwd_parts: dropout needs a device seed pointer");
+  hipLaunchKernelGGL(gated_bwd_kernel, dim3(grid_for((long long)M * Nh / 8)), dim3(256), 0, stream, (const bf16_t*)dy, lddy, (const bf16_t*)h, ldh, (bf16_t*)dh, lddh, M, Nh,
+                     mk_drop(seed_ptr, site, p), (const bf16_t*)dy_ext, mk_drop(seed_ptr, ext_site, ext_p));
+  return mrblip_check_launch("gated_gelu_bwd_parts");
 }
 extern "C" int mrblip_cross_entropy(const float* logits, long long ldl, const int* labels, int R, int V, float inv_count, float* loss,
                                     void* dlogits_bf16, long long ldd, hipStream_t stream) {

@@ -54,6 +54,7 @@ struct GemmArgs {
   // (the caller pre-initialised it: residual or zero).  With M <= 32 rows a [32 x N] output has only N / 32 tiles — 64 for the T5
   // d_model — and one CU streams ~20 GB/s of weights: the K split puts every CU on the weight stream.
   int k_splits;
+  long long part_stride;   // 4-wave kernel in SPLIT form: elements between the partial outputs (gemm_w4_kernel)
   // round 4 (tile kernels, bf16 output, plain / bias epilogue only; set through mrblip_gemm_set_extra for the NEXT launch of the thread):
   // head-transposed copies of up to three consecutive column ranges of width t_inner (heads of 64) — what mrblip_head_transpose would
   // write from the output, pad columns [t_rows, t_spad) included: tout[j][b][h][d][s] = out[b * t_rows + s][j * t_inner + h * 64 + d];
@@ -796,7 +797,13 @@ __device__ constexpr int w4_piece_slot(int i, int total, int nslot) {
 // barrier that needs them; a piece that misses the L2 lands later than that and all four waves (one per SIMD: nothing else to run) wait.
 // With W2 the W pieces of K-tile kt + 2 go out in the first slice of K-tile kt (seven slices ahead); the hand-over waits with
 // vmcnt(JW): only those youngest pieces may still be in flight (LDS-DMA loads retire in order).
-template <bool OUT_F32, int ACT, bool RES, int TN, bool F16 = false, bool W3 = false>
+// SPLIT (round 5): K-SPLIT units for outputs with too few tiles to fill the chip — the T5 encoder's [2012 x 2048] input gradients are 64
+// tiles of 256x256 with K = 6144 / 10240.  A unit = (part, tile): part s < k_splits multiplies the K range [s, s + 1) K / k_splits and
+// writes its 256 x BN block of out + s * part_stride (fp32 or bf16 PARTIAL products; the consumer adds the parts in part order — a fixed
+// order, so the result does not depend on which unit finishes first); with a K extension (Aext [M, 64], Wext [N, 64]: the LoRA term,
+// which the consumer MASKS before adding it) its product is the LAST part, from one-K-tile units that every XCD's queue holds behind
+// its main units (they fill the tail of the last round).  No bias / residual / activation.
+template <bool OUT_F32, int ACT, bool RES, int TN, bool F16 = false, bool W3 = false, bool SPLIT = false>
 __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
   constexpr int BM = 256, BN = 64 * TN, WN = BN / 2, RB = 128, NW = 4, RPI = 8;
   constexpr int A_BYTES = BM * RB, W_BYTES = BN * RB, STAGE = A_BYTES + W_BYTES;
@@ -819,6 +826,12 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
   int bm = 0, bn = 0;
   uint32_t vpa[JA], vpw[JW];
   f32x16 acc[4][TN];
+  // the unit's operands (SPLIT: set by W4_OPEN_TILE; otherwise the launch's)
+  const bf16_t* tA = p.A;
+  const bf16_t* tW = p.W;
+  uint32_t tba = bytes_a, tbw = bytes_w;
+  int nk_t = nk, part = 0;
+  (void)part;
 
 #ifdef EXP_W4_NOSYNC
 #define W4_SYNC
@@ -853,9 +866,9 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
         if (w4_piece_phidx(i_, JA + JW) == (PHIDX) && j_ == w4_piece_slot(i_, JA + JW, NSLOT)) {                         \
           const int st_ = ((PHIDX) == 0 || W3) ? kt + 2 : kt + 1;                                                        \
           if (i_ < JA)                                                                                                   \
-            gemm_dma_piece(smem + (st_ & 1) * STAGE + (i_ * NW + w) * (RPI * RB), p.A, bytes_a, vpa[i_ < JA ? i_ : 0], (uint32_t)st_ * (uint32_t)RB); \
+            gemm_dma_piece(smem + (st_ & 1) * STAGE + (i_ * NW + w) * (RPI * RB), tA, tba, vpa[i_ < JA ? i_ : 0], (uint32_t)st_ * (uint32_t)RB); \
           else                                                                                                           \
-            gemm_dma_piece(smem + (W3 ? w3ofs2 : (st_ & 1) * STAGE + A_BYTES) + ((i_ - JA) * NW + w) * (RPI * RB), p.W, bytes_w, \
+            gemm_dma_piece(smem + (W3 ? w3ofs2 : (st_ & 1) * STAGE + A_BYTES) + ((i_ - JA) * NW + w) * (RPI * RB), tW, tbw, \
                            vpw[i_ >= JA ? i_ - JA : 0], (uint32_t)st_ * (uint32_t)RB);                                   \
         }                                                                                                                \
     }                                                                                                                    \
@@ -889,14 +902,34 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
   // atomic counters instead measured the same, alone and in the train step, and needed device-side state: dropped.)
   const int ntiles = p.tiles_m * p.tiles_n;
   const int my_xcd = blockIdx.x & 7;
-  const int my_count = (ntiles - my_xcd + 7) >> 3;       // tiles in this XCD's queue
+  // SPLIT: the XCD's queue = its share of the k_splits * ntiles main units, then its share of the ntiles K-extension units
+  const int n_main = SPLIT ? ntiles * p.k_splits : ntiles;
+  const int my_main = (n_main - my_xcd + 7) >> 3;
+  const int my_count = my_main + ((SPLIT && p.Aext) ? (ntiles - my_xcd + 7) >> 3 : 0);       // units in this XCD's queue
+  const int nk_main = SPLIT ? nk / p.k_splits : nk;
   int cur = blockIdx.x >> 3;                             // position in this XCD's list
   // tile id -> (bm, bn) and the per-piece source offsets, then the LDS-DMA of its first K-tile into buffer 0
 #define W4_OPEN_TILE(T)                                                                                                   \
   {                                                                                                                      \
-    int bid = (T) * 8 + my_xcd;                                                                                          \
-    const int q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, idx = bid >> 3;                                            \
+    const bool ext_ = SPLIT && (T) >= my_main;                                                                           \
+    const int nq_ = ext_ ? ntiles : n_main;                                                                              \
+    int bid = ((T) - (ext_ ? my_main : 0)) * 8 + my_xcd;                                                                 \
+    const int q = nq_ >> 3, r = nq_ & 7, xcd = bid & 7, idx = bid >> 3;                                                  \
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;                                                 \
+    long long lda_ = p.lda, ldw_ = p.ldw;                                                                                \
+    uint32_t k0_ = 0;                                                                                                    \
+    if (SPLIT) {                                                                                                         \
+      part = ext_ ? p.k_splits : bid / ntiles;                                                                           \
+      bid -= ext_ ? 0 : part * ntiles;                                                                                   \
+      tA = ext_ ? p.Aext : p.A;                                                                                          \
+      tW = ext_ ? p.Wext : p.W;                                                                                          \
+      lda_ = ext_ ? p.ldaext : p.lda;                                                                                    \
+      ldw_ = ext_ ? p.ldwext : p.ldw;                                                                                    \
+      tba = (uint32_t)((long long)p.M * lda_ * 2);                                                                       \
+      tbw = (uint32_t)((long long)p.N * ldw_ * 2);                                                                       \
+      nk_t = ext_ ? 1 : nk_main;                                                                                         \
+      k0_ = ext_ ? 0u : (uint32_t)(part * nk_main * RB);                                                                 \
+    }                                                                                                                    \
     constexpr int GROUP_M = W4_GROUP_M;                                                                                  \
     const int per_group = GROUP_M * p.tiles_n;                                                                           \
     const int gid = bid / per_group;                                                                                     \
@@ -904,9 +937,11 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
     const int gsize = min(p.tiles_m - first_m, GROUP_M);                                                                 \
     bm = first_m + (bid % per_group) % gsize;                                                                            \
     bn = (bid % per_group) / gsize;                                                                                      \
-    _Pragma("unroll") for (int j = 0; j < JA; ++j) vpa[j] = vA + (uint32_t)((long long)(bm * BM + (j * NW + w) * RPI) * p.lda * 2); \
-    _Pragma("unroll") for (int j = 0; j < JW; ++j) vpw[j] = vW + (uint32_t)((long long)(bn * BN + (j * NW + w) * RPI) * p.ldw * 2); \
-    gemm_stage_dma<JA, JW, NW, RPI * RB>(smem, smem + A_BYTES, p.A, bytes_a, p.W, bytes_w, vpa, vpw, w, 0u);             \
+    const uint32_t vA_ = SPLIT ? (uint32_t)((long long)(lane >> 3) * lda_ * 2) + chunk * 16 + k0_ : vA;                  \
+    const uint32_t vW_ = SPLIT ? (uint32_t)((long long)(lane >> 3) * ldw_ * 2) + chunk * 16 + k0_ : vW;                  \
+    _Pragma("unroll") for (int j = 0; j < JA; ++j) vpa[j] = vA_ + (uint32_t)((long long)(bm * BM + (j * NW + w) * RPI) * lda_ * 2); \
+    _Pragma("unroll") for (int j = 0; j < JW; ++j) vpw[j] = vW_ + (uint32_t)((long long)(bn * BN + (j * NW + w) * RPI) * ldw_ * 2); \
+    gemm_stage_dma<JA, JW, NW, RPI * RB>(smem, smem + A_BYTES, tA, tba, tW, tbw, vpa, vpw, w, 0u);                       \
   }
 #ifdef EXP_W4_STAGGER
   {  // EXPERIMENT: 8 phase groups of 32 CUs (4 per XCD) start EXP_W4_STAGGER x 10 ns apart, so the epilogue store bursts of a round interleave
@@ -932,13 +967,14 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
 
     int w3 = 0;    // (W3) kt % 3
     (void)w3;
+    const int nk = nk_t;   // (SPLIT: this unit's K-tiles)
     if (nk > 1) {  // the pieces of K-tile 1 a hand-over slice would have issued (the rest go out in the slices of K-tile 0; W3: all of K-tile 1)
       constexpr int N3 = W3 ? JA + JW : w4_piece_count(0, JA + JW);
 #pragma unroll
       for (int i = 0; i < JA + JW; ++i)
         if (W3 || w4_piece_phidx(i, JA + JW) == 0) {
-          if (i < JA) gemm_dma_piece(smem + STAGE + (i * NW + w) * (RPI * RB), p.A, bytes_a, vpa[i < JA ? i : 0], (uint32_t)RB);
-          else gemm_dma_piece(smem + STAGE + A_BYTES + ((i - JA) * NW + w) * (RPI * RB), p.W, bytes_w, vpw[i >= JA ? i - JA : 0], (uint32_t)RB);
+          if (i < JA) gemm_dma_piece(smem + STAGE + (i * NW + w) * (RPI * RB), tA, tba, vpa[i < JA ? i : 0], (uint32_t)RB);
+          else gemm_dma_piece(smem + STAGE + A_BYTES + ((i - JA) * NW + w) * (RPI * RB), tW, tbw, vpw[i >= JA ? i - JA : 0], (uint32_t)RB);
         }
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N3) : "memory");
     } else {
@@ -969,6 +1005,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
     __syncthreads();  // every wave is done with both stage buffers
     const int nxt = cur + (int)(gridDim.x >> 3);
     const int bm_e = bm, bn_e = bn;
+    const uint32_t part_off = SPLIT ? (uint32_t)((long long)part * p.part_stride * (OUT_F32 ? 4 : 2)) : 0u;
     if (nxt < my_count) W4_OPEN_TILE(nxt)  // the next tile's first K-tile flies into buffer 0 under this epilogue
     char* slab = smem + STAGE + w * (32 * RS);
     const bool lane_on = lane < LPR * ROWS;
@@ -986,7 +1023,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
     const __amdgpu_buffer_rsrc_t rres =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.residual), 0, RES ? (int)((((long long)p.M - 1) * p.ldr + p.N) * 4) : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rout =
-        __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)((((long long)p.M - 1) * p.ldo + p.N) * (OUT_F32 ? 4 : 2)), 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)(((SPLIT ? (long long)(p.k_splits + (p.Aext ? 1 : 0) - 1) * p.part_stride : 0ll) + ((long long)p.M - 1) * p.ldo + p.N) * (OUT_F32 ? 4 : 2)), 0x00020000);
     float bias8[8];
     {
       const uint32_t ob = n_ok ? (uint32_t)n0 * 4u : 0x80000000u;
@@ -1037,11 +1074,11 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
           for (int e = 0; e < 4; ++e) { v[e] += rq[mt & 1][i][0][e]; v[4 + e] += rq[mt & 1][i][1][e]; }
         }
         if (OUT_F32) {
-          const uint32_t off = ok ? (uint32_t)(((long long)m * p.ldo + n0) * 4) : 0x80000000u;
+          const uint32_t off = ok ? (uint32_t)(((long long)m * p.ldo + n0) * 4) + part_off : 0x80000000u;
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(mrb_u32x4, mrb_f32x4{v[0], v[1], v[2], v[3]}), rout, off, 0, W4_STORE_AUX);
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(mrb_u32x4, mrb_f32x4{v[4], v[5], v[6], v[7]}), rout, off + 16u, 0, W4_STORE_AUX);
         } else {
-          const uint32_t off = ok ? (uint32_t)(((long long)m * p.ldo + n0) * 2) : 0x80000000u;
+          const uint32_t off = ok ? (uint32_t)(((long long)m * p.ldo + n0) * 2) + part_off : 0x80000000u;
           __builtin_amdgcn_raw_buffer_store_b128(mrb_u32x4{pack2x<F16>(v[0], v[1]), pack2x<F16>(v[2], v[3]), pack2x<F16>(v[4], v[5]), pack2x<F16>(v[6], v[7])}, rout, off, 0, W4_STORE_AUX);
         }
       }
@@ -1814,6 +1851,7 @@ static int gemm_dispatch(const void* A, long long lda, const void* W, long long 
   a.ext_first = ext_first;
   a.m_rows_per_block = 32;
   a.k_splits = 1;
+  a.part_stride = 0;
   a.tout[0] = (bf16_t*)extra.tout[0]; a.tout[1] = (bf16_t*)extra.tout[1]; a.tout[2] = (bf16_t*)extra.tout[2];
   a.t_inner = extra.set ? extra.t_inner : 0; a.t_rows = extra.t_rows; a.t_spad = extra.t_spad; a.t_bs = extra.t_bs; a.t_hs = extra.t_hs;
   a.t_stride = extra.t_stride; a.t_count = extra.set ? extra.t_count : 0;
@@ -2191,6 +2229,74 @@ extern "C" int mrblip_gemm_lora_dx(const void* dY, long long lddy, const void* W
                                    int tile_cfg, hipStream_t stream) {
   return gemm_dispatch(dY, lddy, Wt, ldwt, G, ldg, AcatT, ldat, M, N, K, dX, lddx, out_f32, nullptr, 0, nullptr, residual, ldr, 0, 0, seed_ptr, 0,
                        0.f, tile_cfg, 1, site, p_drop, 0, 0.f, stream);
+}
+
+// K-split form of the 4-wave kernel (round 5; gemm_w4_kernel<..., SPLIT>):  out[s] = A[:, s-th K range] W[:, s-th K range]^T for s < k_splits,
+// and with a K extension  out[k_splits] = Aext Wext^T  — PARTIAL products, parts part_stride elements apart, fp32 or bf16.  The consumer
+// adds them (mrblip_rmsnorm_bwd_parts / mrblip_gated_gelu_bwd_parts: in part order, the extension part under the lora_dropout mask).
+// For the LoRA input gradients of the T5 encoder:  dX = dY W (+) mask (.) (g A): lora.py Linear.forward differentiated, blip2_mr.py:182-200.
+// tile_cfg 13 (256x256 tiles) or 14 (256x192).  K %% (64 k_splits) == 0.
+extern "C" int mrblip_gemm_ksplit(const void* A, long long lda, const void* W, long long ldw, const void* Aext, long long ldaext, const void* Wext,
+                                  long long ldwext, int M, int N, int K, void* out, long long ldo, long long part_stride, int out_f32, int k_splits,
+                                  int tile_cfg, hipStream_t stream) {
+  const int cfg = tile_cfg & 0xff;
+  MRB_REQUIRE(cfg == 13 || cfg == 14, "gemm_ksplit: tile_cfg 13 (256x256) or 14 (256x192)");
+  MRB_REQUIRE(M > 0 && N > 0 && (N % 8) == 0 && k_splits >= 1 && k_splits <= 16 && K > 0 && (K % (64 * k_splits)) == 0,
+              "gemm_ksplit: need M, N > 0, N %% 8 == 0 and K %% (64 k_splits) == 0 (M=%d N=%d K=%d k_splits=%d)", M, N, K, k_splits);
+  MRB_REQUIRE((lda % 8) == 0 && (ldw % 8) == 0 && (ldo % (out_f32 ? 4 : 8)) == 0 && (part_stride % 8) == 0, "gemm_ksplit: leading dims must keep 16-B alignment");
+  MRB_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0 && ((uintptr_t)out % 16) == 0, "gemm_ksplit: pointers must be 16-B aligned");
+  MRB_REQUIRE((Aext == nullptr) == (Wext == nullptr) && (!Aext || (((uintptr_t)Aext % 16) == 0 && ((uintptr_t)Wext % 16) == 0 && (ldaext % 8) == 0 && (ldwext % 8) == 0 && ldaext >= 64 && ldwext >= 64)),
+              "gemm_ksplit: the K extension is a pair of 64-column operands with 16-B rows");
+  MRB_REQUIRE(((long long)(M + 256) * lda * 2 + 256) < (1ll << 32) && ((long long)(N + 256) * ldw * 2 + 256) < (1ll << 32),
+              "gemm_ksplit: operand exceeds the 4 GiB buffer-descriptor range");
+  const int parts = k_splits + (Aext ? 1 : 0);
+  MRB_REQUIRE(part_stride >= (long long)(M - 1) * ldo + N && ((long long)(parts - 1) * part_stride + (long long)M * ldo) * (out_f32 ? 4 : 2) < (1ll << 31),
+              "gemm_ksplit: the parts must not overlap and together stay below 2 GiB");
+  // the one-shot extras of the generic tile kernel are not for this launch: drop them loudly
+  MRB_REQUIRE(!g_gemm_extra.set && !g_gemm_thin.set && !g_gemm_prefetch.ptr, "gemm_ksplit: head-transposed copies / thin role / prefetch role belong to the generic tile kernel");
+  GemmArgs a = {};
+  a.A = (const bf16_t*)A; a.W = (const bf16_t*)W; a.Aext = (const bf16_t*)Aext; a.Wext = (const bf16_t*)Wext;
+  a.out = out; a.lda = lda; a.ldw = ldw; a.ldaext = ldaext; a.ldwext = ldwext; a.ldo = ldo;
+  a.M = M; a.N = N; a.K = K; a.k_splits = k_splits; a.part_stride = part_stride;
+  a.drop.inv_keep = a.ext_drop.inv_keep = a.a_drop.inv_keep = a.th_drop.inv_keep = 1.0f;
+  const int bn = cfg == 13 ? 256 : 192;
+  a.tiles_m = (M + 255) / 256;
+  a.tiles_n = (N + bn - 1) / bn;
+  const int stage = (256 + bn) * 128, slab = 4 * 32 * (bn / 2 * 4 + 16);
+  const int LDS = 2 * stage > stage + slab ? 2 * stage : stage + slab;
+  static int ncu = 0;
+  if (ncu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+  }
+  const int units = a.tiles_m * a.tiles_n * parts;
+  const int reserve = ((tile_cfg >> 8) & 0x1ff) ? ((tile_cfg >> 8) & 0x1ff) / 8 * 8 : g_cu_reserve;
+  const int cus = ncu - reserve > 8 ? ncu - reserve : 8;
+  const int grid = units < cus ? (units + 7) / 8 * 8 : cus;
+  const int variant = (cfg == 14 ? 2 : 0) | (out_f32 ? 1 : 0);
+  static bool attr_set[4] = {};
+#define MRB_W4S_LAUNCH(V, F32, TN_)                                                                                                \
+  case V: {                                                                                                                        \
+    auto k = gemm_w4_kernel<F32, 0, false, TN_, false, false, true>;                                                               \
+    if (!attr_set[V]) {                                                                                                            \
+      if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {                    \
+        mrblip_set_error("gemm_ksplit: cannot raise dynamic LDS to %d", LDS);                                                      \
+        return MRBLIP_ELAUNCH;                                                                                                     \
+      }                                                                                                                            \
+      attr_set[V] = true;                                                                                                          \
+    }                                                                                                                              \
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), LDS, stream, a);                                                                  \
+    break;                                                                                                                         \
+  }
+  switch (variant) {
+    MRB_W4S_LAUNCH(0, false, 4)
+    MRB_W4S_LAUNCH(1, true, 4)
+    MRB_W4S_LAUNCH(2, false, 3)
+    MRB_W4S_LAUNCH(3, true, 3)
+  }
+#undef MRB_W4S_LAUNCH
+  return mrblip_check_launch("gemm_ksplit");
 }
 
 // ---- thin "TN" product for the LoRA weight gradients:  D[r, c] += sum_m U[m, r] * drop(Y)[m, c],  r < 32, contraction over the

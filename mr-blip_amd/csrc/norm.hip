@@ -81,14 +81,18 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const float* __restrict__
                                                        long long ldx, const float* __restrict__ gamma, int M, int D, float eps,
                                                        const float* dx_add, long long ldadd, float* dx, long long lddx,
                                                        float* dgamma, float* dbeta, bf16_t* out_b = nullptr, long long ldob = 0,
-                                                       DropoutArg drop = DropoutArg{nullptr, 0u, 0u, 1.0f}, int ordered_dw = 0) {
+                                                       DropoutArg drop = DropoutArg{nullptr, 0u, 0u, 1.0f}, int ordered_dw = 0,
+                                                       int nparts = 1, long long pstride = 0, int ext_part = 0,
+                                                       DropoutArg ext_drop = DropoutArg{nullptr, 0u, 0u, 1.0f}) {
+  // nparts > 1 (round 5, mrblip_rmsnorm_bwd_parts): dy arrives as PARTIAL products pstride elements apart (mrblip_gemm_ksplit) and is
+  // their sum in part order; ext_part: the last part is the LoRA term g A, added under the lora_dropout keep mask of ext_drop over [M, D]
   __shared__ float red[2][4][64 * 4];
   __shared__ int last_flag;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int nv = D >> 2;
   float4 ag[NORM_MAXV], ab[NORM_MAXV];
   const bool want_dw = dgamma != nullptr;
-  const uint32_t seed = drop.seed_ptr ? mrb_seed_load(drop.seed_ptr) : 0u;
+  const uint32_t seed = drop.seed_ptr ? mrb_seed_load(drop.seed_ptr) : ext_drop.seed_ptr ? mrb_seed_load(ext_drop.seed_ptr) : 0u;
   if (want_dw) {
 #pragma unroll
     for (int j = 0; j < NORM_MAXV; ++j) ag[j] = ab[j] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -103,6 +107,26 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const float* __restrict__
       const int i = lane + 64 * j;
       v[j] = (i < nv) ? xr[i] : make_float4(0.f, 0.f, 0.f, 0.f);
       g[j] = (i < nv) ? dr[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int s_ = 1; s_ < nparts; ++s_) {
+      const float4* ds = reinterpret_cast<const float4*>(dy + (long long)s_ * pstride + (long long)row * lddy);
+      float4 t[NORM_MAXV];
+#pragma unroll
+      for (int j = 0; j < NORM_MAXV; ++j) {
+        const int i = lane + 64 * j;
+        t[j] = (i < nv) ? ds[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      const bool masked = ext_part && s_ == nparts - 1;
+#pragma unroll
+      for (int j = 0; j < NORM_MAXV; ++j) {
+        if (masked) {
+          bool k0 = true, k1 = true, k2 = true, k3 = true;
+          if (ext_drop.seed_ptr) mrb_keep4((uint32_t)row * (uint32_t)D + (uint32_t)(4 * (lane + 64 * j)), seed, ext_drop.site, ext_drop.thresh24, k0, k1, k2, k3);
+          t[j].x = k0 ? t[j].x * ext_drop.inv_keep : 0.f; t[j].y = k1 ? t[j].y * ext_drop.inv_keep : 0.f;
+          t[j].z = k2 ? t[j].z * ext_drop.inv_keep : 0.f; t[j].w = k3 ? t[j].w * ext_drop.inv_keep : 0.f;
+        }
+        g[j].x += t[j].x; g[j].y += t[j].y; g[j].z += t[j].z; g[j].w += t[j].w;
+      }
     }
     // gamma and the dx_add rows ride with them (round 3, ISA reading: loaded inside the loops that use them, each of these — and the
     // dropout seed — was a load + s_waitcnt vmcnt(0) pair per column: ~24 round trips in series per row, the kernel's whole 24 us)
@@ -317,6 +341,25 @@ extern "C" int mrblip_rmsnorm_bwd_cast(const float* dy, long long lddy, const fl
   hipLaunchKernelGGL(norm_bwd_kernel<true>, dim3(grid), dim3(256), 0, stream, dy, lddy, x, ldx, weight, M, D, eps, dx_add, ldadd, dx, lddx, (float*)nullptr,
                      (float*)nullptr, (bf16_t*)out_bf16, ldob, d);
   return mrblip_check_launch("rmsnorm_bwd_cast");
+}
+
+// rmsnorm_bwd (+ the consumer's bf16 operand when out_bf16 != nullptr) with dy in nparts fp32 PARTS, pstride elements apart — the K-split
+// input gradient of mrblip_gemm_ksplit; ext_part != 0: the last part is the LoRA term, added under the keep mask (ext_site, ext_p) over [M, D]
+extern "C" int mrblip_rmsnorm_bwd_parts(const float* dy, long long lddy, int nparts, long long pstride, int ext_part, uint32_t ext_site, float ext_p,
+                                        const float* x, long long ldx, const float* weight, int M, int D, float eps, const float* dx_add, long long ldadd,
+                                        float* dx, long long lddx, void* out_bf16, long long ldob, const uint32_t* seed_ptr, uint32_t site, float p_drop,
+                                        hipStream_t stream) {
+  if (int e = norm_check(M, D, x, ldx)) return e;
+  MRB_REQUIRE(nparts >= 1 && nparts <= 32 && (pstride % 4) == 0 && (lddy % 4) == 0 && ((uintptr_t)dy % 16) == 0, "rmsnorm_bwd_parts: 1..32 parts of 16-B aligned rows");
+  MRB_REQUIRE(!out_bf16 || (ldob % 4) == 0, "rmsnorm_bwd_parts: bf16 output unaligned");
+  MRB_REQUIRE(!(p_drop > 0.f || ext_p > 0.f) || seed_ptr, "rmsnorm_bwd_parts: dropout needs a device seed pointer");
+  DropoutArg d, de;
+  d.seed_ptr = (p_drop > 0.f) ? seed_ptr : nullptr; d.site = site; d.thresh24 = (uint32_t)(p_drop * 65536.0f + 0.5f); d.inv_keep = 1.0f / (1.0f - p_drop);
+  de.seed_ptr = (ext_p > 0.f) ? seed_ptr : nullptr; de.site = ext_site; de.thresh24 = (uint32_t)(ext_p * 65536.0f + 0.5f); de.inv_keep = 1.0f / (1.0f - ext_p);
+  const int grid = min((M + 3) / 4, 2048);
+  hipLaunchKernelGGL(norm_bwd_kernel<true>, dim3(grid), dim3(256), 0, stream, dy, lddy, x, ldx, weight, M, D, eps, dx_add, ldadd, dx, lddx, (float*)nullptr,
+                     (float*)nullptr, (bf16_t*)out_bf16, ldob, d, 0, nparts, pstride, ext_part, de);
+  return mrblip_check_launch("rmsnorm_bwd_parts");
 }
 
 extern "C" int mrblip_rmsnorm_bwd(const float* dy, long long lddy, const float* x, long long ldx, const float* weight, int M, int D,

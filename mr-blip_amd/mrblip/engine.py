@@ -18,7 +18,7 @@ import contextlib
 import math
 import os
 from dataclasses import dataclass, field
-from typing import Callable, Dict, List, Optional
+from typing import Callable, Dict, List, Optional, Tuple
 
 import torch
 
@@ -1052,8 +1052,12 @@ class MrBlipEngine:
 
     def lg_bwd(self, g: LoraGroup, dy: torch.Tensor, x: torch.Tensor, u: torch.Tensor, gbuf: torch.Tensor, dx: Optional[torch.Tensor],
                residual: Optional[torch.Tensor] = None, side: bool = False, tile_cfg: int = 0, flush: bool = True, tout=None, t_rows: int = 0,
-               prefetch=None, collect: Optional[list] = None):
-        """dy bf16 [M,N]; x the saved bf16 input; u the saved [M,64] LoRA activations.  Accumulates dA, dB of every adapter of the
+               prefetch=None, collect: Optional[list] = None, parts: Optional[torch.Tensor] = None, parts_cfg: Tuple[int, int] = (1, 13)):
+        """parts (round 5, [k_splits + 1, M, K_in] fp32 or bf16; dx must be None): the input gradient as PARTIAL products of the 4-wave
+        kernel's K-split form (ops.gemm_ksplit, parts_cfg = (k_splits, tile config)); the LoRA term is the last part, unmasked — the
+        consumer (ops.rmsnorm_bwd / ops.gated_gelu_bwd) adds the parts and applies this group's lora_dropout mask to it.
+
+        dy bf16 [M,N]; x the saved bf16 input; u the saved [M,64] LoRA activations.  Accumulates dA, dB of every adapter of the
         group (one launch) and (optionally) dx = dy W (+ residual) + mask * (g A) (one GEMM: the rank-8 term is its K-extension).
         side=True: the weight-gradient launch goes to the gradient side stream and runs beside the dX GEMM (the caller guarantees
         that dy / gbuf are not overwritten before its next side_join()).  flush=False only QUEUES that launch: it goes out with the
@@ -1080,6 +1084,7 @@ class MrBlipEngine:
                 for j, a in enumerate(g.adapters):
                     ops.lora_dx_add(dx, gbuf[:, 8 * j: 8 * j + 8], g.acat[8 * j: 8 * j + 8], drop=self.drop(a.site, self.cfg.lora_dropout))
             return
+        assert parts is None or dx is None
         fused = dx is not None and g.N % 32 == 0 and self._dec_proj_ok(g, dy.shape[0], {}, self.dec_proj_max_rows) and g.Wt.shape[0] % 16 == 0
         ks = self.k_splits_for(dy.shape[0], g.K, pad64(g.N), dx) if (dx is not None and not fused) else 1
         if fused:    # <= 16 decoder rows: g = dy B and dX = dy W + mask (.) (g A) [+ residual] in one launch
@@ -1107,6 +1112,9 @@ class MrBlipEngine:
                     self.side_flush()
             else:
                 grads()
+        if parts is not None:
+            ops.gemm_ksplit(dy, g.Wt, parts, pad64(g.N), parts_cfg[0], ext=(gbuf, g.acatt), tile_cfg=parts_cfg[1])
+            return False
         if dx is not None and not fused:
             if ks > 1:
                 ops.lora_dx(dy, g.Wt, gbuf, g.acatt, dx, pad64(g.N), residual=None, drop=drop, k_splits=ks)
@@ -1244,6 +1252,31 @@ class MrBlipEngine:
     enc_qkv_w4 = int(os.environ.get("MRB_ENC_QKV_W4", "14"))
     enc_qkv_wc = None
 
+    # Round 5: the encoder backward's input-gradient GEMMs on the 4-wave kernel (K-split where the output has too few tiles): wo 83.5 -> 44 us,
+    # wi 146.5 -> 79 us, qkv 88 -> 53 us per layer stand-alone (tools/bwd_w4_probe.py).  MRB_ENC_BWD_W4=0: the generic tile with its
+    # masked K extension, roles and all (round 4).
+    enc_bwd_w4 = os.environ.get("MRB_ENC_BWD_W4", "1") == "1"
+
+    def _enc_bwd_w4_ok(self, M: int) -> bool:
+        c = self.cfg
+        return bool(self.enc_bwd_w4 and M >= 1024 and not (c.lora_mask_per_adapter and self.training and c.lora_dropout > 0))
+
+    @staticmethod
+    def ksplit_cfg(M: int, N: int, K: int, n_cu: int = 256, max_ks: int = 8) -> Tuple[int, int]:
+        """(k_splits, tile config) of ops.gemm_ksplit for an [M x N x K] product: the pair with the shortest estimated time — rounds of
+        n_cu units x tile width x K-tiles per unit (the 256x192 tile of config 14 does 3/4 of the work of config 13's 256x256 per K-tile)"""
+        best = None
+        for cfg, bn in ((13, 256), (14, 192)):
+            tiles = -(-M // 256) * -(-N // bn)
+            for ks in (1, 2, 3, 4, 6, 8):
+                if (K // 64) % ks or ks > max_ks:
+                    continue
+                units = tiles * ks
+                cost = -(-units // n_cu) * bn * (K // 64 // ks + 6) + 16 * ks      # (+ 6 K-tiles: a unit's prologue and epilogue; + the consumer's extra part)
+                if best is None or cost < best[0]:
+                    best = (cost, ks, cfg)
+        return best[1], best[2]
+
     def _enc_qkv_w4_ok(self, M: int) -> bool:
         if not self.enc_qkv_w4 or M < 1024 or (self.cfg.lora_mask_per_adapter and self.training and self.cfg.lora_dropout > 0):
             return False
@@ -1289,6 +1322,16 @@ class MrBlipEngine:
         dyb2_s = [self.buf("eb_dyb2" + "_alt" * k, (M, pad64(d)), bf16) for k in range(nb)]
         g_s = [tuple(self.buf(n + "_alt" * k, (M, 64), bf16) for n in ("eb_g", "eb_g2", "eb_g3", "eb_g4")) for k in range(nb)]
         dyact = self.buf("eb_dyact", (M, ff), bf16, zero=False)
+        # Round 5: the three big input-gradient GEMMs of a layer (wo: [M x ff x d], wi: [M x d x 2 ff], qkv: [M x d x 3 inner]) on the
+        # hand-pipelined 4-wave kernel, the [M x d] ones as a K-split that fills the chip; their outputs are parts the consumers add
+        w4b = self._enc_bwd_w4_ok(M)
+        if w4b:
+            L0 = self.t5["enc"][0]
+            cfg_wo = self.ksplit_cfg(M, L0["wo"].K, pad64(L0["wo"].N), max_ks=1)       # (the gated-GELU backward adds exactly two parts)
+            cfg_wi, cfg_qkv = (self.ksplit_cfg(M, g.K, pad64(g.N)) for g in (L0["wi"], L0["qkv"]))
+            dyact_p = self.buf("eb_dyact_p", (cfg_wo[0] + 1, M, ff), bf16, zero=False)
+            dxn_p_wi = self.buf("eb_dxn_p_wi", (cfg_wi[0] + 1, M, d), f32, zero=False)
+            dxn_p_qkv = self.buf("eb_dxn_p_qkv", (cfg_qkv[0] + 1, M, d), f32, zero=False)
         dh_s = [self.buf("eb_dh" + "_alt" * k, (M, 2 * ff), bf16, zero=False) for k in range(nb)]
         dxn = self.buf("eb_dxn", (M, d), f32, zero=False)
         do = self.buf("eb_do", (M, inner), bf16, zero=False)
@@ -1334,17 +1377,27 @@ class MrBlipEngine:
             # and one 16 MB read fewer per sub-layer; only the top layer, whose dx comes from the decoder, casts on its own)
             if not dyb_ready:
                 ops.cast_dropout(dx, out_bf16=dyb, drop=self.drop(L["sites"][3], p))
-            self.lg_bwd(L["wo"], dyb, self.ws[f"e{i}_y"], self.ws[f"e{i}_u_wo"], gb, dyact, side=True, tile_cfg=_ENC_BWD_CFG[0], flush=False,
-                        prefetch=self.enc_pf_bwd([L["wi"]], M), collect=layer_jobs)
-            ops.gated_gelu_bwd(dyact, self.ws[f"e{i}_h"], dh, drop=self.drop(L["sites"][2], p))
-            self.lg_bwd(L["wi"], dh, self.ws[f"e{i}_xn2"], self.ws[f"e{i}_u_wi"], gb2, dxn, side=True, tile_cfg=_ENC_BWD_CFG[1],
-                        prefetch=self.enc_pf_bwd([L["o"]], M), collect=layer_jobs)
+            if w4b:
+                self.lg_bwd(L["wo"], dyb, self.ws[f"e{i}_y"], self.ws[f"e{i}_u_wo"], gb, None, side=True, flush=False, collect=layer_jobs,
+                            parts=dyact_p, parts_cfg=cfg_wo)
+                ops.gated_gelu_bwd(dyact_p[0], self.ws[f"e{i}_h"], dh, drop=self.drop(L["sites"][2], p), dy_ext=dyact_p[1],
+                                   ext_drop=self.drop(L["wo"].site, c.lora_dropout))
+                self.lg_bwd(L["wi"], dh, self.ws[f"e{i}_xn2"], self.ws[f"e{i}_u_wi"], gb2, None, side=True, collect=layer_jobs,
+                            parts=dxn_p_wi, parts_cfg=cfg_wi)
+            else:
+                self.lg_bwd(L["wo"], dyb, self.ws[f"e{i}_y"], self.ws[f"e{i}_u_wo"], gb, dyact, side=True, tile_cfg=_ENC_BWD_CFG[0], flush=False,
+                            prefetch=self.enc_pf_bwd([L["wi"]], M), collect=layer_jobs)
+                ops.gated_gelu_bwd(dyact, self.ws[f"e{i}_h"], dh, drop=self.drop(L["sites"][2], p))
+                self.lg_bwd(L["wi"], dh, self.ws[f"e{i}_xn2"], self.ws[f"e{i}_u_wi"], gb2, dxn, side=True, tile_cfg=_ENC_BWD_CFG[1],
+                            prefetch=self.enc_pf_bwd([L["o"]], M), collect=layer_jobs)
             if batch and kq_ready is not None:
                 self.side_flush()      # (the K^T / Q^T job queued above must go out here: this layer's attention backward waits for it)
+            dxn_wi = dxn_p_wi if w4b else dxn
+            ext_wi = dict(ext_drop=self.drop(L["wi"].site, c.lora_dropout), ext_part=True) if w4b else {}
             if self.fuse_bwd_cast:
-                ops.rmsnorm_bwd(dxn, self.ws[f"e{i}_xm"], L["ln1"], c.t5_eps, other, dx_add=dx, out_bf16=dyb2, out_drop=self.drop(L["sites"][1], p))
+                ops.rmsnorm_bwd(dxn_wi, self.ws[f"e{i}_xm"], L["ln1"], c.t5_eps, other, dx_add=dx, out_bf16=dyb2, out_drop=self.drop(L["sites"][1], p), **ext_wi)
             else:
-                ops.rmsnorm_bwd(dxn, self.ws[f"e{i}_xm"], L["ln1"], c.t5_eps, other, dx_add=dx)
+                ops.rmsnorm_bwd(dxn_wi, self.ws[f"e{i}_xm"], L["ln1"], c.t5_eps, other, dx_add=dx, **ext_wi)
                 ops.cast_dropout(other, out_bf16=dyb2, drop=self.drop(L["sites"][1], p))
             dx, other = other, dx
             # xm = x_in + drop(o(attn(qkv(xn))))
@@ -1367,8 +1420,14 @@ class MrBlipEngine:
                               self.v4(dqkv, B, S, H, dk, 0), self.v4(dqkv, B, S, H, dk, inner), self.v4(dqkv, B, S, H, dk, 2 * inner),
                               scale=1.0, bias_lut=self.lut_enc, kmask=kmask, drop=self.drop(L["sites"][0], p),
                               drop_bits=self.ws.get(f"e{i}_dbits") if self.drop(L["sites"][0], p) is not None else None)
-            self.lg_bwd(L["qkv"], dqkv, self.ws[f"e{i}_xn"], self.ws[f"e{i}_u_qkv"], gb4, dxn, side=True, tile_cfg=_ENC_BWD_CFG[3],
-                        prefetch=self.enc_pf_bwd([self.t5["enc"][i - 1]["wo"]], M) if i > 0 else None, collect=layer_jobs)
+            if w4b:
+                self.lg_bwd(L["qkv"], dqkv, self.ws[f"e{i}_xn"], self.ws[f"e{i}_u_qkv"], gb4, None, side=True, collect=layer_jobs,
+                            parts=dxn_p_qkv, parts_cfg=cfg_qkv)
+            else:
+                self.lg_bwd(L["qkv"], dqkv, self.ws[f"e{i}_xn"], self.ws[f"e{i}_u_qkv"], gb4, dxn, side=True, tile_cfg=_ENC_BWD_CFG[3],
+                            prefetch=self.enc_pf_bwd([self.t5["enc"][i - 1]["wo"]], M) if i > 0 else None, collect=layer_jobs)
+            dxn_qkv = dxn_p_qkv if w4b else dxn
+            ext_qkv = dict(ext_drop=self.drop(L["qkv"].site, c.lora_dropout), ext_part=True) if w4b else {}
             if batch and layer_jobs:   # the layer's four weight-gradient pairs: one launch, one hand-over
                 ev_done = torch.cuda.Event()
 
@@ -1379,11 +1438,11 @@ class MrBlipEngine:
                 self.side_flush()
                 grads_done[i] = ev_done
             if i > 0 and self.fuse_bwd_cast:   # ... and the layer below's first operand
-                ops.rmsnorm_bwd(dxn, self.ws[f"e{i}_xin"], L["ln0"], c.t5_eps, other, dx_add=dx, out_bf16=dyb_pair[(i - 1) % nd],
-                                out_drop=self.drop(self.t5["enc"][i - 1]["sites"][3], p))
+                ops.rmsnorm_bwd(dxn_qkv, self.ws[f"e{i}_xin"], L["ln0"], c.t5_eps, other, dx_add=dx, out_bf16=dyb_pair[(i - 1) % nd],
+                                out_drop=self.drop(self.t5["enc"][i - 1]["sites"][3], p), **ext_qkv)
                 dyb_ready = True
             else:
-                ops.rmsnorm_bwd(dxn, self.ws[f"e{i}_xin"], L["ln0"], c.t5_eps, other, dx_add=dx)
+                ops.rmsnorm_bwd(dxn_qkv, self.ws[f"e{i}_xin"], L["ln0"], c.t5_eps, other, dx_add=dx, **ext_qkv)
                 dyb_ready = False
             dx, other = other, dx
         self.side_join()

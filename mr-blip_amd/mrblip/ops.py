@@ -96,6 +96,9 @@ _lora_dx_add_b = _sig("mrblip_lora_dx_add_batched", vp, ll, vp, ll, ll, vp, ll, 
 _lora_rows_b = _sig("mrblip_lora_rows_batched", vp, ll, ll, vp, ll, ll, i32, i32, i32, vp, ll, ll, i32, vp, u32, u32, f32, vp)
 _gemm_extra = _sig("mrblip_gemm_set_extra", vp, vp, vp, i32, i32, i32, ll, ll, ll, i32, i32)
 _attn_split_ws = _sig("mrblip_attention_set_split_workspace", vp, ll, i32)
+_gemm_ksplit = _sig("mrblip_gemm_ksplit", vp, ll, vp, ll, vp, ll, vp, ll, i32, i32, i32, vp, ll, ll, i32, i32, i32, vp)
+_rms_bwd_parts = _sig("mrblip_rmsnorm_bwd_parts", vp, ll, i32, ll, i32, u32, f32, vp, ll, vp, i32, i32, f32, vp, ll, vp, ll, vp, ll, vp, u32, f32, vp)
+_gated_bwd_parts = _sig("mrblip_gated_gelu_bwd_parts", vp, vp, ll, vp, ll, vp, ll, i32, i32, vp, u32, f32, u32, f32, vp)
 _rms_lora = _sig("mrblip_rmsnorm_lora_fwd", vp, ll, vp, i32, i32, f32, vp, ll, vp, ll, i32, vp, ll, vp, u32, f32, vp)
 
 EXPORTS = [
@@ -106,6 +109,7 @@ EXPORTS = [
     "mrblip_seed_bump", "mrblip_prefetch", "mrblip_gemm_set_prefetch", "mrblip_gemm_set_thin", "mrblip_lora_dx_add", "mrblip_dropout_bf16", "mrblip_colsum", "mrblip_lora_pack", "mrblip_lora_tn",
     "mrblip_lora_grads", "mrblip_lora_grads_batched", "mrblip_gemm_lora_down", "mrblip_gemm_lora_dx", "mrblip_patchify_u8",
     "mrblip_gemm_set_cu_reserve", "mrblip_lora_rows", "mrblip_rmsnorm_lora_fwd", "mrblip_lora_rows_init", "mrblip_dec_proj", "mrblip_dec_proj_config", "mrblip_lora_dx_add_batched", "mrblip_lora_rows_batched", "mrblip_gemm_set_extra", "mrblip_attention_set_split_workspace",
+    "mrblip_gemm_ksplit", "mrblip_rmsnorm_bwd_parts", "mrblip_gated_gelu_bwd_parts",
     "mrblip_gemm_f16", "mrblip_layernorm_fwd_f16", "mrblip_attention_fwd_rowv_f16", "mrblip_patchify_f16", "mrblip_patchify_u8_f16",
 ]
 
@@ -331,10 +335,18 @@ def layernorm_bwd(dy, x, gamma, eps, dx, dx_add=None, dgamma=None, dbeta=None):
     _chk(_ln_bwd(_p(dy), _ld(dy), _p(x), _ld(x), _p(gamma), M, D, eps, _p(dx_add), _ld(dx_add), _p(dx), _ld(dx), _p(dgamma), _p(dbeta), _stream()))
 
 
-def rmsnorm_bwd(dy, x, weight, eps, dx, dx_add=None, out_bf16=None, out_drop: Optional["Dropout"] = None):
+def rmsnorm_bwd(dy, x, weight, eps, dx, dx_add=None, out_bf16=None, out_drop: Optional["Dropout"] = None, ext_drop: Optional["Dropout"] = None, ext_part: bool = False):
     """out_bf16 (optional): also write bf16(dropout-backward(dx)) for the mask of ``out_drop`` — the next GEMM's operand, saving the
-    separate cast_dropout launch and its read of dx"""
+    separate cast_dropout launch and its read of dx.  dy of 3 dims [parts, M, D]: partial products (gemm_ksplit), added in part order;
+    ext_part: the last one is the LoRA term, added under the keep mask of ``ext_drop``."""
     M, D = x.shape
+    if dy.dim() == 3:
+        sp, site, p = _d(out_drop)
+        esp, esite, ep = _d(ext_drop)
+        assert dy.stride(2) == 1 and (sp == esp or not sp or not esp)
+        _chk(_rms_bwd_parts(_p(dy), dy.stride(1), dy.shape[0], dy.stride(0), 1 if ext_part else 0, esite, ep, _p(x), _ld(x), _p(weight), M, D, eps,
+                            _p(dx_add), _ld(dx_add), _p(dx), _ld(dx), _p(out_bf16), _ld(out_bf16), sp or esp, site, p, _stream()))
+        return
     if out_bf16 is None:
         _chk(_rms_bwd(_p(dy), _ld(dy), _p(x), _ld(x), _p(weight), M, D, eps, _p(dx_add), _ld(dx_add), _p(dx), _ld(dx), _stream()))
     else:
@@ -633,10 +645,29 @@ def gelu_bwd(dy, h, dh):
     _chk(_gelu_bwd(_p(dy), _p(h), _p(dh), dy.numel(), _stream()))
 
 
-def gated_gelu_bwd(dy, h, dh, drop: Optional[Dropout] = None):
+def gated_gelu_bwd(dy, h, dh, drop: Optional[Dropout] = None, dy_ext=None, ext_drop: Optional[Dropout] = None):
+    """dy_ext (optional, bf16, laid out like dy): a second part of dy, added under the keep mask of ``ext_drop`` (gemm_ksplit's LoRA part)"""
     M, Nh = dy.shape
     sp, site, p = _d(drop)
-    _chk(_gated_bwd(_p(dy), _ld(dy), _p(h), _ld(h), _p(dh), _ld(dh), M, Nh, sp, site, p, _stream()))
+    if dy_ext is None:
+        _chk(_gated_bwd(_p(dy), _ld(dy), _p(h), _ld(h), _p(dh), _ld(dh), M, Nh, sp, site, p, _stream()))
+        return
+    esp, esite, ep = _d(ext_drop)
+    assert _ld(dy_ext) == _ld(dy) and dy_ext.dtype == dy.dtype and (sp == esp or not sp or not esp)
+    _chk(_gated_bwd_parts(_p(dy), _p(dy_ext), _ld(dy), _p(h), _ld(h), _p(dh), _ld(dh), M, Nh, sp or esp, site, p, esite, ep, _stream()))
+
+
+def gemm_ksplit(a, w, parts, K: int, k_splits: int, ext=None, tile_cfg: int = 13):
+    """parts[s] = a[:, K range s] @ w[:, K range s]^T for s < k_splits; with ext = (g [M, >= 64], acatt [N, >= 64]) parts[k_splits] = g @ acatt^T.
+    ``parts``: [k_splits (+ 1), M, N] fp32 or bf16 (rows may be strided).  The hand-pipelined 4-wave kernel in its K-split form
+    (mrblip_gemm_ksplit): for outputs with too few 256-wide tiles to fill the chip."""
+    M, N = parts.shape[1], parts.shape[2]
+    _req(a, torch.bfloat16, "gemm_ksplit.a")
+    _req(w, torch.bfloat16, "gemm_ksplit.w")
+    assert parts.shape[0] == k_splits + (1 if ext is not None else 0) and parts.stride(2) == 1 and a.shape[0] == M and w.shape[0] == N
+    g, at = ext if ext is not None else (None, None)
+    _chk(_gemm_ksplit(_p(a), _ld(a), _p(w), _ld(w), _p(g), _ld(g), _p(at), _ld(at), M, N, int(K), _p(parts), parts.stride(1), parts.stride(0),
+                      1 if parts.dtype == torch.float32 else 0, int(k_splits), int(tile_cfg), _stream()))
 
 
 def cross_entropy(logits, labels_i32, inv_count, loss, dlogits=None):

@@ -950,6 +950,110 @@ def test_rmsnorm_bwd_with_fused_operand_cast(ops, D, p):
         assert 0.85 < (got != 0).float().mean().item() < 0.95
 
 
+# ---- round 5: K-split form of the 4-wave kernel and the consumers that add its parts -------------------------------------------------
+@pytest.mark.parametrize("f32out", [True, False])
+@pytest.mark.parametrize("M,N,K,ks,cfg,ext", [(2012, 2048, 2560, 4, 13, True), (1312, 256, 768, 6, 14, True), (300, 264, 128, 2, 13, False),
+                                               (2012, 1024, 1024, 1, 14, True), (513, 520, 192, 3, 13, True), (257, 8, 64, 1, 13, True)])
+def test_gemm_k_split_parts_of_the_four_wave_kernel(ops, M, N, K, ks, cfg, ext, f32out):
+    """mrblip_gemm_ksplit: part s = A[:, K range s] W[:, K range s]^T, the K extension's product as the last part — against fp32 matmuls of
+    the bf16 operands (fp32 parts: accumulation order only, 2e-6 measured; bf16 parts: one rounding); rows beyond M and columns beyond N of
+    the last tiles must not be written (canary)."""
+    torch.manual_seed(5)
+    a = bf(torch.randn(M, K + 64, device=dev()))[:, :K]           # (row stride != K)
+    w = bf(torch.randn(N, K, device=dev()) * 0.1)
+    g = bf(torch.randn(M, 64, device=dev())) if ext else None
+    at = bf(torch.randn(N, 64, device=dev()) * 0.1) if ext else None
+    nparts = ks + (1 if ext else 0)
+    dt = torch.float32 if f32out else torch.bfloat16
+    buf = torch.full((nparts, M + 3, N + 8), 7.0, dtype=dt, device=dev())
+    parts = buf[:, :M, :N]
+    ops.gemm_ksplit(a, w, parts, K, ks, ext=(g, at) if ext else None, tile_cfg=cfg)
+    torch.cuda.synchronize()
+    kp = K // ks
+    for s_ in range(ks):
+        ref = a[:, s_ * kp:(s_ + 1) * kp].float() @ w[:, s_ * kp:(s_ + 1) * kp].float().t()
+        assert rel(parts[s_].float(), ref) < (5e-6 if f32out else 4e-3), (s_, rel(parts[s_].float(), ref))
+    if ext:
+        ref = g.float() @ at.float().t()
+        assert rel(parts[ks].float(), ref) < (5e-6 if f32out else 4e-3)
+    assert torch.all(buf[:, M:, :] == 7.0) and torch.all(buf[:, :, N:] == 7.0)
+    # the same launch again: the same bits (fixed K ranges, no atomics)
+    again = torch.full_like(buf, 3.0)
+    ops.gemm_ksplit(a, w, again[:, :M, :N], K, ks, ext=(g, at) if ext else None, tile_cfg=cfg)
+    assert torch.equal(again[:, :M, :N], parts)
+    with pytest.raises(ops.MrblipError):
+        ops.gemm_ksplit(a, w, parts, K, ks, ext=(g, at) if ext else None, tile_cfg=2)
+
+
+@pytest.mark.parametrize("D,p,pe", [(2048, 0.1, 0.05), (768, 0.0, 0.05), (256, 0.1, 0.0)])
+def test_rmsnorm_bwd_adds_k_split_parts_and_masks_the_lora_part(ops, D, p, pe):
+    """mrblip_rmsnorm_bwd_parts = mrblip_rmsnorm_bwd(_cast) on dy = part 0 + ... + mask (.) last part, the parts added in part order in
+    fp32: bit for bit the launch on a dy summed the same way by torch (the mask from the oracle's restatement of the hash)."""
+    torch.manual_seed(33)
+    M, nparts = 301, 5
+    x = torch.randn(M, D, device=dev()) * 1.5
+    w = torch.randn(D, device=dev()) * 0.1 + 1
+    parts = torch.randn(nparts, M + 2, D, device=dev())[:, :M]
+    add = torch.randn(M, D, device=dev())
+    seed = torch.tensor([4242], dtype=torch.int32, device=dev())
+    drop = ops.Dropout(seed, 23, p) if p > 0 else None
+    edrop = ops.Dropout(seed, 57, pe) if pe > 0 else None
+    dy = parts[0].clone()
+    for s_ in range(1, nparts - 1):
+        dy = dy + parts[s_]
+    last = parts[nparts - 1]
+    if pe > 0:
+        inv_keep = (torch.tensor(1.0) / (torch.tensor(1.0) - torch.tensor(pe, dtype=torch.float32))).item()     # (fp32 arithmetic, as the C side)
+        last = torch.where(keep_mask((M, D), 4242, 57, pe) > 0, last * inv_keep, torch.zeros_like(last))
+    dy = dy + last
+    dx_ref, dx = torch.empty_like(x), torch.empty_like(x)
+    want = torch.zeros(M, D, dtype=torch.bfloat16, device=dev())
+    got = torch.zeros(M, D, dtype=torch.bfloat16, device=dev())
+    ops.rmsnorm_bwd(dy, x, w, 1e-6, dx_ref, dx_add=add, out_bf16=want, out_drop=drop)
+    ops.rmsnorm_bwd(parts, x, w, 1e-6, dx, dx_add=add, out_bf16=got, out_drop=drop, ext_drop=edrop, ext_part=True)
+    assert torch.equal(dx, dx_ref) and torch.equal(got, want)
+    ops.rmsnorm_bwd(parts, x, w, 1e-6, dx, dx_add=add, ext_drop=edrop, ext_part=True)          # without the bf16 operand
+    assert torch.equal(dx, dx_ref)
+    # no masked part: a plain sum
+    ops.rmsnorm_bwd(parts[:1], x, w, 1e-6, dx, dx_add=add)
+    ops.rmsnorm_bwd(parts[0], x, w, 1e-6, dx_ref, dx_add=add)
+    assert torch.equal(dx, dx_ref)
+
+
+@pytest.mark.parametrize("p,pe", [(0.1, 0.05), (0.0, 0.05), (0.1, 0.0)])
+def test_gated_gelu_bwd_adds_the_masked_lora_part(ops, p, pe):
+    """mrblip_gated_gelu_bwd_parts: dy + mask (.) dy_ext in fp32 before the gate's derivative — against the one-part launch on the sum
+    (which rounds the sum to bf16 first: one bf16 rounding of dy apart)"""
+    torch.manual_seed(35)
+    M, Nh = 203, 512
+    parts = bf(torch.randn(2, M, Nh, device=dev()))
+    parts[1] *= 0.05
+    h = bf(torch.randn(M, 2 * Nh, device=dev()))
+    seed = torch.tensor([99], dtype=torch.int32, device=dev())
+    drop = ops.Dropout(seed, 3, p) if p > 0 else None
+    edrop = ops.Dropout(seed, 9, pe) if pe > 0 else None
+    e = parts[1].float()
+    if pe > 0:
+        e = torch.where(keep_mask((M, Nh), 99, 9, pe) > 0, e * (1.0 / (1.0 - pe)), torch.zeros_like(e))
+    dy = parts[0].float() + e
+    # fp32 reference of the gate's backward on the exact sum
+    hf = h.float()
+    h0, h1 = hf[:, :Nh], hf[:, Nh:]
+    gy = dy
+    if p > 0:
+        gy = torch.where(keep_mask((M, Nh), 99, 3, p) > 0, gy * (1.0 / (1.0 - p)), torch.zeros_like(gy))
+    cdf = 0.5 * (1 + torch.erf(h0 / math.sqrt(2)))
+    pdf = torch.exp(-0.5 * h0 * h0) / math.sqrt(2 * math.pi)
+    ref = torch.cat([gy * h1 * (cdf + h0 * pdf), gy * h0 * cdf], 1)
+    dh = torch.empty(M, 2 * Nh, dtype=torch.bfloat16, device=dev())
+    ops.gated_gelu_bwd(parts[0], h, dh, drop=drop, dy_ext=parts[1], ext_drop=edrop)
+    assert rel(dh.float(), ref) < 4e-3, rel(dh.float(), ref)
+    one = torch.empty_like(dh)
+    ops.gated_gelu_bwd(bf(dy), h, one, drop=drop)
+    assert rel(dh.float(), one.float()) < 4e-3
+    assert rel(dh.float(), ref) <= rel(one.float(), ref) * 1.05          # no extra rounding of the sum: at least as close
+
+
 # ---- fused decoder projection (csrc/decproj.hip) against the two-launch paths it replaces ------------------------------------------------
 def _dp_operands(R, N, K, Rk, gated=False, seed=41):
     torch.manual_seed(seed)

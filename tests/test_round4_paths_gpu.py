@@ -22,7 +22,7 @@ def _step(flags, B=1, steps=2):
     cfg = EngineConfig(vit_dim=320, vit_depth=2, vit_heads=5, vit_mlp=512, qf_dim=256, qf_heads=4, qf_inter=512, qf_layers=4, num_query=32,
                        d_model=256, d_kv=64, t5_heads=4, d_ff=512, t5_layers=3, t5_dec_layers=3)
     eng = MrBlipEngine(cfg, RandomSource(dev, seed=77), dev, lora_init=bench.lora_init_nonzero, seed=11)
-    flags = dict(dict(enc_qkv_w4=0), **flags)     # the round-4 paths under test live in the generic tile's qkv projection; the 4-wave form has its own test below
+    flags = dict(dict(enc_qkv_w4=0, enc_bwd_w4=False), **flags)     # the round-4 paths under test live in the generic tile; the 4-wave forms have their own tests below
     for k, v in flags.items():
         setattr(eng, k, v)
     if flags.get("xs_off"):
@@ -150,3 +150,16 @@ def test_encoder_qkv_through_the_four_wave_kernel_equals_the_generic_tile_path()
         torch.cuda.synchronize()
         g0 = eng.t5["enc"][0]["qkv"]
         assert torch.equal(eng.enc_qkv_wc[0, :, eng.cfg.d_model:], g0.wext) and torch.equal(eng.enc_qkv_wc[0, :, :g0.K], g0.W[:, :g0.K])
+
+
+def test_encoder_input_gradients_through_the_k_split_four_wave_kernel_equal_the_generic_tile_path():
+    """Round 5: the encoder backward's wo / wi / qkv input gradients as PARTS of the 4-wave kernel (a K-split where the [M x d] output has
+    too few tiles), added by the gated-GELU / RMSNorm backward that consumes them, the LoRA part under its lora_dropout mask.  Same
+    forward (same loss bits); the gradient differs by summation order and by ONE bf16 rounding less on the wo path."""
+    base_l, base_g, eng0, lay = _step(dict(enc_bwd_w4=False))
+    l, g, eng, _ = _step(dict(enc_bwd_w4=True))
+    assert eng._enc_bwd_w4_ok(lay.S) and "eb_dxn_p_wi" in eng.ws and "eb_dxn_p_wi" not in eng0.ws
+    assert l == base_l
+    check("encoder input gradients via K-split parts vs the generic tile path: flat gradient", relerr(g, base_g), 1e-2)
+    l2, g2, _, _ = _step(dict(enc_bwd_w4=True))
+    assert l2 == l and torch.equal(g2, g)          # parts are added in part order: reproducible
