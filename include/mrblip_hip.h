@@ -293,6 +293,10 @@ int mrblip_rmsnorm_bwd_parts(const float* dy, long long lddy, int nparts, long l
                              const float* x, long long ldx, const float* weight, int M, int D, float eps, const float* dx_add, long long ldadd,
                              float* dx, long long lddx, void* out_bf16, long long ldob, const uint32_t* seed_ptr, uint32_t site, float p_drop,
                              mrblip_stream_t stream);
+/* out = (residual, may be NULL or out itself) + part 0 + ... + part nparts-1, fp32, added in part order (the reduce of mrblip_gemm_ksplit for
+ * consumers without a parts form: the encoder-output gradient of the stacked cross-attention K / V projections, modeling_t5.py:561-599) */
+int mrblip_sum_parts(const float* parts, long long ldp, long long pstride, int nparts, const float* residual, long long ldr, float* out,
+                     long long ldo, int M, int N, mrblip_stream_t stream);
 int mrblip_gated_gelu_bwd_parts(const void* dy, const void* dy_ext, long long lddy, const void* h, long long ldh, void* dh, long long lddh, int M, int Nh,
                                 const uint32_t* seed_ptr, uint32_t site, float p, uint32_t ext_site, float ext_p, mrblip_stream_t stream);
 /* fp32 LoRA master weights -> bf16 GEMM operands for every adapter of a device descriptor table (10 int64 per adapter:

@@ -512,6 +512,28 @@ extern "C" int mrblip_gated_gelu_bwd(const void* dy, long long lddy, const void*
   hipLaunchKernelGGL(gated_bwd_kernel, dim3(grid_for((long long)M * Nh / 8)), dim3(256), 0, stream, (const bf16_t*)dy, lddy, (const bf16_t*)h, ldh, (bf16_t*)dh, lddh, M, Nh, mk_drop(seed_ptr, site, p));
   return mrblip_check_launch("gated_gelu_bwd");
 }
+// out = (residual) + part 0 + part 1 + ... (fp32, in part order): the K-split partial products of mrblip_gemm_ksplit for a consumer that has no
+// parts form of its own (the encoder-output gradient that the decoder's stacked cross K / V projections accumulate chunk by chunk)
+__global__ __launch_bounds__(256) void sum_parts_kernel(const float* __restrict__ parts, long long ldp, long long pstride, int nparts, const float* residual,
+                                                        long long ldr, float* out, long long ldo, int M, int N) {
+  const long long total4 = (long long)M * (N / 4);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
+    const int m = (int)(i / (N / 4)), c = (int)(i % (N / 4)) * 4;
+    float4 acc = residual ? *reinterpret_cast<const float4*>(residual + (long long)m * ldr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s_ = 0; s_ < nparts; ++s_) {
+      const float4 t = *reinterpret_cast<const float4*>(parts + (long long)s_ * pstride + (long long)m * ldp + c);
+      acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+    }
+    *reinterpret_cast<float4*>(out + (long long)m * ldo + c) = acc;
+  }
+}
+extern "C" int mrblip_sum_parts(const float* parts, long long ldp, long long pstride, int nparts, const float* residual, long long ldr, float* out,
+                                long long ldo, int M, int N, hipStream_t stream) {
+  MRB_REQUIRE(M > 0 && N > 0 && (N % 4) == 0 && nparts >= 1 && (ldp % 4) == 0 && (pstride % 4) == 0 && (ldo % 4) == 0 && (!residual || (ldr % 4) == 0) &&
+                  ((uintptr_t)parts % 16) == 0 && ((uintptr_t)out % 16) == 0 && ((uintptr_t)residual % 16) == 0, "sum_parts: 16-B aligned fp32 rows");
+  hipLaunchKernelGGL(sum_parts_kernel, dim3(grid_for((long long)M * N / 4)), dim3(256), 0, stream, parts, ldp, pstride, nparts, residual, ldr, out, ldo, M, N);
+  return mrblip_check_launch("sum_parts");
+}
 // ... with dy in two bf16 parts: dy + mask(ext_site, ext_p) (.) dy_ext (same leading dimension; dy_ext == nullptr: plain)
 extern "C" int mrblip_gated_gelu_bwd_parts(const void* dy, const void* dy_ext, long long lddy, const void* h, long long ldh, void* dh, long long lddh, int M, int Nh,
                                            const uint32_t* seed_ptr, uint32_t site, float p, uint32_t ext_site, float ext_p, hipStream_t stream) {

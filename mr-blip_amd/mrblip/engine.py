@@ -1516,7 +1516,15 @@ class MrBlipEngine:
                            [a.out for a in ads], [a.dA for a in ads], g.K, drop=self.drop(g.site, c.lora_dropout))
         ops.lora_dx_add_batched(denc, g_all[:, i0 * 64:], ca["acat"][i0 * R:], K, G, g_gstride=64, a_gstride=R * K, R=R,
                                 drop=self.drop(ca["site0"] + i0 * ca["site_stride"], c.lora_dropout), site_stride=ca["site_stride"])
-        ops.gemm(dckv_all[:, i0 * N:i1 * N], ca["Wt"][:, i0 * N:i1 * N], denc, residual=denc)
+        Me = denc.shape[0]
+        if self._enc_bwd_w4_ok(Me) and ((G * N) // 64) % 4 == 0:
+            # round 5: [Me x d] is 64 tiles of 256x256 and K = G * 2 * inner is 8192 .. 40960: the 4-wave kernel's K-split, then one add
+            ks, cfg = self.ksplit_cfg(Me, K, G * N)
+            parts = self.buf("db_denc_parts", (8, Me, K), f32, zero=False)[:ks]
+            ops.gemm_ksplit(dckv_all[:, i0 * N:i1 * N], ca["Wt"][:, i0 * N:i1 * N], parts, G * N, ks, tile_cfg=cfg)
+            ops.sum_parts(parts, denc, residual=denc)
+        else:
+            ops.gemm(dckv_all[:, i0 * N:i1 * N], ca["Wt"][:, i0 * N:i1 * N], denc, residual=denc)
 
     @torch.no_grad()
     def t5_cross_kv(self, enc: torch.Tensor, Be: int, S: int):

@@ -99,6 +99,7 @@ _attn_split_ws = _sig("mrblip_attention_set_split_workspace", vp, ll, i32)
 _gemm_ksplit = _sig("mrblip_gemm_ksplit", vp, ll, vp, ll, vp, ll, vp, ll, i32, i32, i32, vp, ll, ll, i32, i32, i32, vp)
 _rms_bwd_parts = _sig("mrblip_rmsnorm_bwd_parts", vp, ll, i32, ll, i32, u32, f32, vp, ll, vp, i32, i32, f32, vp, ll, vp, ll, vp, ll, vp, u32, f32, vp)
 _gated_bwd_parts = _sig("mrblip_gated_gelu_bwd_parts", vp, vp, ll, vp, ll, vp, ll, i32, i32, vp, u32, f32, u32, f32, vp)
+_sum_parts = _sig("mrblip_sum_parts", vp, ll, ll, i32, vp, ll, vp, ll, i32, i32, vp)
 _rms_lora = _sig("mrblip_rmsnorm_lora_fwd", vp, ll, vp, i32, i32, f32, vp, ll, vp, ll, i32, vp, ll, vp, u32, f32, vp)
 
 EXPORTS = [
@@ -109,7 +110,7 @@ EXPORTS = [
     "mrblip_seed_bump", "mrblip_prefetch", "mrblip_gemm_set_prefetch", "mrblip_gemm_set_thin", "mrblip_lora_dx_add", "mrblip_dropout_bf16", "mrblip_colsum", "mrblip_lora_pack", "mrblip_lora_tn",
     "mrblip_lora_grads", "mrblip_lora_grads_batched", "mrblip_gemm_lora_down", "mrblip_gemm_lora_dx", "mrblip_patchify_u8",
     "mrblip_gemm_set_cu_reserve", "mrblip_lora_rows", "mrblip_rmsnorm_lora_fwd", "mrblip_lora_rows_init", "mrblip_dec_proj", "mrblip_dec_proj_config", "mrblip_lora_dx_add_batched", "mrblip_lora_rows_batched", "mrblip_gemm_set_extra", "mrblip_attention_set_split_workspace",
-    "mrblip_gemm_ksplit", "mrblip_rmsnorm_bwd_parts", "mrblip_gated_gelu_bwd_parts",
+    "mrblip_gemm_ksplit", "mrblip_rmsnorm_bwd_parts", "mrblip_gated_gelu_bwd_parts", "mrblip_sum_parts",
     "mrblip_gemm_f16", "mrblip_layernorm_fwd_f16", "mrblip_attention_fwd_rowv_f16", "mrblip_patchify_f16", "mrblip_patchify_u8_f16",
 ]
 
@@ -655,6 +656,15 @@ def gated_gelu_bwd(dy, h, dh, drop: Optional[Dropout] = None, dy_ext=None, ext_d
     esp, esite, ep = _d(ext_drop)
     assert _ld(dy_ext) == _ld(dy) and dy_ext.dtype == dy.dtype and (sp == esp or not sp or not esp)
     _chk(_gated_bwd_parts(_p(dy), _p(dy_ext), _ld(dy), _p(h), _ld(h), _p(dh), _ld(dh), M, Nh, sp or esp, site, p, esite, ep, _stream()))
+
+
+def sum_parts(parts, out, residual=None):
+    """out = (residual) + parts[0] + parts[1] + ... in part order; parts fp32 [n, M, N]"""
+    n, M, N = parts.shape
+    _req(parts, torch.float32, "sum_parts.parts")
+    _req(out, torch.float32, "sum_parts.out")
+    assert parts.stride(2) == 1
+    _chk(_sum_parts(_p(parts), parts.stride(1), parts.stride(0), n, _p(residual), _ld(residual), _p(out), _ld(out), M, N, _stream()))
 
 
 def gemm_ksplit(a, w, parts, K: int, k_splits: int, ext=None, tile_cfg: int = 13):

@@ -455,6 +455,10 @@ def test_c3_batch4_step_equals_four_accumulated_single_clip_steps(xl):
     # split of the decoder's cross attention (other merge order of the softmax partials)
     ckv_b, xs_ws = eng.cross_kv_batched, eng.xs_ws
     eng.cross_kv_batched, eng.xs_ws = False, None
+    # round 5: one more — the encoder backward's input gradients as K-split parts of the 4-wave kernel: four splits for one clip's 2012 rows
+    # (64 output tiles), none for four clips' 8048 (256 tiles): another summation order over K
+    bw4 = eng.enc_bwd_w4
+    eng.enc_bwd_w4 = False
     samples, lay4 = _layout(xl, 4, 60, 150.0)
     # four different clips (same prompt, hence the same layout / label length per clip)
     video = samples["video"]
@@ -490,6 +494,12 @@ def test_c3_batch4_step_equals_four_accumulated_single_clip_steps(xl):
     l4t = eng.forward_backward(video, lay4, backward=True).item()
     check("c3.loss B=4, product thin-LoRA kernel choice vs pinned (rel)", abs(l4t - l4f) / abs(l4f), 1e-4)          # measured 9.4e-6
     check("c3.flat-grad B=4, product thin-LoRA kernel choice vs pinned", relerr(eng.grad, g4f), 1.3e-2)              # measured 6.1e-3
+    # ... and the round-5 K-split parts of the encoder backward (B = 4: one part + the LoRA part per product)
+    eng.enc_bwd_w4 = bw4
+    eng.zero_grad()
+    l4k = eng.forward_backward(video, lay4, backward=True).item()
+    assert l4k == l4t                                                                                                 # (the forward is the same launches)
+    check("c3.flat-grad B=4, encoder input gradients as 4-wave-kernel parts vs the generic tile path", relerr(eng.grad, g4f), 1.3e-2)
     # ... and the round-4 choices for ONE clip (stacked cross K / V, key-split cross attention): the accumulated single-clip steps again
     eng.cross_kv_batched, eng.xs_ws = ckv_b, xs_ws
     eng.zero_grad()

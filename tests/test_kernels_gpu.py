@@ -983,6 +983,14 @@ def test_gemm_k_split_parts_of_the_four_wave_kernel(ops, M, N, K, ks, cfg, ext, 
     assert torch.equal(again[:, :M, :N], parts)
     with pytest.raises(ops.MrblipError):
         ops.gemm_ksplit(a, w, parts, K, ks, ext=(g, at) if ext else None, tile_cfg=2)
+    if f32out:     # the plain reduce: residual + parts in part order
+        res = torch.randn(M, N, device=dev())
+        want = res.clone()
+        for s_ in range(nparts):
+            want = want + parts[s_]
+        out = res.clone()
+        ops.sum_parts(parts, out, residual=out)
+        assert torch.equal(out, want)
 
 
 @pytest.mark.parametrize("D,p,pe", [(2048, 0.1, 0.05), (768, 0.0, 0.05), (256, 0.1, 0.0)])
