@@ -499,7 +499,7 @@ def test_c3_batch4_step_equals_four_accumulated_single_clip_steps(xl):
     eng.zero_grad()
     l4k = eng.forward_backward(video, lay4, backward=True).item()
     assert l4k == l4t                                                                                                 # (the forward is the same launches)
-    check("c3.flat-grad B=4, encoder input gradients as 4-wave-kernel parts vs the generic tile path", relerr(eng.grad, g4f), 1.3e-2)
+    check("c3.flat-grad B=4, encoder input gradients as 4-wave-kernel parts vs the generic tile path", relerr(eng.grad, g4f), 1.3e-2)    # measured 6.3e-3
     # ... and the round-4 choices for ONE clip (stacked cross K / V, key-split cross attention): the accumulated single-clip steps again
     eng.cross_kv_batched, eng.xs_ws = ckv_b, xs_ws
     eng.zero_grad()
