@@ -1189,18 +1189,14 @@ class MrBlipEngine:
         ops.cast_dropout(x0, out_f32=x, drop=self.drop(self.t5["sites"][0], p))
         vt = self.buf("e_vt", (B, H, ops.rup32(dk), ops.rup32(S)), bf16)
         self.enc_t_saved.clear()     # (sticky flags a later backward trusts: reset by every forward)
+        w4q = self._enc_qkv_w4_ok(M)
         for i, L in enumerate(self.t5["enc"]):
-            xn = self.buf(f"e{i}_xn", (M, pad64(d)), bf16)
-            u = self.buf(f"e{i}_u_qkv", (M, 64), bf16)
             qkv = self.buf(f"e{i}_qkv", (M, 3 * inner), bf16, zero=False)
-            # (round 4: the projection's epilogue writes V^T for this layer's attention and Q^T / K^T for its backward)
-            t_ok = self.tout_ok(dk, B, S)
-            qt_i = self.buf(f"e{i}_qt", (B, H, 64, ops.rup32(S)), bf16) if (t_ok and want_grad) else None
-            kt_i = self.buf(f"e{i}_kt", (B, H, 64, ops.rup32(S)), bf16) if (t_ok and want_grad) else None
-            if self._enc_qkv_w4_ok(M):
-                # Round 5 (opt-in, MRB_ENC_QKV_W4): the projection through the hand-pipelined 4-wave kernel, which has no K extension —
+            vt_i = vt
+            if w4q:
+                # Round 5 (MRB_ENC_QKV_W4): the projection through the hand-pipelined 4-wave kernel, which has no K extension —
                 # [xn | u] x [W | B]^T is ONE plain product over K + 64 (csrc/gemm.hip gemm_w4_kernel; tools/qkv_tile_probe.py: 50-54 us
-                # against 80 us for the 16-wave tile).  u by its own thin launch, V^T by a transpose launch, Q^T / K^T in the backward.
+                # against 80 us for the 16-wave tile).  u by its own thin launch, the transposed copies by a transpose launch.
                 g = L["qkv"]
                 xnu = self.buf(f"e{i}_xnu", (M, g.K + 64), bf16)
                 xn, u = xnu[:, :g.K], xnu[:, g.K:]
@@ -1209,7 +1205,20 @@ class MrBlipEngine:
                 self.lora_thin(xn, g.acat, u, g.K, drop=self.drop(g.site, c.lora_dropout))
                 ops.gemm(xnu, self.enc_qkv_wc[i], qkv, tile_cfg=self.enc_qkv_w4, K=g.K + 64)
                 t_done = False
+                if B == 1 and want_grad and dk == 64 and self.enc_qkv_t3:
+                    # Q^T, K^T (for the backward) and V^T in ONE transpose launch over the 3 H "heads" of the fused output: the backward
+                    # then needs no side-stream transposes, no hand-over record and no wait in front of its attention kernels
+                    qkvt = self.buf(f"e{i}_qkvt", (1, 3 * H, 64, ops.rup32(S)), bf16)
+                    ops.head_transpose(self.v4(qkv, B, S, 3 * H, dk, 0), out=qkvt)
+                    self.ws[f"e{i}_qt"], self.ws[f"e{i}_kt"], vt_i = qkvt[:, :H], qkvt[:, H:2 * H], qkvt[:, 2 * H:]
+                    t_done = True
             else:
+                xn = self.buf(f"e{i}_xn", (M, pad64(d)), bf16)
+                u = self.buf(f"e{i}_u_qkv", (M, 64), bf16)
+                # (round 4: the projection's epilogue writes V^T for this layer's attention and Q^T / K^T for its backward)
+                t_ok = self.tout_ok(dk, B, S)
+                qt_i = self.buf(f"e{i}_qt", (B, H, 64, ops.rup32(S)), bf16) if (t_ok and want_grad) else None
+                kt_i = self.buf(f"e{i}_kt", (B, H, 64, ops.rup32(S)), bf16) if (t_ok and want_grad) else None
                 t_done = self.norm_lg_fwd(x, L["ln0"], L["qkv"], xn, u, qkv, tile_cfg=_ENC_FWD_CFG[0], tout=(qt_i, kt_i, vt) if t_ok else None, t_rows=S,
                                           prefetch=self.enc_pf([L["o"], L["wi"]] if self.enc_pf_plan == 0 else [L["o"]], M))
             self.enc_t_saved[i] = bool(t_done) and want_grad
@@ -1220,7 +1229,7 @@ class MrBlipEngine:
             lse = self.buf(f"e{i}_lse", (B, H, ops.rup32(S)), f32)
             adrop = self.drop(L["sites"][0], p)
             dbits = self.buf(f"e{i}_dbits", ops.drop_bits_shape(B, H, S, S), torch.int32, zero=False) if adrop is not None else None
-            ops.attention_fwd(q4, k4, vt, self.v4(o, B, S, H, dk), lse, scale=1.0, bias_lut=self.lut_enc, kmask=kmask, drop=adrop, drop_bits=dbits)
+            ops.attention_fwd(q4, k4, vt_i, self.v4(o, B, S, H, dk), lse, scale=1.0, bias_lut=self.lut_enc, kmask=kmask, drop=adrop, drop_bits=dbits)
             uo = self.buf(f"e{i}_u_o", (M, 64), bf16)
             xm = self.buf(f"e{i}_xm", (M, d), f32, zero=False)
             self.lg_fwd(L["o"], o, uo, xm, residual=x, drop=self.drop(L["sites"][1], p), tile_cfg=_ENC_FWD_CFG[1],
@@ -1251,6 +1260,10 @@ class MrBlipEngine:
     # norm + thin + GEMM + V^T transpose = 70 us against 96 (profiles/r05_layer_timeline_w4qkv.txt), 67.90 vs 68.18 ms per step.
     enc_qkv_w4 = int(os.environ.get("MRB_ENC_QKV_W4", "14"))
     enc_qkv_wc = None
+    # 1: one clip's Q^T / K^T / V^T from ONE transpose launch of the forward instead of V^T there and Q^T / K^T on the backward's side stream
+    # (no hand-over record, no wait in front of the attention backward).  Measured same box: 65.70 / 65.69 vs 65.49 / 65.65 ms — the forward
+    # runs with the chip to itself and pays its +8 us per layer 1:1, the backward's bubbles are absorbed by the look-ahead: off.
+    enc_qkv_t3 = os.environ.get("MRB_ENC_QKV_T3", "0") == "1"
 
     # Round 5: the encoder backward's input-gradient GEMMs on the 4-wave kernel (K-split where the output has too few tiles): wo 83.5 -> 44 us,
     # wi 146.5 -> 79 us, qkv 88 -> 53 us per layer stand-alone (tools/bwd_w4_probe.py).  MRB_ENC_BWD_W4=0: the generic tile with its

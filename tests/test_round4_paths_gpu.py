@@ -150,6 +150,17 @@ def test_encoder_qkv_through_the_four_wave_kernel_equals_the_generic_tile_path()
         torch.cuda.synchronize()
         g0 = eng.t5["enc"][0]["qkv"]
         assert torch.equal(eng.enc_qkv_wc[0, :, eng.cfg.d_model:], g0.wext) and torch.equal(eng.enc_qkv_wc[0, :, :g0.K], g0.W[:, :g0.K])
+    # one clip, the three transposed copies from ONE launch of the forward (enc_qkv_t3; measured, not the default)
+    l3, g3, eng, _ = _step(dict(enc_qkv_w4=14, enc_qkv_t3=True))
+    assert eng.enc_t_saved[0] and eng.ws["e0_kt"].shape[1] == eng.cfg.t5_heads
+    l, g, eng, _ = _step(dict(enc_qkv_w4=14))
+    assert l3 == l and relerr(g3, g) < 1e-6                     # the same bits reach the same kernels (fp32 atomics in the LayerNorm weight gradients: 1e-7)
+    # several clips: V^T by its own launch, Q^T / K^T by the backward's side stream
+    b2_l, b2_g, _, _ = _step(dict(enc_qkv_w4=0), B=2, steps=1)
+    l, g, eng, _ = _step(dict(enc_qkv_w4=14), B=2, steps=1)
+    assert not eng.enc_t_saved[0]
+    check("encoder qkv via the 4-wave kernel, 2 clips vs the generic tile path: loss (rel)", abs(l[0] - b2_l[0]) / abs(b2_l[0]), 2e-4)
+    check("encoder qkv via the 4-wave kernel, 2 clips vs the generic tile path: flat gradient", relerr(g, b2_g), 1e-2)
 
 
 def test_encoder_input_gradients_through_the_k_split_four_wave_kernel_equal_the_generic_tile_path():
