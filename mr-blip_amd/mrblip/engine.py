@@ -1905,8 +1905,11 @@ class MrBlipEngine:
         F_ = Bv * T
         Tv = (c.img // c.patch) ** 2 + 1
         xv = self._take_prefetched_vit(video)
+        head_next, self._head_next = getattr(self, "_head_next", None), None
         if xv is None:
             xv = self.vit_forward(video.reshape(F_, 3, c.img, c.img), slot=self._vit_slot)
+        elif head_next is not None:
+            self.prefetch_vit_head(head_next)     # (this step runs no ViT kernel of its own: the ViT workspaces are free)
         img = self.buf("img", (F_ * Tv, pad64(c.vit_dim)), bf16)
         ops.layernorm_fwd(xv, self.lnv_w, self.lnv_b, self.ln_vision_eps, out_bf16=img)
         qb = self.qformer_forward(img, F_)
@@ -1936,9 +1939,20 @@ class MrBlipEngine:
     def _video_key(video: torch.Tensor):
         return (video.data_ptr(), tuple(video.shape), video._version)
 
+    # Round 5: a HEAD leg of the look-ahead.  The step starts with ln_vision + Q-Former forward + t5_proj of the clip being trained: ~120 launches
+    # of 5-25 us on 1920 rows (2.7 ms of wall clock, 1.8 ms of kernels on a fraction of the CUs) before the encoder forward fills the chip.
+    # The first ``vit_head[0]`` blocks of the NEXT clip's frozen ViT run beside them, leaving ``vit_head[1]`` CUs to those launches; the first
+    # leg proper (prefetch_vit, after the encoder forward has been issued) continues from there.  MRB_VIT_HEAD="blocks:reserve", 0 blocks = off.
+    vit_head = tuple(int(x) for x in os.environ.get("MRB_VIT_HEAD", "2:128").split(":"))
+    _vit_head_done = None
+    vit_head_legs = 0        # (class-wide tally) first legs that continued a head leg
+
     @torch.no_grad()
-    def prefetch_vit(self, next_video: torch.Tensor):
+    def prefetch_vit_head(self, next_video: torch.Tensor):
         c = self.cfg
+        nh = min(int(self.vit_head[0]), c.vit_depth - 1)
+        if nh <= 0 or self._vit_ready is not None:
+            return
         if self._vit_stream is None:
             self._vit_stream = torch.cuda.Stream(device=self.dev)
         start = torch.cuda.Event()
@@ -1947,10 +1961,29 @@ class MrBlipEngine:
         with torch.cuda.stream(self._vit_stream):
             self._vit_stream.wait_event(start)
             F_ = next_video.shape[0] * next_video.shape[1]
+            with ops.gemm_cu_reserve(int(self.vit_head[1])):
+                self.vit_forward(next_video.reshape(F_, 3, c.img, c.img), slot=slot, blocks=(0, nh))
+        self._vit_head_done = (self._video_key(next_video), slot, nh)
+
+    @torch.no_grad()
+    def prefetch_vit(self, next_video: torch.Tensor):
+        c = self.cfg
+        if self._vit_stream is None:
+            self._vit_stream = torch.cuda.Stream(device=self.dev)
+        start = torch.cuda.Event()
+        start.record()
+        slot = 1 - self._vit_slot
+        head, self._vit_head_done = self._vit_head_done, None
+        with torch.cuda.stream(self._vit_stream):
+            self._vit_stream.wait_event(start)
+            F_ = next_video.shape[0] * next_video.shape[1]
             nb = c.vit_depth if self.vit_lookahead_blocks is None else max(1, min(c.vit_depth, int(self.vit_lookahead_blocks)))
             nb = max(1, nb - self._tail_blocks_for(F_))
             frames = next_video.reshape(F_, 3, c.img, c.img)
             b0 = 0
+            if head is not None and head[0] == self._video_key(next_video) and head[1] == slot and head[2] < nb:
+                b0 = head[2]      # (the head leg ran blocks 0 .. b0-1 into this slot, on this stream)
+                MrBlipEngine.vit_head_legs += 1
             for upto, reserve in self._reserve_schedule_for(F_):   # (first-leg blocks < upto run with `reserve` CUs left to the other streams)
                 b1 = min(nb, upto)
                 if b1 > b0:
@@ -2062,6 +2095,7 @@ class MrBlipEngine:
             nf = next_video.shape[0] * next_video.shape[1] if next_video is not None else 0
             ops.dec_proj_config(self._reserve_schedule_for(nf)[-1][1] if next_video is not None else 0)
         self._mark("start")
+        self._head_next = next_video if (backward and not sharded) else None
         fr, img, xv, qb = self.frames_forward(video)
         self._mark("frames_forward (ViT + ln_vision + Q-Former + t5_proj)")
         dev = self.dev

@@ -253,8 +253,11 @@ def test_vit_lookahead_is_transparent():
         torch.cuda.synchronize()
         return losses, eng.flat.clone()
 
+    from mrblip.engine import MrBlipEngine
     la, pa = run(False)
+    legs0 = MrBlipEngine.vit_head_legs
     lb, pb = run(True)
+    assert MrBlipEngine.vit_head_legs > legs0      # round 5: the head leg beside the Q-Former forward ran and was continued
     assert la[0] != la[1]  # the clips really differ
     for a, b in zip(la, lb):
         assert abs(a - b) < 2e-4 * abs(a), (la, lb)
