@@ -2240,7 +2240,7 @@ extern "C" int mrblip_gemm_ksplit(const void* A, long long lda, const void* W, l
                                   long long ldwext, int M, int N, int K, void* out, long long ldo, long long part_stride, int out_f32, int k_splits,
                                   int tile_cfg, hipStream_t stream) {
   const int cfg = tile_cfg & 0xff;
-  MRB_REQUIRE(cfg == 13 || cfg == 14, "gemm_ksplit: tile_cfg 13 (256x256) or 14 (256x192)");
+  MRB_REQUIRE(cfg == 13 || cfg == 14 || cfg == 22, "gemm_ksplit: tile_cfg 13 (256x256), 14 (256x192) or 22 (256x128)");
   MRB_REQUIRE(M > 0 && N > 0 && (N % 8) == 0 && k_splits >= 1 && k_splits <= 16 && K > 0 && (K % (64 * k_splits)) == 0,
               "gemm_ksplit: need M, N > 0, N %% 8 == 0 and K %% (64 k_splits) == 0 (M=%d N=%d K=%d k_splits=%d)", M, N, K, k_splits);
   MRB_REQUIRE((lda % 8) == 0 && (ldw % 8) == 0 && (ldo % (out_f32 ? 4 : 8)) == 0 && (part_stride % 8) == 0, "gemm_ksplit: leading dims must keep 16-B alignment");
@@ -2259,7 +2259,7 @@ extern "C" int mrblip_gemm_ksplit(const void* A, long long lda, const void* W, l
   a.out = out; a.lda = lda; a.ldw = ldw; a.ldaext = ldaext; a.ldwext = ldwext; a.ldo = ldo;
   a.M = M; a.N = N; a.K = K; a.k_splits = k_splits; a.part_stride = part_stride;
   a.drop.inv_keep = a.ext_drop.inv_keep = a.a_drop.inv_keep = a.th_drop.inv_keep = 1.0f;
-  const int bn = cfg == 13 ? 256 : 192;
+  const int bn = cfg == 13 ? 256 : cfg == 14 ? 192 : 128;
   a.tiles_m = (M + 255) / 256;
   a.tiles_n = (N + bn - 1) / bn;
   const int stage = (256 + bn) * 128, slab = 4 * 32 * (bn / 2 * 4 + 16);
@@ -2274,8 +2274,8 @@ extern "C" int mrblip_gemm_ksplit(const void* A, long long lda, const void* W, l
   const int reserve = ((tile_cfg >> 8) & 0x1ff) ? ((tile_cfg >> 8) & 0x1ff) / 8 * 8 : g_cu_reserve;
   const int cus = ncu - reserve > 8 ? ncu - reserve : 8;
   const int grid = units < cus ? (units + 7) / 8 * 8 : cus;
-  const int variant = (cfg == 14 ? 2 : 0) | (out_f32 ? 1 : 0);
-  static bool attr_set[4] = {};
+  const int variant = (cfg == 14 ? 2 : cfg == 22 ? 4 : 0) | (out_f32 ? 1 : 0);
+  static bool attr_set[6] = {};
 #define MRB_W4S_LAUNCH(V, F32, TN_)                                                                                                \
   case V: {                                                                                                                        \
     auto k = gemm_w4_kernel<F32, 0, false, TN_, false, false, true>;                                                               \
@@ -2294,6 +2294,8 @@ extern "C" int mrblip_gemm_ksplit(const void* A, long long lda, const void* W, l
     MRB_W4S_LAUNCH(1, true, 4)
     MRB_W4S_LAUNCH(2, false, 3)
     MRB_W4S_LAUNCH(3, true, 3)
+    MRB_W4S_LAUNCH(4, false, 2)
+    MRB_W4S_LAUNCH(5, true, 2)
   }
 #undef MRB_W4S_LAUNCH
   return mrblip_check_launch("gemm_ksplit");

@@ -2093,7 +2093,7 @@ class MrBlipEngine:
         # measured: 256 blocks beside a ViT that holds 192 CUs cost +0.4 ms per step, 64 blocks -0.3 ms); 0 = one block per CU
         if self.dec_grid_follows_reserve:
             nf = next_video.shape[0] * next_video.shape[1] if next_video is not None else 0
-            ops.dec_proj_config(self._reserve_schedule_for(nf)[-1][1] if next_video is not None else 0)
+            ops.dec_proj_config(self._reserve_schedule_for(nf)[0][1] if next_video is not None else 0)   # (the first leg's first segment runs beside the decoder)
         self._mark("start")
         self._head_next = next_video if (backward and not sharded) else None
         fr, img, xv, qb = self.frames_forward(video)

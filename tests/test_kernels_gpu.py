@@ -953,7 +953,8 @@ def test_rmsnorm_bwd_with_fused_operand_cast(ops, D, p):
 # ---- round 5: K-split form of the 4-wave kernel and the consumers that add its parts -------------------------------------------------
 @pytest.mark.parametrize("f32out", [True, False])
 @pytest.mark.parametrize("M,N,K,ks,cfg,ext", [(2012, 2048, 2560, 4, 13, True), (1312, 256, 768, 6, 14, True), (300, 264, 128, 2, 13, False),
-                                               (2012, 1024, 1024, 1, 14, True), (513, 520, 192, 3, 13, True), (257, 8, 64, 1, 13, True)])
+                                               (2012, 1024, 1024, 1, 14, True), (513, 520, 192, 3, 13, True), (257, 8, 64, 1, 13, True),
+                                               (517, 264, 384, 3, 22, True), (2012, 2048, 1024, 2, 22, False)])
 def test_gemm_k_split_parts_of_the_four_wave_kernel(ops, M, N, K, ks, cfg, ext, f32out):
     """mrblip_gemm_ksplit: part s = A[:, K range s] W[:, K range s]^T, the K extension's product as the last part — against fp32 matmuls of
     the bf16 operands (fp32 parts: accumulation order only, 2e-6 measured; bf16 parts: one rounding); rows beyond M and columns beyond N of

@@ -1,11 +1,7 @@
-run() { env $1 timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$1', d['ms_per_step'])" >> gpurun_out/t29.log 2>&1; }
+#!/bin/bash
+# same-box sweeps of step-level knobs: bash tools/r05_sweep.sh "ENV=VAL ENV2=VAL" "..." -> gpurun_out/sweep.log (one bench line each, default first and last)
+cd "$(dirname "$0")/.."
+run() { env $1 timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$1', d['ms_per_step'])" >> gpurun_out/sweep.log 2>&1; }
 run A=1
-run MRB_LORA_THIN_ROWS=8
-run MRB_VIT_RESERVE=48
-run MRB_VIT_RESERVE=80
-run A=1
-run MRB_GRAD_SIDE=0
-run MRB_CKV_BWD_CHUNKS=12,8,4
-run MRB_CKV_BWD_CHUNKS=8,8,6,2
-run MRB_DEC_GRID_AUTO=0
+for cfg in "$@"; do run "$cfg"; done
 run A=1
