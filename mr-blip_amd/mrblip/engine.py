@@ -1201,8 +1201,11 @@ class MrBlipEngine:
                 xnu = self.buf(f"e{i}_xnu", (M, g.K + 64), bf16)
                 xn, u = xnu[:, :g.K], xnu[:, g.K:]
                 self.ws[f"e{i}_xn"], self.ws[f"e{i}_u_qkv"] = xn, u
-                ops.rmsnorm_fwd(x, L["ln0"], c.t5_eps, out_bf16=xn)
-                self.lora_thin(xn, g.acat, u, g.K, drop=self.drop(g.site, c.lora_dropout))
+                if self.enc_qkv_fuse_norm:
+                    ops.rmsnorm_lora_fwd(x, L["ln0"], c.t5_eps, xn, g.acat, u, drop=self.drop(g.site, c.lora_dropout))
+                else:
+                    ops.rmsnorm_fwd(x, L["ln0"], c.t5_eps, out_bf16=xn)
+                    self.lora_thin(xn, g.acat, u, g.K, drop=self.drop(g.site, c.lora_dropout))
                 ops.gemm(xnu, self.enc_qkv_wc[i], qkv, tile_cfg=self.enc_qkv_w4, K=g.K + 64)
                 t_done = False
                 if B == 1 and want_grad and dk == 64 and self.enc_qkv_t3:
@@ -1260,6 +1263,7 @@ class MrBlipEngine:
     # norm + thin + GEMM + V^T transpose = 70 us against 96 (profiles/r05_layer_timeline_w4qkv.txt), 67.90 vs 68.18 ms per step.
     enc_qkv_w4 = int(os.environ.get("MRB_ENC_QKV_W4", "14"))
     enc_qkv_wc = None
+    enc_qkv_fuse_norm = os.environ.get("MRB_ENC_QKV_FUSE_NORM", "0") == "1"   # RMSNorm + LoRA down product in one launch (rmsnorm_lora_fwd) instead of norm + thin
     # 1: one clip's Q^T / K^T / V^T from ONE transpose launch of the forward instead of V^T there and Q^T / K^T on the backward's side stream
     # (no hand-over record, no wait in front of the attention backward).  Measured same box: 65.70 / 65.69 vs 65.49 / 65.65 ms — the forward
     # runs with the chip to itself and pays its +8 us per layer 1:1, the backward's bubbles are absorbed by the look-ahead: off.
