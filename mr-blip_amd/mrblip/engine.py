@@ -1951,10 +1951,17 @@ class MrBlipEngine:
     _vit_head_done = None
     vit_head_legs = 0        # (class-wide tally) first legs that continued a head leg
 
+    def _first_leg_blocks(self, frames: int) -> int:
+        """ViT blocks the look-ahead runs before its tail leg (prefetch_vit_tail runs the rest beside the Q-Former backward)"""
+        c = self.cfg
+        nb = c.vit_depth if self.vit_lookahead_blocks is None else max(1, min(c.vit_depth, int(self.vit_lookahead_blocks)))
+        return max(1, nb - self._tail_blocks_for(frames))
+
     @torch.no_grad()
     def prefetch_vit_head(self, next_video: torch.Tensor):
         c = self.cfg
-        nh = min(int(self.vit_head[0]), c.vit_depth - 1)
+        F_ = next_video.shape[0] * next_video.shape[1]
+        nh = min(int(self.vit_head[0]), self._first_leg_blocks(F_) - 1)     # (the first leg must have something left to continue with)
         if nh <= 0 or self._vit_ready is not None:
             return
         if self._vit_stream is None:
@@ -1964,7 +1971,6 @@ class MrBlipEngine:
         slot = 1 - self._vit_slot
         with torch.cuda.stream(self._vit_stream):
             self._vit_stream.wait_event(start)
-            F_ = next_video.shape[0] * next_video.shape[1]
             with ops.gemm_cu_reserve(int(self.vit_head[1])):
                 self.vit_forward(next_video.reshape(F_, 3, c.img, c.img), slot=slot, blocks=(0, nh))
         self._vit_head_done = (self._video_key(next_video), slot, nh)
@@ -1981,8 +1987,7 @@ class MrBlipEngine:
         with torch.cuda.stream(self._vit_stream):
             self._vit_stream.wait_event(start)
             F_ = next_video.shape[0] * next_video.shape[1]
-            nb = c.vit_depth if self.vit_lookahead_blocks is None else max(1, min(c.vit_depth, int(self.vit_lookahead_blocks)))
-            nb = max(1, nb - self._tail_blocks_for(F_))
+            nb = self._first_leg_blocks(F_)
             frames = next_video.reshape(F_, 3, c.img, c.img)
             b0 = 0
             if head is not None and head[0] == self._video_key(next_video) and head[1] == slot and head[2] < nb:

@@ -244,6 +244,7 @@ def test_vit_lookahead_is_transparent():
     def run(lookahead):
         eng = _engine(_peft_sd(golden_state_dict(g)))
         eng.training = True
+        eng.vit_tail_blocks, eng._vit_tail_fixed = 0, True      # (a 2-block ViT: the head leg runs block 0, the first leg block 1, no tail leg)
         losses = []
         for i in range(3):
             eng.zero_grad()
