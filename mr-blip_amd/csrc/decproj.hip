@@ -331,6 +331,9 @@ extern "C" int mrblip_dec_proj_config(int n_blocks, int version) {
   return prev;
 }
 
+#ifndef DP2_UB_LONGK
+#define DP2_UB_LONGK 4   // k-steps per batch of the K > 2048 forms (input rows streamed with the weights)
+#endif
 template <int MODE, int XM, int UB>   // XM: 0 = input rows streamed with the weights (K > 2048), 1 = bf16 rows copied into LDS, 2 = RMSNorm of fp32 rows into LDS
 __global__ __launch_bounds__(512) void dec_proj2_kernel(const DecProjArgs p, const int tpb) {
   constexpr int NTW = MODE == 2 ? 2 : 1, NA = 2;
@@ -743,8 +746,8 @@ extern "C" int mrblip_dec_proj(const float* x32, long long ldx32, const float* g
   }
     const int xm = !xl ? 0 : (x32 ? 2 : 1);
     if (mode == 2) { if (xm == 2) MRB_DP2_LAUNCH(0, 2, 2, 4) else if (xm == 1) MRB_DP2_LAUNCH(1, 2, 1, 4) else MRB_DP2_LAUNCH(2, 2, 0, 4) }
-    else if (mode == 0) { if (xm == 2) MRB_DP2_LAUNCH(3, 0, 2, 8) else if (xm == 1) MRB_DP2_LAUNCH(4, 0, 1, 8) else MRB_DP2_LAUNCH(5, 0, 0, 4) }
-    else { if (xm == 2) MRB_DP2_LAUNCH(6, 1, 2, 8) else if (xm == 1) MRB_DP2_LAUNCH(7, 1, 1, 8) else MRB_DP2_LAUNCH(8, 1, 0, 4) }
+    else if (mode == 0) { if (xm == 2) MRB_DP2_LAUNCH(3, 0, 2, 8) else if (xm == 1) MRB_DP2_LAUNCH(4, 0, 1, 8) else MRB_DP2_LAUNCH(5, 0, 0, DP2_UB_LONGK) }
+    else { if (xm == 2) MRB_DP2_LAUNCH(6, 1, 2, 8) else if (xm == 1) MRB_DP2_LAUNCH(7, 1, 1, 8) else MRB_DP2_LAUNCH(8, 1, 0, DP2_UB_LONGK) }
 #undef MRB_DP2_LAUNCH
     return mrblip_check_launch("dec_proj");
   }
