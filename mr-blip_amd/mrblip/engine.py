@@ -1273,6 +1273,10 @@ class MrBlipEngine:
     # wi 146.5 -> 79 us, qkv 88 -> 53 us per layer stand-alone (tools/bwd_w4_probe.py).  MRB_ENC_BWD_W4=0: the generic tile with its
     # masked K extension, roles and all (round 4).
     enc_bwd_w4 = os.environ.get("MRB_ENC_BWD_W4", "1") == "1"
+    # 1: ONE side-stream hand-over per encoder layer of the backward, at the point where the K^T / Q^T job must leave anyway (behind the wi
+    # product): the weight-gradient launch then holds wo, wi of the layer and o, qkv of the layer above and runs beside the o product and
+    # the attention backward instead of beside the next layer's thin / wo launches.  0: a second hand-over at the end of the layer.
+    enc_grads_at_wi = os.environ.get("MRB_ENC_GRADS_AT_WI", "0") == "1"
 
     def _enc_bwd_w4_ok(self, M: int) -> bool:
         c = self.cfg
@@ -1334,6 +1338,8 @@ class MrBlipEngine:
         # layer below, three times), so the main stream never waits for a side-stream launch that was issued a moment ago (round 4: four
         # launches, two hand-overs and one join per layer — the join at the top of a layer waited for the qkv group's launch).
         batch = self.lora_grads_batch and self.grad_side_stream_enabled and not c.lora_mask_per_adapter
+        at_wi = batch and self.enc_grads_at_wi
+        carry: list = []
         dyb_pair = (self.buf("eb_dyb", (M, pad64(d)), bf16), self.buf("eb_dyb_alt", (M, pad64(d)), bf16)) + ((self.buf("eb_dyb_alt2", (M, pad64(d)), bf16),) if batch else ())
         nb = 2 if batch else 1
         dyb2_s = [self.buf("eb_dyb2" + "_alt" * k, (M, pad64(d)), bf16) for k in range(nb)]
@@ -1368,7 +1374,9 @@ class MrBlipEngine:
             gb, gb2, gb3, gb4 = g_s[par]
             layer_jobs: Optional[list] = [] if batch else None
             if batch:
-                ev_old = grads_done.pop(i + 2, None)     # the launch that read this parity's buffers two layers ago
+                # the launch that read this parity's buffers two layers ago (at_wi: the launch of the layer above, which holds the o / qkv
+                # jobs of the layer two above and was handed over a whole layer ago)
+                ev_old = grads_done.pop(i + 1 if at_wi else i + 2, None)
                 if ev_old is not None:
                     torch.cuda.current_stream().wait_event(ev_old)
             else:
@@ -1407,7 +1415,21 @@ class MrBlipEngine:
                 ops.gated_gelu_bwd(dyact, self.ws[f"e{i}_h"], dh, drop=self.drop(L["sites"][2], p))
                 self.lg_bwd(L["wi"], dh, self.ws[f"e{i}_xn2"], self.ws[f"e{i}_u_wi"], gb2, dxn, side=True, tile_cfg=_ENC_BWD_CFG[1],
                             prefetch=self.enc_pf_bwd([L["o"]], M), collect=layer_jobs)
-            if batch and kq_ready is not None:
+            if at_wi:
+                # ONE hand-over per layer: behind the K^T / Q^T job go the weight-gradient pairs that are ready here — wo, wi of this layer,
+                # o, qkv of the layer above — and run beside the o product and the attention backward
+                jobs_now = carry + layer_jobs
+                layer_jobs = []
+                if jobs_now:
+                    ev_done = torch.cuda.Event()
+
+                    def grads_job(jobs=jobs_now, ev_done=ev_done):
+                        ops.lora_grads_batched(jobs)
+                        ev_done.record()
+                    self.side_defer(grads_job)
+                    grads_done[i] = ev_done
+                self.side_flush()
+            elif batch and kq_ready is not None:
                 self.side_flush()      # (the K^T / Q^T job queued above must go out here: this layer's attention backward waits for it)
             dxn_wi = dxn_p_wi if w4b else dxn
             ext_wi = dict(ext_drop=self.drop(L["wi"].site, c.lora_dropout), ext_part=True) if w4b else {}
@@ -1445,7 +1467,9 @@ class MrBlipEngine:
                             prefetch=self.enc_pf_bwd([self.t5["enc"][i - 1]["wo"]], M) if i > 0 else None, collect=layer_jobs)
             dxn_qkv = dxn_p_qkv if w4b else dxn
             ext_qkv = dict(ext_drop=self.drop(L["qkv"].site, c.lora_dropout), ext_part=True) if w4b else {}
-            if batch and layer_jobs:   # the layer's four weight-gradient pairs: one launch, one hand-over
+            if at_wi:
+                carry = layer_jobs          # (o, qkv: they leave with the layer below's hand-over)
+            elif batch and layer_jobs:   # the layer's four weight-gradient pairs: one launch, one hand-over
                 ev_done = torch.cuda.Event()
 
                 def grads_job(jobs=layer_jobs, ev_done=ev_done):
@@ -1462,6 +1486,8 @@ class MrBlipEngine:
                 ops.rmsnorm_bwd(dxn_qkv, self.ws[f"e{i}_xin"], L["ln0"], c.t5_eps, other, dx_add=dx, **ext_qkv)
                 dyb_ready = False
             dx, other = other, dx
+        if at_wi and carry:
+            self.side_defer(lambda jobs=carry: ops.lora_grads_batched(jobs))
         self.side_join()
         dinp = self.buf("eb_dinp", (M, d), f32, zero=False)
         ops.cast_dropout(dx, out_f32=dinp, drop=self.drop(self.t5["sites"][0], p))

@@ -174,3 +174,12 @@ def test_encoder_input_gradients_through_the_k_split_four_wave_kernel_equal_the_
     check("encoder input gradients via K-split parts vs the generic tile path: flat gradient", relerr(g, base_g), 1e-2)
     l2, g2, _, _ = _step(dict(enc_bwd_w4=True))
     assert l2 == l and torch.equal(g2, g)          # parts are added in part order: reproducible
+
+
+def test_one_side_stream_hand_over_per_encoder_layer_changes_no_bit():
+    """enc_grads_at_wi: the weight-gradient launch of the encoder backward leaves with the K^T / Q^T job behind the wi product (wo, wi of the
+    layer + o, qkv of the layer above) instead of at the end of the layer — the same jobs in other launches, the same bits."""
+    base_l, base_g, _, lay = _step(dict(enc_bwd_w4=True, enc_qkv_w4=14, enc_grads_at_wi=False))
+    l, g, eng, _ = _step(dict(enc_bwd_w4=True, enc_qkv_w4=14, enc_grads_at_wi=True))
+    assert l == base_l and relerr(g, base_g) < 1e-6      # (fp32 atomics in the LayerNorm weight gradients of the Q-Former: 1e-7)
+    assert torch.equal(g[: eng.n_lora], base_g[: eng.n_lora])
