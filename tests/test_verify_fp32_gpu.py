@@ -165,3 +165,74 @@ def test_finite_differences_of_the_fp32_operand_forward_confirm_the_product_grad
     eng.refresh_trainable()
     del eng
     torch.cuda.empty_cache()
+
+
+def test_finite_differences_confirm_the_lora_gradients_c1():
+    """The same finite-difference check for what the optimizer mostly updates: the LoRA tensors (92 % of the trainable floats), with every
+    adapter of the real-depth C1 model in a NON-ZERO state (N(0, 0.02)).  The verification mode takes the LoRA branch in fp32 from the
+    master tensors (tests/verify_fp32.py), so A and B can be moved: its loss is first pinned to the oracle's fp32 run of the same state,
+    then the product path's dA / dB, projected on their own direction — all LoRA floats, all A, all B, the encoder's, the decoder's
+    adapters — must equal the central difference of that loss.  (peft itself is absent: the LoRA semantics are the oracle's restatement
+    of its published algorithm, blip2_mr.py:182-200; this test shows that the HIP backward differentiates the HIP forward, and that
+    forward equals the restatement.)"""
+    from weights import seeded_state_dict
+    from mrblip import prompt as P
+    from mrblip.engine import EngineConfig, MrBlipEngine, StateDictSource
+    from mrblip.tokenizer import FixtureTokenizer
+    from oracle import mrblip_oracle as O
+    from test_fullsize_gpu import _c1_samples, C1_CFG
+    from test_model_gpu import _peft_sd
+
+    g = load_golden("mr_c1")
+    sd = seeded_state_dict(g["manifest"], wscale=g["strings"]["wscale"], fast=True)
+    sdl = _peft_sd(sd, lora_std=0.02)
+    tok = FixtureTokenizer()
+    repl = P.annoying_replacement_dict(P.find_annoying_numbers(tok, 200)[0])
+    samples = _c1_samples(g)
+    cfg = EngineConfig(d_model=768, d_kv=64, t5_heads=12, d_ff=2048, t5_layers=12, t5_dec_layers=12)
+    eng = MrBlipEngine(cfg, StateDictSource(sdl), torch.device("cuda:0"))
+    eng.training = False
+    eng._verify_src = StateDictSource(sdl)
+    lay = P.build_layout(tok, samples, repl, 32, T=4)
+    video = samples["video"].cuda()
+    with torch.no_grad():
+        ref_loss = float(O.Oracle(sdl, C1_CFG, emu_bf16=False, lora=dict(r=8, alpha=8)).forward_mr(tok, samples, repl)["loss"])
+    l0 = _run(eng, video, lay)[0]
+    check("c1.lora!=0.verify-fp32: loss vs oracle-fp32 (rel)", abs(l0 - ref_loss) / abs(ref_loss), 1e-5)
+    eng.zero_grad()
+    l_prod = eng.forward_backward(video, lay, backward=True).item()
+    torch.cuda.synchronize()
+    n0 = eng.n_lora
+    grad = eng.grad[:n0].double().clone()
+    theta = eng.flat[:n0].clone()
+    is_a = torch.zeros(n0, dtype=torch.bool, device=grad.device)
+    is_enc = torch.zeros(n0, dtype=torch.bool, device=grad.device)
+    for a in eng.adapters:
+        is_a[a.a_off: a.a_off + a.A.numel()] = True
+        if a.name.startswith("encoder."):
+            is_enc[a.a_off: a.a_off + a.A.numel()] = True
+            is_enc[a.bt_off: a.bt_off + a.Bt.numel()] = True
+    assert a.A.data_ptr() == eng.flat.data_ptr() + 4 * a.a_off
+    spans = [("all LoRA tensors", torch.ones_like(is_a)), ("every lora_A", is_a), ("every lora_B", ~is_a), ("encoder adapters", is_enc), ("decoder + lm_head adapters", ~is_enc)]
+
+    def loss_at(delta):
+        eng.flat[:n0].copy_((theta.double() + delta).float())
+        eng.refresh_trainable()
+        return _run(eng, video, lay)[0]
+
+    for name, mask in spans:
+        v = torch.where(mask, grad, torch.zeros_like(grad))
+        nrm = float(v.norm())
+        v /= nrm
+        eps = 0.03 / nrm
+        fd = [(loss_at(e * v) - loss_at(-e * v)) / (2 * e) for e in (eps, eps / 2)]
+        rel = abs(nrm - fd[1]) / abs(fd[1])
+        print(f"finite differences, own direction in {name}: |g_product| = {nrm:.6e}, fd(eps) = {fd[0]:.6e}, fd(eps/2) = {fd[1]:.6e}, rel {rel:.2e} (loss {l0:.5f}, product {l_prod:.5f})")
+        # measured (profiles/r05_finite_difference_c1.txt): all 5.0e-4, lora_A 5.3e-4, lora_B 5.0e-4, encoder 3.7e-4, decoder + lm_head 1.3e-3;
+        # eps vs eps / 2: 0.6-2.2e-4
+        check(f"c1.lora!=0.finite-difference (fp32-operand forward) vs product gradient norm, {name} (rel)", rel, 3e-3 if name.startswith("decoder") else 1.5e-3)
+        check(f"c1.lora!=0.finite-difference convergence eps vs eps/2, {name} (rel)", abs(fd[0] - fd[1]) / abs(fd[1]), 1e-3)
+    eng.flat[:n0].copy_(theta)
+    eng.refresh_trainable()
+    del eng
+    torch.cuda.empty_cache()

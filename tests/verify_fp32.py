@@ -12,7 +12,9 @@ GEMM / norm / elementwise / interleave / CE kernels) is re-run with every GEMM o
   * attention (whose kernels take bf16 q / k / v by construction and have their own fp32 reference tests up to S = 4003) is
     evaluated in fp32 torch on the re-assembled hi + lo operands — the one piece of this mode that is not the product kernel.
 
-Forward / eval mode only, LoRA B = 0 (peft's initial state: the LoRA branch contributes exactly zero), no dropout.
+Forward / eval mode only, no dropout.  LoRA (round 5): the branch is taken in fp32 from the MASTER tensors — u = x (s A)^T on the re-assembled
+fp32 rows, out += u B^T on the GEMM's fp32 result — so the mode also serves engines whose adapters are not in peft's initial B = 0 state
+(the finite-difference checks of the LoRA gradients move A and B).
 Usage:  with Fp32Verify(engine): loss = engine.forward_backward(video, layout, backward=False)
 """
 import contextlib
@@ -114,8 +116,21 @@ class Fp32Verify(contextlib.AbstractContextManager):
         ops.attention_fwd_rowv = self.attention_fwd_rowv
         ops.head_transpose = self.head_transpose
         ops.patchify = self.patchify
-        ops.lora_rows = lambda *a, **k: None      # LoRA B = 0: the branch contributes exactly zero (u buffers stay zero)
-        ops.lora_down = lambda *a, **k: None
+        # LoRA in fp32 from the master tensors: per group the stacked s * A [8 nad, K] and the dense B [N, 8 nad] (adapter j's rows only in ITS
+        # 8 columns), keyed by the operand tensors the engine hands to the launches
+        self.A32, self.B32, self.u32 = {}, {}, {}
+        for grp in eng.groups:
+            if grp.acat is None or not grp.adapters:
+                continue
+            nad = len(grp.adapters)
+            A = torch.cat([a.A.detach().float() * eng.lora_scale for a in grp.adapters])          # [8 nad, K]
+            Bd = torch.zeros(grp.wext.shape[0], 8 * nad, device=eng.dev)
+            for j, a in enumerate(grp.adapters):
+                Bd[a.row0: a.row0 + a.out, 8 * j: 8 * j + 8] = a.Bt.detach().float().t()
+            self.A32[grp.acat.data_ptr()] = A
+            self.B32[grp.wext.data_ptr()] = Bd
+        ops.lora_rows = self.lora_rows
+        ops.lora_down = self.lora_rows
         return self
 
     def __exit__(self, *exc):
@@ -191,13 +206,23 @@ class Fp32Verify(contextlib.AbstractContextManager):
         real = self.saved["ops.gemm"]
         assert drop is None
         if out.dtype == bf16 and out.shape[1] == 64:
-            return out                                   # a LoRA "down" product: B = 0, the branch is exactly zero
+            if w.data_ptr() in self.A32:                 # a LoRA "down" product issued as a skinny GEMM (no dropout)
+                self.lora_rows(a, w, out, K)
+            return out
         wide_out = out.dtype == bf16
         N = w.shape[0]
+        lora = None
+        if aext is not None and aext.data_ptr() in self.u32 and wext.data_ptr() in self.B32:
+            lora = self.u32[aext.data_ptr()] @ self.B32[wext.data_ptr()].t()           # [M, N] fp32: u B^T
         if not wide_out and not gated and act == 0:
-            return real(a, w, out, bias=bias, residual=residual, tile_cfg=0)     # fp32 out: the product kernel as is (longer K)
+            real(a, w, out, bias=bias, residual=residual, tile_cfg=0)     # fp32 out: the product kernel as is (longer K)
+            if lora is not None:
+                out[:, :N] += lora
+            return out
         tmp = torch.empty(a.shape[0], N, device=a.device)
         real(a, w, tmp, bias=bias, residual=residual if not wide_out else None, tile_cfg=0)
+        if lora is not None:
+            tmp += lora
         if gated:
             nh = N // 2
             y = torch.nn.functional.gelu(tmp[:, :nh]) * tmp[:, nh:]
@@ -211,6 +236,17 @@ class Fp32Verify(contextlib.AbstractContextManager):
         else:
             out.copy_(y)
         return out
+
+    def lora_rows(self, x, a, u, K, drop=None, seg=None, init_dst=None, init_src=None):
+        """u = x (s A)^T in fp32 from the master A (kept beside the bf16 u buffer, which stays untouched), x re-assembled from its wide buffer"""
+        assert drop is None
+        A = self.A32.get(a.data_ptr())
+        if A is None:
+            raise KeyError("verification mode: a LoRA down product with an operand that is no group's stacked A")
+        x32 = self.read32(x, int(K)) if x.shape[1] % 3 == 0 and x.shape[1] >= 3 * int(K) else x[:, :int(K)].float()
+        self.u32[u.data_ptr()] = x32 @ A.t()
+        if init_dst is not None:
+            init_dst.copy_(init_src if init_src is not None else torch.zeros_like(init_dst))
 
     def layernorm_fwd(self, x, gamma, beta, eps, out_bf16=None, out_f32=None):
         real = self.saved["ops.layernorm_fwd"]
