@@ -236,3 +236,60 @@ def test_finite_differences_confirm_the_lora_gradients_c1():
     eng.refresh_trainable()
     del eng
     torch.cuda.empty_cache()
+
+
+def test_finite_differences_confirm_the_gradients_at_the_benched_size_c2():
+    """The finite-difference check AT THE BENCHED SIZE (C2: 60 frames, Flan-T5-XL width, 24 + 24 layers, S_enc = 2012, every one of the 433
+    adapters non-zero: the state of tests/golden/mr_c2_lora.npz) — the 4-wave kernel's K-split input gradients, the stacked cross K / V
+    backward, the thin launches above 512 rows, which C1 does not reach.  ~10 minutes of fp32-operand forwards: runs with MRB_FD_C2=1
+    (tools: `MRB_FD_C2=1 python -m pytest tests/test_verify_fp32_gpu.py -k benched_size_c2 -s`; measured: profiles/r05_finite_difference_c2.txt)."""
+    import os
+    if os.environ.get("MRB_FD_C2", "0") != "1":
+        pytest.skip("set MRB_FD_C2=1 (ten minutes of fp32-operand forwards at the benched size)")
+    from util import GOLDEN
+    if not os.path.exists(os.path.join(GOLDEN, "mr_c2_lora.npz")):
+        pytest.skip("tests/golden/mr_c2_lora.npz not generated")
+    from weights import seeded_array
+    from test_fullsize_gpu import _c2_setup
+    gl = load_golden("mr_c2_lora")
+    std = float(gl["strings"]["lora_std"])
+
+    def lora_init(a, gen):
+        base = "t5_model.base_model.model." + a.name
+        a.A.copy_(torch.from_numpy(seeded_array(base + ".lora_A.default.weight", (8, a.in_dim), std=std)))
+        a.Bt.copy_(torch.from_numpy(seeded_array(base + ".lora_B.default.weight", (a.out, 8), std=std)).t())
+
+    eng, src, lay, video, g, T = _c2_setup(lora_init=lora_init)
+    eng._verify_src = src
+    video = video.cuda()
+    l0 = _run(eng, video, lay)[0]
+    ref_loss = float(gl["loss"])
+    print(f"finite differences c2: fp32-operand forward loss {l0:.6f}, oracle-fp32 loss of the same state {ref_loss:.6f}, rel {abs(l0 - ref_loss) / abs(ref_loss):.2e}")
+    check("c2.lora!=0.verify-fp32: loss vs oracle-fp32 (rel)", abs(l0 - ref_loss) / abs(ref_loss), 1e-5)
+    eng.zero_grad()
+    l_prod = eng.forward_backward(video, lay, backward=True).item()
+    torch.cuda.synchronize()
+    assert eng._enc_bwd_w4_ok(lay.S) and "eb_dxn_p_wi" in eng.ws           # the K-split parts were what ran
+    n0 = eng.n_lora
+    grad = eng.grad.double().clone()
+    theta = eng.flat.clone()
+    idx = torch.arange(grad.numel(), device=grad.device)
+
+    def loss_at(delta):
+        eng.flat.copy_((theta.double() + delta).float())
+        eng.refresh_trainable()
+        return _run(eng, video, lay)[0]
+
+    for name, mask, steps in (("all LoRA tensors", idx < n0, 2), ("t5_proj + ln_vision", idx >= n0, 1)):
+        v = torch.where(mask, grad, torch.zeros_like(grad))
+        nrm = float(v.norm())
+        v /= nrm
+        eps = 0.03 / nrm
+        fd = [(loss_at(e * v) - loss_at(-e * v)) / (2 * e) for e in (eps, eps / 2)[:steps]]
+        rel = abs(nrm - fd[-1]) / abs(fd[-1])
+        print(f"finite differences c2, own direction in {name}: |g_product| = {nrm:.6e}, fd = {[f'{x:.6e}' for x in fd]}, rel {rel:.2e} (loss {l0:.5f}, product {l_prod:.5f})")
+        check(f"c2.lora!=0.finite-difference (fp32-operand forward) vs product gradient norm, {name} (rel)", rel, 5e-3)     # measured 2.0e-3 / 1.2e-3
+    eng.flat.copy_(theta)
+    eng.refresh_trainable()
+    del eng
+    torch.cuda.empty_cache()
