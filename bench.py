@@ -485,7 +485,10 @@ def main():
                        "global_batch": global_batch, "batch_per_gpu": B, "frames": wl["T"], "parallelism": f"dp{world}" if shard is None else f"frame-shard{world} (ViT + Q-Former over T/{world} frames per rank, T5 replicated)",
                        "vit_lookahead": not args.no_lookahead,
                        "vary_text": ([l.S for l in layouts] if args.vary_text else False), "vary_video": bool(args.vary_video), "graph_mode": eng.graph_mode, "graph_replays": MrBlipEngine.graph_replays,
-                       "lookahead_hits": MrBlipEngine.vit_prefetch_hits, "lookahead_misses": MrBlipEngine.vit_prefetch_misses},
+                       "lookahead_hits": MrBlipEngine.vit_prefetch_hits, "lookahead_misses": MrBlipEngine.vit_prefetch_misses,
+                       "lookahead_head_legs": MrBlipEngine.vit_head_legs,
+                       "t5_encoder_4wave": {"qkv_forward_tile": int(eng.enc_qkv_w4) if (eng.enc_qkv_wc is not None and B * layout.S >= 1024) else 0,
+                                            "ksplit_input_gradients": bool(eng._enc_bwd_w4_ok(B * layout.S))}},
             "launches_per_step": round(launches, 1),     # C-ABI kernel launches per step (torch-native ones: ~10, profiles/r02_native_in_step.txt)
             "host_enqueue_ms": round(1e3 * min(host_s), 2) if host_s else None,   # host time to enqueue one step onto an idle GPU (untimed extra steps); must stay below ms_per_step
             "workspace_allocations_in_timed_region": [n for n, _ in allocs_timed],
