@@ -330,6 +330,7 @@ def _bias_report(tag, got, want):
     ratio = (got.norm() / want.norm().clamp_min(1e-30)).item()
     cos = (torch.dot(got, want) / (got.norm() * want.norm()).clamp_min(1e-30)).item()
     record(tag + ": |g_hip| / |g_ref| - 1 (abs)", abs(ratio - 1.0), 1e-2)
+    print(f"bias report {tag}: |g_hip| / |g_ref| - 1 = {ratio - 1.0:+.3e}, 1 - cosine = {1.0 - cos:.3e}")
     record(tag + ": 1 - cosine", 1.0 - cos, 1e-3)
     return ratio, cos
 
@@ -395,6 +396,8 @@ def test_c2_benched_size_nonzero_lora_gradients():
         k["r"] += [ga.reshape(-1), gb.reshape(-1)]
         if max(ea, eb) > worst:
             worst, worst_name = max(ea, eb), nm
+        if os.environ.get("MRB_BIAS_DEBUG") and (nm == "lm_head" or nm.endswith("block.23.layer.2.DenseReluDense.wo") or nm.endswith("block.23.layer.1.DenseReluDense.wo")):
+            print(f"bias debug {nm}: dA ratio-1 {float(ha.double().norm() / ga.double().norm()) - 1:+.3e} (err {ea:.2e}), dB ratio-1 {float(hb.double().norm() / gb.double().norm()) - 1:+.3e} (err {eb:.2e})")
     assert oa == gl["lora_dA_sub"].size and ob == gl["lora_dB_sub"].size
     for kind, k in sorted(kinds.items()):
         record(tag + f"worst dA/dB (sub-sampled) of {kind} adapters vs oracle-fp32", k["worst"], 1e-1)
