@@ -2263,7 +2263,10 @@ extern "C" int mrblip_gemm_ksplit(const void* A, long long lda, const void* W, l
   a.tiles_m = (M + 255) / 256;
   a.tiles_n = (N + bn - 1) / bn;
   const int stage = (256 + bn) * 128, slab = 4 * 32 * (bn / 2 * 4 + 16);
-  const int LDS = 2 * stage > stage + slab ? 2 * stage : stage + slab;
+  static int w3s = -1;    // MRB_KSPLIT_W3=1: the 256x256 form with a third W stage (experiment; see cfg 17)
+  if (w3s < 0) { const char* e = getenv("MRB_KSPLIT_W3"); w3s = (e && e[0] == '1') ? 1 : 0; }
+  const bool w3 = w3s == 1 && cfg == 13;
+  const int LDS = w3 ? 2 * stage + 256 * 128 : (2 * stage > stage + slab ? 2 * stage : stage + slab);
   static int ncu = 0;
   if (ncu == 0) {
     int dev = 0;
@@ -2274,11 +2277,11 @@ extern "C" int mrblip_gemm_ksplit(const void* A, long long lda, const void* W, l
   const int reserve = ((tile_cfg >> 8) & 0x1ff) ? ((tile_cfg >> 8) & 0x1ff) / 8 * 8 : g_cu_reserve;
   const int cus = ncu - reserve > 8 ? ncu - reserve : 8;
   const int grid = units < cus ? (units + 7) / 8 * 8 : cus;
-  const int variant = (cfg == 14 ? 2 : cfg == 22 ? 4 : 0) | (out_f32 ? 1 : 0);
-  static bool attr_set[6] = {};
-#define MRB_W4S_LAUNCH(V, F32, TN_)                                                                                                \
+  const int variant = w3 ? 6 + (out_f32 ? 1 : 0) : ((cfg == 14 ? 2 : cfg == 22 ? 4 : 0) | (out_f32 ? 1 : 0));
+  static bool attr_set[8] = {};
+#define MRB_W4S_LAUNCH(V, F32, TN_, ...)                                                                                           \
   case V: {                                                                                                                        \
-    auto k = gemm_w4_kernel<F32, 0, false, TN_, false, false, true>;                                                               \
+    auto k = gemm_w4_kernel<F32, 0, false, TN_, false, ##__VA_ARGS__>;                                                             \
     if (!attr_set[V]) {                                                                                                            \
       if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {                    \
         mrblip_set_error("gemm_ksplit: cannot raise dynamic LDS to %d", LDS);                                                      \
@@ -2290,12 +2293,14 @@ extern "C" int mrblip_gemm_ksplit(const void* A, long long lda, const void* W, l
     break;                                                                                                                         \
   }
   switch (variant) {
-    MRB_W4S_LAUNCH(0, false, 4)
-    MRB_W4S_LAUNCH(1, true, 4)
-    MRB_W4S_LAUNCH(2, false, 3)
-    MRB_W4S_LAUNCH(3, true, 3)
-    MRB_W4S_LAUNCH(4, false, 2)
-    MRB_W4S_LAUNCH(5, true, 2)
+    MRB_W4S_LAUNCH(0, false, 4, false, true)
+    MRB_W4S_LAUNCH(1, true, 4, false, true)
+    MRB_W4S_LAUNCH(2, false, 3, false, true)
+    MRB_W4S_LAUNCH(3, true, 3, false, true)
+    MRB_W4S_LAUNCH(4, false, 2, false, true)
+    MRB_W4S_LAUNCH(5, true, 2, false, true)
+    MRB_W4S_LAUNCH(6, false, 4, true, true)
+    MRB_W4S_LAUNCH(7, true, 4, true, true)
   }
 #undef MRB_W4S_LAUNCH
   return mrblip_check_launch("gemm_ksplit");
