@@ -63,7 +63,16 @@ int mrblip_layernorm_fwd_f16(const float* x, long long ldx, const float* gamma, 
                              void* out_f16, long long ldob, float* out_f32, long long ldof, mrblip_stream_t stream);
 int mrblip_rmsnorm_fwd(const float* x, long long ldx, const float* weight, int M, int D, float eps, void* out_bf16,
                        long long ldob, float* out_f32, long long ldof, mrblip_stream_t stream);
-/* dx = dx_add + dLN(dy); optional dgamma/dbeta += (fp32 atomics) */
+/* Workspace of the ORDERED reductions (round 6).  mrblip_cross_entropy (row terms), mrblip_colsum (row-block partial sums) and
+ * mrblip_layernorm_bwd with dgamma (block partial sums) add their partials in a FIXED order — the block that draws the last ticket does it —
+ * so a train step is bit-reproducible.  Scratch and tickets are the CALLER's: register, per calling thread, `bytes` >=
+ * mrblip_reduce_workspace_bytes() of ZEROED, 16-B aligned device memory (the kernels return the tickets to zero); the registration stays
+ * until replaced (ws = NULL removes it).  Launches that share one workspace must be stream-ordered — give every stream its own
+ * (mrblip/ops.py keeps one per (device, stream)).  Without a workspace the three kernels fall back to fp32 atomics (arrival order).
+ * The library itself keeps no device-side or process-global mutable state. */
+int mrblip_set_reduce_workspace(void* ws, long long bytes);
+long long mrblip_reduce_workspace_bytes(void);
+/* dx = dx_add + dLN(dy); optional dgamma/dbeta += the row sums (ordered through the reduce workspace, else fp32 atomics) */
 int mrblip_layernorm_bwd(const float* dy, long long lddy, const float* x, long long ldx, const float* gamma, int M, int D,
                          float eps, const float* dx_add, long long ldadd, float* dx, long long lddx, float* dgamma,
                          float* dbeta, mrblip_stream_t stream);
@@ -137,9 +146,14 @@ int mrblip_cast_dropout(const float* x, long long ldx, void* out_bf16, long long
 int mrblip_gelu_bwd(const void* dy, const void* h, void* dh, long long n, mrblip_stream_t stream);
 int mrblip_gated_gelu_bwd(const void* dy, long long lddy, const void* h, long long ldh, void* dh, long long lddh, int M, int Nh,
                           const uint32_t* seed_ptr, uint32_t site, float p, mrblip_stream_t stream);
-/* CrossEntropyLoss(ignore_index=-100, mean) + dlogits (modeling_t5.py:1873-1877) */
+/* CrossEntropyLoss(ignore_index=-100, mean) + dlogits (modeling_t5.py:1873-1877); *loss += the row terms in ROW order through the reduce
+ * workspace (mrblip_set_reduce_workspace; R <= 4096), else by fp32 atomics */
 int mrblip_cross_entropy(const float* logits, long long ldl, const int* labels, int R, int V, float inv_count, float* loss,
                          void* dlogits_bf16, long long ldd, mrblip_stream_t stream);
+/* the same with the count of valid rows in DEVICE memory (inv_count = 1 / max(*n_valid, 1), fp32): a captured graph (hipGraph) of the step
+ * then serves batches with any number of valid label tokens */
+int mrblip_cross_entropy_nvalid(const float* logits, long long ldl, const int* labels, int R, int V, const int* n_valid, float* loss,
+                                void* dlogits_bf16, long long ldd, mrblip_stream_t stream);
 /* torch.optim.AdamW step on a flat segment; hyper = {lr, 1/bias_corr1, 1/sqrt(bias_corr2), grad_scale} on device
  * (runner_base.py:102-132, moment_retrieval.py:221-233) */
 int mrblip_adamw(float* p, const float* g, float* m, float* v, long long n, const float* hyper, float beta1, float beta2, float eps,
@@ -180,7 +194,8 @@ int mrblip_lora_dx_add(void* dx, long long lddx, int dx_f32, const void* G, long
                        const uint32_t* seed_ptr, uint32_t site, float p, mrblip_stream_t stream);
 int mrblip_dropout_bf16(const void* x, long long ldx, void* out, long long ldo, int M, int N, const uint32_t* seed_ptr, uint32_t site,
                         float p, mrblip_stream_t stream);
-/* out[c] += sum_m x[m,c] (bias gradient of t5_proj, blip2_mr.py:270-272) */
+/* out[c] += sum_m x[m,c] (bias gradient of t5_proj, blip2_mr.py:270-272); row blocks added in block order through the reduce workspace
+ * (N <= 8192), else by fp32 atomics */
 int mrblip_colsum(const float* x, long long ldx, int M, int N, float* out, mrblip_stream_t stream);
 /* LoRA weight gradients without transposed copies: for j < R/8: outs[j][(r%8)*lds[j] + c - col0[j]] += sum_m U[m, 8j + r%8] * drop(Y)[m, c]
  * for the columns col0[j] <= c < col0[j] + ncols[j]  (dB^T = u^T dy is block-diagonal over the adapters of a fused group, dA = g^T dropout(x)) */
@@ -255,6 +270,9 @@ int mrblip_dec_proj(const float* x32, long long ldx32, const float* gamma, float
  * independent of dispatch order.  ws: >= 16 KB + B * H * n_split * 9216 bytes of 16-B aligned device memory whose first 16 KB are ZERO
  * (the tickets; the kernels leave them zero); launches that use it must be stream-ordered.  ws = NULL: the one-block-per-head form. */
 int mrblip_attention_set_split_workspace(void* ws, long long bytes, int n_split);
+/* Drops every pending one-shot of the calling thread (mrblip_gemm_set_extra / _set_prefetch / _set_thin) without launching anything: the
+ * exception path of a caller that fails between a setter and its GEMM (every dispatch also consumes them, whether it launches or not). */
+int mrblip_gemm_clear_one_shots(void);
 /* One-shot extras of the calling thread's NEXT mrblip_gemm_bf16 / mrblip_gemm_lora_dx launch (round 4; generic tile kernels only, the call
  * fails loudly for a kernel form that cannot honour them):
  *  - tout0..2 (bf16 output, plain or bias epilogue, heads of 64): head-transposed copies of up to three consecutive column ranges of width
@@ -293,6 +311,14 @@ int mrblip_rmsnorm_bwd_parts(const float* dy, long long lddy, int nparts, long l
                              const float* x, long long ldx, const float* weight, int M, int D, float eps, const float* dx_add, long long ldadd,
                              float* dx, long long lddx, void* out_bf16, long long ldob, const uint32_t* seed_ptr, uint32_t site, float p_drop,
                              mrblip_stream_t stream);
+/* Round 6: mrblip_rmsnorm_bwd_parts that ALSO computes the rank-8 LoRA product of the operand it writes,
+ *   g_out[m, 0:8] = sum_c out_bf16[m, c] * g_b[r, c]      (g_b = scale * B^T of the adapter on the projection that consumes out_bf16, bf16 [8, >= D])
+ * i.e. what mrblip_lora_rows(out_bf16, g_b, g_out) would compute in a launch of its own (peft lora.Linear backward: grad of lora_A's output,
+ * blip2_mr.py:182-200) — the rows are in this kernel's registers, g_b in LDS, the products on v_dot2c_f32_bf16.  nparts = 1: plain dy. */
+int mrblip_rmsnorm_bwd_parts_g(const float* dy, long long lddy, int nparts, long long pstride, int ext_part, uint32_t ext_site, float ext_p,
+                               const float* x, long long ldx, const float* weight, int M, int D, float eps, const float* dx_add, long long ldadd,
+                               float* dx, long long lddx, void* out_bf16, long long ldob, const uint32_t* seed_ptr, uint32_t site, float p_drop,
+                               const void* g_b, long long ldgb, void* g_out, long long ldg, mrblip_stream_t stream);
 /* out = (residual, may be NULL or out itself) + part 0 + ... + part nparts-1, fp32, added in part order (the reduce of mrblip_gemm_ksplit for
  * consumers without a parts form: the encoder-output gradient of the stacked cross-attention K / V projections, modeling_t5.py:561-599) */
 int mrblip_sum_parts(const float* parts, long long ldp, long long pstride, int nparts, const float* residual, long long ldr, float* out,

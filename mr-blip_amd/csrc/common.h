@@ -16,6 +16,25 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 void mrblip_set_error(const char* fmt, ...);
 int mrblip_check_launch(const char* what);
 
+// Workspace of the ORDERED reductions (cross-entropy row terms, bias column sums, LayerNorm dgamma / dbeta): partial sums leave the blocks
+// with write-through stores and the block that draws the last ticket adds them in a fixed order, so the result is the same bits on every
+// run.  The scratch and the tickets are CALLER-provided (mrblip_set_reduce_workspace, per calling thread; round 6 — until then they were
+// library-owned __device__ arrays, i.e. process-global state that two streams would have corrupted): zeroed device memory of
+// MRB_RWS_BYTES, one per stream that may run these kernels concurrently.  Without one the kernels fall back to fp32 atomics (arrival order).
+#define MRB_RWS_CE_ROWS 4096
+#define MRB_RWS_CS_MAXY 64
+#define MRB_RWS_CS_MAXN 8192
+#define MRB_RWS_DW_MAXB 256
+#define MRB_RWS_DW_MAXD 2048
+#define MRB_RWS_TICKET_CE 0                                        /* uint32 index */
+#define MRB_RWS_TICKET_DW 1
+#define MRB_RWS_TICKET_CS 4                                        /* .. 4 + MRB_RWS_CS_MAXN / 256 */
+#define MRB_RWS_OFF_CE 1024ll                                      /* byte offsets */
+#define MRB_RWS_OFF_CS (MRB_RWS_OFF_CE + 4ll * MRB_RWS_CE_ROWS)
+#define MRB_RWS_OFF_DW (MRB_RWS_OFF_CS + 4ll * MRB_RWS_CS_MAXY * MRB_RWS_CS_MAXN)
+#define MRB_RWS_BYTES (MRB_RWS_OFF_DW + 4ll * MRB_RWS_DW_MAXB * 2 * MRB_RWS_DW_MAXD)
+char* mrblip_reduce_workspace();   // the calling thread's registered workspace (>= MRB_RWS_BYTES) or nullptr
+
 #define MRB_REQUIRE(cond, ...)            \
   do {                                    \
     if (!(cond)) {                        \

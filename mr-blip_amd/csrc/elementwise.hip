@@ -227,13 +227,17 @@ __global__ __launch_bounds__(256) void gated_bwd_kernel(const bf16_t* __restrict
 // Round 4: the row terms are added in ROW order by the block that finishes last (ticket), not by fp32 atomics in arrival order: the loss of a
 // step is the same bits on every run and on every rank of a replicated T5 (tests/test_frame_shard_gpu.py compares ranks bit for bit; with
 // atomicAdd the sum of the 8-14 row terms changed in the last bit from run to run).  The terms travel through a library-owned scratch
-// (write-through stores, one agent-scope acquire by the last arriver: cdna_hip_programming.md Guideline 16), so launches are expected to be
-// stream-ordered; R > CE_MAX_ROWS falls back to the atomic sum.
-#define CE_MAX_ROWS 4096
-__device__ float g_ce_terms[CE_MAX_ROWS];
-__device__ unsigned int g_ce_ticket;
+// (write-through stores, one agent-scope acquire by the last arriver: cdna_hip_programming.md Guideline 16).  Round 6: the scratch is the
+// caller's (mrblip_set_reduce_workspace; common.h) — launches that share one must be stream-ordered; without one, or with R > CE_MAX_ROWS,
+// the sum falls back to atomics.
+#define CE_MAX_ROWS MRB_RWS_CE_ROWS
 __global__ __launch_bounds__(1024) void ce_kernel(const float* __restrict__ logits, long long ldl, const int* __restrict__ labels, int V,
-                                                  float inv_count, float* loss, bf16_t* dlogits, long long ldd, int ordered) {
+                                                  float inv_count, float* loss, bf16_t* dlogits, long long ldd, float* g_ce_terms, unsigned int* g_ce_ticket,
+                                                  const int* __restrict__ n_valid_dev) {
+  const bool ordered = g_ce_terms != nullptr;
+  // the mean's 1 / count from a DEVICE word (mrblip_cross_entropy_nvalid): a captured graph then serves batches with any number of valid
+  // label tokens (correctly rounded fp32 division: the same bits as the host's float32(1) / float32(count))
+  if (n_valid_dev) inv_count = 1.0f / (float)max(*n_valid_dev, 1);
   __shared__ float red[16];
   const int r = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const float* lr = logits + (long long)r * ldl;
@@ -264,9 +268,9 @@ __global__ __launch_bounds__(1024) void ce_kernel(const float* __restrict__ logi
     } else {
       __hip_atomic_store(&g_ce_terms[r], term, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // write-through
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      const unsigned int old = __hip_atomic_fetch_add(&g_ce_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned int old = __hip_atomic_fetch_add(g_ce_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (old == gridDim.x - 1) {
-        __hip_atomic_store(&g_ce_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(g_ce_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         float acc = *loss;
         for (int i = 0; i < (int)gridDim.x; ++i) acc += __hip_atomic_load(&g_ce_terms[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -374,11 +378,11 @@ __global__ __launch_bounds__(256) void dropout_bf16_kernel(const bf16_t* __restr
 // out[c] += sum_m x[m,c]  (bias gradients).  Round 4: the row blocks' partial sums are added in BLOCK order by the last-arriving block of a
 // column group (ticket; write-through partials in a library-owned scratch, as ce_kernel) instead of fp32 atomics in arrival order: the
 // t5_proj bias gradient is the same bits on every run.  Launches are expected to be stream-ordered.
-#define CS_MAXY 64
-#define CS_MAXN 8192
-__device__ float g_cs_part[CS_MAXY * CS_MAXN];
-__device__ unsigned int g_cs_ticket[CS_MAXN / 256];
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, long long ldx, int M, int N, int rows_per_block, float* __restrict__ out, int ordered) {
+#define CS_MAXY MRB_RWS_CS_MAXY
+#define CS_MAXN MRB_RWS_CS_MAXN
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, long long ldx, int M, int N, int rows_per_block, float* __restrict__ out,
+                                                     float* g_cs_part, unsigned int* g_cs_ticket) {
+  const bool ordered = g_cs_part != nullptr;
   __shared__ int last_flag;
   const int c = blockIdx.x * 256 + threadIdx.x;
   const int mbeg = blockIdx.y * rows_per_block, mend = min(M, mbeg + rows_per_block);
@@ -546,8 +550,19 @@ extern "C" int mrblip_gated_gelu_bwd_parts(const void* dy, const void* dy_ext, l
 extern "C" int mrblip_cross_entropy(const float* logits, long long ldl, const int* labels, int R, int V, float inv_count, float* loss,
                                     void* dlogits_bf16, long long ldd, hipStream_t stream) {
   MRB_REQUIRE(R > 0 && V > 0, "cross_entropy: bad shape");
-  hipLaunchKernelGGL(ce_kernel, dim3(R), dim3(1024), 0, stream, logits, ldl, labels, V, inv_count, loss, (bf16_t*)dlogits_bf16, ldd, R <= CE_MAX_ROWS ? 1 : 0);
+  char* ws = R <= CE_MAX_ROWS ? mrblip_reduce_workspace() : nullptr;
+  hipLaunchKernelGGL(ce_kernel, dim3(R), dim3(1024), 0, stream, logits, ldl, labels, V, inv_count, loss, (bf16_t*)dlogits_bf16, ldd,
+                     ws ? (float*)(ws + MRB_RWS_OFF_CE) : nullptr, ws ? (unsigned int*)ws + MRB_RWS_TICKET_CE : nullptr, (const int*)nullptr);
   return mrblip_check_launch("cross_entropy");
+}
+// the same with the number of valid (label != -100) rows read from DEVICE memory: inv_count = 1 / max(*n_valid, 1)
+extern "C" int mrblip_cross_entropy_nvalid(const float* logits, long long ldl, const int* labels, int R, int V, const int* n_valid, float* loss,
+                                           void* dlogits_bf16, long long ldd, hipStream_t stream) {
+  MRB_REQUIRE(R > 0 && V > 0 && n_valid, "cross_entropy_nvalid: bad shape / no count");
+  char* ws = R <= CE_MAX_ROWS ? mrblip_reduce_workspace() : nullptr;
+  hipLaunchKernelGGL(ce_kernel, dim3(R), dim3(1024), 0, stream, logits, ldl, labels, V, 0.f, loss, (bf16_t*)dlogits_bf16, ldd,
+                     ws ? (float*)(ws + MRB_RWS_OFF_CE) : nullptr, ws ? (unsigned int*)ws + MRB_RWS_TICKET_CE : nullptr, n_valid);
+  return mrblip_check_launch("cross_entropy_nvalid");
 }
 extern "C" int mrblip_adamw(float* p, const float* g, float* m, float* v, long long n, const float* hyper, float beta1, float beta2, float eps,
                             float weight_decay, hipStream_t stream) {
@@ -655,9 +670,11 @@ extern "C" int mrblip_dropout_bf16(const void* x, long long ldx, void* out, long
 extern "C" int mrblip_colsum(const float* x, long long ldx, int M, int N, float* out, hipStream_t stream) {
   MRB_REQUIRE(M > 0 && N > 0, "colsum: bad shape");
   int rpb = 64;
-  const int ordered = N <= CS_MAXN ? 1 : 0;
+  char* ws = N <= CS_MAXN ? mrblip_reduce_workspace() : nullptr;
+  const int ordered = ws ? 1 : 0;
   if (ordered && (M + rpb - 1) / rpb > CS_MAXY) rpb = (M + CS_MAXY - 1) / CS_MAXY;
-  hipLaunchKernelGGL(colsum_kernel, dim3((N + 255) / 256, (M + rpb - 1) / rpb), dim3(256), 0, stream, x, ldx, M, N, rpb, out, ordered);
+  hipLaunchKernelGGL(colsum_kernel, dim3((N + 255) / 256, (M + rpb - 1) / rpb), dim3(256), 0, stream, x, ldx, M, N, rpb, out,
+                     ws ? (float*)(ws + MRB_RWS_OFF_CS) : nullptr, ws ? (unsigned int*)ws + MRB_RWS_TICKET_CS : nullptr);
   return mrblip_check_launch("colsum");
 }
 extern "C" int mrblip_lora_pack(const float* flat, void* acat_bf16, void* wext_bf16, void* bblk_bf16, void* acatt_bf16, const long long* desc,

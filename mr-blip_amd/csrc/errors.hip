@@ -21,5 +21,14 @@ int mrblip_check_launch(const char* what) {
   return MRBLIP_OK;
 }
 
+static thread_local char* g_reduce_ws = nullptr;
+char* mrblip_reduce_workspace() { return g_reduce_ws; }
+extern "C" int mrblip_set_reduce_workspace(void* ws, long long bytes) {
+  MRB_REQUIRE(!ws || (bytes >= MRB_RWS_BYTES && ((uintptr_t)ws % 16) == 0), "reduce workspace: need >= %lld bytes of 16-B aligned, ZEROED device memory", (long long)MRB_RWS_BYTES);
+  g_reduce_ws = (char*)ws;
+  return MRBLIP_OK;
+}
+extern "C" long long mrblip_reduce_workspace_bytes(void) { return MRB_RWS_BYTES; }
+
 extern "C" const char* mrblip_last_error(void) { return g_err; }
 extern "C" int mrblip_abi_version(void) { return 1; }

@@ -1826,6 +1826,15 @@ extern "C" int mrblip_gemm_set_thin(const void* acat, long long lda, int R, int 
   return MRBLIP_OK;
 }
 
+// drop every pending one-shot (extras, prefetch range, thin role) of the calling thread: for a caller that fails between a setter and the
+// launch it was meant for (mrblip/ops.py does this in its exception path), so that they cannot ride on an unrelated later GEMM
+extern "C" int mrblip_gemm_clear_one_shots(void) {
+  g_gemm_extra = GemmExtra{};
+  g_gemm_prefetch = GemmPrefetch{};
+  g_gemm_thin = GemmThin{};
+  return MRBLIP_OK;
+}
+
 static int gemm_dispatch(const void* A, long long lda, const void* W, long long ldw, const void* Aext, long long ldaext,
                          const void* Wext, long long ldwext, int M, int N, int K, void* out, long long ldo, int out_f32,
                          void* out2, long long ldo2, const float* bias, const float* residual, long long ldr, int act,

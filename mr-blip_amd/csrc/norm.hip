@@ -68,30 +68,46 @@ __global__ __launch_bounds__(256) void norm_fwd_kernel(const float* __restrict__
   }
 }
 
-#define NORM_DW_MAXD 2048
-#define NORM_DW_MAXB 256
+#define NORM_DW_MAXD MRB_RWS_DW_MAXD
+#define NORM_DW_MAXB MRB_RWS_DW_MAXB
 typedef uint32_t norm_u32x4 __attribute__((ext_vector_type(4)));
-__device__ float g_dw_part[NORM_DW_MAXB * 2 * NORM_DW_MAXD];   // ordered weight gradients: [block][dgamma | dbeta][D] partial sums
-__device__ unsigned int g_dw_ticket;
+// ordered weight gradients: [block][dgamma | dbeta][D] partial sums + a ticket, both in the CALLER's reduce workspace (common.h; round 6)
 
 // dx = dx_add + rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma   (RMS: no mean(g) term, xhat = x*rstd)
 // dgamma += sum_rows dy * xhat, dbeta += sum_rows dy  (optional, fp32 atomics, one per column per block)
-template <bool RMS>
+// GOUT (round 6, mrblip_rmsnorm_bwd_parts_g): the launch also computes the LoRA "g" product of the operand it writes,
+//   g_out[row, 0:8] = sum_c out_b[row, c] * g_b[r, c]      (g_b = scale * B^T of the NEXT projection's adapter, bf16 [8, D])
+// — what a lora_thin launch over out_b would compute (19 + 10 us per T5 encoder layer of the backward, each a pass over a 8 MB operand that
+// this kernel holds in registers): g_b is staged in LDS once per block (32 KB at D = 2048), the products run on v_dot2c_f32_bf16 over the
+// PACKED bf16 pairs the store writes anyway (exact products, fp32 accumulation, as on the matrix cores), one wave reduction per r.
+typedef __bf16 norm_bf2 __attribute__((ext_vector_type(2)));
+template <bool RMS, bool GOUT = false>
 __global__ __launch_bounds__(256) void norm_bwd_kernel(const float* __restrict__ dy, long long lddy, const float* __restrict__ x,
                                                        long long ldx, const float* __restrict__ gamma, int M, int D, float eps,
                                                        const float* dx_add, long long ldadd, float* dx, long long lddx,
                                                        float* dgamma, float* dbeta, bf16_t* out_b = nullptr, long long ldob = 0,
-                                                       DropoutArg drop = DropoutArg{nullptr, 0u, 0u, 1.0f}, int ordered_dw = 0,
+                                                       DropoutArg drop = DropoutArg{nullptr, 0u, 0u, 1.0f}, float* g_dw_part = nullptr,
                                                        int nparts = 1, long long pstride = 0, int ext_part = 0,
-                                                       DropoutArg ext_drop = DropoutArg{nullptr, 0u, 0u, 1.0f}) {
+                                                       DropoutArg ext_drop = DropoutArg{nullptr, 0u, 0u, 1.0f},
+                                                       const bf16_t* __restrict__ g_b = nullptr, long long ldgb = 0, bf16_t* g_out = nullptr, long long ldg = 0) {
   // nparts > 1 (round 5, mrblip_rmsnorm_bwd_parts): dy arrives as PARTIAL products pstride elements apart (mrblip_gemm_ksplit) and is
   // their sum in part order; ext_part: the last part is the LoRA term g A, added under the lora_dropout keep mask of ext_drop over [M, D]
   __shared__ float red[2][4][64 * 4];
   __shared__ int last_flag;
+  __shared__ uint2 gb_sh[GOUT ? 8 * (NORM_MAXV * 64) : 1];   // g_b as [r][column quad] (GOUT)
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int nv = D >> 2;
+  if (GOUT) {
+    for (int q = threadIdx.x; q < 8 * nv; q += 256) {
+      const int r = q / nv, i = q - r * nv;
+      gb_sh[r * (NORM_MAXV * 64) + i] = *reinterpret_cast<const uint2*>(g_b + (long long)r * ldgb + 4 * i);
+    }
+    __syncthreads();
+  }
   float4 ag[NORM_MAXV], ab[NORM_MAXV];
   const bool want_dw = dgamma != nullptr;
+  const bool ordered_dw = g_dw_part != nullptr;
+  unsigned int* const g_dw_ticket = reinterpret_cast<unsigned int*>(g_dw_part) - (MRB_RWS_OFF_DW / 4) + MRB_RWS_TICKET_DW;   // (same workspace)
   const uint32_t seed = drop.seed_ptr ? mrb_seed_load(drop.seed_ptr) : ext_drop.seed_ptr ? mrb_seed_load(ext_drop.seed_ptr) : 0u;
   if (want_dw) {
 #pragma unroll
@@ -172,6 +188,7 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const float* __restrict__
     const float mg = RMS ? 0.f : wave_sum(sg) / (float)D;
     const float mgx = wave_sum(sgx) / (float)D;
     MRB_ALL_LOADS_DONE();
+    float gacc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < NORM_MAXV; ++j) {
       const int i = lane + 64 * j;
@@ -194,9 +211,25 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const float* __restrict__
             o.z = k2 ? o.z * drop.inv_keep : 0.f;
             o.w = k3 ? o.w * drop.inv_keep : 0.f;
           }
-          reinterpret_cast<uint2*>(out_b + (long long)row * ldob)[i] = make_uint2(pack2bf(o.x, o.y), pack2bf(o.z, o.w));
+          const uint2 pk = make_uint2(pack2bf(o.x, o.y), pack2bf(o.z, o.w));
+          reinterpret_cast<uint2*>(out_b + (long long)row * ldob)[i] = pk;
+          if (GOUT) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+              const uint2 b = gb_sh[r * (NORM_MAXV * 64) + i];
+              gacc[r] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(norm_bf2, pk.x), __builtin_bit_cast(norm_bf2, b.x), gacc[r], false);
+              gacc[r] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(norm_bf2, pk.y), __builtin_bit_cast(norm_bf2, b.y), gacc[r], false);
+            }
+          }
         }
       }
+    }
+    if (GOUT) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) gacc[r] = wave_sum_uniform(gacc[r]);
+      if (lane == 0)
+        *reinterpret_cast<uint4*>(g_out + (long long)row * ldg) =
+            make_uint4(pack2bf(gacc[0], gacc[1]), pack2bf(gacc[2], gacc[3]), pack2bf(gacc[4], gacc[5]), pack2bf(gacc[6], gacc[7]));
     }
   }
   if (want_dw) {
@@ -242,9 +275,9 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const float* __restrict__
       if (wv == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (threadIdx.x == 0) {
-        const unsigned int old = __hip_atomic_fetch_add(&g_dw_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned int old = __hip_atomic_fetch_add(g_dw_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         last_flag = old == gridDim.x - 1;
-        if (last_flag) __hip_atomic_store(&g_dw_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (last_flag) __hip_atomic_store(g_dw_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       __syncthreads();
       if (last_flag) {
@@ -318,10 +351,11 @@ extern "C" int mrblip_layernorm_bwd(const float* dy, long long lddy, const float
   // (dgamma / dbeta: at most NORM_DW_MAXB blocks, whose partial sums the last one adds in block order; MRB_NORM_DW_ATOMIC=1: fp32 atomics)
   static int dw_atomic = -1;
   if (dw_atomic < 0) { const char* e = getenv("MRB_NORM_DW_ATOMIC"); dw_atomic = (e && e[0] == '1') ? 1 : 0; }
-  const int ordered = (dgamma && !dw_atomic && ((uintptr_t)dgamma % 16) == 0 && (!dbeta || ((uintptr_t)dbeta % 16) == 0)) ? 1 : 0;
+  char* ws = (dgamma && !dw_atomic && ((uintptr_t)dgamma % 16) == 0 && (!dbeta || ((uintptr_t)dbeta % 16) == 0)) ? mrblip_reduce_workspace() : nullptr;
+  const int ordered = ws ? 1 : 0;
   const int grid = min((M + 3) / 4, dgamma ? (ordered ? NORM_DW_MAXB : 512) : 2048);
   hipLaunchKernelGGL(norm_bwd_kernel<false>, dim3(grid), dim3(256), 0, stream, dy, lddy, x, ldx, gamma, M, D, eps, dx_add, ldadd, dx, lddx, dgamma, dbeta,
-                     (bf16_t*)nullptr, 0ll, DropoutArg{nullptr, 0u, 0u, 1.0f}, ordered);
+                     (bf16_t*)nullptr, 0ll, DropoutArg{nullptr, 0u, 0u, 1.0f}, ws ? (float*)(ws + MRB_RWS_OFF_DW) : nullptr);
   return mrblip_check_launch("layernorm_bwd");
 }
 
@@ -358,8 +392,30 @@ extern "C" int mrblip_rmsnorm_bwd_parts(const float* dy, long long lddy, int npa
   de.seed_ptr = (ext_p > 0.f) ? seed_ptr : nullptr; de.site = ext_site; de.thresh24 = (uint32_t)(ext_p * 65536.0f + 0.5f); de.inv_keep = 1.0f / (1.0f - ext_p);
   const int grid = min((M + 3) / 4, 2048);
   hipLaunchKernelGGL(norm_bwd_kernel<true>, dim3(grid), dim3(256), 0, stream, dy, lddy, x, ldx, weight, M, D, eps, dx_add, ldadd, dx, lddx, (float*)nullptr,
-                     (float*)nullptr, (bf16_t*)out_bf16, ldob, d, 0, nparts, pstride, ext_part, de);
+                     (float*)nullptr, (bf16_t*)out_bf16, ldob, d, (float*)nullptr, nparts, pstride, ext_part, de);
   return mrblip_check_launch("rmsnorm_bwd_parts");
+}
+
+// mrblip_rmsnorm_bwd_parts that ALSO writes g_out[M, 0:8] = out_bf16 [M, D] x g_b[8, D]^T (bf16, fp32 accumulation): the rank-8 "g = dy (scale B)"
+// product of the LoRA adapter on the projection that consumes out_bf16 (peft lora.Linear backward, blip2_mr.py:182-200), for which the
+// engine otherwise launches mrblip_lora_rows over the operand this kernel has just written.  nparts = 1: plain dy.
+extern "C" int mrblip_rmsnorm_bwd_parts_g(const float* dy, long long lddy, int nparts, long long pstride, int ext_part, uint32_t ext_site, float ext_p,
+                                          const float* x, long long ldx, const float* weight, int M, int D, float eps, const float* dx_add, long long ldadd,
+                                          float* dx, long long lddx, void* out_bf16, long long ldob, const uint32_t* seed_ptr, uint32_t site, float p_drop,
+                                          const void* g_b, long long ldgb, void* g_out, long long ldg, hipStream_t stream) {
+  if (int e = norm_check(M, D, x, ldx)) return e;
+  MRB_REQUIRE(nparts >= 1 && nparts <= 32 && (pstride % 4) == 0 && (lddy % 4) == 0 && ((uintptr_t)dy % 16) == 0, "rmsnorm_bwd_parts_g: 1..32 parts of 16-B aligned rows");
+  MRB_REQUIRE(out_bf16 && (ldob % 4) == 0, "rmsnorm_bwd_parts_g: bf16 output missing / unaligned");
+  MRB_REQUIRE(g_b && g_out && (ldgb % 4) == 0 && ((uintptr_t)g_b % 8) == 0 && (ldg % 8) == 0 && ((uintptr_t)g_out % 16) == 0 && ldgb >= D,
+              "rmsnorm_bwd_parts_g: g_b is [8, >= D] with 8-B aligned rows, g_out [M, >= 8] with 16-B aligned rows");
+  MRB_REQUIRE(!(p_drop > 0.f || ext_p > 0.f) || seed_ptr, "rmsnorm_bwd_parts_g: dropout needs a device seed pointer");
+  DropoutArg d, de;
+  d.seed_ptr = (p_drop > 0.f) ? seed_ptr : nullptr; d.site = site; d.thresh24 = (uint32_t)(p_drop * 65536.0f + 0.5f); d.inv_keep = 1.0f / (1.0f - p_drop);
+  de.seed_ptr = (ext_p > 0.f) ? seed_ptr : nullptr; de.site = ext_site; de.thresh24 = (uint32_t)(ext_p * 65536.0f + 0.5f); de.inv_keep = 1.0f / (1.0f - ext_p);
+  const int grid = min((M + 3) / 4, 2048);
+  hipLaunchKernelGGL((norm_bwd_kernel<true, true>), dim3(grid), dim3(256), 0, stream, dy, lddy, x, ldx, weight, M, D, eps, dx_add, ldadd, dx, lddx, (float*)nullptr,
+                     (float*)nullptr, (bf16_t*)out_bf16, ldob, d, (float*)nullptr, nparts, pstride, ext_part, de, (const bf16_t*)g_b, ldgb, (bf16_t*)g_out, ldg);
+  return mrblip_check_launch("rmsnorm_bwd_parts_g");
 }
 
 extern "C" int mrblip_rmsnorm_bwd(const float* dy, long long lddy, const float* x, long long ldx, const float* weight, int M, int D,

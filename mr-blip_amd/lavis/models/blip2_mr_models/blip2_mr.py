@@ -33,24 +33,27 @@ class _TrainStep(torch.autograd.Function):
     micro-step overlaps with its t5_proj / Q-Former backward."""
 
     @staticmethod
-    def forward(ctx, decay, no_decay, model, video, layout, need_grad, next_video=None):
-        eng = model.engine  # (grad mode is always off inside Function.forward, hence the explicit flag)
+    def forward(ctx, decay, no_decay, model, video, layout, need_grad, next_video=None, frame_tokens=None):
+        eng = model.train_engine  # (grad mode is always off inside Function.forward, hence the explicit flag)
         if model._fused_scale is None:
             eng.zero_grad()
-        loss = eng.forward_backward(video, layout, backward=need_grad, next_video=next_video)
+        if frame_tokens is not None:   # video-QA: the ANSWERER's step on frame tokens the shared towers produced without gradient
+            loss = eng.forward_backward(None, layout, backward=need_grad, frames=frame_tokens, train_frames=False)
+        else:
+            loss = eng.forward_backward(video, layout, backward=need_grad, next_video=next_video)
         ctx.model = model
         return loss.clone().reshape(())
 
     @staticmethod
     def backward(ctx, g):
         model = ctx.model
-        eng = model.engine
+        eng = model.train_engine
         if model._fused_scale is not None:
             model._check_fused_scale(g)   # (device-side compare, read one step late: no host sync behind ~2900 queued launches)
-            return None, None, None, None, None, None, None
+            return None, None, None, None, None, None, None, None
         model._ensure_named_grads()
         nd = eng.n_decay
-        return eng.grad[:nd] * g, eng.grad[nd:] * g, None, None, None, None, None
+        return eng.grad[:nd] * g, eng.grad[nd:] * g, None, None, None, None, None, None
 
 
 @registry.register_model("blip2_mr")
@@ -68,8 +71,10 @@ class BLIP2_MR(BaseModel):
         super().__init__()
         if not freeze_vit:
             raise NotImplementedError("the MI355X engine keeps the ViT frozen (every Mr. BLIP config sets freeze_vit: True)")
-        if "QA" in task:
-            raise NotImplementedError("video-QA variants (forward_QA) are outside the moment-retrieval hot path")
+        if "QA" in task and resample_frames:
+            # get_relevant_frames_resampled (blip2_mr.py:1166-1235) re-decodes the clip from samples["video_path"] for the localized window
+            raise NotImplementedError("video-QA with resample_frames=True re-reads the video file through the eval video processor: not built "
+                                      "(resample_frames=False selects the answerer's frames from the frames already in the batch)")
         if input_time_format not in ("seconds_integers", "seconds_floats"):
             raise NotImplementedError(f"input_time_format={input_time_format!r}: 'seconds_integers' (every shipped config) and 'seconds_floats' are "
                                       "implemented; the reference's relative_*/framenumbers formats are broken upstream (SURVEY.md §8c)")
@@ -99,15 +104,30 @@ class BLIP2_MR(BaseModel):
         else:
             src = StateDictSource(weights) if isinstance(weights, dict) else weights
         self.engine = MrBlipEngine(cfg, src, self._device, seed=seed)
-        nd = self.engine.n_decay
+        # ---- video-QA variants (blip2_mr.py:103-118, 152-161, 206-236): the moment-retrieval model above becomes the frozen LOCALIZER and a
+        # second T5 with its own LoRA — the ANSWERER, keys answerer_model.* — is what trains; ViT / ln_vision / Q-Former / t5_proj are shared
+        self.is_qa = "QA" in task
+        self.use_localizer = "with_localizer" in task
+        self.use_oracle_localizer = "oracle_localizer" in task
+        self.resample_frames, self.num_frames_for_answer = resample_frames, int(num_frames_for_answer)
+        self.ANS_MAPPING_C_TO_I = {"A": 0, "B": 1, "C": 2, "D": 3, "E": 4}
+        self.ANS_MAPPING_I_TO_C = {0: "A", 1: "B", 2: "C", 3: "D", 4: "E"}
+        self.answerer = None
+        if self.is_qa:
+            self.answerer = MrBlipEngine(cfg, src, self._device, seed=seed, t5_prefix="answerer_model.", share_towers=self.engine)
+            self.answerer_tokenizer = self.t5_tokenizer
+            # the reference freezes the localizer's T5 by casting it to bf16 (blip2_mr.py:206-209): its embedding rows are bf16 values
+            self.engine.emb.copy_(self.engine.emb.bfloat16().float())
+        self.train_engine = self.answerer if self.is_qa else self.engine       # the engine whose flat buffer the optimizer updates
+        nd = self.train_engine.n_decay
         # the trainable tensors as two flat Parameters that ALIAS the engine's buffer (AdamW decay / no-decay groups)
-        self.trainable_decay = nn.Parameter(self.engine.flat[:nd])
-        self.trainable_no_decay = nn.Parameter(self.engine.flat[nd:])
+        self.trainable_decay = nn.Parameter(self.train_engine.flat[:nd])
+        self.trainable_no_decay = nn.Parameter(self.train_engine.flat[nd:])
         # ONE flat gradient buffer behind both Parameters (generic mode: autograd accumulates g * engine.grad into it)
-        self.flat_grad = torch.zeros_like(self.engine.flat)
+        self.flat_grad = torch.zeros_like(self.train_engine.flat)
         self._fused_scale = None
         self._named = None                                   # reference-named per-tensor Parameters, built on first use
-        self._flat_version = self.engine.flat._version       # torch-side writes to the trainable buffer bump it (see forward)
+        self._flat_version = self.train_engine.flat._version       # torch-side writes to the trainable buffer bump it (see forward)
         self._bind_grads(self.flat_grad)
         self.post_process = post_process
 
@@ -118,7 +138,7 @@ class BLIP2_MR(BaseModel):
         """reference parameter name -> view of ``buf``, a flat fp32 buffer laid out like the engine's trainable buffer.  LoRA in peft's
         naming (blip2_mr.py:182-200 wraps t5_model in a PeftModel): lora_A.default.weight [r, in], lora_B.default.weight [out, r] —
         the engine stores B transposed, so that one is a transposed (non-contiguous) view."""
-        eng = self.engine
+        eng = self.train_engine
         base = eng.flat.data_ptr()
 
         def like(t, transpose=False):
@@ -127,12 +147,14 @@ class BLIP2_MR(BaseModel):
             return v.t() if transpose else v
 
         out = OrderedDict()
-        out["ln_vision.weight"], out["ln_vision.bias"] = like(eng.lnv_w), like(eng.lnv_b)
+        if not self.is_qa:   # (video-QA: the frame path runs without gradient, only the answerer's LoRA tensors train)
+            out["ln_vision.weight"], out["ln_vision.bias"] = like(eng.lnv_w), like(eng.lnv_b)
         for a in eng.adapters:
-            name = "t5_model.base_model.model." + a.name
+            name = eng.t5_prefix + "base_model.model." + a.name
             out[name + ".lora_A.default.weight"] = like(a.A)
             out[name + ".lora_B.default.weight"] = like(a.Bt, True)
-        out["t5_proj.weight"], out["t5_proj.bias"] = like(eng.proj_w), like(eng.proj_b)
+        if not self.is_qa:
+            out["t5_proj.weight"], out["t5_proj.bias"] = like(eng.proj_w), like(eng.proj_b)
         return out
 
     def reference_named_parameters(self):
@@ -142,7 +164,7 @@ class BLIP2_MR(BaseModel):
         clipping, a stock ``torch.optim`` optimizer — works on the engine's own memory.  forward() notices torch-side updates of the
         buffer (tensor version counter) and re-derives the bf16 operand copies."""
         if self._named is None:
-            self._named = OrderedDict((n, nn.Parameter(v)) for n, v in self._trainable_views(self.engine.flat).items())
+            self._named = OrderedDict((n, nn.Parameter(v)) for n, v in self._trainable_views(self.train_engine.flat).items())
             self._rebind_named_grads()
         return self._named
 
@@ -168,7 +190,7 @@ class BLIP2_MR(BaseModel):
 
     # ------------------------------------------------------------------ gradients: one flat buffer
     def _bind_grads(self, buf):
-        nd = self.engine.n_decay
+        nd = self.train_engine.n_decay
         self.trainable_decay.grad = buf[:nd]
         self.trainable_no_decay.grad = buf[nd:]
         self._rebind_named_grads()
@@ -179,7 +201,7 @@ class BLIP2_MR(BaseModel):
 
     def grad_buffer(self) -> torch.Tensor:
         """the flat fp32 gradient of every trainable tensor: the only thing data-parallel ranks exchange"""
-        return self.engine.grad if self._fused_scale is not None else self.flat_grad
+        return self.train_engine.grad if self._fused_scale is not None else self.flat_grad
 
     def grad_scale(self) -> float:
         """factor AdamW applies to grad_buffer() (fused mode: the loss scale the engine did not apply)"""
@@ -235,7 +257,7 @@ class BLIP2_MR(BaseModel):
         """fused mode (see _TrainStep): micro-step gradients accumulate in the engine's buffer; every loss.backward() of the window
         must come with the upstream scale ``loss_scale``"""
         self._fused_scale = float(loss_scale)
-        self._bind_grads(self.engine.grad)
+        self._bind_grads(self.train_engine.grad)
 
     def end_accumulation(self):
         self._raise_if_scale_violation(block=True)
@@ -291,6 +313,8 @@ class BLIP2_MR(BaseModel):
     def train(self, mode=True):
         super().train(mode)
         self.engine.training = mode
+        if self.answerer is not None:
+            self.answerer.training = mode
         return self
 
     def _layout(self, samples):
@@ -312,6 +336,8 @@ class BLIP2_MR(BaseModel):
     def forward(self, samples):
         """samples: the reference's dict (blip2_mr.py:433-445).  Optional extra key ``next_video``: the NEXT batch's frames (the train
         loop's one-batch look-ahead, tasks/moment_retrieval.py); its frozen-ViT forward is overlapped with this step's T5 decoder."""
+        if self.is_qa:
+            return self.forward_QA(samples)
         src = samples["video"]
         if self._staged_next is not None and self._staged_next[0] is src:
             video = self._staged_next[1]  # the device copy whose ViT features were prefetched during the previous step
@@ -328,11 +354,7 @@ class BLIP2_MR(BaseModel):
             self.engine.reserve(layout.S, int(layout.S * 1.12) + int(self.max_txt_len))
             self._reserved = True
         need_grad = torch.is_grad_enabled() and (self.trainable_decay.requires_grad or self.trainable_no_decay.requires_grad)
-        if self.engine.flat._version != self._flat_version:
-            # a torch-side optimizer / load wrote the trainable buffer through one of its aliases (the engine's own AdamW kernel does
-            # not go through torch and re-packs by itself): re-derive the bf16 GEMM operand copies of LoRA A / B and t5_proj
-            self.engine.refresh_trainable()
-            self._flat_version = self.engine.flat._version
+        self._sync_trainable_operands()
         if need_grad:
             self._ensure_named_grads()
         nxt = samples.get("next_video") if need_grad else None
@@ -342,6 +364,153 @@ class BLIP2_MR(BaseModel):
             self._staged_next = (nxt, nxt_dev)
         loss = _TrainStep.apply(self.trainable_decay, self.trainable_no_decay, self, video, layout, need_grad, nxt_dev)
         return {"loss": loss}
+
+    def _sync_trainable_operands(self):
+        eng = self.train_engine
+        if eng.flat._version != self._flat_version:
+            # a torch-side optimizer / load wrote the trainable buffer through one of its aliases (the engine's own AdamW kernel does
+            # not go through torch and re-packs by itself): re-derive the bf16 GEMM operand copies of LoRA A / B and t5_proj
+            eng.refresh_trainable()
+            self._flat_version = eng.flat._version
+
+    # ------------------------------------------------------------------ video-QA two-stage path (blip2_mr.py:309-431, 948-1314)
+    def extract_frames(self, samples, relevant_moments, num_frames_for_answer):
+        """blip2_mr.py:1127-1164: per clip the batch's frames whose timestamps are closest to [start, end] (start >= end: end = duration),
+        padded with the last frame / thinned with linspace(...).long() to num_frames_for_answer -> [B, n, 3, H, W]"""
+        video, ts = samples["video"], samples["timestamps"]
+        out = []
+        for i, (start, end) in enumerate(relevant_moments):
+            if start >= end:
+                end = samples["duration"][i].item()
+            s_i = torch.argmin(torch.abs(ts[i] - start)).item()
+            e_i = torch.argmin(torch.abs(ts[i] - end)).item()
+            frames = video[i, s_i: e_i + 1]
+            assert frames.shape[0] > 0, "No frames found for the relevant moment."
+            if frames.shape[0] < num_frames_for_answer:
+                frames = torch.cat([frames, frames[-1:].expand(num_frames_for_answer - frames.shape[0], *frames.shape[1:])])
+            elif frames.shape[0] > num_frames_for_answer:
+                frames = frames[torch.linspace(0, frames.shape[0] - 1, num_frames_for_answer).long().to(frames.device)]
+            out.append(frames)
+        return torch.stack(out)
+
+    def get_relevant_frames(self, samples, relevant_moments_out, num_frames_for_answer):
+        """blip2_mr.py:1098-1125: the localizer's answer strings -> one [start, end] per clip (none -> the whole video, several -> the
+        first, an end beyond the duration -> round(duration)) and the frames extract_frames selects for it"""
+        from lavis.models.blip2_mr_models.utils import moment_str_to_list
+        relevant_moments = []
+        for i, sample in enumerate(relevant_moments_out):
+            m = moment_str_to_list(sample)
+            if m == [[-1, -1]]:
+                m = [0, samples["duration"][i].item()]
+            else:
+                m = m[0]
+            if m[1] > samples["duration"][i].item():
+                m[1] = round(samples["duration"][i].item())
+            relevant_moments.append(m)
+        assert len(relevant_moments) == samples["video"].shape[0]
+        return relevant_moments, self.extract_frames(samples, relevant_moments, num_frames_for_answer)
+
+    def get_relevant_frames_resampled(self, samples, relevant_moments, num_frames_for_answer):
+        raise NotImplementedError("resample_frames=True re-reads samples['video_path'] through the eval video processor (blip2_mr.py:1166-1235): not built")
+
+    @torch.no_grad()
+    def get_frame_embeddings_and_attentions(self, image):
+        """blip2_mr.py:948-988: [B, t, 3, H, W] -> frame tokens [B * t * n, d_model] (fp32, on the device; the attention mask is all ones) through
+        the SHARED ViT / ln_vision / Q-Former / t5_proj of the localizer's engine.  The rows stay in that engine's workspace: consume them
+        before its next call."""
+        if isinstance(image, (list, tuple)):
+            image = torch.stack(list(image))
+        return self.engine.frames_forward(self._frames_to_device(image))[0]
+
+    def _qa_layout(self, samples, n_frames):
+        n = 1 if self.engine.cfg.mean_pool else self.engine.cfg.num_query
+        answers = samples.get("qa_output") or [""] * len(samples["qa_input"])
+        return P.build_qa_layout(self.t5_tokenizer, list(samples["qa_input"]), list(answers), n_frames * n, self.max_txt_len)
+
+    def _localize(self, samples, generate_kwargs=None):
+        """stage 1 of the QA path: [start, end] per clip and the frames the answerer sees"""
+        n = self.num_frames_for_answer
+        B = samples["video"].shape[0]
+        if self.use_localizer:
+            s2 = dict(samples)
+            s2["relevant_windows"] = ["[[0, 0]]"] * B          # (the reference's dummy answer, blip2_mr.py:314)
+            s2.setdefault("query_id", samples.get("question_id"))
+            out_mr = self.generate(s2, **(generate_kwargs or {}))
+            return self.get_relevant_frames(samples, out_mr["prediction"], n)
+        if self.use_oracle_localizer and generate_kwargs is not None:   # (videoQA_generate only: the ground-truth windows, first one per clip)
+            rw = samples["relevant_windows"]
+            moments = [list(m[0]) for m in (rw.tolist() if torch.is_tensor(rw) else rw)]
+            return moments, self.extract_frames(samples, moments, n)
+        moments = [[0, d.item()] for d in samples["duration"]]      # uniform sampling over the whole video
+        return moments, self.extract_frames(samples, moments, n)
+
+    def forward_QA(self, samples):
+        """blip2_mr.py:309-431.  Stage 1 (no gradient): the localizer's generate() — or the whole video — picks num_frames_for_answer
+        frames per clip, which the shared towers turn into frame tokens.  Stage 2: the answerer T5 (its own LoRA: the only trainable
+        tensors) on [frame tokens | question] -> CE loss of the answer; the HIP step returns loss and the LoRA gradients."""
+        need_grad = torch.is_grad_enabled() and self.trainable_decay.requires_grad
+        with torch.no_grad():
+            moments, frames = self._localize(samples)
+            fr = self.get_frame_embeddings_and_attentions(frames)
+        self.last_relevant_moments = moments
+        layout = self._qa_layout(samples, frames.shape[1])
+        self._sync_trainable_operands()
+        if need_grad:
+            self._ensure_named_grads()
+        loss = _TrainStep.apply(self.trainable_decay, self.trainable_no_decay, self, None, layout, need_grad, None, fr)
+        return {"loss": loss}
+
+    ANSWER_IDS = (71, 272, 205, 309, 262)     # "A" .. "E" in the flan-t5 vocabulary (blip2_mr.py:1299)
+
+    @torch.no_grad()
+    def videoQA_answer(self, samples, use_nucleus_sampling=False, num_beams=5, max_length=50, min_length=8, top_p=0.9, repetition_penalty=1.0,
+                       length_penalty=1.0, num_captions=1, temperature=1, output_attentions=False):
+        """blip2_mr.py:1237-1314: the answerer decodes greedily (num_beams=1 there, whatever the argument says) and the answer is the argmax
+        of the SECOND step's scores over the five option tokens.  On the HIP decoder: encoder once, cross K/V once, two cached decoding
+        steps; EOS is suppressed at step 0 while min_length > 1 (HF's MinLengthLogitsProcessor), sampling warps are not applied to the
+        option argmax.  The question is embedded with the LOCALIZER's table, as the reference does (blip2_mr.py:1262)."""
+        from mrblip import ops
+        ans, loc = self.answerer, self.engine
+        was = (ans.training, loc.training)
+        ans.training = loc.training = False
+        try:
+            fr = self.get_frame_embeddings_and_attentions(samples["relevant_frames"])
+            layout = self._qa_layout(samples, samples["relevant_frames"].shape[1])
+            B, S, d = layout.attention_mask.shape[0], layout.S, ans.cfg.d_model
+            L = ans._layout_dev(layout)
+            inp = ans.buf("inputs_embeds", (B * S, d), torch.float32, zero=False)
+            ops.row_copy(fr, L["frame_src"], inp, L["frame_dst"])
+            ops.row_copy(loc.emb, L["emb_src"], inp, L["emb_dst"])
+            enc = ans.t5_encoder_forward(inp, B, S, L["mask"], want_grad=False)
+            cross = ans.t5_cross_kv(enc, B, S)
+            state = ans.t5_decode_begin(B, 3)
+            start = torch.zeros(B, dtype=torch.long)
+            lg0 = ans.t5_decode_step(state, start, None, cross, B, L["mask"]).float()
+            if int(min_length) > 1:
+                lg0[:, 1] = float("-inf")
+            first = lg0.argmax(-1).cpu()
+            lg1 = ans.t5_decode_step(state, first, torch.arange(B), cross, B, L["mask"]).float()
+            opt = lg1[:, list(self.ANSWER_IDS)]
+            self.last_option_logits, self.last_first_token = opt.cpu(), first
+            return {"output_text": opt.argmax(-1).cpu().tolist(), "answer": samples.get("qa_output"), "qid": samples.get("question_id"),
+                    "relevant_moments_gt": samples.get("relevant_windows")}
+        finally:
+            ans.training, loc.training = was
+
+    @torch.no_grad()
+    def videoQA_generate(self, samples, num_frames_for_answer=4, use_nucleus_sampling=False, num_beams=5, max_length=50, min_length=8, top_p=0.9,
+                         repetition_penalty=1.0, length_penalty=1.0, num_captions=1, temperature=1, output_attentions=False):
+        """blip2_mr.py:990-1096: stage 1 picks the frames (localizer / oracle windows / whole video), stage 2 answers on them"""
+        samples = dict(samples)
+        samples.setdefault("relevant_windows", [[0, 0]])
+        samples["query_id"] = samples.get("question_id")
+        kw = dict(use_nucleus_sampling=use_nucleus_sampling, num_beams=num_beams, max_length=max_length, min_length=min_length, top_p=top_p,
+                  repetition_penalty=repetition_penalty, length_penalty=length_penalty, num_captions=num_captions, temperature=temperature)
+        moments, frames = self._localize(samples, generate_kwargs=kw)
+        samples["relevant_frames"] = frames
+        out = self.videoQA_answer(samples)
+        out["relevant_moments"] = [moments]
+        return out
 
     @torch.no_grad()
     def generate(self, samples, use_nucleus_sampling=False, num_beams=5, max_length=50, min_length=1, top_p=0.9, repetition_penalty=1.0,
@@ -428,11 +597,14 @@ class BLIP2_MR(BaseModel):
 
     # ------------------------------------------------------------------ checkpoints: trainable tensors only, reference key names
     def state_dict(self, *args, **kwargs):
+        """the tensors that require grad in the reference (runner_base.py:572-598 keeps exactly those): t5_proj, ln_vision and the LoRA
+        tensors of the model that trains — the answerer's in the video-QA variants, whose localizer LoRA is frozen (blip2_mr.py:206-209)"""
         eng = self.engine
         sd = {"t5_proj.weight": eng.proj_w.detach().clone(), "t5_proj.bias": eng.proj_b.detach().clone(),
               "ln_vision.weight": eng.lnv_w.detach().clone(), "ln_vision.bias": eng.lnv_b.detach().clone()}
-        for a in eng.adapters:
-            base = "t5_model.base_model.model." + a.name
+        te = self.train_engine
+        for a in te.adapters:
+            base = te.t5_prefix + "base_model.model." + a.name
             sd[base + ".lora_A.default.weight"] = a.A.detach().clone()
             sd[base + ".lora_B.default.weight"] = a.Bt.detach().t().contiguous()
         return sd
@@ -440,19 +612,25 @@ class BLIP2_MR(BaseModel):
     def load_state_dict(self, state_dict, strict=False):
         eng = self.engine
         own = self.state_dict()
+        engines = [eng] + ([self.answerer] if self.answerer is not None else [])
+        # (video-QA: a moment-retrieval checkpoint brings the LOCALIZER's LoRA under t5_model.*, a QA checkpoint the answerer's)
+        known = set(own) | {e.t5_prefix + "base_model.model." + a.name + sfx for e in engines for a in e.adapters
+                            for sfx in (".lora_A.default.weight", ".lora_B.default.weight")}
         missing = [k for k in own if k not in state_dict]
-        unexpected = [k for k in state_dict if k not in own]
+        unexpected = [k for k in state_dict if k not in known]
         with torch.no_grad():
             for k, dst in (("t5_proj.weight", eng.proj_w), ("t5_proj.bias", eng.proj_b), ("ln_vision.weight", eng.lnv_w), ("ln_vision.bias", eng.lnv_b)):
                 if k in state_dict:
                     dst.copy_(state_dict[k])
-            for a in eng.adapters:
-                base = "t5_model.base_model.model." + a.name
-                if base + ".lora_A.default.weight" in state_dict:
-                    a.A.copy_(state_dict[base + ".lora_A.default.weight"])
-                if base + ".lora_B.default.weight" in state_dict:
-                    a.Bt.copy_(state_dict[base + ".lora_B.default.weight"].t())
-        eng.refresh_trainable()
+            for e in engines:
+                for a in e.adapters:
+                    base = e.t5_prefix + "base_model.model." + a.name
+                    if base + ".lora_A.default.weight" in state_dict:
+                        a.A.copy_(state_dict[base + ".lora_A.default.weight"])
+                    if base + ".lora_B.default.weight" in state_dict:
+                        a.Bt.copy_(state_dict[base + ".lora_B.default.weight"].t())
+        for e in engines:
+            e.refresh_trainable()
         if strict and (missing or unexpected):
             raise RuntimeError(f"missing {missing[:5]} unexpected {unexpected[:5]}")
         return torch.nn.modules.module._IncompatibleKeys(missing, unexpected)

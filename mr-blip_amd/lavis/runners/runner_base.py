@@ -22,7 +22,7 @@ class FlatAdamW:
 
     def __init__(self, model, lr, weight_decay, betas=(0.9, 0.999), eps=1e-8):
         self.model, self.lr, self.wd, self.betas, self.eps = model, lr, weight_decay, betas, eps
-        flat = model.engine.flat
+        flat = getattr(model, "train_engine", model.engine).flat
         self.m, self.v = torch.zeros_like(flat), torch.zeros_like(flat)
         self.t = 0
         self.grad_scale = 1.0
@@ -36,9 +36,13 @@ class FlatAdamW:
 
     @torch.no_grad()
     def step(self):
+        eng = getattr(self.model, "train_engine", self.model.engine)
+        # (the verdict itself is only consumed at a step's ENTRY or at a blocking check point — never between a step and its own AdamW, which
+        # must stay guarded by the error word: mrblip/engine.py check_thin_role)
+        self.t = max(0, self.t - eng.consume_thin_skipped())    # steps the guarded kernel dropped on the device do not count (bias correction)
         self.t += 1
+        eng.note_optimizer_step()
         b1, b2 = self.betas
-        eng = self.model.engine
         scale = self.grad_scale * self.model.grad_scale()
         self.hyper.copy_(torch.tensor([self.lr, 1.0 / (1 - b1 ** self.t), 1.0 / math.sqrt(1 - b2 ** self.t), scale]).pin_memory(), non_blocking=True)
         g, nd = self.model.grad_buffer(), eng.n_decay
@@ -86,10 +90,10 @@ class RunnerBase:
             if multi:
                 from mrblip.dist import GradExchange, broadcast_trainable
                 # what the reference's DDP wrapper does at construction (runner_base.py:89-96): replicas start from rank 0's trainable tensors
-                broadcast_trainable(model.engine)
+                broadcast_trainable(getattr(model, "train_engine", model.engine))
                 # the buffer AdamW reads: the engine's own flat gradient in fused mode (segments are then sent from inside the backward),
                 # model.flat_grad after end_accumulation() (one all-reduce at finish())
-                self.exchange = GradExchange(model.engine, buffer=model.grad_buffer)
+                self.exchange = GradExchange(getattr(model, "train_engine", model.engine), buffer=model.grad_buffer)
         elif multi:
             raise RuntimeError("runner_base: data-parallel training needs a model with a flat gradient buffer (begin_accumulation / grad_buffer, "
                                "i.e. blip2_mr on the MI355X engine); no generic per-parameter all-reduce is built")
@@ -213,9 +217,9 @@ class RunnerBase:
         chk = getattr(m, "check_fused_scale_now", None)
         if chk is not None:
             chk()
-        eng = getattr(m, "engine", None)
-        if eng is not None and hasattr(eng, "check_thin_role"):
-            eng.check_thin_role(block=True)   # (the same deferral, the same two blocking points: end of epoch, before a checkpoint)
+        for eng in (getattr(m, "engine", None), getattr(m, "answerer", None)):
+            if eng is not None and hasattr(eng, "check_thin_role"):
+                eng.check_thin_role(block=True)   # (the same deferral, the same two blocking points: end of epoch, before a checkpoint)
 
     def _save_checkpoint(self, cur_epoch, is_best=False):
         self._check_loss_scale()

@@ -115,13 +115,14 @@ class StateDictSource:
     def get(self, key: str, shape=None) -> torch.Tensor:
         if key in self.sd:
             return self.sd[key]
-        if key.startswith("t5_model."):
-            k2 = "t5_model.base_model.model." + key[len("t5_model."):]
-            if k2 in self.sd:
-                return self.sd[k2]
-            k3 = k2.replace(".weight", ".base_layer.weight")
-            if k3 in self.sd:
-                return self.sd[k3]
+        for pre in ("t5_model.", "answerer_model."):      # (peft wraps both T5s of the video-QA variants the same way)
+            if key.startswith(pre):
+                k2 = pre + "base_model.model." + key[len(pre):]
+                if k2 in self.sd:
+                    return self.sd[k2]
+                k3 = k2.replace(".weight", ".base_layer.weight")
+                if k3 in self.sd:
+                    return self.sd[k3]
         raise KeyError(key)
 
     def has(self, key: str) -> bool:
@@ -203,9 +204,15 @@ def _with_attention_split(fn):
 
 class MrBlipEngine:
     @torch.no_grad()
-    def __init__(self, cfg: EngineConfig, src, device, lora_init: Optional[Callable] = None, seed: Optional[int] = 42):
+    def __init__(self, cfg: EngineConfig, src, device, lora_init: Optional[Callable] = None, seed: Optional[int] = 42,
+                 t5_prefix: str = "t5_model.", share_towers: Optional["MrBlipEngine"] = None):
         """seed: dropout stream of THIS rank (the reference seeds every RNG with run.seed + rank, train.py:57-65); None = derive it
-        from torch's current seed, which train.py's setup_seeds has already offset by the rank."""
+        from torch's current seed, which train.py's setup_seeds has already offset by the rank.
+        t5_prefix / share_towers (round 6, video-QA): the ANSWERER of the two-stage path is a second T5 with its own LoRA under the keys
+        ``answerer_model.*`` (blip2_mr.py:152-161, 206-236) over the SAME frozen ViT / Q-Former as the localizer: share_towers = the
+        localizer's engine, whose packed ViT / Q-Former operands (and Q-Former dropout call sites) this engine then uses instead of
+        packing its own copies; t5_proj / ln_vision are read from ``src`` again (nothing trains them in QA: blip2_mr.py:325-363 runs
+        the frame path under no_grad)."""
         if seed is None:
             seed = int(torch.initial_seed()) & 0x7FFFFFFF
         self.cfg, self.dev = cfg, device
@@ -230,8 +237,17 @@ class MrBlipEngine:
         for nm, v in (("d_model", cfg.d_model), ("t5 inner", inner), ("d_ff", cfg.d_ff), ("qf_dim", cfg.qf_dim), ("qf_inter", cfg.qf_inter)):
             assert v % 64 == 0, f"{nm} must be a multiple of 64 (got {v})"
         assert cfg.vit_dim % 8 == 0 and (cfg.vit_dim // cfg.vit_heads) % 8 == 0 and cfg.vit_dim // cfg.vit_heads <= 96
-        self._build_vit(src)
-        self._build_qformer(src)
+        self.t5_prefix = t5_prefix
+        if share_towers is None:
+            self._build_vit(src)
+            self._build_qformer(src)
+        else:
+            o = share_towers
+            assert o.cfg.vit_dim == cfg.vit_dim and o.cfg.qf_dim == cfg.qf_dim and o.cfg.img == cfg.img and o.dev == self.dev
+            self.vit_kpad, self.vit_fp, self.vit_dtype, self.vit = o.vit_kpad, o.vit_fp, o.vit_dtype, o.vit
+            self.qf, self.ln_vision_eps, self.qf_emb_site = o.qf, o.ln_vision_eps, o.qf_emb_site
+            self._site = o._site_after_towers
+        self._site_after_towers = self._site
         self._build_t5(src, lora_init)
 
     # ------------------------------------------------------------------------------------------ utilities
@@ -592,8 +608,20 @@ class MrBlipEngine:
         Tv = img.shape[0] // F_
         eps, pdrop = 1e-12, c.qf_dropout
         scale = 1.0 / math.sqrt(hd)
-        dimg = self.buf("qf_dimg", (F_ * Tv, Dv), f32)
-        dimg.zero_()
+        dimg = self.buf("qf_dimg", (F_ * Tv, Dv), f32, zero=False)
+        # Round 6 (MRB_QF_KV_BWD_MERGE): the image-token gradient of the cross-attention K / V projections of ALL cross layers as ONE product
+        # [dKV_0 | dKV_1 | ...] x [Wkv_0 | Wkv_1 | ...]^T over K = layers x 2 D (6 x 1536 = 9216) at the end of the backward, instead of one
+        # [F Tv x Dv x 2 D] GEMM per cross layer that read-modify-writes the 87 MB fp32 accumulator (6 x 172 us in the QVH step): nothing but
+        # ln_vision's backward reads d(img), and it runs after the last layer either way.
+        cross_ids = [j for j, L_ in enumerate(self.qf["layers"]) if L_["cross"] is not None]
+        merge_kv = self.qf_kv_bwd_merge and len(cross_ids) > 1
+        if merge_kv:
+            pw = self.qf["layers"][cross_ids[0]]["cross"]["kv_wt"].shape[1]       # pad64(2 D)
+            if self.qf.get("kv_wt_all") is None:
+                self.qf["kv_wt_all"] = torch.cat([self.qf["layers"][j]["cross"]["kv_wt"] for j in cross_ids], dim=1).contiguous()
+            dkv_all = self.buf("qf_dkvc_all", (F_ * Tv, len(cross_ids) * pw), bf16)
+        else:
+            dimg.zero_()
         dy = self.buf("qf_dy", (Mq, D), f32, zero=False)
         dyb = self.buf("qf_dyb", (Mq, pad64(D)), bf16)
         dh = self.buf("qf_dh", (Mq, pad64(I)), bf16, zero=False)
@@ -637,10 +665,12 @@ class MrBlipEngine:
                 else:
                     ops.head_transpose(q4, out=qt_s)
                     ops.head_transpose(do4, out=dot_s)
+                dkv_i, c0 = (dkv_all, cross_ids.index(i) * pw) if merge_kv else (dkv, 0)
                 ops.attention_bwd(q4, k4, v4, self.v4(oc, F_, nq, H, hd), do4, kt_c, qt_x, dot_s, self.ws[f"qf{i}_lsec"], delta,
-                                  self.v4(dqc, F_, nq, H, hd), self.v4(dkv, F_, Tv, H, hd, 0), self.v4(dkv, F_, Tv, H, hd, D),
+                                  self.v4(dqc, F_, nq, H, hd), self.v4(dkv_i, F_, Tv, H, hd, c0), self.v4(dkv_i, F_, Tv, H, hd, c0 + D),
                                   scale=scale, drop=self.qdrop(C_["sites"][0], pdrop))
-                ops.gemm(dkv, C_["kv_wt"], dimg, residual=dimg, tile_cfg=_QF_KV_BWD_CFG)
+                if not merge_kv:
+                    ops.gemm(dkv, C_["kv_wt"], dimg, residual=dimg, tile_cfg=_QF_KV_BWD_CFG)
                 if i > 0:
                     ops.gemm(dqc, C_["q_wt"], nxt, residual=dy)
                     cur = nxt
@@ -670,7 +700,11 @@ class MrBlipEngine:
                               scale=scale, drop=self.qdrop(S_["sites"][0], pdrop))
             ops.gemm(dqkv, S_["qkv_wt"], nxt, residual=dy)
             cur = nxt
+        if merge_kv:
+            ops.gemm(dkv_all, self.qf["kv_wt_all"], dimg, tile_cfg=_QF_KV_BWD_CFG)
         return dimg
+
+    qf_kv_bwd_merge = os.environ.get("MRB_QF_KV_BWD_MERGE", "1") == "1"
 
     # ------------------------------------------------------------------------------------------ T5 + LoRA, t5_proj, ln_vision
     def _build_t5(self, src, lora_init):
@@ -678,7 +712,7 @@ class MrBlipEngine:
         d, inner, ff, V = c.d_model, c.t5_heads * c.d_kv, c.d_ff, c.vocab
         r = c.lora_r
         self.lora_scale = c.lora_alpha / c.lora_r
-        t = "t5_model."
+        t = self.t5_prefix
         groups: List[LoraGroup] = []
         adapters: List[Adapter] = []
 
@@ -1052,8 +1086,10 @@ class MrBlipEngine:
 
     def lg_bwd(self, g: LoraGroup, dy: torch.Tensor, x: torch.Tensor, u: torch.Tensor, gbuf: torch.Tensor, dx: Optional[torch.Tensor],
                residual: Optional[torch.Tensor] = None, side: bool = False, tile_cfg: int = 0, flush: bool = True, tout=None, t_rows: int = 0,
-               prefetch=None, collect: Optional[list] = None, parts: Optional[torch.Tensor] = None, parts_cfg: Tuple[int, int] = (1, 13)):
-        """parts (round 5, [k_splits + 1, M, K_in] fp32 or bf16; dx must be None): the input gradient as PARTIAL products of the 4-wave
+               prefetch=None, collect: Optional[list] = None, parts: Optional[torch.Tensor] = None, parts_cfg: Tuple[int, int] = (1, 13),
+               g_ready: bool = False):
+        """g_ready (round 6): gbuf already holds g = dy (scale B) — the kernel that wrote dy computed it (ops.rmsnorm_bwd(g_prod=)).
+        parts (round 5, [k_splits + 1, M, K_in] fp32 or bf16; dx must be None): the input gradient as PARTIAL products of the 4-wave
         kernel's K-split form (ops.gemm_ksplit, parts_cfg = (k_splits, tile config)); the LoRA term is the last part, unmasked — the
         consumer (ops.rmsnorm_bwd / ops.gated_gelu_bwd) adds the parts and applies this group's lora_dropout mask to it.
 
@@ -1092,7 +1128,7 @@ class MrBlipEngine:
             ops.dec_proj(dy, g.Wt, g.bblk, g.acatt, gbuf, dx, g.N, residual=residual, ext_drop=drop, tout=tout if t_ok else None, t_rows=t_rows)
         elif ks > 1:   # dX by the K-split skinny GEMM: this launch also pre-initialises dx (residual or zero)
             self.lora_thin(dy, g.bblk, gbuf, g.N, seg=seg, init_dst=dx, init_src=residual)
-        else:
+        elif not g_ready:
             self.lora_thin(dy, g.bblk, gbuf, g.N, seg=seg)                  # g' = scale * dy @ B      [M, 8*nad]
         ads = g.adapters
         if self.lora_grads_batch and (collect is not None or (side and self.grad_side_stream_enabled)):
@@ -1273,6 +1309,7 @@ class MrBlipEngine:
     # wi 146.5 -> 79 us, qkv 88 -> 53 us per layer stand-alone (tools/bwd_w4_probe.py).  MRB_ENC_BWD_W4=0: the generic tile with its
     # masked K extension, roles and all (round 4).
     enc_bwd_w4 = os.environ.get("MRB_ENC_BWD_W4", "1") == "1"
+    enc_fuse_g = os.environ.get("MRB_ENC_FUSE_G", "1") == "1"   # round 6: g = dy (scale B) of the wo / o groups from the RMSNorm backward launches (0: lora_thin launches)
     # 1: ONE side-stream hand-over per encoder layer of the backward, at the point where the K^T / Q^T job must leave anyway (behind the wi
     # product): the weight-gradient launch then holds wo, wi of the layer and o, qkv of the layer above and runs beside the o product and
     # the attention backward instead of beside the next layer's thin / wo launches.  0: a second hand-over at the end of the layer.
@@ -1344,6 +1381,14 @@ class MrBlipEngine:
         nb = 2 if batch else 1
         dyb2_s = [self.buf("eb_dyb2" + "_alt" * k, (M, pad64(d)), bf16) for k in range(nb)]
         g_s = [tuple(self.buf(n + "_alt" * k, (M, 64), bf16) for n in ("eb_g", "eb_g2", "eb_g3", "eb_g4")) for k in range(nb)]
+        # Round 6: the rank-8 products g = dy (scale B) of the wo and o groups come out of the RMSNorm backward launches that write their dy
+        # operands (ops.rmsnorm_bwd(g_prod=)): two lora_thin launches per layer (19-48 + 10 us on the main stream) disappear.  The wo group's g
+        # is written by the layer ABOVE, like its dy: three buffers by layer index, as for dyb.
+        L0_ = self.t5["enc"][0]
+        fuse_g = (self.enc_fuse_g and self.fuse_bwd_cast and not (c.lora_mask_per_adapter and self.training and c.lora_dropout > 0)
+                  and all(len(L0_[n].adapters) == 1 and L0_[n].N == d and L0_[n].bblk.shape[0] == 8 for n in ("wo", "o")) and d % 4 == 0 and d <= 2048
+                  and M > max(self.dec_proj_max_rows, 32))     # (fewer rows: the one-launch projection computes g itself)
+        gbw = [self.buf("eb_gw" + "_alt" * k, (M, 64), bf16) for k in range(3)] if fuse_g else None
         dyact = self.buf("eb_dyact", (M, ff), bf16, zero=False)
         # Round 5: the three big input-gradient GEMMs of a layer (wo: [M x ff x d], wi: [M x d x 2 ff], qkv: [M x d x 3 inner]) on the
         # hand-pipelined 4-wave kernel, the [M x d] ones as a K-split that fills the chip; their outputs are parts the consumers add
@@ -1402,16 +1447,18 @@ class MrBlipEngine:
             # and one 16 MB read fewer per sub-layer; only the top layer, whose dx comes from the decoder, casts on its own)
             if not dyb_ready:
                 ops.cast_dropout(dx, out_bf16=dyb, drop=self.drop(L["sites"][3], p))
+            if fuse_g:
+                gb = gbw[i % 3]
             if w4b:
                 self.lg_bwd(L["wo"], dyb, self.ws[f"e{i}_y"], self.ws[f"e{i}_u_wo"], gb, None, side=True, flush=False, collect=layer_jobs,
-                            parts=dyact_p, parts_cfg=cfg_wo)
+                            parts=dyact_p, parts_cfg=cfg_wo, g_ready=fuse_g and dyb_ready)
                 ops.gated_gelu_bwd(dyact_p[0], self.ws[f"e{i}_h"], dh, drop=self.drop(L["sites"][2], p), dy_ext=dyact_p[1],
                                    ext_drop=self.drop(L["wo"].site, c.lora_dropout))
                 self.lg_bwd(L["wi"], dh, self.ws[f"e{i}_xn2"], self.ws[f"e{i}_u_wi"], gb2, None, side=True, collect=layer_jobs,
                             parts=dxn_p_wi, parts_cfg=cfg_wi)
             else:
                 self.lg_bwd(L["wo"], dyb, self.ws[f"e{i}_y"], self.ws[f"e{i}_u_wo"], gb, dyact, side=True, tile_cfg=_ENC_BWD_CFG[0], flush=False,
-                            prefetch=self.enc_pf_bwd([L["wi"]], M), collect=layer_jobs)
+                            prefetch=self.enc_pf_bwd([L["wi"]], M), collect=layer_jobs, g_ready=fuse_g and dyb_ready)
                 ops.gated_gelu_bwd(dyact, self.ws[f"e{i}_h"], dh, drop=self.drop(L["sites"][2], p))
                 self.lg_bwd(L["wi"], dh, self.ws[f"e{i}_xn2"], self.ws[f"e{i}_u_wi"], gb2, dxn, side=True, tile_cfg=_ENC_BWD_CFG[1],
                             prefetch=self.enc_pf_bwd([L["o"]], M), collect=layer_jobs)
@@ -1434,14 +1481,15 @@ class MrBlipEngine:
             dxn_wi = dxn_p_wi if w4b else dxn
             ext_wi = dict(ext_drop=self.drop(L["wi"].site, c.lora_dropout), ext_part=True) if w4b else {}
             if self.fuse_bwd_cast:
-                ops.rmsnorm_bwd(dxn_wi, self.ws[f"e{i}_xm"], L["ln1"], c.t5_eps, other, dx_add=dx, out_bf16=dyb2, out_drop=self.drop(L["sites"][1], p), **ext_wi)
+                ops.rmsnorm_bwd(dxn_wi, self.ws[f"e{i}_xm"], L["ln1"], c.t5_eps, other, dx_add=dx, out_bf16=dyb2, out_drop=self.drop(L["sites"][1], p),
+                                g_prod=(L["o"].bblk, gb3) if fuse_g else None, **ext_wi)
             else:
                 ops.rmsnorm_bwd(dxn_wi, self.ws[f"e{i}_xm"], L["ln1"], c.t5_eps, other, dx_add=dx, **ext_wi)
                 ops.cast_dropout(other, out_bf16=dyb2, drop=self.drop(L["sites"][1], p))
             dx, other = other, dx
             # xm = x_in + drop(o(attn(qkv(xn))))
             dot_done = self.lg_bwd(L["o"], dyb2, self.ws[f"e{i}_o"], self.ws[f"e{i}_u_o"], gb3, do, side=True, tile_cfg=_ENC_BWD_CFG[2], flush=False,
-                                   tout=(dot,) if self.tout_ok(dk, B, S, 2) else None, t_rows=S, collect=layer_jobs)
+                                   tout=(dot,) if self.tout_ok(dk, B, S, 2) else None, t_rows=S, collect=layer_jobs, g_ready=fuse_g)
             qkv, o = self.ws[f"e{i}_qkv"], self.ws[f"e{i}_o"]
             q4, k4, v4 = self.v4(qkv, B, S, H, dk, 0), self.v4(qkv, B, S, H, dk, inner), self.v4(qkv, B, S, H, dk, 2 * inner)
             do4 = self.v4(do, B, S, H, dk)
@@ -1480,7 +1528,8 @@ class MrBlipEngine:
                 grads_done[i] = ev_done
             if i > 0 and self.fuse_bwd_cast:   # ... and the layer below's first operand
                 ops.rmsnorm_bwd(dxn_qkv, self.ws[f"e{i}_xin"], L["ln0"], c.t5_eps, other, dx_add=dx, out_bf16=dyb_pair[(i - 1) % nd],
-                                out_drop=self.drop(self.t5["enc"][i - 1]["sites"][3], p), **ext_qkv)
+                                out_drop=self.drop(self.t5["enc"][i - 1]["sites"][3], p),
+                                g_prod=(self.t5["enc"][i - 1]["wo"].bblk, gbw[(i - 1) % 3]) if fuse_g else None, **ext_qkv)
                 dyb_ready = True
             else:
                 ops.rmsnorm_bwd(dxn_qkv, self.ws[f"e{i}_xin"], L["ln0"], c.t5_eps, other, dx_add=dx, **ext_qkv)
@@ -1710,11 +1759,14 @@ class MrBlipEngine:
         if labels is None:  # generation: logits only
             return None, logits
         lab = dev_in["labels32"] if dev_in is not None else self.h2d(labels.reshape(-1), torch.int32)
-        n_valid = dev_in["n_valid"] if dev_in is not None else int((labels != -100).sum())
         loss = self.buf("loss", (1,), f32)
         loss.zero_()
         dlog = self.buf("d_dlogits", (R, V), bf16, zero=False) if want_grad else None
-        ops.cross_entropy(logits, lab, 1.0 / max(n_valid, 1), loss, dlog)
+        if dev_in is not None:     # captured step: the valid-label count is a device word of the bucket's static set (not part of the key)
+            ops.cross_entropy(logits, lab, 0.0, loss, dlog, n_valid_dev=dev_in["n_valid"])
+        else:                       # (float32 division: the same bits as the device form)
+            import numpy as np
+            ops.cross_entropy(logits, lab, float(np.float32(1.0) / np.float32(max(int((labels != -100).sum()), 1))), loss, dlog)
         return loss, logits
 
     # ---- incremental decoding (generate): self-attention K / V cache, one new position per call
@@ -2101,9 +2153,14 @@ class MrBlipEngine:
 
     @torch.no_grad()
     def forward_backward(self, video: torch.Tensor, layout: EncoderLayout, backward: bool = True, next_video: Optional[torch.Tensor] = None,
-                         shard=None):
+                         shard=None, train_frames: bool = True, frames: Optional[torch.Tensor] = None):
         """One micro-step: loss (device scalar) and, if ``backward``, gradients accumulated into self.grad.  ``next_video`` (optional):
         the next step's clip, whose frozen-ViT forward is overlapped with this step's decoder (see prefetch_vit).
+        ``train_frames`` = False (round 6, the ANSWERER step of the video-QA path, forward_QA blip2_mr.py:325-431): the frame tokens are
+        computed WITHOUT gradient (the reference runs ViT / ln_vision / Q-Former / t5_proj under torch.no_grad there), so the backward ends
+        with the T5's LoRA gradients — no frame-token gradient, no t5_proj / Q-Former / ln_vision backward.  ``frames`` (with
+        train_frames = False; ``video`` is then ignored): the [B * t * n, d_model] fp32 frame tokens themselves, produced by the engine
+        that owns the shared towers (the localizer's).
 
         ``shard`` (mrblip.dist.FrameShard, optional): frame-sharded long-video mode (blip2_mr.py:444-445 — [B, T] is
         just a batch through ViT + Q-Former).  ``video`` then holds only THIS rank's frames [1, T_r, 3, IMG, IMG] of one clip whose
@@ -2113,7 +2170,11 @@ class MrBlipEngine:
         produced the same gradient everywhere, so the "reduce-scatter" of a sharded T5 degenerates to a slice.  The LoRA gradients
         are then identical on all ranks; t5_proj / ln_vision gradients are partial sums over local frames (FrameShard.combine_grads)."""
         c = self.cfg
-        Bv, T = video.shape[:2]
+        if frames is not None:
+            assert not train_frames and next_video is None and shard is None, "precomputed frame tokens: the answerer step (no frame gradient, no look-ahead, no shard)"
+            Bv, T = int(layout.attention_mask.shape[0]), 0
+        else:
+            Bv, T = video.shape[:2]
         F_ = Bv * T
         S, d = layout.S, c.d_model
         n = 1 if c.mean_pool else c.num_query
@@ -2131,10 +2192,13 @@ class MrBlipEngine:
             ops.dec_proj_config(self._reserve_schedule_for(nf)[0][1] if next_video is not None else 0)   # (the first leg's first segment runs beside the decoder)
         self._mark("start")
         self._head_next = next_video if (backward and not sharded) else None
-        fr, img, xv, qb = self.frames_forward(video)
+        if frames is not None:
+            fr, img, xv, qb = frames, None, None, None
+        else:
+            fr, img, xv, qb = self.frames_forward(video)
         self._mark("frames_forward (ViT + ln_vision + Q-Former + t5_proj)")
         dev = self.dev
-        use_graph = self._graph_wanted(Bv, S, backward, sharded)
+        use_graph = self._graph_wanted(Bv, S, backward, sharded) and frames is None
         L = self._layout_dev(layout, static=use_graph)
         inp = self.buf("inputs_embeds", (Bv * S, d), f32, zero=False)
         if sharded:
@@ -2191,8 +2255,8 @@ class MrBlipEngine:
             rec["g2"].replay()
             rec.update(state="ready", loss=loss, dinp=dinp, allocs=self.ws_allocations)
         else:
-            if rec is not None:
-                rec["state"] = "warm"
+            if rec is not None and rec["visits"] + 1 >= self.graph_capture_after:
+                rec["state"] = "warm"          # the NEXT visit of this bucket captures
             if next_video is not None and self.vit_lookahead_early:
                 self.prefetch_vit(next_video)
             enc = t5_part1()
@@ -2208,6 +2272,13 @@ class MrBlipEngine:
             # every LoRA gradient (92 % of the trainable floats) is final here: a data-parallel caller starts their all-reduce now and it
             # runs beside the t5_proj / Q-Former backward below (mrblip/dist.py: GradExchange)
             self.grad_ready_hook("lora")
+        if not train_frames:
+            self._mark("t5_proj + Q-Former backward")
+            if self.grad_ready_hook is not None:
+                self.grad_ready_hook("all")
+            if self.gemm_thin_enabled:
+                self._post_thin_check()
+            return loss
         # interleave backward: only frame-token rows carry gradient (embeddings are frozen)
         dfr = self.buf("dframes", ((shard.T if sharded else F_) * n, d), f32)
         ops.row_copy(dinp, L["frame_dst"], dfr, L["frame_src"])
@@ -2284,15 +2355,30 @@ class MrBlipEngine:
             return False
         return self.graph_mode == "1" or (self.graph_mode == "auto" and B * S <= self.graph_auto_rows)
 
+    # the bucket caches are BOUNDED.  A bucket (shape key) is captured on its ``graph_capture_after``-th visit (earlier visits run
+    # eager: with B > 1 many buckets are seen once), at most ``graph_max_buckets`` captured buckets / static sets are kept, least recently
+    # used first out — an evicted bucket's CUDAGraphs (about 1000 nodes and a private pool each) and its pinned staging sets are released.
+    graph_max_buckets = int(os.environ.get("MRB_GRAPH_MAX_BUCKETS", "16"))
+    graph_capture_after = max(2, int(os.environ.get("MRB_GRAPH_AFTER", "2")))     # (>= 2: the first visit creates the bucket's workspaces)
+    graph_evictions = 0
+
     def _graph_record(self, L: dict, fr: torch.Tensor, lookahead: bool) -> dict:
+        from collections import OrderedDict
         if self._graphs is None:
-            self._graphs = {}
+            self._graphs = OrderedDict()
         key = L["key"] + (bool(self.training), fr.data_ptr(), lookahead, ops.dec_proj_config(-1))
         rec = self._graphs.get(key)
         if rec is None:
-            rec = self._graphs[key] = dict(state="new")
-        elif rec["state"] == "ready":
-            MrBlipEngine.graph_replays += 1
+            rec = self._graphs[key] = dict(state="new", visits=0)
+            while len(self._graphs) > self.graph_max_buckets:
+                _, old = self._graphs.popitem(last=False)
+                old.clear()                      # drops the CUDAGraph objects (g1 / g2) and the tensors they return
+                MrBlipEngine.graph_evictions += 1
+        else:
+            self._graphs.move_to_end(key)
+            if rec["state"] == "ready":
+                MrBlipEngine.graph_replays += 1
+        rec["visits"] = rec.get("visits", 0) + 1
         return rec
 
     def _capture(self, fn, reset_thin: bool = False):
@@ -2321,14 +2407,17 @@ class MrBlipEngine:
     _static_sets: Dict[tuple, dict] = None
 
     def _layout_dev_static(self, layout: EncoderLayout) -> dict:
+        from collections import OrderedDict
         if self._static_sets is None:
-            self._static_sets = {}
+            self._static_sets = OrderedDict()
         B, Ld = layout.labels.shape
         has_k = not bool((layout.attention_mask != 0).all())
         has_d = not bool((layout.decoder_mask != 0).all())
         n_valid = int((layout.labels != -100).sum())
-        key = (B, layout.S, Ld, layout.frame_src.numel(), layout.emb_src.numel(), has_k, has_d, n_valid)
+        key = (B, layout.S, Ld, layout.frame_src.numel(), layout.emb_src.numel(), has_k, has_d)
         st = self._static_sets.get(key)
+        if st is not None:
+            self._static_sets.move_to_end(key)
         i32 = torch.int32
         if st is None:
             def dv(n):
@@ -2336,7 +2425,7 @@ class MrBlipEngine:
 
             def pin(n):
                 return torch.zeros(n, dtype=i32).pin_memory()
-            st = dict(key=key, n_valid=n_valid,
+            st = dict(key=key, n_valid=dv(1),
                       frame_src=dv(layout.frame_src.numel()), frame_dst=dv(layout.frame_dst.numel()), emb_src=dv(layout.emb_src.numel()),
                       emb_dst=dv(layout.emb_dst.numel()), dec_ids32=dv(B * Ld), labels32=dv(B * Ld),
                       dec_rows=torch.arange(B * Ld, dtype=i32, device=self.dev),
@@ -2350,9 +2439,16 @@ class MrBlipEngine:
             st["_slot"] = 0
             st["_last"] = None
             self._static_sets[key] = st
+            while len(self._static_sets) > 2 * self.graph_max_buckets:      # (a set may outlive its graphs' eviction by a while: twice the cap)
+                k_old, old = self._static_sets.popitem(last=False)
+                if self._graphs:
+                    for gk in [gk for gk in self._graphs if gk[:len(k_old)] == k_old]:
+                        self._graphs.pop(gk).clear()
+                        MrBlipEngine.graph_evictions += 1
+                old.clear()
         if st["_last"] is not layout:      # (the same layout object again: the buffers already hold it)
             src = dict(frame_src=layout.frame_src, frame_dst=layout.frame_dst, emb_src=layout.emb_src, emb_dst=layout.emb_dst,
-                       dec_ids32=layout.decoder_input_ids, labels32=layout.labels)
+                       dec_ids32=layout.decoder_input_ids, labels32=layout.labels, n_valid=torch.tensor([n_valid]))
             if has_k:
                 m = torch.zeros(B, ops.rup32(layout.S), dtype=i32)
                 m[:, :layout.S] = layout.attention_mask
@@ -2429,6 +2525,26 @@ class MrBlipEngine:
     def thin_guard(self) -> torch.Tensor:
         return ops.thin_error_word(self.dev)
 
+    # a timeout is loud AND survivable.  thin_fallback (MRB_THIN_FALLBACK, default on): the first set error word switches THIS engine
+    # to the thin product as a launch of its own (gemm_thin_enabled = False: same bits, no in-launch wait, nothing to time out), clears the
+    # word, drops the captured graphs (they hold thin-role launches) and REWINDS the optimizer clock by the steps the guarded AdamW skipped
+    # on the device in the meantime (opt_step here, FlatAdamW.t through consume_thin_skipped) — bias correction then counts applied steps
+    # only — and training continues with a warning.  thin_fallback = False: raise, as in round 5.
+    thin_fallback = os.environ.get("MRB_THIN_FALLBACK", "1") == "1"
+    thin_fallbacks = 0            # how often this engine fell back (0 in every run that owns its GPU)
+    opt_clock = 0                 # optimizer steps ISSUED so far (engine.optimizer_step and the runner's FlatAdamW both tick it)
+    _thin_post_clock = 0
+    _thin_skipped = 0
+
+    def note_optimizer_step(self):
+        self.opt_clock += 1
+
+    def consume_thin_skipped(self) -> int:
+        """optimizer steps that were issued but dropped on the device by the guard since the last call (an external optimizer rewinds its
+        own step count by this much: FlatAdamW)"""
+        n, self._thin_skipped = self._thin_skipped, 0
+        return n
+
     def _post_thin_check(self):
         """enqueue the error word's copy to the host behind everything this step launched"""
         if self._thin_host is None:
@@ -2436,6 +2552,7 @@ class MrBlipEngine:
         self._thin_host.copy_(self.thin_guard(), non_blocking=True)
         self._thin_event = torch.cuda.Event()
         self._thin_event.record()
+        self._thin_post_clock = self.opt_clock
 
     def check_thin_role(self, block: bool = False):
         ev = self._thin_event
@@ -2452,6 +2569,25 @@ class MrBlipEngine:
         self._thin_event = None
         if int(self._thin_host[0]) != 0:
             w = int(self._thin_host[0]) & 0xffffffff
+            if self.thin_fallback and self.gemm_thin_enabled:
+                import logging
+                # every AdamW issued since the check that carried this verdict was posted ran (or will run) with the word set: dropped
+                torch.cuda.synchronize(self.dev)
+                skipped = self.opt_clock - self._thin_post_clock
+                self.gemm_thin_enabled = False
+                self.thin_fallbacks += 1
+                self._thin_skipped += skipped
+                self.opt_step = max(0, self.opt_step - skipped)
+                ops.gemm_thin_clear()
+                self._thin_host.zero_()
+                if self._graphs:
+                    for rec in self._graphs.values():
+                        rec.clear()
+                    self._graphs.clear()
+                logging.warning("mrblip: [error word %#010x: row block %d, workgroup %d] a tile GEMM's bounded wait for its in-launch thin-role "
+                                "workgroups ran out (a shared GPU?).  %d optimizer step(s) were dropped on the device; this engine now runs the LoRA "
+                                "'down' products as launches of their own (same results) and continues.", w, (w >> 16) & 0x7fff, w & 0xffff, skipped)
+                return
             raise ops.MrblipError(
                 f"[error word {w:#010x}: row block {(w >> 16) & 0x7fff}, workgroup {w & 0xffff}] "
                 "a tile GEMM's bounded wait for its in-launch thin-role workgroups (the LoRA 'down' product, csrc/gemm.hip) ran out: the "
@@ -2464,6 +2600,7 @@ class MrBlipEngine:
         """AdamW(beta=(0.9,0.999), wd on >=2-D non-bias/ln params) as in runner_base.py:102-132.  Guarded by the thin role's error word: see
         check_thin_role."""
         self.opt_step += 1
+        self.note_optimizer_step()
         t = self.opt_step
         self.hyper.copy_(torch.tensor([lr, 1.0 / (1 - beta1 ** t), 1.0 / math.sqrt(1 - beta2 ** t), grad_scale], dtype=f32).pin_memory(), non_blocking=True)
         nd = self.n_decay

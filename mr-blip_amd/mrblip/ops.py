@@ -78,6 +78,7 @@ _cast_drop = _sig("mrblip_cast_dropout", vp, ll, vp, ll, vp, ll, i32, i32, vp, u
 _gelu_bwd = _sig("mrblip_gelu_bwd", vp, vp, vp, ll, vp)
 _gated_bwd = _sig("mrblip_gated_gelu_bwd", vp, ll, vp, ll, vp, ll, i32, i32, vp, u32, f32, vp)
 _ce = _sig("mrblip_cross_entropy", vp, ll, vp, i32, i32, f32, vp, vp, ll, vp)
+_ce_nv = _sig("mrblip_cross_entropy_nvalid", vp, ll, vp, i32, i32, vp, vp, vp, ll, vp)
 _adamw = _sig("mrblip_adamw", vp, vp, vp, vp, ll, vp, f32, f32, f32, f32, vp)
 _seed_bump = _sig("mrblip_seed_bump", vp, vp)
 _prefetch = _sig("mrblip_prefetch", vp, ll, i32, vp)
@@ -98,6 +99,10 @@ _gemm_extra = _sig("mrblip_gemm_set_extra", vp, vp, vp, i32, i32, i32, ll, ll, l
 _attn_split_ws = _sig("mrblip_attention_set_split_workspace", vp, ll, i32)
 _gemm_ksplit = _sig("mrblip_gemm_ksplit", vp, ll, vp, ll, vp, ll, vp, ll, i32, i32, i32, vp, ll, ll, i32, i32, i32, vp)
 _rms_bwd_parts = _sig("mrblip_rmsnorm_bwd_parts", vp, ll, i32, ll, i32, u32, f32, vp, ll, vp, i32, i32, f32, vp, ll, vp, ll, vp, ll, vp, u32, f32, vp)
+_rms_bwd_parts_g = _sig("mrblip_rmsnorm_bwd_parts_g", vp, ll, i32, ll, i32, u32, f32, vp, ll, vp, i32, i32, f32, vp, ll, vp, ll, vp, ll, vp, u32, f32, vp, ll, vp, ll, vp)
+_gemm_clear = _sig("mrblip_gemm_clear_one_shots")
+_set_reduce_ws = _sig("mrblip_set_reduce_workspace", vp, ll)
+_lib.mrblip_reduce_workspace_bytes.restype = ll
 _gated_bwd_parts = _sig("mrblip_gated_gelu_bwd_parts", vp, vp, ll, vp, ll, vp, ll, i32, i32, vp, u32, f32, u32, f32, vp)
 _sum_parts = _sig("mrblip_sum_parts", vp, ll, ll, i32, vp, ll, vp, ll, i32, i32, vp)
 _rms_lora = _sig("mrblip_rmsnorm_lora_fwd", vp, ll, vp, i32, i32, f32, vp, ll, vp, ll, i32, vp, ll, vp, u32, f32, vp)
@@ -106,11 +111,11 @@ EXPORTS = [
     "mrblip_last_error", "mrblip_abi_version", "mrblip_gemm_bf16", "mrblip_layernorm_fwd", "mrblip_rmsnorm_fwd",
     "mrblip_layernorm_bwd", "mrblip_rmsnorm_bwd", "mrblip_rmsnorm_bwd_cast", "mrblip_attention_fwd", "mrblip_attention_fwd_rowv", "mrblip_attention_bwd", "mrblip_head_transpose",
     "mrblip_patchify", "mrblip_vit_assemble", "mrblip_row_copy", "mrblip_mean_pool", "mrblip_mean_pool_bwd",
-    "mrblip_cast_dropout", "mrblip_gelu_bwd", "mrblip_gated_gelu_bwd", "mrblip_cross_entropy", "mrblip_adamw", "mrblip_adamw_guarded", "mrblip_gemm_debug_stall_thin",
+    "mrblip_cast_dropout", "mrblip_gelu_bwd", "mrblip_gated_gelu_bwd", "mrblip_cross_entropy", "mrblip_cross_entropy_nvalid", "mrblip_adamw", "mrblip_adamw_guarded", "mrblip_gemm_debug_stall_thin",
     "mrblip_seed_bump", "mrblip_prefetch", "mrblip_gemm_set_prefetch", "mrblip_gemm_set_thin", "mrblip_lora_dx_add", "mrblip_dropout_bf16", "mrblip_colsum", "mrblip_lora_pack", "mrblip_lora_tn",
     "mrblip_lora_grads", "mrblip_lora_grads_batched", "mrblip_gemm_lora_down", "mrblip_gemm_lora_dx", "mrblip_patchify_u8",
     "mrblip_gemm_set_cu_reserve", "mrblip_lora_rows", "mrblip_rmsnorm_lora_fwd", "mrblip_lora_rows_init", "mrblip_dec_proj", "mrblip_dec_proj_config", "mrblip_lora_dx_add_batched", "mrblip_lora_rows_batched", "mrblip_gemm_set_extra", "mrblip_attention_set_split_workspace",
-    "mrblip_gemm_ksplit", "mrblip_rmsnorm_bwd_parts", "mrblip_gated_gelu_bwd_parts", "mrblip_sum_parts",
+    "mrblip_gemm_ksplit", "mrblip_rmsnorm_bwd_parts", "mrblip_rmsnorm_bwd_parts_g", "mrblip_set_reduce_workspace", "mrblip_reduce_workspace_bytes", "mrblip_gemm_clear_one_shots", "mrblip_gated_gelu_bwd_parts", "mrblip_sum_parts",
     "mrblip_gemm_f16", "mrblip_layernorm_fwd_f16", "mrblip_attention_fwd_rowv_f16", "mrblip_patchify_f16", "mrblip_patchify_u8_f16",
 ]
 
@@ -175,45 +180,65 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, aext=None, wext
     g = n // ext_group_n takes columns [64 g, 64 g + 64) of ``aext`` as its K extension (one GEMM for several LoRA groups).
     thin = (acat [R, K'], K', Dropout or None): the launch computes aext[:, :R] = dropout(a)[:, :K'] @ acat^T itself (``lora_rows`` without a
     launch of its own: the first workgroups of the GEMM do it while the tiles run; M > 64)."""
-    f16 = a.dtype == torch.float16   # IEEE fp16 operands (the fp16-operand ViT): both operands, and a 16-bit output, are fp16
-    _req(a, torch.float16 if f16 else torch.bfloat16, "gemm.a"); _req(w, a.dtype, "gemm.w")
-    if out.dtype != torch.float32 and out.dtype != a.dtype:
-        raise MrblipError(f"gemm: 16-bit output must have the operands' dtype ({a.dtype}), got {out.dtype}")
-    M = a.shape[0]
-    N = w.shape[0]
-    K = a.shape[1] if K is None else K
-    sp, site, p = _d(drop)
-    reserve = getattr(_tls, "cu_reserve", 0) if cu_reserve is None else cu_reserve
-    _set_gemm_extra(tout, t_rows, ext_group_n)
-    if thin is not None:
-        acat, tk, tdrop = thin
-        tsp, tsite, tp = _d(tdrop)
-        if sp is None:
-            sp = tsp          # the launch's one seed pointer (the epilogue's own dropout stays off: p = 0)
-        flags, epoch = _thin_flags(a.device, (M + 15) // 16)
-        rc = _gemm_set_thin(_p(acat), _ld(acat), acat.shape[0], int(tk), tsite, tp, _p(flags), flags.numel(), epoch, _p(thin_error_word(a.device)))
-        if rc != 0:
-            msg = _lib.mrblip_last_error().decode()
-            _clear_one_shots()     # the extras set above belong to THIS call: they must not ride on the thread's next unrelated GEMM
-            raise MrblipError(msg)
-    _chk((_gemm_f16 if f16 else _gemm)(_p(a), _ld(a), _p(w), _ld(w), _p(aext), _ld(aext), _p(wext), _ld(wext), M, N, K, _p(out), _ld(out),
-               1 if out.dtype == torch.float32 else 0, _p(out2), _ld(out2), _p(bias), _p(residual), _ld(residual), act,
-               1 if gated else 0, sp, site, p, (tile_cfg & 0xff) | ((int(reserve) & 0x1ff) << 8) | ((int(k_splits) & 0xf) << 17), _stream()))
+    try:     # (the one-shots set below — and a prefetch range the caller set before this call — belong to THIS launch: an exception on the way drops them)
+        f16 = a.dtype == torch.float16   # IEEE fp16 operands (the fp16-operand ViT): both operands, and a 16-bit output, are fp16
+        _req(a, torch.float16 if f16 else torch.bfloat16, "gemm.a"); _req(w, a.dtype, "gemm.w")
+        if out.dtype != torch.float32 and out.dtype != a.dtype:
+            raise MrblipError(f"gemm: 16-bit output must have the operands' dtype ({a.dtype}), got {out.dtype}")
+        M = a.shape[0]
+        N = w.shape[0]
+        K = a.shape[1] if K is None else K
+        sp, site, p = _d(drop)
+        reserve = getattr(_tls, "cu_reserve", 0) if cu_reserve is None else cu_reserve
+        _set_gemm_extra(tout, t_rows, ext_group_n)
+        if thin is not None:
+            acat, tk, tdrop = thin
+            tsp, tsite, tp = _d(tdrop)
+            if sp is None:
+                sp = tsp          # the launch's one seed pointer (the epilogue's own dropout stays off: p = 0)
+            flags, epoch = _thin_flags(a.device, (M + 15) // 16)
+            if _gemm_set_thin(_p(acat), _ld(acat), acat.shape[0], int(tk), tsite, tp, _p(flags), flags.numel(), epoch, _p(thin_error_word(a.device))) != 0:
+                raise MrblipError(_lib.mrblip_last_error().decode())
+        _chk((_gemm_f16 if f16 else _gemm)(_p(a), _ld(a), _p(w), _ld(w), _p(aext), _ld(aext), _p(wext), _ld(wext), M, N, K, _p(out), _ld(out),
+                   1 if out.dtype == torch.float32 else 0, _p(out2), _ld(out2), _p(bias), _p(residual), _ld(residual), act,
+                   1 if gated else 0, sp, site, p, (tile_cfg & 0xff) | ((int(reserve) & 0x1ff) << 8) | ((int(k_splits) & 0xf) << 17), _stream()))
+    except BaseException:
+        _clear_one_shots()
+        raise
     return out
 
 
 _tls = threading.local()
 _thin_state = {}
+_reduce_state = {}
+
+
+def _reduce_ws(device):
+    """Register the ordered-reduction workspace of the CURRENT stream with the library (mrblip_set_reduce_workspace) for the launch that
+    follows: cross_entropy, colsum and layernorm_bwd(dgamma) add their partial sums in a fixed order through caller-owned scratch + tickets,
+    and launches on different streams must not share them — one zeroed buffer per (device, stream), allocated once and never moved (a
+    captured graph keeps its address)."""
+    key = (device.index, _stream())
+    ws = _reduce_state.get(key)
+    if ws is None:
+        ws = _reduce_state[key] = torch.zeros(int(_lib.mrblip_reduce_workspace_bytes()), dtype=torch.uint8, device=device)
+    if _set_reduce_ws(ws.data_ptr(), ws.numel()) != 0:
+        raise MrblipError(_lib.mrblip_last_error().decode())
+
+
+THIN_FLAG_WORDS = 1 << 17     # flag words per (device, stream): one per 16 rows -> GEMMs of up to ~2 M rows
 
 
 def _thin_flags(device, n: int):
     """(flag words, fresh epoch) for a GEMM with the thin role on the CURRENT stream: launches of one stream are ordered, so they share a
-    buffer and tell their flags apart by the epoch; another stream gets its own buffer"""
+    buffer and tell their flags apart by the epoch; another stream gets its own buffer.  The buffer is allocated ONCE at its maximum size
+    and never replaced: a captured graph bakes its address (and a fill of it) in, and a replaced buffer would be freed under it."""
     key = (device.index, _stream())
     st = _thin_state.get(key)
-    if st is None or st[0].numel() < n + 4:      # flags | ticket, finished count (the kernel keeps them at zero between launches) | spare
-        st = [torch.zeros(max(n + 4, 1024), dtype=torch.int32, device=device), 0]
-        _thin_state[key] = st
+    if st is None:      # flags | ticket, finished count (the kernel keeps them at zero between launches) | spare
+        st = _thin_state[key] = [torch.zeros(THIN_FLAG_WORDS, dtype=torch.int32, device=device), 0]
+    if n + 4 > st[0].numel():
+        raise MrblipError(f"gemm thin role: {n} row blocks exceed the flag buffer ({st[0].numel() - 4}); run this launch without the thin role")
     st[1] = st[1] % 0x7fffffff + 1
     return st[0], st[1]
 
@@ -240,7 +265,7 @@ def thin_flags_reset(device):
     key = (device.index, _stream())
     st = _thin_state.get(key)
     if st is None:
-        _thin_state[key] = [torch.zeros(4096, dtype=torch.int32, device=device), 0]
+        _thin_state[key] = [torch.zeros(THIN_FLAG_WORDS, dtype=torch.int32, device=device), 0]
     else:
         st[0].zero_()
 
@@ -272,8 +297,7 @@ class gemm_debug_stall_thin:
 def _clear_one_shots():
     """drop the calling thread's pending one-shot GEMM extras (head-transposed copies, grouped K extension, prefetch range) after a
     failure between their setters and the launch they were meant for"""
-    _gemm_extra(None, None, None, 0, 0, 0, 0, 0, 0, 0, 0)
-    _gemm_set_prefetch(None, 0, None, 0, 0)
+    _gemm_clear()
 
 
 def _set_gemm_extra(tout, t_rows: int, ext_group_n: int = 0):
@@ -333,14 +357,30 @@ def rmsnorm_fwd(x, weight, eps, out_bf16=None, out_f32=None):
 
 def layernorm_bwd(dy, x, gamma, eps, dx, dx_add=None, dgamma=None, dbeta=None):
     M, D = x.shape
+    if dgamma is not None:
+        _reduce_ws(x.device)
     _chk(_ln_bwd(_p(dy), _ld(dy), _p(x), _ld(x), _p(gamma), M, D, eps, _p(dx_add), _ld(dx_add), _p(dx), _ld(dx), _p(dgamma), _p(dbeta), _stream()))
 
 
-def rmsnorm_bwd(dy, x, weight, eps, dx, dx_add=None, out_bf16=None, out_drop: Optional["Dropout"] = None, ext_drop: Optional["Dropout"] = None, ext_part: bool = False):
+def rmsnorm_bwd(dy, x, weight, eps, dx, dx_add=None, out_bf16=None, out_drop: Optional["Dropout"] = None, ext_drop: Optional["Dropout"] = None, ext_part: bool = False,
+                g_prod=None):
     """out_bf16 (optional): also write bf16(dropout-backward(dx)) for the mask of ``out_drop`` — the next GEMM's operand, saving the
     separate cast_dropout launch and its read of dx.  dy of 3 dims [parts, M, D]: partial products (gemm_ksplit), added in part order;
-    ext_part: the last one is the LoRA term, added under the keep mask of ``ext_drop``."""
+    ext_part: the last one is the LoRA term, added under the keep mask of ``ext_drop``.
+    g_prod = (g_b bf16 [8, >= D], g_out bf16 [M, >= 8]) (needs out_bf16): also g_out[:, :8] = out_bf16 @ g_b[:, :D]^T — the LoRA "g" product
+    of the projection that consumes out_bf16 (what ``lora_rows(out_bf16, g_b, g_out, D)`` would compute in a launch of its own)."""
     M, D = x.shape
+    if g_prod is not None:
+        g_b, g_out = g_prod
+        assert out_bf16 is not None and g_b.shape[0] == 8 and g_b.dtype == torch.bfloat16 and g_out.dtype == torch.bfloat16
+        parts = dy if dy.dim() == 3 else dy.unsqueeze(0)
+        sp, site, p = _d(out_drop)
+        esp, esite, ep = _d(ext_drop)
+        assert parts.stride(2) == 1 and (sp == esp or not sp or not esp)
+        _chk(_rms_bwd_parts_g(_p(parts), parts.stride(1), parts.shape[0], parts.stride(0), 1 if ext_part else 0, esite, ep, _p(x), _ld(x), _p(weight), M, D, eps,
+                              _p(dx_add), _ld(dx_add), _p(dx), _ld(dx), _p(out_bf16), _ld(out_bf16), sp or esp, site, p,
+                              _p(g_b), _ld(g_b), _p(g_out), _ld(g_out), _stream()))
+        return
     if dy.dim() == 3:
         sp, site, p = _d(out_drop)
         esp, esite, ep = _d(ext_drop)
@@ -380,6 +420,7 @@ def head_transpose(x: torch.Tensor, out: Optional[torch.Tensor] = None, spad: in
 
 def colsum(x, out):
     M, N = x.shape
+    _reduce_ws(x.device)
     _chk(_colsum(_p(x), _ld(x), M, N, _p(out), _stream()))
 
 
@@ -554,10 +595,15 @@ def lora_dx(dy, wt, g, acatt, dx, K, residual=None, drop: Optional[Dropout] = No
     M = dy.shape[0]
     N = wt.shape[0]
     sp, site, p = _d(drop)
-    _set_gemm_extra(tout, t_rows)
-    _chk(_gemm_lora_dx(_p(dy), _ld(dy), _p(wt), _ld(wt), _p(g), _ld(g), _p(acatt), _ld(acatt), M, N, K, _p(dx), _ld(dx),
-                  1 if dx.dtype == torch.float32 else 0, _p(residual), _ld(residual) if residual is not None else 0, sp, site, p,
-                  (tile_cfg & 0xff) | ((int(k_splits) & 0xf) << 17), _stream()))
+    try:
+        _req(dy, torch.bfloat16, "lora_dx.dy"); _req(wt, torch.bfloat16, "lora_dx.wt")
+        _set_gemm_extra(tout, t_rows)
+        _chk(_gemm_lora_dx(_p(dy), _ld(dy), _p(wt), _ld(wt), _p(g), _ld(g), _p(acatt), _ld(acatt), M, N, K, _p(dx), _ld(dx),
+                      1 if dx.dtype == torch.float32 else 0, _p(residual), _ld(residual) if residual is not None else 0, sp, site, p,
+                      (tile_cfg & 0xff) | ((int(k_splits) & 0xf) << 17), _stream()))
+    except BaseException:
+        _clear_one_shots()
+        raise
 
 
 def dropout_bf16(x, out, drop: Optional[Dropout] = None):
@@ -680,8 +726,13 @@ def gemm_ksplit(a, w, parts, K: int, k_splits: int, ext=None, tile_cfg: int = 13
                       1 if parts.dtype == torch.float32 else 0, int(k_splits), int(tile_cfg), _stream()))
 
 
-def cross_entropy(logits, labels_i32, inv_count, loss, dlogits=None):
+def cross_entropy(logits, labels_i32, inv_count, loss, dlogits=None, n_valid_dev=None):
+    """n_valid_dev (int32 device tensor): inv_count = 1 / max(n_valid, 1) is computed on the device instead (inv_count is then ignored)"""
     R, V = logits.shape
+    _reduce_ws(logits.device)
+    if n_valid_dev is not None:
+        _chk(_ce_nv(_p(logits), _ld(logits), _p(labels_i32), R, V, _p(n_valid_dev), _p(loss), _p(dlogits), _ld(dlogits), _stream()))
+        return
     _chk(_ce(_p(logits), _ld(logits), _p(labels_i32), R, V, inv_count, _p(loss), _p(dlogits), _ld(dlogits), _stream()))
 
 

@@ -203,6 +203,27 @@ def build_layout(tokenizer, samples: dict, repl: Dict[int, int], n_per_frame: in
                          decoder_mask=ans.attention_mask.int())
 
 
+def build_qa_layout(tokenizer, qa_input: Sequence[str], qa_output: Sequence[str], n_frame_tokens: int, max_txt_len: int = 200) -> EncoderLayout:
+    """Answerer input of the video-QA path (forward_QA, blip2_mr.py:365-405): [ all t * n frame tokens of the clip (mask 1) | question tokens
+    (right padded, mask 0 on the pads) ]; labels = the answer's tokens with the pads at -100, decoder mask = the answer's attention mask."""
+    q = tokenizer(list(qa_input), padding="longest", truncation=True, max_length=max_txt_len, return_tensors="pt")
+    B, Lq, Lf = q.input_ids.shape[0], q.input_ids.shape[1], int(n_frame_tokens)
+    S = Lf + Lq
+    f_src, f_dst, e_src, e_dst = [], [], [], []
+    mask = torch.ones(B, S, dtype=torch.int32)
+    for j in range(B):
+        f_src.extend(j * Lf + r for r in range(Lf))
+        f_dst.extend(j * S + r for r in range(Lf))
+        e_src.extend(int(t) for t in q.input_ids[j].tolist())
+        e_dst.extend(j * S + Lf + s for s in range(Lq))
+        mask[j, Lf:] = q.attention_mask[j].int()
+    ans = tokenizer(list(qa_output), padding="longest", truncation=True, max_length=max_txt_len, return_tensors="pt")
+    labels = ans.input_ids.masked_fill(ans.input_ids == tokenizer.pad_token_id, -100)
+    i32 = lambda x: torch.tensor(x, dtype=torch.int32)  # noqa: E731
+    return EncoderLayout(S=S, frame_src=i32(f_src), frame_dst=i32(f_dst), emb_src=i32(e_src), emb_dst=i32(e_dst), attention_mask=mask,
+                         labels=labels, decoder_input_ids=shift_right(labels), decoder_mask=ans.attention_mask.int())
+
+
 def relative_position_bucket(rel: int, bidirectional: bool, num_buckets: int = 32, max_distance: int = 128) -> int:
     """T5 bucket of one relative position (memory - query).  Integer restatement of modeling_t5.py:392-445: the log
     branch is evaluated in float32 like the reference's tensor code, then truncated."""

@@ -316,17 +316,21 @@ class Oracle:
         return x
 
     # ---- T5 with optional LoRA (modeling_t5.py:254-277, 314-329, 350-620, 697-826, 1021-1282, 1734-1893)
+    # which T5 of the state dict the t5_* methods read: "t5_model." (the localizer / moment-retrieval model) or "answerer_model." (the second
+    # T5 of the video-QA variants, blip2_mr.py:152-161)
+    t5_prefix = "t5_model."
+
     def _t5w(self, name: str) -> Tuple[Tensor, Optional[Tensor], Optional[Tensor]]:
         """weights of T5 Linear `name` (e.g. 'encoder.block.0.layer.0.SelfAttention.q'): plain or peft naming."""
-        k = "t5_model." + name + ".weight"
+        k = self.t5_prefix + name + ".weight"
         if k in self.sd:
             return self.sd[k], None, None
-        b = "t5_model.base_model.model." + name
+        b = self.t5_prefix + "base_model.model." + name
         return self.sd[b + ".base_layer.weight"], self.sd.get(b + ".lora_A.default.weight"), self.sd.get(b + ".lora_B.default.weight")
 
     def _t5p(self, name: str) -> Tensor:
-        k = "t5_model." + name
-        return self.sd[k] if k in self.sd else self.sd["t5_model.base_model.model." + name]
+        k = self.t5_prefix + name
+        return self.sd[k] if k in self.sd else self.sd[self.t5_prefix + "base_model.model." + name]
 
     def t5lin(self, x: Tensor, name: str) -> Tensor:
         w, a, b = self._t5w(name)
@@ -502,6 +506,109 @@ class Oracle:
         self._tower = "head"
         logits = self.t5lin(dec[:, -1:], "lm_head")[:, 0]
         return torch.log_softmax(logits.float(), -1)
+
+
+    # ---- video-QA two-stage path (blip2_mr.py:309-431, 948-1314) -------------------------------------------------------------------
+    @staticmethod
+    def extract_frames(video: Tensor, timestamps: Tensor, durations: Tensor, moments, n_frames: int):
+        """blip2_mr.py:1127-1164: per clip the frames whose timestamps are closest to [start, end] (start >= end: end = duration), padded
+        with the last one / thinned with linspace(...).long() to n_frames.  Returns (frames [B, n, 3, H, W], index lists)."""
+        out, idxs = [], []
+        for i, (start, end) in enumerate(moments):
+            if start >= end:
+                end = durations[i].item()
+            s_i = torch.argmin(torch.abs(timestamps[i] - start)).item()
+            e_i = torch.argmin(torch.abs(timestamps[i] - end)).item()
+            ids = list(range(s_i, e_i + 1))
+            assert len(ids) > 0, "No frames found for the relevant moment."
+            if len(ids) < n_frames:
+                ids = ids + [ids[-1]] * (n_frames - len(ids))
+            elif len(ids) > n_frames:
+                ids = [ids[j] for j in torch.linspace(0, len(ids) - 1, n_frames).long().tolist()]
+            idxs.append(ids)
+            out.append(video[i, ids])
+        return torch.stack(out), idxs
+
+    @staticmethod
+    def relevant_moments(preds: Sequence[str], durations: Tensor):
+        """blip2_mr.py:1098-1117 (get_relevant_frames): the localizer's answer string -> ONE [start, end] per clip (no window -> the whole
+        video; several -> the first; an end beyond the duration -> round(duration))."""
+        out = []
+        for i, sample in enumerate(preds):
+            m = moment_str_to_list(sample)
+            if m == [[-1, -1]]:
+                m = [0, durations[i].item()]
+            else:
+                m = m[0]
+            if m[1] > durations[i].item():
+                m[1] = round(durations[i].item())
+            out.append(m)
+        return out
+
+    def frame_tokens(self, frames: Tensor, mean_pool: bool = False) -> Tensor:
+        """get_frame_embeddings_and_attentions (blip2_mr.py:948-988): [B, t, 3, H, W] -> [B, t * n, d] (attention mask: all ones)"""
+        b, t = frames.shape[:2]
+        with torch.no_grad():
+            f = self.lin(self.qformer(self.ln_vision(self.vit(frames.reshape(b * t, *frames.shape[2:])))), self.P("t5_proj.weight"), self.P("t5_proj.bias"))
+        if mean_pool:
+            f = f.mean(dim=1, keepdim=True)
+        return f.reshape(b, t * f.shape[1], -1)
+
+    def qa_inputs(self, tok, frames_for_t5: Tensor, qa_input: Sequence[str], max_txt_len: int = 200):
+        """[ frame tokens | question tokens (right padded, mask 0 on the pads) ] with the ANSWERER's embedding table (blip2_mr.py:365-383)"""
+        q = tok(list(qa_input), padding="longest", truncation=True, max_length=max_txt_len, return_tensors="pt")
+        emb = self._t5p("shared.weight")
+        embs = torch.cat([frames_for_t5, emb[q.input_ids]], 1)
+        atts = torch.cat([torch.ones(frames_for_t5.shape[:2], dtype=torch.long), q.attention_mask], 1)
+        return embs, atts
+
+    def forward_qa(self, tok, samples: dict, n_frames: int, moments=None, mean_pool: bool = False, max_txt_len: int = 200):
+        """forward_QA (blip2_mr.py:309-431).  moments = None: uniform sampling over the whole video (use_localizer False); otherwise the
+        [start, end] per clip the localizer stage produced (``relevant_moments`` of its generate() output).  The frame features come
+        out of the shared ViT / ln_vision / Q-Former / t5_proj WITHOUT gradient; the loss is the answerer T5's."""
+        if moments is None:
+            moments = [[0, d.item()] for d in samples["duration"]]
+        frames, idxs = self.extract_frames(samples["video"], samples["timestamps"], samples["duration"], moments, n_frames)
+        f = self.frame_tokens(frames, mean_pool)
+        prev, self.t5_prefix = self.t5_prefix, "answerer_model."
+        try:
+            embs, atts = self.qa_inputs(tok, f, samples["qa_input"], max_txt_len)
+            ans = tok(list(samples["qa_output"]), padding="longest", truncation=True, max_length=max_txt_len, return_tensors="pt")
+            labels = ans.input_ids.masked_fill(ans.input_ids == tok.pad_token_id, -100)
+            loss, logits, enc = self.t5_loss(embs, atts, labels, ans.attention_mask)
+        finally:
+            self.t5_prefix = prev
+        return dict(loss=loss, logits=logits, inputs_embs=embs, inputs_atts=atts, labels=labels, enc=enc, frame_idx=idxs, frames=f)
+
+    ANSWER_IDS = (71, 272, 205, 309, 262)   # "A" .. "E" in the flan-t5 vocabulary (blip2_mr.py:1299)
+
+    def qa_answer(self, tok, samples: dict, n_frames: int, moments=None, mean_pool: bool = False, min_length: int = 8, max_txt_len: int = 200):
+        """videoQA_answer (blip2_mr.py:1237-1314): greedy answerer_model.generate(num_beams=1, min_length=8, output_scores=True) and the
+        argmax of the SECOND step's scores over the five option tokens.  Restated: HF's greedy search evaluates step 0 from the decoder
+        start token (EOS is suppressed while the sequence is shorter than min_length: MinLengthLogitsProcessor), appends its argmax and
+        evaluates step 1; `scores` are the processed logits, whose option columns equal the raw ones.  Returns (predicted option index per
+        clip, option logits [B, 5], first greedy token).  (The question is embedded with the LOCALIZER's table there, blip2_mr.py:1262.)"""
+        if moments is None:
+            moments = [[0, d.item()] for d in samples["duration"]]
+        frames, _ = self.extract_frames(samples["video"], samples["timestamps"], samples["duration"], moments, n_frames)
+        f = self.frame_tokens(frames, mean_pool)
+        embs, atts = self.qa_inputs(tok, f, samples["qa_input"], max_txt_len)          # t5_model.encoder.embed_tokens
+        prev, self.t5_prefix = self.t5_prefix, "answerer_model."
+        try:
+            with torch.no_grad():
+                enc = self.t5_encoder(embs, atts)
+                B = embs.shape[0]
+                seqs = torch.zeros(B, 1, dtype=torch.long)
+                lp0 = self.next_token_logprobs(seqs, enc, atts)
+                if min_length > 1:
+                    lp0[:, 1] = float("-inf")
+                first = lp0.argmax(-1)
+                dec = self.t5_decoder(torch.cat([seqs, first[:, None]], 1), torch.ones(B, 2, dtype=torch.long), enc, atts)
+                logits1 = self.t5lin(dec[:, -1:], "lm_head")[:, 0].float()
+        finally:
+            self.t5_prefix = prev
+        opt = logits1[:, list(self.ANSWER_IDS)]
+        return opt.argmax(-1).tolist(), opt, first
 
 
 # ====================================================================================== dropout mask restatement

@@ -49,7 +49,7 @@ def test_two_rank_gradient_equals_single_rank_batch(tmp_path, overlap):
     tag = "dp2 (overlap=%d): " % overlap
     print(tag, "rank losses", dp["losses"].tolist(), "single-rank per-clip losses", ls, "batch loss", l2)
     # (the CE kernel sums its rows with fp32 atomics: a loss of ~10.45 moves by 1-2 ulp = 1-2e-6 between two runs of the same step)
-    check(tag + "rank losses vs single-rank per-clip losses", float((dp["losses"] - torch.tensor(ls)).abs().max()), 4e-6)
+    check(tag + "rank losses vs single-rank per-clip losses", float((dp["losses"] - torch.tensor(ls)).abs().max()), 2e-7)    # (measured 0)
     check(tag + "exchanged grad vs accumulated micro-steps / 2", relerr(dp["grad"], g_acc), 1e-7)
     check(tag + "exchanged grad vs 2-clip batch on one rank", relerr(dp["grad"], g_batch), 1.5e-2)
     check(tag + "batch loss vs mean of rank losses", abs(l2 - float(dp["losses"].mean())) / abs(l2), 6e-5)

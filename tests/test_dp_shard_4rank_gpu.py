@@ -50,8 +50,8 @@ def test_clips_times_two_frame_shards_on_four_and_eight_ranks(tmp_path, world):
     nl = sh["n_lora"]
     tag = "DP x frame shard (%d clips x 2 shards, %d ranks): " % (nclip, world)
     assert all(sh["losses"][2 * c] == sh["losses"][2 * c + 1] for c in range(nclip))         # a pair runs one replicated T5
-    check(tag + "pair losses vs the clips' own losses", max(abs(sh["losses"][2 * c] - losses[c]) / abs(losses[c]) for c in range(nclip)), 2e-6)
+    check(tag + "pair losses vs the clips' own losses", max(abs(sh["losses"][2 * c] - losses[c]) / abs(losses[c]) for c in range(nclip)), 2e-7)   # (measured 0)
     check(tag + "slowest rank's host enqueue of one tiny step [ms] (recorded, not a parity bound)", max(sh["host_enqueue_ms"]), 5e3)
-    check(tag + "LoRA gradients vs mean of the unsharded clips", relerr(sh["grad"][:nl], ref[:nl]), 2e-5)
-    check(tag + "t5_proj / ln_vision gradients vs mean of the unsharded clips", relerr(sh["grad"][nl:], ref[nl:]), 2e-5)
+    check(tag + "LoRA gradients vs mean of the unsharded clips", relerr(sh["grad"][:nl], ref[:nl]), 3e-7)     # (measured 2.9e-8 / 5.3e-8: the mean over clips in another order)
+    check(tag + "t5_proj / ln_vision gradients vs mean of the unsharded clips", relerr(sh["grad"][nl:], ref[nl:]), 3.5e-7)   # (measured 2.9e-8 / 6.2e-8)
     assert ref[nl:].abs().sum() > 0 and ref[:nl].abs().sum() > 0

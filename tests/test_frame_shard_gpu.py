@@ -41,10 +41,10 @@ def test_frame_sharded_step_equals_unsharded(tmp_path, mean):
     ref = eng.grad.cpu()
     nl = sh["n_lora"]
     tag = "frame-shard x2 (mean_pool=%d): " % mean
-    check(tag + "loss vs unsharded", abs(sh["loss"] - loss) / abs(loss), 2e-6)
-    check(tag + "LoRA grads vs unsharded", relerr(sh["grad"][:nl], ref[:nl]), 2e-5)
+    check(tag + "loss vs unsharded", abs(sh["loss"] - loss) / abs(loss), 2e-7)    # (measured 0: the replicated T5 sees the same bits)
+    check(tag + "LoRA grads vs unsharded", relerr(sh["grad"][:nl], ref[:nl]), 2e-7)    # (measured 0)
     check(tag + "LoRA grads rank 1 vs rank 0 (replicated T5)", relerr(sh["grad_other"][:nl], sh["grad"][:nl]), 1e-7)
-    check(tag + "t5_proj / ln_vision grads (summed over ranks) vs unsharded", relerr(sh["grad"][nl:], ref[nl:]), 2e-5)
+    check(tag + "t5_proj / ln_vision grads (summed over ranks) vs unsharded", relerr(sh["grad"][nl:], ref[nl:]), 2e-7)    # (measured 1.6e-8 / 3.4e-8: one more fp32 add per element)
     check(tag + "combined tail identical on both ranks", relerr(sh["grad_other"][nl:], sh["grad"][nl:]), 1e-7)
     assert ref[nl:].abs().sum() > 0
 

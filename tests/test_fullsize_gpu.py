@@ -310,15 +310,15 @@ def test_c2_benched_size_against_reference():
     check("c2.ln_vision vs reference-fp32", relerr(eng.ws["img"].view(T, Tv, -1)[::6, ::16, :1408:16].float().cpu(), g["ln_sub"]), 1.3e-2)
     check("c2.qformer.out vs reference-fp32", relerr(eng._qf_last_f32.view(T, 32, 768)[::6, ::4, ::8].cpu(), g["qf_sub"]), 5e-3)
     check("c2.inputs_embeds vs reference-fp32", relerr(eng.ws["inputs_embeds"].view(1, S, d)[:, ::4, ::16].cpu(), g["inputs_embs_sub"]), 8e-3)
-    check("c2.t5.enc_out (24 layers, XL) vs reference-fp32", relerr(eng.ws["e_out"][:, :d].float().view(1, S, d)[:, ::4, ::16].cpu(), g["enc_sub"]), 2.5e-2)
+    check("c2.t5.enc_out (24 layers, XL) vs reference-fp32", relerr(eng.ws["e_out"][:, :d].float().view(1, S, d)[:, ::4, ::16].cpu(), g["enc_sub"]), 1.6e-2)   # (measured 1.02e-2)
     logits = eng.ws["d_logits"].view(1, -1, 32128).cpu()
-    check("c2.logits vs reference-fp32", relerr(logits[..., ::64], g["logits_sub"]), 2.4e-2)
+    check("c2.logits vs reference-fp32", relerr(logits[..., ::64], g["logits_sub"]), 1.5e-2)   # (measured 9.25e-3: bf16 operand rounding; north_star's 1e-3 is met by the fp32-operand mode, 1.5e-5)
     check("c2.logits_lse vs reference-fp32", relerr(torch.logsumexp(logits, -1), g["logits_lse"]), 1e-5)
     check("c2.loss vs reference-fp32 (rel)", abs(loss.item() - float(g["loss"])) / abs(float(g["loss"])), 6e-4)   # (bf16 rounding of the towers: 2.7e-5 .. 1.7e-4 between builds; C1: 4.6e-4)
-    check("c2.grad t5_proj.weight vs reference-fp32 autograd", relerr(eng.dproj_w.cpu()[::16, ::4], g["grad__t5_proj__weight"]), 5e-2)
-    check("c2.grad t5_proj.bias vs reference-fp32 autograd", relerr(eng.dproj_b.cpu(), g["grad__t5_proj__bias"]), 5e-2)
-    check("c2.grad ln_vision.weight vs reference-fp32 autograd", relerr(eng.dlnv_w.cpu(), g["grad__ln_vision__weight"]), 5e-2)
-    check("c2.grad ln_vision.bias vs reference-fp32 autograd", relerr(eng.dlnv_b.cpu(), g["grad__ln_vision__bias"]), 5e-2)
+    check("c2.grad t5_proj.weight vs reference-fp32 autograd", relerr(eng.dproj_w.cpu()[::16, ::4], g["grad__t5_proj__weight"]), 3e-2)   # (measured 2.05e-2 / 1.73e-2 / 1.65e-2 / 1.69e-2)
+    check("c2.grad t5_proj.bias vs reference-fp32 autograd", relerr(eng.dproj_b.cpu(), g["grad__t5_proj__bias"]), 3e-2)
+    check("c2.grad ln_vision.weight vs reference-fp32 autograd", relerr(eng.dlnv_w.cpu(), g["grad__ln_vision__weight"]), 3e-2)
+    check("c2.grad ln_vision.bias vs reference-fp32 autograd", relerr(eng.dlnv_b.cpu(), g["grad__ln_vision__bias"]), 3e-2)
     del eng
     torch.cuda.empty_cache()
 

@@ -205,8 +205,9 @@ def test_training_mode_dropout_parity(per_adapter):
     ref = orc.forward_mr(tok, samples, repl)
     assert len(used) > 60 and any(k.startswith("lora:") for k in used) and "t5.dec.1.cross.attn" in used
     tg = "train-mode (per-adapter LoRA masks)" if per_adapter else "train-mode"
-    # (round 5: the attention draws changed — "v3", other masks; measured 1.05e-4 with per-adapter LoRA masks: 2.5e-4 = ~2.5x)
-    check(tg + ".loss vs emu-oracle, same masks (rel)", abs(loss.item() - ref["loss"].item()) / abs(ref["loss"].item()), 2.5e-4)
+    # (per case — ADVICE r5: the shared-mask default measures 1.2e-5 and keeps the 1e-4 bound of round 4; only the per-adapter masks, whose draws
+    # changed with "draws v3", measure 1.05e-4 -> 2.5e-4)
+    check(tg + ".loss vs emu-oracle, same masks (rel)", abs(loss.item() - ref["loss"].item()) / abs(ref["loss"].item()), 2.5e-4 if per_adapter else 1e-4)
     # dropout really happened (the eval-mode loss differs)
     eng.training = False
     l_eval = eng.forward_backward(samples["video"].cuda(), lay, backward=False).item()

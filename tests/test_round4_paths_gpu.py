@@ -57,8 +57,8 @@ def test_gemm_epilogue_transposes_and_stacked_cross_kv_equal_the_launches_they_r
         # transposes from the epilogue: the same bits.  Stacked cross K / V: its backward adds the layers' contributions to the encoder-output
         # gradient in another fp32 order (chunks of layers in one K loop) — 1e-7 there, which flips bf16 roundings of the operands the encoder
         # backward builds from it (measured 3.4e-4 on the flat gradient); the key split re-orders the softmax merge as well.
-        check(tag + "loss (rel)", max(abs(a - b) / abs(b) for a, b in zip(l, base_l)), 2e-6 if "split" not in name else 2e-4)
-        check(tag + "flat gradient", relerr(g, base_g), 1e-6 if "epilogue" in name else 1e-3 if "split" not in name else 1.2e-2)   # (split: measured 5.2e-3)
+        check(tag + "loss (rel)", max(abs(a - b) / abs(b) for a, b in zip(l, base_l)), 2e-7 if "split" not in name else 1.8e-4)   # (measured 0 / 0 / 3.5e-5)
+        check(tag + "flat gradient", relerr(g, base_g), 2e-7 if "epilogue" in name else 1e-3 if "split" not in name else 1.2e-2)   # (measured 0 / 3.6e-4 / 5.2e-3)
         assert eng.grad[: eng.n_lora].abs().sum() > 0
     n0 = ops.launch_count
     _step(dict(), steps=1)
@@ -73,7 +73,7 @@ def test_several_clips_whose_length_is_not_a_multiple_of_32_fall_back():
     l, g, eng, _ = _step(dict(), B=2, steps=1)
     assert lay.S % 32 != 0
     assert l == base_l          # same forward kernels -> the same loss bits; the gradient has fp32 atomics (LayerNorm weight gradients): 1e-6
-    check("round-4 paths, 2 ragged clips: flat gradient of the fall-back vs forced-off run", relerr(g, base_g), 1e-6)
+    check("round-4 paths, 2 ragged clips: flat gradient of the fall-back vs forced-off run", relerr(g, base_g), 2e-7)   # (measured 0)
 
 
 def test_role_workgroups_of_the_encoder_gemms_change_no_bit():
@@ -104,7 +104,7 @@ def test_a_thin_role_timeout_is_loud_and_skips_the_optimizer_step():
     publishing): the device error word must be set, the guarded AdamW must leave parameters AND moments untouched, the NEXT step's entry
     check (and the runner's blocking check) must raise — and after clearing the word training continues."""
     from mrblip import ops
-    _, _, eng, lay = _step(dict(), steps=1)        # a healthy step first (workspaces, flag buffer, error word exist)
+    _, _, eng, lay = _step(dict(thin_fallback=False), steps=1)        # a healthy step first (workspaces, flag buffer, error word exist)
     assert ops.gemm_thin_timeouts() == 0
     eng.optimizer_step(1e-3)
     torch.cuda.synchronize()
@@ -132,6 +132,45 @@ def test_a_thin_role_timeout_is_loud_and_skips_the_optimizer_step():
     assert l == l and not torch.equal(eng.flat, flat0) and ops.gemm_thin_timeouts() == 0
 
 
+def test_a_thin_role_timeout_falls_back_to_thin_launches_and_rewinds_the_optimizer_clock():
+    """the default reaction to a timeout is not to abort.  The step in which the wait ran out and every optimizer step issued until
+    the verdict is read are dropped ON THE DEVICE (guarded AdamW); the next step's entry check then switches this engine to the thin products
+    as launches of their own, clears the word, rewinds the optimizer clock by the dropped steps (bias correction counts applied steps) and
+    training goes on — with the bits of a run that never had the role."""
+    from mrblip import ops
+    _, _, eng, lay = _step(dict(), steps=1)
+    assert eng.thin_fallback and eng.gemm_thin_enabled and ops.gemm_thin_timeouts() == 0
+    eng.optimizer_step(1e-3)
+    torch.cuda.synchronize()
+    t0, flat0 = eng.opt_step, eng.flat.clone()
+    import bench
+    samples = bench.synthetic_samples(1, 40, 150.0, torch.device("cuda:0"), 5)
+    eng.zero_grad()
+    with ops.gemm_debug_stall_thin():
+        eng.forward_backward(samples["video"], lay, backward=True)
+    eng.optimizer_step(1e-3)                       # issued, dropped on the device
+    torch.cuda.synchronize()
+    assert ops.gemm_thin_timeouts() == 1 and torch.equal(eng.flat, flat0) and eng.opt_step == t0 + 1
+    eng.zero_grad()
+    seed_before = eng.seed.clone()
+    l = eng.forward_backward(samples["video"], lay, backward=True).item()      # entry check: falls back, this step already runs without the role
+    assert not eng.gemm_thin_enabled and eng.thin_fallbacks == 1 and ops.gemm_thin_timeouts() == 0
+    assert eng.opt_step == t0 and eng.consume_thin_skipped() == 1
+    g_fb = eng.grad.clone()
+    eng.optimizer_step(1e-3)
+    torch.cuda.synchronize()
+    eng.check_thin_role(block=True)
+    assert l == l and not torch.equal(eng.flat, flat0) and eng.opt_step == t0 + 1
+    # the same step on an engine that never had the role: the same gradient bits
+    _, _, ref, _ = _step(dict(gemm_thin_enabled=False), steps=1)
+    ref.flat.copy_(flat0)
+    ref.refresh_trainable()
+    ref.seed.copy_(seed_before)                     # (forward_backward bumps the seed first: replay the fallen-back step's dropout stream)
+    ref.zero_grad()
+    l_ref = ref.forward_backward(samples["video"], lay, backward=True).item()
+    assert l_ref == l and torch.equal(ref.grad, g_fb)
+
+
 def test_encoder_qkv_through_the_four_wave_kernel_equals_the_generic_tile_path():
     """Round 5: above 1024 rows the T5 encoder's qkv projection runs as ONE plain product [xn | u] x [W | B]^T over K + 64 on the
     hand-pipelined 4-wave kernel (no K extension, no thin role, no epilogue transposes there: a thin launch, a V^T transpose and the
@@ -143,8 +182,8 @@ def test_encoder_qkv_through_the_four_wave_kernel_equals_the_generic_tile_path()
         l, g, eng, _ = _step(dict(enc_qkv_w4=cfg))
         assert eng.enc_qkv_wc is not None and eng.enc_qkv_wc.shape[2] == eng.cfg.d_model + 64
         tag = "encoder qkv via the 4-wave kernel (cfg %d) vs the generic tile path: " % cfg
-        check(tag + "loss (rel)", max(abs(a - b) / abs(b) for a, b in zip(l, base_l)), 2e-4)
-        check(tag + "flat gradient", relerr(g, base_g), 1e-2)
+        check(tag + "loss (rel)", max(abs(a - b) / abs(b) for a, b in zip(l, base_l)), 2e-7)     # (measured 0: the K tiles are accumulated in the same order)
+        check(tag + "flat gradient", relerr(g, base_g), 2e-7)
         # the B columns of [W | B] are refreshed with the trainable tensors
         eng.optimizer_step(1e-2)
         torch.cuda.synchronize()
@@ -159,8 +198,8 @@ def test_encoder_qkv_through_the_four_wave_kernel_equals_the_generic_tile_path()
     b2_l, b2_g, _, _ = _step(dict(enc_qkv_w4=0), B=2, steps=1)
     l, g, eng, _ = _step(dict(enc_qkv_w4=14), B=2, steps=1)
     assert not eng.enc_t_saved[0]
-    check("encoder qkv via the 4-wave kernel, 2 clips vs the generic tile path: loss (rel)", abs(l[0] - b2_l[0]) / abs(b2_l[0]), 2e-4)
-    check("encoder qkv via the 4-wave kernel, 2 clips vs the generic tile path: flat gradient", relerr(g, b2_g), 1e-2)
+    check("encoder qkv via the 4-wave kernel, 2 clips vs the generic tile path: loss (rel)", abs(l[0] - b2_l[0]) / abs(b2_l[0]), 2e-7)
+    check("encoder qkv via the 4-wave kernel, 2 clips vs the generic tile path: flat gradient", relerr(g, b2_g), 2e-7)
 
 
 def test_encoder_input_gradients_through_the_k_split_four_wave_kernel_equal_the_generic_tile_path():
@@ -171,7 +210,7 @@ def test_encoder_input_gradients_through_the_k_split_four_wave_kernel_equal_the_
     l, g, eng, _ = _step(dict(enc_bwd_w4=True))
     assert eng._enc_bwd_w4_ok(lay.S) and "eb_dxn_p_wi" in eng.ws and "eb_dxn_p_wi" not in eng0.ws
     assert l == base_l
-    check("encoder input gradients via K-split parts vs the generic tile path: flat gradient", relerr(g, base_g), 1e-2)
+    check("encoder input gradients via K-split parts vs the generic tile path: flat gradient", relerr(g, base_g), 2.5e-3)   # (measured 5.1e-4: one bf16 rounding less on the wo path)
     l2, g2, _, _ = _step(dict(enc_bwd_w4=True))
     assert l2 == l and torch.equal(g2, g)          # parts are added in part order: reproducible
 

@@ -61,8 +61,8 @@ def test_stream_of_different_sequence_lengths(training):
         ref.zero_grad()
         l = ref.forward_backward(video, layouts[k], backward=True).item()
         tag = f"variable-S ({'train' if training else 'eval'}) step {step} S={lens[k]}: "
-        check(tag + "loss vs fixed-shape engine", abs(got[step][0] - l) / abs(l), 1e-6)
-        check(tag + "flat grad vs fixed-shape engine", relerr(got[step][1], ref.grad), 2e-5)
+        check(tag + "loss vs fixed-shape engine", abs(got[step][0] - l) / abs(l), 2e-7)      # (measured 0: capacity-based workspaces change no bit)
+        check(tag + "flat grad vs fixed-shape engine", relerr(got[step][1], ref.grad), 2e-7)  # (measured 0)
     # no (re)allocation after the first step: reserve() sized every workspace for the longest prompt
     assert allocs[0] > 0 and allocs[-1] == allocs[0], allocs
 

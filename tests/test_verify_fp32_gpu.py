@@ -241,11 +241,13 @@ def test_finite_differences_confirm_the_lora_gradients_c1():
 def test_finite_differences_confirm_the_gradients_at_the_benched_size_c2():
     """The finite-difference check AT THE BENCHED SIZE (C2: 60 frames, Flan-T5-XL width, 24 + 24 layers, S_enc = 2012, every one of the 433
     adapters non-zero: the state of tests/golden/mr_c2_lora.npz) — the 4-wave kernel's K-split input gradients, the stacked cross K / V
-    backward, the thin launches above 512 rows, which C1 does not reach.  ~10 minutes of fp32-operand forwards: runs with MRB_FD_C2=1
-    (tools: `MRB_FD_C2=1 python -m pytest tests/test_verify_fp32_gpu.py -k benched_size_c2 -s`; measured: profiles/r05_finite_difference_c2.txt)."""
+    backward, the thin launches above 512 rows, which C1 does not reach.
+    ALWAYS ON since round 6 in its short form: ONE direction (all LoRA tensors, 92 % of the trainable floats), ONE step size — two fp32-operand
+    forwards, about a minute — so that the driver's GPUTEST carries a benched-size gradient check that does not go through the oracle.  The
+    long form (MRB_FD_C2=1, ~5 minutes: the loss pin of the non-zero-LoRA state, eps and eps / 2, the t5_proj + ln_vision direction;
+    `MRB_FD_C2=1 python -m pytest tests/test_verify_fp32_gpu.py -k benched_size_c2 -s`; measured: profiles/r05_finite_difference_c2.txt)."""
     import os
-    if os.environ.get("MRB_FD_C2", "0") != "1":
-        pytest.skip("set MRB_FD_C2=1 (ten minutes of fp32-operand forwards at the benched size)")
+    full = os.environ.get("MRB_FD_C2", "0") == "1"
     from util import GOLDEN
     if not os.path.exists(os.path.join(GOLDEN, "mr_c2_lora.npz")):
         pytest.skip("tests/golden/mr_c2_lora.npz not generated")
@@ -262,10 +264,12 @@ def test_finite_differences_confirm_the_gradients_at_the_benched_size_c2():
     eng, src, lay, video, g, T = _c2_setup(lora_init=lora_init)
     eng._verify_src = src
     video = video.cuda()
-    l0 = _run(eng, video, lay)[0]
-    ref_loss = float(gl["loss"])
-    print(f"finite differences c2: fp32-operand forward loss {l0:.6f}, oracle-fp32 loss of the same state {ref_loss:.6f}, rel {abs(l0 - ref_loss) / abs(ref_loss):.2e}")
-    check("c2.lora!=0.verify-fp32: loss vs oracle-fp32 (rel)", abs(l0 - ref_loss) / abs(ref_loss), 1e-5)
+    l0 = float("nan")
+    if full:
+        l0 = _run(eng, video, lay)[0]
+        ref_loss = float(gl["loss"])
+        print(f"finite differences c2: fp32-operand forward loss {l0:.6f}, oracle-fp32 loss of the same state {ref_loss:.6f}, rel {abs(l0 - ref_loss) / abs(ref_loss):.2e}")
+        check("c2.lora!=0.verify-fp32: loss vs oracle-fp32 (rel)", abs(l0 - ref_loss) / abs(ref_loss), 1e-5)
     eng.zero_grad()
     l_prod = eng.forward_backward(video, lay, backward=True).item()
     torch.cuda.synchronize()
@@ -280,7 +284,7 @@ def test_finite_differences_confirm_the_gradients_at_the_benched_size_c2():
         eng.refresh_trainable()
         return _run(eng, video, lay)[0]
 
-    for name, mask, steps in (("all LoRA tensors", idx < n0, 2), ("t5_proj + ln_vision", idx >= n0, 1)):
+    for name, mask, steps in ((("all LoRA tensors", idx < n0, 2), ("t5_proj + ln_vision", idx >= n0, 1)) if full else (("all LoRA tensors", idx < n0, 1),)):
         v = torch.where(mask, grad, torch.zeros_like(grad))
         nrm = float(v.norm())
         v /= nrm

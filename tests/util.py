@@ -44,12 +44,14 @@ def relerr(a, b):
 _ERR_LOG = os.environ.get("MRB_PARITY_LOG") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_errors.json")
 
 
-def record(name: str, value: float, tol: float = None):
+def record(name: str, value: float, tol: float = None, written: float = None):
     """log a measured error; returns the value (use as ``assert record(...) < tol``)"""
     try:
         os.makedirs(os.path.dirname(_ERR_LOG), exist_ok=True)
         data = json.load(open(_ERR_LOG)) if os.path.exists(_ERR_LOG) else {}
         data[name] = {"measured": float(value), "tolerance": tol}
+        if written is not None and written != tol:
+            data[name]["written"] = written
         with open(_ERR_LOG, "w") as f:
             json.dump(data, f, indent=1, sort_keys=True)
     except OSError:
@@ -57,13 +59,35 @@ def record(name: str, value: float, tol: float = None):
     return value
 
 
+# ---- tolerance policy (round 6).  Every check has TWO bounds: the tolerance WRITTEN in the test (what the quantity is allowed to be: ~2x the
+# error measured when the test was written, or the bound the reference demands), and a REGRESSION CEILING taken from the committed log of the
+# last full `pytest -m gpu` run on an MI355X (tests/golden/parity_baseline.json = the "measured" column of profiles/rNN_parity_errors.json):
+# at most CEIL x the value measured there, never below the fp32 summation-order floor.  The arithmetic is deterministic (the train step is
+# bit-reproducible), so a row that moves by more than CEIL x has changed its arithmetic and must be looked at — and no self-comparison row can
+# hide a 1e-3 bug behind a tolerance written 10^3-10^5 x above its measured error.  Rows that do not exist in the
+# baseline (new tests) have the written tolerance only, until the next full run records them.
+CEIL = 5.0
+FP32_FLOOR = 1.5e-7      # two fp32 summation orders of the same sum differ by about this much (relative L2)
+_BASELINE_PATH = os.path.join(GOLDEN, "parity_baseline.json")
+try:
+    _BASELINE = json.load(open(_BASELINE_PATH)) if os.environ.get("MRB_PARITY_NO_BASELINE") is None else {}
+except (OSError, ValueError):
+    _BASELINE = {}
+
+
+def effective_tolerance(name: str, tol: float) -> float:
+    base = _BASELINE.get(name)
+    if base is None or "not a parity bound" in name:
+        return tol
+    return min(tol, max(CEIL * float(base), FP32_FLOOR))
+
+
 def check(name: str, value: float, tol: float):
-    """assert + log.  Tolerance policy: every ``tol`` passed here is ~2x (at most ~3x) the error MEASURED on an MI355X and logged by the
-    last full `pytest -m gpu` run (committed as profiles/r02_parity_errors.json), not a guess; the product path's bf16-operand error
-    (logits ~6e-3 tiny, ~1.2e-2 at real depth vs the reference's fp32 run) is shown to be rounding only by the fp32-operand
-    verification rows ("verify-fp32": ~1e-5, i.e. 50-100x inside north_star's 1e-3 bar)."""
-    record(name, value, tol)
-    assert value < tol, f"{name}: measured {value:.3e} >= tolerance {tol:.3e}"
+    """assert + log: value < min(written tolerance, CEIL x the value measured by the last full GPU run) — see the policy above."""
+    eff = effective_tolerance(name, tol)
+    record(name, value, eff, written=tol)
+    assert value < eff, (f"{name}: measured {value:.3e} >= tolerance {eff:.3e}" +
+                         (f" (regression ceiling: {CEIL:g} x the committed baseline {_BASELINE.get(name):.3e}; written tolerance {tol:.3e})" if eff < tol else ""))
 
 
 def free_port() -> int:
