@@ -31,6 +31,7 @@ _PIECE_RE = re.compile(r"<extra_id_\d+>|<vid>|[A-Za-z]+|\d+|[^\sA-Za-z\d]")
 
 VOCAB_SIZE = 32128
 PAD, EOS, UNK, SPACE = 0, 1, 2, 3
+_OPTION_IDS = {"A": 71, "B": 272, "C": 205, "D": 309, "E": 262}    # the answer options of the video-QA path, as in the flan-t5 vocabulary
 
 
 def _fnv1a(s: str) -> int:
@@ -89,6 +90,8 @@ class FixtureTokenizer:
                 ids.append(9)
             elif p.isdigit():
                 ids.extend(self._int_pieces(p))
+            elif p in _OPTION_IDS:     # the one vocabulary fact the reference states: "A B C D E" -> [71, 272, 205, 309, 262] (blip2_mr.py:1299)
+                ids.append(_OPTION_IDS[p])
             elif p[0].isalpha():
                 wid = 1000 + _fnv1a(p) % 30000
                 self._id2word.setdefault(wid, p)
