@@ -245,6 +245,29 @@ def hbm_kernel_report(eng, video, layout, iters=20):
     return rows
 
 
+def parity_note():
+    """north_star asks for logits within 1e-3 relative of the reference's fp32 run.  The product path computes with 16-bit MFMA operands
+    (which north_star also mandates) and sits at ~1e-2; the SAME kernels fed with fp32-accurate (split-bf16) operands reach ~1.5e-5.  Both
+    numbers are read from the committed log of the last full `pytest -m gpu` run (profiles/rNN_parity_errors.json), not measured by this
+    command — labelled as such."""
+    import glob
+    logs = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_parity_errors.json")))
+    if not logs:
+        return None
+    try:
+        d = json.load(open(logs[-1]))
+        g = lambda k: (d.get(k) or {}).get("measured")  # noqa: E731
+        return {"source": "profiles/" + os.path.basename(logs[-1]) + " (committed log of the last full pytest -m gpu run; not measured by this command)",
+                "north_star_bar_logits_rel": 1e-3,
+                "logits_rel_vs_reference_fp32": g("c2.logits vs reference-fp32"),            # product path, bf16 operands, benched size C2
+                "verify_fp32": g("c2.verify-fp32: logits vs reference-fp32"),                 # same kernels, fp32-accurate operands
+                "loss_rel_vs_reference_fp32": g("c2.loss vs reference-fp32 (rel)"),
+                "reading": "the product path misses the 1e-3 bar by ~9x through bf16 operand rounding alone; the fp32-operand verification mode of the "
+                           "same kernels is ~65x inside it"}
+    except (OSError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -499,6 +522,9 @@ def main():
             "thin_role_timeouts": ops.gemm_thin_timeouts(),
             "roofline": roof,
         }
+        note = parity_note()
+        if note is not None:
+            out["parity_note"] = note
         if selftest is not None:
             out["collective_selftest"] = selftest   # {"backend": "nccl" (= RCCL), "ranks": N, "ok": true, "allreduce_ms": ...}
             out["rccl_ranks"] = selftest["ranks"] if selftest.get("backend") == "nccl" else 0

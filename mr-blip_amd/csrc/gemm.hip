@@ -803,8 +803,14 @@ __device__ constexpr int w4_piece_slot(int i, int total, int nslot) {
 // order, so the result does not depend on which unit finishes first); with a K extension (Aext [M, 64], Wext [N, 64]: the LoRA term,
 // which the consumer MASKS before adding it) its product is the LAST part, from one-K-tile units that every XCD's queue holds behind
 // its main units (they fill the tail of the last round).  No bias / residual / activation.
-template <bool OUT_F32, int ACT, bool RES, int TN, bool F16 = false, bool W3 = false, bool SPLIT = false>
+// GATED (round 6): the T5 gated-GELU projection [wi_0; wi_1] (modeling_t5.py:323-329) on this tile.  A tile covers 128 OUTPUT columns: each
+// wave's 128 tile columns are 64 rows of wi_0 (gate, nt 0 / 1) and the SAME 64 rows of wi_1 (linear, nt 2 / 3), fetched from the two halves
+// of the stacked weight by the per-piece source rows below, so gate and linear value of an output element meet in one wave's slab and the
+// epilogue is y = dropout(gelu(h0) * h1) with the pre-activations [h0 | h1] as a second bf16 output — bit for bit gemm_tile_kernel's gated
+// epilogue (same K order, same GELU, same dropout hash over m * Nh + n).  The LoRA term rides as 64 more K columns ([xn | u] x [W | B]^T).
+template <bool OUT_F32, int ACT, bool RES, int TN, bool F16 = false, bool W3 = false, bool SPLIT = false, bool GATED = false>
 __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
+  static_assert(!GATED || (TN == 4 && !OUT_F32 && !RES && !SPLIT && !F16 && ACT == 0), "gated: bf16 out, 256 x 256 tile");
   constexpr int BM = 256, BN = 64 * TN, WN = BN / 2, RB = 128, NW = 4, RPI = 8;
   constexpr int A_BYTES = BM * RB, W_BYTES = BN * RB, STAGE = A_BYTES + W_BYTES;
   constexpr int JA = BM / RPI / NW, JW = BN / RPI / NW;  // LDS-DMA pieces per wave: 8 of A, 8 / 6 of W
@@ -940,7 +946,12 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
     const uint32_t vA_ = SPLIT ? (uint32_t)((long long)(lane >> 3) * lda_ * 2) + chunk * 16 + k0_ : vA;                  \
     const uint32_t vW_ = SPLIT ? (uint32_t)((long long)(lane >> 3) * ldw_ * 2) + chunk * 16 + k0_ : vW;                  \
     _Pragma("unroll") for (int j = 0; j < JA; ++j) vpa[j] = vA_ + (uint32_t)((long long)(bm * BM + (j * NW + w) * RPI) * lda_ * 2); \
-    _Pragma("unroll") for (int j = 0; j < JW; ++j) vpw[j] = vW_ + (uint32_t)((long long)(bn * BN + (j * NW + w) * RPI) * ldw_ * 2); \
+    _Pragma("unroll") for (int j = 0; j < JW; ++j) {                                                                      \
+      const int tr_ = (j * NW + w) * RPI;                                     /* tile row of the piece's first W row */  \
+      const long long srow_ = GATED ? (long long)((tr_ >> 6) & 1) * (p.N >> 1) + bn * 128 + (tr_ >> 7) * 64 + (tr_ & 63)  \
+                                    : (long long)bn * BN + tr_;                                                         \
+      vpw[j] = vW_ + (uint32_t)(srow_ * ldw_ * 2);                                                                        \
+    }                                                                                                                    \
     gemm_stage_dma<JA, JW, NW, RPI * RB>(smem, smem + A_BYTES, tA, tba, tW, tbw, vpa, vpw, w, 0u);                       \
   }
 #ifdef EXP_W4_STAGGER
@@ -1019,6 +1030,66 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
     // Now bias, residual and output go through bounds-checked buffer resources (rows >= M / columns >= N get an out-of-range offset:
     // loads return 0, stores are dropped; every resource is < 2 GiB, the sentinel offset is 2^31), the residual rows of group mt + 1 are requested before group mt is finished, and nothing
     // waits for a store.
+    if constexpr (GATED) {
+      // 8 lanes cover the 64 output columns of a slab row (8 each), 8 rows per pass, 4 passes per 32-row slab; global side branch-free
+      // through bounds-checked resources (rows >= M / columns >= Nh get the sentinel offset: the store is dropped)
+      const int Nh = p.N >> 1;
+      const int grow = lane >> 3, gc8 = (lane & 7) * 8;
+      const int gn0 = bn_e * 128 + wn * 64 + gc8;
+      const bool gn_ok = gn0 < Nh;
+      const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)((((long long)p.M - 1) * p.ldo + Nh) * 2), 0x00020000);
+      const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(p.out2, 0, p.out2 ? (int)((((long long)p.M - 1) * p.ldo2 + 2 * Nh) * 2) : 0, 0x00020000);
+      const bool has_drop = p.drop.seed_ptr != nullptr;
+      const uint32_t seed = has_drop ? mrb_seed_load(p.drop.seed_ptr) : 0u;
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+        for (int nt = 0; nt < TN; ++nt)
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<float4*>(slab + l31 * RS + (nt * 32 + 8 * g + 4 * hi) * 4) =
+                make_float4(acc[mt][nt][4 * g], acc[mt][nt][4 * g + 1], acc[mt][nt][4 * g + 2], acc[mt][nt][4 * g + 3]);
+        const int m_base = bm_e * BM + wm * 128 + mt * 32;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int r = i * 8 + grow, m = m_base + r;
+          const bool ok = gn_ok && m < p.M;
+          const char* sp = slab + r * RS + gc8 * 4;
+          const float4 a0 = *reinterpret_cast<const float4*>(sp), a1 = *reinterpret_cast<const float4*>(sp + 16);
+          const float4 b0 = *reinterpret_cast<const float4*>(sp + 256), b1 = *reinterpret_cast<const float4*>(sp + 272);
+          const float h0[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+          const float h1[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+          if (p.out2) {
+            const uint32_t oh = ok ? (uint32_t)(((long long)m * p.ldo2 + gn0) * 2) : 0x80000000u;
+            __builtin_amdgcn_raw_buffer_store_b128(mrb_u32x4{pack2bf(h0[0], h0[1]), pack2bf(h0[2], h0[3]), pack2bf(h0[4], h0[5]), pack2bf(h0[6], h0[7])}, rh, oh, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(mrb_u32x4{pack2bf(h1[0], h1[1]), pack2bf(h1[2], h1[3]), pack2bf(h1[4], h1[5]), pack2bf(h1[6], h1[7])}, rh,
+                                                   ok ? oh + (uint32_t)Nh * 2u : 0x80000000u, 0, 0);
+          }
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 8; e += 2) {
+            float g0 = h0[e], g1 = h0[e + 1];
+            gelu_erf2(g0, g1);
+            v[e] = g0 * h1[e];
+            v[e + 1] = g1 * h1[e + 1];
+          }
+          if (has_drop) {
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {   // (gn0 % 8 == 0, Nh even: pairs share a hash — as epilogue_gated8)
+              bool k0, k1;
+              mrb_keep2((uint32_t)m * (uint32_t)Nh + (uint32_t)(gn0 + e), seed, p.drop.site, p.drop.thresh24, k0, k1);
+              v[e] = k0 ? v[e] * p.drop.inv_keep : 0.f;
+              v[e + 1] = k1 ? v[e + 1] * p.drop.inv_keep : 0.f;
+            }
+          }
+          __builtin_amdgcn_raw_buffer_store_b128(mrb_u32x4{pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])}, ry,
+                                                 ok ? (uint32_t)(((long long)m * p.ldo + gn0) * 2) : 0x80000000u, 0, 0);
+        }
+      }
+      __syncthreads();
+      cur = nxt;
+      continue;
+    }
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias), 0, p.bias ? p.N * 4 : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rres =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.residual), 0, RES ? (int)((((long long)p.M - 1) * p.ldr + p.N) * 4) : 0, 0x00020000);
@@ -2095,13 +2166,16 @@ static int gemm_dispatch(const void* A, long long lda, const void* W, long long 
   }
   if (cfg == 17) cfg = 13;
   if (cfg == 13 || cfg == 14) {  // four waves of 128 x 128 (cfg 13, 256x256 tile) / 128 x 96 (cfg 14, 256x192), hand-pipelined K loop
-    MRB_REQUIRE(!gated && !Aext && !out2 && !(p_drop > 0.f), "gemm: cfg 13 / 14 take plain epilogues only");
+    MRB_REQUIRE(gated || (!Aext && !out2 && !(p_drop > 0.f)), "gemm: cfg 13 / 14 take plain epilogues only (or the gated-GELU form of cfg 13)");
+    MRB_REQUIRE(!gated || (cfg == 13 && !Aext && !f16 && (N % 16) == 0 && (!out2 || (long long)M * ldo2 * 2 < (1ll << 31))),
+                "gemm: the gated form of the 4-wave kernel is cfg 13 on bf16 operands without a K extension ([x | u] x [W | B]^T instead)");
     MRB_REQUIRE(act == 0 || act == 1, "gemm: cfg 13 / 14 know act 0 / 1");
     MRB_REQUIRE((long long)M * ldo * (out_f32 ? 4 : 2) < (1ll << 31) && (!residual || (long long)M * ldr * 4 < (1ll << 31)),
                 "gemm: cfg 13 / 14 address output and residual through 2 GiB buffer resources");
     const int bn13 = cfg == 13 ? 256 : 192;
     a.tiles_m = (M + 255) / 256;
-    a.tiles_n = (N + bn13 - 1) / bn13;
+    a.tiles_n = gated ? (N / 2 + 127) / 128 : (N + bn13 - 1) / bn13;      // (gated: 128 output columns per tile)
+    if (gated) w3 = false;
     const int stage13 = (256 + bn13) * 128, slab13 = 4 * 32 * (bn13 / 2 * 4 + 16);
     MRB_REQUIRE(!w3 || (cfg == 13 && !f16), "gemm: the three-W-stage form (cfg 17) exists for the bf16 256x256 tile");
     const int LDS = w3 ? 2 * stage13 + 256 * 128 : (2 * stage13 > stage13 + slab13 ? 2 * stage13 : stage13 + slab13);
@@ -2121,8 +2195,8 @@ static int gemm_dispatch(const void* A, long long lda, const void* W, long long 
     // that keep the round count — ceil(tiles / rounds): ViT fc1 1464 tiles = 8 rounds on 184 CUs as on 192 — so that the other stream
     // gets the difference: +0.3 ms per step; the CUs of a partly filled last round are not idle, they go to the other stream EARLIER.)
     const int grid = nt13 < cus ? (nt13 + 7) / 8 * 8 : cus;
-    const int variant = (w3 ? 24 : 0) + ((f16 ? 16 : 0) | (cfg == 14 ? 8 : 0) | (out_f32 ? 4 : 0) | (act == 1 ? 2 : 0) | (residual ? 1 : 0));
-    static bool attr_set13[32] = {};
+    const int variant = gated ? 32 : (w3 ? 24 : 0) + ((f16 ? 16 : 0) | (cfg == 14 ? 8 : 0) | (out_f32 ? 4 : 0) | (act == 1 ? 2 : 0) | (residual ? 1 : 0));
+    static bool attr_set13[33] = {};
 #define MRB_W4_LAUNCH(V, F32, ACT_, RES_, TN_, ...)                                                                                \
   case V: {                                                                                                                        \
     auto k = gemm_w4_kernel<F32, ACT_, RES_, TN_, ##__VA_ARGS__>;                                                                                 \
@@ -2163,6 +2237,8 @@ static int gemm_dispatch(const void* A, long long lda, const void* W, long long 
       MRB_W4_LAUNCH(26, false, 1, false, 4, false, true)
       MRB_W4_LAUNCH(28, true, 0, false, 4, false, true)
       MRB_W4_LAUNCH(29, true, 0, true, 4, false, true)
+      // gated-GELU (T5 wi_0 / wi_1): bf16 y + bf16 pre-activations, dropout
+      MRB_W4_LAUNCH(32, false, 0, false, 4, false, false, false, true)
       default:
         mrblip_set_error("gemm: no such 4-wave kernel variant (%d)%s", variant, f16 ? " - the fp16 form exists for bias / bias+GELU (16-bit out) and fp32 out with or without residual" : "");
         return MRBLIP_EINVAL;

@@ -881,6 +881,9 @@ class MrBlipEngine:
         if getattr(self, "enc_qkv_wc", None) is not None:   # [W | B] of the encoder's qkv groups (enc_qkv_w4): refresh the B columns
             K = self.enc_qkv_wc.shape[2] - 64
             self.enc_qkv_wc[:, :, K:].copy_(self.wext_all.index_select(0, self._enc_qkv_rows).view(self.enc_qkv_wc.shape[0], -1, 64))
+        if getattr(self, "enc_wi_wc", None) is not None:    # ... and of its wi groups (enc_wi_w4)
+            K = self.enc_wi_wc.shape[2] - 64
+            self.enc_wi_wc[:, :, K:].copy_(self.wext_all.index_select(0, self._enc_wi_rows).view(self.enc_wi_wc.shape[0], -1, 64))
         ops.cast_dropout(self.proj_w, out_bf16=self.proj_wb)
         self.transpose2d(self.proj_wb, c.qf_dim, self.proj_wtb)
 
@@ -1226,6 +1229,7 @@ class MrBlipEngine:
         vt = self.buf("e_vt", (B, H, ops.rup32(dk), ops.rup32(S)), bf16)
         self.enc_t_saved.clear()     # (sticky flags a later backward trusts: reset by every forward)
         w4q = self._enc_qkv_w4_ok(M)
+        w4wi = self._enc_wi_w4_ok(M)
         for i, L in enumerate(self.t5["enc"]):
             qkv = self.buf(f"e{i}_qkv", (M, 3 * inner), bf16, zero=False)
             vt_i = vt
@@ -1273,13 +1277,25 @@ class MrBlipEngine:
             xm = self.buf(f"e{i}_xm", (M, d), f32, zero=False)
             self.lg_fwd(L["o"], o, uo, xm, residual=x, drop=self.drop(L["sites"][1], p), tile_cfg=_ENC_FWD_CFG[1],
                         prefetch=self.enc_pf([L["wi"]], M, 1) if self.enc_pf_plan else None)
-            xn2 = self.buf(f"e{i}_xn2", (M, pad64(d)), bf16)
-            uw = self.buf(f"e{i}_u_wi", (M, 64), bf16)
             y = self.buf(f"e{i}_y", (M, pad64(ff)), bf16)
             h = self.buf(f"e{i}_h", (M, 2 * ff), bf16, zero=False)
             nxt = [self.t5["enc"][i + 1]["qkv"]] if i + 1 < len(self.t5["enc"]) else []
-            self.norm_lg_fwd(xm, L["ln1"], L["wi"], xn2, uw, y, out2=h, gated=True, drop=self.drop(L["sites"][2], p), tile_cfg=_ENC_FWD_CFG[2],
-                             prefetch=self.enc_pf([L["wo"]] + (nxt if self.enc_pf_plan < 2 else []), M, 2))
+            if w4wi:
+                # Round 6 (MRB_ENC_WI_W4): the gated-GELU projection on the 4-wave kernel's GATED form — [xn2 | u] x [W | B]^T over K + 64, the
+                # gate / linear halves of a tile from the two halves of the stacked weight, y = dropout(gelu(h0) * h1) and the
+                # pre-activations from its epilogue (csrc/gemm.hip gemm_w4_kernel<GATED>): same bits as the generic tile's gated epilogue
+                g = L["wi"]
+                xnu2 = self.buf(f"e{i}_xnu2", (M, g.K + 64), bf16)
+                xn2, uw = xnu2[:, :g.K], xnu2[:, g.K:]
+                self.ws[f"e{i}_xn2"], self.ws[f"e{i}_u_wi"] = xn2, uw
+                ops.rmsnorm_fwd(xm, L["ln1"], c.t5_eps, out_bf16=xn2)
+                self.lora_thin(xn2, g.acat, uw, g.K, drop=self.drop(g.site, c.lora_dropout))
+                ops.gemm(xnu2, self.enc_wi_wc[i], y, out2=h, gated=True, drop=self.drop(L["sites"][2], p), tile_cfg=13, K=g.K + 64)
+            else:
+                xn2 = self.buf(f"e{i}_xn2", (M, pad64(d)), bf16)
+                uw = self.buf(f"e{i}_u_wi", (M, 64), bf16)
+                self.norm_lg_fwd(xm, L["ln1"], L["wi"], xn2, uw, y, out2=h, gated=True, drop=self.drop(L["sites"][2], p), tile_cfg=_ENC_FWD_CFG[2],
+                                 prefetch=self.enc_pf([L["wo"]] + (nxt if self.enc_pf_plan < 2 else []), M, 2))
             uwo = self.buf(f"e{i}_u_wo", (M, 64), bf16)
             xo = self.buf(f"e{i + 1}_x" if i + 1 < len(self.t5["enc"]) else "e_xlast", (M, d), f32, zero=False)
             self.lg_fwd(L["wo"], y, uwo, xo, residual=xm, drop=self.drop(L["sites"][3], p), tile_cfg=_ENC_FWD_CFG[3],
@@ -1334,6 +1350,39 @@ class MrBlipEngine:
                 if best is None or cost < best[0]:
                     best = (cost, ks, cfg)
         return best[1], best[2]
+
+    # Round 6: the encoder's gated wi projection ([2012 x 2 x 5120 x 2048] at QVH) on the 4-wave kernel's gated form (1: on above 1024 rows)
+    enc_wi_w4 = int(os.environ.get("MRB_ENC_WI_W4", "1"))
+    enc_wi_wc = None
+
+    def _enc_wc_build(self, name: str):
+        """[layers, N, K + 64] = [W | B] of the encoder's ``name`` groups (+ the rows of wext_all their B columns are refreshed from)"""
+        gs = [L[name] for L in self.t5["enc"]]
+        g0 = gs[0]
+        if g0.K % 64 or any(g.K != g0.K or g.W.shape[0] != g0.W.shape[0] for g in gs):
+            return None, None
+        N = g0.W.shape[0]
+        wc = torch.zeros(len(gs), N, g0.K + 64, dtype=bf16, device=self.dev)
+        rows = []
+        base = self.wext_all.data_ptr()
+        for i, g in enumerate(gs):
+            wc[i, :, :g.K].copy_(g.W[:, :g.K])
+            r0 = (g.wext.data_ptr() - base) // (64 * 2)
+            rows.append(torch.arange(r0, r0 + N, dtype=torch.int64))
+        rows = torch.cat(rows).to(self.dev)
+        wc[:, :, g0.K:].copy_(self.wext_all.index_select(0, rows).view(len(gs), N, 64))
+        return wc, rows
+
+    def _enc_wi_w4_ok(self, M: int) -> bool:
+        c = self.cfg
+        if not self.enc_wi_w4 or M < 1024 or (c.lora_mask_per_adapter and self.training and c.lora_dropout > 0) or c.d_ff % 8:
+            return False
+        if self.enc_wi_wc is None:
+            self.enc_wi_wc, self._enc_wi_rows = self._enc_wc_build("wi")
+            if self.enc_wi_wc is None:
+                self.enc_wi_w4 = 0
+                return False
+        return True
 
     def _enc_qkv_w4_ok(self, M: int) -> bool:
         if not self.enc_qkv_w4 or M < 1024 or (self.cfg.lora_mask_per_adapter and self.training and self.cfg.lora_dropout > 0):

@@ -28,6 +28,66 @@ def equal_layout_clips(s):
     return out
 
 
+def clips_n(s, n):
+    """n different clips with ONE layout (see equal_layout_clips): the fixture's two, their frame-reversed copies, and the sign-flipped
+    versions of those four"""
+    vids = [s["video"], s["video"].flip(1), -s["video"], -s["video"].flip(1)]
+    v = torch.cat(vids)[:n]
+    assert v.shape[0] == n, "at most 8 clips"
+    out = {"video": v}
+    for k, x in s.items():
+        if k == "video":
+            continue
+        out[k] = torch.cat([x[:1]] * n) if torch.is_tensor(x) else [x[0]] * n
+    return out
+
+
+def main_graph(out_path):
+    """world ranks, ONE clip each, the CAPTURED step (hipGraph, engine.graph_mode = "1") with the overlapped exchange armed on every step: visit
+    1 of the shape bucket runs eager, visit 2 captures, visit 3 REPLAYS — the replayed step's grad_ready_hook("lora") must fire behind the
+    second graph launch and its all-reduce must see the replayed gradients.  Rank 0 saves the exchanged gradient and the
+    losses of the replayed step."""
+    from mrblip import prompt as P
+    from mrblip.dist import GradExchange
+    from mrblip.engine import EngineConfig, MrBlipEngine, StateDictSource
+    from mrblip.tokenizer import FixtureTokenizer
+    from util import load_golden, golden_state_dict
+    from test_model_gpu import _peft_sd, _samples
+
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo")
+    g = load_golden("mr_tiny_mean")                 # the Charades-STA form: 32 -> 1 mean-pooled frame tokens
+    tok = FixtureTokenizer()
+    repl = P.annoying_replacement_dict(P.find_annoying_numbers(tok, 200)[0])
+    s = clips_n(equal_layout_clips(_samples(g)), world)
+    mine = {k: v[rank:rank + 1] for k, v in s.items()}
+    eng = MrBlipEngine(EngineConfig.tiny(mean_pool=True), StateDictSource(_peft_sd(golden_state_dict(g))), torch.device("cuda:0"), seed=42 + rank)
+    eng.training = False
+    eng.graph_mode = "1"
+    lay = P.build_layout(tok, mine, repl, 1, T=3)
+    ex = GradExchange(eng, overlap=True)
+    video = mine["video"].cuda()
+    fired = []
+    for step in range(3):
+        eng.zero_grad()
+        ex.arm()
+        hook = eng.grad_ready_hook
+        eng.grad_ready_hook = lambda what, hook=hook, step=step: (fired.append((step, what)), hook(what))[1]
+        loss = eng.forward_backward(video, lay, backward=True)
+        scale = ex.finish()
+        torch.cuda.synchronize()
+    assert MrBlipEngine.graph_replays >= 1, "the third visit of the bucket must replay the captured graphs"
+    assert fired == [(0, "lora"), (0, "all"), (1, "lora"), (1, "all"), (2, "lora"), (2, "all")], fired
+    assert scale == 1.0 / world
+    losses = [torch.zeros(1) for _ in range(world)]
+    dist.all_gather(losses, loss.detach().cpu().reshape(1))
+    if rank == 0:
+        torch.save({"grad": (eng.grad * scale).cpu(), "losses": torch.cat(losses), "n_lora": eng.n_lora, "replays": MrBlipEngine.graph_replays}, out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main(out_path, overlap):
     from mrblip import prompt as P
     from mrblip.dist import GradExchange
@@ -70,4 +130,7 @@ def main(out_path, overlap):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    if sys.argv[2] == "graph":
+        main_graph(sys.argv[1])
+    else:
+        main(sys.argv[1], sys.argv[2])

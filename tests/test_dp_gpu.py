@@ -55,3 +55,44 @@ def test_two_rank_gradient_equals_single_rank_batch(tmp_path, overlap):
     check(tag + "batch loss vs mean of rank losses", abs(l2 - float(dp["losses"].mean())) / abs(l2), 6e-5)
     nl = dp["n_lora"]
     assert dp["grad"][:nl].abs().sum() > 0 and dp["grad"][nl:].abs().sum() > 0
+
+
+def test_eight_ranks_captured_step_with_the_overlapped_exchange(tmp_path):
+    """the process layout of one 8-GPU node (here: eight ranks on the test box's one GPU over gloo) running the CAPTURED
+    Charades-form step (mean-pooled frame tokens, hipGraph replay) with GradExchange armed — the graph replay followed by
+    grad_ready_hook("lora") and the two asynchronous all-reduces.  The exchanged gradient of the REPLAYED step must be the mean of the eight
+    clips' own gradients, its losses the clips' own losses."""
+    from mrblip import prompt as P
+    from mrblip.engine import EngineConfig, MrBlipEngine, StateDictSource
+    from mrblip.tokenizer import FixtureTokenizer
+    from test_model_gpu import _peft_sd, _samples
+    from dp_worker import equal_layout_clips, clips_n
+
+    world = 8
+    out = str(tmp_path / "dp8.pt")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1", "--master-port",
+           str(free_port()), os.path.join(ROOT, "tests", "dp_worker.py"), out, "graph"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-3000:])
+    dp = torch.load(out)
+    assert dp["replays"] >= 1
+    g = load_golden("mr_tiny_mean")
+    tok = FixtureTokenizer()
+    repl = P.annoying_replacement_dict(P.find_annoying_numbers(tok, 200)[0])
+    s = clips_n(equal_layout_clips(_samples(g)), world)
+    eng = MrBlipEngine(EngineConfig.tiny(mean_pool=True), StateDictSource(_peft_sd(golden_state_dict(g))), torch.device("cuda:0"))
+    eng.training = False
+    eng.graph_mode = "0"
+    ref = torch.zeros_like(eng.grad, device="cpu")
+    ls = []
+    for i in range(world):
+        one = {k: v[i:i + 1] for k, v in s.items()}
+        lay1 = P.build_layout(tok, one, repl, 1, T=3)
+        eng.zero_grad()
+        ls.append(eng.forward_backward(one["video"].cuda(), lay1, backward=True).item())
+        ref += eng.grad.cpu() / world
+    tag = "dp8, captured step + overlapped exchange: "
+    check(tag + "rank losses (replayed graph) vs the clips' own eager losses", float((dp["losses"] - torch.tensor(ls)).abs().max()), 2e-6)
+    check(tag + "exchanged gradient vs mean of the clips' own gradients", relerr(dp["grad"], ref), 1e-6)
+    nl = dp["n_lora"]
+    assert dp["grad"][:nl].abs().sum() > 0 and dp["grad"][nl:].abs().sum() > 0

@@ -329,7 +329,9 @@ def _bias_report(tag, got, want):
     got, want = torch.as_tensor(got, dtype=torch.float64).reshape(-1), torch.as_tensor(want, dtype=torch.float64).reshape(-1)
     ratio = (got.norm() / want.norm().clamp_min(1e-30)).item()
     cos = (torch.dot(got, want) / (got.norm() * want.norm()).clamp_min(1e-30)).item()
-    record(tag + ": |g_hip| / |g_ref| - 1 (abs)", abs(ratio - 1.0), 1e-2)
+    # (a SIGNED quantity's magnitude — it can sit arbitrarily close to 0 by chance, so no regression ceiling: the bound is the claim itself,
+    # the norm ratio of a rounding-limited gradient — worst class measured 4.3e-3 (lm_head), the others 0.05-0.33 %)
+    record(tag + ": |g_hip| / |g_ref| - 1 (abs)", abs(ratio - 1.0), 8e-3)
     print(f"bias report {tag}: |g_hip| / |g_ref| - 1 = {ratio - 1.0:+.3e}, 1 - cosine = {1.0 - cos:.3e}")
     record(tag + ": 1 - cosine", 1.0 - cos, 1e-3)
     return ratio, cos
@@ -402,7 +404,7 @@ def test_c2_benched_size_nonzero_lora_gradients():
     for kind, k in sorted(kinds.items()):
         record(tag + f"worst dA/dB (sub-sampled) of {kind} adapters vs oracle-fp32", k["worst"], 1e-1)
         ratio, cos = _bias_report(tag + f"{kind} adapters, dA and dB together", torch.cat(k["h"]), torch.cat(k["r"]))
-        assert abs(ratio - 1.0) < 1e-2 and 1.0 - cos < 1e-3, (kind, ratio, cos)
+        assert abs(ratio - 1.0) < 8e-3 and 1.0 - cos < 1e-3, (kind, ratio, cos)
     check(tag + f"ALL LoRA gradients (flat over the sub-samples of {len(names)} adapters) vs oracle-fp32 autograd", math.sqrt(num / den), 2.8e-2)
     check(tag + f"worst single adapter dA/dB vs oracle-fp32 autograd ({worst_name})", worst, 1e-1)
     del eng

@@ -1060,7 +1060,7 @@ def test_rmsnorm_bwd_also_writes_the_lora_g_product_of_its_operand(ops, D, p, np
     if D % 32 == 0:
         thin = torch.zeros(M, 64, dtype=torch.bfloat16, device=dev())
         ops.lora_rows(want, gb, thin, D)
-        check(f"rmsnorm_bwd g product D={D} vs the lora_rows launch", rel(gout[:M, :8].float(), thin[:, :8].float()), 4e-3)
+        check(f"rmsnorm_bwd g product D={D} vs the lora_rows launch", rel(gout[:M, :8].float(), thin[:, :8].float()), 2.1e-3)   # (bf16 last-bit flips of a fp32 sum in another order: measured 5.5e-8 ... 4e-4)
 
 
 @pytest.mark.parametrize("p,pe", [(0.1, 0.05), (0.0, 0.05), (0.1, 0.0)])
@@ -1664,3 +1664,40 @@ def test_one_shot_gemm_extras_do_not_outlive_a_failed_call(ops):
     ops.gemm_ksplit(a, w, parts, 256, 2)
     ref = a[:, :128].float() @ w[:, :128].float().t()
     assert rel(parts[0], ref) < 5e-6
+
+
+# ---- round 6: the gated-GELU form of the hand-pipelined 4-wave kernel -----------------------------------------------------------------
+@pytest.mark.parametrize("M,Nh,K,p", [(2012, 5120, 2048, 0.1), (300, 136, 128, 0.1), (517, 1032, 320, 0.0), (2012, 640, 768, 0.1)])
+def test_gated_gelu_on_the_four_wave_kernel_equals_the_generic_tile(ops, M, Nh, K, p):
+    """T5 wi_0 / wi_1 (modeling_t5.py:323-329) with the LoRA term: ONE plain product [x | u] x [W | B]^T over K + 64 on gemm_w4_kernel<GATED>
+    (tile_cfg 13, gated) against the generic tile's gated epilogue with its K extension — the same K order, GELU and dropout hash, so y and
+    the pre-activations [h0 | h1] must be the same bits; rows >= M / columns >= Nh of the last tiles must not be written (canary)."""
+    torch.manual_seed(61)
+    x = bf(torch.randn(M, K, device=dev()))
+    w = bf(torch.randn(2 * Nh, K, device=dev()) * 0.05)
+    u = torch.zeros(M, 64, dtype=torch.bfloat16, device=dev())
+    u[:, :16] = bf(torch.randn(M, 16, device=dev()))
+    wext = torch.zeros(2 * Nh, 64, dtype=torch.bfloat16, device=dev())
+    wext[:, :16] = bf(torch.randn(2 * Nh, 16, device=dev()) * 0.05)
+    seed = torch.tensor([1234], dtype=torch.int32, device=dev())
+    drop = ops.Dropout(seed, 31, p) if p > 0 else None
+    y0 = torch.zeros(M, Nh + 64, dtype=torch.bfloat16, device=dev())[:, :Nh]
+    h0 = torch.zeros(M, 2 * Nh, dtype=torch.bfloat16, device=dev())
+    ops.gemm(x, w, y0, aext=u, wext=wext, out2=h0, gated=True, drop=drop, tile_cfg=2)
+    xu = torch.cat([x, u], 1).contiguous()
+    wc = torch.cat([w, wext], 1).contiguous()
+    ybuf = torch.full((M + 5, Nh + 64), 7.0, dtype=torch.bfloat16, device=dev())
+    hbuf = torch.full((M + 5, 2 * Nh + 8), 7.0, dtype=torch.bfloat16, device=dev())
+    y1, h1 = ybuf[:M, :Nh], hbuf[:M, :2 * Nh]
+    ops.gemm(xu, wc, y1, out2=h1, gated=True, drop=drop, tile_cfg=13, K=K + 64)
+    torch.cuda.synchronize()
+    assert torch.equal(h1, h0), rel(h1.float(), h0.float())
+    assert torch.equal(y1, y0), rel(y1.float(), y0.float())
+    assert torch.all(ybuf[M:] == 7.0) and torch.all(ybuf[:, Nh:] == 7.0) and torch.all(hbuf[M:] == 7.0) and torch.all(hbuf[:, 2 * Nh:] == 7.0)
+    if p > 0:
+        assert 0.85 < (y1 != 0).float().mean().item() < 0.95
+    ref = x.float() @ w.float().t() + u.float() @ wext.float().t()
+    from util import check
+    check(f"gated 4-wave kernel M={M} Nh={Nh} K={K}: pre-activations vs fp32 torch", rel(h1.float(), ref), 4e-3)
+    with pytest.raises(ops.MrblipError):      # no K extension in this kernel: the LoRA term must come concatenated
+        ops.gemm(x, w, y1, aext=u, wext=wext, out2=h1, gated=True, tile_cfg=13)
