@@ -1351,8 +1351,11 @@ class MrBlipEngine:
                     best = (cost, ks, cfg)
         return best[1], best[2]
 
-    # Round 6: the encoder's gated wi projection ([2012 x 2 x 5120 x 2048] at QVH) on the 4-wave kernel's gated form (1: on above 1024 rows)
-    enc_wi_w4 = int(os.environ.get("MRB_ENC_WI_W4", "1"))
+    # Round 6: the encoder's gated wi projection ([2012 x 2 x 5120 x 2048] at QVH) on the 4-wave kernel's gated form (1: on above 1024 rows).
+    # OFF by default: same box, alternating runs (profiles/r06_ab_switches.txt) 65.06 / 65.11 ms with it, 64.17 ms without — in the step the
+    # launch takes 113 us + a 9 us thin launch where the generic gated tile with its in-GEMM thin role and the prefetch of wo's weights took
+    # 102 us, and wo behind it 80 instead of 67 us (profiles/r06_base_layer_timeline.txt): the 4-wave kernel has no role workgroups.
+    enc_wi_w4 = int(os.environ.get("MRB_ENC_WI_W4", "0"))
     enc_wi_wc = None
 
     def _enc_wc_build(self, name: str):

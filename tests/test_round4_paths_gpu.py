@@ -171,6 +171,23 @@ def test_a_thin_role_timeout_falls_back_to_thin_launches_and_rewinds_the_optimiz
     assert l_ref == l and torch.equal(ref.grad, g_fb)
 
 
+def test_encoder_gated_wi_through_the_four_wave_kernel_equals_the_generic_tile_path():
+    """Round 6 (opt-in, MRB_ENC_WI_W4=1: measured 0.9 ms per step SLOWER than the generic gated tile, profiles/r06_ab_switches.txt): the gated wi
+    projection as [xn2 | u] x [W | B]^T on the 4-wave kernel's gated form.  Same arithmetic as the generic tile's gated epilogue; loss and
+    flat gradient against that path, dropout on, and the B columns of [W | B] must follow the optimizer."""
+    base_l, base_g, eng0, lay = _step(dict(enc_wi_w4=0))
+    assert lay.S >= 1024
+    l, g, eng, _ = _step(dict(enc_wi_w4=1))
+    assert eng.enc_wi_wc is not None and eng.enc_wi_wc.shape[2] == eng.cfg.d_model + 64
+    tag = "encoder gated wi via the 4-wave kernel vs the generic tile path: "
+    check(tag + "loss (rel)", max(abs(a - b) / abs(b) for a, b in zip(l, base_l)), 2e-6)
+    check(tag + "flat gradient", relerr(g, base_g), 2e-3)
+    eng.optimizer_step(1e-2)
+    torch.cuda.synchronize()
+    g0 = eng.t5["enc"][0]["wi"]
+    assert torch.equal(eng.enc_wi_wc[0, :, eng.cfg.d_model:], g0.wext) and torch.equal(eng.enc_wi_wc[0, :, :g0.K], g0.W[:, :g0.K])
+
+
 def test_encoder_qkv_through_the_four_wave_kernel_equals_the_generic_tile_path():
     """Round 5: above 1024 rows the T5 encoder's qkv projection runs as ONE plain product [xn | u] x [W | B]^T over K + 64 on the
     hand-pipelined 4-wave kernel (no K extension, no thin role, no epilogue transposes there: a thin launch, a V^T transpose and the

@@ -90,6 +90,8 @@ class Fp32Verify(contextlib.AbstractContextManager):
         eng.gemm_thin_enabled = False      # (the patched gemm has no thin role: the "down" product stays a launch of its own)
         S["qkv_w4"] = eng.enc_qkv_w4
         eng.enc_qkv_w4 = 0                 # (round 5: the qkv projection as one [xn | u] x [W | B]^T product is a bf16-operand layout too)
+        S["wi_w4"] = eng.enc_wi_w4
+        eng.enc_wi_w4 = 0                  # (round 6: likewise the gated wi projection's [xn2 | u] x [W | B]^T form)
         S["pf"] = (eng.enc_prefetch, eng.qf_prefetch)
         eng.enc_prefetch, eng.qf_prefetch = (0,), False   # (... and would leave the prefetch hints unconsumed)
 
@@ -145,6 +147,7 @@ class Fp32Verify(contextlib.AbstractContextManager):
         eng.gemm_tout_enabled, eng.cross_kv_batched, eng.gemm_thin_enabled = S["tout"], S["ckv"], S["thin"]
         eng.enc_prefetch, eng.qf_prefetch = S["pf"]
         eng.enc_qkv_w4 = S["qkv_w4"]
+        eng.enc_wi_w4 = S["wi_w4"]
         eng.vit_dtype = S["vit_dtype"]
         for obj, key, val in self._weight_restore:
             obj[key] = val
