@@ -330,6 +330,41 @@ int mrblip_gated_gelu_bwd_parts(const void* dy, const void* dy_ext, long long ld
 int mrblip_lora_pack(const float* flat, void* acat_bf16, void* wext_bf16, void* bblk_bf16, void* acatt_bf16, const long long* desc,
                      int n_adapters, float scale, mrblip_stream_t stream);
 
+/* Round 6: one Q-Former layer's QUERY BRANCH in ONE launch — a workgroup owns one frame's 32 query tokens for the whole layer (every
+ * query-side operation is row-wise or confined to one frame, so frames never exchange data): self-attention (qkv dense, 12 heads of 32 x 32,
+ * output dense + dropout + residual + LayerNorm), optionally cross-attention over the frame's Tv image tokens (query dense, attention over
+ * the caller's precomputed K | V projections `kv` [F * Tv, 1536] and their head-transposed V^T `vt` [F, 12, 64, Tvp], output dense + ...
+ * LayerNorm) and the FFN 768 -> 3072 -> 768 (erf-GELU, dropout, residual, LayerNorm).  BERT-base geometry only: 768 features, 12 heads of
+ * 64, 32 queries, 3072 intermediate.  Weights are bf16 [N, K] row-major with ld = K (2304x768, 768x768, 768x768, 768x768, 3072x768,
+ * 768x3072), vectors fp32.  x_in / x_out: fp32 [F * 32, 768] (the post-LayerNorm hidden state); xb_out: optional bf16 copy of x_out.
+ * Saved for the backward, exactly what the launch chain it replaces leaves behind: qkv (bf16 [F * 32, 2304]), o / oc (bf16 attention
+ * outputs, ld = ldo), lse / lsec (fp32 [F, 12, 32]), qc (bf16 [F * 32, 768]), y / y2 / y3 (fp32 pre-LayerNorm sums), hpre (bf16 pre-GELU).
+ * Dropout (p_drop, *seed_ptr): the draws of the launches it replaces — element dropout on index row * 768 + n per call site, attention
+ * draws v3 on (frame * 12 + head) * 32 + query — so a training step is the same function of the seed with either path.
+ * Replaces Qformer.py:111-289 (BertSelfAttention + BertSelfOutput), 349-375 (intermediate_query / output_query), 402-474 (BertLayer). */
+typedef struct mrblip_qformer_layer {
+  const void *qkv_w, *so_w, *cq_w, *co_w, *i_w, *o_w;
+  const float *qkv_b, *so_b, *s_lnw, *s_lnb, *cq_b, *co_b, *c_lnw, *c_lnb, *i_b, *o_b, *o_lnw, *o_lnb;
+  const float* x_in;
+  float* x_out;
+  void* xb_out;
+  long long ldxb;
+  void *qkv, *o;
+  long long ldo;
+  float *lse, *y;
+  void *qc, *oc;
+  float *lsec, *y2;
+  const void *kv, *vt;
+  void* hpre;
+  float* y3;
+  int F, Tv, Tvp, has_cross;
+  const uint32_t* seed_ptr;
+  float p_drop;
+  uint32_t site_sattn, site_so, site_cattn, site_co, site_ffn;
+  float eps;
+} mrblip_qformer_layer;
+int mrblip_qformer_layer_fwd(const mrblip_qformer_layer* layer, mrblip_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

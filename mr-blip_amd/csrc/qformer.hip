@@ -27,7 +27,7 @@
 // probability dropout: draws v3, attention.hip) — outputs agree with the chain to fp32 summation order (tests/test_qformer_fused_gpu.py).
 #include "common.h"
 
-struct QfLayerArgs {   // mirrors mrblip_qformer_layer (include/mrblip_hip.h)
+struct QfLayerArgs {   // kernel-side form of mrblip_qformer_layer (include/mrblip_hip.h)
   const bf16_t *qkv_w, *so_w, *cq_w, *co_w, *i_w, *o_w;            // bf16 [N, K] row-major (ld = K): 2304x768, 768x768, 768x768, 768x768, 3072x768, 768x3072
   const float *qkv_b, *so_b, *s_lnw, *s_lnb, *cq_b, *co_b, *c_lnw, *c_lnb, *i_b, *o_b, *o_lnw, *o_lnb;
   const float* x_in;      // fp32 [F * 32, 768]: the layer's input (LayerNorm output of the layer below)
@@ -59,11 +59,10 @@ constexpr int HC = 512;                    // FFN chunk (intermediate features p
 constexpr int HSTR = HC * 2 + 16;
 constexpr int XB_BYTES = NQ * XSTR;        // 49664
 constexpr int HB_BYTES = NQ * HSTR;        // 33280
-constexpr int NSTG = 4, TILE_BYTES = 4096; // W ring: 4 tiles of [32 rows][64 k] per wave
-constexpr int W_BYTES = 4 * NSTG * TILE_BYTES;
 constexpr int RED_BYTES = 2 * 4 * 32 * 4;
-constexpr int LDS_BYTES = XB_BYTES + HB_BYTES + W_BYTES + RED_BYTES;   // 149504
-constexpr int MAXKT = 9;                   // cross-attention: key tiles of 32 (Tv <= 288)
+constexpr int NSTG = 4, TILE_BYTES = 4096; // W ring of the LDS-DMA form: 4 tiles of [32 rows][64 k] per wave
+constexpr int W_BYTES = 4 * NSTG * TILE_BYTES;
+constexpr int LDS_BYTES = XB_BYTES + HB_BYTES + RED_BYTES + W_BYTES;   // 149504
 }  // namespace qf
 
 typedef __attribute__((address_space(3))) void* qf_lds_ptr_t;
@@ -91,13 +90,66 @@ __device__ __forceinline__ uint32_t qf_draw(uint32_t hash, int j) {   // attenti
 }
 
 // One wave's product  acc[t] (+)= W[rows of tile t][k0 .. k0 + 64 nkc) . X^T  for NT 32-feature tiles, K walked in 64-wide chunks.
-// The wave streams ITS weight rows through its private ring of NSTG [32][64] tiles: LDS-DMA, 8 rows x 128 B per instruction (whole
-// cache lines), 16-B pieces XOR-swizzled by the row through the SOURCE address; three tiles in flight, counted vmcnt waits (LDS-DMA
-// loads retire in order), fragments of tile i + 1 are read while the MFMAs of tile i run.  No workgroup barrier inside.
+// The weights go from L2 / HBM STRAIGHT into registers: lane (n, hi) of a tile reads the 64 contiguous bytes W[n][64 kc + 32 hi .. + 31]
+// as four 16-B loads — the A operands of the chunk's four MFMA steps under the k permutation "step s of lane half hi = k 32 hi + 8 s .. + 7",
+// which the token operand's LDS reads follow (any permutation serves a contraction as long as both operands use it).  A ring of
+// NT * KCB tiles (16 registers each) is kept in flight per wave: 12 tiles = 48 KB per wave, 192 KB per CU — what hides the ~1 us of an L2
+// miss (the first version staged the tiles through a 4-deep LDS-DMA ring per wave, 48 KB in flight per CU: 380 us per layer, latency
+// bound; profiles/r06_qformer_fused.txt).  The compiler counts the loads (they return in order) and waits with vmcnt(N) per tile.
 // row0(t): first weight row of tile t.  SWAPMASK bit t: operand-swapped MFMA for tile t (lane = feature, registers = tokens).
-template <int NT, int SWAPMASK, typename RowFn>
+template <int NT, int SWAPMASK, int KCB, typename RowFn>
 __device__ __forceinline__ void qf_wave_gemm(f32x16 (&acc)[NT], const char* xl, int xstr, int nkc, const bf16_t* W, long long ldw, long long k0,
-                                             uint32_t w_bytes, RowFn row0, char* ring, int lane) {
+                                             uint32_t w_bytes, RowFn row0, int lane) {
+  typedef uint32_t qf_u32x4 __attribute__((ext_vector_type(4)));
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(W), 0, (int)w_bytes, 0x00020000);
+  const int l31 = lane & 31, hi = lane >> 5;
+  uint32_t voff[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) voff[t] = (uint32_t)((((long long)row0(t) + l31) * ldw + k0 + 32 * hi) * 2);
+  constexpr int DEPTH = NT * KCB;
+  bf16x8 ring[DEPTH][4];
+  auto load = [&](bf16x8 (&f)[4], int kc, int t) __attribute__((always_inline)) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+      f[s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, voff[t] + 16 * s, (uint32_t)(128 * kc), 0));
+  };
+  const char* xrow = xl + l31 * xstr + 64 * hi;
+  auto chunk = [&](int kc, int j, bool more) __attribute__((always_inline)) {
+    bf16x8 xf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) xf[s] = *reinterpret_cast<const bf16x8*>(xrow + 128 * kc + 16 * s);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        if ((SWAPMASK >> t) & 1) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[s], ring[j * NT + t][s], acc[t], 0, 0, 0);
+        else acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[j * NT + t][s], xf[s], acc[t], 0, 0, 0);
+      }
+      if (more) load(ring[j * NT + t], kc + KCB, t);
+    }
+  };
+#pragma unroll
+  for (int j = 0; j < KCB; ++j)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) load(ring[j * NT + t], j, t);
+  int kb = 0;
+#pragma unroll 1
+  for (; kb + KCB < nkc; kb += KCB) {
+#pragma unroll
+    for (int j = 0; j < KCB; ++j) chunk(kb + j, j, true);
+  }
+#pragma unroll
+  for (int j = 0; j < KCB; ++j) chunk(kb + j, j, false);
+}
+
+// The LDS-DMA form of the same product (QF_W_DMA, the default — measured 4.9 ms per 12-layer forward against 7.3 ms for the register ring
+// above: the fragment-shaped register loads take the texture-address path lane by lane, profiles/r06_qformer_fused.txt).  The wave streams
+// ITS weight rows through its private ring of NSTG [32][64] tiles: 8 rows x 128 B per DMA instruction (whole cache lines), 16-B pieces
+// XOR-swizzled by the row through the SOURCE address; three tiles in flight, counted vmcnt waits (LDS-DMA loads retire in order), the
+// fragments of tile i + 1 are read while the MFMAs of tile i run.  Plain k order (step s of lane half hi = k 16 s + 8 hi .. + 7).
+template <int NT, int SWAPMASK, typename RowFn>
+__device__ __forceinline__ void qf_wave_gemm_dma(f32x16 (&acc)[NT], const char* xl, int xstr, int nkc, const bf16_t* W, long long ldw, long long k0,
+                                                 uint32_t w_bytes, RowFn row0, char* ring, int lane) {
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(W), 0, (int)w_bytes, 0x00020000);
   const int r8 = lane >> 3, c8 = lane & 7, l31 = lane & 31, hi = lane >> 5;
   uint32_t voff[4];
@@ -152,17 +204,31 @@ __device__ __forceinline__ void qf_wave_gemm(f32x16 (&acc)[NT], const char* xl, 
   }
 }
 
+#ifndef QF_W_DMA
+#define QF_W_DMA 1
+#endif
+template <int NT, int SWAPMASK, int KCB, typename RowFn>
+__device__ __forceinline__ void qf_gemm(f32x16 (&acc)[NT], const char* xl, int xstr, int nkc, const bf16_t* W, long long ldw, long long k0, uint32_t w_bytes,
+                                        RowFn row0, char* ring, int lane) {
+#if QF_W_DMA
+  qf_wave_gemm_dma<NT, SWAPMASK>(acc, xl, xstr, nkc, W, ldw, k0, w_bytes, row0, ring, lane);
+#else
+  qf_wave_gemm<NT, SWAPMASK, KCB>(acc, xl, xstr, nkc, W, ldw, k0, w_bytes, row0, lane);
+#endif
+}
+
 __device__ __forceinline__ void qf_zero(f32x16& a) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) a[r] = 0.f;
 }
 
-// v[t][r] (+bias) -> dropout -> + residual xr -> y (stored) -> LayerNorm -> xr; then the bf16 copy goes to the LDS operand (after a
-// barrier: every wave has finished reading the operand this overwrites) and optionally to x_out / xb_out.
-// Lane (m, hi), tile t, register r = 4 j + i  <->  feature nb + 32 t + 8 j + 4 hi + i.
-__device__ __forceinline__ void qf_block_epilogue(f32x16 (&acc)[6], float (&xr)[6][16], int nb, int row, int hi, int l31, int w, const float* bias,
-                                                  const DropoutArg& dr, float* ysave, const float* lnw, const float* lnb, float eps, float* red, char* xl,
-                                                  float* x_out, bf16_t* xb_out, long long ldxb) {
+// acc (+ bias) -> dropout -> + residual (fp32, global) -> y (stored: the backward's LayerNorm input) -> LayerNorm -> fp32 to xdst, bf16 to
+// the LDS token operand (after a barrier: every wave has finished reading the operand this overwrites) and optionally to xb_out.
+// Lane (m, hi), tile t, register r = 4 j + i  <->  feature nb + 32 t + 8 j + 4 hi + i.  xres / xdst may be the same buffer: a lane reads
+// and writes only its own elements.
+__device__ __forceinline__ void qf_block_epilogue(f32x16 (&acc)[6], int nb, int row, int hi, int l31, int w, const float* bias, const DropoutArg& dr,
+                                                  const float* xres, float* ysave, const float* lnw, const float* lnb, float eps, float* red, char* xl,
+                                                  float* xdst, bf16_t* xb_out, long long ldxb) {
   const uint32_t seed = dr.seed_ptr ? mrb_seed_load(dr.seed_ptr) : 0u;
   float s = 0.f;
 #pragma unroll
@@ -171,6 +237,7 @@ __device__ __forceinline__ void qf_block_epilogue(f32x16 (&acc)[6], float (&xr)[
     for (int j = 0; j < 4; ++j) {
       const int n = nb + 32 * t + 8 * j + 4 * hi;
       const float4 b = *reinterpret_cast<const float4*>(bias + n);
+      const float4 xr = *reinterpret_cast<const float4*>(xres + (long long)row * qf::D + n);
       float v0 = acc[t][4 * j] + b.x, v1 = acc[t][4 * j + 1] + b.y, v2 = acc[t][4 * j + 2] + b.z, v3 = acc[t][4 * j + 3] + b.w;
       if (dr.seed_ptr) {
         bool k0, k1, k2, k3;
@@ -178,8 +245,8 @@ __device__ __forceinline__ void qf_block_epilogue(f32x16 (&acc)[6], float (&xr)[
         v0 = k0 ? v0 * dr.inv_keep : 0.f; v1 = k1 ? v1 * dr.inv_keep : 0.f;
         v2 = k2 ? v2 * dr.inv_keep : 0.f; v3 = k3 ? v3 * dr.inv_keep : 0.f;
       }
-      v0 += xr[t][4 * j]; v1 += xr[t][4 * j + 1]; v2 += xr[t][4 * j + 2]; v3 += xr[t][4 * j + 3];
-      xr[t][4 * j] = v0; xr[t][4 * j + 1] = v1; xr[t][4 * j + 2] = v2; xr[t][4 * j + 3] = v3;
+      v0 += xr.x; v1 += xr.y; v2 += xr.z; v3 += xr.w;
+      acc[t][4 * j] = v0; acc[t][4 * j + 1] = v1; acc[t][4 * j + 2] = v2; acc[t][4 * j + 3] = v3;
       *reinterpret_cast<float4*>(ysave + (long long)row * qf::D + n) = make_float4(v0, v1, v2, v3);
       s += (v0 + v1) + (v2 + v3);
     }
@@ -193,12 +260,12 @@ __device__ __forceinline__ void qf_block_epilogue(f32x16 (&acc)[6], float (&xr)[
   for (int t = 0; t < 6; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float d = xr[t][r] - mean;
+      const float d = acc[t][r] - mean;
       q += d * d;
     }
   q = qf_sum_x32(q);
   if (hi == 0) red[128 + w * 32 + l31] = q;
-  __syncthreads();   // (also: every wave is past its reads of the LDS operand the bf16 copy below overwrites)
+  __syncthreads();
   const float var = (red[128 + l31] + red[160 + l31] + red[192 + l31] + red[224 + l31]) * (1.0f / qf::D);
   const float rstd = rsqrtf(var + eps);
 #pragma unroll
@@ -207,59 +274,132 @@ __device__ __forceinline__ void qf_block_epilogue(f32x16 (&acc)[6], float (&xr)[
     for (int j = 0; j < 4; ++j) {
       const int n = nb + 32 * t + 8 * j + 4 * hi;
       const float4 g = *reinterpret_cast<const float4*>(lnw + n), b = *reinterpret_cast<const float4*>(lnb + n);
-      const float v0 = (xr[t][4 * j] - mean) * rstd * g.x + b.x, v1 = (xr[t][4 * j + 1] - mean) * rstd * g.y + b.y;
-      const float v2 = (xr[t][4 * j + 2] - mean) * rstd * g.z + b.z, v3 = (xr[t][4 * j + 3] - mean) * rstd * g.w + b.w;
-      xr[t][4 * j] = v0; xr[t][4 * j + 1] = v1; xr[t][4 * j + 2] = v2; xr[t][4 * j + 3] = v3;
+      const float v0 = (acc[t][4 * j] - mean) * rstd * g.x + b.x, v1 = (acc[t][4 * j + 1] - mean) * rstd * g.y + b.y;
+      const float v2 = (acc[t][4 * j + 2] - mean) * rstd * g.z + b.z, v3 = (acc[t][4 * j + 3] - mean) * rstd * g.w + b.w;
       const uint2 pk = make_uint2(pack2bf(v0, v1), pack2bf(v2, v3));
       *reinterpret_cast<uint2*>(xl + l31 * qf::XSTR + n * 2) = pk;
-      if (x_out) *reinterpret_cast<float4*>(x_out + (long long)row * qf::D + n) = make_float4(v0, v1, v2, v3);
+      *reinterpret_cast<float4*>(xdst + (long long)row * qf::D + n) = make_float4(v0, v1, v2, v3);
       if (xb_out) *reinterpret_cast<uint2*>(xb_out + (long long)row * ldxb + n) = pk;
     }
   __syncthreads();   // the new operand is complete
 }
 
-// softmax + dropout of NKT score tiles held in registers (lane = query, register r of tile kt <-> key 32 kt + 8 (r >> 2) + 4 hi + (r & 3)),
-// packed probabilities out (bf16, unnormalised, dropped), row sum of the UNdropped probabilities and the running maximum (log2 domain).
-template <int NKT>
-__device__ __forceinline__ void qf_softmax(f32x16 (&sc)[NKT], bf16x8 (&pp)[NKT][2], float scale2, int nkeys, int hi, uint32_t row_id, const DropoutArg& dr,
-                                           float& m_out, float& l_out) {
-  float mx = -1.0e30f;
-#pragma unroll
-  for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int key = 32 * kt + 8 * (r >> 2) + 4 * hi + (r & 3);
-      float v = sc[kt][r] * scale2;
-      if (32 * kt + 32 > nkeys) v = key < nkeys ? v : -__builtin_inff();
-      sc[kt][r] = v;
-      mx = fmaxf(mx, v);
-    }
-  mx = qf_max_x32(mx);
-  float l = 0.f;
+// One head's attention for the wave's 32 queries (lane = query): flash-style walk over nkt 32-key tiles with the running maximum in the
+// log2 domain, lazy rescale, dropout draws v3 on the probabilities (attention.hip) and the row sum of the UNdropped probabilities.
+// S^T tile: lane (query, hi), register r <-> key 32 kt + 8 (r >> 2) + 4 hi + (r & 3); the packed probabilities (registers 8 s .. 8 s + 7)
+// are the B operand of O^T += V^T P^T.  kfrag(kt, s): A operand of the score product (32 keys x the 16 head dims of step s, in the dim
+// permutation the packed q carries); vfrag(kt, t, s): A operand of the output product (head dims 32 t .. + 31 x the 16 keys of step s).
+template <typename KF, typename VF>
+__device__ __forceinline__ void qf_attend(int nkt, int nkeys, const bf16x8 (&qp)[4], KF&& kfrag, VF&& vfrag, float scale2, int hi, uint32_t row_id,
+                                          const DropoutArg& dr, f32x16 (&oa)[2], float& m_out, float& l_out) {
   const uint32_t seed = dr.seed_ptr ? mrb_seed_load(dr.seed_ptr) : 0u;
   const uint32_t skq = (uint32_t)((nkeys + 3) >> 2);
   const uint32_t tl = dr.seed_ptr ? (row_id * skq + (uint32_t)hi) * MRB_H1 + mrb_lin_base(seed, dr.site) : 0u;
+  float m_run = -1.0e30f, l_run = 0.f;
+  qf_zero(oa[0]);
+  qf_zero(oa[1]);
+  bf16x8 kc[4], kn[4], vc[2][2], vn[2][2];
 #pragma unroll
-  for (int kt = 0; kt < NKT; ++kt) {
+  for (int s = 0; s < 4; ++s) kc[s] = kn[s] = kfrag(0, s);
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) vc[t][s] = vn[t][s] = vfrag(0, t, s);
+#pragma unroll 1
+  for (int kt = 0; kt < nkt; ++kt) {
+    if (kt + 1 < nkt) {   // the next tile's operands fly while this one is computed
+#pragma unroll
+      for (int s = 0; s < 4; ++s) kn[s] = kfrag(kt + 1, s);
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) vn[t][s] = vfrag(kt + 1, t, s);
+    }
+    f32x16 sc;
+    qf_zero(sc);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kc[s], qp[s], sc, 0, 0, 0);
+    const bool edge = 32 * kt + 32 > nkeys;
+    float mx = -1.0e30f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float p = __builtin_amdgcn_exp2f(sc[kt][r] - mx);
-      l += p;
-      sc[kt][r] = p;
+      float v = sc[r] * scale2;
+      if (edge) v = (32 * kt + 8 * (r >> 2) + 4 * hi + (r & 3)) < nkeys ? v : -__builtin_inff();
+      sc[r] = v;
+      mx = fmaxf(mx, v);
     }
+    mx = qf_max_x32(mx);
+    if (__builtin_amdgcn_ballot_w64(mx > m_run) != 0) {
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      l_run *= alpha;
+      m_run = m_new;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oa[t][r] *= alpha;
+    }
+    float ps = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      sc[r] = __builtin_amdgcn_exp2f(sc[r] - m_run);
+      ps += sc[r];
+    }
+    l_run += ps;
     if (dr.seed_ptr) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {   // keys 32 kt + 8 j + 4 hi + i: quad index 8 kt + 2 j + hi, draw i
         const uint32_t hsh = mrb_lin_fin24(tl + (uint32_t)(8 * kt + 2 * j) * MRB_H1);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) sc[kt][4 * j + i] = qf_draw(hsh, i) >= dr.thresh24 ? sc[kt][4 * j + i] : 0.f;
+        for (int i = 0; i < 4; ++i) sc[4 * j + i] = qf_draw(hsh, i) >= dr.thresh24 ? sc[4 * j + i] : 0.f;
       }
     }
-    pp[kt][0] = qf_pack8(sc[kt], 0);
-    pp[kt][1] = qf_pack8(sc[kt], 8);
+    const bf16x8 p0 = qf_pack8(sc, 0), p1 = qf_pack8(sc, 8);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      oa[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vc[t][0], p0, oa[t], 0, 0, 0);
+      oa[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vc[t][1], p1, oa[t], 0, 0, 0);
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) kc[s] = kn[s];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) vc[t][s] = vn[t][s];
   }
-  m_out = mx;
-  l_out = qf_sum_x32(l);
+  const float l_tot = qf_sum_x32(l_run);
+  const float inv = (dr.seed_ptr ? dr.inv_keep : 1.0f) / l_tot;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oa[t][r] *= inv;
+  m_out = m_run;
+  l_out = l_tot;
+}
+
+// the packed output of head hh goes to opk[hh] with STATIC indices (hh is a rolled loop counter: a dynamic index would send the array to scratch)
+__device__ __forceinline__ void qf_keep_head(bf16x8 (&opk)[3][4], int hh, const f32x16 (&oa)[2]) {
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+    if (hh == k) {
+      opk[k][0] = qf_pack8(oa[0], 0); opk[k][1] = qf_pack8(oa[0], 8);
+      opk[k][2] = qf_pack8(oa[1], 0); opk[k][3] = qf_pack8(oa[1], 8);
+    }
+}
+// attention output of the wave's three heads -> the LDS token operand and the saved copy
+__device__ __forceinline__ void qf_store_heads(const bf16x8 (&opk)[3][4], char* xl, bf16_t* og, long long ldo, int row, int l31, int hi, int w) {
+#pragma unroll
+  for (int hh = 0; hh < 3; ++hh)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = 64 * (3 * w + hh) + 32 * t + 8 * j + 4 * hi;
+        union { bf16x8 v8; uint2 u2[2]; } u;
+        u.v8 = opk[hh][2 * t + (j >> 1)];
+        *reinterpret_cast<uint2*>(xl + l31 * qf::XSTR + n * 2) = u.u2[j & 1];
+        *reinterpret_cast<uint2*>(og + (long long)row * ldo + n) = u.u2[j & 1];
+      }
 }
 
 __global__ __launch_bounds__(256, 1) void qformer_layer_fwd_kernel(const QfLayerArgs p) {
@@ -268,22 +408,20 @@ __global__ __launch_bounds__(256, 1) void qformer_layer_fwd_kernel(const QfLayer
   char* hl = sm + qf::XB_BYTES;                    // bf16 [32][512] FFN chunk
   const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  char* ring = sm + qf::XB_BYTES + qf::HB_BYTES + w * (qf::NSTG * qf::TILE_BYTES);
-  float* red = reinterpret_cast<float*>(sm + qf::XB_BYTES + qf::HB_BYTES + qf::W_BYTES);
+  char* ring = sm + qf::XB_BYTES + qf::HB_BYTES + qf::RED_BYTES + w * (qf::NSTG * qf::TILE_BYTES);   // (QF_W_DMA)
+  float* red = reinterpret_cast<float*>(sm + qf::XB_BYTES + qf::HB_BYTES);
   const int f = blockIdx.x;
   const int row = f * qf::NQ + l31;                // this lane's token (global row)
   const int nb = 192 * w;                          // this wave's feature slice of the N = 768 products
   const float scale2 = 0.125f * 1.4426950408889634f;
 
-  // ---- the frame's residual stream: fp32 registers in accumulator layout + bf16 operand in LDS
-  float xr[6][16];
+  // ---- the frame's hidden state: bf16 token operand in LDS (the fp32 residual is re-read from memory by the epilogues: a lane's own elements)
 #pragma unroll
   for (int t = 0; t < 6; ++t)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int n = nb + 32 * t + 8 * j + 4 * hi;
       const float4 v = *reinterpret_cast<const float4*>(p.x_in + (long long)row * qf::D + n);
-      xr[t][4 * j] = v.x; xr[t][4 * j + 1] = v.y; xr[t][4 * j + 2] = v.z; xr[t][4 * j + 3] = v.w;
       *reinterpret_cast<uint2*>(xl + l31 * qf::XSTR + n * 2) = make_uint2(pack2bf(v.x, v.y), pack2bf(v.z, v.w));
     }
   __syncthreads();
@@ -297,8 +435,8 @@ __global__ __launch_bounds__(256, 1) void qformer_layer_fwd_kernel(const QfLayer
 #pragma unroll
     for (int t = 0; t < 6; ++t) qf_zero(acc[t]);
     // tiles 0, 1: q_h   2, 3: k_h   4, 5: v_h (operand-swapped: lane = head dim, registers = tokens)
-    qf_wave_gemm<6, 0x30>(acc, xl, qf::XSTR, qf::D / 64, p.qkv_w, qf::D, 0, 3u * qf::D * qf::D * 2u,
-                          [&](int t) { return (t >> 1) * qf::D + 64 * h + 32 * (t & 1); }, ring, lane);
+    qf_gemm<6, 0x30, 2>(acc, xl, qf::XSTR, qf::D / 64, p.qkv_w, qf::D, 0, 3u * qf::D * qf::D * 2u,
+                             [&](int t) { return (t >> 1) * qf::D + 64 * h + 32 * (t & 1); }, ring, lane);
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -320,52 +458,34 @@ __global__ __launch_bounds__(256, 1) void qformer_layer_fwd_kernel(const QfLayer
         p.qkv[(long long)(f * qf::NQ + m) * (3 * qf::D) + n] = f2bf(acc[t][r]);
       }
     }
-    // S^T[key][query] = K Q^T: four MFMA steps over the 64 head dims, step s = registers 8 (s & 1) .. + 7 of tile s >> 1 on both sides
-    f32x16 sc[1];
-    qf_zero(sc[0]);
+    // S^T[key][query] = K Q^T: four MFMA steps over the 64 head dims, step s = registers 8 (s & 1) .. + 7 of tile s >> 1 on both sides;
+    // V^T (tiles 4, 5: lane = head dim, registers = tokens) is the A operand of O^T = V^T P^T as it stands
+    bf16x8 qp[4], kp[4], vp[2][2];
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
-      sc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf_pack8(acc[2 + (s >> 1)], 8 * (s & 1)), qf_pack8(acc[s >> 1], 8 * (s & 1)), sc[0], 0, 0, 0);
-    bf16x8 pp[1][2];
-    float mrun, ltot;
-    qf_softmax<1>(sc, pp, scale2, qf::NQ, hi, (uint32_t)(f * qf::H + h) * qf::NQ + (uint32_t)l31, p.d_sattn, mrun, ltot);
-    f32x16 oa[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      qf_zero(oa[t]);
-#pragma unroll
-      for (int s = 0; s < 2; ++s) oa[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf_pack8(acc[4 + t], 8 * s), pp[0][s], oa[t], 0, 0, 0);
+    for (int s = 0; s < 4; ++s) {
+      qp[s] = qf_pack8(acc[s >> 1], 8 * (s & 1));
+      kp[s] = qf_pack8(acc[2 + (s >> 1)], 8 * (s & 1));
     }
-    const float inv = (p.d_sattn.seed_ptr ? p.d_sattn.inv_keep : 1.0f) / ltot;
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) oa[t][r] *= inv;
-      opk[hh][2 * t] = qf_pack8(oa[t], 0);
-      opk[hh][2 * t + 1] = qf_pack8(oa[t], 8);
-    }
-    if (hi == 0) p.lse[(long long)(f * qf::H + h) * qf::NQ + l31] = mrun * 0.6931471805599453f + __logf(ltot);
-  }
-  __syncthreads();   // every wave is done with the LayerNorm'd operand: the attention output takes its place
-#pragma unroll
-  for (int hh = 0; hh < 3; ++hh)
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int n = 64 * (3 * w + hh) + 32 * t + 8 * j + 4 * hi;
-        union { bf16x8 v8; uint2 u2[2]; } u;
-        u.v8 = opk[hh][2 * t + (j >> 1)];
-        *reinterpret_cast<uint2*>(xl + l31 * qf::XSTR + n * 2) = u.u2[j & 1];
-        *reinterpret_cast<uint2*>(p.o + (long long)row * p.ldo + n) = u.u2[j & 1];
-      }
+      for (int s = 0; s < 2; ++s) vp[t][s] = qf_pack8(acc[4 + t], 8 * s);
+    f32x16 oa[2];
+    float mrun, ltot;
+    qf_attend(1, qf::NQ, qp, [&](int, int s) { return kp[s]; }, [&](int, int t, int s) { return vp[t][s]; }, scale2, hi,
+              (uint32_t)(f * qf::H + h) * qf::NQ + (uint32_t)l31, p.d_sattn, oa, mrun, ltot);
+    qf_keep_head(opk, hh, oa);
+    if (hi == 0) p.lse[(long long)(f * qf::H + h) * qf::NQ + l31] = mrun * 0.6931471805599453f + __logf(ltot);
+  }
+  __syncthreads();   // every wave is done with the LayerNorm'd operand: the attention output takes its place
+  qf_store_heads(opk, xl, p.o, p.ldo, row, l31, hi, w);
   __syncthreads();
   {
     f32x16 acc[6];
 #pragma unroll
     for (int t = 0; t < 6; ++t) qf_zero(acc[t]);
-    qf_wave_gemm<6, 0>(acc, xl, qf::XSTR, qf::D / 64, p.so_w, qf::D, 0, (uint32_t)(qf::D * qf::D * 2), [&](int t) { return nb + 32 * t; }, ring, lane);
-    qf_block_epilogue(acc, xr, nb, row, hi, l31, w, p.so_b, p.d_so, p.y, p.s_lnw, p.s_lnb, p.eps, red, xl, nullptr, nullptr, 0);
+    qf_gemm<6, 0, 2>(acc, xl, qf::XSTR, qf::D / 64, p.so_w, qf::D, 0, (uint32_t)(qf::D * qf::D * 2), [&](int t) { return nb + 32 * t; }, ring, lane);
+    qf_block_epilogue(acc, nb, row, hi, l31, w, p.so_b, p.d_so, p.x_in, p.y, p.s_lnw, p.s_lnb, p.eps, red, xl, p.x_out, nullptr, 0);
   }
 
   // ---- cross-attention over the frame's image tokens (every second layer)
@@ -373,7 +493,7 @@ __global__ __launch_bounds__(256, 1) void qformer_layer_fwd_kernel(const QfLayer
     f32x16 qa[6];
 #pragma unroll
     for (int t = 0; t < 6; ++t) qf_zero(qa[t]);
-    qf_wave_gemm<6, 0>(qa, xl, qf::XSTR, qf::D / 64, p.cq_w, qf::D, 0, (uint32_t)(qf::D * qf::D * 2), [&](int t) { return nb + 32 * t; }, ring, lane);
+    qf_gemm<6, 0, 2>(qa, xl, qf::XSTR, qf::D / 64, p.cq_w, qf::D, 0, (uint32_t)(qf::D * qf::D * 2), [&](int t) { return nb + 32 * t; }, ring, lane);
     bf16x8 qp[3][4];
 #pragma unroll
     for (int t = 0; t < 6; ++t) {
@@ -391,75 +511,42 @@ __global__ __launch_bounds__(256, 1) void qformer_layer_fwd_kernel(const QfLayer
 #pragma unroll 1
     for (int hh = 0; hh < 3; ++hh) {
       const int h = 3 * w + hh;
-      f32x16 sc[qf::MAXKT];
-      const bf16_t* kb = p.kv + (long long)f * p.Tv * (2 * qf::D) + 64 * h;
+      bf16x8 qh[4];
 #pragma unroll
-      for (int kt = 0; kt < qf::MAXKT; ++kt) {
-        qf_zero(sc[kt]);
-        if (kt < nkt) {
-          const int key = min(32 * kt + l31, p.Tv - 1);
-          const bf16_t* kr = kb + (long long)key * (2 * qf::D);
-#pragma unroll
-          for (int s = 0; s < 4; ++s) {   // head dims 32 (s >> 1) + 16 (s & 1) + 8 (e >> 2) + 4 hi + (e & 3): the permutation the packed q carries
-            union { bf16x8 v8; uint2 u2[2]; } kf;
-            kf.u2[0] = *reinterpret_cast<const uint2*>(kr + 16 * s + 4 * hi);
-            kf.u2[1] = *reinterpret_cast<const uint2*>(kr + 16 * s + 8 + 4 * hi);
-            sc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf.v8, qp[hh][s], sc[kt], 0, 0, 0);
-          }
-        }
-      }
-      bf16x8 pp[qf::MAXKT][2];
-      float mrun, ltot;
-      qf_softmax<qf::MAXKT>(sc, pp, scale2, p.Tv, hi, (uint32_t)(f * qf::H + h) * qf::NQ + (uint32_t)l31, p.d_cattn, mrun, ltot);
+      for (int s = 0; s < 4; ++s) qh[s] = hh == 0 ? qp[0][s] : hh == 1 ? qp[1][s] : qp[2][s];
+      const bf16_t* kb = p.kv + (long long)f * p.Tv * (2 * qf::D) + 64 * h + 4 * hi;
+      const bf16_t* vb = p.vt + ((long long)(f * qf::H + h) * 64 + l31) * p.Tvp + 4 * hi;
+      const int tv1 = p.Tv - 1;
+      const long long tvp = p.Tvp;
       f32x16 oa[2];
-      qf_zero(oa[0]);
-      qf_zero(oa[1]);
-      const bf16_t* vb = p.vt + ((long long)(f * qf::H + h) * 64) * p.Tvp;
-#pragma unroll
-      for (int kt = 0; kt < qf::MAXKT; ++kt) {
-        if (kt < nkt) {
-#pragma unroll
-          for (int t = 0; t < 2; ++t) {
-            const bf16_t* vr = vb + (long long)(32 * t + l31) * p.Tvp + 32 * kt;
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {   // keys 32 kt + 16 s + 8 (e >> 2) + 4 hi + (e & 3)
-              union { bf16x8 v8; uint2 u2[2]; } vf;
-              vf.u2[0] = *reinterpret_cast<const uint2*>(vr + 16 * s + 4 * hi);
-              vf.u2[1] = *reinterpret_cast<const uint2*>(vr + 16 * s + 8 + 4 * hi);
-              oa[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.v8, pp[kt][s], oa[t], 0, 0, 0);
-            }
-          }
-        }
-      }
-      const float inv = (p.d_cattn.seed_ptr ? p.d_cattn.inv_keep : 1.0f) / ltot;
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) oa[t][r] *= inv;
-        opk[hh][2 * t] = qf_pack8(oa[t], 0);
-        opk[hh][2 * t + 1] = qf_pack8(oa[t], 8);
-      }
+      float mrun, ltot;
+      qf_attend(nkt, p.Tv, qh,
+                [&](int kt, int s) {   // key row min(32 kt + lane, Tv - 1); head dims 16 s + 8 (e >> 2) + 4 hi + (e & 3): the permutation the packed q carries
+                  const bf16_t* kr = kb + (long long)min(32 * kt + l31, tv1) * (2 * qf::D) + 16 * s;
+                  union { bf16x8 v8; uint2 u2[2]; } kf;
+                  kf.u2[0] = *reinterpret_cast<const uint2*>(kr);
+                  kf.u2[1] = *reinterpret_cast<const uint2*>(kr + 8);
+                  return kf.v8;
+                },
+                [&](int kt, int t, int s) {   // V^T row 32 t + lane; keys 32 kt + 16 s + 8 (e >> 2) + 4 hi + (e & 3)
+                  const bf16_t* vr = vb + 32 * t * tvp + 32 * kt + 16 * s;
+                  union { bf16x8 v8; uint2 u2[2]; } vf;
+                  vf.u2[0] = *reinterpret_cast<const uint2*>(vr);
+                  vf.u2[1] = *reinterpret_cast<const uint2*>(vr + 8);
+                  return vf.v8;
+                },
+                scale2, hi, (uint32_t)(f * qf::H + h) * qf::NQ + (uint32_t)l31, p.d_cattn, oa, mrun, ltot);
+      qf_keep_head(opk, hh, oa);
       if (hi == 0) p.lsec[(long long)(f * qf::H + h) * qf::NQ + l31] = mrun * 0.6931471805599453f + __logf(ltot);
     }
     __syncthreads();
-#pragma unroll
-    for (int hh = 0; hh < 3; ++hh)
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int n = 64 * (3 * w + hh) + 32 * t + 8 * j + 4 * hi;
-          union { bf16x8 v8; uint2 u2[2]; } u;
-          u.v8 = opk[hh][2 * t + (j >> 1)];
-          *reinterpret_cast<uint2*>(xl + l31 * qf::XSTR + n * 2) = u.u2[j & 1];
-          *reinterpret_cast<uint2*>(p.oc + (long long)row * p.ldo + n) = u.u2[j & 1];
-        }
+    qf_store_heads(opk, xl, p.oc, p.ldo, row, l31, hi, w);
     __syncthreads();
     f32x16 acc[6];
 #pragma unroll
     for (int t = 0; t < 6; ++t) qf_zero(acc[t]);
-    qf_wave_gemm<6, 0>(acc, xl, qf::XSTR, qf::D / 64, p.co_w, qf::D, 0, (uint32_t)(qf::D * qf::D * 2), [&](int t) { return nb + 32 * t; }, ring, lane);
-    qf_block_epilogue(acc, xr, nb, row, hi, l31, w, p.co_b, p.d_co, p.y2, p.c_lnw, p.c_lnb, p.eps, red, xl, nullptr, nullptr, 0);
+    qf_gemm<6, 0, 2>(acc, xl, qf::XSTR, qf::D / 64, p.co_w, qf::D, 0, (uint32_t)(qf::D * qf::D * 2), [&](int t) { return nb + 32 * t; }, ring, lane);
+    qf_block_epilogue(acc, nb, row, hi, l31, w, p.co_b, p.d_co, p.x_out, p.y2, p.c_lnw, p.c_lnb, p.eps, red, xl, p.x_out, nullptr, 0);
   }
 
   // ---- FFN: six passes over 512 intermediate features; the GELU output of a pass is the token operand of the second product
@@ -473,7 +560,7 @@ __global__ __launch_bounds__(256, 1) void qformer_layer_fwd_kernel(const QfLayer
 #pragma unroll
       for (int t = 0; t < 4; ++t) qf_zero(ha[t]);
       const int hb = qf::HC * c + 128 * w;   // this wave's 128 intermediate features of the pass
-      qf_wave_gemm<4, 0>(ha, xl, qf::XSTR, qf::D / 64, p.i_w, qf::D, 0, (uint32_t)((long long)qf::DI * qf::D * 2), [&](int t) { return hb + 32 * t; }, ring, lane);
+      qf_gemm<4, 0, 2>(ha, xl, qf::XSTR, qf::D / 64, p.i_w, qf::D, 0, (uint32_t)((long long)qf::DI * qf::D * 2), [&](int t) { return hb + 32 * t; }, ring, lane);
       uint2 hp[4][4];
 #pragma unroll
       for (int t = 0; t < 4; ++t)
@@ -493,22 +580,76 @@ __global__ __launch_bounds__(256, 1) void qformer_layer_fwd_kernel(const QfLayer
 #pragma unroll
         for (int j = 0; j < 4; ++j) *reinterpret_cast<uint2*>(hl + l31 * qf::HSTR + (128 * w + 32 * t + 8 * j + 4 * hi) * 2) = hp[t][j];
       __syncthreads();
-      qf_wave_gemm<6, 0>(acc, hl, qf::HSTR, qf::HC / 64, p.o_w, qf::DI, (long long)qf::HC * c, (uint32_t)((long long)qf::D * qf::DI * 2),
-                         [&](int t) { return nb + 32 * t; }, ring, lane);
+      qf_gemm<6, 0, 2>(acc, hl, qf::HSTR, qf::HC / 64, p.o_w, qf::DI, (long long)qf::HC * c, (uint32_t)((long long)qf::D * qf::DI * 2),
+                            [&](int t) { return nb + 32 * t; }, ring, lane);
     }
-    qf_block_epilogue(acc, xr, nb, row, hi, l31, w, p.o_b, p.d_ffn, p.y3, p.o_lnw, p.o_lnb, p.eps, red, xl, p.x_out, p.xb_out, p.ldxb);
+    qf_block_epilogue(acc, nb, row, hi, l31, w, p.o_b, p.d_ffn, p.x_out, p.y3, p.o_lnw, p.o_lnb, p.eps, red, xl, p.x_out, p.xb_out, p.ldxb);
   }
 }
 
-extern "C" int mrblip_qformer_layer_fwd(const QfLayerArgs* a, hipStream_t stream) {
+// the public argument block (include/mrblip_hip.h: mrblip_qformer_layer) — plain pointers and sizes
+struct mrblip_qformer_layer {
+  const void *qkv_w, *so_w, *cq_w, *co_w, *i_w, *o_w;
+  const float *qkv_b, *so_b, *s_lnw, *s_lnb, *cq_b, *co_b, *c_lnw, *c_lnb, *i_b, *o_b, *o_lnw, *o_lnb;
+  const float* x_in;
+  float* x_out;
+  void* xb_out;
+  long long ldxb;
+  void *qkv, *o;
+  long long ldo;
+  float *lse, *y;
+  void *qc, *oc;
+  float *lsec, *y2;
+  const void *kv, *vt;
+  void* hpre;
+  float* y3;
+  int F, Tv, Tvp, has_cross;
+  const uint32_t* seed_ptr;
+  float p_drop;
+  uint32_t site_sattn, site_so, site_cattn, site_co, site_ffn;
+  float eps;
+};
+
+static DropoutArg qf_drop(const uint32_t* seed_ptr, uint32_t site, float p) {
+  DropoutArg d;
+  const bool on = seed_ptr != nullptr && p > 0.f;
+  d.seed_ptr = on ? seed_ptr : nullptr;
+  d.site = site;
+  d.thresh24 = (uint32_t)(p * 65536.0f + 0.5f);
+  if (on && d.thresh24 < 1u) d.thresh24 = 1u;
+  d.inv_keep = on ? 1.0f / (1.0f - p) : 1.0f;
+  return d;
+}
+
+extern "C" int mrblip_qformer_layer_fwd(const mrblip_qformer_layer* a, hipStream_t stream) {
   MRB_REQUIRE(a != nullptr && a->F > 0, "qformer_layer_fwd: no frames");
+  MRB_REQUIRE(a->qkv_w && a->so_w && a->i_w && a->o_w && a->qkv_b && a->so_b && a->s_lnw && a->s_lnb && a->i_b && a->o_b && a->o_lnw && a->o_lnb,
+              "qformer_layer_fwd: missing weight");
   MRB_REQUIRE(a->x_in && a->x_out && a->qkv && a->o && a->lse && a->y && a->hpre && a->y3, "qformer_layer_fwd: missing buffer");
-  MRB_REQUIRE(a->ldo >= qf::D && a->ldo % 4 == 0, "qformer_layer_fwd: ldo");
+  MRB_REQUIRE(a->ldo >= qf::D && a->ldo % 4 == 0, "qformer_layer_fwd: ldo %lld", a->ldo);
+  MRB_REQUIRE(!a->xb_out || (a->ldxb >= qf::D && a->ldxb % 4 == 0), "qformer_layer_fwd: ldxb %lld", a->ldxb);
+  MRB_REQUIRE(a->p_drop >= 0.f && a->p_drop < 1.f, "qformer_layer_fwd: p_drop %f", a->p_drop);
   if (a->has_cross) {
-    MRB_REQUIRE(a->qc && a->oc && a->lsec && a->y2 && a->kv && a->vt && a->cq_w && a->co_w, "qformer_layer_fwd: missing cross-attention buffer");
-    MRB_REQUIRE(a->Tv >= 1 && a->Tv <= 32 * qf::MAXKT && a->Tvp >= a->Tv && a->Tvp % 32 == 0, "qformer_layer_fwd: Tv %d / Tvp %d", a->Tv, a->Tvp);
+    MRB_REQUIRE(a->qc && a->oc && a->lsec && a->y2 && a->kv && a->vt && a->cq_w && a->co_w && a->cq_b && a->co_b && a->c_lnw && a->c_lnb,
+                "qformer_layer_fwd: missing cross-attention buffer");
+    MRB_REQUIRE(a->Tv >= 1 && a->Tvp >= a->Tv && a->Tvp % 32 == 0, "qformer_layer_fwd: Tv %d / Tvp %d", a->Tv, a->Tvp);
   }
-  static bool attr_set = false;
+  QfLayerArgs k;
+  k.qkv_w = (const bf16_t*)a->qkv_w; k.so_w = (const bf16_t*)a->so_w; k.cq_w = (const bf16_t*)a->cq_w; k.co_w = (const bf16_t*)a->co_w;
+  k.i_w = (const bf16_t*)a->i_w; k.o_w = (const bf16_t*)a->o_w;
+  k.qkv_b = a->qkv_b; k.so_b = a->so_b; k.s_lnw = a->s_lnw; k.s_lnb = a->s_lnb; k.cq_b = a->cq_b; k.co_b = a->co_b; k.c_lnw = a->c_lnw; k.c_lnb = a->c_lnb;
+  k.i_b = a->i_b; k.o_b = a->o_b; k.o_lnw = a->o_lnw; k.o_lnb = a->o_lnb;
+  k.x_in = a->x_in; k.x_out = a->x_out; k.xb_out = (bf16_t*)a->xb_out; k.ldxb = a->ldxb;
+  k.qkv = (bf16_t*)a->qkv; k.o = (bf16_t*)a->o; k.ldo = a->ldo; k.lse = a->lse; k.y = a->y;
+  k.qc = (bf16_t*)a->qc; k.oc = (bf16_t*)a->oc; k.lsec = a->lsec; k.y2 = a->y2; k.kv = (const bf16_t*)a->kv; k.vt = (const bf16_t*)a->vt;
+  k.hpre = (bf16_t*)a->hpre; k.y3 = a->y3;
+  k.F = a->F; k.Tv = a->Tv; k.Tvp = a->Tvp; k.has_cross = a->has_cross;
+  k.d_sattn = qf_drop(a->seed_ptr, a->site_sattn, a->p_drop); k.d_so = qf_drop(a->seed_ptr, a->site_so, a->p_drop);
+  k.d_cattn = qf_drop(a->seed_ptr, a->site_cattn, a->p_drop); k.d_co = qf_drop(a->seed_ptr, a->site_co, a->p_drop);
+  k.d_ffn = qf_drop(a->seed_ptr, a->site_ffn, a->p_drop);
+  k.eps = a->eps;
+  // (idempotent; a thread-local "done" flag only skips the repeated driver call)
+  static thread_local bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(qformer_layer_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, qf::LDS_BYTES) != hipSuccess) {
       mrblip_set_error("qformer_layer_fwd: cannot reserve %d bytes of LDS", qf::LDS_BYTES);
@@ -516,6 +657,6 @@ extern "C" int mrblip_qformer_layer_fwd(const QfLayerArgs* a, hipStream_t stream
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL(qformer_layer_fwd_kernel, dim3(a->F), dim3(256), qf::LDS_BYTES, stream, *a);
+  hipLaunchKernelGGL(qformer_layer_fwd_kernel, dim3(a->F), dim3(256), qf::LDS_BYTES, stream, k);
   return mrblip_check_launch("qformer_layer_fwd");
 }

@@ -499,6 +499,8 @@ class MrBlipEngine:
         ops.layernorm_fwd(q_exp, self.qf["emb_w"], self.qf["emb_b"], eps, out_f32=x)
         xb = self.buf("qf_xb0", (Mq, pad64(D)), bf16)
         ops.cast_dropout(x, out_bf16=xb, out_f32=x, drop=self.qdrop(self.qf_emb_site, pdrop))
+        if self._qf_fused_ok():
+            return self._qformer_forward_fused(img, F_, x)
         vt_s = self.buf("qf_vt_s", (F_, H, ops.rup32(hd), ops.rup32(nq)), bf16)
         vt_c = self.buf("qf_vt_c", (F_, H, ops.rup32(hd), ops.rup32(Tv)), bf16)
         t_ok = self.tout_ok(hd, F_, nq, 4)
@@ -595,6 +597,86 @@ class MrBlipEngine:
             x = self.buf(f"qf{i}_x3", (Mq, D), f32, zero=False)
             xb = self.buf(f"qf{i}_x3b", (Mq, pad64(D)), bf16)
             ops.layernorm_fwd(y3, L["lnw"], L["lnb"], eps, out_bf16=xb, out_f32=x)
+        self._qf_last_f32 = x
+        return xb
+
+    # Round 6: one launch per Q-Former layer (csrc/qformer.hip: a workgroup owns one frame's 32 query tokens through the whole layer) instead
+    # of the chain of 7 / 11 launches above.  BERT-base geometry only (the real Q-Former).  Built, parity-tested against the chain
+    # (tests/test_qformer_fused_gpu.py) and MEASURED SLOWER — off by default (MRB_QF_FUSED=1 selects it): every workgroup has to pull the
+    # layer's 14-17 MB of weights through ONE CU, and one CU draws ~43 GB/s through LDS-DMA with 48 KB in flight (27 GB/s with fragment-shaped
+    # register loads), whatever the number of frames — 4.8 ms per 12-layer forward on 60 CUs against 2.0 ms for the chain on the whole chip;
+    # in the step, with the look-ahead's head leg widened to fill the other 196 CUs, 66.1 ms against 65.6 (profiles/r06_qformer_fused.txt).
+    qf_fused = os.environ.get("MRB_QF_FUSED", "0") == "1"
+
+    def _qf_fused_ok(self) -> bool:
+        c = self.cfg
+        return bool(self.qf_fused and c.qf_dim == 768 and c.qf_heads == 12 and c.num_query == 32 and c.qf_inter == 3072)
+
+    @torch.no_grad()
+    def _qformer_forward_fused(self, img: torch.Tensor, F_: int, x: torch.Tensor) -> torch.Tensor:
+        """x: fp32 [F * nq, D], the (dropped) embedding LayerNorm output.  The cross-attention K / V projections of the image tokens — the
+        Q-Former's only big GEMMs — and their V^T copies are issued first, on the side stream when there is one (each cross layer waits for
+        its own event); then one fused launch per layer on F_ CUs."""
+        c = self.cfg
+        D, H, nq, I = c.qf_dim, c.qf_heads, c.num_query, c.qf_inter
+        hd = D // H
+        Mq = F_ * nq
+        Tv = img.shape[0] // F_
+        Tvp = ops.rup32(Tv)
+        pdrop = c.qf_dropout if self.training else 0.0
+        self.qf_t_saved = False
+        kv_of = {}
+
+        def kv_jobs():
+            for i, L in enumerate(self.qf["layers"]):
+                if L["cross"] is None:
+                    continue
+                C_ = L["cross"]
+                kv = self.buf(f"qf{i}_kvc", (F_ * Tv, 2 * D), bf16, zero=False)
+                vt_i = self.buf(f"qf{i}_vt_c", (F_, H, ops.rup32(hd), Tvp), bf16)
+                ops.gemm(img, C_["kv_w"], kv, bias=C_["kv_b"])
+                ops.head_transpose(self.v4(kv, F_, Tv, H, hd, D), out=vt_i)
+                ev = None
+                if side:
+                    ev = torch.cuda.Event()
+                    ev.record()
+                kv_of[i] = (kv, vt_i, ev)
+
+        side = self.qf_kv_side and self.grad_side_stream_enabled
+        if side:
+            st, ev0 = self._grad_stream(), torch.cuda.Event()
+            ev0.record()
+            with torch.cuda.stream(st):
+                st.wait_event(ev0)
+                kv_jobs()
+        else:
+            kv_jobs()
+        n_layers = len(self.qf["layers"])
+        xb = None
+        for i, L in enumerate(self.qf["layers"]):
+            S_, C_ = L["self"], L["cross"]
+            last = i == n_layers - 1
+            x_out = self.buf(f"qf{i}_x3", (Mq, D), f32, zero=False)
+            xb = self.buf(f"qf{i}_x3b", (Mq, pad64(D)), bf16) if last else None
+            o = self.buf(f"qf{i}_o", (Mq, pad64(D)), bf16)
+            fields = dict(qkv_w=S_["qkv_w"], so_w=S_["ow"], i_w=L["iw"], o_w=L["ow"], qkv_b=S_["qkv_b"], so_b=S_["ob"], s_lnw=S_["lnw"], s_lnb=S_["lnb"],
+                          i_b=L["ib"], o_b=L["ob"], o_lnw=L["lnw"], o_lnb=L["lnb"], x_in=x, x_out=x_out, xb_out=xb, ldxb=pad64(D),
+                          qkv=self.buf(f"qf{i}_qkv", (Mq, 3 * D), bf16, zero=False), o=o, ldo=o.stride(0),
+                          lse=self.buf(f"qf{i}_lse", (F_, H, ops.rup32(nq)), f32), y=self.buf(f"qf{i}_y", (Mq, D), f32, zero=False),
+                          hpre=self.buf(f"qf{i}_hpre", (Mq, pad64(I)), bf16, zero=False), y3=self.buf(f"qf{i}_y3", (Mq, D), f32, zero=False),
+                          F=F_, Tv=Tv, Tvp=Tvp, has_cross=int(C_ is not None))
+            sites = [S_["sites"][0], S_["sites"][1], 0, 0, L["site"]]
+            if C_ is not None:
+                kv, vt_i, ev = kv_of[i]
+                if ev is not None:
+                    torch.cuda.current_stream().wait_event(ev)
+                oc = self.buf(f"qf{i}_oc", (Mq, pad64(D)), bf16)
+                fields.update(cq_w=C_["q_w"], co_w=C_["ow"], cq_b=C_["q_b"], co_b=C_["ob"], c_lnw=C_["lnw"], c_lnb=C_["lnb"],
+                              qc=self.buf(f"qf{i}_qc", (Mq, D), bf16, zero=False), oc=oc,
+                              lsec=self.buf(f"qf{i}_lsec", (F_, H, ops.rup32(nq)), f32), y2=self.buf(f"qf{i}_y2", (Mq, D), f32, zero=False), kv=kv, vt=vt_i)
+                sites[2], sites[3] = C_["sites"][0], C_["sites"][1]
+            ops.qformer_layer_fwd(fields, seed=self.seed if pdrop > 0 else None, p_drop=pdrop, sites=[s_ + self.qf_site_salt for s_ in sites], eps=1e-12)
+            x = x_out
         self._qf_last_f32 = x
         return xb
 

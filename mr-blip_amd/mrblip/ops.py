@@ -107,6 +107,19 @@ _gated_bwd_parts = _sig("mrblip_gated_gelu_bwd_parts", vp, vp, ll, vp, ll, vp, l
 _sum_parts = _sig("mrblip_sum_parts", vp, ll, ll, i32, vp, ll, vp, ll, i32, i32, vp)
 _rms_lora = _sig("mrblip_rmsnorm_lora_fwd", vp, ll, vp, i32, i32, f32, vp, ll, vp, ll, i32, vp, ll, vp, u32, f32, vp)
 
+
+
+class QformerLayer(C.Structure):
+    """mrblip_qformer_layer (include/mrblip_hip.h)"""
+    _fields_ = ([(n, vp) for n in ("qkv_w", "so_w", "cq_w", "co_w", "i_w", "o_w", "qkv_b", "so_b", "s_lnw", "s_lnb", "cq_b", "co_b", "c_lnw", "c_lnb",
+                                   "i_b", "o_b", "o_lnw", "o_lnb", "x_in", "x_out", "xb_out")] + [("ldxb", ll), ("qkv", vp), ("o", vp), ("ldo", ll)] +
+                [(n, vp) for n in ("lse", "y", "qc", "oc", "lsec", "y2", "kv", "vt", "hpre", "y3")] +
+                [("F", i32), ("Tv", i32), ("Tvp", i32), ("has_cross", i32), ("seed_ptr", vp), ("p_drop", f32)] +
+                [(n, u32) for n in ("site_sattn", "site_so", "site_cattn", "site_co", "site_ffn")] + [("eps", f32)])
+
+
+_qf_layer_fwd = _sig("mrblip_qformer_layer_fwd", C.POINTER(QformerLayer), vp)
+
 EXPORTS = [
     "mrblip_last_error", "mrblip_abi_version", "mrblip_gemm_bf16", "mrblip_layernorm_fwd", "mrblip_rmsnorm_fwd",
     "mrblip_layernorm_bwd", "mrblip_rmsnorm_bwd", "mrblip_rmsnorm_bwd_cast", "mrblip_attention_fwd", "mrblip_attention_fwd_rowv", "mrblip_attention_bwd", "mrblip_head_transpose",
@@ -116,6 +129,7 @@ EXPORTS = [
     "mrblip_lora_grads", "mrblip_lora_grads_batched", "mrblip_gemm_lora_down", "mrblip_gemm_lora_dx", "mrblip_patchify_u8",
     "mrblip_gemm_set_cu_reserve", "mrblip_lora_rows", "mrblip_rmsnorm_lora_fwd", "mrblip_lora_rows_init", "mrblip_dec_proj", "mrblip_dec_proj_config", "mrblip_lora_dx_add_batched", "mrblip_lora_rows_batched", "mrblip_gemm_set_extra", "mrblip_attention_set_split_workspace",
     "mrblip_gemm_ksplit", "mrblip_rmsnorm_bwd_parts", "mrblip_rmsnorm_bwd_parts_g", "mrblip_set_reduce_workspace", "mrblip_reduce_workspace_bytes", "mrblip_gemm_clear_one_shots", "mrblip_gated_gelu_bwd_parts", "mrblip_sum_parts",
+    "mrblip_qformer_layer_fwd",
     "mrblip_gemm_f16", "mrblip_layernorm_fwd_f16", "mrblip_attention_fwd_rowv_f16", "mrblip_patchify_f16", "mrblip_patchify_u8_f16",
 ]
 
@@ -166,6 +180,24 @@ def _d(d: Optional[Dropout]):
     if d is None or d.p <= 0.0:
         return None, 0, 0.0
     return d.seed.data_ptr(), d.site, d.p
+
+
+def qformer_layer_fwd(fields: dict, *, seed: Optional[torch.Tensor], p_drop: float, sites: Sequence[int], eps: float):
+    """One Q-Former layer's query branch in one launch (mrblip_qformer_layer_fwd).  ``fields``: tensor per pointer field of
+    mrblip_qformer_layer (None where the layer has no cross-attention) plus the ints F, Tv, Tvp, has_cross, ldxb, ldo."""
+    a = QformerLayer()
+    for name, typ in QformerLayer._fields_:
+        v = fields.get(name)
+        if typ is vp and name != "seed_ptr":
+            setattr(a, name, None if v is None else v.data_ptr())
+        elif name in ("F", "Tv", "Tvp", "has_cross", "ldxb", "ldo"):
+            setattr(a, name, int(v or 0))
+    on = seed is not None and p_drop > 0.0
+    a.seed_ptr = seed.data_ptr() if on else None
+    a.p_drop = float(p_drop) if on else 0.0
+    a.site_sattn, a.site_so, a.site_cattn, a.site_co, a.site_ffn = (int(x) & 0xFFFFFFFF for x in sites)
+    a.eps = float(eps)
+    _chk(_qf_layer_fwd(C.byref(a), _stream()))
 
 
 # ------------------------------------------------------------------------------------------------ GEMM

@@ -1,0 +1,105 @@
+"""Round 6: the Q-Former's query branch as ONE launch per layer (csrc/qformer.hip, mrblip_qformer_layer_fwd: a workgroup owns one frame's
+32 query tokens through self-attention, cross-attention and the FFN) against the launch chain it replaces (Qformer.py:111-289, 349-375,
+402-474) — same rounding points, same dropout draws, other fp32 summation orders.  BERT-base geometry (the real Q-Former) over a small ViT
+width; everything the backward reads (qkv, attention outputs, log-sum-exps, pre-LayerNorm sums, pre-GELU) is compared, with dropout on."""
+import os
+import sys
+
+import pytest
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "mr-blip_amd"))
+pytestmark = pytest.mark.gpu
+
+from util import check, relerr  # noqa: E402
+
+
+def _engine(layers=4, seed=5):
+    import bench
+    from mrblip.engine import EngineConfig, MrBlipEngine, RandomSource
+    dev = torch.device("cuda:0")
+    cfg = EngineConfig(vit_dim=320, vit_depth=1, vit_heads=5, vit_mlp=512, qf_layers=layers, d_model=256, d_kv=64, t5_heads=4, d_ff=512, t5_layers=1,
+                       t5_dec_layers=1)
+    eng = MrBlipEngine(cfg, RandomSource(dev, seed=seed, std=0.05), dev, lora_init=bench.lora_init_nonzero, seed=11)
+    # RandomSource hands out zero biases and unit LayerNorm weights: give every Q-Former vector a value
+    g = torch.Generator(device=dev).manual_seed(seed + 1)
+
+    def jitter(d):
+        for k, v in d.items():
+            if isinstance(v, dict):
+                jitter(v)
+            elif torch.is_tensor(v) and v.dtype == torch.float32 and v.dim() == 1:
+                v.add_(torch.randn(v.shape, generator=g, device=dev) * 0.1)
+    for L in eng.qf["layers"]:
+        jitter(L)
+    return eng
+
+
+_SAVED = ("qkv", "o", "lse", "y", "qc", "oc", "lsec", "y2", "hpre", "y3")
+
+
+def _run(eng, img, F, fused, training):
+    eng.qf_fused = fused
+    eng.training = training
+    xb = eng.qformer_forward(img, F)
+    torch.cuda.synchronize()
+    out = {"out_bf16": xb.float().clone(), "out_f32": eng._qf_last_f32.clone()}
+    for i, L in enumerate(eng.qf["layers"]):
+        for n in _SAVED:
+            if n in ("qc", "oc", "lsec", "y2") and L["cross"] is None:
+                continue
+            out[f"{i}.{n}"] = eng.ws[f"qf{i}_{n}"].float().clone()
+    return out
+
+
+@pytest.mark.parametrize("training", [False, True])
+def test_fused_qformer_layer_equals_the_launch_chain(training):
+    eng = _engine()
+    eng.qf_fused = True
+    assert eng._qf_fused_ok()
+    F = 7
+    Tv = (eng.cfg.img // eng.cfg.patch) ** 2 + 1
+    g = torch.Generator(device="cuda").manual_seed(3)
+    img = torch.zeros(F * Tv, (eng.cfg.vit_dim + 63) // 64 * 64, dtype=torch.bfloat16, device="cuda")
+    img[:, :eng.cfg.vit_dim] = torch.randn(F * Tv, eng.cfg.vit_dim, generator=g, device="cuda").bfloat16()
+    ref = _run(eng, img, F, False, training)
+    got = _run(eng, img, F, True, training)
+    tag = "fused Q-Former layer vs launch chain (%s): " % ("dropout on" if training else "eval")
+    worst = 0.0
+    for k in ref:
+        e = relerr(got[k], ref[k])
+        worst = max(worst, e)
+        assert e < 2e-2, (k, e)
+    check(tag + "worst saved tensor", worst, 1e-2)
+    check(tag + "last hidden state (fp32)", relerr(got["out_f32"], ref["out_f32"]), 1e-2)
+    check(tag + "layer 0 qkv", relerr(got["0.qkv"], ref["0.qkv"]), 2e-3)
+    check(tag + "layer 0 self-attention output", relerr(got["0.o"], ref["0.o"]), 3e-3)
+    check(tag + "layer 0 log-sum-exp", relerr(got["0.lse"], ref["0.lse"]), 1e-3)
+    check(tag + "layer 0 cross-attention output", relerr(got["0.oc"], ref["0.oc"]), 3e-3)
+    check(tag + "layer 0 pre-GELU", relerr(got["0.hpre"], ref["0.hpre"]), 3e-3)
+
+
+def test_train_step_with_the_fused_qformer_equals_the_launch_chain():
+    """loss and flat gradient of whole train steps (dropout on, backward through the chain's saved tensors) with either forward"""
+    import bench
+    from mrblip import prompt as P
+    from mrblip.tokenizer import FixtureTokenizer
+    res = {}
+    for fused in (False, True):
+        eng = _engine(layers=2, seed=9)
+        eng.qf_fused = fused
+        eng.training = True
+        tok = FixtureTokenizer()
+        repl = P.annoying_replacement_dict(P.find_annoying_numbers(tok, 200)[0])
+        T = 6
+        samples = bench.synthetic_samples(1, T, 150.0, eng.dev, 5)
+        lay = P.build_layout(tok, samples, repl, eng.cfg.num_query, T=T)
+        eng.zero_grad()
+        loss = eng.forward_backward(samples["video"], lay, backward=True).item()
+        torch.cuda.synchronize()
+        res[fused] = (loss, eng.grad.detach().clone())
+    tag = "train step, fused Q-Former forward vs launch chain: "
+    check(tag + "loss (rel)", abs(res[True][0] - res[False][0]) / abs(res[False][0]), 1e-3)
+    # (the backward consumes the forward's SAVED bf16 tensors: one-ulp flips there move single gradient elements by percent — the band in which
+    # the product path's gradients sit against the oracle's fp32 autograd; measured 4.2e-2 on this 6-frame toy step)
+    check(tag + "flat gradient", relerr(res[True][1], res[False][1]), 8e-2)

@@ -90,6 +90,8 @@ class Fp32Verify(contextlib.AbstractContextManager):
         eng.gemm_thin_enabled = False      # (the patched gemm has no thin role: the "down" product stays a launch of its own)
         S["qkv_w4"] = eng.enc_qkv_w4
         eng.enc_qkv_w4 = 0                 # (round 5: the qkv projection as one [xn | u] x [W | B]^T product is a bf16-operand layout too)
+        S["qf_fused"] = eng.qf_fused
+        eng.qf_fused = False               # (round 6: the fused Q-Former layer has no wide-operand form; the launch chain it replaces is what is verified)
         S["wi_w4"] = eng.enc_wi_w4
         eng.enc_wi_w4 = 0                  # (round 6: likewise the gated wi projection's [xn2 | u] x [W | B]^T form)
         S["pf"] = (eng.enc_prefetch, eng.qf_prefetch)
@@ -148,6 +150,7 @@ class Fp32Verify(contextlib.AbstractContextManager):
         eng.enc_prefetch, eng.qf_prefetch = S["pf"]
         eng.enc_qkv_w4 = S["qkv_w4"]
         eng.enc_wi_w4 = S["wi_w4"]
+        eng.qf_fused = S["qf_fused"]
         eng.vit_dtype = S["vit_dtype"]
         for obj, key, val in self._weight_restore:
             obj[key] = val
