@@ -2267,6 +2267,15 @@ static int gemm_dispatch(const void* A, long long lda, const void* W, long long 
     if (gated) return launch_tile<128, 128, 2, 2, false, true, 64, 4>(a, stream);
     return out_f32 ? launch_tile<128, 128, 2, 2, true, false, 64, 4>(a, stream) : launch_tile<128, 128, 2, 2, false, false, 64, 4>(a, stream);
   }
+  // round 6: the same for the 64x64 tile (the Q-Former's M = 1920 products over K = 768: twelve K-tiles, each a full LDS-DMA latency with two stages)
+  if (cfg == 22) {  // 64x64, 3 stages (48 KB: three blocks per CU)
+    MRB_REQUIRE(!gated, "gemm: the 64x64 tile has no gated epilogue");
+    return out_f32 ? launch_tile<64, 64, 2, 2, true, false, 64, 3>(a, stream) : launch_tile<64, 64, 2, 2, false, false, 64, 3>(a, stream);
+  }
+  if (cfg == 23) {  // 64x64, 4 stages (64 KB: two blocks per CU)
+    MRB_REQUIRE(!gated, "gemm: the 64x64 tile has no gated epilogue");
+    return out_f32 ? launch_tile<64, 64, 2, 2, true, false, 64, 4>(a, stream) : launch_tile<64, 64, 2, 2, false, false, 64, 4>(a, stream);
+  }
   if (cfg == 4) {
     if (gated) return launch_tile<64, 128, 2, 2, false, true>(a, stream);
     return out_f32 ? launch_tile<64, 128, 2, 2, true, false>(a, stream) : launch_tile<64, 128, 2, 2, false, false>(a, stream);
