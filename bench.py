@@ -457,7 +457,7 @@ def main():
         m, n, k = F_ * 257, cfg.vit_mlp, cfg.vit_dim
         traffic_note = None
         traffic = None  # HBM-side bytes per launch of the same kernel from the committed PMC pass (tools/pmc_fc1.sh), QVH B=1 shape only
-        pmc = next((q for q in (os.path.join(ROOT, "profiles", n) for n in ("r05_pmc_fc1.json", "r04_pmc_fc1.json", "r03_pmc_fc1.json", "r02_pmc_fc1.json")) if os.path.exists(q)), None)
+        pmc = next((q for q in (os.path.join(ROOT, "profiles", n) for n in ("r06_pmc_fc1.json", "r05_pmc_fc1.json", "r04_pmc_fc1.json", "r03_pmc_fc1.json", "r02_pmc_fc1.json")) if os.path.exists(q)), None)
         if pmc and args.workload == "qvh" and B == 1 and F_ == 60:
             pj = json.load(open(pmc))
             traffic = pj.get("traffic_bytes_per_launch")
