@@ -2414,7 +2414,7 @@ struct TnArgs {
   DropoutArg drop;
 };
 
-struct TnArgs2 { TnArgs a, b; int blocks_a; };  // two independent problems in one launch (blocks [0, blocks_a) -> a, the rest -> b)
+struct TnArgs2 { TnArgs a, b; int blocks_a; int has_b; };  // two independent problems in one launch (blocks [0, blocks_a) -> a, the rest -> b)
 // Round 5: up to TN_MAX_PROBLEMS independent problems in one launch — the weight-gradient pairs of ALL LoRA groups of a T5 layer (round
 // 4: one launch per group, ~305 launches and ~5 ms of side-stream kernel time per step for ~20 GFLOP).  blk_end[i] = first block id
 // behind problem i.
@@ -2422,57 +2422,72 @@ struct TnArgs2 { TnArgs a, b; int blocks_a; };  // two independent problems in o
 struct TnMulti { TnArgs p[TN_MAX_PROBLEMS]; int blk_end[TN_MAX_PROBLEMS]; int n; };
 
 // the block body shared by both kernels: the problem's scalars arrive in registers (see the note on kernarg re-fetches below), its four
-// output segments through a pointer into the kernel arguments (read once, in the epilogue)
+// output segments through a pointer into the kernel arguments (read once, in the epilogue).
+// CT (round 6): 32-column tiles of Y per block.  With CT = 1 a block reads 64 B of every Y row — half a cache line, the other half belongs
+// to the neighbour block, and every block re-reads all of U: the encoder layer's launch moved 128 MB of Y and 128 MB of U through the
+// L2s in 66-77 us (1.65 TB/s of algorithmic bytes).  CT = 2: whole 128-B lines per row, half the blocks, half the U traffic; the U
+// fragment of a slice serves both tiles.  Same per-wave row ranges, same MFMA accumulation order, same wave-order reduction: the same bits.
+template <int CT>
 __device__ __forceinline__ void lora_tn_body(const bf16_t* __restrict__ const Y, const bf16_t* __restrict__ const U, const long long ldy,
                                              const long long ldu, const int M, const int C, const int R, const uint32_t* const seed_ptr,
                                              const uint32_t site, const uint32_t thresh24, const float inv_keep, const TnSeg* const segs,
                                              const int bx) {
   const bool has_drop = seed_ptr != nullptr;
-  // Each wave stages its own 16-row slices of Y (16 x 32 columns) and U (16 x 32) with ONE 16-B global load per lane each,
-  // parks them in a wave-private LDS slot and gathers the k-major MFMA fragments from there with 2-byte LDS reads.
-  // UNROLL 16-row slices are in flight per wave (one 16-B load per lane and operand each) and go through the wave's two LDS slots in
-  // pairs.  (The 2 / 4 / 8 / 16 sweep of profiles/r03_lora_tn_unroll.txt — no gain from more slices in flight — was taken BEFORE the
-  // kernarg re-fetch above was found; see profiles/r03_lora_tn_v2.txt for the sweep after it.)
+  // Each wave stages its own 16-row slices of Y (16 x 32 CT columns) and U (16 x 32) with 16-B global loads (CT per lane for Y, one for
+  // U), parks them in a wave-private LDS slot and gathers the k-major MFMA fragments from there with the LDS transpose read.
+  // UNROLL 16-row slices are in flight per wave and go through the wave's LDS slots in pairs.  (The 2 / 4 / 8 / 16 sweep of
+  // profiles/r03_lora_tn_unroll.txt — no gain from more slices in flight — was taken BEFORE the kernarg re-fetch above was found; see
+  // profiles/r03_lora_tn_v2.txt for the sweep after it.)
 #ifndef LORA_TN_UNROLL
 #define LORA_TN_UNROLL 2
 #endif
   constexpr int UNROLL = LORA_TN_UNROLL;  // slices per iteration = LDS slots per wave
-  // LDS: the wave-private staging slots (8 waves x UNROLL x 2 KB) and, after the M loop, the cross-wave reduction buffer (32 KB) share
-  // one allocation
-  constexpr int SLOT_BYTES = 8 * UNROLL * 2 * 16 * 32 * 2, RED_BYTES = 8 * 16 * 64 * 4;
+  constexpr int YP = 64 * CT;             // row pitch of a Y slice image (bytes)
+  constexpr int YIMG = 16 * YP, UIMG = 16 * 64, SLOT = YIMG + UIMG;
+  // LDS: the wave-private staging slots and, after the M loop, the cross-wave reduction buffer (32 KB) share one allocation
+  constexpr int SLOT_BYTES = 8 * UNROLL * SLOT, RED_BYTES = 8 * 16 * 64 * 4;
   __shared__ __attribute__((aligned(16))) char tn_lds[SLOT_BYTES > RED_BYTES ? SLOT_BYTES : RED_BYTES];
-  typedef bf16_t slot_t[UNROLL][2][16 * 32];
-  slot_t* const slot = reinterpret_cast<slot_t*>(tn_lds);
   typedef float red_t[16][64];
   red_t* const red = reinterpret_cast<red_t*>(tn_lds);
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), hi = lane >> 5, l31 = lane & 31;
-  const int c0 = bx * 32;
-  const int c = c0 + l31;
-  const bool c_ok = c < C;
+  const int c0 = bx * 32 * CT;
   const uint32_t seed = has_drop ? *seed_ptr : 0u;
-  f32x16 acc;
+  f32x16 acc[CT];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
   const int steps = (M + 15) / 16;                 // 16 rows of M per MFMA
   const int per = (steps + 7) / 8;
   const int s_beg = w * per, s_end = min(steps, s_beg + per);
-  const int srow = lane >> 2, schunk = lane & 3;     // staging role: row of the 16-row slice, 8-column chunk
-  const int tr_off = (8 * hi + ((lane & 15) >> 2)) * 64 + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;   // transpose-read address inside a [16][32] slice image
-  const bool ychunk_ok = c0 + 8 * schunk < C, uchunk_ok = 8 * schunk < R;
+  // staging roles.  U: row lane >> 2 of the 16-row slice, 8-column chunk lane & 3.  Y: 4 CT lanes per row, 16 / CT rows per instruction
+  const int srow = lane >> 2, schunk = lane & 3;
+  constexpr int YLPR = 4 * CT, YRPI = 64 / YLPR;
+  const int yrow = lane / YLPR, ychunk = lane % YLPR;
+  // transpose-read addresses inside the slice images ([16][32 CT] for Y, [16][32] for U)
+  const int trr = 8 * hi + ((lane & 15) >> 2), trc = (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+  const int tr_y = trr * YP + trc, tr_u = trr * 64 + trc;
+  const bool ychunk_ok = c0 + 8 * ychunk < C, uchunk_ok = 8 * schunk < R;
   const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
-  const bf16_t* const ysrc = Y + c0 + 8 * schunk;
+  const bf16_t* const ysrc = Y + c0 + 8 * ychunk;
   const bf16_t* const usrc = U + 8 * schunk;
-  bf16x8 gy[UNROLL], gu[UNROLL];
+  char* const myslot = tn_lds + w * (UNROLL * SLOT);
+  bf16x8 gy[UNROLL][CT], gu[UNROLL];
   // software pipeline: the global loads of iteration i+1 are issued as soon as iteration i's registers have been parked in LDS, and
   // fly while iteration i's fragments are gathered and multiplied
   auto fetch = [&](int s0) {
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
+      const bool s_ok = s0 + u < s_end;
+#pragma unroll
+      for (int j = 0; j < CT; ++j) {
+        const int m = (s0 + u) * 16 + j * YRPI + yrow;
+        const bool ok = s_ok && m < M;
+        gy[u][j] = (ok && ychunk_ok) ? *reinterpret_cast<const bf16x8*>(ysrc + (long long)(ok ? m : 0) * ldy) : zero;
+      }
       const int m = (s0 + u) * 16 + srow;
-      const bool ok = (s0 + u < s_end) && m < M;
-      const long long mm = ok ? m : 0;
-      gy[u] = (ok && ychunk_ok) ? *reinterpret_cast<const bf16x8*>(ysrc + mm * ldy) : zero;
-      gu[u] = (ok && uchunk_ok) ? *reinterpret_cast<const bf16x8*>(usrc + mm * ldu) : zero;
+      const bool ok = s_ok && m < M;
+      gu[u] = (ok && uchunk_ok) ? *reinterpret_cast<const bf16x8*>(usrc + (long long)(ok ? m : 0) * ldu) : zero;
     }
   };
   if (s_beg < s_end) fetch(s_beg);
@@ -2480,8 +2495,9 @@ __device__ __forceinline__ void lora_tn_body(const bf16_t* __restrict__ const Y,
   for (int s0 = s_beg; s0 < s_end; s0 += UNROLL) {
 #pragma unroll
     for (int v = 0; v < UNROLL; ++v) {
-      *reinterpret_cast<bf16x8*>(&slot[w][v][0][srow * 32 + schunk * 8]) = gy[v];
-      *reinterpret_cast<bf16x8*>(&slot[w][v][1][srow * 32 + schunk * 8]) = gu[v];
+#pragma unroll
+      for (int j = 0; j < CT; ++j) *reinterpret_cast<bf16x8*>(myslot + v * SLOT + (j * YRPI + yrow) * YP + ychunk * 16) = gy[v][j];
+      *reinterpret_cast<bf16x8*>(myslot + v * SLOT + YIMG + srow * 64 + schunk * 16) = gu[v];
     }
     if (s0 + UNROLL < s_end) fetch(s0 + UNROLL);   // wave-uniform
 #pragma unroll
@@ -2492,42 +2508,50 @@ __device__ __forceinline__ void lora_tn_body(const bf16_t* __restrict__ const Y,
       // (the same gather as the ViT attention's row-major V, attention.hip; lane map probed in tools/probes/tr_probe.hip)
       typedef short tn_v4s __attribute__((ext_vector_type(4)));
       typedef __attribute__((address_space(3))) tn_v4s* tn_tr_ptr;
-      const char* sy = reinterpret_cast<const char*>(&slot[w][v][0][0]) + tr_off;
-      const char* su = reinterpret_cast<const char*>(&slot[w][v][1][0]) + tr_off;
-      const tn_v4s y0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tn_tr_ptr)(sy)), y1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tn_tr_ptr)(sy + 4 * 64));
+      const char* su = myslot + v * SLOT + YIMG + tr_u;
       const tn_v4s u0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tn_tr_ptr)(su)), u1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tn_tr_ptr)(su + 4 * 64));
-      bf16x8 yf = {y0[0], y0[1], y0[2], y0[3], y1[0], y1[1], y1[2], y1[3]}, uf = {u0[0], u0[1], u0[2], u0[3], u1[0], u1[1], u1[2], u1[3]};
-      if (has_drop) {  // wave-uniform
-        // One 32-bit hash serves the element pair (c even, c + 1) of a row (mrb_keep) and the pair sits in neighbouring lanes: each lane
-        // hashes FOUR of its eight rows and takes the other four from its partner (DPP quad_perm [1,0,3,2]) — the hashes were ~1/3 of
-        // this kernel's time (o group 14.7 us with the mask, 9.6 us without).  (C % 8 == 0 and c0 % 32 == 0: the pair never straddles rows.)
-        const int q = lane & 1;
-        uint32_t mine[4], theirs[4];
+      const bf16x8 uf = {u0[0], u0[1], u0[2], u0[3], u1[0], u1[1], u1[2], u1[3]};
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-          const int m = (s0 + v) * 16 + 8 * hi + 4 * q + jj;
-          mine[jj] = mrb_hash(((uint32_t)m * (uint32_t)C + (uint32_t)c) >> 1, seed, site);
+      for (int ct = 0; ct < CT; ++ct) {
+        const char* sy = myslot + v * SLOT + tr_y + ct * 64;
+        const tn_v4s y0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tn_tr_ptr)(sy)), y1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tn_tr_ptr)(sy + 4 * YP));
+        bf16x8 yf = {y0[0], y0[1], y0[2], y0[3], y1[0], y1[1], y1[2], y1[3]};
+        if (has_drop) {  // wave-uniform
+          // One 32-bit hash serves the element pair (c even, c + 1) of a row (mrb_keep) and the pair sits in neighbouring lanes: each lane
+          // hashes FOUR of its eight rows and takes the other four from its partner (DPP quad_perm [1,0,3,2]) — the hashes were ~1/3 of
+          // this kernel's time (o group 14.7 us with the mask, 9.6 us without).  (C % 8 == 0 and c0 % 32 == 0: the pair never straddles rows.)
+          const int q = lane & 1;
+          const int c = c0 + 32 * ct + l31;
+          uint32_t mine[4], theirs[4];
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            const int m = (s0 + v) * 16 + 8 * hi + 4 * q + jj;
+            mine[jj] = mrb_hash(((uint32_t)m * (uint32_t)C + (uint32_t)c) >> 1, seed, site);
+          }
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) theirs[jj] = (uint32_t)__builtin_amdgcn_mov_dpp((int)mine[jj], 0xB1, 0xf, 0xf, true);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const uint32_t h = ((j >> 2) == q) ? mine[j & 3] : theirs[j & 3];
+            const bool keep = (q ? (h >> 16) : (h & 0xffffu)) >= thresh24;
+            yf[j] = keep ? (short)f2bf(bf2f((bf16_t)yf[j]) * inv_keep) : (short)0;
+          }
         }
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) theirs[jj] = (uint32_t)__builtin_amdgcn_mov_dpp((int)mine[jj], 0xB1, 0xf, 0xf, true);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const uint32_t h = ((j >> 2) == q) ? mine[j & 3] : theirs[j & 3];
-          const bool keep = (q ? (h >> 16) : (h & 0xffffu)) >= thresh24;
-          yf[j] = keep ? (short)f2bf(bf2f((bf16_t)yf[j]) * inv_keep) : (short)0;
-        }
+        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uf, yf, acc[ct], 0, 0, 0);
       }
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uf, yf, acc, 0, 0, 0);
     }
   }
-  __syncthreads();  // every wave is done with its staging slots: the reduction buffer may overwrite them
+  // epilogue spread over the 8 waves, one column tile at a time: wave w owns accumulator rows r = 2w, 2w+1 (both in adapter segment
+  // w >> 1), sums the 8 partials in wave order (same order as ever: bit-identical) and does its two read-modify-writes with both loads in
+  // flight.  (Before: wave 0 did all 16 as a chain of load -> wait -> store round trips.)
 #pragma unroll
-  for (int r = 0; r < 16; ++r) red[w][r][lane] = acc[r];
-  __syncthreads();
-  // epilogue spread over the 8 waves: wave w owns accumulator rows r = 2w, 2w+1 (both in adapter segment w >> 1), sums the 8 partials in
-  // wave order (same order as ever: bit-identical) and does its two read-modify-writes with both loads in flight.  (Before: wave 0 did
-  // all 16 as a chain of load -> wait -> store round trips.)
-  {
+  for (int ct = 0; ct < CT; ++ct) {
+    __syncthreads();  // every wave is done with its staging slots (ct > 0: with the previous tile's partials): the reduction buffer may overwrite them
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[w][r][lane] = acc[ct][r];
+    __syncthreads();
+    const int c = c0 + 32 * ct + l31;
+    const bool c_ok = c < C;
     const int sgi = w >> 1;
     const TnSeg sg = segs[sgi];
     float v[2], old[2];
@@ -2550,6 +2574,7 @@ __device__ __forceinline__ void lora_tn_body(const bf16_t* __restrict__ const Y,
   }
 }
 
+template <int CT>
 __global__ __launch_bounds__(512) void lora_tn_kernel(const TnArgs2 q) {
   const bool second = (int)blockIdx.x >= q.blocks_a;  // block-uniform
   const int bx = second ? blockIdx.x - q.blocks_a : blockIdx.x;
@@ -2557,11 +2582,12 @@ __global__ __launch_bounds__(512) void lora_tn_kernel(const TnArgs2 q) {
   // the compiler kept a run-time pointer into the kernarg segment and re-fetched p.Y / p.ldy / p.drop.* with s_load + s_waitcnt lgkmcnt(0)
   // at every use — 40 scalar round trips per loop iteration, ~1 us per pair of slices.)
 #define TN_SEL(f) (second ? q.b.f : q.a.f)
-  lora_tn_body(TN_SEL(Y), TN_SEL(U), TN_SEL(ldy), TN_SEL(ldu), TN_SEL(M), TN_SEL(C), TN_SEL(R), TN_SEL(drop.seed_ptr), TN_SEL(drop.site),
+  lora_tn_body<CT>(TN_SEL(Y), TN_SEL(U), TN_SEL(ldy), TN_SEL(ldu), TN_SEL(M), TN_SEL(C), TN_SEL(R), TN_SEL(drop.seed_ptr), TN_SEL(drop.site),
                TN_SEL(drop.thresh24), TN_SEL(drop.inv_keep), second ? q.b.seg : q.a.seg, bx);
 #undef TN_SEL
 }
 
+template <int CT>
 __global__ __launch_bounds__(512) void lora_tn_multi_kernel(const TnMulti q) {
   int pi = 0, b0 = 0;   // block-uniform: the problem this block belongs to (scalar compares over <= 16 cumulative counts)
 #pragma unroll 1
@@ -2575,14 +2601,32 @@ __global__ __launch_bounds__(512) void lora_tn_multi_kernel(const TnMulti q) {
   const uint32_t* const seed_ptr = a.drop.seed_ptr;
   const uint32_t site = a.drop.site, thresh24 = a.drop.thresh24;
   const float inv_keep = a.drop.inv_keep;
-  lora_tn_body(Y, U, ldy, ldu, M, C, R, seed_ptr, site, thresh24, inv_keep, a.seg, (int)blockIdx.x - b0);
+  lora_tn_body<CT>(Y, U, ldy, ldu, M, C, R, seed_ptr, site, thresh24, inv_keep, a.seg, (int)blockIdx.x - b0);
 }
 
 // (A VALU form of these products - one lane per Y column, the row's U values as wave-uniform scalar loads, M split over 8 waves and
 // merged through LDS - was built and measured: 130-270 us per launch against 23-30 us here.  With 2-byte loads per lane and 4 waves per
 // CU it keeps ~0.5 MB in flight where the HBM pipe needs ~16 MB; the MFMA form's 16-B row loads win by an order of magnitude.)
-static int launch_tn(const TnArgs2& q, int blocks, hipStream_t stream) {
-  hipLaunchKernelGGL(lora_tn_kernel, dim3(blocks), dim3(512), 0, stream, q);
+// column tiles per block (CT).  Measured (tools/lora_grads_bench.py, profiles/r06_lora_tn_ct.txt): the encoder layer's batched launch (16
+// problems, 992 blocks of 32 columns) 45.7 -> 36.2 us with CT = 2 (25.9 us without the lora_dropout hashes); a single group's launch
+// (64-256 blocks) gets SLOWER, 12-14 -> 20 us — half the blocks on a chip it did not fill, and every wave's chain of slices is latency
+// bound.  So: CT = 2 for batched launches whose every problem has a column count that is a multiple of 64, CT = 1 otherwise.
+// MRB_LORA_TN_CT = 1 / 2 forces one form for A/B (2 still needs the multiples of 64).
+static int tn_ct(const TnArgs* const* ps, int n, bool batched) {
+  static int env = -1;
+  if (env < 0) { const char* e = getenv("MRB_LORA_TN_CT"); env = e ? atoi(e) : 0; }
+  if (env == 1 || (env == 0 && !batched)) return 1;
+  for (int i = 0; i < n; ++i)
+    if (ps[i]->C % 64) return 1;
+  return 2;
+}
+static int launch_tn(TnArgs2& q, hipStream_t stream) {   // blocks of a, then blocks of b
+  const TnArgs* ps[2] = {&q.a, &q.b};
+  const int ct = tn_ct(ps, 2, false);
+  q.blocks_a = (q.a.C + 32 * ct - 1) / (32 * ct);
+  const int blocks = q.blocks_a + (q.has_b ? (q.b.C + 32 * ct - 1) / (32 * ct) : 0);
+  if (ct == 2) hipLaunchKernelGGL(lora_tn_kernel<2>, dim3(blocks), dim3(512), 0, stream, q);
+  else hipLaunchKernelGGL(lora_tn_kernel<1>, dim3(blocks), dim3(512), 0, stream, q);
   return mrblip_check_launch("lora_tn");
 }
 
@@ -2605,8 +2649,8 @@ extern "C" int mrblip_lora_tn(const void* Y, long long ldy, const void* U, long 
   TnArgs2 q = {};
   if (int e = tn_fill(q.a, Y, ldy, U, ldu, M, C, R, outs, col0, ncols, lds, seed_ptr, site, p_drop)) return e;
   q.b = q.a;
-  q.blocks_a = (C + 31) / 32;
-  return launch_tn(q, q.blocks_a, stream);
+  q.has_b = 0;
+  return launch_tn(q, stream);
 }
 
 // The weight-gradient pairs of SEVERAL fused groups in ONE launch (round 5): jobs[i] is what one mrblip_lora_grads call took (same
@@ -2626,11 +2670,17 @@ extern "C" int mrblip_lora_grads_batched(int n_jobs, const MrblipLoraGradsJob* j
     const MrblipLoraGradsJob& j = jobs[i];
     if (int e = tn_fill(q.p[2 * i], j.dY, j.lddy, j.U, j.ldu, j.M, j.N, j.R, j.dBt, j.b_col0, j.b_ncols, j.b_lds, nullptr, 0, 0.f)) return e;
     if (int e = tn_fill(q.p[2 * i + 1], j.X, j.ldx, j.G, j.ldg, j.M, j.K, j.R, j.dA, nullptr, nullptr, j.a_lds, seed_ptr, j.site, j.p_drop)) return e;
-    blocks += (j.N + 31) / 32; q.blk_end[2 * i] = blocks;
-    blocks += (j.K + 31) / 32; q.blk_end[2 * i + 1] = blocks;
   }
   q.n = 2 * n_jobs;
-  hipLaunchKernelGGL(lora_tn_multi_kernel, dim3(blocks), dim3(512), 0, stream, q);
+  const TnArgs* ps[TN_MAX_PROBLEMS];
+  for (int i = 0; i < q.n; ++i) ps[i] = &q.p[i];
+  const int ct = tn_ct(ps, q.n, true);
+  for (int i = 0; i < q.n; ++i) {
+    blocks += (q.p[i].C + 32 * ct - 1) / (32 * ct);
+    q.blk_end[i] = blocks;
+  }
+  if (ct == 2) hipLaunchKernelGGL(lora_tn_multi_kernel<2>, dim3(blocks), dim3(512), 0, stream, q);
+  else hipLaunchKernelGGL(lora_tn_multi_kernel<1>, dim3(blocks), dim3(512), 0, stream, q);
   return mrblip_check_launch("lora_tn_multi");
 }
 
@@ -2644,6 +2694,6 @@ extern "C" int mrblip_lora_grads(const void* dY, long long lddy, const void* U, 
   TnArgs2 q = {};
   if (int e = tn_fill(q.a, dY, lddy, U, ldu, M, N, R, dBt, b_col0, b_ncols, b_lds, nullptr, 0, 0.f)) return e;
   if (int e = tn_fill(q.b, X, ldx, G, ldg, M, K, R, dA, nullptr, nullptr, a_lds, seed_ptr, site, p_drop)) return e;
-  q.blocks_a = (N + 31) / 32;
-  return launch_tn(q, q.blocks_a + (K + 31) / 32, stream);
+  q.has_b = 1;
+  return launch_tn(q, stream);
 }
