@@ -1413,6 +1413,9 @@ class MrBlipEngine:
     # the attention backward instead of beside the next layer's thin / wo launches.  0: a second hand-over at the end of the layer.
     enc_grads_at_wi = os.environ.get("MRB_ENC_GRADS_AT_WI", "0") == "1"
 
+    # most K-split parts of the wi / qkv input gradients (A/B knob: fewer parts = fewer units than CUs but a cheaper consumer)
+    enc_bwd_max_ks = int(os.environ.get("MRB_ENC_BWD_MAX_KS", "8"))
+
     def _enc_bwd_w4_ok(self, M: int) -> bool:
         c = self.cfg
         return bool(self.enc_bwd_w4 and M >= 1024 and not (c.lora_mask_per_adapter and self.training and c.lora_dropout > 0))
@@ -1530,7 +1533,7 @@ class MrBlipEngine:
         if w4b:
             L0 = self.t5["enc"][0]
             cfg_wo = self.ksplit_cfg(M, L0["wo"].K, pad64(L0["wo"].N), max_ks=1)       # (the gated-GELU backward adds exactly two parts)
-            cfg_wi, cfg_qkv = (self.ksplit_cfg(M, g.K, pad64(g.N)) for g in (L0["wi"], L0["qkv"]))
+            cfg_wi, cfg_qkv = (self.ksplit_cfg(M, g.K, pad64(g.N), max_ks=self.enc_bwd_max_ks) for g in (L0["wi"], L0["qkv"]))
             dyact_p = self.buf("eb_dyact_p", (cfg_wo[0] + 1, M, ff), bf16, zero=False)
             dxn_p_wi = self.buf("eb_dxn_p_wi", (cfg_wi[0] + 1, M, d), f32, zero=False)
             dxn_p_qkv = self.buf("eb_dxn_p_qkv", (cfg_qkv[0] + 1, M, d), f32, zero=False)
