@@ -26,6 +26,9 @@ int mrblip_abi_version(void);
 /* C[M,N] = A[M,K] W[N,K]^T (+ Aext[M,64] Wext[N,64]^T : LoRA K-extension) with fused epilogue
  *   v = acc + bias;  out2 = bf16(v) (optional pre-activation);  v = gelu_erf(v) if act==1;  v = dropout(v);
  *   out = residual + v   (fp32 or bf16 out).
+ * act == 2 (round 6, GELU BACKWARD: Qformer.py:349-360 backward): out2 is READ — the forward's saved pre-activation — and
+ *   out = bf16(bf16(acc) * gelu_erf'(out2)), the same bits as a bf16 GEMM followed by mrblip_gelu_bwd; bf16 out, no bias / residual /
+ *   dropout / K extension, generic tile forms only.
  * gated != 0: W = [wi_0; wi_1] stacked ([N = 2*Nh, K]); out[M,Nh] = dropout(gelu(h0) * h1), out2 = [h0 | h1].
  * tile_cfg bits 0..7 = tile form: 0 auto; 1 = 256x256 / 8 waves; 2 = 128x128 / 4 waves; 3 = skinny-M weight-streaming kernel; 4 = 64x128;
  *   5 = 64x64; 6 = 256x256 / 4 waves (compiler-scheduled); 7 = 256x128 BK=32 3-stage; 8 = 256x256 / 16 waves (persistent); 9 = 128x128 / 8 waves;
@@ -76,6 +79,11 @@ long long mrblip_reduce_workspace_bytes(void);
 int mrblip_layernorm_bwd(const float* dy, long long lddy, const float* x, long long ldx, const float* gamma, int M, int D,
                          float eps, const float* dx_add, long long ldadd, float* dx, long long lddx, float* dgamma,
                          float* dbeta, mrblip_stream_t stream);
+/* layernorm_bwd (dx only) that also writes bf16(dropout-backward(dx)) — the next GEMM's operand — in the same launch; bit-identical to
+ * mrblip_layernorm_bwd + mrblip_cast_dropout (Q-Former post-LayerNorm sub-layers: Qformer.py:285-289, 372-375) */
+int mrblip_layernorm_bwd_cast(const float* dy, long long lddy, const float* x, long long ldx, const float* gamma, int M, int D, float eps,
+                              const float* dx_add, long long ldadd, float* dx, long long lddx, void* out_bf16, long long ldob,
+                              const uint32_t* seed_ptr, uint32_t site, float p_drop, mrblip_stream_t stream);
 int mrblip_rmsnorm_bwd(const float* dy, long long lddy, const float* x, long long ldx, const float* weight, int M, int D,
                        float eps, const float* dx_add, long long ldadd, float* dx, long long lddx, mrblip_stream_t stream);
 /* mrblip_rmsnorm_bwd that additionally writes the next GEMM's bf16 operand: out_bf16 = bf16(dropout-backward(dx)) for the mask of

@@ -40,7 +40,8 @@ struct GemmArgs {
   const float* residual;  // fp32 [M,ldr] or nullptr
   long long lda, ldw, ldaext, ldwext, ldo, ldo2, ldr;
   int M, N, K;  // N = rows of W (for GATED: 2*Nh, output has Nh columns)
-  int act;      // 0 none, 1 gelu(erf)
+  int act;      // 0 none, 1 gelu(erf), 2 (round 6, generic tile kernel, bf16 out): GELU BACKWARD — out = bf16(bf16(acc) * gelu'(out2[m, n])), out2 is READ
+                // (the forward's saved pre-activation): the same bits as a bf16 GEMM followed by mrblip_gelu_bwd
   int tiles_m, tiles_n;
   DropoutArg drop;
   // LoRA backward form  out = A W^T + mask(ext_drop) * (Aext Wext^T):  the K-extension tile is taken FIRST and the accumulators
@@ -162,9 +163,25 @@ __device__ __forceinline__ void epilogue_apply4v(const GemmArgs& p, uint32_t see
   if (p.residual) { v0 += r.x; v1 += r.y; v2 += r.z; v3 += r.w; }
 }
 
+// act == 2: v <- bf16(v) * gelu'(h) for the 8 saved pre-activations h = out2[m, n0 .. n0 + 7] (rounded through bf16 first: what the bf16 output
+// of a plain GEMM would have handed mrblip_gelu_bwd)
+__device__ __forceinline__ void epilogue_gelu_bwd8(const GemmArgs& p, int m, int n0, float4& a, float4& b) {
+  const uint4 h = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.out2) + (long long)m * p.ldo2 + n0);
+  a.x = bf2f(f2bf(a.x)) * gelu_erf_grad(bf2f((bf16_t)(h.x & 0xffffu))); a.y = bf2f(f2bf(a.y)) * gelu_erf_grad(bf2f((bf16_t)(h.x >> 16)));
+  a.z = bf2f(f2bf(a.z)) * gelu_erf_grad(bf2f((bf16_t)(h.y & 0xffffu))); a.w = bf2f(f2bf(a.w)) * gelu_erf_grad(bf2f((bf16_t)(h.y >> 16)));
+  b.x = bf2f(f2bf(b.x)) * gelu_erf_grad(bf2f((bf16_t)(h.z & 0xffffu))); b.y = bf2f(f2bf(b.y)) * gelu_erf_grad(bf2f((bf16_t)(h.z >> 16)));
+  b.z = bf2f(f2bf(b.z)) * gelu_erf_grad(bf2f((bf16_t)(h.w & 0xffffu))); b.w = bf2f(f2bf(b.w)) * gelu_erf_grad(bf2f((bf16_t)(h.w >> 16)));
+}
+
 __device__ __forceinline__ void epilogue_store8v(const GemmArgs& p, uint32_t seed, bool out_f32, int m, int n0, float4 a, float4 b, int ncols,
                                                  const float4 b0, const float4 b1, const float4 r0, const float4 r1) {
   uint2 pre0, pre1;
+  if (p.act == 2) {   // (launch-uniform)
+    epilogue_gelu_bwd8(p, m, n0, a, b);
+    *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.out) + (long long)m * p.ldo + n0) =
+        make_uint4(pack2bf(a.x, a.y), pack2bf(a.z, a.w), pack2bf(b.x, b.y), pack2bf(b.z, b.w));
+    return;
+  }
   epilogue_apply4v(p, seed, m, n0, a.x, a.y, a.z, a.w, ncols, pre0, b0, r0);
   epilogue_apply4v(p, seed, m, n0 + 4, b.x, b.y, b.z, b.w, ncols, pre1, b1, r1);
   if (p.out2) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.out2) + (long long)m * p.ldo2 + n0) = make_uint4(pre0.x, pre0.y, pre1.x, pre1.y);
@@ -1927,6 +1944,8 @@ static int gemm_dispatch(const void* A, long long lda, const void* W, long long 
   MRB_REQUIRE(((long long)(M + 256) * lda * 2 + 256) < (1ll << 32) && ((long long)(N + 256) * ldw * 2 + 256) < (1ll << 32),
               "gemm: operand exceeds the 4 GiB buffer-descriptor range");
   MRB_REQUIRE(!gated || (!out_f32 && !bias && !residual && act == 0 && (N % 16) == 0), "gemm: gated mode takes no bias/residual/act");
+  MRB_REQUIRE(act != 2 || (out2 && !out_f32 && !gated && !bias && !residual && !Aext && !(p_drop > 0.f) && (N % 8) == 0 && (ldo2 % 8) == 0 && ((uintptr_t)out2 % 16) == 0),
+              "gemm: act 2 (GELU backward) = bf16 out, out2 = the saved pre-activation (read), no bias / residual / dropout / K extension");
   GemmArgs a;
   a.ext_first = ext_first;
   a.m_rows_per_block = 32;
@@ -2022,6 +2041,10 @@ static int gemm_dispatch(const void* A, long long lda, const void* W, long long 
                 "gemm: head-transposed copies / grouped K extension are not available in tile config %d", cfg);
   }
   MRB_REQUIRE(!a.th_flags || !(cfg == 3 || (cfg >= 13 && cfg <= 17)), "gemm: the thin role lives in the generic tile kernel (tile config %d has none)", cfg);
+  if (act == 2) {   // the GELU-backward epilogue lives in the generic tile kernel's non-gated store path
+    if (cfg == 3 || cfg == 8 || (cfg >= 13 && cfg <= 17)) cfg = (M >= 1024 && N >= 1024) ? 4 : 5;
+    MRB_REQUIRE(cfg == 2 || cfg == 4 || cfg == 5 || (cfg >= 18 && cfg <= 23), "gemm: act 2 (GELU backward) is not available in tile config %d", cfg);
+  }
   if (cfg == 3) {
     MRB_REQUIRE(!gated, "gemm: skinny kernel has no gated epilogue");
     // rows of the tall operand per block: 32, fewer when the grid would leave most CUs idle (LoRA down / g products at M = 2012)

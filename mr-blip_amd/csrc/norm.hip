@@ -359,6 +359,26 @@ extern "C" int mrblip_layernorm_bwd(const float* dy, long long lddy, const float
   return mrblip_check_launch("layernorm_bwd");
 }
 
+// layernorm_bwd (dx only: frozen gamma / beta) that also writes the NEXT GEMM's operand: out_bf16 = bf16(dropout-backward(dx)) with the mask
+// of (seed, site, p) over element index row * D + col — bit-identical to mrblip_cast_dropout(dx) in a second launch (round 6: the Q-Former's
+// post-LayerNorm sub-layers, Qformer.py:285-289, 372-375 — 29 launches per step off the backward's dependent chain)
+extern "C" int mrblip_layernorm_bwd_cast(const float* dy, long long lddy, const float* x, long long ldx, const float* gamma, int M, int D,
+                                         float eps, const float* dx_add, long long ldadd, float* dx, long long lddx, void* out_bf16,
+                                         long long ldob, const uint32_t* seed_ptr, uint32_t site, float p_drop, hipStream_t stream) {
+  if (int e = norm_check(M, D, x, ldx)) return e;
+  MRB_REQUIRE(out_bf16 && (ldob % 4) == 0, "layernorm_bwd_cast: bf16 output missing / unaligned");
+  MRB_REQUIRE(!(p_drop > 0.f) || seed_ptr, "layernorm_bwd_cast: dropout needs a device seed pointer");
+  DropoutArg d;
+  d.seed_ptr = (p_drop > 0.f) ? seed_ptr : nullptr;
+  d.site = site;
+  d.thresh24 = (uint32_t)(p_drop * 65536.0f + 0.5f);
+  d.inv_keep = 1.0f / (1.0f - p_drop);
+  const int grid = min((M + 3) / 4, 2048);
+  hipLaunchKernelGGL(norm_bwd_kernel<false>, dim3(grid), dim3(256), 0, stream, dy, lddy, x, ldx, gamma, M, D, eps, dx_add, ldadd, dx, lddx, (float*)nullptr,
+                     (float*)nullptr, (bf16_t*)out_bf16, ldob, d);
+  return mrblip_check_launch("layernorm_bwd_cast");
+}
+
 // rmsnorm_bwd that also writes the NEXT GEMM's operand: out_bf16 = bf16(dropout-backward(dx)) with the mask of (seed, site, p) over
 // element index row * D + col — bit-identical to mrblip_cast_dropout(dx) in a second launch (T5 sub-layer dropout, modeling_t5.py:613-615)
 extern "C" int mrblip_rmsnorm_bwd_cast(const float* dy, long long lddy, const float* x, long long ldx, const float* weight, int M, int D,

@@ -511,6 +511,7 @@ class MrBlipEngine:
         # entry and run beside the chain of small query-side kernels, each cross layer waits for its own event.  This phase runs with the
         # chip to itself (the look-ahead ViT starts behind the encoder forward), so what is hidden here comes off the step 1:1.
         kv_ready = {}
+        self.qf_kt_saved = False
         if self.qf_kv_side and self.grad_side_stream_enabled:
             st, ev0 = self._grad_stream(), torch.cuda.Event()
             ev0.record()
@@ -527,6 +528,14 @@ class MrBlipEngine:
                     ev = torch.cuda.Event()
                     ev.record()
                     kv_ready[i] = (kv, vt_i, ev)
+                if want_t and self.qf_kt_fwd and getattr(self, "_qf_backward_follows", False):
+                    # round 6: the cross-attention K^T copies of the BACKWARD are written here, behind every layer's K / V^T (nothing of the forward
+                    # waits for them), instead of by six launches on the backward's dependent chain; the backward waits for ONE event
+                    for i, (kv, _, _) in kv_ready.items():
+                        ops.head_transpose(self.v4(kv, F_, Tv, H, hd, 0), out=self.buf(f"qf{i}_kt_c", (F_, H, ops.rup32(hd), ops.rup32(Tv)), bf16))
+                    self._qf_kt_event = torch.cuda.Event()
+                    self._qf_kt_event.record()
+                    self.qf_kt_saved = True
         # the query chain's GEMMs are 10-40 us each and every weight is touched once: each launch carries prefetch workgroups for the NEXT
         # launch's weights (see enc_prefetch; stand-alone o 13.3 -> 11.2, fc2 37.9 -> 28.8 us on cold weights)
         chain = []
@@ -717,21 +726,24 @@ class MrBlipEngine:
         kt_s, qt_s, dot_s = (self.buf(n, (F_, H, ops.rup32(hd), rq), bf16) for n in ("qf_kt_s", "qf_qt_s", "qf_dot_s"))
         kt_c = self.buf("qf_kt_c", (F_, H, ops.rup32(hd), rt), bf16)
         cur = dx
+        if getattr(self, "qf_kt_saved", False):
+            torch.cuda.current_stream().wait_event(self._qf_kt_event)
         for i in reversed(range(len(self.qf["layers"]))):
             L = self.qf["layers"][i]
             nxt = self.buf(f"qf_dx_{i % 2}", (Mq, D), f32, zero=False)
             # FFN: x3 = LN(y3), y3 = x2 + drop(dense(gelu(dense_i(x2b))))
-            ops.layernorm_bwd(cur, self.ws[f"qf{i}_y3"], L["lnw"], eps, dy)
-            ops.cast_dropout(dy, out_bf16=dyb, drop=self.qdrop(L["site"], pdrop))
-            ops.gemm(dyb, L["owt"], dh)
-            ops.gelu_bwd(dh, self.ws[f"qf{i}_hpre"], dhp)
+            self._qf_ln_bwd(cur, self.ws[f"qf{i}_y3"], L["lnw"], eps, dy, dyb, self.qdrop(L["site"], pdrop))
+            if self.qf_gelu_bwd_fused:   # round 6: dh = (dy W) * gelu'(hpre) from the GEMM's epilogue (act = 2 reads the saved pre-activation): the same bits, 12 launches fewer
+                ops.gemm(dyb, L["owt"], dhp, out2=self.ws[f"qf{i}_hpre"], act=2)
+            else:
+                ops.gemm(dyb, L["owt"], dh)
+                ops.gelu_bwd(dh, self.ws[f"qf{i}_hpre"], dhp)
             ops.gemm(dhp, L["iwt"], nxt, residual=dy)
             cur = nxt
             if L["cross"] is not None:
                 C_ = L["cross"]
                 nxt = self.buf(f"qf_dxc_{i % 2}", (Mq, D), f32, zero=False)
-                ops.layernorm_bwd(cur, self.ws[f"qf{i}_y2"], C_["lnw"], eps, dy)
-                ops.cast_dropout(dy, out_bf16=dyb, drop=self.qdrop(C_["sites"][1], pdrop))
+                self._qf_ln_bwd(cur, self.ws[f"qf{i}_y2"], C_["lnw"], eps, dy, dyb, self.qdrop(C_["sites"][1], pdrop))
                 t_saved = getattr(self, "qf_t_saved", False) and self.tout_ok(hd, F_, nq, 8)
                 if t_saved:
                     ops.gemm(dyb, C_["owt"], do, tout=(dot_s,), t_rows=nq)
@@ -740,7 +752,11 @@ class MrBlipEngine:
                 qc, kv, oc = self.ws[f"qf{i}_qc"], self.ws[f"qf{i}_kvc"], self.ws[f"qf{i}_oc"]
                 q4, k4, v4 = self.v4(qc, F_, nq, H, hd), self.v4(kv, F_, Tv, H, hd, 0), self.v4(kv, F_, Tv, H, hd, D)
                 do4 = self.v4(do, F_, nq, H, hd)
-                ops.head_transpose(k4, out=kt_c)
+                kt_x = kt_c
+                if getattr(self, "qf_kt_saved", False):
+                    kt_x = self.ws[f"qf{i}_kt_c"]
+                else:
+                    ops.head_transpose(k4, out=kt_c)
                 qt_x = qt_s
                 if t_saved:
                     qt_x = self.ws[f"qf{i}_qt_c"]
@@ -748,7 +764,7 @@ class MrBlipEngine:
                     ops.head_transpose(q4, out=qt_s)
                     ops.head_transpose(do4, out=dot_s)
                 dkv_i, c0 = (dkv_all, cross_ids.index(i) * pw) if merge_kv else (dkv, 0)
-                ops.attention_bwd(q4, k4, v4, self.v4(oc, F_, nq, H, hd), do4, kt_c, qt_x, dot_s, self.ws[f"qf{i}_lsec"], delta,
+                ops.attention_bwd(q4, k4, v4, self.v4(oc, F_, nq, H, hd), do4, kt_x, qt_x, dot_s, self.ws[f"qf{i}_lsec"], delta,
                                   self.v4(dqc, F_, nq, H, hd), self.v4(dkv_i, F_, Tv, H, hd, c0), self.v4(dkv_i, F_, Tv, H, hd, c0 + D),
                                   scale=scale, drop=self.qdrop(C_["sites"][0], pdrop))
                 if not merge_kv:
@@ -760,8 +776,7 @@ class MrBlipEngine:
                 break  # layer 0's self-attention only feeds the frozen query tokens
             S_ = L["self"]
             nxt = self.buf(f"qf_dxs_{i % 2}", (Mq, D), f32, zero=False)
-            ops.layernorm_bwd(cur, self.ws[f"qf{i}_y"], S_["lnw"], eps, dy)
-            ops.cast_dropout(dy, out_bf16=dyb, drop=self.qdrop(S_["sites"][1], pdrop))
+            self._qf_ln_bwd(cur, self.ws[f"qf{i}_y"], S_["lnw"], eps, dy, dyb, self.qdrop(S_["sites"][1], pdrop))
             t_saved = getattr(self, "qf_t_saved", False) and self.tout_ok(hd, F_, nq, 8)
             if t_saved:
                 ops.gemm(dyb, S_["owt"], do, tout=(dot_s,), t_rows=nq)
@@ -787,6 +802,18 @@ class MrBlipEngine:
         return dimg
 
     qf_kv_bwd_merge = os.environ.get("MRB_QF_KV_BWD_MERGE", "1") == "1"
+    # round 6: LayerNorm backward + the dropout-backward cast of its result (the next GEMM's operand) in ONE launch: 29 launches per step off
+    # the Q-Former backward's dependent chain, the same bits (MRB_QF_LN_BWD_CAST=0: two launches)
+    qf_ln_bwd_cast = os.environ.get("MRB_QF_LN_BWD_CAST", "1") == "1"
+    qf_gelu_bwd_fused = os.environ.get("MRB_QF_GELU_BWD_FUSED", "1") == "1"
+    qf_kt_fwd = os.environ.get("MRB_QF_KT_FWD", "1") == "1"   # cross-attention K^T for the backward written by the forward's side stream (0: by the backward chain)
+
+    def _qf_ln_bwd(self, cur, y, lnw, eps, dy, dyb, drop):
+        if self.qf_ln_bwd_cast:
+            ops.layernorm_bwd(cur, y, lnw, eps, dy, out_bf16=dyb, out_drop=drop)
+        else:
+            ops.layernorm_bwd(cur, y, lnw, eps, dy)
+            ops.cast_dropout(dy, out_bf16=dyb, drop=drop)
 
     # ------------------------------------------------------------------------------------------ T5 + LoRA, t5_proj, ln_vision
     def _build_t5(self, src, lora_init):
@@ -2332,7 +2359,11 @@ class MrBlipEngine:
         if frames is not None:
             fr, img, xv, qb = frames, None, None, None
         else:
-            fr, img, xv, qb = self.frames_forward(video)
+            self._qf_backward_follows = bool(backward)
+            try:
+                fr, img, xv, qb = self.frames_forward(video)
+            finally:
+                self._qf_backward_follows = False
         self._mark("frames_forward (ViT + ln_vision + Q-Former + t5_proj)")
         dev = self.dev
         use_graph = self._graph_wanted(Bv, S, backward, sharded) and frames is None

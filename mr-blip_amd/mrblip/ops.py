@@ -53,6 +53,7 @@ _ln_fwd = _sig("mrblip_layernorm_fwd", vp, ll, vp, vp, i32, i32, f32, vp, ll, vp
 _rms_fwd = _sig("mrblip_rmsnorm_fwd", vp, ll, vp, i32, i32, f32, vp, ll, vp, ll, vp)
 _ln_bwd = _sig("mrblip_layernorm_bwd", vp, ll, vp, ll, vp, i32, i32, f32, vp, ll, vp, ll, vp, vp, vp)
 _rms_bwd = _sig("mrblip_rmsnorm_bwd", vp, ll, vp, ll, vp, i32, i32, f32, vp, ll, vp, ll, vp)
+_ln_bwd_cast = _sig("mrblip_layernorm_bwd_cast", vp, ll, vp, ll, vp, i32, i32, f32, vp, ll, vp, ll, vp, ll, vp, u32, f32, vp)
 _rms_bwd_cast = _sig("mrblip_rmsnorm_bwd_cast", vp, ll, vp, ll, vp, i32, i32, f32, vp, ll, vp, ll, vp, ll, vp, u32, f32, vp)
 _attn_fwd = _sig("mrblip_attention_fwd", vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp, vp, i32, vp, u32, f32, vp, vp)
 _attn_fwd_rowv = _sig("mrblip_attention_fwd_rowv", vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp)
@@ -129,7 +130,7 @@ EXPORTS = [
     "mrblip_lora_grads", "mrblip_lora_grads_batched", "mrblip_gemm_lora_down", "mrblip_gemm_lora_dx", "mrblip_patchify_u8",
     "mrblip_gemm_set_cu_reserve", "mrblip_lora_rows", "mrblip_rmsnorm_lora_fwd", "mrblip_lora_rows_init", "mrblip_dec_proj", "mrblip_dec_proj_config", "mrblip_lora_dx_add_batched", "mrblip_lora_rows_batched", "mrblip_gemm_set_extra", "mrblip_attention_set_split_workspace",
     "mrblip_gemm_ksplit", "mrblip_rmsnorm_bwd_parts", "mrblip_rmsnorm_bwd_parts_g", "mrblip_set_reduce_workspace", "mrblip_reduce_workspace_bytes", "mrblip_gemm_clear_one_shots", "mrblip_gated_gelu_bwd_parts", "mrblip_sum_parts",
-    "mrblip_qformer_layer_fwd",
+    "mrblip_qformer_layer_fwd", "mrblip_layernorm_bwd_cast",
     "mrblip_gemm_f16", "mrblip_layernorm_fwd_f16", "mrblip_attention_fwd_rowv_f16", "mrblip_patchify_f16", "mrblip_patchify_u8_f16",
 ]
 
@@ -387,8 +388,16 @@ def rmsnorm_fwd(x, weight, eps, out_bf16=None, out_f32=None):
     _chk(_rms_fwd(_p(x), _ld(x), _p(weight), M, D, eps, _p(out_bf16), _ld(out_bf16), _p(out_f32), _ld(out_f32), _stream()))
 
 
-def layernorm_bwd(dy, x, gamma, eps, dx, dx_add=None, dgamma=None, dbeta=None):
+def layernorm_bwd(dy, x, gamma, eps, dx, dx_add=None, dgamma=None, dbeta=None, out_bf16=None, out_drop: Optional["Dropout"] = None):
+    """out_bf16 (optional, dx-only form): also write bf16(dropout-backward(dx)) for the mask of ``out_drop`` — the next GEMM's operand — in the
+    same launch (mrblip_layernorm_bwd_cast; the same bits as a cast_dropout launch behind it)"""
     M, D = x.shape
+    if out_bf16 is not None:
+        assert dgamma is None and dbeta is None, "layernorm_bwd: the fused cast is the frozen-weights (dx only) form"
+        sp, site, p = _d(out_drop)
+        _chk(_ln_bwd_cast(_p(dy), _ld(dy), _p(x), _ld(x), _p(gamma), M, D, eps, _p(dx_add), _ld(dx_add), _p(dx), _ld(dx), _p(out_bf16), _ld(out_bf16),
+                          sp, site, p, _stream()))
+        return
     if dgamma is not None:
         _reduce_ws(x.device)
     _chk(_ln_bwd(_p(dy), _ld(dy), _p(x), _ld(x), _p(gamma), M, D, eps, _p(dx_add), _ld(dx_add), _p(dx), _ld(dx), _p(dgamma), _p(dbeta), _stream()))

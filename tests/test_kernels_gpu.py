@@ -950,6 +950,49 @@ def test_rmsnorm_bwd_with_fused_operand_cast(ops, D, p):
         assert 0.85 < (got != 0).float().mean().item() < 0.95
 
 
+@pytest.mark.parametrize("D,p", [(768, 0.1), (768, 0.0), (64, 0.1)])
+def test_layernorm_bwd_with_fused_operand_cast(ops, D, p):
+    """mrblip_layernorm_bwd_cast (round 6, the Q-Former's post-LayerNorm sub-layers): dx as mrblip_layernorm_bwd writes it, plus
+    bf16(dropout-backward(dx)) — bit for bit what a following mrblip_cast_dropout launch produces."""
+    torch.manual_seed(32)
+    M = 1920 if D == 768 else 77
+    x = torch.randn(M, D, device=dev()) * 1.5 + 0.3
+    w = torch.randn(D, device=dev()) * 0.1 + 1
+    dy = torch.randn(M, D, device=dev())
+    seed = torch.tensor([778], dtype=torch.int32, device=dev())
+    drop = ops.Dropout(seed, 24, p) if p > 0 else None
+    dx_ref = torch.empty_like(x)
+    ops.layernorm_bwd(dy, x, w, 1e-12, dx_ref)
+    want = torch.zeros(M, D + 64, dtype=torch.bfloat16, device=dev())[:, :D]
+    ops.cast_dropout(dx_ref, out_bf16=want, drop=drop)
+    dx = torch.empty_like(x)
+    got = torch.zeros(M, D + 64, dtype=torch.bfloat16, device=dev())[:, :D]
+    ops.layernorm_bwd(dy, x, w, 1e-12, dx, out_bf16=got, out_drop=drop)
+    assert torch.equal(dx, dx_ref) and torch.equal(got, want)
+    if p > 0:
+        assert 0.85 < (got != 0).float().mean().item() < 0.95
+
+
+@pytest.mark.parametrize("M,N,K,cfg", [(1920, 3072, 768, 0), (1920, 3072, 768, 5), (640, 3072, 768, 0), (77, 128, 64, 0), (1920, 3072, 768, 2)])
+def test_gemm_gelu_backward_epilogue_equals_gemm_plus_gelu_bwd(ops, M, N, K, cfg):
+    """act = 2 (round 6): dh = (dy W^T) * gelu'(hpre) from the GEMM's epilogue, out2 READ as the saved pre-activation — bit for bit the bf16 GEMM
+    followed by mrblip_gelu_bwd (the accumulator is rounded through bf16 first); the Q-Former FFN's backward (Qformer.py:349-360)."""
+    torch.manual_seed(33)
+    a = torch.randn(M, K, device=dev()).bfloat16()
+    w = (torch.randn(N, K, device=dev()) * 0.05).bfloat16()
+    hpre = (torch.randn(M, N, device=dev()) * 1.5).bfloat16()
+    hpre0 = hpre.clone()
+    dh = torch.empty(M, N, dtype=torch.bfloat16, device=dev())
+    ops.gemm(a, w, dh, tile_cfg=cfg)
+    want = torch.empty_like(dh)
+    ops.gelu_bwd(dh, hpre, want)
+    got = torch.empty_like(dh)
+    ops.gemm(a, w, got, out2=hpre, act=2, tile_cfg=cfg)
+    assert torch.equal(got, want) and torch.equal(hpre, hpre0)      # (the pre-activation is read, never written)
+    with pytest.raises(ops.MrblipError):
+        ops.gemm(a, w, got, act=2)                                  # no saved pre-activation
+
+
 # ---- round 5: K-split form of the 4-wave kernel and the consumers that add its parts -------------------------------------------------
 @pytest.mark.parametrize("f32out", [True, False])
 @pytest.mark.parametrize("M,N,K,ks,cfg,ext", [(2012, 2048, 2560, 4, 13, True), (1312, 256, 768, 6, 14, True), (300, 264, 128, 2, 13, False),
