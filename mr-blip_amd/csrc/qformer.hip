@@ -12,11 +12,16 @@
 // workgroup from L2 (frames on one XCD walk the same weight rows at the same pace) into a wave-private LDS ring by LDS-DMA.  The launch
 // occupies F CUs (60 at QVH) and leaves the rest of the chip to the look-ahead ViT that runs beside it.
 //
+// MEASURED (profiles/r06_qformer_fused.txt): correct on its first run, and SLOWER than the chain — 4.8 ms per 12-layer forward against 2.0 ms,
+// for 8, 60 or 120 frames alike: one workgroup pulls all of a layer's weights through ONE CU, and one CU draws ~43 GB/s through LDS-DMA with
+// the 48 KB this ring keeps in flight (27 GB/s with fragment-shaped loads straight into registers, QF_W_DMA=0).  The engine therefore keeps
+// the launch chain (MRB_QF_FUSED=1 selects this kernel); the file stays as the measured alternative, tested against the chain.
+//
 // Layout.  All GEMMs run "transposed": Y^T[n][m] = W[n][:] . X^T[:][m] with the WEIGHT rows as the MFMA A operand and the 32 tokens as
 // the B operand (32x32x16 bf16), so a lane owns ONE token m = lane & 31 and its 16 accumulator registers of a 32-feature tile hold
 // features 8 (r >> 2) + 4 hi + (r & 3): LayerNorm statistics, biases, residual adds and softmax are in-lane (+ one lane ^ 32 exchange),
-// and the fp32 residual stream of the frame stays in registers in exactly the accumulator layout of the N = 768 products (wave w owns
-// features [192 w, 192 w + 192): 96 registers).  The token operand X lives in LDS as bf16 [32][768] (row pitch 1552 B: conflict-free
+// and the fp32 residual stream is re-read by every epilogue in exactly the accumulator layout of the N = 768 products (wave w owns
+// features [192 w, 192 w + 192); a lane reads and writes only its own elements).  The token operand X lives in LDS as bf16 [32][768] (row pitch 1552 B: conflict-free
 // 16-B fragment reads).  Self-attention never leaves the registers: with the projection's accumulators packed to bf16 in register
 // order, Q and K are both "lane = token, 8 packed head dims" fragments with the SAME dim permutation — all the MFMA contraction needs —
 // and V is produced by the operand-swapped MFMA (lane = head dim, registers = tokens), which is the A operand of O^T = V^T P^T with the
