@@ -130,6 +130,11 @@ __device__ __forceinline__ uint32_t mrb_lin_fin(uint32_t t) {
 // Round 5: the finaliser of the attention-probability draws on the FULL-RATE 24-bit multiplier (v_mul_u32_u24: low 32 bits of the product
 // of the operands' low 24 bits; v_mul_lo_u32 is quarter rate).  The xor-shift in front folds bits 15..31 into the 24 bits the multiplier
 // sees; statistics of the resulting draws (marginals, neighbour conditionals, quad patterns): tests/test_host_cpu.py.
+// The output is a function of 24 bits, so a (seed, site) has at most 2^24 distinct quad hashes: one T5-XL encoder layer at S = 2012 draws
+// 32.4 M quads, 87 % of which share their hash with some other quad of the layer (14.6 M distinct values, no value more than 10 times, never
+// twice inside one query row: test_attention_dropout_quad_hashes_repeat_at_production_size...).  Far-apart score tiles may therefore carry the
+// same 4-key keep pattern; marginals, within-quad conditionals and row / neighbour independence are unaffected.  Folding the dropped top
+// byte back in would cost 2 VALU per hash (~4 % of the VALU-bound encoder attention forward): not taken.
 __device__ __forceinline__ uint32_t mrb_lin_fin24(uint32_t t) {
   t ^= t >> 15;
   t = (t & 0xffffffu) * 0x9E3779u;

@@ -187,6 +187,40 @@ def test_attention_dropout_draws_statistics():
     assert not torch.equal(keep, O.dropout_keep_attn(2, 8, 256, 2012, seed=12345, site=78, p=p))
 
 
+def test_attention_dropout_quad_hashes_repeat_at_production_size_and_what_that_costs():
+    """mrb_lin_fin24 feeds 24 bits into its multiplier, so a (seed, site) has at most 2^24 distinct quad hashes, and one T5-XL
+    encoder layer at S = 2012 draws 32 heads x 2012 queries x 503 key quads = 32.4 M of them: quads MUST repeat.  Measured here on the
+    restatement at that size: how many of a layer's quads share their hash with another quad of the layer (the balls-in-bins expectation
+    for 2^24 equally likely values), that the repeats are spread evenly (no value is hit much more often than Poisson says: no lattice
+    structure a training signal could lock on to) and that two quads of the SAME query row never share a hash (an attention row never
+    sees a repeated 4-key pattern).  What it costs: far-apart score tiles of a layer may carry the same 4-key keep pattern — the marginal
+    rate, the within-quad conditionals and the row / neighbour independence (test above) are untouched; the oracle restates the same function,
+    so this is a property of the RNG, not a parity gap.  (The remedy — folding the dropped top byte back in — costs 2 VALU per hash, ~4 % of
+    the VALU-bound encoder attention forward: not taken.)"""
+    import numpy as np
+    import torch
+    from oracle import mrblip_oracle as O
+
+    H, S = 32, 2012
+    skq = (S + 3) // 4
+    n = H * S * skq
+    idx = torch.arange(n, dtype=torch.int64)
+    h = O.dropout_hash_lin24(idx, seed=12345, site=77).numpy().astype(np.uint32)
+    vals, counts = np.unique(h, return_counts=True)
+    distinct = vals.size
+    lam = n / 2.0 ** 24
+    expect_distinct = 2.0 ** 24 * (1.0 - np.exp(-lam))
+    assert distinct <= 2 ** 24
+    # measured: 14.58 M distinct values of 32.4 M quads (2^24 equally likely values: 14.34 M — the Weyl walk covers slightly BETTER than random)
+    assert abs(distinct - expect_distinct) < 0.03 * expect_distinct, (distinct, expect_distinct)
+    shared = 1.0 - (counts == 1).sum() / n                                                            # quads whose hash another quad also has
+    assert abs(shared - (1.0 - np.exp(-lam))) < 0.03, shared                                          # measured 0.873 (Poisson: 0.855)
+    assert counts.max() <= 16, counts.max()                                                           # measured 10 (Poisson(1.93): P(> 16) ~ 1e-10 per value)
+    # inside one query row (503 consecutive indices = a Weyl walk) every quad has its own hash
+    rows = h.reshape(H * S, skq)[:: 97]
+    assert all(np.unique(r).size == skq for r in rows)
+
+
 @pytest.mark.parametrize("tag,fmt", [("mr_tiny_nointerleave", "seconds_integers"), ("mr_tiny_nointerleave_floats", "seconds_floats")])
 def test_non_interleaved_prompt_layout_and_oracle_against_reference(tag, fmt):
     """interleave_data: False (blip2_mr.py:783-822; the reference constructor's default, no shipped config): the prompt is
