@@ -38,6 +38,10 @@ _ENC_BWD_CFG = (tuple(int(x) for x in os.environ.get("MRB_ENC_BWD_CFG", "0,0,0,0
 
 # tile configs of the ViT qkv / proj / fc2 / fc1 GEMMs (0 = the library's own choice); MRB_VIT_CFG="q,p,f2,f1" overrides for experiments
 _VIT_CFG = (tuple(int(x) for x in os.environ.get("MRB_VIT_CFG", "0,0,0,0").split(",")) + (0, 0, 0, 0))[:4]
+# round 6: CU reserve PER ViT GEMM (qkv, proj, fc2, fc1) while the ViT runs as the look-ahead, -1 = the look-ahead's reserve.  The 4-wave kernel is
+# persistent, one 256 x 256 tile per CU and round: 60 frames are 61 row tiles, so qkv = 1037, proj / fc2 = 366, fc1 = 1464 tiles, i.e. 6 / 2 / 8
+# rounds on the 192 CUs a reserve of 64 leaves — but 5 rounds on 208 CUs (qkv) and 7 on 216 (fc1), and still 2 on 184 (proj / fc2).
+_VIT_RSV = (tuple(int(x) for x in os.environ.get("MRB_VIT_RESERVE_BY_GEMM", "-1,-1,-1,-1").split(",")) + (-1, -1, -1, -1))[:4]
 
 
 @dataclass
@@ -422,24 +426,26 @@ class MrBlipEngine:
         o4 = self.v4(o, F_, T, H, hd)
         scale = hd ** -0.5
         probe = getattr(self, "probe", None)
+        ctx_rsv = getattr(ops._tls, "cu_reserve", 0)
+        rsv = [(r if (r >= 0 and ctx_rsv > 0) else None) for r in _VIT_RSV]     # (only beside another stream: an exclusive ViT pass keeps the whole chip)
         for blk in v["blocks"][b0:b1]:
             ops.layernorm_fwd(x, blk["n1w"], blk["n1b"], 1e-6, out_bf16=h)
-            ops.gemm(h, blk["qkv_w"], qkv, bias=blk["qkv_b"], tile_cfg=_VIT_CFG[0])
+            ops.gemm(h, blk["qkv_w"], qkv, bias=blk["qkv_b"], tile_cfg=_VIT_CFG[0], cu_reserve=rsv[0])
             if self.vit_rowv and hd > 64 and T > 32:   # V read row-major from the qkv buffer (LDS transpose reads): no V^T copy
                 ops.attention_fwd_rowv(q4, k4, v4, o4, None, scale=scale)
             else:
                 ops.head_transpose(v4, out=vt)
                 ops.attention_fwd(q4, k4, vt, o4, None, scale=scale)
-            ops.gemm(o, blk["proj_w"], x, bias=blk["proj_b"], residual=x, tile_cfg=_VIT_CFG[1])
+            ops.gemm(o, blk["proj_w"], x, bias=blk["proj_b"], residual=x, tile_cfg=_VIT_CFG[1], cu_reserve=rsv[1])
             ops.layernorm_fwd(x, blk["n2w"], blk["n2b"], 1e-6, out_bf16=h)
             if probe is not None:  # HIP events around the dominant kernel's launch (bench.py roofline.achieved)
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 ev[0].record()
-            ops.gemm(h, blk["fc1_w"], f, bias=blk["fc1_b"], act=1, tile_cfg=_VIT_CFG[3])
+            ops.gemm(h, blk["fc1_w"], f, bias=blk["fc1_b"], act=1, tile_cfg=_VIT_CFG[3], cu_reserve=rsv[3])
             if probe is not None:
                 ev[1].record()
                 probe.append(ev)
-            ops.gemm(f, blk["fc2_w"], x, bias=blk["fc2_b"], residual=x, tile_cfg=_VIT_CFG[2])
+            ops.gemm(f, blk["fc2_w"], x, bias=blk["fc2_b"], residual=x, tile_cfg=_VIT_CFG[2], cu_reserve=rsv[2])
 
     # ------------------------------------------------------------------------------------------ Q-Former (frozen weights, dX needed)
     def _build_qformer(self, src):
