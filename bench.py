@@ -112,7 +112,7 @@ def cpu_baseline(budget_s=30.0, full_c2=False, c2_iters=3):
     FLOPs (QVH clip step = 45.37 TFLOP at this bench's S/L_dec; C1 clip step = step_tflop_per_clip at its S/L_dec).  full_c2=True
     (--cpu-baseline-c2, minutes of CPU time and ~45 GB of RAM) times the metric's OWN configuration: whole QVH clip steps (T = 60,
     Flan-T5-XL dims), one warm-up + ``c2_iters`` timed.  Without it, `value` is the committed C2 run of this round
-    (profiles/r04_cpu_baseline_c2.json, `value_source: c2_committed`) when present, with the live C1 sample beside it."""
+    (profiles/r06_cpu_baseline_c2.json, `value_source: c2_committed`) when present, with the live C1 sample beside it."""
     from mrblip import prompt as P
     from mrblip.engine import EngineConfig
     from mrblip.tokenizer import FixtureTokenizer
@@ -166,7 +166,7 @@ def cpu_baseline(budget_s=30.0, full_c2=False, c2_iters=3):
     else:
         # not live: the one-off --cpu-baseline-c2 run committed with the profiles (a whole QVH clip step of the oracle on a GPU box's host:
         # minutes), shown beside the live C1 sample so the scale-up by FLOPs can be judged; `value` stays the live, C1-scaled number
-        for name in ("r04_cpu_baseline_c2.json", "r02_cpu_baseline_c2.json"):
+        for name in ("r06_cpu_baseline_c2.json", "r04_cpu_baseline_c2.json", "r02_cpu_baseline_c2.json"):
             ref = os.path.join(ROOT, "profiles", name)
             if os.path.exists(ref):
                 c2 = json.load(open(ref)).get("c2")
